@@ -1,0 +1,163 @@
+"""Seeded synthetic worlds / scans / initial guesses for tests and bench.
+
+World: jittered 0.2 m lattices on a ground plane (z ~ 0.3 m) plus a grid of 6 m high vertical walls in both
+axis directions every 22 m, 3-axis uniform jitter +-0.004 m, float32-exact, centred on the origin so that
+negative coordinates (the trunc-vs-floor voxel key quirk, vhm.cpp:275 vs vhm.hpp:176-180) are exercised.
+Everything here is plain numpy on the host; nothing in this module is on the measured path.
+"""
+import math
+
+import numpy as np
+
+PITCH = 0.2
+JITTER = 0.004
+WALL_SPACING = 22.0
+WALL_ROWS = 30  # 30 rows * 0.2 m = 6 m
+PTS_PER_M2 = 25.0 + 2 * (WALL_ROWS / PITCH / WALL_SPACING) * 0.93  # rough density used to size the extent
+
+
+def make_world(n_points, seed=1001):
+    """Return (n_points, 3) float32 map points in a fixed, spatially coherent order."""
+    rng = np.random.default_rng(seed)
+    L = 0.5 * math.sqrt(n_points * 1.08 / PTS_PER_M2) + 2.0
+    L = math.ceil(L / WALL_SPACING * 2) * WALL_SPACING / 2 + 1.0  # keep whole wall cells around the origin
+    n_side = int(round(2 * L / PITCH))
+    lat = (np.arange(n_side, dtype=np.float64) + 0.5) * PITCH - L
+
+    parts = []
+    # ground plane, row-major (x outer, y inner)
+    gx, gy = np.meshgrid(lat, lat, indexing="ij")
+    ground = np.stack([gx.ravel(), gy.ravel(), np.full(gx.size, 0.3)], axis=1)
+    parts.append(ground)
+    del gx, gy
+    # vertical walls: z rows 1.1 .. 6.9 (voxel layers 1..6, never sharing a voxel with the ground layer)
+    zrow = 1.0 + (np.arange(WALL_ROWS, dtype=np.float64) + 0.5) * PITCH
+    kmax = int(math.floor(L / WALL_SPACING)) + 1
+    for k in range(-kmax, kmax + 1):
+        xw = k * WALL_SPACING + 0.5
+        if abs(xw) < L:
+            wy, wz = np.meshgrid(lat, zrow, indexing="ij")
+            parts.append(np.stack([np.full(wy.size, xw), wy.ravel(), wz.ravel()], axis=1))
+    for k in range(-kmax, kmax + 1):
+        yw = k * WALL_SPACING + 11.5
+        if abs(yw) < L:
+            # leave a 1.6 m gap either side of every x-wall so wall voxels never hold two lattices
+            d = np.abs((lat - 0.5 + WALL_SPACING / 2) % WALL_SPACING - WALL_SPACING / 2)
+            lx = lat[d >= 1.6]
+            wx, wz = np.meshgrid(lx, zrow, indexing="ij")
+            parts.append(np.stack([wx.ravel(), np.full(wx.size, yw), wz.ravel()], axis=1))
+    pts = np.concatenate(parts, axis=0)
+    del parts
+    if pts.shape[0] < n_points:
+        raise RuntimeError(f"world extent too small: {pts.shape[0]} < {n_points}")
+    # keep the n_points closest to the origin in the Chebyshev sense, in generation order
+    r = np.maximum(np.abs(pts[:, 0]), np.abs(pts[:, 1]))
+    idx = np.argpartition(r, n_points - 1)[:n_points]
+    idx.sort()
+    pts = pts[idx]
+    pts += rng.uniform(-JITTER, JITTER, size=pts.shape)
+    return np.ascontiguousarray(pts.astype(np.float32))
+
+
+def rot_zyx(roll, pitch, yaw):
+    cr, sr, cp, sp, cy, sy = math.cos(roll), math.sin(roll), math.cos(pitch), math.sin(pitch), math.cos(yaw), math.sin(yaw)
+    return np.array([[cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
+                     [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr],
+                     [-sp, cp * sr, cp * cr]])
+
+
+def rotvec_to_matrix(v):
+    v = np.asarray(v, dtype=np.float64)
+    th = np.linalg.norm(v)
+    if th == 0:
+        return np.eye(3)
+    k = v / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + math.sin(th) * K + (1 - math.cos(th)) * (K @ K)
+
+
+def make_pose(map_xyz, seed):
+    """Sensor pose T_true: translation uniform in the central half of the map, yaw uniform, roll/pitch +-2 deg."""
+    rng = np.random.default_rng(seed)
+    ext = float(np.max(np.abs(map_xyz[:, :2])))
+    t = np.array([rng.uniform(-ext / 2, ext / 2), rng.uniform(-ext / 2, ext / 2), 0.3 + 1.8])
+    roll, pitch = np.deg2rad(rng.uniform(-2, 2, size=2))
+    yaw = rng.uniform(-math.pi, math.pi)
+    T = np.eye(4)
+    T[:3, :3] = rot_zyx(roll, pitch, yaw)
+    T[:3, 3] = t
+    return T
+
+
+def make_scan(map_xyz, n_scan, seed, T_true=None, max_range=60.0, noise=0.01):
+    """Draw n_scan map points within max_range of the sensor, add N(0, noise), express in the sensor frame.
+
+    Returns (scan_xyz float32 (n,3) sensor frame, T_true 4x4 float64)."""
+    if T_true is None:
+        T_true = make_pose(map_xyz, seed)
+    rng = np.random.default_rng(seed + 7919)
+    d = map_xyz.astype(np.float64) - T_true[:3, 3]
+    near = np.flatnonzero(np.einsum("ij,ij->i", d, d) < max_range * max_range)
+    if near.size >= n_scan:
+        pick = rng.choice(near, size=n_scan, replace=False)
+    else:  # small worlds: sample with replacement, the noise makes the points distinct
+        pick = rng.choice(near, size=n_scan, replace=True)
+    pick.sort()
+    world = map_xyz[pick].astype(np.float64) + rng.normal(0.0, noise, size=(n_scan, 3))
+    local = (world - T_true[:3, 3]) @ T_true[:3, :3]  # R^T (w - t)
+    return np.ascontiguousarray(local.astype(np.float32)), T_true
+
+
+def perturb(T_true, seed, max_trans=0.15, max_rot_deg=0.5):
+    """Initial guess T0 = T_true * delta; delta translation uniform in a ball, rotation angle uniform <= max."""
+    rng = np.random.default_rng(seed)
+    v = rng.normal(size=3)
+    v /= np.linalg.norm(v)
+    t = v * max_trans * rng.uniform() ** (1.0 / 3.0)
+    a = rng.normal(size=3)
+    a /= np.linalg.norm(a)
+    ang = np.deg2rad(max_rot_deg) * rng.uniform()
+    D = np.eye(4)
+    D[:3, :3] = rotvec_to_matrix(a * ang)
+    D[:3, 3] = t
+    return T_true @ D
+
+
+def pose_error(Ta, Tb):
+    """(translation error m, rotation angle rad) of Ta^-1 Tb."""
+    D = np.linalg.inv(Ta) @ Tb
+    dt = float(np.linalg.norm(D[:3, 3]))
+    c = (np.trace(D[:3, :3]) - 1.0) / 2.0
+    s = 0.5 * np.linalg.norm([D[2, 1] - D[1, 2], D[0, 2] - D[2, 0], D[1, 0] - D[0, 1]])
+    return dt, float(math.atan2(s, c))
+
+
+def make_deskew_stream(n_points, seed, scan_period=0.1, imu_hz=200.0, odom_hz=100.0, yaw_rate=0.3, speed=10.0,
+                       stamp=1000.0):
+    """Raw scan with per-point time + IMU/odom samples around it (config 5).
+
+    lidar_scan_time_end semantics: point times are a linear ramp -scan_period..0 in azimuth order and the
+    message stamp is the scan END (loc.ini:5).  Returns dict of numpy arrays."""
+    rng = np.random.default_rng(seed)
+    az = np.sort(rng.uniform(-math.pi, math.pi, n_points))
+    rngs = rng.uniform(2.0, 80.0, n_points)
+    el = np.deg2rad(rng.uniform(-15, 15, n_points))
+    xyz = np.stack([rngs * np.cos(el) * np.cos(az), rngs * np.cos(el) * np.sin(az), rngs * np.sin(el)], axis=1)
+    t = (-scan_period + scan_period * (np.arange(n_points) + 0.5) / n_points).astype(np.float32)
+    t[-1] = 0.0
+    imu_t = stamp - scan_period - 0.05 + np.arange(int((scan_period + 0.1) * imu_hz) + 1) / imu_hz
+    imu_w = np.stack([rng.normal(0, 0.01, imu_t.size), rng.normal(0, 0.01, imu_t.size),
+                      yaw_rate + rng.normal(0, 0.01, imu_t.size)], axis=1)
+    od_t = stamp - scan_period - 0.095 + np.arange(int((scan_period + 0.2) * odom_hz) + 1) / odom_hz
+    odom = np.zeros((od_t.size, 14))
+    yaw = yaw_rate * (od_t - od_t[0])
+    odom[:, 0] = od_t
+    odom[:, 1] = speed * (od_t - od_t[0]) * np.cos(0.1)
+    odom[:, 2] = speed * (od_t - od_t[0]) * np.sin(0.1)
+    odom[:, 3] = 0.02 * (od_t - od_t[0])
+    odom[:, 6] = np.sin(yaw / 2)
+    odom[:, 7] = np.cos(yaw / 2)
+    odom[:, 8] = speed
+    odom[:, 13] = yaw_rate
+    return dict(xyz=np.ascontiguousarray(xyz.astype(np.float32)), time=t, stamp=stamp, imu_t=imu_t, imu_w=imu_w,
+                odom=odom)
