@@ -1,0 +1,185 @@
+"""ctypes loader of the C-ABI library (include/elimaloc_hip.h -> elimaloc_amd/libelimaloc_hip.so).
+
+There is no CPU fallback: a missing library or a missing gfx950 device raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libelimaloc_hip.so")
+
+ELM_OK = 0
+P2P, GICP, VGICP, AVGICP = 0, 1, 2, 3
+MAX_ITER_TRACE = 64
+PACKED_SUMS = 32
+COMM_ID_BYTES = 128
+
+
+class ElmError(RuntimeError):
+    pass
+
+
+class RegConfig(C.Structure):
+    """POD mirror of RegistrationConfig (reg.hpp:62-85)."""
+    _fields_ = [
+        ("i_max_thread", C.c_int32),
+        ("icp_method", C.c_int32),
+        ("voxel_search_method", C.c_int32),
+        ("use_radar_cov", C.c_int32),
+        ("max_iteration", C.c_int32),
+        ("b_debug_print", C.c_int32),
+        ("gicp_cov_search_dist", C.c_double),
+        ("max_search_dist", C.c_double),
+        ("lm_lambda", C.c_double),
+        ("icp_termination_threshold_m", C.c_double),
+        ("min_overlap_ratio", C.c_double),
+        ("max_fitness_score", C.c_double),
+        ("doppler_trans_lambda", C.c_double),
+        ("range_variance_m", C.c_double),
+        ("azimuth_variance_deg", C.c_double),
+        ("elevation_variance_deg", C.c_double),
+        ("ego_to_lidar_trans", C.c_double * 3),
+        ("ego_to_lidar_rot", C.c_double * 9),
+        ("ego_to_imu_rot", C.c_double * 9),
+    ]
+
+
+class IterTrace(C.Structure):
+    _fields_ = [
+        ("JTJ", C.c_double * 36),
+        ("JTr", C.c_double * 6),
+        ("residual_sum", C.c_double),
+        ("n_corr", C.c_double),
+        ("x", C.c_double * 6),
+        ("step_norm", C.c_double),
+        ("T", C.c_double * 16),
+    ]
+
+
+class RegResult(C.Structure):
+    _fields_ = [
+        ("T", C.c_double * 16),
+        ("fitness_score", C.c_double),
+        ("d_fitness", C.c_double),
+        ("local_cov", C.c_double * 36),
+        ("is_success", C.c_int32),
+        ("iterations", C.c_int32),
+        ("gate", C.c_int32),
+        ("_pad", C.c_int32),
+        ("n_corr_last", C.c_double),
+    ]
+
+
+class MapInfo(C.Structure):
+    _fields_ = [
+        ("n_input_points", C.c_uint64),
+        ("n_points", C.c_uint64),
+        ("n_voxels", C.c_uint64),
+        ("hash_capacity", C.c_uint64),
+        ("voxel_size", C.c_double),
+        ("max_points_per_voxel", C.c_int32),
+        ("has_voxel_cov", C.c_int32),
+        ("has_point_cov", C.c_int32),
+        ("_pad", C.c_int32),
+        ("device_bytes", C.c_uint64),
+    ]
+
+
+class DeskewTables(C.Structure):
+    _fields_ = [
+        ("d_time_scan_cur", C.c_double),
+        ("d_time_scan_end", C.c_double),
+        ("i_imu_pointer_cur", C.c_int32),
+        ("b_run_deskew", C.c_int32),
+        ("b_is_imu_available", C.c_int32),
+        ("b_is_odom_available", C.c_int32),
+        ("f_odom_incre_x", C.c_float),
+        ("f_odom_incre_y", C.c_float),
+        ("f_odom_incre_z", C.c_float),
+        ("_pad", C.c_float),
+        ("vec_d_imu_time", C.POINTER(C.c_double)),
+        ("vec_d_imu_rot_x", C.POINTER(C.c_double)),
+        ("vec_d_imu_rot_y", C.POINTER(C.c_double)),
+        ("vec_d_imu_rot_z", C.POINTER(C.c_double)),
+    ]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p)
+
+# every symbol include/elimaloc_hip.h declares (checked by the CPU test-suite)
+EXPORTS = [
+    "elm_reg_config_default", "elm_ctx_create", "elm_ctx_destroy", "elm_last_error", "elm_strerror",
+    "elm_ctx_synchronize", "elm_ctx_stream", "elm_map_build", "elm_map_destroy", "elm_map_cal_voxel_cov_all",
+    "elm_map_cal_point_cov_all", "elm_map_get_info", "elm_map_empty", "elm_map_download_points",
+    "elm_map_download_voxels", "elm_map_find_ground_height", "elm_scan_upload", "elm_scan_destroy",
+    "elm_scan_size", "elm_register", "elm_register_batch", "elm_register_batch_enqueue",
+    "elm_register_batch_finish", "elm_deskew", "elm_deskew_prepare", "elm_comm_get_unique_id", "elm_comm_init",
+    "elm_comm_destroy", "elm_comm_set_hook",
+]
+
+_LIB = None
+
+
+def lib():
+    """Load libelimaloc_hip.so (fails loudly when it has not been built)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ElmError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, dp, fp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int)
+    L.elm_reg_config_default.argtypes = [C.POINTER(RegConfig)]
+    L.elm_reg_config_default.restype = None
+    L.elm_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.elm_ctx_destroy.argtypes = [vp]
+    L.elm_ctx_destroy.restype = None
+    L.elm_last_error.argtypes = [vp]
+    L.elm_last_error.restype = C.c_char_p
+    L.elm_strerror.argtypes = [C.c_int]
+    L.elm_strerror.restype = C.c_char_p
+    L.elm_ctx_synchronize.argtypes = [vp]
+    L.elm_ctx_stream.argtypes = [vp]
+    L.elm_ctx_stream.restype = vp
+    L.elm_map_build.argtypes = [vp, fp, C.c_size_t, C.c_double, C.c_int, C.POINTER(vp)]
+    L.elm_map_destroy.argtypes = [vp]
+    L.elm_map_destroy.restype = None
+    L.elm_map_cal_voxel_cov_all.argtypes = [vp]
+    L.elm_map_cal_point_cov_all.argtypes = [vp, C.c_double]
+    L.elm_map_get_info.argtypes = [vp, C.POINTER(MapInfo)]
+    L.elm_map_empty.argtypes = [vp]
+    L.elm_map_download_points.argtypes = [vp, dp, dp, dp, C.c_size_t]
+    L.elm_map_download_voxels.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp, dp, C.c_size_t]
+    L.elm_map_find_ground_height.argtypes = [vp, C.c_double, C.c_double, dp, ip]
+    L.elm_scan_upload.argtypes = [vp, fp, C.c_size_t, C.c_size_t, C.POINTER(vp)]
+    L.elm_scan_destroy.argtypes = [vp]
+    L.elm_scan_destroy.restype = None
+    L.elm_scan_size.argtypes = [vp]
+    L.elm_scan_size.restype = C.c_size_t
+    L.elm_register.argtypes = [vp, vp, fp, C.c_size_t, dp, C.POINTER(RegConfig), dp, ip, dp, dp,
+                               C.POINTER(RegResult), C.POINTER(IterTrace)]
+    L.elm_register_batch.argtypes = [vp, vp, C.POINTER(vp), C.c_int, dp, C.POINTER(RegConfig),
+                                     C.POINTER(RegResult), C.POINTER(IterTrace)]
+    L.elm_register_batch_enqueue.argtypes = [vp, vp, C.POINTER(vp), C.c_int, dp, C.POINTER(RegConfig), C.c_int]
+    L.elm_register_batch_finish.argtypes = [vp, C.POINTER(RegResult), C.POINTER(IterTrace)]
+    L.elm_deskew.argtypes = [vp, fp, fp, C.c_size_t, C.POINTER(DeskewTables), fp, ip]
+    L.elm_deskew_prepare.argtypes = [dp, C.c_size_t, dp, C.c_size_t, C.c_double, C.c_float, C.c_float, C.c_int,
+                                     C.c_int, dp, dp, dp, dp, C.c_size_t, C.POINTER(DeskewTables)]
+    L.elm_comm_get_unique_id.argtypes = [vp]
+    L.elm_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.elm_comm_destroy.argtypes = [vp]
+    L.elm_comm_set_hook.argtypes = [vp, ALLREDUCE_FN, vp]
+    _LIB = L
+    return L
+
+
+def check(status, ctx=None, what=""):
+    if status != ELM_OK:
+        L = lib()
+        msg = L.elm_strerror(status).decode()
+        if ctx is not None:
+            detail = L.elm_last_error(ctx)
+            if detail:
+                msg += ": " + detail.decode()
+        raise ElmError(f"{what} failed ({status}): {msg}")

@@ -1,0 +1,1056 @@
+// elm_api.cpp -- C ABI (include/elimaloc_hip.h) over the HIP kernels: context, device-resident voxel map, scans,
+// the per-iteration launch sequence of RunRegister, deskew, and the RCCL exchange.  Host-side C++17.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "elm_internal.hpp"
+#include "elm_la.hpp"
+
+using namespace elm;
+
+// ------------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+typedef int (*nccl_get_unique_id_t)(void*);
+typedef int (*nccl_comm_init_rank_t)(void**, int, struct elm_nccl_id, int);
+typedef int (*nccl_all_reduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*nccl_comm_destroy_t)(void*);
+typedef const char* (*nccl_get_error_string_t)(int);
+struct elm_nccl_id {
+    char internal[ELM_COMM_ID_BYTES];
+};
+
+struct RcclApi {
+    void* handle = nullptr;
+    nccl_get_unique_id_t get_unique_id = nullptr;
+    nccl_comm_init_rank_t comm_init_rank = nullptr;
+    nccl_all_reduce_t all_reduce = nullptr;
+    nccl_comm_destroy_t comm_destroy = nullptr;
+    nccl_get_error_string_t get_error_string = nullptr;
+};
+static RcclApi g_rccl;
+
+static bool load_rccl(std::string* err) {
+    if (g_rccl.handle) return true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) {
+        if (err) *err = std::string("cannot dlopen librccl: ") + dlerror();
+        return false;
+    }
+    g_rccl.get_unique_id = (nccl_get_unique_id_t)dlsym(h, "ncclGetUniqueId");
+    g_rccl.comm_init_rank = (nccl_comm_init_rank_t)dlsym(h, "ncclCommInitRank");
+    g_rccl.all_reduce = (nccl_all_reduce_t)dlsym(h, "ncclAllReduce");
+    g_rccl.comm_destroy = (nccl_comm_destroy_t)dlsym(h, "ncclCommDestroy");
+    g_rccl.get_error_string = (nccl_get_error_string_t)dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.all_reduce || !g_rccl.comm_destroy) {
+        if (err) *err = "librccl lacks ncclGetUniqueId/ncclCommInitRank/ncclAllReduce/ncclCommDestroy";
+        return false;
+    }
+    g_rccl.handle = h;
+    return true;
+}
+
+struct elm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    // scratch (grow-only; no allocation on the per-scan path after warm-up)
+    DevBuf d_scans, d_state, d_partials, d_sums, d_T0, d_trace, d_stage_pts;
+    void* h_state = nullptr; // pinned
+    size_t h_state_cap = 0;
+    void* h_trace = nullptr; // pinned
+    size_t h_trace_cap = 0;
+    void* h_stage = nullptr; // pinned staging for synchronous uploads (scan points, deskew tables)
+    size_t h_stage_cap = 0;
+    void* h_desc = nullptr; // pinned staging of the batch descriptors (read by an async copy)
+    size_t h_desc_cap = 0;
+    // in-flight batch
+    int batch = 0;
+    bool want_trace = false;
+    bool in_flight = false;
+    RegParams rp{};
+    // exchange
+    void* comm = nullptr;
+    int rank = 0, nranks = 1;
+    elm_allreduce_fn hook = nullptr;
+    void* hook_user = nullptr;
+};
+
+#define HIPCHK(ctx, call)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            (ctx)->last_error = std::string(#call) + ": " + hipGetErrorString(e_);                     \
+            return ELM_ERR_DEVICE;                                                                     \
+        }                                                                                              \
+    } while (0)
+
+static int dev_reserve(elm_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return ELM_OK;
+    if (b.p) HIPCHK(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t cap = std::max<size_t>(bytes, 256);
+    HIPCHK(ctx, hipMalloc(&b.p, cap));
+    b.cap = cap;
+    return ELM_OK;
+}
+static int pinned_reserve(elm_ctx* ctx, void** p, size_t* cap, size_t bytes) {
+    if (bytes <= *cap) return ELM_OK;
+    if (*p) HIPCHK(ctx, hipHostFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    HIPCHK(ctx, hipHostMalloc(p, bytes, hipHostMallocDefault));
+    *cap = bytes;
+    return ELM_OK;
+}
+
+extern "C" const char* elm_strerror(int status) {
+    switch (status) {
+    case ELM_OK: return "ok";
+    case ELM_ERR_INVALID: return "invalid argument";
+    case ELM_ERR_DEVICE: return "HIP runtime error";
+    case ELM_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case ELM_ERR_COMM: return "RCCL error";
+    case ELM_ERR_UNSUPPORTED: return "unsupported configuration";
+    default: return "unknown status";
+    }
+}
+
+extern "C" void elm_reg_config_default(elm_reg_config* c) {
+    // config/localization.ini:80-105
+    memset(c, 0, sizeof(*c));
+    c->i_max_thread = 10;
+    c->icp_method = ELM_GICP;
+    c->voxel_search_method = 2;
+    c->use_radar_cov = 0;
+    c->max_iteration = 10;
+    c->b_debug_print = 0;
+    c->gicp_cov_search_dist = 0.4;
+    c->max_search_dist = 5.0;
+    c->lm_lambda = 0.5;
+    c->icp_termination_threshold_m = 0.02;
+    c->min_overlap_ratio = 0.4;
+    c->max_fitness_score = 0.5;
+    c->doppler_trans_lambda = 0.5;
+    c->range_variance_m = 1.0;
+    c->azimuth_variance_deg = 0.4;
+    c->elevation_variance_deg = 0.4;
+    for (int i = 0; i < 3; ++i) c->ego_to_lidar_rot[i * 4] = c->ego_to_imu_rot[i * 4] = 1.0;
+}
+
+extern "C" int elm_ctx_create(int device_id, elm_ctx** out) {
+    if (!out) return ELM_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return ELM_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= count) return ELM_ERR_INVALID;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return ELM_ERR_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ELM_ERR_NO_DEVICE; // kernels are built for gfx950 only
+    elm_ctx* ctx = new elm_ctx();
+    ctx->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return ELM_ERR_DEVICE;
+    }
+    *out = ctx;
+    return ELM_OK;
+}
+
+extern "C" void elm_ctx_destroy(elm_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm && g_rccl.comm_destroy) g_rccl.comm_destroy(ctx->comm);
+    DevBuf* bufs[] = {&ctx->d_scans, &ctx->d_state, &ctx->d_partials, &ctx->d_sums, &ctx->d_T0, &ctx->d_trace, &ctx->d_stage_pts};
+    for (DevBuf* b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    if (ctx->h_state) (void)hipHostFree(ctx->h_state);
+    if (ctx->h_trace) (void)hipHostFree(ctx->h_trace);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    if (ctx->h_desc) (void)hipHostFree(ctx->h_desc);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" const char* elm_last_error(const elm_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+extern "C" void* elm_ctx_stream(elm_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+extern "C" int elm_ctx_synchronize(elm_ctx* ctx) {
+    if (!ctx) return ELM_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ELM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// map: host-side AddPoints (vhm.cpp:270-285) + upload
+// ------------------------------------------------------------------------------------------------------
+struct elm_map {
+    elm_ctx* ctx = nullptr;
+    elm_map_info info{};
+    DevMap dm{};
+    HashSlot* d_slots = nullptr;
+    float4* d_pts = nullptr;
+    uint2* d_ranges = nullptr;
+    int32_t* d_keys = nullptr; // [n_vox][3] stored keys (for downloads)
+    double *d_vox_mean = nullptr, *d_vox_cov = nullptr;
+    double *d_pt_mean = nullptr, *d_pt_cov = nullptr, *d_pt_nfit = nullptr;
+    std::vector<int32_t> h_keys;
+    std::vector<uint2> h_ranges;
+};
+
+namespace {
+
+struct HostTable { // open addressing: key -> voxel id, first-seen order
+    std::vector<int32_t> kx, ky, kz;
+    std::vector<int32_t> vid;
+    uint32_t mask = 0;
+    uint32_t used = 0;
+    void init(uint32_t cap) {
+        kx.assign(cap, 0); ky.assign(cap, 0); kz.assign(cap, 0);
+        vid.assign(cap, -1);
+        mask = cap - 1;
+        used = 0;
+    }
+    void grow() {
+        HostTable n;
+        n.init((mask + 1) * 2);
+        for (uint32_t i = 0; i <= mask; ++i)
+            if (vid[i] >= 0) n.insert_known(kx[i], ky[i], kz[i], vid[i]);
+        *this = std::move(n);
+    }
+    void insert_known(int32_t x, int32_t y, int32_t z, int32_t v) {
+        uint32_t h = hash3(x, y, z) & mask;
+        while (vid[h] >= 0) h = (h + 1) & mask;
+        kx[h] = x; ky[h] = y; kz[h] = z; vid[h] = v;
+        ++used;
+    }
+    // returns the voxel id, creating next_id when absent
+    int32_t find_or_add(int32_t x, int32_t y, int32_t z, int32_t next_id, bool* added) {
+        uint32_t h = hash3(x, y, z) & mask;
+        while (vid[h] >= 0) {
+            if (kx[h] == x && ky[h] == y && kz[h] == z) {
+                *added = false;
+                return vid[h];
+            }
+            h = (h + 1) & mask;
+        }
+        kx[h] = x; ky[h] = y; kz[h] = z; vid[h] = next_id;
+        ++used;
+        *added = true;
+        return next_id;
+    }
+};
+
+static uint32_t next_pow2(uint64_t v) {
+    uint64_t p = 16;
+    while (p < v) p <<= 1;
+    return (uint32_t)p;
+}
+
+struct HostBuild {
+    std::vector<int32_t> keys; // 3 per voxel (stored / trunc keys)
+    std::vector<uint2> ranges; // per voxel (start, cnt) into pts
+    std::vector<float4> pts;   // retained points, bucket order
+};
+
+// AddPoints (vhm.cpp:270-285) + VoxelBlock::AddPointWithSpacing (vhm.hpp:106-113).  Insertion into one voxel never
+// depends on another voxel, so the serial order only matters inside a voxel: points are grouped per voxel in input
+// order (stable counting sort) and every voxel replays its own insertions sequentially.
+static void build_host(const float* xyz, size_t n, double voxel_size, int max_points, HostBuild& hb) {
+    const double map_resolution = sqrt(voxel_size * voxel_size / max_points);
+    std::vector<uint32_t> pvid(n);
+    HostTable tab;
+    tab.init(next_pow2(std::max<uint64_t>(1024, n / 4)));
+    int32_t n_vox = 0;
+    for (size_t i = 0; i < n; ++i) {
+        // Voxel((point.pose / voxel_size_).cast<int>()): truncation toward zero (vhm.cpp:275)
+        const int32_t kx = (int32_t)((double)xyz[3 * i] / voxel_size);
+        const int32_t ky = (int32_t)((double)xyz[3 * i + 1] / voxel_size);
+        const int32_t kz = (int32_t)((double)xyz[3 * i + 2] / voxel_size);
+        if (tab.used * 2 >= tab.mask) tab.grow();
+        bool added;
+        const int32_t v = tab.find_or_add(kx, ky, kz, n_vox, &added);
+        if (added) {
+            hb.keys.push_back(kx); hb.keys.push_back(ky); hb.keys.push_back(kz);
+            ++n_vox;
+        }
+        pvid[i] = (uint32_t)v;
+    }
+    // stable grouping of the input indices per voxel
+    std::vector<uint64_t> off((size_t)n_vox + 1, 0);
+    for (size_t i = 0; i < n; ++i) off[pvid[i] + 1]++;
+    for (int32_t v = 0; v < n_vox; ++v) off[v + 1] += off[v];
+    std::vector<uint32_t> order(n);
+    {
+        std::vector<uint64_t> cur(off.begin(), off.end() - 1);
+        for (size_t i = 0; i < n; ++i) order[cur[pvid[i]]++] = (uint32_t)i;
+    }
+    std::vector<uint32_t>().swap(pvid);
+    // per-voxel replay of the insertions
+    std::vector<uint32_t> kept_cnt((size_t)n_vox, 0);
+    unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    unsigned T = (n_vox > 4096) ? std::min(hw, 32u) : 1u;
+    auto work = [&](int32_t vb, int32_t ve) {
+        std::vector<uint32_t> kept;
+        for (int32_t v = vb; v < ve; ++v) {
+            kept.clear();
+            for (uint64_t o = off[v]; o < off[v + 1]; ++o) {
+                const uint32_t i = order[o];
+                if (kept.empty()) { // map_.insert({voxel, VoxelBlock{{point}, ...}}): the first point is always kept
+                    kept.push_back(i);
+                    continue;
+                }
+                if (kept.size() >= (size_t)max_points) continue; // points.size() < num_points
+                const double px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+                bool near = false;
+                for (uint32_t k : kept) {
+                    const double dx = (double)xyz[3 * k] - px, dy = (double)xyz[3 * k + 1] - py, dz = (double)xyz[3 * k + 2] - pz;
+                    if (sqrt((dx * dx + dy * dy) + dz * dz) < map_resolution) { // (voxel_point.pose - point.pose).norm() < map_resolution
+                        near = true;
+                        break;
+                    }
+                }
+                if (!near) kept.push_back(i);
+            }
+            kept_cnt[v] = (uint32_t)kept.size();
+            for (size_t k = 0; k < kept.size(); ++k) order[off[v] + k] = kept[k]; // compact in place
+        }
+    };
+    if (T <= 1) {
+        work(0, n_vox);
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < T; ++t) {
+            int32_t vb = (int32_t)((int64_t)n_vox * t / T), ve = (int32_t)((int64_t)n_vox * (t + 1) / T);
+            pool.emplace_back(work, vb, ve);
+        }
+        for (auto& th : pool) th.join();
+    }
+    hb.ranges.resize(n_vox);
+    uint64_t total = 0;
+    for (int32_t v = 0; v < n_vox; ++v) {
+        hb.ranges[v] = make_uint2((uint32_t)total, kept_cnt[v]);
+        total += kept_cnt[v];
+    }
+    hb.pts.resize(total);
+    for (int32_t v = 0; v < n_vox; ++v)
+        for (uint32_t k = 0; k < kept_cnt[v]; ++k) {
+            const uint32_t i = order[off[v] + k];
+            hb.pts[hb.ranges[v].x + k] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.f);
+        }
+}
+
+} // namespace
+
+static void map_free(elm_map* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->ctx->device);
+    void* ptrs[] = {m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_pt_mean, m->d_pt_cov, m->d_pt_nfit};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete m;
+}
+
+extern "C" int elm_map_build(elm_ctx* ctx, const float* xyz, size_t n, double voxel_size, int max_points_per_voxel,
+                             elm_map** out) {
+    if (!ctx || !out || (!xyz && n) || !(voxel_size > 0.0) || max_points_per_voxel <= 0 || n > 0xFFFFFFF0ull) return ELM_ERR_INVALID;
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HostBuild hb;
+    if (n) build_host(xyz, n, voxel_size, max_points_per_voxel, hb);
+    elm_map* m = new elm_map();
+    m->ctx = ctx;
+    const uint32_t n_vox = (uint32_t)hb.ranges.size();
+    const uint32_t n_pts = (uint32_t)hb.pts.size();
+    const uint32_t cap = next_pow2((uint64_t)n_vox * 2);
+    std::vector<HashSlot> slots(cap);
+    for (auto& s : slots) {
+        s.kx = s.ky = s.kz = 0;
+        s.vid = -1;
+        s.start = s.cnt = s.pad0 = s.pad1 = 0;
+    }
+    for (uint32_t v = 0; v < n_vox; ++v) {
+        uint32_t h = hash3(hb.keys[3 * v], hb.keys[3 * v + 1], hb.keys[3 * v + 2]) & (cap - 1);
+        while (slots[h].vid >= 0) h = (h + 1) & (cap - 1);
+        slots[h].kx = hb.keys[3 * v]; slots[h].ky = hb.keys[3 * v + 1]; slots[h].kz = hb.keys[3 * v + 2];
+        slots[h].vid = (int32_t)v;
+        slots[h].start = hb.ranges[v].x;
+        slots[h].cnt = hb.ranges[v].y;
+    }
+    size_t bytes = 0;
+#define MAP_ALLOC(ptr, count, T)                                                        \
+    do {                                                                                \
+        size_t b_ = std::max<size_t>((size_t)(count) * sizeof(T), 256);                 \
+        hipError_t e_ = hipMalloc((void**)&(ptr), b_);                                  \
+        if (e_ != hipSuccess) {                                                         \
+            ctx->last_error = std::string("hipMalloc(map): ") + hipGetErrorString(e_);  \
+            map_free(m);                                                                \
+            return ELM_ERR_DEVICE;                                                      \
+        }                                                                               \
+        bytes += b_;                                                                    \
+    } while (0)
+    MAP_ALLOC(m->d_slots, cap, HashSlot);
+    MAP_ALLOC(m->d_pts, n_pts, float4);
+    MAP_ALLOC(m->d_ranges, n_vox, uint2);
+    MAP_ALLOC(m->d_keys, (size_t)n_vox * 3, int32_t);
+    hipError_t e = hipMemcpy(m->d_slots, slots.data(), (size_t)cap * sizeof(HashSlot), hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_pts) e = hipMemcpy(m->d_pts, hb.pts.data(), (size_t)n_pts * sizeof(float4), hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_vox) e = hipMemcpy(m->d_ranges, hb.ranges.data(), (size_t)n_vox * sizeof(uint2), hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_vox) e = hipMemcpy(m->d_keys, hb.keys.data(), (size_t)n_vox * 3 * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        ctx->last_error = std::string("hipMemcpy(map): ") + hipGetErrorString(e);
+        map_free(m);
+        return ELM_ERR_DEVICE;
+    }
+    m->h_keys = std::move(hb.keys);
+    m->h_ranges = std::move(hb.ranges);
+    m->dm.slots = m->d_slots;
+    m->dm.mask = cap - 1;
+    m->dm.n_vox = n_vox;
+    m->dm.n_pts = n_pts;
+    m->dm.pts = m->d_pts;
+    m->dm.voxel_size = voxel_size;
+    m->info.n_input_points = n;
+    m->info.n_points = n_pts;
+    m->info.n_voxels = n_vox;
+    m->info.hash_capacity = cap;
+    m->info.voxel_size = voxel_size;
+    m->info.max_points_per_voxel = max_points_per_voxel;
+    m->info.device_bytes = bytes;
+    *out = m;
+    return ELM_OK;
+}
+
+extern "C" void elm_map_destroy(elm_map* m) { map_free(m); }
+
+extern "C" int elm_map_cal_voxel_cov_all(elm_map* m) {
+    if (!m) return ELM_ERR_INVALID;
+    elm_ctx* ctx = m->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!m->d_vox_mean) {
+        HIPCHK(ctx, hipMalloc((void**)&m->d_vox_mean, std::max<size_t>((size_t)m->dm.n_vox * 3 * sizeof(double), 256)));
+        HIPCHK(ctx, hipMalloc((void**)&m->d_vox_cov, std::max<size_t>((size_t)m->dm.n_vox * 9 * sizeof(double), 256)));
+        m->info.device_bytes += (size_t)m->dm.n_vox * 12 * sizeof(double);
+    }
+    if (m->dm.n_vox) {
+        launch_voxel_cov(ctx->stream, m->dm, m->d_ranges, m->d_vox_mean, m->d_vox_cov);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    m->dm.vox_mean = m->d_vox_mean;
+    m->dm.vox_cov = m->d_vox_cov;
+    m->info.has_voxel_cov = 1;
+    return ELM_OK;
+}
+
+extern "C" int elm_map_cal_point_cov_all(elm_map* m, double d_search_dist) {
+    if (!m) return ELM_ERR_INVALID;
+    elm_ctx* ctx = m->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!m->d_pt_mean) {
+        HIPCHK(ctx, hipMalloc((void**)&m->d_pt_mean, std::max<size_t>((size_t)m->dm.n_pts * 3 * sizeof(double), 256)));
+        HIPCHK(ctx, hipMalloc((void**)&m->d_pt_cov, std::max<size_t>((size_t)m->dm.n_pts * 9 * sizeof(double), 256)));
+        HIPCHK(ctx, hipMalloc((void**)&m->d_pt_nfit, std::max<size_t>((size_t)m->dm.n_pts * 3 * sizeof(double), 256)));
+        m->info.device_bytes += (size_t)m->dm.n_pts * 15 * sizeof(double);
+    }
+    if (m->dm.n_pts) {
+        launch_point_cov(ctx->stream, m->dm, d_search_dist * d_search_dist, m->d_pt_mean, m->d_pt_cov, m->d_pt_nfit);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    m->dm.pt_mean = m->d_pt_mean;
+    m->dm.pt_cov = m->d_pt_cov;
+    m->dm.pt_nfit = m->d_pt_nfit;
+    m->info.has_point_cov = 1;
+    return ELM_OK;
+}
+
+extern "C" int elm_map_get_info(const elm_map* m, elm_map_info* info) {
+    if (!m || !info) return ELM_ERR_INVALID;
+    *info = m->info;
+    return ELM_OK;
+}
+extern "C" int elm_map_empty(const elm_map* m) { return (!m || m->dm.n_vox == 0) ? 1 : 0; }
+
+static void rowmajor_to_colmajor3(const double* src, double* dst) {
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) dst[c * 3 + r] = src[r * 3 + c];
+}
+
+extern "C" int elm_map_download_points(const elm_map* m, double* xyz, double* cov9, double* mean3, size_t cap) {
+    if (!m) return ELM_ERR_INVALID;
+    elm_ctx* ctx = m->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t n = std::min<size_t>(cap, m->dm.n_pts);
+    if (xyz && n) {
+        std::vector<float4> tmp(n);
+        HIPCHK(ctx, hipMemcpy(tmp.data(), m->d_pts, n * sizeof(float4), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) {
+            xyz[3 * i] = tmp[i].x; xyz[3 * i + 1] = tmp[i].y; xyz[3 * i + 2] = tmp[i].z;
+        }
+    }
+    if ((cov9 || mean3) && !m->info.has_point_cov) {
+        // default CovStruct of every PointStruct: (I, 0) (vhm.hpp:45)
+        for (size_t i = 0; i < n; ++i) {
+            if (cov9) for (int k = 0; k < 9; ++k) cov9[9 * i + k] = (k % 4 == 0) ? 1.0 : 0.0;
+            if (mean3) mean3[3 * i] = mean3[3 * i + 1] = mean3[3 * i + 2] = 0.0;
+        }
+        return ELM_OK;
+    }
+    if (cov9 && n) {
+        std::vector<double> tmp(n * 9);
+        HIPCHK(ctx, hipMemcpy(tmp.data(), m->d_pt_cov, n * 9 * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) rowmajor_to_colmajor3(&tmp[9 * i], &cov9[9 * i]);
+    }
+    if (mean3 && n) HIPCHK(ctx, hipMemcpy(mean3, m->d_pt_mean, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    return ELM_OK;
+}
+
+extern "C" int elm_map_download_voxels(const elm_map* m, int32_t* key3, int32_t* npts, double* cov9, double* mean3, size_t cap) {
+    if (!m) return ELM_ERR_INVALID;
+    elm_ctx* ctx = m->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t n = std::min<size_t>(cap, m->dm.n_vox);
+    if (key3) memcpy(key3, m->h_keys.data(), n * 3 * sizeof(int32_t));
+    if (npts) for (size_t v = 0; v < n; ++v) npts[v] = (int32_t)m->h_ranges[v].y;
+    if ((cov9 || mean3) && !m->info.has_voxel_cov) {
+        for (size_t i = 0; i < n; ++i) {
+            if (cov9) for (int k = 0; k < 9; ++k) cov9[9 * i + k] = (k % 4 == 0) ? 1.0 : 0.0;
+            if (mean3) mean3[3 * i] = mean3[3 * i + 1] = mean3[3 * i + 2] = 0.0;
+        }
+        return ELM_OK;
+    }
+    if (cov9 && n) {
+        std::vector<double> tmp(n * 9);
+        HIPCHK(ctx, hipMemcpy(tmp.data(), m->d_vox_cov, n * 9 * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) rowmajor_to_colmajor3(&tmp[9 * i], &cov9[9 * i]);
+    }
+    if (mean3 && n) HIPCHK(ctx, hipMemcpy(mean3, m->d_vox_mean, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    return ELM_OK;
+}
+
+extern "C" int elm_map_find_ground_height(const elm_map* m, double x, double y, double* ground_z, int* found) {
+    // vhm.hpp:285-322: mean z of the (up to) 5 lowest map points within 5 m in xy; needs more than 3 points
+    if (!m || !ground_z || !found) return ELM_ERR_INVALID;
+    elm_ctx* ctx = m->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    *found = 0;
+    const size_t n = m->dm.n_pts;
+    std::vector<float4> tmp(n);
+    if (n) HIPCHK(ctx, hipMemcpy(tmp.data(), m->d_pts, n * sizeof(float4), hipMemcpyDeviceToHost));
+    std::vector<double> zs;
+    for (size_t i = 0; i < n; ++i) {
+        const double dx = (double)tmp[i].x - x, dy = (double)tmp[i].y - y;
+        if (dx * dx + dy * dy <= 25.0) zs.push_back((double)tmp[i].z);
+    }
+    if (zs.size() <= 3) return ELM_OK;
+    const size_t N = std::min<size_t>(5, zs.size());
+    std::partial_sort(zs.begin(), zs.begin() + N, zs.end());
+    double s = 0.0;
+    for (size_t i = 0; i < N; ++i) s += zs[i];
+    *ground_z = s / (double)N;
+    *found = 1;
+    return ELM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// scans
+// ------------------------------------------------------------------------------------------------------
+struct elm_scan {
+    elm_ctx* ctx = nullptr;
+    float4* d_pts = nullptr;
+    uint32_t n = 0, n_total = 0;
+};
+
+static inline uint32_t spread10(uint32_t v) { // 10 bits -> every third bit
+    v &= 0x3ff;
+    v = (v | (v << 16)) & 0x030000FF;
+    v = (v | (v << 8)) & 0x0300F00F;
+    v = (v | (v << 4)) & 0x030C30C3;
+    v = (v | (v << 2)) & 0x09249249;
+    return v;
+}
+
+extern "C" int elm_scan_upload(elm_ctx* ctx, const float* xyz, size_t n, size_t n_total, elm_scan** out) {
+    if (!ctx || !out || (!xyz && n) || n > 0x7FFFFFFFull || n_total > 0x7FFFFFFFull || n_total < n) return ELM_ERR_INVALID;
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // Z-order over 2 m sensor-frame cells: consecutive points (hence consecutive workgroups and, through the
+    // XCD-aware block mapping, every XCD's L2) touch the same few map voxels.  Stable in the input index.
+    const double cs = 2.0;
+    std::vector<uint64_t> keyidx(n);
+    for (size_t i = 0; i < n; ++i) {
+        const int cx = (int)floor((double)xyz[3 * i] / cs) + 512, cy = (int)floor((double)xyz[3 * i + 1] / cs) + 512,
+                  cz = (int)floor((double)xyz[3 * i + 2] / cs) + 512;
+        const uint32_t ux = (uint32_t)std::min(std::max(cx, 0), 1023), uy = (uint32_t)std::min(std::max(cy, 0), 1023),
+                       uz = (uint32_t)std::min(std::max(cz, 0), 1023);
+        const uint32_t mort = spread10(ux) | (spread10(uy) << 1) | (spread10(uz) << 2);
+        keyidx[i] = ((uint64_t)mort << 32) | (uint64_t)i;
+    }
+    std::sort(keyidx.begin(), keyidx.end());
+    int rc = pinned_reserve(ctx, &ctx->h_stage, &ctx->h_stage_cap, std::max<size_t>(n * sizeof(float4), 4096));
+    if (rc != ELM_OK) return rc;
+    float4* hp = (float4*)ctx->h_stage;
+    for (size_t k = 0; k < n; ++k) {
+        const size_t i = (size_t)(keyidx[k] & 0xFFFFFFFFull);
+        hp[k] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.f);
+    }
+    elm_scan* s = new elm_scan();
+    s->ctx = ctx;
+    s->n = (uint32_t)n;
+    s->n_total = (uint32_t)n_total;
+    hipError_t e = hipMalloc((void**)&s->d_pts, std::max<size_t>(n * sizeof(float4), 256));
+    if (e == hipSuccess && n) e = hipMemcpyAsync(s->d_pts, hp, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        ctx->last_error = std::string("scan upload: ") + hipGetErrorString(e);
+        if (s->d_pts) (void)hipFree(s->d_pts);
+        delete s;
+        return ELM_ERR_DEVICE;
+    }
+    *out = s;
+    return ELM_OK;
+}
+
+extern "C" void elm_scan_destroy(elm_scan* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    if (s->d_pts) (void)hipFree(s->d_pts);
+    delete s;
+}
+extern "C" size_t elm_scan_size(const elm_scan* s) { return s ? s->n : 0; }
+
+// ------------------------------------------------------------------------------------------------------
+// registration
+// ------------------------------------------------------------------------------------------------------
+static int exchange(elm_ctx* ctx, double* d_sums, size_t count) {
+    if (ctx->hook) {
+        int rc = ctx->hook(d_sums, count, (void*)ctx->stream, ctx->hook_user);
+        if (rc != 0) {
+            ctx->last_error = "allreduce hook failed";
+            return ELM_ERR_COMM;
+        }
+        return ELM_OK;
+    }
+    if (ctx->comm) {
+        // ONE sum all-reduce of the packed normal equations of the whole batch per ICP iteration
+        int rc = g_rccl.all_reduce(d_sums, d_sums, count, /*ncclDouble*/ 8, /*ncclSum*/ 0, ctx->comm, ctx->stream);
+        if (rc != 0) {
+            ctx->last_error = std::string("ncclAllReduce: ") + (g_rccl.get_error_string ? g_rccl.get_error_string(rc) : "error");
+            return ELM_ERR_COMM;
+        }
+    }
+    return ELM_OK;
+}
+
+extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_scan* const* scans, int batch,
+                                          const double* T0, const elm_reg_config* cfg, int want_trace) {
+    if (!ctx || !map || !scans || batch <= 0 || !T0 || !cfg) return ELM_ERR_INVALID;
+    if (map->ctx != ctx) return ELM_ERR_INVALID;
+    if (cfg->use_radar_cov) return ELM_ERR_UNSUPPORTED;
+    if (cfg->icp_method < ELM_P2P || cfg->icp_method > ELM_AVGICP) return ELM_ERR_INVALID;
+    if (ctx->in_flight) return ELM_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int method = cfg->icp_method;
+    const bool map_empty = map->dm.n_vox == 0;
+    if (!map_empty) {
+        if ((method == ELM_VGICP || method == ELM_AVGICP) && !map->info.has_voxel_cov) {
+            ctx->last_error = "VGICP/AVGICP need elm_map_cal_voxel_cov_all() (pcm.cpp:92-95)";
+            return ELM_ERR_INVALID;
+        }
+        if (method == ELM_GICP && !map->info.has_point_cov) {
+            ctx->last_error = "GICP needs elm_map_cal_point_cov_all() (pcm.cpp:97-100)";
+            return ELM_ERR_INVALID;
+        }
+    }
+    // batch descriptors
+    int rc;
+    const size_t stage_bytes = (size_t)batch * (sizeof(ScanDesc) + 16 * sizeof(double));
+    if ((rc = pinned_reserve(ctx, &ctx->h_desc, &ctx->h_desc_cap, std::max<size_t>(stage_bytes, 4096))) != ELM_OK) return rc;
+    ScanDesc* hd = (ScanDesc*)ctx->h_desc;
+    double* hT = (double*)((char*)ctx->h_desc + (size_t)batch * sizeof(ScanDesc));
+    uint32_t blocks = 0;
+    for (int b = 0; b < batch; ++b) {
+        if (!scans[b] || scans[b]->ctx != ctx) return ELM_ERR_INVALID;
+        hd[b].pts = scans[b]->d_pts;
+        hd[b].n = scans[b]->n;
+        hd[b].n_total = scans[b]->n_total;
+        hd[b].blk_begin = blocks;
+        blocks += (scans[b]->n + kBlock - 1) / kBlock;
+        hd[b].blk_end = blocks;
+    }
+    memcpy(hT, T0, (size_t)batch * 16 * sizeof(double));
+    if ((rc = dev_reserve(ctx, ctx->d_scans, (size_t)batch * sizeof(ScanDesc))) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_T0, (size_t)batch * 16 * sizeof(double))) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_state, (size_t)batch * sizeof(ScanState))) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_partials, (size_t)std::max<uint32_t>(blocks, 1) * kSums * sizeof(double))) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_sums, (size_t)batch * kSums * sizeof(double))) != ELM_OK) return rc;
+    if ((rc = pinned_reserve(ctx, &ctx->h_state, &ctx->h_state_cap, (size_t)batch * sizeof(ScanState))) != ELM_OK) return rc;
+    elm_iter_trace* d_trace = nullptr;
+    if (want_trace) {
+        const size_t tb = (size_t)batch * ELM_MAX_ITER_TRACE * sizeof(elm_iter_trace);
+        if ((rc = dev_reserve(ctx, ctx->d_trace, tb)) != ELM_OK) return rc;
+        if ((rc = pinned_reserve(ctx, &ctx->h_trace, &ctx->h_trace_cap, tb)) != ELM_OK) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_trace.p, 0, tb, ctx->stream));
+        d_trace = (elm_iter_trace*)ctx->d_trace.p;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_scans.p, hd, (size_t)batch * sizeof(ScanDesc), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_T0.p, hT, (size_t)batch * 16 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+
+    RegParams rp;
+    rp.th = cfg->max_search_dist;
+    rp.th2 = cfg->max_search_dist * cfg->max_search_dist;
+    rp.lm_lambda = cfg->lm_lambda;
+    rp.term_thr = cfg->icp_termination_threshold_m;
+    rp.min_overlap = cfg->min_overlap_ratio;
+    rp.max_fitness = cfg->max_fitness_score;
+    rp.method = method;
+    rp.max_iter = cfg->max_iteration;
+    ctx->rp = rp;
+
+    ScanState* st = (ScanState*)ctx->d_state.p;
+    const ScanDesc* dsc = (const ScanDesc*)ctx->d_scans.p;
+    launch_init_state(ctx->stream, st, (const double*)ctx->d_T0.p, batch, map_empty ? 1 : 0);
+    const bool distributed = (ctx->comm != nullptr) || (ctx->hook != nullptr);
+    if (!map_empty) {
+        for (int it = 0; it < cfg->max_iteration; ++it) {
+            if (blocks) launch_accumulate(ctx->stream, map->dm, dsc, batch, (int)blocks, st, (double*)ctx->d_partials.p, rp);
+            if (distributed) {
+                launch_solve(ctx->stream, dsc, batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 1);
+                if ((rc = exchange(ctx, (double*)ctx->d_sums.p, (size_t)batch * kSums)) != ELM_OK) return rc;
+                launch_solve(ctx->stream, dsc, batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 2);
+            } else {
+                launch_solve(ctx->stream, dsc, batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 0);
+            }
+        }
+    }
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_state, st, (size_t)batch * sizeof(ScanState), hipMemcpyDeviceToHost, ctx->stream));
+    if (want_trace)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_trace, ctx->d_trace.p, (size_t)batch * ELM_MAX_ITER_TRACE * sizeof(elm_iter_trace),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    ctx->batch = batch;
+    ctx->want_trace = want_trace != 0;
+    ctx->in_flight = true;
+    return ELM_OK;
+}
+
+extern "C" int elm_register_batch_finish(elm_ctx* ctx, elm_reg_result* results, elm_iter_trace* trace) {
+    if (!ctx || !ctx->in_flight) return ELM_ERR_INVALID;
+    ctx->in_flight = false;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const ScanState* hs = (const ScanState*)ctx->h_state;
+    for (int b = 0; results && b < ctx->batch; ++b) {
+        elm_reg_result& r = results[b];
+        memset(&r, 0, sizeof(r));
+        memcpy(r.T, hs[b].T, sizeof(r.T));
+        memcpy(r.local_cov, hs[b].local_cov, sizeof(r.local_cov));
+        r.d_fitness = hs[b].fitness;
+        r.is_success = hs[b].success;
+        r.fitness_score = hs[b].success ? hs[b].fitness : 0.0; // written only on success (reg.cpp:415)
+        r.iterations = hs[b].iters;
+        r.gate = hs[b].gate;
+        r.n_corr_last = hs[b].n_corr_last;
+        if (ctx->rp.max_iter <= 0 && hs[b].gate == 0) { // no iteration ran: fitness gate on the initial 0.0 passes
+            r.is_success = 1;
+        }
+    }
+    if (trace && ctx->want_trace)
+        memcpy(trace, ctx->h_trace, (size_t)ctx->batch * ELM_MAX_ITER_TRACE * sizeof(elm_iter_trace));
+    return ELM_OK;
+}
+
+extern "C" int elm_register_batch(elm_ctx* ctx, const elm_map* map, elm_scan* const* scans, int batch, const double* T0,
+                                  const elm_reg_config* cfg, elm_reg_result* results, elm_iter_trace* trace) {
+    int rc = elm_register_batch_enqueue(ctx, map, scans, batch, T0, cfg, trace != nullptr);
+    if (rc != ELM_OK) return rc;
+    return elm_register_batch_finish(ctx, results, trace);
+}
+
+extern "C" int elm_register(elm_ctx* ctx, const elm_map* map, const float* scan_xyz, size_t n, const double T0[16],
+                            const elm_reg_config* cfg, double T_out[16], int* is_success, double* fitness_score,
+                            double local_cov[36], elm_reg_result* result, elm_iter_trace* trace) {
+    if (!ctx || !map || !T0 || !cfg) return ELM_ERR_INVALID;
+    elm_scan* s = nullptr;
+    int rc = elm_scan_upload(ctx, scan_xyz, n, n, &s);
+    if (rc != ELM_OK) return rc;
+    elm_reg_result res;
+    rc = elm_register_batch(ctx, map, &s, 1, T0, cfg, &res, trace);
+    elm_scan_destroy(s);
+    if (rc != ELM_OK) return rc;
+    if (T_out) memcpy(T_out, res.T, sizeof(res.T));
+    if (is_success) *is_success = res.is_success;
+    if (fitness_score && res.is_success) *fitness_score = res.fitness_score; // untouched on failure, like the reference
+    if (local_cov) memcpy(local_cov, res.local_cov, sizeof(res.local_cov));
+    if (result) *result = res;
+    return ELM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// deskew
+// ------------------------------------------------------------------------------------------------------
+extern "C" int elm_deskew(elm_ctx* ctx, const float* xyz, const float* rel_time, size_t n, const elm_deskew_tables* tab,
+                          float* xyz_out, int* ok) {
+    if (!ctx || !tab || !ok || (n && (!xyz || !rel_time || !xyz_out)) || n > 0x7FFFFFFFull) return ELM_ERR_INVALID;
+    *ok = 0;
+    if (!tab->b_is_imu_available || !tab->b_is_odom_available) return ELM_OK; // pcm.cpp:494-496
+    *ok = 1;
+    if (!tab->b_run_deskew) { // pcm.cpp:513-525: plain copy
+        memcpy(xyz_out, xyz, n * 3 * sizeof(float));
+        return ELM_OK;
+    }
+    if (n == 0) return ELM_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t k = (size_t)tab->i_imu_pointer_cur + 1;
+    const size_t in_bytes = n * 4 * sizeof(float);
+    const size_t tab_bytes = k * 4 * sizeof(double);
+    int rc;
+    if ((rc = dev_reserve(ctx, ctx->d_stage_pts, in_bytes + n * 3 * sizeof(float) + tab_bytes + 64)) != ELM_OK) return rc;
+    if ((rc = pinned_reserve(ctx, &ctx->h_stage, &ctx->h_stage_cap, std::max<size_t>(tab_bytes, 4096))) != ELM_OK) return rc;
+    char* base = (char*)ctx->d_stage_pts.p;
+    double* d_tab = (double*)base;
+    float* d_xyz = (float*)(base + ((tab_bytes + 63) / 64) * 64);
+    float* d_time = d_xyz + 3 * n;
+    float* d_out = d_time + n;
+    double* ht = (double*)ctx->h_stage;
+    memcpy(ht, tab->vec_d_imu_time, k * sizeof(double));
+    memcpy(ht + k, tab->vec_d_imu_rot_x, k * sizeof(double));
+    memcpy(ht + 2 * k, tab->vec_d_imu_rot_y, k * sizeof(double));
+    memcpy(ht + 3 * k, tab->vec_d_imu_rot_z, k * sizeof(double));
+    HIPCHK(ctx, hipMemcpyAsync(d_tab, ht, tab_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_xyz, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_time, rel_time, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    DeskewDev d;
+    d.time_scan_cur = tab->d_time_scan_cur;
+    d.time_scan_end = tab->d_time_scan_end;
+    d.imu_pointer_cur = tab->i_imu_pointer_cur;
+    d.odom_available = tab->b_is_odom_available;
+    d.incre_x = tab->f_odom_incre_x; d.incre_y = tab->f_odom_incre_y; d.incre_z = tab->f_odom_incre_z;
+    d._pad = 0.f;
+    d.imu_time = d_tab; d.rot_x = d_tab + k; d.rot_y = d_tab + 2 * k; d.rot_z = d_tab + 3 * k;
+    launch_deskew(ctx->stream, d_xyz, d_time, (uint32_t)n, d, d_out);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(xyz_out, d_out, n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ELM_OK;
+}
+
+namespace {
+// pcl::getTransformation (float) -- rotation Rz(yaw) Ry(pitch) Rx(roll) and translation
+struct Aff3f { float m[3][4]; };
+static Aff3f get_transformation_f(float x, float y, float z, float roll, float pitch, float yaw) {
+    const float A = cosf(yaw), B = sinf(yaw), C = cosf(pitch), D = sinf(pitch), E = cosf(roll), F = sinf(roll);
+    const float DE = D * E, DF = D * F;
+    Aff3f t;
+    t.m[0][0] = A * C; t.m[0][1] = A * DF - B * E; t.m[0][2] = B * F + A * DE; t.m[0][3] = x;
+    t.m[1][0] = B * C; t.m[1][1] = A * E + B * DF; t.m[1][2] = B * DE - A * F; t.m[1][3] = y;
+    t.m[2][0] = -D;    t.m[2][1] = C * F;          t.m[2][2] = C * E;          t.m[2][3] = z;
+    return t;
+}
+// tf::Matrix3x3(q).getRPY()
+static void quat_to_rpy(const double q[4], double* roll, double* pitch, double* yaw) {
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double s = 2.0 / (x * x + y * y + z * z + w * w);
+    const double xs = x * s, ys = y * s, zs = z * s;
+    const double wx = w * xs, wy = w * ys, wz = w * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
+    const double m00 = 1.0 - (yy + zz), m10 = xy + wz, m20 = xz - wy, m21 = yz + wx, m22 = 1.0 - (xx + yy);
+    if (fabs(m20) >= 1.0) {
+        *yaw = 0.0;
+        *roll = atan2(m21, m22);
+        *pitch = (m20 < 0) ? M_PI / 2.0 : -M_PI / 2.0;
+    } else {
+        *pitch = -asin(m20);
+        const double cp = cos(*pitch);
+        *roll = atan2(m21 / cp, m22 / cp);
+        *yaw = atan2(m10 / cp, m00 / cp);
+    }
+}
+} // namespace
+
+extern "C" int elm_deskew_prepare(const double* imu4, size_t n_imu, const double* odom14, size_t n_odom, double stamp,
+                                  float front_time, float back_time, int lidar_scan_time_end, int run_deskew,
+                                  double* tab_time, double* tab_rx, double* tab_ry, double* tab_rz, size_t tab_cap,
+                                  elm_deskew_tables* out) {
+    if (!out || !tab_time || !tab_rx || !tab_ry || !tab_rz || tab_cap < 2) return ELM_ERR_INVALID;
+    memset(out, 0, sizeof(*out));
+    // DeskewPointCloud head (pcm.cpp:473-486)
+    double scan_cur = stamp, scan_end = stamp + (double)back_time;
+    if (lidar_scan_time_end) {
+        scan_end = stamp;
+        scan_cur = scan_end + (double)front_time;
+    }
+    out->d_time_scan_cur = scan_cur;
+    out->d_time_scan_end = scan_end;
+    out->b_run_deskew = run_deskew;
+    out->vec_d_imu_time = tab_time; out->vec_d_imu_rot_x = tab_rx; out->vec_d_imu_rot_y = tab_ry; out->vec_d_imu_rot_z = tab_rz;
+    // ImuDeskewInfo (pcm.cpp:533-585)
+    {
+        size_t first = 0;
+        while (first < n_imu && imu4[4 * first] < scan_cur - 0.01) ++first;
+        int cur = 0;
+        if (first < n_imu) {
+            for (size_t i = first; i < n_imu; ++i) {
+                const double t = imu4[4 * i];
+                if (t > scan_end + 0.01) break;
+                if ((size_t)cur >= tab_cap) break;
+                if (cur == 0) {
+                    tab_rx[0] = tab_ry[0] = tab_rz[0] = 0.0;
+                    tab_time[0] = t;
+                    ++cur;
+                    continue;
+                }
+                const double dt = t - tab_time[cur - 1];
+                tab_rx[cur] = tab_rx[cur - 1] + imu4[4 * i + 1] * dt;
+                tab_ry[cur] = tab_ry[cur - 1] + imu4[4 * i + 2] * dt;
+                tab_rz[cur] = tab_rz[cur - 1] + imu4[4 * i + 3] * dt;
+                tab_time[cur] = t;
+                ++cur;
+            }
+            --cur;
+            out->i_imu_pointer_cur = cur < 0 ? 0 : cur;
+            out->b_is_imu_available = cur > 0 ? 1 : 0;
+        }
+    }
+    // OdomDeskewInfo (pcm.cpp:587-729)
+    {
+        size_t first = 0;
+        while (first < n_odom && odom14[14 * first] < scan_cur - 0.1) ++first;
+        if (first < n_odom && !(odom14[14 * first] > scan_cur)) {
+            size_t si = first;
+            for (size_t i = first; i < n_odom; ++i) {
+                si = i;
+                if (odom14[14 * i] < scan_cur) continue;
+                break;
+            }
+            const double* so = odom14 + 14 * si;
+            double roll, pitch, yaw;
+            quat_to_rpy(so + 4, &roll, &pitch, &yaw);
+            const Aff3f begin = get_transformation_f((float)so[1], (float)so[2], (float)so[3], (float)roll, (float)pitch, (float)yaw);
+            const double* lo = odom14 + 14 * (n_odom - 1);
+            double end_stamp, ep[3], eq[4];
+            if (lo[0] > scan_end) {
+                size_t ei = first;
+                for (size_t i = first; i < n_odom; ++i) {
+                    ei = i;
+                    if (odom14[14 * i] < scan_end) continue;
+                    break;
+                }
+                const double* eo = odom14 + 14 * ei;
+                end_stamp = eo[0];
+                for (int k = 0; k < 3; ++k) ep[k] = eo[1 + k];
+                for (int k = 0; k < 4; ++k) eq[k] = eo[4 + k];
+            } else { // extrapolate with the last twist (pcm.cpp:648-708)
+                const double dt = scan_end - lo[0];
+                end_stamp = scan_end;
+                double r2, p2, y2;
+                quat_to_rpy(lo + 4, &r2, &p2, &y2);
+                const double cy = cos(y2), sy = sin(y2), cp = cos(p2), sp = sin(p2), cr = cos(r2), sr = sin(r2);
+                const double R[3][3] = {{cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr},
+                                        {sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr},
+                                        {-sp, cp * sr, cp * cr}};
+                for (int k = 0; k < 3; ++k) ep[k] = lo[1 + k] + (R[k][0] * lo[8] + R[k][1] * lo[9] + R[k][2] * lo[10]) * dt;
+                r2 += lo[11] * dt; p2 += lo[12] * dt; y2 += lo[13] * dt;
+                const double cY = cos(y2 * 0.5), sY = sin(y2 * 0.5), cP = cos(p2 * 0.5), sP = sin(p2 * 0.5), cR = cos(r2 * 0.5), sR = sin(r2 * 0.5);
+                eq[0] = sR * cP * cY - cR * sP * sY;
+                eq[1] = cR * sP * cY + sR * cP * sY;
+                eq[2] = cR * cP * sY - sR * sP * cY;
+                eq[3] = cR * cP * cY + sR * sP * sY;
+            }
+            quat_to_rpy(eq, &roll, &pitch, &yaw);
+            const Aff3f end = get_transformation_f((float)ep[0], (float)ep[1], (float)ep[2], (float)roll, (float)pitch, (float)yaw);
+            // (begin^-1 * end).translation(), float32 (Eigen Affine3f: linear().inverse(), -linv * t)
+            float L[9], Li[9];
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) L[i * 3 + j] = begin.m[i][j];
+            {
+                const float c00 = L[4] * L[8] - L[5] * L[7], c01 = L[5] * L[6] - L[3] * L[8], c02 = L[3] * L[7] - L[4] * L[6];
+                const float det = (c00 * L[0] + c01 * L[1]) + c02 * L[2];
+                const float id = 1.0f / det;
+                Li[0] = c00 * id; Li[3] = c01 * id; Li[6] = c02 * id;
+                Li[1] = (L[2] * L[7] - L[1] * L[8]) * id; Li[4] = (L[0] * L[8] - L[2] * L[6]) * id; Li[7] = (L[1] * L[6] - L[0] * L[7]) * id;
+                Li[2] = (L[1] * L[5] - L[2] * L[4]) * id; Li[5] = (L[2] * L[3] - L[0] * L[5]) * id; Li[8] = (L[0] * L[4] - L[1] * L[3]) * id;
+            }
+            float bt[3];
+            for (int i = 0; i < 3; ++i) {
+                const float ti = -((Li[i * 3] * begin.m[0][3] + Li[i * 3 + 1] * begin.m[1][3]) + Li[i * 3 + 2] * begin.m[2][3]);
+                bt[i] = ((Li[i * 3] * end.m[0][3] + Li[i * 3 + 1] * end.m[1][3]) + Li[i * 3 + 2] * end.m[2][3]) + ti * 1.0f;
+            }
+            // InterpolateTfWithTime (lf.hpp:219-241): only the translation reaches the per-point deskew
+            const double dt_scan = scan_end - scan_cur, dt_trans = end_stamp - so[0];
+            if (dt_trans == 0.0) {
+                out->f_odom_incre_x = out->f_odom_incre_y = out->f_odom_incre_z = 0.f;
+            } else {
+                const float fr = (float)(dt_scan / dt_trans);
+                out->f_odom_incre_x = bt[0] * fr;
+                out->f_odom_incre_y = bt[1] * fr;
+                out->f_odom_incre_z = bt[2] * fr;
+            }
+            out->b_is_odom_available = 1;
+        }
+    }
+    return ELM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// multi-GPU
+// ------------------------------------------------------------------------------------------------------
+extern "C" int elm_comm_get_unique_id(void* id_bytes) {
+    if (!id_bytes) return ELM_ERR_INVALID;
+    std::string err;
+    if (!load_rccl(&err)) return ELM_ERR_COMM;
+    return g_rccl.get_unique_id(id_bytes) == 0 ? ELM_OK : ELM_ERR_COMM;
+}
+
+extern "C" int elm_comm_init(elm_ctx* ctx, int rank, int nranks, const void* id_bytes) {
+    if (!ctx || !id_bytes || nranks < 1 || rank < 0 || rank >= nranks) return ELM_ERR_INVALID;
+    if (!load_rccl(&ctx->last_error)) return ELM_ERR_COMM;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    elm_nccl_id id;
+    memcpy(id.internal, id_bytes, ELM_COMM_ID_BYTES);
+    void* comm = nullptr;
+    int rc = g_rccl.comm_init_rank(&comm, nranks, id, rank);
+    if (rc != 0) {
+        ctx->last_error = std::string("ncclCommInitRank: ") + (g_rccl.get_error_string ? g_rccl.get_error_string(rc) : "error");
+        return ELM_ERR_COMM;
+    }
+    ctx->comm = comm;
+    ctx->rank = rank;
+    ctx->nranks = nranks;
+    return ELM_OK;
+}
+
+extern "C" int elm_comm_destroy(elm_ctx* ctx) {
+    if (!ctx) return ELM_ERR_INVALID;
+    if (ctx->comm && g_rccl.comm_destroy) g_rccl.comm_destroy(ctx->comm);
+    ctx->comm = nullptr;
+    ctx->nranks = 1;
+    ctx->rank = 0;
+    return ELM_OK;
+}
+
+extern "C" int elm_comm_set_hook(elm_ctx* ctx, elm_allreduce_fn fn, void* user) {
+    if (!ctx) return ELM_ERR_INVALID;
+    ctx->hook = fn;
+    ctx->hook_user = user;
+    return ELM_OK;
+}

@@ -1,0 +1,107 @@
+// elm_internal.hpp -- device-side data layout shared by the kernels (elm_kernels.hip) and the C ABI (elm_api.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/elimaloc_hip.h"
+
+namespace elm {
+
+// ---- map in HBM -------------------------------------------------------------------------------------
+// Open-addressing table keyed by the STORED voxel key (truncation toward zero, vhm.cpp:275).  One 32-byte slot
+// carries everything a probe needs (key, voxel id, bucket range), so a hit costs one 32-B access.
+struct __attribute__((aligned(32))) HashSlot {
+    int32_t kx, ky, kz;
+    int32_t vid; // -1 = empty
+    uint32_t start;
+    uint32_t cnt;
+    uint32_t pad0, pad1;
+};
+
+struct DevMap {
+    const HashSlot* slots;
+    uint32_t mask; // capacity - 1 (capacity is a power of two >= 2 * n_voxels)
+    uint32_t n_vox;
+    uint32_t n_pts;
+    uint32_t _pad;
+    const float4* pts;      // bucket-ordered map points, xyz + pad (w unused), insertion order inside a bucket
+    const double* vox_mean; // [n_vox][3]            CalVoxelCov (vhm.hpp:114-148)
+    const double* vox_cov;  // [n_vox][9] row-major
+    const double* pt_mean;  // [n_pts][3]            ProcessVoxelBlock (vhm.hpp:195-250)
+    const double* pt_cov;   // [n_pts][9] row-major
+    const double* pt_nfit;  // [n_pts][3] eigenvector of the smallest eigenvalue of pt_cov (reg.cpp:89-91)
+    double voxel_size;
+};
+
+__host__ __device__ __forceinline__ uint32_t hash3(int32_t x, int32_t y, int32_t z) {
+    uint32_t h = (uint32_t)x * 73856093u ^ (uint32_t)y * 19349669u ^ (uint32_t)z * 83492791u;
+    h ^= h >> 16;
+    h *= 0x7feb352du;
+    h ^= h >> 15;
+    h *= 0x846ca68bu;
+    h ^= h >> 16;
+    return h;
+}
+
+// ---- scans / per-registration state -----------------------------------------------------------------
+struct ScanDesc {
+    const float4* pts; // sensor-frame points (xyz, w unused), coarse-cell ordered
+    uint32_t n;        // points resident on this GPU
+    uint32_t n_total;  // points of the whole scan (== n on one GPU)
+    uint32_t blk_begin; // first logical block of this scan in the batch launch
+    uint32_t blk_end;
+};
+
+// one per scan of the batch, lives in HBM for the whole registration
+struct ScanState {
+    double T[16];    // current pose, column-major
+    double Rinv[9];  // row-major inverse of the rotation block (3x3 cofactor inverse, reg.cpp:79)
+    double tinv[3];  // -Rinv t
+    double fitness;  // d_fitness_score_
+    double local_cov[36]; // column-major == row-major (symmetric)
+    double n_corr_last;
+    int32_t done;
+    int32_t success;
+    int32_t gate;
+    int32_t iters;
+};
+
+struct RegParams {
+    double th;  // max_search_dist
+    double th2; // th * th
+    double lm_lambda;
+    double term_thr;
+    double min_overlap;
+    double max_fitness;
+    int32_t method;
+    int32_t max_iter;
+};
+
+constexpr int kBlock = 256;
+constexpr int kSums = ELM_PACKED_SUMS; // 21 + 6 + 1 + 1 (+ n_cand, n_occ, pad)
+
+// ---- launchers (elm_kernels.hip) ----------------------------------------------------------------------
+void launch_init_state(hipStream_t s, ScanState* st, const double* T0, int batch, int map_empty);
+void launch_accumulate(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
+                       ScanState* st, double* partials, const RegParams& rp);
+// mode 0: reduce + solve (single GPU); 1: reduce only -> sums; 2: solve only from sums
+void launch_solve(hipStream_t s, const ScanDesc* scans, int batch, ScanState* st, const double* partials,
+                  double* sums, const RegParams& rp, elm_iter_trace* trace, int mode);
+void launch_voxel_cov(hipStream_t s, const DevMap& m, const uint2* ranges, double* vox_mean, double* vox_cov);
+void launch_point_cov(hipStream_t s, const DevMap& m, double d2max, double* pt_mean, double* pt_cov, double* pt_nfit);
+
+struct DeskewDev {
+    double time_scan_cur, time_scan_end;
+    int32_t imu_pointer_cur;
+    int32_t odom_available;
+    float incre_x, incre_y, incre_z;
+    float _pad;
+    const double* imu_time;
+    const double* rot_x;
+    const double* rot_y;
+    const double* rot_z;
+};
+void launch_deskew(hipStream_t s, const float* xyz, const float* rel_time, uint32_t n, const DeskewDev& d,
+                   float* xyz_out);
+
+} // namespace elm

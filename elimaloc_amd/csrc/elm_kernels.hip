@@ -1,0 +1,607 @@
+// elm_kernels.hip -- hand-written HIP kernels for gfx950 (CDNA4 / MI355X).
+//
+//   K1  k_accumulate<METHOD>  fused  T*p -> floor key -> 27(7)-voxel hash probe -> nearest point / voxel mean
+//                             -> residual + Jacobian -> wave + block reduction of the packed normal equations
+//                             (replaces TransformPoints reg.hpp:136-148, GetCorrespondence* vhm.cpp:31-206 and
+//                             the serial loops of AlignCloudsLocal* reg.cpp:28-51, 85-132, 171-208)
+//   K2  k_solve               deterministic final reduction, overlap gate (reg.cpp:349-356), LM-damped LDLT solve,
+//                             exp, pose composition, termination and fitness gates (reg.cpp:55-65, 378-387, 405-417)
+//   K3  k_voxel_cov           VoxelBlock::CalVoxelCov for every voxel (vhm.hpp:114-148, 183-193)
+//   K4  k_point_cov           ProcessVoxelBlock for every map point (vhm.hpp:195-257)
+//   K0  k_deskew              DeskewPoint / FindRotation / FindPosition (pcm.cpp:731-824), float32 semantics
+//
+// Compiled with -ffp-contract=off: every discrete decision (voxel key, strict-< nearest neighbour, range test,
+// gates) is taken on fp64 values computed in the same operation order as the reference's scalar code; fused
+// multiply-adds are used only where written explicitly (fma()).
+#include <float.h>
+#include <hip/hip_runtime.h>
+
+#include "elm_internal.hpp"
+#include "elm_la.hpp"
+
+namespace elm {
+
+// ------------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nb) {
+    // blocks are dispatched round-robin over the 8 XCDs; give every XCD one contiguous range of logical
+    // blocks so that its private L2 sees one spatially compact part of the (cell-ordered) scans.
+    unsigned q = nb >> 3, r = nb & 7u, xcd = bid & 7u, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+struct Probe {
+    int vid;
+    unsigned start, cnt;
+};
+__device__ __forceinline__ Probe probe_voxel(const DevMap& m, int kx, int ky, int kz) {
+    unsigned h = hash3(kx, ky, kz) & m.mask;
+    Probe p;
+    p.vid = -1;
+    p.start = 0;
+    p.cnt = 0;
+    for (;;) {
+        const int4 key = *reinterpret_cast<const int4*>(&m.slots[h]);
+        if (key.w < 0) break;
+        if (key.x == kx && key.y == ky && key.z == kz) {
+            const uint2 rg = *reinterpret_cast<const uint2*>(&m.slots[h].start);
+            p.vid = key.w;
+            p.start = rg.x;
+            p.cnt = rg.y;
+            break;
+        }
+        h = (h + 1) & m.mask;
+    }
+    return p;
+}
+
+__device__ __forceinline__ int floor_key(double g, double vs) { return (int)floor(g / vs); } // vhm.hpp:176-180
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// upper-triangle packing of the symmetric 6x6: idx(i,j), i <= j
+__host__ __device__ constexpr int tri(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
+
+// Adds one (source point, target) pair to the thread's packed sums.
+//   acc[0..20] upper JTJ, acc[21..26] JTr, acc[27] residual sum, acc[28] pair count
+// p = source point in the sensor frame, (mx,my,mz) = target position in the world frame,
+// C = world-frame covariance of the target (row-major) or nullptr for the identity metric.
+template <int METHOD>
+__device__ __forceinline__ void add_pair(double* acc, const double* Rinv, const double* tinv, double px, double py,
+                                         double pz, double mx, double my, double mz, const double* C,
+                                         const double* nfit, const RegParams& rp) {
+    // target_local = T^-1 * [m,1]  (reg.cpp:31 / 98 / 177)
+    const double lx = ((Rinv[0] * mx + Rinv[1] * my) + Rinv[2] * mz) + tinv[0];
+    const double ly = ((Rinv[3] * mx + Rinv[4] * my) + Rinv[5] * mz) + tinv[1];
+    const double lz = ((Rinv[6] * mx + Rinv[7] * my) + Rinv[8] * mz) + tinv[2];
+    const double rx = lx - px, ry = ly - py, rz = lz - pz; // residual_local
+    const double r2 = (rx * rx + ry * ry) + rz * rz;
+    const double den = rp.th + r2;
+    double w = rp.th2 / (den * den); // square(th) / square(th + |r|^2)
+    if (METHOD == ELM_GICP) w = w * 0.8 + 0.2;
+    acc[28] += 1.0;
+    if (METHOD == ELM_VGICP || METHOD == ELM_AVGICP) {
+        if (w < 0.01) return; // reg.cpp:201 -- skipped pairs stay in the fitness denominator
+    }
+    // A = w * M, M = (Rinv C Rinv^T)^-1 (reg.cpp:107-113, 187-191) or I
+    double A[9];
+    if (METHOD == ELM_P2P) {
+        A[0] = w; A[1] = 0; A[2] = 0; A[3] = 0; A[4] = w; A[5] = 0; A[6] = 0; A[7] = 0; A[8] = w;
+    } else {
+        double RC[9], RCR[9], M[9];
+        mul3(Rinv, C, RC);
+        mul3_bt(RC, Rinv, RCR);
+        inv3(RCR, M);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) A[i] = w * M[i];
+    }
+    // B = -[p]x
+    //     [  0   pz  -py ]
+    //     [ -pz  0    px ]
+    //     [  py -px   0  ]
+    double AB[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        AB[i * 3 + 0] = A[i * 3 + 2] * py - A[i * 3 + 1] * pz;
+        AB[i * 3 + 1] = A[i * 3 + 0] * pz - A[i * 3 + 2] * px;
+        AB[i * 3 + 2] = A[i * 3 + 1] * px - A[i * 3 + 0] * py;
+    }
+    // translation block (upper triangle of A)
+    acc[tri(0, 0)] += A[0]; acc[tri(0, 1)] += A[1]; acc[tri(0, 2)] += A[2];
+    acc[tri(1, 1)] += A[4]; acc[tri(1, 2)] += A[5]; acc[tri(2, 2)] += A[8];
+    // translation x rotation block: all nine entries of A B
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[tri(i, 3 + j)] += AB[i * 3 + j];
+    // rotation block: B^T (A B), upper triangle.  B^T rows: (0,-pz,py) (pz,0,-px) (-py,px,0)
+    acc[tri(3, 3)] += py * AB[6] - pz * AB[3];
+    acc[tri(3, 4)] += py * AB[7] - pz * AB[4];
+    acc[tri(3, 5)] += py * AB[8] - pz * AB[5];
+    acc[tri(4, 4)] += pz * AB[1] - px * AB[7];
+    acc[tri(4, 5)] += pz * AB[2] - px * AB[8];
+    acc[tri(5, 5)] += px * AB[5] - py * AB[2];
+    // J^T (w M) r
+    const double ax = (A[0] * rx + A[1] * ry) + A[2] * rz;
+    const double ay = (A[3] * rx + A[4] * ry) + A[5] * rz;
+    const double az = (A[6] * rx + A[7] * ry) + A[8] * rz;
+    acc[21] += ax; acc[22] += ay; acc[23] += az;
+    acc[24] += py * az - pz * ay;
+    acc[25] += pz * ax - px * az;
+    acc[26] += px * ay - py * ax;
+    if (METHOD == ELM_GICP) {
+        // |r . n_l|, n_l = normalised Rinv * n (reg.cpp:91-95, 128)
+        double nx = (Rinv[0] * nfit[0] + Rinv[1] * nfit[1]) + Rinv[2] * nfit[2];
+        double ny = (Rinv[3] * nfit[0] + Rinv[4] * nfit[1]) + Rinv[5] * nfit[2];
+        double nz = (Rinv[6] * nfit[0] + Rinv[7] * nfit[1]) + Rinv[8] * nfit[2];
+        const double nn2 = (nx * nx + ny * ny) + nz * nz;
+        if (nn2 > 0.0) {
+            const double nn = sqrt(nn2);
+            nx /= nn; ny /= nn; nz /= nn;
+        }
+        acc[27] += fabs((rx * nx + ry * ny) + rz * nz);
+    } else {
+        acc[27] += sqrt(r2);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K1
+// ------------------------------------------------------------------------------------------------------
+template <int METHOD>
+__global__ __launch_bounds__(kBlock) void k_accumulate(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
+                                                       unsigned total_blocks, const ScanState* __restrict__ st,
+                                                       double* __restrict__ partials, const RegParams rp) {
+    const unsigned L = xcd_remap(blockIdx.x, total_blocks);
+    // scan of this logical block (binary search over blk_begin)
+    int lo = 0, hi = batch - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (scans[mid].blk_begin <= L) lo = mid; else hi = mid - 1;
+    }
+    const int s = lo;
+    const ScanState& S = st[s];
+    if (S.done) return; // uniform: the whole block leaves; k_solve skips this scan too
+
+    const ScanDesc sd = scans[s];
+    const unsigned i = (L - sd.blk_begin) * kBlock + threadIdx.x;
+    const bool valid = i < sd.n;
+
+    double acc[31];
+#pragma unroll
+    for (int k = 0; k < 31; ++k) acc[k] = 0.0;
+
+    if (valid) {
+        const float4 pf = sd.pts[i];
+        const double px = pf.x, py = pf.y, pz = pf.z;
+        // g = T * [p,1]  (reg.hpp:141-146), same association as the reference's scalar product
+        const double gx = ((S.T[0] * px + S.T[4] * py) + S.T[8] * pz) + S.T[12];
+        const double gy = ((S.T[1] * px + S.T[5] * py) + S.T[9] * pz) + S.T[13];
+        const double gz = ((S.T[2] * px + S.T[6] * py) + S.T[10] * pz) + S.T[14];
+        const int vx = floor_key(gx, m.voxel_size), vy = floor_key(gy, m.voxel_size), vz = floor_key(gz, m.voxel_size);
+        double n_cand = 0.0, n_occ = 0.0;
+
+        if (METHOD == ELM_P2P || METHOD == ELM_GICP) {
+            // GetCorrespondencePoints (vhm.cpp:31-88): strict-< minimum over every bucket point of the 27 voxels,
+            // voxels visited x-major .. z-minor (vhm.cpp:234-240), bucket in insertion order
+            double bd2 = DBL_MAX;
+            float bx = 0.f, by = 0.f, bz = 0.f;
+            int bidx = -1;
+            for (int dx = -1; dx <= 1; ++dx)
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dz = -1; dz <= 1; ++dz) {
+                        const Probe pr = probe_voxel(m, vx + dx, vy + dy, vz + dz);
+                        if (pr.vid < 0) continue;
+                        n_occ += 1.0;
+                        n_cand += (double)pr.cnt;
+                        for (unsigned j = 0; j < pr.cnt; ++j) {
+                            const float4 q = m.pts[pr.start + j];
+                            const double ex = (double)q.x - gx, ey = (double)q.y - gy, ez = (double)q.z - gz;
+                            const double d2 = (ex * ex + ey * ey) + ez * ez;
+                            if (d2 < bd2) {
+                                bd2 = d2;
+                                bx = q.x; by = q.y; bz = q.z;
+                                bidx = (int)(pr.start + j);
+                            }
+                        }
+                    }
+            // no bucket at all: the reference's default PointStruct at the origin with cov I (vhm.cpp:37, QUIRK)
+            const double dfin = (bidx >= 0) ? bd2 : (gx * gx + gy * gy) + gz * gz;
+            if (dfin < rp.th2) {
+                if (METHOD == ELM_P2P) {
+                    add_pair<ELM_P2P>(acc, S.Rinv, S.tinv, px, py, pz, (double)bx, (double)by, (double)bz, nullptr, nullptr, rp);
+                } else {
+                    double C[9], mean[3], nf[3];
+                    if (bidx >= 0) {
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) C[k] = m.pt_cov[(size_t)bidx * 9 + k];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) { mean[k] = m.pt_mean[(size_t)bidx * 3 + k]; nf[k] = m.pt_nfit[(size_t)bidx * 3 + k]; }
+                    } else {
+                        C[0] = 1; C[1] = 0; C[2] = 0; C[3] = 0; C[4] = 1; C[5] = 0; C[6] = 0; C[7] = 0; C[8] = 1;
+                        mean[0] = mean[1] = mean[2] = 0.0;
+                        nf[0] = 1.0; nf[1] = 0.0; nf[2] = 0.0;
+                    }
+                    // GICP's target position is the neighbourhood MEAN of the matched point (reg.cpp:97)
+                    add_pair<ELM_GICP>(acc, S.Rinv, S.tinv, px, py, pz, mean[0], mean[1], mean[2], C, nf, rp);
+                }
+            }
+        } else if (METHOD == ELM_VGICP) {
+            // GetCorrespondencesCov (vhm.cpp:90-151): nearest voxel MEAN among the existing neighbours
+            double bd2 = DBL_MAX;
+            int bvid = -1;
+            double bmx = 0.0, bmy = 0.0, bmz = 0.0;
+            for (int dx = -1; dx <= 1; ++dx)
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dz = -1; dz <= 1; ++dz) {
+                        const Probe pr = probe_voxel(m, vx + dx, vy + dy, vz + dz);
+                        if (pr.vid < 0 || pr.cnt == 0) continue;
+                        n_occ += 1.0;
+                        n_cand += 1.0;
+                        const double cx = m.vox_mean[(size_t)pr.vid * 3], cy = m.vox_mean[(size_t)pr.vid * 3 + 1], cz = m.vox_mean[(size_t)pr.vid * 3 + 2];
+                        const double ex = cx - gx, ey = cy - gy, ez = cz - gz;
+                        const double d2 = (ex * ex + ey * ey) + ez * ez;
+                        if (d2 < bd2) { bd2 = d2; bvid = pr.vid; bmx = cx; bmy = cy; bmz = cz; }
+                    }
+            const double dfin = (bvid >= 0) ? bd2 : (gx * gx + gy * gy) + gz * gz;
+            if (dfin < rp.th2) {
+                double C[9];
+                if (bvid >= 0) {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) C[k] = m.vox_cov[(size_t)bvid * 9 + k];
+                } else {
+                    C[0] = 1; C[1] = 0; C[2] = 0; C[3] = 0; C[4] = 1; C[5] = 0; C[6] = 0; C[7] = 0; C[8] = 1;
+                }
+                add_pair<ELM_VGICP>(acc, S.Rinv, S.tinv, px, py, pz, bmx, bmy, bmz, C, nullptr, rp);
+            }
+        } else {
+            // GetCorrespondencesAllCov (vhm.cpp:153-206): every existing face-neighbour voxel within range is a pair,
+            // order (0, +x, -x, +y, -y, +z, -z) (vhm.cpp:224-230)
+            const int ox[7] = {0, 1, -1, 0, 0, 0, 0}, oy[7] = {0, 0, 0, 1, -1, 0, 0}, oz[7] = {0, 0, 0, 0, 0, 1, -1};
+#pragma unroll
+            for (int k7 = 0; k7 < 7; ++k7) {
+                const Probe pr = probe_voxel(m, vx + ox[k7], vy + oy[k7], vz + oz[k7]);
+                if (pr.vid < 0 || pr.cnt == 0) continue;
+                n_occ += 1.0;
+                n_cand += 1.0;
+                const double cx = m.vox_mean[(size_t)pr.vid * 3], cy = m.vox_mean[(size_t)pr.vid * 3 + 1], cz = m.vox_mean[(size_t)pr.vid * 3 + 2];
+                const double ex = cx - gx, ey = cy - gy, ez = cz - gz;
+                const double d2 = (ex * ex + ey * ey) + ez * ez;
+                if (d2 < rp.th2) {
+                    double C[9];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) C[k] = m.vox_cov[(size_t)pr.vid * 9 + k];
+                    add_pair<ELM_AVGICP>(acc, S.Rinv, S.tinv, px, py, pz, cx, cy, cz, C, nullptr, rp);
+                }
+            }
+        }
+        acc[29] = n_cand;
+        acc[30] = n_occ;
+    }
+
+    // wave reduction (64 lanes), then the four waves of the block through LDS
+    __shared__ double red[kBlock / 64][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 31; ++k) {
+        const double v = wave_sum(acc[k]);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double v = 0.0;
+        if (threadIdx.x < 31) v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+        partials[(size_t)L * kSums + threadIdx.x] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K2
+// ------------------------------------------------------------------------------------------------------
+__device__ void update_inverse(ScanState& S) {
+    double R[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) R[r * 3 + c] = S.T[c * 4 + r];
+    inv3(R, S.Rinv);
+    for (int r = 0; r < 3; ++r)
+        S.tinv[r] = -((S.Rinv[r * 3] * S.T[12] + S.Rinv[r * 3 + 1] * S.T[13]) + S.Rinv[r * 3 + 2] * S.T[14]);
+}
+
+__global__ __launch_bounds__(64) void k_init_state(ScanState* st, const double* __restrict__ T0, int batch, int map_empty) {
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= batch) return;
+    ScanState& S = st[s];
+    for (int k = 0; k < 16; ++k) S.T[k] = T0[(size_t)s * 16 + k];
+    update_inverse(S);
+    S.fitness = 0.0;
+    for (int k = 0; k < 36; ++k) S.local_cov[k] = (k % 7 == 0) ? 1.0 : 0.0; // reg.cpp:280
+    S.n_corr_last = 0.0;
+    S.done = map_empty ? 1 : 0; // VOXEL MAP EMPTY (reg.cpp:291-295): is_success = false, return initial_guess
+    S.success = 0;
+    S.gate = map_empty ? 1 : 0;
+    S.iters = 0;
+}
+
+__global__ __launch_bounds__(64) void k_solve(const ScanDesc* __restrict__ scans, ScanState* st,
+                                              const double* __restrict__ partials, double* sums, const RegParams rp,
+                                              elm_iter_trace* trace, int mode) {
+    const int s = blockIdx.x;
+    ScanState& S = st[s];
+    const int t = threadIdx.x;
+    __shared__ double tot[kSums];
+    const bool done = S.done != 0;
+    if (mode != 2) {
+        // deterministic two-lane-per-entry reduction of this scan's per-block partial sums
+        const int k = t & 31, half = t >> 5;
+        double v = 0.0;
+        if (!done) {
+            const ScanDesc sd = scans[s];
+            for (unsigned b = sd.blk_begin + half; b < sd.blk_end; b += 2) v += partials[(size_t)b * kSums + k];
+        }
+        v += __shfl_xor(v, 32, 64);
+        if (mode == 1) {
+            if (t < 32) sums[(size_t)s * kSums + k] = v; // zeros for finished scans keep the all-reduce buffer defined
+            return;
+        }
+        if (t < 32) tot[k] = v;
+    } else {
+        if (t < 32) tot[t] = sums[(size_t)s * kSums + t];
+    }
+    __syncthreads();
+    if (done || t != 0) return;
+
+    const ScanDesc sd = scans[s];
+    S.iters += 1; // i_iteration++ (reg.cpp:311)
+    const int iter = S.iters;
+    const double n_corr = tot[28];
+    S.n_corr_last = n_corr;
+    elm_iter_trace* tr = (trace && iter <= ELM_MAX_ITER_TRACE) ? &trace[(size_t)s * ELM_MAX_ITER_TRACE + (iter - 1)] : nullptr;
+
+    // corres_ratio = (float)i_source_corr_num / i_source_total_num (reg.cpp:351): float division, compared as double
+    const float ratio_f = (float)n_corr / (float)sd.n_total;
+    if (tr) {
+        for (int k = 0; k < 36; ++k) tr->JTJ[k] = 0.0;
+        for (int k = 0; k < 6; ++k) { tr->JTr[k] = 0.0; tr->x[k] = 0.0; }
+        tr->residual_sum = tot[27];
+        tr->n_corr = n_corr;
+        tr->step_norm = 0.0;
+        for (int k = 0; k < 16; ++k) tr->T[k] = S.T[k];
+    }
+    if ((double)ratio_f < rp.min_overlap) { // reg.cpp:352-356: fail, return the current pose, fitness untouched
+        S.done = 1;
+        S.success = 0;
+        S.gate = 2;
+        return;
+    }
+    S.fitness = tot[27] / n_corr; // d_fitness_score_ = d_residual_sum / source_global.size()
+
+    double H[36], b[6];
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j) {
+            H[i * 6 + j] = tot[tri(i, j)];
+            H[j * 6 + i] = tot[tri(i, j)];
+        }
+    for (int i = 0; i < 6; ++i) b[i] = tot[21 + i];
+    double Hd[36];
+    for (int k = 0; k < 36; ++k) Hd[k] = H[k];
+    for (int i = 0; i < 6; ++i) Hd[i * 7] = H[i * 7] + rp.lm_lambda * H[i * 7]; // JTJ + lambda * diag(JTJ)
+    double x[6];
+    ldlt_solve6(Hd, b, x);
+    if (rp.method == ELM_GICP) inv6(Hd, S.local_cov); // reg.cpp:141-142
+
+    double dR[9];
+    rotvec_to_matrix(&x[3], dR);
+    // T <- T * [dR | dt]  (reg.cpp:378), column-major T
+    double Tn[16];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c)
+            Tn[c * 4 + r] = (S.T[0 * 4 + r] * dR[0 * 3 + c] + S.T[1 * 4 + r] * dR[1 * 3 + c]) + S.T[2 * 4 + r] * dR[2 * 3 + c];
+        Tn[12 + r] = ((S.T[0 * 4 + r] * x[0] + S.T[1 * 4 + r] * x[1]) + S.T[2 * 4 + r] * x[2]) + S.T[12 + r];
+    }
+    Tn[3] = 0.0; Tn[7] = 0.0; Tn[11] = 0.0; Tn[15] = 1.0;
+    for (int k = 0; k < 16; ++k) S.T[k] = Tn[k];
+    update_inverse(S);
+
+    const double step = matrix_to_angle(dR) + sqrt((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2]); // reg.cpp:381-384
+    if (tr) {
+        for (int k = 0; k < 36; ++k) tr->JTJ[k] = H[k];
+        for (int k = 0; k < 6; ++k) { tr->JTr[k] = b[k]; tr->x[k] = x[k]; }
+        tr->step_norm = step;
+        for (int k = 0; k < 16; ++k) tr->T[k] = S.T[k];
+    }
+    if (step < rp.term_thr || iter >= rp.max_iter) { // reg.cpp:385-387 / loop end
+        S.done = 1;
+        const bool bad = S.fitness > rp.max_fitness; // reg.cpp:405-409 (NaN compares false, like the reference)
+        S.success = bad ? 0 : 1;
+        S.gate = bad ? 3 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K3 / K4: map covariances
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_voxel_cov(const DevMap m, const uint2* __restrict__ ranges, double* vox_mean,
+                                                   double* vox_cov) {
+    const unsigned v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= m.n_vox) return;
+    const uint2 rg = ranges[v];
+    const unsigned n = rg.y;
+    double mean[3] = {0, 0, 0};
+    double C[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (n == 1) {
+        const float4 q = m.pts[rg.x];
+        mean[0] = q.x; mean[1] = q.y; mean[2] = q.z;
+    } else if (n >= 2) {
+        double sx = 0, sy = 0, sz = 0;
+        for (unsigned j = 0; j < n; ++j) {
+            const float4 q = m.pts[rg.x + j];
+            sx += (double)q.x; sy += (double)q.y; sz += (double)q.z;
+        }
+        mean[0] = sx / (double)n; mean[1] = sy / (double)n; mean[2] = sz / (double)n;
+        double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (unsigned j = 0; j < n; ++j) {
+            const float4 q = m.pts[rg.x + j];
+            const double d[3] = {(double)q.x - mean[0], (double)q.y - mean[1], (double)q.z - mean[2]};
+            for (int a = 0; a < 3; ++a)
+                for (int bq = 0; bq < 3; ++bq) c[a * 3 + bq] += d[a] * d[bq];
+        }
+        for (int k = 0; k < 9; ++k) c[k] /= (double)(n - 1);
+        double nrm[3];
+        plane_regularize(c, C, nrm);
+    }
+    for (int k = 0; k < 3; ++k) vox_mean[(size_t)v * 3 + k] = mean[k];
+    for (int k = 0; k < 9; ++k) vox_cov[(size_t)v * 9 + k] = C[k];
+}
+
+__global__ __launch_bounds__(256) void k_point_cov(const DevMap m, double d2max, double* pt_mean, double* pt_cov,
+                                                   double* pt_nfit) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m.n_pts) return;
+    const float4 pf = m.pts[i];
+    const double px = pf.x, py = pf.y, pz = pf.z;
+    const int vx = floor_key(px, m.voxel_size), vy = floor_key(py, m.voxel_size), vz = floor_key(pz, m.voxel_size);
+    // pass 1: neighbours = {self} + every bucket point of the 27 floor-keyed voxels with d^2 <= r^2 -- the point
+    // itself is found again there (vhm.hpp:202-220), so it is counted twice
+    double sx = px, sy = py, sz = pz;
+    unsigned n = 1;
+    for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dz = -1; dz <= 1; ++dz) {
+                const Probe pr = probe_voxel(m, vx + dx, vy + dy, vz + dz);
+                if (pr.vid < 0) continue;
+                for (unsigned j = 0; j < pr.cnt; ++j) {
+                    const float4 q = m.pts[pr.start + j];
+                    const double ex = (double)q.x - px, ey = (double)q.y - py, ez = (double)q.z - pz;
+                    if ((ex * ex + ey * ey) + ez * ez <= d2max) {
+                        sx += (double)q.x; sy += (double)q.y; sz += (double)q.z;
+                        ++n;
+                    }
+                }
+            }
+    double mean[3] = {px, py, pz};
+    double C[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    double nf[3] = {1, 0, 0}; // eigenvectors of the identity are the identity: col(0) = e_x
+    if (n > 1) {
+        mean[0] = sx / (double)n; mean[1] = sy / (double)n; mean[2] = sz / (double)n;
+        double c[9];
+        {
+            const double d[3] = {px - mean[0], py - mean[1], pz - mean[2]};
+            for (int a = 0; a < 3; ++a)
+                for (int bq = 0; bq < 3; ++bq) c[a * 3 + bq] = d[a] * d[bq];
+        }
+        for (int dx = -1; dx <= 1; ++dx)
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dz = -1; dz <= 1; ++dz) {
+                    const Probe pr = probe_voxel(m, vx + dx, vy + dy, vz + dz);
+                    if (pr.vid < 0) continue;
+                    for (unsigned j = 0; j < pr.cnt; ++j) {
+                        const float4 q = m.pts[pr.start + j];
+                        const double ex = (double)q.x - px, ey = (double)q.y - py, ez = (double)q.z - pz;
+                        if ((ex * ex + ey * ey) + ez * ez <= d2max) {
+                            const double d[3] = {(double)q.x - mean[0], (double)q.y - mean[1], (double)q.z - mean[2]};
+                            for (int a = 0; a < 3; ++a)
+                                for (int bq = 0; bq < 3; ++bq) c[a * 3 + bq] += d[a] * d[bq];
+                        }
+                    }
+                }
+        for (int k = 0; k < 9; ++k) c[k] /= (double)(n - 1);
+        plane_regularize(c, C, nf);
+    }
+    for (int k = 0; k < 3; ++k) { pt_mean[(size_t)i * 3 + k] = mean[k]; pt_nfit[(size_t)i * 3 + k] = nf[k]; }
+    for (int k = 0; k < 9; ++k) pt_cov[(size_t)i * 9 + k] = C[k];
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K0: deskew (float32 semantics of pcm.cpp:780-824; sin/cos evaluated in fp64 and rounded once to float32,
+// which reproduces glibc's correctly-rounded sinf/cosf results)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_deskew(const float* __restrict__ xyz, const float* __restrict__ rel_time,
+                                                unsigned n, const DeskewDev d, float* __restrict__ out) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    const double d_rel_time = (double)rel_time[i];
+    const double d_point_time = d.time_scan_cur + d_rel_time;
+    const int cur = d.imu_pointer_cur;
+    const float f_rot_x_end = (float)d.rot_x[cur], f_rot_y_end = (float)d.rot_y[cur], f_rot_z_end = (float)d.rot_z[cur];
+    // FindRotation (pcm.cpp:731-762)
+    int front = 0;
+    while (front < cur) {
+        if (d_point_time < d.imu_time[front]) break;
+        ++front;
+    }
+    float rxc, ryc, rzc;
+    if (d_point_time > d.imu_time[front] || front == 0) {
+        rxc = (float)d.rot_x[front]; ryc = (float)d.rot_y[front]; rzc = (float)d.rot_z[front];
+    } else {
+        const int back = front - 1;
+        const double tf = d.imu_time[front], tb = d.imu_time[back];
+        const double ratio_front = (d_point_time - tb) / (tf - tb);
+        const double ratio_back = (tf - d_point_time) / (tf - tb);
+        rxc = (float)(d.rot_x[front] * ratio_front + d.rot_x[back] * ratio_back);
+        ryc = (float)(d.rot_y[front] * ratio_front + d.rot_y[back] * ratio_back);
+        rzc = (float)(d.rot_z[front] * ratio_front + d.rot_z[back] * ratio_back);
+    }
+    // FindPosition (pcm.cpp:764-778)
+    float pxc = 0.f, pyc = 0.f;
+    if (d.odom_available) {
+        const float f_ratio = (float)(d_rel_time / (d.time_scan_end - d.time_scan_cur));
+        pxc = f_ratio * d.incre_x;
+        pyc = f_ratio * d.incre_y;
+    }
+    const float roll = rxc - f_rot_x_end, pitch = ryc - f_rot_y_end, yaw = rzc - f_rot_z_end;
+    const float tx = pxc - d.incre_x, ty = pyc - d.incre_y;
+    const float tz = rzc - d.incre_z; // pcm.cpp:804 uses f_rot_z_cur here (kept: drop-in parity)
+    // pcl::getTransformation(x, y, z, roll, pitch, yaw), Scalar = float
+    const float A = (float)cos((double)yaw), B = (float)sin((double)yaw), Cc = (float)cos((double)pitch),
+                D = (float)sin((double)pitch), E = (float)cos((double)roll), F = (float)sin((double)roll);
+    const float DE = D * E, DF = D * F;
+    const float t00 = A * Cc, t01 = A * DF - B * E, t02 = B * F + A * DE;
+    const float t10 = B * Cc, t11 = A * E + B * DF, t12 = B * DE - A * F;
+    const float t20 = -D, t21 = Cc * F, t22 = Cc * E;
+    out[3 * i] = t00 * x + t01 * y + t02 * z + tx;
+    out[3 * i + 1] = t10 * x + t11 * y + t12 * z + ty;
+    out[3 * i + 2] = t20 * x + t21 * y + t22 * z + tz;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------------
+void launch_init_state(hipStream_t s, ScanState* st, const double* T0, int batch, int map_empty) {
+    hipLaunchKernelGGL(k_init_state, dim3((batch + 63) / 64), dim3(64), 0, s, st, T0, batch, map_empty);
+}
+
+void launch_accumulate(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
+                       ScanState* st, double* partials, const RegParams& rp) {
+    dim3 g(total_blocks), b(kBlock);
+    switch (rp.method) {
+    case ELM_P2P: hipLaunchKernelGGL(k_accumulate<ELM_P2P>, g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp); break;
+    case ELM_GICP: hipLaunchKernelGGL(k_accumulate<ELM_GICP>, g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp); break;
+    case ELM_VGICP: hipLaunchKernelGGL(k_accumulate<ELM_VGICP>, g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp); break;
+    default: hipLaunchKernelGGL(k_accumulate<ELM_AVGICP>, g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp); break;
+    }
+}
+
+void launch_solve(hipStream_t s, const ScanDesc* scans, int batch, ScanState* st, const double* partials,
+                  double* sums, const RegParams& rp, elm_iter_trace* trace, int mode) {
+    hipLaunchKernelGGL(k_solve, dim3(batch), dim3(64), 0, s, scans, st, partials, sums, rp, trace, mode);
+}
+
+void launch_voxel_cov(hipStream_t s, const DevMap& m, const uint2* ranges, double* vox_mean, double* vox_cov) {
+    hipLaunchKernelGGL(k_voxel_cov, dim3((m.n_vox + 255) / 256), dim3(256), 0, s, m, ranges, vox_mean, vox_cov);
+}
+
+void launch_point_cov(hipStream_t s, const DevMap& m, double d2max, double* pt_mean, double* pt_cov, double* pt_nfit) {
+    hipLaunchKernelGGL(k_point_cov, dim3((m.n_pts + 255) / 256), dim3(256), 0, s, m, d2max, pt_mean, pt_cov, pt_nfit);
+}
+
+void launch_deskew(hipStream_t s, const float* xyz, const float* rel_time, uint32_t n, const DeskewDev& d, float* xyz_out) {
+    hipLaunchKernelGGL(k_deskew, dim3((n + 255) / 256), dim3(256), 0, s, xyz, rel_time, n, d, xyz_out);
+}
+
+} // namespace elm

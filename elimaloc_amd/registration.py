@@ -1,0 +1,334 @@
+"""Host-side mirror of the reference's operator interface for the registration hot path.
+
+Same names, argument meaning and error behaviour as
+  pcm_matching/include/registration.hpp      (IcpMethod :60, RegistrationConfig :62-85, Registration :101-230)
+  pcm_matching/include/voxel_hash_map.hpp    (VoxelHashMap :89-335)
+so that parity tests read like calls into the reference.  Everything numerical happens in the C-ABI library
+(HIP kernels); this file only marshals numpy arrays.  Out-params of the C++ signatures are returned as tuples.
+"""
+import ctypes as C
+import enum
+
+import numpy as np
+
+from . import _lib
+from ._lib import ElmError, RegConfig, RegResult, IterTrace, MapInfo, check
+
+
+class IcpMethod(enum.IntEnum):  # reg.hpp:60
+    P2P = 0
+    GICP = 1
+    VGICP = 2
+    AVGICP = 3
+
+
+def RegistrationConfig(**kw):
+    """RegistrationConfig with the shipped defaults of config/localization.ini:80-105."""
+    cfg = RegConfig()
+    _lib.lib().elm_reg_config_default(C.byref(cfg))
+    for k, v in kw.items():
+        if not hasattr(cfg, k):
+            raise AttributeError(f"RegistrationConfig has no field {k}")
+        setattr(cfg, k, int(v) if k in ("icp_method", "max_iteration", "i_max_thread", "use_radar_cov") else v)
+    return cfg
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _colmajor16(T):
+    return np.ascontiguousarray(np.asarray(T, dtype=np.float64).reshape(4, 4).T).ravel()
+
+
+class Context:
+    """One GPU, one HIP stream (one process per GPU).  elm_ctx_create fails without a gfx950 device."""
+
+    def __init__(self, device_id=0):
+        self._h = C.c_void_p()
+        check(_lib.lib().elm_ctx_create(device_id, C.byref(self._h)), None, "elm_ctx_create")
+        self.device_id = device_id
+        self._hook_ref = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().elm_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(_lib.lib().elm_ctx_synchronize(self._h), self._h, "elm_ctx_synchronize")
+
+    @property
+    def stream(self):
+        return _lib.lib().elm_ctx_stream(self._h)
+
+    # ---- multi-GPU (RCCL over xGMI): one small all-reduce of the packed normal equations per iteration
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_char * _lib.COMM_ID_BYTES)()
+        check(_lib.lib().elm_comm_get_unique_id(C.cast(buf, C.c_void_p)), None, "elm_comm_get_unique_id")
+        return bytes(buf)
+
+    def comm_init(self, rank, nranks, id_bytes):
+        buf = (C.c_char * _lib.COMM_ID_BYTES).from_buffer_copy(id_bytes)
+        check(_lib.lib().elm_comm_init(self._h, rank, nranks, C.cast(buf, C.c_void_p)), self._h, "elm_comm_init")
+
+    def comm_destroy(self):
+        check(_lib.lib().elm_comm_destroy(self._h), self._h, "elm_comm_destroy")
+
+    def set_allreduce_hook(self, fn):
+        """fn(dev_ptr:int, n_doubles:int, hip_stream:int) -> 0 on success; None removes the hook."""
+        if fn is None:
+            self._hook_ref = _lib.ALLREDUCE_FN(0)
+        else:
+            self._hook_ref = _lib.ALLREDUCE_FN(lambda p, n, s, u: int(fn(p, n, s)))
+        check(_lib.lib().elm_comm_set_hook(self._h, self._hook_ref, None), self._h, "elm_comm_set_hook")
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+class VoxelHashMap:
+    """vhm.hpp:89-335.  Points are (n,3) float32 arrays (the PCD map and the LiDAR are float32, pcm.hpp:205-215)."""
+
+    def __init__(self, voxel_size=1.0, max_points_per_voxel=30, ctx=None):
+        self.ctx = ctx or default_context()
+        self.voxel_size_ = float(voxel_size)
+        self.max_points_per_voxel_ = int(max_points_per_voxel)
+        self._pending = []
+        self._h = None
+        self._want_voxel_cov = False
+        self._want_point_cov = None
+
+    def Init(self, voxel_size, max_points_per_voxel):  # vhm.cpp:26-29
+        self.voxel_size_ = float(voxel_size)
+        self.max_points_per_voxel_ = int(max_points_per_voxel)
+
+    def Clear(self):  # vhm.hpp:324
+        self._release()
+        self._pending = []
+
+    def _release(self):
+        if self._h is not None:
+            _lib.lib().elm_map_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def AddPoints(self, points):  # vhm.cpp:270-285
+        pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+        if pts.shape[0] == 0:
+            return
+        self._pending.append(pts)
+        self._release()  # rebuilt on next use; sequential AddPoints == one AddPoints of the concatenation
+
+    def Update(self, points, origin=None):  # vhm.cpp:268
+        self.AddPoints(points)
+
+    def _handle(self):
+        if self._h is None:
+            allp = (np.concatenate(self._pending, axis=0) if len(self._pending) > 1 else
+                    (self._pending[0] if self._pending else np.zeros((0, 3), np.float32)))
+            self._pending = [allp] if allp.shape[0] else []
+            h = C.c_void_p()
+            check(_lib.lib().elm_map_build(self.ctx._h, _fp(allp), allp.shape[0], self.voxel_size_,
+                                           self.max_points_per_voxel_, C.byref(h)), self.ctx._h, "elm_map_build")
+            self._h = h
+            if self._want_voxel_cov:
+                check(_lib.lib().elm_map_cal_voxel_cov_all(self._h), self.ctx._h, "elm_map_cal_voxel_cov_all")
+            if self._want_point_cov is not None:
+                check(_lib.lib().elm_map_cal_point_cov_all(self._h, self._want_point_cov), self.ctx._h,
+                      "elm_map_cal_point_cov_all")
+        return self._h
+
+    def CalVoxelCovAll(self):  # vhm.hpp:183-193
+        self._want_voxel_cov = True
+        if self._h is not None:
+            check(_lib.lib().elm_map_cal_voxel_cov_all(self._h), self.ctx._h, "elm_map_cal_voxel_cov_all")
+        else:
+            self._handle()
+
+    def CalPointCovAll(self, d_search_dist):  # vhm.hpp:252-257
+        self._want_point_cov = float(d_search_dist)
+        if self._h is not None:
+            check(_lib.lib().elm_map_cal_point_cov_all(self._h, float(d_search_dist)), self.ctx._h,
+                  "elm_map_cal_point_cov_all")
+        else:
+            self._handle()
+
+    def Empty(self):  # vhm.hpp:325
+        return bool(_lib.lib().elm_map_empty(self._handle()))
+
+    def info(self):
+        mi = MapInfo()
+        check(_lib.lib().elm_map_get_info(self._handle(), C.byref(mi)), self.ctx._h, "elm_map_get_info")
+        return mi
+
+    def Pointcloud(self, with_cov=False):  # vhm.cpp:245-255
+        n = int(self.info().n_points)
+        xyz = np.empty((n, 3))
+        if not with_cov:
+            check(_lib.lib().elm_map_download_points(self._handle(), _dp(xyz), None, None, n), self.ctx._h,
+                  "elm_map_download_points")
+            return xyz
+        cov = np.empty((n, 9)); mean = np.empty((n, 3))
+        check(_lib.lib().elm_map_download_points(self._handle(), _dp(xyz), _dp(cov), _dp(mean), n), self.ctx._h,
+              "elm_map_download_points")
+        return xyz, cov.reshape(n, 3, 3).transpose(0, 2, 1).copy(), mean
+
+    def Voxels(self):
+        """(stored keys, point counts, covs, means) of every voxel."""
+        n = int(self.info().n_voxels)
+        key = np.empty((n, 3), np.int32); npts = np.empty(n, np.int32)
+        cov = np.empty((n, 9)); mean = np.empty((n, 3))
+        check(_lib.lib().elm_map_download_voxels(self._handle(), key.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                 npts.ctypes.data_as(C.POINTER(C.c_int32)), _dp(cov), _dp(mean), n),
+              self.ctx._h, "elm_map_download_voxels")
+        return key, npts, cov.reshape(n, 3, 3).transpose(0, 2, 1).copy(), mean
+
+    def Covariances(self):  # vhm.cpp:257-265: voxels with more than 2 points
+        key, npts, cov, mean = self.Voxels()
+        sel = npts > 2
+        return cov[sel], mean[sel]
+
+    def FindGroundHeight(self, position):  # vhm.hpp:285-322 -> (found, ground_z)
+        z = C.c_double(0.0); found = C.c_int(0)
+        check(_lib.lib().elm_map_find_ground_height(self._handle(), float(position[0]), float(position[1]),
+                                                    C.byref(z), C.byref(found)), self.ctx._h,
+              "elm_map_find_ground_height")
+        return bool(found.value), z.value
+
+    @staticmethod
+    def PointToVoxel(point, voxel_size):  # vhm.hpp:176-180
+        return np.floor(np.asarray(point, dtype=np.float64) / voxel_size).astype(np.int32)
+
+    @staticmethod
+    def VoxelDownsample(points, voxel_size):  # vhm.hpp:260-283: first point of every floor-keyed voxel
+        pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+        keys = np.floor(pts.astype(np.float64) / voxel_size).astype(np.int64)
+        _, first = np.unique(keys, axis=0, return_index=True)
+        first.sort()
+        return pts[first]
+
+
+class Scan:
+    """A device-resident source scan (sensor frame)."""
+
+    def __init__(self, ctx, xyz, n_total=None):
+        self.ctx = ctx
+        pts = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        self.n = pts.shape[0]
+        self._h = C.c_void_p()
+        check(_lib.lib().elm_scan_upload(ctx._h, _fp(pts), self.n, self.n if n_total is None else int(n_total),
+                                         C.byref(self._h)), ctx._h, "elm_scan_upload")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().elm_scan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _result_dict(r, trace=None):
+    d = dict(T=np.array(r.T).reshape(4, 4).T.copy(), is_success=bool(r.is_success), iterations=int(r.iterations),
+             gate=int(r.gate), fitness_score=float(r.fitness_score), d_fitness=float(r.d_fitness),
+             local_cov=np.array(r.local_cov).reshape(6, 6).T.copy(), n_corr_last=float(r.n_corr_last))
+    if trace is not None:
+        its = []
+        for k in range(min(r.iterations, _lib.MAX_ITER_TRACE)):
+            t = trace[k]
+            its.append(dict(n_corr=t.n_corr, JTJ=np.array(t.JTJ).reshape(6, 6).T.copy(), JTr=np.array(t.JTr),
+                            residual_sum=t.residual_sum, x=np.array(t.x), step_norm=t.step_norm,
+                            T=np.array(t.T).reshape(4, 4).T.copy()))
+        d["iters"] = its
+    return d
+
+
+class Registration:
+    """reg.hpp:101-230."""
+
+    def __init__(self, config=None, ctx=None):
+        self.ctx = ctx or default_context()
+        self.config_ = config if config is not None else RegistrationConfig()
+        self.d_fitness_score_ = 0.0
+
+    def Init(self, config):  # reg.hpp:104
+        self.config_ = config
+
+    def RunRegister(self, source_local, voxel_map, initial_guess, m_config=None, trace=False):
+        """reg.cpp:274-418.  Returns (pose 4x4, is_success, fitness_score, local_cov 6x6[, details]).
+
+        fitness_score is None on failure (the reference leaves its out-param untouched, reg.cpp:415)."""
+        cfg = m_config if m_config is not None else self.config_
+        scan = np.ascontiguousarray(source_local, dtype=np.float32).reshape(-1, 3)
+        T0 = _colmajor16(initial_guess)
+        Tout = np.empty(16); ok = C.c_int(0); fit = C.c_double(float("nan")); cov = np.empty(36)
+        res = RegResult()
+        tr = (IterTrace * _lib.MAX_ITER_TRACE)() if trace else None
+        check(_lib.lib().elm_register(self.ctx._h, voxel_map._handle(), _fp(scan), scan.shape[0], _dp(T0),
+                                      C.byref(cfg), _dp(Tout), C.byref(ok), C.byref(fit), _dp(cov), C.byref(res),
+                                      tr), self.ctx._h, "elm_register")
+        self.d_fitness_score_ = res.d_fitness
+        pose = Tout.reshape(4, 4).T.copy()
+        out = (pose, bool(ok.value), (fit.value if ok.value else None), cov.reshape(6, 6).T.copy())
+        if trace:
+            return out + (_result_dict(res, tr),)
+        return out
+
+    def RunRegisterBatch(self, scans, voxel_map, initial_guesses, m_config=None, trace=False):
+        """Many resident scans against one map, iterated together. Returns a list of result dicts."""
+        self.EnqueueBatch(scans, voxel_map, initial_guesses, m_config, trace)
+        return self.FinishBatch()
+
+    def EnqueueBatch(self, scans, voxel_map, initial_guesses, m_config=None, trace=False):
+        cfg = m_config if m_config is not None else self.config_
+        B = len(scans)
+        arr = (C.c_void_p * B)(*[s._h for s in scans])
+        T0 = np.concatenate([_colmajor16(T) for T in initial_guesses])
+        self._pending = (B, trace)
+        check(_lib.lib().elm_register_batch_enqueue(self.ctx._h, voxel_map._handle(), arr, B, _dp(T0),
+                                                    C.byref(cfg), int(bool(trace))), self.ctx._h,
+              "elm_register_batch_enqueue")
+
+    def FinishBatch(self):
+        B, trace = self._pending
+        res = (RegResult * B)()
+        tr = (IterTrace * (_lib.MAX_ITER_TRACE * B))() if trace else None
+        check(_lib.lib().elm_register_batch_finish(self.ctx._h, res, tr), self.ctx._h, "elm_register_batch_finish")
+        out = []
+        for b in range(B):
+            t = tr[b * _lib.MAX_ITER_TRACE:(b + 1) * _lib.MAX_ITER_TRACE] if trace else None
+            out.append(_result_dict(res[b], t))
+        return out
+
+    @staticmethod
+    def TransformPoints(T, points):  # reg.hpp:126-148 (host-side convenience, float64)
+        p = np.asarray(points, dtype=np.float64).reshape(-1, 3)
+        T = np.asarray(T, dtype=np.float64)
+        return p @ T[:3, :3].T + T[:3, 3]

@@ -1,0 +1,221 @@
+/*
+ * elimaloc_hip.h -- C ABI of the MI355X-native pcm_matching registration hot path.
+ *
+ * This is the drop-in boundary: every entry point replaces one in-process C++ call of the reference
+ * (ELiMaLoc @ 2025-02-27).  Citations are relative to /root/reference/src/app/localization/ :
+ *   reg.hpp/reg.cpp = pcm_matching/{include,src}/registration.{hpp,cpp}
+ *   vhm.hpp/vhm.cpp = pcm_matching/{include,src}/voxel_hash_map.{hpp,cpp}
+ *   pcm.hpp/pcm.cpp = pcm_matching/{include,src}/pcm_matching.{hpp,cpp}
+ *
+ * Conventions
+ *   - plain pointers and sizes only; 4x4 / 6x6 / 3x3 matrices are column-major doubles (Eigen's default).
+ *   - every function returns an int status: 0 = ok, <0 = error (see elm_strerror); the status is SEPARATE
+ *     from the algorithmic is_success flag of RunRegister.
+ *   - a context owns one GPU (one process per GPU), one HIP stream and all scratch memory.  Calls on one
+ *     context must be serialised by the caller (the reference serialises them with mutex_pcl_, pcm.cpp:199,357).
+ *   - no CPU fallback exists: without a gfx950 device elm_ctx_create fails.
+ */
+#ifndef ELIMALOC_HIP_H
+#define ELIMALOC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ELM_OK 0
+#define ELM_ERR_INVALID -1     /* bad argument */
+#define ELM_ERR_DEVICE -2      /* HIP runtime error (elm_last_error has the text) */
+#define ELM_ERR_NO_DEVICE -3   /* no usable gfx950 device */
+#define ELM_ERR_COMM -4        /* RCCL error / not initialised */
+#define ELM_ERR_UNSUPPORTED -5 /* e.g. use_radar_cov = 1 */
+
+#define ELM_MAX_ITER_TRACE 64
+
+typedef struct elm_ctx elm_ctx;
+typedef struct elm_map elm_map;   /* VoxelHashMap, device resident (vhm.hpp:89-335) */
+typedef struct elm_scan elm_scan; /* one source scan (sensor frame), device resident */
+
+/* IcpMethod (reg.hpp:60) */
+enum { ELM_P2P = 0, ELM_GICP = 1, ELM_VGICP = 2, ELM_AVGICP = 3 };
+
+/* POD mirror of RegistrationConfig (reg.hpp:62-85), same field names. */
+typedef struct elm_reg_config {
+    int32_t i_max_thread;        /* unused on the GPU; kept for API parity */
+    int32_t icp_method;          /* ELM_P2P .. ELM_AVGICP */
+    int32_t voxel_search_method; /* parsed but unused by the reference (pcm.cpp:175) */
+    int32_t use_radar_cov;       /* must be 0 (reg.hpp:210-217 not built) */
+    int32_t max_iteration;
+    int32_t b_debug_print;
+    double gicp_cov_search_dist;
+    double max_search_dist;
+    double lm_lambda;
+    double icp_termination_threshold_m;
+    double min_overlap_ratio;
+    double max_fitness_score;
+    double doppler_trans_lambda;
+    double range_variance_m;
+    double azimuth_variance_deg;
+    double elevation_variance_deg;
+    double ego_to_lidar_trans[3];
+    double ego_to_lidar_rot[9];
+    double ego_to_imu_rot[9];
+} elm_reg_config;
+
+/* Fills the shipped defaults of config/localization.ini:80-105. */
+void elm_reg_config_default(elm_reg_config* cfg);
+
+/* Per-iteration record (optional; see elm_reg_result.trace). */
+typedef struct elm_iter_trace {
+    double JTJ[36]; /* column-major, before damping */
+    double JTr[6];
+    double residual_sum;
+    double n_corr;
+    double x[6];
+    double step_norm;
+    double T[16];
+} elm_iter_trace;
+
+/* Outputs of one RunRegister (reg.cpp:274-418). */
+typedef struct elm_reg_result {
+    double T[16];         /* returned pose (column-major) */
+    double fitness_score; /* written only on success, as the reference's out-param (reg.cpp:415); else 0 */
+    double d_fitness;     /* Registration::d_fitness_score_ at return */
+    double local_cov[36]; /* I unless GICP (reg.cpp:280,142) */
+    int32_t is_success;
+    int32_t iterations; /* executed iterations */
+    int32_t gate;       /* 0 none, 1 empty map, 2 overlap ratio (reg.cpp:352), 3 fitness (reg.cpp:405) */
+    int32_t _pad;
+    double n_corr_last; /* correspondences of the last executed iteration */
+} elm_reg_result;
+
+typedef struct elm_map_info {
+    uint64_t n_input_points;
+    uint64_t n_points; /* retained by AddPoints' spacing rule */
+    uint64_t n_voxels;
+    uint64_t hash_capacity;
+    double voxel_size;
+    int32_t max_points_per_voxel;
+    int32_t has_voxel_cov;
+    int32_t has_point_cov;
+    int32_t _pad;
+    uint64_t device_bytes;
+} elm_map_info;
+
+/* ---------------------------------------------------------------- context ------------------------- */
+int elm_ctx_create(int device_id, elm_ctx** out);
+void elm_ctx_destroy(elm_ctx* ctx);
+const char* elm_last_error(const elm_ctx* ctx); /* text of the last ELM_ERR_DEVICE / ELM_ERR_COMM */
+const char* elm_strerror(int status);
+int elm_ctx_synchronize(elm_ctx* ctx);
+/* native hipStream_t of the context (for hipEvent timing by the caller) */
+void* elm_ctx_stream(elm_ctx* ctx);
+
+/* ---------------------------------------------------------------- map ----------------------------- */
+/* VoxelHashMap::Init + AddPoints (vhm.cpp:26-29, 270-285; call site pcm.cpp:87-88).  xyz: n*3 float32 map
+ * points in file order (the PCD is float32, pcm.hpp:205-215).  Serial insertion semantics (trunc keys,
+ * min-spacing rule, <= max_points) are reproduced per voxel; buckets are uploaded to the device. */
+int elm_map_build(elm_ctx* ctx, const float* xyz, size_t n, double voxel_size, int max_points_per_voxel,
+                  elm_map** out);
+void elm_map_destroy(elm_map* map);
+/* VoxelHashMap::CalVoxelCovAll (vhm.hpp:183-193), HIP kernel over voxels */
+int elm_map_cal_voxel_cov_all(elm_map* map);
+/* VoxelHashMap::CalPointCovAll (vhm.hpp:252-257), HIP kernel over map points */
+int elm_map_cal_point_cov_all(elm_map* map, double d_search_dist);
+int elm_map_get_info(const elm_map* map, elm_map_info* info);
+/* VoxelHashMap::Empty (vhm.hpp:325) */
+int elm_map_empty(const elm_map* map);
+/* VoxelHashMap::Pointcloud (vhm.cpp:245-255): xyz[3n] doubles; optional per-point cov (9, col-major) and mean (3).
+ * Order is bucket order (the reference's order is unordered_map iteration order; only the set is contractual). */
+int elm_map_download_points(const elm_map* map, double* xyz, double* cov9, double* mean3, size_t cap);
+/* all voxels: stored key (3 ints), point count, cov (9) and mean (3); Covariances() (vhm.cpp:257-265) is the
+ * subset with count > 2 */
+int elm_map_download_voxels(const elm_map* map, int32_t* key3, int32_t* npts, double* cov9, double* mean3,
+                            size_t cap);
+/* VoxelHashMap::FindGroundHeight (vhm.hpp:285-322); *found = 0/1 */
+int elm_map_find_ground_height(const elm_map* map, double x, double y, double* ground_z, int* found);
+
+/* ---------------------------------------------------------------- scans --------------------------- */
+/* Upload one source scan (sensor frame, float32 xyz; PointStruct.local == .pose, pcm.hpp:205-220).
+ * n_total is the size of the whole scan when this context holds only a shard of it (multi-GPU; the overlap
+ * ratio of reg.cpp:351 is taken against n_total); pass n_total = n on one GPU.  The points are re-ordered into
+ * coarse sensor-frame cells for cache locality (source order is not contractual: the reference's own
+ * VoxelDownsample emits unordered_map order, vhm.hpp:278-280). */
+int elm_scan_upload(elm_ctx* ctx, const float* xyz, size_t n, size_t n_total, elm_scan** out);
+void elm_scan_destroy(elm_scan* scan);
+size_t elm_scan_size(const elm_scan* scan);
+
+/* ---------------------------------------------------------------- registration -------------------- */
+/* Registration::RunRegister (reg.hpp:122-124, reg.cpp:274-418; call sites pcm.cpp:280-282, 412-414) on host
+ * buffers: uploads the scan, iterates on the device, downloads the result.  trace may be NULL or an array of
+ * ELM_MAX_ITER_TRACE entries. */
+int elm_register(elm_ctx* ctx, const elm_map* map, const float* scan_xyz, size_t n, const double T0[16],
+                 const elm_reg_config* cfg, double T_out[16], int* is_success, double* fitness_score,
+                 double local_cov[36], elm_reg_result* result, elm_iter_trace* trace);
+
+/* The same on B device-resident scans against one map, all iterated together (one accumulate launch, one
+ * optional all-reduce and one solve launch per ICP iteration for the whole batch).  T0: 16*B doubles.
+ * results: B entries.  trace: NULL or B*ELM_MAX_ITER_TRACE entries. */
+int elm_register_batch(elm_ctx* ctx, const elm_map* map, elm_scan* const* scans, int batch, const double* T0,
+                       const elm_reg_config* cfg, elm_reg_result* results, elm_iter_trace* trace);
+/* Asynchronous halves of the above: enqueue everything on the context stream / wait and fetch results. */
+int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_scan* const* scans, int batch,
+                               const double* T0, const elm_reg_config* cfg, int want_trace);
+int elm_register_batch_finish(elm_ctx* ctx, elm_reg_result* results, elm_iter_trace* trace);
+
+/* ---------------------------------------------------------------- deskew -------------------------- */
+/* Tables produced by ImuDeskewInfo / OdomDeskewInfo (pcm.cpp:533-729). */
+typedef struct elm_deskew_tables {
+    double d_time_scan_cur;     /* pcm.cpp:474/481 */
+    double d_time_scan_end;     /* pcm.cpp:475/480 */
+    int32_t i_imu_pointer_cur;  /* last valid table index (pcm.cpp:580) */
+    int32_t b_run_deskew;       /* loc.ini:86 */
+    int32_t b_is_imu_available; /* pcm.cpp:584 */
+    int32_t b_is_odom_available;/* pcm.cpp:728 */
+    float f_odom_incre_x, f_odom_incre_y, f_odom_incre_z; /* pcm.cpp:725 */
+    float _pad;
+    const double* vec_d_imu_time;  /* [i_imu_pointer_cur + 1] host pointers */
+    const double* vec_d_imu_rot_x;
+    const double* vec_d_imu_rot_y;
+    const double* vec_d_imu_rot_z;
+} elm_deskew_tables;
+
+/* The per-point loop of DeskewPointCloud (pcm.cpp:498-525 -> DeskewPoint :780-824) as one HIP kernel.
+ * xyz: n*3 float32, rel_time: n float32 (already rebased as pcm.cpp:483-485), xyz_out: n*3 float32 (host).
+ * Returns ELM_OK and *ok = 0 when IMU or odom tables are unavailable (pcm.cpp:494-496, nothing written). */
+int elm_deskew(elm_ctx* ctx, const float* xyz, const float* rel_time, size_t n, const elm_deskew_tables* tab,
+               float* xyz_out, int* ok);
+/* Host-side table preparation, same arithmetic as the reference (doubles for the IMU table, float32
+ * PCL/Eigen transforms for the odometry increment).
+ * imu: n_imu rows (t, wx, wy, wz) already rotated into the ego frame (pcm.cpp:328).
+ * odom: n_odom rows of 14 doubles (t, px,py,pz, qx,qy,qz,qw, vx,vy,vz, wx,wy,wz).
+ * front_time/back_time: time field of the first/last raw point; stamp: message stamp - lidar_time_delay. */
+int elm_deskew_prepare(const double* imu4, size_t n_imu, const double* odom14, size_t n_odom, double stamp,
+                       float front_time, float back_time, int lidar_scan_time_end, int run_deskew,
+                       double* tab_time, double* tab_rx, double* tab_ry, double* tab_rz, size_t tab_cap,
+                       elm_deskew_tables* out);
+
+/* ---------------------------------------------------------------- multi-GPU ----------------------- */
+/* One process per GPU.  Rank 0 obtains an id, the host distributes its bytes (e.g. torch.distributed
+ * broadcast), every rank calls elm_comm_init.  Afterwards elm_register_batch* sums the packed normal
+ * equations of every scan over all ranks with ONE ncclAllReduce(double, sum) per ICP iteration (RCCL/xGMI).
+ * RCCL is dlopen'ed ("librccl.so.1") on first use, a single-GPU process never needs it. */
+#define ELM_COMM_ID_BYTES 128
+int elm_comm_get_unique_id(void* id_bytes /* ELM_COMM_ID_BYTES */);
+int elm_comm_init(elm_ctx* ctx, int rank, int nranks, const void* id_bytes);
+int elm_comm_destroy(elm_ctx* ctx);
+/* Alternative exchange hook (e.g. a torch.distributed all_reduce from Python): called between the accumulate
+ * and the solve launches with the device pointer of the packed sums. Pass NULL to remove. */
+typedef int (*elm_allreduce_fn)(void* dev_ptr, size_t n_doubles, void* hip_stream, void* user);
+int elm_comm_set_hook(elm_ctx* ctx, elm_allreduce_fn fn, void* user);
+
+/* number of doubles all-reduced per scan per iteration: 21 (upper JTJ) + 6 (JTr) + 1 (residual) + 1 (n_corr)
+ * padded to 32 */
+#define ELM_PACKED_SUMS 32
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ELIMALOC_HIP_H */

@@ -1,0 +1,191 @@
+"""Independent numpy float64 re-derivation of one RunRegister, used to cross-check the C++
+oracle.  Written from the math, not from oracle/elm_oracle.cpp: dict-of-lists voxel map, numpy SVD / solve / eigh,
+Rodrigues via the closed form.  Pure-Python loops -> small cases only (<= a few thousand scan points).
+"""
+import math
+
+import numpy as np
+
+
+def build_map(points, voxel_size=1.0, max_points=30):
+    """AddPoints: truncation keys, first point always kept, later ones iff < max_points stored and none within
+    sqrt(vs^2/max_points) (strict <)."""
+    res = math.sqrt(voxel_size * voxel_size / max_points)
+    vox = {}
+    for p in np.asarray(points, dtype=np.float64):
+        key = tuple(int(c) for c in np.trunc(p / voxel_size))
+        b = vox.get(key)
+        if b is None:
+            vox[key] = [p]
+        elif len(b) < max_points and all(np.linalg.norm(q - p) >= res for q in b):
+            b.append(p)
+    return vox
+
+
+def regularize(cov):
+    U, _, Vt = np.linalg.svd(cov)
+    return U @ np.diag([1.0, 1.0, 1e-3]) @ Vt
+
+
+def voxel_covs(vox):
+    out = {}
+    for k, b in vox.items():
+        n = len(b)
+        if n == 1:
+            out[k] = (np.eye(3), b[0].copy())
+        else:
+            P = np.array(b)
+            mean = P.mean(axis=0)
+            D = P - mean
+            out[k] = (regularize(D.T @ D / (n - 1)), mean)
+    return out
+
+
+def neighbours27(g, voxel_size):
+    v = np.floor(g / voxel_size).astype(int)
+    for i in (-1, 0, 1):
+        for j in (-1, 0, 1):
+            for k in (-1, 0, 1):
+                yield (v[0] + i, v[1] + j, v[2] + k)
+
+
+def point_covs(vox, voxel_size, dist):
+    """per stored point: {itself} + every stored point of the 27 floor-keyed voxels within dist (itself again)."""
+    out = {}
+    for k, b in vox.items():
+        for idx, p in enumerate(b):
+            nb = [p]
+            for nk in neighbours27(p, voxel_size):
+                for q in vox.get(nk, ()):
+                    if np.sum((q - p) ** 2) <= dist * dist:
+                        nb.append(q)
+            if len(nb) == 1:
+                out[(k, idx)] = (np.eye(3), p.copy())
+            else:
+                P = np.array(nb)
+                mean = P.mean(axis=0)
+                D = P - mean
+                out[(k, idx)] = (regularize(D.T @ D / (len(nb) - 1)), mean)
+    return out
+
+
+def skew(p):
+    return np.array([[0, -p[2], p[1]], [p[2], 0, -p[0]], [-p[1], p[0], 0]])
+
+
+def exp_so3(w):
+    th = np.linalg.norm(w)
+    if th == 0:
+        return np.eye(3)
+    K = skew(w / th)
+    return np.eye(3) + math.sin(th) * K + (1 - math.cos(th)) * K @ K
+
+
+def rot_angle(R):
+    c = (np.trace(R) - 1) / 2
+    s = 0.5 * np.linalg.norm([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    return math.atan2(s, c)
+
+
+def register(vox, scan, T0, method, voxel_size=1.0, max_iteration=10, th=5.0, lam=0.5, term=0.02, min_overlap=0.4,
+             max_fitness=0.5, vcov=None, pcov=None):
+    """method: 0 P2P, 1 GICP, 2 VGICP, 3 AVGICP."""
+    scan = np.asarray(scan, dtype=np.float64)
+    T = np.array(T0, dtype=np.float64)
+    N = len(scan)
+    trace = []
+    fitness = 0.0
+    local_cov = np.eye(6)
+    if not vox:
+        return dict(T=T, is_success=False, iterations=0, gate=1, iters=[], fitness=0.0, local_cov=local_cov)
+    iters = 0
+    for _ in range(max_iteration):
+        iters += 1
+        R, t = T[:3, :3], T[:3, 3]
+        pairs = []  # (p_local, target_pos, cov or None, normal or None)
+        for p in scan:
+            g = R @ p + t
+            if method in (0, 1):
+                best, bd = None, np.inf
+                for nk in neighbours27(g, voxel_size):
+                    for idx, q in enumerate(vox.get(nk, ())):
+                        d = np.sum((q - g) ** 2)
+                        if d < bd:
+                            bd, best = d, (nk, idx, q)
+                if best is None:
+                    tgt, C, mean = np.zeros(3), np.eye(3), np.zeros(3)
+                    d = np.sum(g ** 2)
+                else:
+                    tgt = best[2]
+                    d = bd
+                    if method == 1:
+                        C, mean = pcov[(best[0], best[1])]
+                if d < th * th:
+                    if method == 0:
+                        pairs.append((p, tgt, None, None))
+                    else:
+                        w, V = np.linalg.eigh((C + C.T) / 2)
+                        n = V[:, 0] if not np.allclose(C, np.eye(3)) else np.array([1.0, 0, 0])
+                        pairs.append((p, mean, C, n))
+            elif method == 2:
+                best, bd = None, np.inf
+                for nk in neighbours27(g, voxel_size):
+                    if nk in vox:
+                        C, mean = vcov[nk]
+                        d = np.sum((mean - g) ** 2)
+                        if d < bd:
+                            bd, best = d, (C, mean)
+                if best is None:
+                    best, bd = (np.eye(3), np.zeros(3)), np.sum(g ** 2)
+                if bd < th * th:
+                    pairs.append((p, best[1], best[0], None))
+            else:
+                v = np.floor(g / voxel_size).astype(int)
+                for off in ((0, 0, 0), (1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)):
+                    nk = (v[0] + off[0], v[1] + off[1], v[2] + off[2])
+                    if nk in vox:
+                        C, mean = vcov[nk]
+                        if np.sum((mean - g) ** 2) < th * th:
+                            pairs.append((p, mean, C, None))
+        n_corr = len(pairs)
+        rec = dict(n_corr=n_corr)
+        if np.float32(n_corr) / np.float32(N) < min_overlap:
+            trace.append(rec)
+            return dict(T=T, is_success=False, iterations=iters, gate=2, iters=trace, fitness=fitness,
+                        local_cov=local_cov)
+        H = np.zeros((6, 6)); b = np.zeros(6); rs = 0.0
+        Rt = R.T
+        for p, m, C, n in pairs:
+            r = Rt @ (m - t) - p
+            J = np.hstack([np.eye(3), -skew(p)])
+            w = th * th / (th + r @ r) ** 2
+            if method == 1:
+                w = w * 0.8 + 0.2
+            M = np.eye(3) if C is None else np.linalg.inv(Rt @ C @ R)
+            if method >= 2 and w < 0.01:
+                continue
+            H += w * J.T @ M @ J
+            b += w * J.T @ M @ r
+            if method == 1:
+                nl = Rt @ n
+                nl = nl / np.linalg.norm(nl)
+                rs += abs(r @ nl)
+            else:
+                rs += np.linalg.norm(r)
+        fitness = rs / n_corr
+        Hd = H + lam * np.diag(np.diag(H))
+        x = np.linalg.solve(Hd, b)
+        if method == 1:
+            local_cov = np.linalg.inv(Hd)
+        dT = np.eye(4)
+        dT[:3, :3] = exp_so3(x[3:])
+        dT[:3, 3] = x[:3]
+        T = T @ dT
+        step = rot_angle(dT[:3, :3]) + np.linalg.norm(x[:3])
+        rec.update(JTJ=H, JTr=b, residual_sum=rs, x=x, step_norm=step, T=T.copy())
+        trace.append(rec)
+        if step < term:
+            break
+    ok = not (fitness > max_fitness)
+    return dict(T=T, is_success=ok, iterations=iters, gate=0 if ok else 3, iters=trace, fitness=fitness,
+                local_cov=local_cov)

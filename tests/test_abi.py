@@ -1,0 +1,153 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/elimaloc_hip.h
+declares, refuses to run without a gfx950 device (no CPU fallback), and its GPU-free host functions work."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "elimaloc_hip.h")
+
+
+@pytest.fixture(scope="module")
+def L():
+    import __graft_entry__ as g
+    from elimaloc_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        g.build()
+    return _lib.lib()
+
+
+def _declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set(re.findall(r"\b(elm_[a-z0-9_]+)\s*\(", src))
+    names.discard("elm_allreduce_fn")
+    return names
+
+
+def test_header_symbols_all_exported(L):
+    from elimaloc_amd import _lib
+    decl = _declared_symbols()
+    assert decl, "no declarations parsed"
+    assert decl == set(_lib.EXPORTS), (decl ^ set(_lib.EXPORTS))
+    for name in decl:
+        assert hasattr(L, name), f"{name} declared in include/elimaloc_hip.h but not exported"
+
+
+def test_struct_layouts_match_header(L):
+    """ctypes mirrors vs the C structs: compile a tiny C probe that prints sizeof/offsetof."""
+    import subprocess
+    import tempfile
+    from elimaloc_amd import _lib
+    probe = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "elimaloc_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu\n", sizeof(elm_reg_config), sizeof(elm_iter_trace), sizeof(elm_reg_result),
+         sizeof(elm_map_info), sizeof(elm_deskew_tables));
+  printf("%zu %zu %zu %zu\n", offsetof(elm_reg_config, gicp_cov_search_dist), offsetof(elm_reg_config, ego_to_lidar_trans),
+         offsetof(elm_reg_result, is_success), offsetof(elm_deskew_tables, vec_d_imu_time));
+  return 0; }
+'''
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "p.c")
+        open(src, "w").write(probe)
+        exe = os.path.join(d, "p")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+        out = subprocess.check_output([exe]).decode().split()
+    sizes = [int(x) for x in out]
+    assert sizes[:5] == [C.sizeof(_lib.RegConfig), C.sizeof(_lib.IterTrace), C.sizeof(_lib.RegResult),
+                         C.sizeof(_lib.MapInfo), C.sizeof(_lib.DeskewTables)]
+    assert sizes[5:] == [_lib.RegConfig.gicp_cov_search_dist.offset, _lib.RegConfig.ego_to_lidar_trans.offset,
+                         _lib.RegResult.is_success.offset, _lib.DeskewTables.vec_d_imu_time.offset]
+
+
+def test_defaults_are_localization_ini(L):
+    from elimaloc_amd.registration import RegistrationConfig, IcpMethod
+    c = RegistrationConfig()
+    # config/localization.ini:83-105
+    assert (c.icp_method, c.max_iteration, c.i_max_thread, c.use_radar_cov) == (IcpMethod.GICP, 10, 10, 0)
+    assert (c.max_search_dist, c.lm_lambda, c.icp_termination_threshold_m) == (5.0, 0.5, 0.02)
+    assert (c.min_overlap_ratio, c.max_fitness_score, c.gicp_cov_search_dist) == (0.4, 0.5, 0.4)
+
+
+def test_no_device_no_fallback(L):
+    """Without a gfx950 device the context cannot be created: the product never computes on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    rc = L.elm_ctx_create(0, C.byref(h))
+    assert rc != 0 and not h.value
+    from elimaloc_amd.registration import Context
+    from elimaloc_amd._lib import ElmError
+    with pytest.raises(ElmError):
+        Context(0)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from elimaloc_amd import _lib
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libelimaloc_hip.so")
+    with pytest.raises(_lib.ElmError):
+        _lib.lib()
+
+
+def test_product_does_not_touch_the_oracle():
+    """Nothing under elimaloc_amd/ or include/ may import, link or dlopen oracle/ (it is test infrastructure)."""
+    bad = []
+    for base in ("elimaloc_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h", "Makefile")):
+                    txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                    if re.search(r"elm_oracle|from oracle|import oracle|oracle/", txt):
+                        bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
+
+
+def test_deskew_prepare_matches_oracle(L, oracle):
+    """elm_deskew_prepare is a host function (no GPU): ImuDeskewInfo / OdomDeskewInfo against the oracle."""
+    from elimaloc_amd import synth, _lib
+    for seed, end_mode in ((1, True), (2, False)):
+        st = synth.make_deskew_stream(1000, seed=seed)
+        odom = st["odom"] if end_mode else st["odom"][st["odom"][:, 0] < st["stamp"] - 0.02]  # forces twist extrapolation
+        imu = np.ascontiguousarray(np.concatenate([st["imu_t"][:, None], st["imu_w"]], axis=1))
+        tabs = [np.zeros(2000) for _ in range(4)]
+        tab = _lib.DeskewTables()
+        dp = C.POINTER(C.c_double)
+        od = np.ascontiguousarray(odom)
+        rc = L.elm_deskew_prepare(imu.ctypes.data_as(dp), imu.shape[0], od.ctypes.data_as(dp), od.shape[0],
+                                  st["stamp"], float(st["time"][0]), float(st["time"][-1]), 1, 1,
+                                  *[t.ctypes.data_as(dp) for t in tabs], 2000, C.byref(tab))
+        assert rc == 0
+        scan_end = st["stamp"]; scan_cur = scan_end + float(st["time"][0])
+        assert (tab.d_time_scan_cur, tab.d_time_scan_end) == (scan_cur, scan_end)
+        iok, itime, irot = oracle.imu_deskew_info(st["imu_t"], st["imu_w"], scan_cur, scan_end)
+        ook, inc = oracle.odom_deskew_info(odom, scan_cur, scan_end)
+        assert bool(tab.b_is_imu_available) == iok and bool(tab.b_is_odom_available) == ook
+        k = tab.i_imu_pointer_cur + 1
+        assert k == len(itime)
+        assert np.array_equal(tabs[0][:k], itime)
+        assert np.array_equal(np.stack([tabs[1][:k], tabs[2][:k], tabs[3][:k]], axis=1), irot)
+        assert (tab.f_odom_incre_x, tab.f_odom_incre_y, tab.f_odom_incre_z) == tuple(inc)
+        assert abs(tab.f_odom_incre_x) > 0.5  # 10 m/s over a 0.1 s scan
+    # unavailable cases (pcm.cpp:544-547, 598-607)
+    tab = _lib.DeskewTables()
+    rc = L.elm_deskew_prepare(imu.ctypes.data_as(dp), 0, od.ctypes.data_as(dp), 0, st["stamp"], -0.1, 0.0, 1, 1,
+                              *[t.ctypes.data_as(dp) for t in tabs], 2000, C.byref(tab))
+    assert rc == 0 and not tab.b_is_imu_available and not tab.b_is_odom_available
+
+
+def test_voxel_downsample_matches_oracle(oracle):
+    from elimaloc_amd.registration import VoxelHashMap
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-20, 20, size=(5000, 3)).astype(np.float32)
+    keep = oracle.voxel_downsample(pts, 1.5)
+    out = VoxelHashMap.VoxelDownsample(pts, 1.5)
+    assert np.array_equal(out, pts[keep])
+    assert 0 < len(keep) < 5000
