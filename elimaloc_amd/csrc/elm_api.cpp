@@ -86,6 +86,11 @@ struct elm_ctx {
     bool want_trace = false;
     bool in_flight = false;
     RegParams rp{};
+    // optional hipEvent timing
+    bool profiling = false;
+    std::vector<hipEvent_t> events;
+    int events_used = 0;
+    elm_profile prof{};
     // exchange
     void* comm = nullptr;
     int rank = 0, nranks = 1;
@@ -187,12 +192,34 @@ extern "C" void elm_ctx_destroy(elm_ctx* ctx) {
     if (ctx->h_trace) (void)hipHostFree(ctx->h_trace);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->h_desc) (void)hipHostFree(ctx->h_desc);
+    for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
 extern "C" const char* elm_last_error(const elm_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 extern "C" void* elm_ctx_stream(elm_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+extern "C" int elm_ctx_set_profiling(elm_ctx* ctx, int enable) {
+    if (!ctx) return ELM_ERR_INVALID;
+    ctx->profiling = enable != 0;
+    return ELM_OK;
+}
+extern "C" int elm_ctx_get_profile(elm_ctx* ctx, elm_profile* out, int reset) {
+    if (!ctx || !out) return ELM_ERR_INVALID;
+    *out = ctx->prof;
+    if (reset) ctx->prof = elm_profile{};
+    return ELM_OK;
+}
+static int prof_mark(elm_ctx* ctx) { // records the next pooled event on the context stream
+    if (!ctx->profiling) return ELM_OK;
+    if (ctx->events_used == (int)ctx->events.size()) {
+        hipEvent_t e;
+        HIPCHK(ctx, hipEventCreate(&e));
+        ctx->events.push_back(e);
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->events[ctx->events_used++], ctx->stream));
+    return ELM_OK;
+}
 extern "C" int elm_ctx_synchronize(elm_ctx* ctx) {
     if (!ctx) return ELM_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -731,9 +758,12 @@ extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_
     const ScanDesc* dsc = (const ScanDesc*)ctx->d_scans.p;
     launch_init_state(ctx->stream, st, (const double*)ctx->d_T0.p, batch, map_empty ? 1 : 0);
     const bool distributed = (ctx->comm != nullptr) || (ctx->hook != nullptr);
+    ctx->events_used = 0;
     if (!map_empty) {
         for (int it = 0; it < cfg->max_iteration; ++it) {
+            if ((rc = prof_mark(ctx)) != ELM_OK) return rc;
             if (blocks) launch_accumulate(ctx->stream, map->dm, dsc, batch, (int)blocks, st, (double*)ctx->d_partials.p, rp);
+            if ((rc = prof_mark(ctx)) != ELM_OK) return rc;
             if (distributed) {
                 launch_solve(ctx->stream, dsc, batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 1);
                 if ((rc = exchange(ctx, (double*)ctx->d_sums.p, (size_t)batch * kSums)) != ELM_OK) return rc;
@@ -742,6 +772,7 @@ extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_
                 launch_solve(ctx->stream, dsc, batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 0);
             }
         }
+        if ((rc = prof_mark(ctx)) != ELM_OK) return rc;
     }
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_state, st, (size_t)batch * sizeof(ScanState), hipMemcpyDeviceToHost, ctx->stream));
@@ -759,6 +790,16 @@ extern "C" int elm_register_batch_finish(elm_ctx* ctx, elm_reg_result* results, 
     ctx->in_flight = false;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->profiling && ctx->events_used >= 3) {
+        // events: [acc_0, solve_0, acc_1, solve_1, ..., end]
+        for (int k = 0; k + 1 < ctx->events_used; ++k) {
+            float ms = 0.f;
+            HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->events[k], ctx->events[k + 1]));
+            if ((k & 1) == 0) { ctx->prof.accumulate_ms += ms; ctx->prof.accumulate_launches++; }
+            else { ctx->prof.solve_ms += ms; ctx->prof.solve_steps++; }
+        }
+    }
+    ctx->events_used = 0;
     const ScanState* hs = (const ScanState*)ctx->h_state;
     for (int b = 0; results && b < ctx->batch; ++b) {
         elm_reg_result& r = results[b];
@@ -771,6 +812,9 @@ extern "C" int elm_register_batch_finish(elm_ctx* ctx, elm_reg_result* results, 
         r.iterations = hs[b].iters;
         r.gate = hs[b].gate;
         r.n_corr_last = hs[b].n_corr_last;
+        r.point_iterations = hs[b].pt_iters;
+        r.n_cand_total = hs[b].cand_total;
+        r.n_occ_total = hs[b].occ_total;
         if (ctx->rp.max_iter <= 0 && hs[b].gate == 0) { // no iteration ran: fitness gate on the initial 0.0 passes
             r.is_success = 1;
         }

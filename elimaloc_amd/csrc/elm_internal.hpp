@@ -60,6 +60,7 @@ struct ScanState {
     double fitness;  // d_fitness_score_
     double local_cov[36]; // column-major == row-major (symmetric)
     double n_corr_last;
+    double pt_iters, cand_total, occ_total; // work counters over the executed iterations
     int32_t done;
     int32_t success;
     int32_t gate;

@@ -321,6 +321,7 @@ __global__ __launch_bounds__(64) void k_init_state(ScanState* st, const double* 
     S.fitness = 0.0;
     for (int k = 0; k < 36; ++k) S.local_cov[k] = (k % 7 == 0) ? 1.0 : 0.0; // reg.cpp:280
     S.n_corr_last = 0.0;
+    S.pt_iters = 0.0; S.cand_total = 0.0; S.occ_total = 0.0;
     S.done = map_empty ? 1 : 0; // VOXEL MAP EMPTY (reg.cpp:291-295): is_success = false, return initial_guess
     S.success = 0;
     S.gate = map_empty ? 1 : 0;
@@ -360,6 +361,9 @@ __global__ __launch_bounds__(64) void k_solve(const ScanDesc* __restrict__ scans
     const int iter = S.iters;
     const double n_corr = tot[28];
     S.n_corr_last = n_corr;
+    S.pt_iters += (double)sd.n_total;
+    S.cand_total += tot[29];
+    S.occ_total += tot[30];
     elm_iter_trace* tr = (trace && iter <= ELM_MAX_ITER_TRACE) ? &trace[(size_t)s * ELM_MAX_ITER_TRACE + (iter - 1)] : nullptr;
 
     // corres_ratio = (float)i_source_corr_num / i_source_total_num (reg.cpp:351): float division, compared as double

@@ -72,6 +72,15 @@ class Context:
     def stream(self):
         return _lib.lib().elm_ctx_stream(self._h)
 
+    def set_profiling(self, on=True):
+        check(_lib.lib().elm_ctx_set_profiling(self._h, int(bool(on))), self._h, "elm_ctx_set_profiling")
+
+    def get_profile(self, reset=False):
+        p = _lib.Profile()
+        check(_lib.lib().elm_ctx_get_profile(self._h, C.byref(p), int(bool(reset))), self._h, "elm_ctx_get_profile")
+        return dict(accumulate_launches=int(p.accumulate_launches), solve_steps=int(p.solve_steps),
+                    accumulate_ms=float(p.accumulate_ms), solve_ms=float(p.solve_ms))
+
     # ---- multi-GPU (RCCL over xGMI): one small all-reduce of the packed normal equations per iteration
     @staticmethod
     def comm_unique_id():
@@ -258,7 +267,9 @@ class Scan:
 def _result_dict(r, trace=None):
     d = dict(T=np.array(r.T).reshape(4, 4).T.copy(), is_success=bool(r.is_success), iterations=int(r.iterations),
              gate=int(r.gate), fitness_score=float(r.fitness_score), d_fitness=float(r.d_fitness),
-             local_cov=np.array(r.local_cov).reshape(6, 6).T.copy(), n_corr_last=float(r.n_corr_last))
+             local_cov=np.array(r.local_cov).reshape(6, 6).T.copy(), n_corr_last=float(r.n_corr_last),
+             point_iterations=float(r.point_iterations), n_cand_total=float(r.n_cand_total),
+             n_occ_total=float(r.n_occ_total))
     if trace is not None:
         its = []
         for k in range(min(r.iterations, _lib.MAX_ITER_TRACE)):

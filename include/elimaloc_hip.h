@@ -89,6 +89,10 @@ typedef struct elm_reg_result {
     int32_t gate;       /* 0 none, 1 empty map, 2 overlap ratio (reg.cpp:352), 3 fitness (reg.cpp:405) */
     int32_t _pad;
     double n_corr_last; /* correspondences of the last executed iteration */
+    /* work counters summed over the executed iterations (for the algorithmic-bytes model) */
+    double point_iterations; /* scan points processed x iterations */
+    double n_cand_total;     /* candidate map points (P2P/GICP) or voxel means (VGICP/AVGICP) distance-tested */
+    double n_occ_total;      /* occupied neighbour voxels visited */
 } elm_reg_result;
 
 typedef struct elm_map_info {
@@ -112,6 +116,17 @@ const char* elm_strerror(int status);
 int elm_ctx_synchronize(elm_ctx* ctx);
 /* native hipStream_t of the context (for hipEvent timing by the caller) */
 void* elm_ctx_stream(elm_ctx* ctx);
+
+/* Optional per-kernel timing with hipEvents recorded on the context stream around every accumulate launch and
+ * every solve(+exchange) step of elm_register_batch*.  Totals accumulate until reset. */
+typedef struct elm_profile {
+    uint64_t accumulate_launches;
+    uint64_t solve_steps;
+    double accumulate_ms; /* sum of the accumulate kernel spans */
+    double solve_ms;      /* sum of the reduce/solve (+ all-reduce) spans */
+} elm_profile;
+int elm_ctx_set_profiling(elm_ctx* ctx, int enable);
+int elm_ctx_get_profile(elm_ctx* ctx, elm_profile* out, int reset);
 
 /* ---------------------------------------------------------------- map ----------------------------- */
 /* VoxelHashMap::Init + AddPoints (vhm.cpp:26-29, 270-285; call site pcm.cpp:87-88).  xyz: n*3 float32 map
