@@ -70,6 +70,8 @@ class RegResult(C.Structure):
         ("point_iterations", C.c_double),
         ("n_cand_total", C.c_double),
         ("n_occ_total", C.c_double),
+        ("fallback_blocks", C.c_double),
+        ("n_tested_total", C.c_double),
     ]
 
 

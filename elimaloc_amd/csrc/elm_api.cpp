@@ -3,6 +3,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -86,6 +87,7 @@ struct elm_ctx {
     bool want_trace = false;
     bool in_flight = false;
     RegParams rp{};
+    int direct_kernel = 0; // ELM_KERNEL=direct selects the un-staged accumulate kernel (A/B measurements)
     // optional hipEvent timing
     bool profiling = false;
     std::vector<hipEvent_t> events;
@@ -176,6 +178,7 @@ extern "C" int elm_ctx_create(int device_id, elm_ctx** out) {
         delete ctx;
         return ELM_ERR_DEVICE;
     }
+    if (const char* k = getenv("ELM_KERNEL")) ctx->direct_kernel = (strcmp(k, "direct") == 0) ? 1 : 0;
     *out = ctx;
     return ELM_OK;
 }
@@ -220,6 +223,8 @@ static int prof_mark(elm_ctx* ctx) { // records the next pooled event on the con
     HIPCHK(ctx, hipEventRecord(ctx->events[ctx->events_used++], ctx->stream));
     return ELM_OK;
 }
+// diagnostic builds only (-DELM_PHASE_TIMING): per-phase cycle totals of the staged accumulate kernel; not in the public header
+extern "C" int elm_debug_phase_cycles(unsigned long long* out16, int reset) { return debug_phase_cycles(out16, reset); }
 extern "C" int elm_ctx_synchronize(elm_ctx* ctx) {
     if (!ctx) return ELM_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -408,7 +413,8 @@ extern "C" int elm_map_build(elm_ctx* ctx, const float* xyz, size_t n, double vo
     m->ctx = ctx;
     const uint32_t n_vox = (uint32_t)hb.ranges.size();
     const uint32_t n_pts = (uint32_t)hb.pts.size();
-    const uint32_t cap = next_pow2((uint64_t)n_vox * 2);
+    // load factor <= 0.25: a probe for an absent key (most of a workgroup's box cells are empty) ends after ~1.4 slots
+    const uint32_t cap = next_pow2((uint64_t)n_vox * 4);
     std::vector<HashSlot> slots(cap);
     for (auto& s : slots) {
         s.kx = s.ky = s.kz = 0;
@@ -608,30 +614,33 @@ struct elm_scan {
     uint32_t n = 0, n_total = 0;
 };
 
-static inline uint32_t spread10(uint32_t v) { // 10 bits -> every third bit
-    v &= 0x3ff;
-    v = (v | (v << 16)) & 0x030000FF;
-    v = (v | (v << 8)) & 0x0300F00F;
-    v = (v | (v << 4)) & 0x030C30C3;
-    v = (v | (v << 2)) & 0x09249249;
-    return v;
+// index of cell (x, y) along a Hilbert curve over a 2^order x 2^order grid
+static inline uint32_t hilbert_xy2d(uint32_t order, uint32_t x, uint32_t y) {
+    uint32_t d = 0;
+    for (uint32_t s = 1u << (order - 1); s > 0; s >>= 1) {
+        const uint32_t rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
+        d += s * s * ((3u * rx) ^ ry);
+        if (ry == 0) { // rotate the quadrant
+            if (rx == 1) { x = s - 1 - x; y = s - 1 - y; }
+            const uint32_t t = x; x = y; y = t;
+        }
+    }
+    return d;
 }
 
 extern "C" int elm_scan_upload(elm_ctx* ctx, const float* xyz, size_t n, size_t n_total, elm_scan** out) {
     if (!ctx || !out || (!xyz && n) || n > 0x7FFFFFFFull || n_total > 0x7FFFFFFFull || n_total < n) return ELM_ERR_INVALID;
     *out = nullptr;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    // Z-order over 2 m sensor-frame cells: consecutive points (hence consecutive workgroups and, through the
-    // XCD-aware block mapping, every XCD's L2) touch the same few map voxels.  Stable in the input index.
+    // Order the points along a Hilbert curve over 2 m x 2 m sensor-frame cells (all heights of a cell together):
+    // consecutive points -- hence every 256-point workgroup and, through the XCD-aware block mapping, every XCD's
+    // L2 -- touch a few adjacent map voxels, and the curve has no long jumps.  Stable in the input index.
     const double cs = 2.0;
     std::vector<uint64_t> keyidx(n);
     for (size_t i = 0; i < n; ++i) {
-        const int cx = (int)floor((double)xyz[3 * i] / cs) + 512, cy = (int)floor((double)xyz[3 * i + 1] / cs) + 512,
-                  cz = (int)floor((double)xyz[3 * i + 2] / cs) + 512;
-        const uint32_t ux = (uint32_t)std::min(std::max(cx, 0), 1023), uy = (uint32_t)std::min(std::max(cy, 0), 1023),
-                       uz = (uint32_t)std::min(std::max(cz, 0), 1023);
-        const uint32_t mort = spread10(ux) | (spread10(uy) << 1) | (spread10(uz) << 2);
-        keyidx[i] = ((uint64_t)mort << 32) | (uint64_t)i;
+        const int cx = (int)floor((double)xyz[3 * i] / cs) + 512, cy = (int)floor((double)xyz[3 * i + 1] / cs) + 512;
+        const uint32_t ux = (uint32_t)std::min(std::max(cx, 0), 1023), uy = (uint32_t)std::min(std::max(cy, 0), 1023);
+        keyidx[i] = ((uint64_t)hilbert_xy2d(10, ux, uy) << 32) | (uint64_t)i;
     }
     std::sort(keyidx.begin(), keyidx.end());
     int rc = pinned_reserve(ctx, &ctx->h_stage, &ctx->h_stage_cap, std::max<size_t>(n * sizeof(float4), 4096));
@@ -762,7 +771,7 @@ extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_
     if (!map_empty) {
         for (int it = 0; it < cfg->max_iteration; ++it) {
             if ((rc = prof_mark(ctx)) != ELM_OK) return rc;
-            if (blocks) launch_accumulate(ctx->stream, map->dm, dsc, batch, (int)blocks, st, (double*)ctx->d_partials.p, rp);
+            if (blocks) launch_accumulate(ctx->stream, map->dm, dsc, batch, (int)blocks, st, (double*)ctx->d_partials.p, rp, (ctx->direct_kernel || map->info.max_points_per_voxel > 255) ? 1 : 0);
             if ((rc = prof_mark(ctx)) != ELM_OK) return rc;
             if (distributed) {
                 launch_solve(ctx->stream, dsc, batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 1);
@@ -815,6 +824,8 @@ extern "C" int elm_register_batch_finish(elm_ctx* ctx, elm_reg_result* results, 
         r.point_iterations = hs[b].pt_iters;
         r.n_cand_total = hs[b].cand_total;
         r.n_occ_total = hs[b].occ_total;
+        r.fallback_blocks = hs[b].fallback_blocks;
+        r.n_tested_total = hs[b].tested_total;
         if (ctx->rp.max_iter <= 0 && hs[b].gate == 0) { // no iteration ran: fitness gate on the initial 0.0 passes
             r.is_success = 1;
         }

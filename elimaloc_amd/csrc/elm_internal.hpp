@@ -20,7 +20,7 @@ struct __attribute__((aligned(32))) HashSlot {
 
 struct DevMap {
     const HashSlot* slots;
-    uint32_t mask; // capacity - 1 (capacity is a power of two >= 2 * n_voxels)
+    uint32_t mask; // capacity - 1 (capacity is a power of two >= 4 * n_voxels)
     uint32_t n_vox;
     uint32_t n_pts;
     uint32_t _pad;
@@ -60,7 +60,7 @@ struct ScanState {
     double fitness;  // d_fitness_score_
     double local_cov[36]; // column-major == row-major (symmetric)
     double n_corr_last;
-    double pt_iters, cand_total, occ_total; // work counters over the executed iterations
+    double pt_iters, cand_total, occ_total, fallback_blocks, tested_total; // work counters over the executed iterations
     int32_t done;
     int32_t success;
     int32_t gate;
@@ -82,9 +82,10 @@ constexpr int kBlock = 256;
 constexpr int kSums = ELM_PACKED_SUMS; // 21 + 6 + 1 + 1 (+ n_cand, n_occ, pad)
 
 // ---- launchers (elm_kernels.hip) ----------------------------------------------------------------------
+int debug_phase_cycles(unsigned long long* out16, int reset); // 1 when built with -DELM_PHASE_TIMING
 void launch_init_state(hipStream_t s, ScanState* st, const double* T0, int batch, int map_empty);
 void launch_accumulate(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
-                       ScanState* st, double* partials, const RegParams& rp);
+                       ScanState* st, double* partials, const RegParams& rp, int direct);
 // mode 0: reduce + solve (single GPU); 1: reduce only -> sums; 2: solve only from sums
 void launch_solve(hipStream_t s, const ScanDesc* scans, int batch, ScanState* st, const double* partials,
                   double* sums, const RegParams& rp, elm_iter_trace* trace, int mode);

@@ -21,6 +21,22 @@
 
 namespace elm {
 
+// Optional per-phase cycle accounting of the staged accumulate kernel (build with -DELM_PHASE_TIMING; thread 0 of
+// every workgroup adds its clock64() deltas).  Diagnostic builds only.
+#ifdef ELM_PHASE_TIMING
+__device__ unsigned long long g_phase[16];
+#define ELM_PHASE_BEGIN unsigned long long ph_t0_ = clock64();
+#define ELM_PHASE(k)                                                              \
+    if (threadIdx.x == 0) {                                                       \
+        const unsigned long long ph_t1_ = clock64();                              \
+        atomicAdd(&g_phase[k], ph_t1_ - ph_t0_);                                  \
+        ph_t0_ = ph_t1_;                                                          \
+    }
+#else
+#define ELM_PHASE_BEGIN
+#define ELM_PHASE(k)
+#endif
+
 // ------------------------------------------------------------------------------------------------------
 // helpers
 // ------------------------------------------------------------------------------------------------------
@@ -153,29 +169,156 @@ __device__ __forceinline__ void add_pair(double* acc, const double* Rinv, const 
 // ------------------------------------------------------------------------------------------------------
 // K1
 // ------------------------------------------------------------------------------------------------------
+// Nearest bucket point straight from global memory (one thread walks its 27 voxels).  Used by the "direct" kernel
+// and as the fall-back of the staged kernel for workgroups whose points are too spread out to stage.
+// GetCorrespondencePoints (vhm.cpp:31-88): strict-< minimum over every bucket point of the 27 voxels, voxels
+// visited x-major .. z-minor (vhm.cpp:234-240), bucket in insertion order.
+__device__ __forceinline__ void nearest_point_direct(const DevMap& m, int vx, int vy, int vz, double gx, double gy,
+                                                     double gz, double& bd2, float& bx, float& by, float& bz,
+                                                     int& bidx, double& n_cand, double& n_occ) {
+    for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dz = -1; dz <= 1; ++dz) {
+                const Probe pr = probe_voxel(m, vx + dx, vy + dy, vz + dz);
+                if (pr.vid < 0) continue;
+                n_occ += 1.0;
+                n_cand += (double)pr.cnt;
+                for (unsigned j = 0; j < pr.cnt; ++j) {
+                    const float4 q = m.pts[pr.start + j];
+                    const double ex = (double)q.x - gx, ey = (double)q.y - gy, ez = (double)q.z - gz;
+                    const double d2 = (ex * ex + ey * ey) + ez * ez;
+                    if (d2 < bd2) {
+                        bd2 = d2;
+                        bx = q.x; by = q.y; bz = q.z;
+                        bidx = (int)(pr.start + j);
+                    }
+                }
+            }
+}
+// GetCorrespondencesCov (vhm.cpp:90-151): nearest voxel MEAN among the existing neighbours, from global memory
+__device__ __forceinline__ void nearest_voxel_direct(const DevMap& m, int vx, int vy, int vz, double gx, double gy,
+                                                     double gz, double& bd2, int& bvid, double& bmx, double& bmy,
+                                                     double& bmz, double& n_cand, double& n_occ) {
+    for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dz = -1; dz <= 1; ++dz) {
+                const Probe pr = probe_voxel(m, vx + dx, vy + dy, vz + dz);
+                if (pr.vid < 0 || pr.cnt == 0) continue;
+                n_occ += 1.0;
+                n_cand += 1.0;
+                const double cx = m.vox_mean[(size_t)pr.vid * 3], cy = m.vox_mean[(size_t)pr.vid * 3 + 1], cz = m.vox_mean[(size_t)pr.vid * 3 + 2];
+                const double ex = cx - gx, ey = cy - gy, ez = cz - gz;
+                const double d2 = (ex * ex + ey * ey) + ez * ez;
+                if (d2 < bd2) { bd2 = d2; bvid = pr.vid; bmx = cx; bmy = cy; bmz = cz; }
+            }
+}
+
+// pair payloads shared by both kernels
 template <int METHOD>
-__global__ __launch_bounds__(kBlock) void k_accumulate(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
-                                                       unsigned total_blocks, const ScanState* __restrict__ st,
-                                                       double* __restrict__ partials, const RegParams rp) {
-    const unsigned L = xcd_remap(blockIdx.x, total_blocks);
-    // scan of this logical block (binary search over blk_begin)
+__device__ __forceinline__ void finish_point_pair(double* acc, const DevMap& m, const ScanState& S, const RegParams& rp,
+                                                  double px, double py, double pz, double gx, double gy, double gz,
+                                                  double bd2, float bx, float by, float bz, int bidx) {
+    // no bucket at all: the reference's default PointStruct at the origin with cov I (vhm.cpp:37, QUIRK)
+    const double dfin = (bidx >= 0) ? bd2 : (gx * gx + gy * gy) + gz * gz;
+    if (!(dfin < rp.th2)) return;
+    if (METHOD == ELM_P2P) {
+        if (bidx < 0) { bx = 0.f; by = 0.f; bz = 0.f; }
+        add_pair<ELM_P2P>(acc, S.Rinv, S.tinv, px, py, pz, (double)bx, (double)by, (double)bz, nullptr, nullptr, rp);
+    } else {
+        double C[9], mean[3], nf[3];
+        if (bidx >= 0) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) C[k] = m.pt_cov[(size_t)bidx * 9 + k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { mean[k] = m.pt_mean[(size_t)bidx * 3 + k]; nf[k] = m.pt_nfit[(size_t)bidx * 3 + k]; }
+        } else {
+            C[0] = 1; C[1] = 0; C[2] = 0; C[3] = 0; C[4] = 1; C[5] = 0; C[6] = 0; C[7] = 0; C[8] = 1;
+            mean[0] = mean[1] = mean[2] = 0.0;
+            nf[0] = 1.0; nf[1] = 0.0; nf[2] = 0.0;
+        }
+        // GICP's target position is the neighbourhood MEAN of the matched point (reg.cpp:97)
+        add_pair<ELM_GICP>(acc, S.Rinv, S.tinv, px, py, pz, mean[0], mean[1], mean[2], C, nf, rp);
+    }
+}
+__device__ __forceinline__ void finish_voxel_pair(double* acc, const DevMap& m, const ScanState& S, const RegParams& rp,
+                                                  double px, double py, double pz, double gx, double gy, double gz,
+                                                  double bd2, int bvid, double bmx, double bmy, double bmz) {
+    const double dfin = (bvid >= 0) ? bd2 : (gx * gx + gy * gy) + gz * gz;
+    if (!(dfin < rp.th2)) return;
+    double C[9];
+    if (bvid >= 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) C[k] = m.vox_cov[(size_t)bvid * 9 + k];
+    } else {
+        C[0] = 1; C[1] = 0; C[2] = 0; C[3] = 0; C[4] = 1; C[5] = 0; C[6] = 0; C[7] = 0; C[8] = 1;
+        bmx = bmy = bmz = 0.0;
+    }
+    add_pair<ELM_VGICP>(acc, S.Rinv, S.tinv, px, py, pz, bmx, bmy, bmz, C, nullptr, rp);
+}
+
+// block -> (scan, first point) ; returns false when the scan is finished
+__device__ __forceinline__ int find_scan(const ScanDesc* __restrict__ scans, int batch, unsigned L) {
     int lo = 0, hi = batch - 1;
     while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
+        const int mid = (lo + hi + 1) >> 1;
         if (scans[mid].blk_begin <= L) lo = mid; else hi = mid - 1;
     }
-    const int s = lo;
+    return lo;
+}
+
+// wave reduction (64 lanes) of the 31 packed sums, then the four waves of the block through LDS
+__device__ __forceinline__ void block_reduce_store(double* acc, double (*red)[32], double* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const double v = wave_sum(acc[k]);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32)
+        out[threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// Block reduction of the 32 packed sums through an LDS transpose (two halves of 16 values, 32 KB each): every
+// thread stores its values column-wise, then 16 lanes per value add 16 strided columns each and finish with four
+// shuffle steps.  ~40 LDS/shuffle operations per thread instead of 192 dependent shuffles.  Deterministic.
+// buf must hold 16 * kBlock doubles and must not be in use by anybody (callers sync before).
+__device__ __forceinline__ void block_reduce_store_lds(const double* acc, double* buf, double* __restrict__ out) {
+    const int tid = threadIdx.x;
+    const int k = tid >> 4, seg = tid & 15;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h) __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) buf[q * kBlock + tid] = acc[h * 16 + q];
+        __syncthreads();
+        double v = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v += buf[k * kBlock + i * 16 + seg];
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 1, 64);
+        if (seg == 0) out[h * 16 + k] = v;
+    }
+}
+
+// ---- K1a: direct kernel (first correct version; kept for A/B measurements, ELM_KERNEL=direct) --------------
+template <int METHOD>
+__global__ __launch_bounds__(kBlock) void k_accumulate_direct(const DevMap m, const ScanDesc* __restrict__ scans,
+                                                              int batch, unsigned total_blocks,
+                                                              const ScanState* __restrict__ st,
+                                                              double* __restrict__ partials, const RegParams rp) {
+    const unsigned L = xcd_remap(blockIdx.x, total_blocks);
+    const int s = find_scan(scans, batch, L);
     const ScanState& S = st[s];
     if (S.done) return; // uniform: the whole block leaves; k_solve skips this scan too
-
     const ScanDesc sd = scans[s];
     const unsigned i = (L - sd.blk_begin) * kBlock + threadIdx.x;
     const bool valid = i < sd.n;
-
-    double acc[31];
+    double acc[32];
 #pragma unroll
-    for (int k = 0; k < 31; ++k) acc[k] = 0.0;
-
+    for (int k = 0; k < 32; ++k) acc[k] = 0.0;
     if (valid) {
         const float4 pf = sd.pts[i];
         const double px = pf.x, py = pf.y, pz = pf.z;
@@ -185,80 +328,17 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(const DevMap m, const Sca
         const double gz = ((S.T[2] * px + S.T[6] * py) + S.T[10] * pz) + S.T[14];
         const int vx = floor_key(gx, m.voxel_size), vy = floor_key(gy, m.voxel_size), vz = floor_key(gz, m.voxel_size);
         double n_cand = 0.0, n_occ = 0.0;
-
         if (METHOD == ELM_P2P || METHOD == ELM_GICP) {
-            // GetCorrespondencePoints (vhm.cpp:31-88): strict-< minimum over every bucket point of the 27 voxels,
-            // voxels visited x-major .. z-minor (vhm.cpp:234-240), bucket in insertion order
             double bd2 = DBL_MAX;
             float bx = 0.f, by = 0.f, bz = 0.f;
             int bidx = -1;
-            for (int dx = -1; dx <= 1; ++dx)
-                for (int dy = -1; dy <= 1; ++dy)
-                    for (int dz = -1; dz <= 1; ++dz) {
-                        const Probe pr = probe_voxel(m, vx + dx, vy + dy, vz + dz);
-                        if (pr.vid < 0) continue;
-                        n_occ += 1.0;
-                        n_cand += (double)pr.cnt;
-                        for (unsigned j = 0; j < pr.cnt; ++j) {
-                            const float4 q = m.pts[pr.start + j];
-                            const double ex = (double)q.x - gx, ey = (double)q.y - gy, ez = (double)q.z - gz;
-                            const double d2 = (ex * ex + ey * ey) + ez * ez;
-                            if (d2 < bd2) {
-                                bd2 = d2;
-                                bx = q.x; by = q.y; bz = q.z;
-                                bidx = (int)(pr.start + j);
-                            }
-                        }
-                    }
-            // no bucket at all: the reference's default PointStruct at the origin with cov I (vhm.cpp:37, QUIRK)
-            const double dfin = (bidx >= 0) ? bd2 : (gx * gx + gy * gy) + gz * gz;
-            if (dfin < rp.th2) {
-                if (METHOD == ELM_P2P) {
-                    add_pair<ELM_P2P>(acc, S.Rinv, S.tinv, px, py, pz, (double)bx, (double)by, (double)bz, nullptr, nullptr, rp);
-                } else {
-                    double C[9], mean[3], nf[3];
-                    if (bidx >= 0) {
-#pragma unroll
-                        for (int k = 0; k < 9; ++k) C[k] = m.pt_cov[(size_t)bidx * 9 + k];
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) { mean[k] = m.pt_mean[(size_t)bidx * 3 + k]; nf[k] = m.pt_nfit[(size_t)bidx * 3 + k]; }
-                    } else {
-                        C[0] = 1; C[1] = 0; C[2] = 0; C[3] = 0; C[4] = 1; C[5] = 0; C[6] = 0; C[7] = 0; C[8] = 1;
-                        mean[0] = mean[1] = mean[2] = 0.0;
-                        nf[0] = 1.0; nf[1] = 0.0; nf[2] = 0.0;
-                    }
-                    // GICP's target position is the neighbourhood MEAN of the matched point (reg.cpp:97)
-                    add_pair<ELM_GICP>(acc, S.Rinv, S.tinv, px, py, pz, mean[0], mean[1], mean[2], C, nf, rp);
-                }
-            }
+            nearest_point_direct(m, vx, vy, vz, gx, gy, gz, bd2, bx, by, bz, bidx, n_cand, n_occ);
+            finish_point_pair<METHOD>(acc, m, S, rp, px, py, pz, gx, gy, gz, bd2, bx, by, bz, bidx);
         } else if (METHOD == ELM_VGICP) {
-            // GetCorrespondencesCov (vhm.cpp:90-151): nearest voxel MEAN among the existing neighbours
-            double bd2 = DBL_MAX;
+            double bd2 = DBL_MAX, bmx = 0.0, bmy = 0.0, bmz = 0.0;
             int bvid = -1;
-            double bmx = 0.0, bmy = 0.0, bmz = 0.0;
-            for (int dx = -1; dx <= 1; ++dx)
-                for (int dy = -1; dy <= 1; ++dy)
-                    for (int dz = -1; dz <= 1; ++dz) {
-                        const Probe pr = probe_voxel(m, vx + dx, vy + dy, vz + dz);
-                        if (pr.vid < 0 || pr.cnt == 0) continue;
-                        n_occ += 1.0;
-                        n_cand += 1.0;
-                        const double cx = m.vox_mean[(size_t)pr.vid * 3], cy = m.vox_mean[(size_t)pr.vid * 3 + 1], cz = m.vox_mean[(size_t)pr.vid * 3 + 2];
-                        const double ex = cx - gx, ey = cy - gy, ez = cz - gz;
-                        const double d2 = (ex * ex + ey * ey) + ez * ez;
-                        if (d2 < bd2) { bd2 = d2; bvid = pr.vid; bmx = cx; bmy = cy; bmz = cz; }
-                    }
-            const double dfin = (bvid >= 0) ? bd2 : (gx * gx + gy * gy) + gz * gz;
-            if (dfin < rp.th2) {
-                double C[9];
-                if (bvid >= 0) {
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) C[k] = m.vox_cov[(size_t)bvid * 9 + k];
-                } else {
-                    C[0] = 1; C[1] = 0; C[2] = 0; C[3] = 0; C[4] = 1; C[5] = 0; C[6] = 0; C[7] = 0; C[8] = 1;
-                }
-                add_pair<ELM_VGICP>(acc, S.Rinv, S.tinv, px, py, pz, bmx, bmy, bmz, C, nullptr, rp);
-            }
+            nearest_voxel_direct(m, vx, vy, vz, gx, gy, gz, bd2, bvid, bmx, bmy, bmz, n_cand, n_occ);
+            finish_voxel_pair(acc, m, S, rp, px, py, pz, gx, gy, gz, bd2, bvid, bmx, bmy, bmz);
         } else {
             // GetCorrespondencesAllCov (vhm.cpp:153-206): every existing face-neighbour voxel within range is a pair,
             // order (0, +x, -x, +y, -y, +z, -z) (vhm.cpp:224-230)
@@ -282,22 +362,466 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(const DevMap m, const Sca
         }
         acc[29] = n_cand;
         acc[30] = n_occ;
+        acc[31] = n_cand; // every candidate is distance-tested on this path
     }
-
-    // wave reduction (64 lanes), then the four waves of the block through LDS
     __shared__ double red[kBlock / 64][32];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    block_reduce_store(acc, red, partials + (size_t)L * kSums);
+}
+
+// ---- K1b: staged kernel -----------------------------------------------------------------------------------
+// A workgroup owns 256 consecutive scan points; scans are stored along a Hilbert curve over 2 m sensor-frame cells,
+// so those points occupy a few adjacent map voxels.  The workgroup
+//   1. transforms its points and reduces the bounding box of their voxel keys (+1 voxel halo),
+//   2. probes every cell of the box ONCE (4 cells per thread; ~10x fewer hash probes than 27 per point),
+//   3. prefix-sums the bucket sizes and copies the buckets into LDS with coalesced 16-byte loads, in cell order
+//      (x-major .. z-minor) and insertion order inside a bucket, i.e. exactly the reference's visiting order,
+//   4. lets every thread scan its 3x3 columns as 9 contiguous LDS ranges (the three z-neighbours of a column are
+//      adjacent in the staged order), all lanes of a voxel reading the same LDS address (broadcast),
+//   5. reduces the packed normal equations.
+// Workgroups whose box is too large (> kMaxCell cells or > kMaxStage points) take the direct path instead; the
+// result is identical either way (same candidates, same order, same fp64 arithmetic).
+constexpr int kMaxCell = 2048;  // box cells (incl. halo) a workgroup may cover
+constexpr int kCellsPerThread = kMaxCell / kBlock;
+constexpr int kMaxStage = 2944; // bucket points a workgroup may stage (34.5 KB as SoA floats; 3 workgroups per CU fit in 160 KB)
+constexpr int kMaxList = 768;   // non-empty cells a workgroup may stage
+constexpr double kFallbackUnit = 1099511627776.0; // 2^40: slot 31 carries tested candidates + 2^40 * fall-back workgroups
+// bucket sizes are packed into 8 bits of the LDS cell table: maps with max_points_per_voxel > 255 use the direct kernel
+
+// marks the 3x3x3 (or the 7 face-neighbour) cells of this thread's voxel in the workgroup's box
+template <bool kSeven>
+__device__ __forceinline__ void mark_needed(unsigned char* s_need, int bx, int by, int bz, int ny, int nz) {
+    if (kSeven) {
+        const int c = (bx * ny + by) * nz + bz;
+        s_need[c] = 1; s_need[c + 1] = 1; s_need[c - 1] = 1;
+        s_need[c + nz] = 1; s_need[c - nz] = 1;
+        s_need[c + ny * nz] = 1; s_need[c - ny * nz] = 1;
+    } else {
 #pragma unroll
-    for (int k = 0; k < 31; ++k) {
-        const double v = wave_sum(acc[k]);
-        if (lane == 0) red[wave][k] = v;
+        for (int dx = -1; dx <= 1; ++dx)
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int c0 = ((bx + dx) * ny + (by + dy)) * nz + (bz - 1);
+                s_need[c0] = 1; s_need[c0 + 1] = 1; s_need[c0 + 2] = 1;
+            }
+    }
+}
+
+// first-slot loads of up to kCellsPerThread probes are issued back to back, then resolved (collisions walk on)
+struct SlotLoad {
+    int4 key;
+    uint2 rg;
+    unsigned h;
+};
+__device__ __forceinline__ SlotLoad slot_load(const DevMap& m, unsigned h) {
+    SlotLoad r;
+    r.h = h;
+    r.key = *reinterpret_cast<const int4*>(&m.slots[h]);
+    r.rg = *reinterpret_cast<const uint2*>(&m.slots[h].start);
+    return r;
+}
+__device__ __forceinline__ Probe slot_resolve(const DevMap& m, SlotLoad sl, int kx, int ky, int kz) {
+    Probe p;
+    p.vid = -1; p.start = 0; p.cnt = 0;
+    for (;;) {
+        if (sl.key.w < 0) break;
+        if (sl.key.x == kx && sl.key.y == ky && sl.key.z == kz) {
+            p.vid = sl.key.w; p.start = sl.rg.x; p.cnt = sl.rg.y;
+            break;
+        }
+        sl = slot_load(m, (sl.h + 1) & m.mask);
+    }
+    return p;
+}
+
+template <int METHOD>
+__global__ __launch_bounds__(kBlock, 3) void k_accumulate(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
+                                                          unsigned total_blocks, const ScanState* __restrict__ st,
+                                                          double* __restrict__ partials, const RegParams rp) {
+    constexpr bool kPoints = (METHOD == ELM_P2P || METHOD == ELM_GICP);
+    // LDS (<= 53 KB -> 3 workgroups per CU): bucket points as SoA floats (36 KB) or voxel means; cell tables; scratch
+    __shared__ __attribute__((aligned(16))) float s_xyz[kPoints ? 3 * kMaxStage : 4];
+    __shared__ unsigned s_cell[kPoints ? kMaxCell : 1];   // (LDS offset << 8) | count; offsets are the running prefix
+    __shared__ uint2 s_list[kPoints ? kMaxList : 1];      // compacted non-empty cells: (cell, global start of its bucket), sorted by cell
+    __shared__ double s_mean[kPoints ? 1 : kMaxList][3];  // means of the non-empty needed cells (compact slots)
+    __shared__ int s_mvid[kPoints ? 1 : kMaxList];        // their voxel ids
+    __shared__ short s_slot[kPoints ? 1 : kMaxCell];      // cell -> slot, -1 = no voxel
+    __shared__ int s_nslot;
+    __shared__ unsigned char s_need[kMaxCell];
+    __shared__ double red[kBlock / 64][32];
+    __shared__ int s_bb[6];
+    __shared__ unsigned long long s_wsum[kBlock / 64];
+    float* const s_x = s_xyz;
+    float* const s_y = s_xyz + (kPoints ? kMaxStage : 0);
+    float* const s_z = s_xyz + (kPoints ? 2 * kMaxStage : 0);
+    uint2* const s_tmp = reinterpret_cast<uint2*>(s_xyz); // (global start, count) per cell while probing (16 KB, aliases s_x/s_y)
+
+    const unsigned L = xcd_remap(blockIdx.x, total_blocks);
+    const int s = find_scan(scans, batch, L);
+    const ScanState& S = st[s];
+    if (S.done) return;
+    const ScanDesc sd = scans[s];
+    const unsigned tid = threadIdx.x;
+    const unsigned i = (L - sd.blk_begin) * kBlock + tid;
+    const bool valid = i < sd.n;
+    const int lane = tid & 63, wave = tid >> 6;
+    ELM_PHASE_BEGIN
+
+    double acc[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc[k] = 0.0;
+
+    double px = 0, py = 0, pz = 0, gx = 0, gy = 0, gz = 0;
+    int vx = 0, vy = 0, vz = 0;
+    if (valid) {
+        const float4 pf = sd.pts[i];
+        px = pf.x; py = pf.y; pz = pf.z;
+        gx = ((S.T[0] * px + S.T[4] * py) + S.T[8] * pz) + S.T[12];
+        gy = ((S.T[1] * px + S.T[5] * py) + S.T[9] * pz) + S.T[13];
+        gz = ((S.T[2] * px + S.T[6] * py) + S.T[10] * pz) + S.T[14];
+        vx = floor_key(gx, m.voxel_size); vy = floor_key(gy, m.voxel_size); vz = floor_key(gz, m.voxel_size);
+    }
+    // ---- 1. bounding box of the voxel keys; clear the need map
+    if (tid < 3) s_bb[tid] = INT_MAX;
+    else if (tid < 6) s_bb[tid] = INT_MIN;
+    for (int k = tid; k < kMaxCell / 4; k += kBlock) reinterpret_cast<unsigned*>(s_need)[k] = 0u;
+    __syncthreads();
+    {
+        int mnx = valid ? vx : INT_MAX, mny = valid ? vy : INT_MAX, mnz = valid ? vz : INT_MAX;
+        int mxx = valid ? vx : INT_MIN, mxy = valid ? vy : INT_MIN, mxz = valid ? vz : INT_MIN;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            mnx = min(mnx, __shfl_xor(mnx, off, 64)); mny = min(mny, __shfl_xor(mny, off, 64)); mnz = min(mnz, __shfl_xor(mnz, off, 64));
+            mxx = max(mxx, __shfl_xor(mxx, off, 64)); mxy = max(mxy, __shfl_xor(mxy, off, 64)); mxz = max(mxz, __shfl_xor(mxz, off, 64));
+        }
+        if (lane == 0) {
+            atomicMin(&s_bb[0], mnx); atomicMin(&s_bb[1], mny); atomicMin(&s_bb[2], mnz);
+            atomicMax(&s_bb[3], mxx); atomicMax(&s_bb[4], mxy); atomicMax(&s_bb[5], mxz);
+        }
     }
     __syncthreads();
-    if (threadIdx.x < 32) {
-        double v = 0.0;
-        if (threadIdx.x < 31) v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-        partials[(size_t)L * kSums + threadIdx.x] = v;
+    const int lox = s_bb[0] - 1, loy = s_bb[1] - 1, loz = s_bb[2] - 1;
+    const long long ex_ = (long long)s_bb[3] - s_bb[0] + 3, ey_ = (long long)s_bb[4] - s_bb[1] + 3, ez_ = (long long)s_bb[5] - s_bb[2] + 3;
+    bool staged = (ex_ <= kMaxCell && ey_ <= kMaxCell && ez_ <= kMaxCell && ex_ * ey_ * ez_ <= kMaxCell);
+    const int ny = (int)ey_, nz = (int)ez_;
+    const int ncell = staged ? (int)(ex_ * ey_ * ez_) : 0;
+    double n_cand = 0.0, n_occ = 0.0, n_tested = 0.0;
+    // cell index -> (cx, cy, cz) without integer division: floor(c / d) == (c * M) >> 22 for c < 2048, d <= 2048
+    const unsigned mg_nz = (1u << 22) / (unsigned)max(nz, 1) + 1u, mg_ny = (1u << 22) / (unsigned)max(ny, 1) + 1u;
+    // ---- 2a. mark the cells some point of the workgroup will visit
+    if (staged) {
+        if (valid) mark_needed<METHOD == ELM_AVGICP>(s_need, vx - lox, vy - loy, vz - loz, ny, nz);
+        __syncthreads();
     }
+    ELM_PHASE(0)
+
+    if (kPoints) {
+        double bd2 = DBL_MAX;
+        float bx = 0.f, by = 0.f, bz = 0.f;
+        int bidx = -1;
+        if (staged) {
+            // ---- 2b. probe the needed cells: thread t takes cells t, t+256, ... (needed cells are clustered, the
+            //          stride spreads them over the threads); all first-slot loads are in flight together
+            {
+                SlotLoad sl[kCellsPerThread];
+                int kx[kCellsPerThread], ky[kCellsPerThread], kz[kCellsPerThread];
+                bool need[kCellsPerThread];
+#pragma unroll
+                for (int k = 0; k < kCellsPerThread; ++k) {
+                    const int c = (int)tid + k * kBlock;
+                    need[k] = (c < ncell) && s_need[c];
+                    const int cxy = (int)(((unsigned)c * mg_nz) >> 22), cz = c - cxy * nz;
+                    const int cx = (int)(((unsigned)cxy * mg_ny) >> 22), cy = cxy - cx * ny;
+                    kx[k] = lox + cx; ky[k] = loy + cy; kz[k] = loz + cz;
+                    if (need[k]) sl[k] = slot_load(m, hash3(kx[k], ky[k], kz[k]) & m.mask);
+                }
+#pragma unroll
+                for (int k = 0; k < kCellsPerThread; ++k) {
+                    const int c = (int)tid + k * kBlock;
+                    uint2 r = make_uint2(0u, 0u);
+                    if (need[k]) {
+                        const Probe pr = slot_resolve(m, sl[k], kx[k], ky[k], kz[k]);
+                        if (pr.vid >= 0) r = make_uint2(pr.start, pr.cnt);
+                    }
+                    if (c < ncell) s_tmp[c] = r;
+                }
+            }
+            __syncthreads();
+            ELM_PHASE(1)
+            // ---- 3a. block-wide exclusive prefix of (points, non-empty cells) in cell order
+            unsigned cstart[kCellsPerThread], ccnt[kCellsPerThread];
+            unsigned lsum = 0, lne = 0;
+#pragma unroll
+            for (int k = 0; k < kCellsPerThread; ++k) {
+                const int c = (int)tid * kCellsPerThread + k;
+                uint2 r = make_uint2(0u, 0u);
+                if (c < ncell) r = s_tmp[c];
+                cstart[k] = r.x; ccnt[k] = r.y;
+                lsum += r.y;
+                lne += (r.y > 0) ? 1u : 0u;
+            }
+            unsigned long long v = ((unsigned long long)lne << 32) | lsum, inc = v;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned long long t = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += t;
+            }
+            if (lane == 63) s_wsum[wave] = inc;
+            __syncthreads(); // also: every s_tmp read is done before s_x/s_y are overwritten below
+            unsigned long long wbase = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; ++w) {
+                const unsigned long long t = s_wsum[w];
+                if (w < wave) wbase += t;
+                total += t;
+            }
+            const unsigned tot_pts = (unsigned)(total & 0xffffffffu), tot_ne = (unsigned)(total >> 32);
+            if (tot_pts > (unsigned)kMaxStage || tot_ne > (unsigned)kMaxList) staged = false; // uniform
+            if (staged) {
+                const unsigned long long excl = wbase + inc - v;
+                unsigned off = (unsigned)(excl & 0xffffffffu), lpos = (unsigned)(excl >> 32);
+#pragma unroll
+                for (int k = 0; k < kCellsPerThread; ++k) {
+                    const int c = (int)tid * kCellsPerThread + k;
+                    if (c < ncell) {
+                        s_cell[c] = (off << 8) | ccnt[k];
+                        if (ccnt[k] > 0) s_list[lpos++] = make_uint2((unsigned)c, cstart[k]);
+                        off += ccnt[k];
+                    }
+                }
+                __syncthreads();
+                ELM_PHASE(2)
+                // ---- 3b. copy the buckets: 16 lanes per non-empty cell (2 points per lane), 4 cells in flight per group
+                const unsigned grp = tid >> 4, l = tid & 15;
+                for (unsigned e0 = grp; e0 < tot_ne; e0 += 64) {
+                    float4 qa[4], qb[4];
+                    unsigned da[4];
+                    bool oka[4], okb[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const unsigned e = e0 + 16u * u;
+                        oka[u] = false; okb[u] = false; da[u] = 0;
+                        if (e < tot_ne) {
+                            const uint2 le = s_list[e];
+                            const unsigned ci = s_cell[le.x];
+                            const unsigned cnt = ci & 0xffu, o = ci >> 8;
+                            da[u] = o + l;
+                            if (l < cnt) { qa[u] = m.pts[le.y + l]; oka[u] = true; }
+                            if (l + 16 < cnt) { qb[u] = m.pts[le.y + l + 16]; okb[u] = true; }
+                            for (unsigned j = l + 32; j < cnt; j += 16) { // buckets larger than 32 points
+                                const float4 qq = m.pts[le.y + j];
+                                s_x[o + j] = qq.x; s_y[o + j] = qq.y; s_z[o + j] = qq.z;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (oka[u]) { s_x[da[u]] = qa[u].x; s_y[da[u]] = qa[u].y; s_z[da[u]] = qa[u].z; }
+                        if (okb[u]) { s_x[da[u] + 16] = qb[u].x; s_y[da[u] + 16] = qb[u].y; s_z[da[u] + 16] = qb[u].z; }
+                    }
+                }
+                __syncthreads();
+                ELM_PHASE(3)
+                // ---- 4. nearest bucket point of the thread's 27 cells, staged in the reference's visiting order.
+                //      The thread's own cell is scanned first; every other cell is skipped when even the closest
+                //      point its key range could hold is STRICTLY farther than the best so far (it can neither win
+                //      nor tie), and ties are resolved towards the smaller staged index, i.e. the candidate the
+                //      reference's x-major / insertion-order walk meets first.  Same winner as the full walk.
+                int bj = -1, bcell = 0;
+                if (valid) {
+                    const int cown = ((vx - lox) * ny + (vy - loy)) * nz + (vz - loz);
+                    auto scan_cell = [&](int c, unsigned info) {
+                        const int beg = (int)(info >> 8), end = beg + (int)(info & 0xffu);
+                        for (int j = beg; j < end; j += 4) {
+                            const int j1 = min(j + 1, end - 1), j2 = min(j + 2, end - 1), j3 = min(j + 3, end - 1);
+                            const float x0 = s_x[j], y0 = s_y[j], z0 = s_z[j];
+                            const float x1 = s_x[j1], y1 = s_y[j1], z1 = s_z[j1];
+                            const float x2 = s_x[j2], y2 = s_y[j2], z2 = s_z[j2];
+                            const float x3 = s_x[j3], y3 = s_y[j3], z3 = s_z[j3];
+                            const double e0x = (double)x0 - gx, e0y = (double)y0 - gy, e0z = (double)z0 - gz;
+                            const double e1x = (double)x1 - gx, e1y = (double)y1 - gy, e1z = (double)z1 - gz;
+                            const double e2x = (double)x2 - gx, e2y = (double)y2 - gy, e2z = (double)z2 - gz;
+                            const double e3x = (double)x3 - gx, e3y = (double)y3 - gy, e3z = (double)z3 - gz;
+                            const double d0 = (e0x * e0x + e0y * e0y) + e0z * e0z;
+                            const double d1 = (e1x * e1x + e1y * e1y) + e1z * e1z;
+                            const double d2 = (e2x * e2x + e2y * e2y) + e2z * e2z;
+                            const double d3 = (e3x * e3x + e3y * e3y) + e3z * e3z;
+                            if (d0 < bd2 || (d0 == bd2 && j < bj)) { bd2 = d0; bj = j; bcell = c; }
+                            if (d1 < bd2 || (d1 == bd2 && j1 < bj)) { bd2 = d1; bj = j1; bcell = c; }
+                            if (d2 < bd2 || (d2 == bd2 && j2 < bj)) { bd2 = d2; bj = j2; bcell = c; }
+                            if (d3 < bd2 || (d3 == bd2 && j3 < bj)) { bd2 = d3; bj = j3; bcell = c; }
+                        }
+                    };
+                    const unsigned iown = s_cell[cown];
+                    scan_cell(cown, iown);
+                    n_tested += (double)(iown & 0xffu);
+                    const double vs = m.voxel_size, slack = 1e-9 * vs;
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        // stored keys truncate toward zero (vhm.cpp:275): key k > 0 holds [k, k+1) vs, k < 0 holds (k-1, k] vs,
+                        // k == 0 holds (-1, 1) vs
+                        const int kx = vx + dx;
+                        const double lx = (double)(kx <= 0 ? kx - 1 : kx) * vs - slack, hx = (double)(kx >= 0 ? kx + 1 : kx) * vs + slack;
+                        const double ax = fmax(fmax(lx - gx, gx - hx), 0.0);
+                        for (int dy = -1; dy <= 1; ++dy) {
+                            const int ky = vy + dy;
+                            const double ly = (double)(ky <= 0 ? ky - 1 : ky) * vs - slack, hy = (double)(ky >= 0 ? ky + 1 : ky) * vs + slack;
+                            const double ay = fmax(fmax(ly - gy, gy - hy), 0.0);
+                            const double axy = ax * ax + ay * ay;
+                            const int c0 = ((kx - lox) * ny + (ky - loy)) * nz + (vz - 1 - loz);
+#pragma unroll
+                            for (int dz = 0; dz < 3; ++dz) {
+                                const int c = c0 + dz;
+                                const unsigned info = s_cell[c];
+                                const unsigned cnt = info & 0xffu;
+                                n_occ += (cnt > 0) ? 1.0 : 0.0;
+                                n_cand += (double)cnt;
+                                if (cnt == 0 || c == cown) continue;
+                                const int kz = vz - 1 + dz;
+                                const double lz = (double)(kz <= 0 ? kz - 1 : kz) * vs - slack, hz = (double)(kz >= 0 ? kz + 1 : kz) * vs + slack;
+                                const double az = fmax(fmax(lz - gz, gz - hz), 0.0);
+                                const double lb = (axy + az * az) * (1.0 - 1e-12);
+                                if (lb > bd2) continue; // every point of the cell is strictly farther than the current best
+                                n_tested += (double)cnt;
+                                scan_cell(c, info);
+                            }
+                        }
+                    }
+                    if (bj >= 0) {
+                        bx = s_x[bj]; by = s_y[bj]; bz = s_z[bj];
+                        bidx = 0;
+                        if (METHOD == ELM_GICP) { // global index of the winner (s_list is sorted by cell)
+                            int lo_ = 0, hi_ = (int)tot_ne - 1;
+                            while (lo_ < hi_) {
+                                const int mid = (lo_ + hi_) >> 1;
+                                if ((int)s_list[mid].x < bcell) lo_ = mid + 1; else hi_ = mid;
+                            }
+                            bidx = (int)(s_list[lo_].y + ((unsigned)bj - (s_cell[bcell] >> 8)));
+                        }
+                    }
+                }
+                ELM_PHASE(4)
+            }
+        }
+        if (!staged) {
+            if (valid) { nearest_point_direct(m, vx, vy, vz, gx, gy, gz, bd2, bx, by, bz, bidx, n_cand, n_occ); n_tested = n_cand; }
+            if (tid == 0) acc[31] = kFallbackUnit; // fall-back workgroups are counted (high part of slot 31)
+            ELM_PHASE(7)
+        }
+        if (valid) finish_point_pair<METHOD>(acc, m, S, rp, px, py, pz, gx, gy, gz, bd2, bx, by, bz, bidx);
+        ELM_PHASE(5)
+    } else {
+        // VGICP / AVGICP: stage the voxel MEANS of the needed cells (GetCorrespondencesCov / AllCov, vhm.cpp:90-206)
+        if (staged) {
+            if (tid == 0) s_nslot = 0;
+            __syncthreads();
+            {
+                SlotLoad sl[kCellsPerThread];
+                int kx[kCellsPerThread], ky[kCellsPerThread], kz[kCellsPerThread];
+                bool need[kCellsPerThread];
+#pragma unroll
+                for (int k = 0; k < kCellsPerThread; ++k) {
+                    const int c = (int)tid + k * kBlock;
+                    need[k] = (c < ncell) && s_need[c];
+                    const int cxy = (int)(((unsigned)c * mg_nz) >> 22), cz = c - cxy * nz;
+                    const int cx = (int)(((unsigned)cxy * mg_ny) >> 22), cy = cxy - cx * ny;
+                    kx[k] = lox + cx; ky[k] = loy + cy; kz[k] = loz + cz;
+                    if (need[k]) sl[k] = slot_load(m, hash3(kx[k], ky[k], kz[k]) & m.mask);
+                }
+#pragma unroll
+                for (int k = 0; k < kCellsPerThread; ++k) {
+                    const int c = (int)tid + k * kBlock;
+                    int slot = -1;
+                    if (need[k]) {
+                        const Probe pr = slot_resolve(m, sl[k], kx[k], ky[k], kz[k]);
+                        if (pr.vid >= 0 && pr.cnt > 0) {
+                            slot = atomicAdd(&s_nslot, 1);
+                            if (slot < kMaxList) {
+                                s_mean[slot][0] = m.vox_mean[(size_t)pr.vid * 3];
+                                s_mean[slot][1] = m.vox_mean[(size_t)pr.vid * 3 + 1];
+                                s_mean[slot][2] = m.vox_mean[(size_t)pr.vid * 3 + 2];
+                                s_mvid[slot] = pr.vid;
+                            }
+                        }
+                    }
+                    if (c < ncell) s_slot[c] = (short)slot;
+                }
+            }
+            __syncthreads();
+            if (s_nslot > kMaxList) staged = false; // uniform
+        }
+        if (!staged && tid == 0) acc[31] = kFallbackUnit;
+        ELM_PHASE(1)
+        if (valid) {
+            if (METHOD == ELM_VGICP) {
+                double bd2 = DBL_MAX, bmx = 0.0, bmy = 0.0, bmz = 0.0;
+                int bvid = -1;
+                if (staged) {
+                    for (int dx = -1; dx <= 1; ++dx)
+                        for (int dy = -1; dy <= 1; ++dy) {
+                            const int c0 = ((vx + dx - lox) * ny + (vy + dy - loy)) * nz + (vz - 1 - loz);
+#pragma unroll
+                            for (int dz = 0; dz < 3; ++dz) {
+                                const int sl = s_slot[c0 + dz];
+                                if (sl < 0) continue;
+                                const int vid = s_mvid[sl];
+                                n_occ += 1.0;
+                                n_cand += 1.0;
+                                const double cx = s_mean[sl][0], cy = s_mean[sl][1], cz = s_mean[sl][2];
+                                const double ex = cx - gx, ey = cy - gy, ez = cz - gz;
+                                const double d2 = (ex * ex + ey * ey) + ez * ez;
+                                if (d2 < bd2) { bd2 = d2; bvid = vid; bmx = cx; bmy = cy; bmz = cz; }
+                            }
+                        }
+                } else {
+                    nearest_voxel_direct(m, vx, vy, vz, gx, gy, gz, bd2, bvid, bmx, bmy, bmz, n_cand, n_occ);
+                }
+                ELM_PHASE(4)
+                finish_voxel_pair(acc, m, S, rp, px, py, pz, gx, gy, gz, bd2, bvid, bmx, bmy, bmz);
+            } else {
+                const int ox[7] = {0, 1, -1, 0, 0, 0, 0}, oy[7] = {0, 0, 0, 1, -1, 0, 0}, oz[7] = {0, 0, 0, 0, 0, 1, -1};
+#pragma unroll
+                for (int k7 = 0; k7 < 7; ++k7) {
+                    int vid;
+                    double cx, cy, cz;
+                    if (staged) {
+                        const int c = ((vx + ox[k7] - lox) * ny + (vy + oy[k7] - loy)) * nz + (vz + oz[k7] - loz);
+                        const int sl = s_slot[c];
+                        if (sl < 0) continue;
+                        vid = s_mvid[sl];
+                        cx = s_mean[sl][0]; cy = s_mean[sl][1]; cz = s_mean[sl][2];
+                    } else {
+                        const Probe pr = probe_voxel(m, vx + ox[k7], vy + oy[k7], vz + oz[k7]);
+                        if (pr.vid < 0 || pr.cnt == 0) continue;
+                        vid = pr.vid;
+                        cx = m.vox_mean[(size_t)vid * 3]; cy = m.vox_mean[(size_t)vid * 3 + 1]; cz = m.vox_mean[(size_t)vid * 3 + 2];
+                    }
+                    n_occ += 1.0;
+                    n_cand += 1.0;
+                    const double ex = cx - gx, ey = cy - gy, ez = cz - gz;
+                    const double d2 = (ex * ex + ey * ey) + ez * ez;
+                    if (d2 < rp.th2) {
+                        double C[9];
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) C[k] = m.vox_cov[(size_t)vid * 9 + k];
+                        add_pair<ELM_AVGICP>(acc, S.Rinv, S.tinv, px, py, pz, cx, cy, cz, C, nullptr, rp);
+                    }
+                }
+            }
+        }
+        ELM_PHASE(5)
+    }
+    if (valid) {
+        acc[29] = n_cand;
+        acc[30] = n_occ;
+        acc[31] += n_tested; // low part of slot 31: candidates actually distance-tested after pruning
+    }
+    // ---- 5. reduce
+    if (kPoints) {
+        __syncthreads(); // every thread is done with the staged points: reuse their LDS
+        block_reduce_store_lds(acc, reinterpret_cast<double*>(s_xyz), partials + (size_t)L * kSums);
+    } else {
+        block_reduce_store(acc, red, partials + (size_t)L * kSums);
+    }
+    ELM_PHASE(6)
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -321,7 +845,7 @@ __global__ __launch_bounds__(64) void k_init_state(ScanState* st, const double* 
     S.fitness = 0.0;
     for (int k = 0; k < 36; ++k) S.local_cov[k] = (k % 7 == 0) ? 1.0 : 0.0; // reg.cpp:280
     S.n_corr_last = 0.0;
-    S.pt_iters = 0.0; S.cand_total = 0.0; S.occ_total = 0.0;
+    S.pt_iters = 0.0; S.cand_total = 0.0; S.occ_total = 0.0; S.fallback_blocks = 0.0; S.tested_total = 0.0;
     S.done = map_empty ? 1 : 0; // VOXEL MAP EMPTY (reg.cpp:291-295): is_success = false, return initial_guess
     S.success = 0;
     S.gate = map_empty ? 1 : 0;
@@ -364,6 +888,11 @@ __global__ __launch_bounds__(64) void k_solve(const ScanDesc* __restrict__ scans
     S.pt_iters += (double)sd.n_total;
     S.cand_total += tot[29];
     S.occ_total += tot[30];
+    {
+        const double fb = floor(tot[31] / 1099511627776.0);
+        S.fallback_blocks += fb;
+        S.tested_total += tot[31] - fb * 1099511627776.0;
+    }
     elm_iter_trace* tr = (trace && iter <= ELM_MAX_ITER_TRACE) ? &trace[(size_t)s * ELM_MAX_ITER_TRACE + (iter - 1)] : nullptr;
 
     // corres_ratio = (float)i_source_corr_num / i_source_total_num (reg.cpp:351): float division, compared as double
@@ -576,19 +1105,44 @@ __global__ __launch_bounds__(256) void k_deskew(const float* __restrict__ xyz, c
 // ------------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------------
+int debug_phase_cycles(unsigned long long* out16, int reset) {
+#ifdef ELM_PHASE_TIMING
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 1;
+#else
+    (void)out16; (void)reset;
+    return 0;
+#endif
+}
+
 void launch_init_state(hipStream_t s, ScanState* st, const double* T0, int batch, int map_empty) {
     hipLaunchKernelGGL(k_init_state, dim3((batch + 63) / 64), dim3(64), 0, s, st, T0, batch, map_empty);
 }
 
 void launch_accumulate(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
-                       ScanState* st, double* partials, const RegParams& rp) {
+                       ScanState* st, double* partials, const RegParams& rp, int direct) {
     dim3 g(total_blocks), b(kBlock);
-    switch (rp.method) {
-    case ELM_P2P: hipLaunchKernelGGL(k_accumulate<ELM_P2P>, g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp); break;
-    case ELM_GICP: hipLaunchKernelGGL(k_accumulate<ELM_GICP>, g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp); break;
-    case ELM_VGICP: hipLaunchKernelGGL(k_accumulate<ELM_VGICP>, g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp); break;
-    default: hipLaunchKernelGGL(k_accumulate<ELM_AVGICP>, g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp); break;
+#define ELM_LAUNCH(K, M) hipLaunchKernelGGL((K<M>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp)
+    if (direct) {
+        switch (rp.method) {
+        case ELM_P2P: ELM_LAUNCH(k_accumulate_direct, ELM_P2P); break;
+        case ELM_GICP: ELM_LAUNCH(k_accumulate_direct, ELM_GICP); break;
+        case ELM_VGICP: ELM_LAUNCH(k_accumulate_direct, ELM_VGICP); break;
+        default: ELM_LAUNCH(k_accumulate_direct, ELM_AVGICP); break;
+        }
+    } else {
+        switch (rp.method) {
+        case ELM_P2P: ELM_LAUNCH(k_accumulate, ELM_P2P); break;
+        case ELM_GICP: ELM_LAUNCH(k_accumulate, ELM_GICP); break;
+        case ELM_VGICP: ELM_LAUNCH(k_accumulate, ELM_VGICP); break;
+        default: ELM_LAUNCH(k_accumulate, ELM_AVGICP); break;
+        }
     }
+#undef ELM_LAUNCH
 }
 
 void launch_solve(hipStream_t s, const ScanDesc* scans, int batch, ScanState* st, const double* partials,

@@ -93,6 +93,8 @@ typedef struct elm_reg_result {
     double point_iterations; /* scan points processed x iterations */
     double n_cand_total;     /* candidate map points (P2P/GICP) or voxel means (VGICP/AVGICP) distance-tested */
     double n_occ_total;      /* occupied neighbour voxels visited */
+    double fallback_blocks;  /* workgroup launches that took the un-staged path */
+    double n_tested_total;   /* candidates whose distance was actually evaluated (after exact cell pruning) */
 } elm_reg_result;
 
 typedef struct elm_map_info {
@@ -155,8 +157,8 @@ int elm_map_find_ground_height(const elm_map* map, double x, double y, double* g
 /* ---------------------------------------------------------------- scans --------------------------- */
 /* Upload one source scan (sensor frame, float32 xyz; PointStruct.local == .pose, pcm.hpp:205-220).
  * n_total is the size of the whole scan when this context holds only a shard of it (multi-GPU; the overlap
- * ratio of reg.cpp:351 is taken against n_total); pass n_total = n on one GPU.  The points are re-ordered into
- * coarse sensor-frame cells for cache locality (source order is not contractual: the reference's own
+ * ratio of reg.cpp:351 is taken against n_total); pass n_total = n on one GPU.  The points are re-ordered along a
+ * Hilbert curve over coarse sensor-frame cells for locality (source order is not contractual: the reference's own
  * VoxelDownsample emits unordered_map order, vhm.hpp:278-280). */
 int elm_scan_upload(elm_ctx* ctx, const float* xyz, size_t n, size_t n_total, elm_scan** out);
 void elm_scan_destroy(elm_scan* scan);
