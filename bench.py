@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--method", type=int, default=0, help="0 P2P (configs[1]), 1 GICP, 2 VGICP, 3 AVGICP")
     ap.add_argument("--cpu-sample", type=int, default=2, help="registrations timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency runs (profiling passes)")
     args = ap.parse_args()
 
     import torch
@@ -141,6 +142,9 @@ def main():
     C = float(sum(r["n_cand_total"] for r in out)) / max(pt_iters, 1)  # candidates tested per point-iteration
     V = float(sum(r["n_occ_total"] for r in out)) / max(pt_iters, 1)   # occupied neighbour voxels per point-iteration
     bytes_unit = b_alg(int(method), C, V)
+    kmode = os.environ.get("ELM_KERNEL", "nbr")
+    kernel_name = (f"k_accumulate_nbr<{METHOD_NAMES[int(method)]}>" if (kmode == "nbr" and int(method) in (0, 1)) else
+                   f"k_accumulate_direct<{METHOD_NAMES[int(method)]}>" if kmode == "direct" else f"k_accumulate<{METHOD_NAMES[int(method)]}>")
     # dominant kernel: k_accumulate. Units one launch processes ON THIS GPU = its shard of the batch's live points.
     launches = max(prof["accumulate_launches"], 1)
     acc_ms_avg = prof["accumulate_ms"] / launches
@@ -151,18 +155,19 @@ def main():
     if os.path.exists(pmc_path):
         try:
             pm = json.load(open(pmc_path))
-            if pm.get("method") == int(method) and pm.get("batch") == args.batch and pm.get("scan_points") == args.scan_points:
+            if (pm.get("method") == int(method) and pm.get("batch") == args.batch and pm.get("scan_points") == args.scan_points
+                    and pm.get("kernel") == kernel_name):
                 traffic = pm.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
     # single-registration latency (B = 1), outside the timed region
     lat = []
-    for _ in range(5):
+    for _ in range(0 if args.no_latency else 5):
         t1 = time.perf_counter()
         reg.RunRegisterBatch(scans[:1], vm, T0s[:1])
         lat.append(time.perf_counter() - t1)
-    latency_ms = 1e3 * float(np.median(lat))
+    latency_ms = 1e3 * float(np.median(lat)) if lat else None
 
     result = {
         "metric": "ICP registrations/sec, 128k-pt scan vs 10M-pt map; pose err vs CPU ref",
@@ -198,7 +203,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": f"k_accumulate<{METHOD_NAMES[int(method)]}>",
+            "kernel": kernel_name,
             "achieved": achieved_gbs,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",

@@ -96,6 +96,8 @@ class MapInfo(C.Structure):
         ("has_point_cov", C.c_int32),
         ("_pad", C.c_int32),
         ("device_bytes", C.c_uint64),
+        ("n_query_voxels", C.c_uint64),
+        ("nbr_entries", C.c_uint64),
     ]
 
 
@@ -124,7 +126,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void
 EXPORTS = [
     "elm_reg_config_default", "elm_ctx_create", "elm_ctx_destroy", "elm_last_error", "elm_strerror",
     "elm_ctx_synchronize", "elm_ctx_stream", "elm_ctx_set_profiling", "elm_ctx_get_profile", "elm_map_build", "elm_map_destroy", "elm_map_cal_voxel_cov_all",
-    "elm_map_cal_point_cov_all", "elm_map_get_info", "elm_map_empty", "elm_map_download_points",
+    "elm_map_cal_point_cov_all", "elm_map_build_neighbourhoods", "elm_map_get_info", "elm_map_empty", "elm_map_download_points",
     "elm_map_download_voxels", "elm_map_find_ground_height", "elm_scan_upload", "elm_scan_destroy",
     "elm_scan_size", "elm_register", "elm_register_batch", "elm_register_batch_enqueue",
     "elm_register_batch_finish", "elm_deskew", "elm_deskew_prepare", "elm_comm_get_unique_id", "elm_comm_init",
@@ -163,6 +165,7 @@ def lib():
     L.elm_map_destroy.restype = None
     L.elm_map_cal_voxel_cov_all.argtypes = [vp]
     L.elm_map_cal_point_cov_all.argtypes = [vp, C.c_double]
+    L.elm_map_build_neighbourhoods.argtypes = [vp]
     L.elm_map_get_info.argtypes = [vp, C.POINTER(MapInfo)]
     L.elm_map_empty.argtypes = [vp]
     L.elm_map_download_points.argtypes = [vp, dp, dp, dp, C.c_size_t]

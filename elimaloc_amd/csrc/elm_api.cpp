@@ -87,7 +87,7 @@ struct elm_ctx {
     bool want_trace = false;
     bool in_flight = false;
     RegParams rp{};
-    int direct_kernel = 0; // ELM_KERNEL=direct selects the un-staged accumulate kernel (A/B measurements)
+    int kernel_mode = 0; // accumulate kernel for P2P/GICP: 0 neighbourhood lists (default), 1 LDS-staged, 2 direct (ELM_KERNEL=nbr|staged|direct)
     // optional hipEvent timing
     bool profiling = false;
     std::vector<hipEvent_t> events;
@@ -178,7 +178,7 @@ extern "C" int elm_ctx_create(int device_id, elm_ctx** out) {
         delete ctx;
         return ELM_ERR_DEVICE;
     }
-    if (const char* k = getenv("ELM_KERNEL")) ctx->direct_kernel = (strcmp(k, "direct") == 0) ? 1 : 0;
+    if (const char* k = getenv("ELM_KERNEL")) ctx->kernel_mode = (strcmp(k, "direct") == 0) ? 2 : (strcmp(k, "staged") == 0) ? 1 : 0;
     *out = ctx;
     return ELM_OK;
 }
@@ -245,6 +245,9 @@ struct elm_map {
     int32_t* d_keys = nullptr; // [n_vox][3] stored keys (for downloads)
     double *d_vox_mean = nullptr, *d_vox_cov = nullptr;
     double *d_pt_mean = nullptr, *d_pt_cov = nullptr, *d_pt_nfit = nullptr;
+    HashSlot* d_qslots = nullptr;
+    float4* d_nbr_pts = nullptr;
+    bool has_nbr = false;
     std::vector<int32_t> h_keys;
     std::vector<uint2> h_ranges;
 };
@@ -396,7 +399,7 @@ static void build_host(const float* xyz, size_t n, double voxel_size, int max_po
 static void map_free(elm_map* m) {
     if (!m) return;
     (void)hipSetDevice(m->ctx->device);
-    void* ptrs[] = {m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_pt_mean, m->d_pt_cov, m->d_pt_nfit};
+    void* ptrs[] = {m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_pt_mean, m->d_pt_cov, m->d_pt_nfit, m->d_qslots, m->d_nbr_pts};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete m;
@@ -514,6 +517,110 @@ extern "C" int elm_map_cal_point_cov_all(elm_map* m, double d_search_dist) {
     m->dm.pt_cov = m->d_pt_cov;
     m->dm.pt_nfit = m->d_pt_nfit;
     m->info.has_point_cov = 1;
+    return ELM_OK;
+}
+
+// Neighbourhood lists (see DevMap): query voxels = every floor key within +-1 of a stored (trunc) key.
+extern "C" int elm_map_build_neighbourhoods(elm_map* m) {
+    if (!m) return ELM_ERR_INVALID;
+    if (m->has_nbr) return ELM_OK;
+    elm_ctx* ctx = m->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint32_t n_vox = m->dm.n_vox;
+    std::vector<int32_t> qkeys;
+    {
+        HostTable tab;
+        tab.init(next_pow2(std::max<uint64_t>(1024, (uint64_t)n_vox * 8)));
+        int32_t nq = 0;
+        for (uint32_t v = 0; v < n_vox; ++v) {
+            if (m->h_ranges[v].y == 0) continue;
+            const int32_t kx = m->h_keys[3 * v], ky = m->h_keys[3 * v + 1], kz = m->h_keys[3 * v + 2];
+            for (int dx = -1; dx <= 1; ++dx)
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dz = -1; dz <= 1; ++dz) {
+                        if (tab.used * 2 >= tab.mask) tab.grow();
+                        bool added;
+                        tab.find_or_add(kx + dx, ky + dy, kz + dz, nq, &added);
+                        if (added) {
+                            qkeys.push_back(kx + dx); qkeys.push_back(ky + dy); qkeys.push_back(kz + dz);
+                            ++nq;
+                        }
+                    }
+        }
+    }
+    const uint32_t n_q = (uint32_t)(qkeys.size() / 3);
+    int32_t* d_qkeys = nullptr;
+    uint32_t *d_counts = nullptr, *d_nocc = nullptr, *d_off = nullptr;
+    auto cleanup = [&]() {
+        if (d_qkeys) (void)hipFree(d_qkeys);
+        if (d_counts) (void)hipFree(d_counts);
+        if (d_nocc) (void)hipFree(d_nocc);
+        if (d_off) (void)hipFree(d_off);
+    };
+#define NBR_CHK(call)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            ctx->last_error = std::string(#call) + ": " + hipGetErrorString(e_);              \
+            cleanup();                                                                        \
+            return ELM_ERR_DEVICE;                                                            \
+        }                                                                                     \
+    } while (0)
+    const size_t nq_alloc = std::max<size_t>(n_q, 1);
+    NBR_CHK(hipMalloc((void**)&d_qkeys, nq_alloc * 3 * sizeof(int32_t)));
+    NBR_CHK(hipMalloc((void**)&d_counts, nq_alloc * sizeof(uint32_t)));
+    NBR_CHK(hipMalloc((void**)&d_nocc, nq_alloc * sizeof(uint32_t)));
+    NBR_CHK(hipMalloc((void**)&d_off, nq_alloc * sizeof(uint32_t)));
+    std::vector<uint32_t> counts(n_q), nocc(n_q), offs(n_q);
+    uint64_t total = 0;
+    if (n_q) {
+        NBR_CHK(hipMemcpy(d_qkeys, qkeys.data(), (size_t)n_q * 3 * sizeof(int32_t), hipMemcpyHostToDevice));
+        launch_nbr_count(ctx->stream, m->dm, d_qkeys, n_q, d_counts, d_nocc);
+        NBR_CHK(hipGetLastError());
+        NBR_CHK(hipStreamSynchronize(ctx->stream));
+        NBR_CHK(hipMemcpy(counts.data(), d_counts, (size_t)n_q * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        NBR_CHK(hipMemcpy(nocc.data(), d_nocc, (size_t)n_q * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (uint32_t q = 0; q < n_q; ++q) {
+            offs[q] = (uint32_t)total;
+            total += counts[q];
+        }
+        if (total > 0xFFFFFFF0ull) {
+            ctx->last_error = "neighbourhood lists exceed 2^32 entries";
+            cleanup();
+            return ELM_ERR_UNSUPPORTED;
+        }
+        NBR_CHK(hipMemcpy(d_off, offs.data(), (size_t)n_q * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    NBR_CHK(hipMalloc((void**)&m->d_nbr_pts, std::max<size_t>((size_t)total * sizeof(float4), 256)));
+    if (n_q) {
+        launch_nbr_fill(ctx->stream, m->dm, d_qkeys, n_q, d_off, m->d_nbr_pts);
+        NBR_CHK(hipGetLastError());
+        NBR_CHK(hipStreamSynchronize(ctx->stream));
+    }
+    const uint32_t qcap = next_pow2((uint64_t)n_q * 2);
+    {
+        std::vector<HashSlot> qs(qcap);
+        for (auto& e : qs) { e.kx = e.ky = e.kz = 0; e.vid = -1; e.start = e.cnt = e.pad0 = e.pad1 = 0; }
+        for (uint32_t q = 0; q < n_q; ++q) {
+            uint32_t h = hash3(qkeys[3 * q], qkeys[3 * q + 1], qkeys[3 * q + 2]) & (qcap - 1);
+            while (qs[h].vid >= 0) h = (h + 1) & (qcap - 1);
+            qs[h].kx = qkeys[3 * q]; qs[h].ky = qkeys[3 * q + 1]; qs[h].kz = qkeys[3 * q + 2];
+            qs[h].vid = (int32_t)q;
+            qs[h].start = offs[q]; qs[h].cnt = counts[q]; qs[h].pad0 = nocc[q];
+        }
+        NBR_CHK(hipMalloc((void**)&m->d_qslots, (size_t)qcap * sizeof(HashSlot)));
+        NBR_CHK(hipMemcpy(m->d_qslots, qs.data(), (size_t)qcap * sizeof(HashSlot), hipMemcpyHostToDevice));
+    }
+#undef NBR_CHK
+    cleanup();
+    m->dm.qslots = m->d_qslots;
+    m->dm.qmask = qcap - 1;
+    m->dm.n_q = n_q;
+    m->dm.nbr_pts = m->d_nbr_pts;
+    m->has_nbr = true;
+    m->info.device_bytes += (size_t)total * sizeof(float4) + (size_t)qcap * sizeof(HashSlot);
+    m->info.n_query_voxels = n_q;
+    m->info.nbr_entries = total;
     return ELM_OK;
 }
 
@@ -763,6 +870,11 @@ extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_
     rp.max_iter = cfg->max_iteration;
     ctx->rp = rp;
 
+    // P2P / GICP default to the neighbourhood-list kernel; the lists are built on first use (init-time cost)
+    const bool use_nbr = !map_empty && ctx->kernel_mode == 0 && (method == ELM_P2P || method == ELM_GICP);
+    if (use_nbr && !map->has_nbr) {
+        if ((rc = elm_map_build_neighbourhoods(const_cast<elm_map*>(map))) != ELM_OK) return rc;
+    }
     ScanState* st = (ScanState*)ctx->d_state.p;
     const ScanDesc* dsc = (const ScanDesc*)ctx->d_scans.p;
     launch_init_state(ctx->stream, st, (const double*)ctx->d_T0.p, batch, map_empty ? 1 : 0);
@@ -771,7 +883,11 @@ extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_
     if (!map_empty) {
         for (int it = 0; it < cfg->max_iteration; ++it) {
             if ((rc = prof_mark(ctx)) != ELM_OK) return rc;
-            if (blocks) launch_accumulate(ctx->stream, map->dm, dsc, batch, (int)blocks, st, (double*)ctx->d_partials.p, rp, (ctx->direct_kernel || map->info.max_points_per_voxel > 255) ? 1 : 0);
+            if (blocks) {
+                if (use_nbr) launch_accumulate_nbr(ctx->stream, map->dm, dsc, batch, (int)blocks, st, (double*)ctx->d_partials.p, rp);
+                else launch_accumulate(ctx->stream, map->dm, dsc, batch, (int)blocks, st, (double*)ctx->d_partials.p, rp,
+                                       (ctx->kernel_mode == 2 || map->info.max_points_per_voxel > 255) ? 1 : 0);
+            }
             if ((rc = prof_mark(ctx)) != ELM_OK) return rc;
             if (distributed) {
                 launch_solve(ctx->stream, dsc, batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 1);

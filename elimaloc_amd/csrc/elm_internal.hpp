@@ -31,6 +31,13 @@ struct DevMap {
     const double* pt_cov;   // [n_pts][9] row-major
     const double* pt_nfit;  // [n_pts][3] eigenvector of the smallest eigenvalue of pt_cov (reg.cpp:89-91)
     double voxel_size;
+    // neighbourhood lists (optional): for every FLOOR-keyed query voxel that has at least one stored neighbour, the
+    // points of its 27 trunc-keyed neighbour buckets concatenated in the reference's visiting order (x-major ..
+    // z-minor, insertion order inside a bucket).  27x duplication of the map points, laid out for streaming.
+    const HashSlot* qslots; // key = query voxel, vid = query id, start/cnt = its list, pad0 = occupied neighbours
+    uint32_t qmask;
+    uint32_t n_q;
+    const float4* nbr_pts;  // xyz + bit-cast global point index
 };
 
 __host__ __device__ __forceinline__ uint32_t hash3(int32_t x, int32_t y, int32_t z) {
@@ -89,6 +96,10 @@ void launch_accumulate(hipStream_t s, const DevMap& m, const ScanDesc* scans, in
 // mode 0: reduce + solve (single GPU); 1: reduce only -> sums; 2: solve only from sums
 void launch_solve(hipStream_t s, const ScanDesc* scans, int batch, ScanState* st, const double* partials,
                   double* sums, const RegParams& rp, elm_iter_trace* trace, int mode);
+void launch_accumulate_nbr(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
+                           ScanState* st, double* partials, const RegParams& rp);
+void launch_nbr_count(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, uint32_t* counts, uint32_t* nocc);
+void launch_nbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets, float4* out);
 void launch_voxel_cov(hipStream_t s, const DevMap& m, const uint2* ranges, double* vox_mean, double* vox_cov);
 void launch_point_cov(hipStream_t s, const DevMap& m, double d2max, double* pt_mean, double* pt_cov, double* pt_nfit);
 

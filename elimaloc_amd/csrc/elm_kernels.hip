@@ -824,6 +824,113 @@ __global__ __launch_bounds__(kBlock, 3) void k_accumulate(const DevMap m, const 
     ELM_PHASE(6)
 }
 
+// ---- K1c: neighbourhood-list kernel -----------------------------------------------------------------------
+// One thread per scan point: ONE hash probe (floor key of the transformed point) finds the precomputed candidate
+// list of that query voxel -- the 27 neighbour buckets already concatenated in the reference's visiting order --
+// and the thread streams it with independent 16-byte loads (8 in flight).  Lanes of the same voxel read the same
+// addresses.  No workgroup cooperation, no barriers before the final reduction.
+template <int METHOD>
+__global__ __launch_bounds__(kBlock) void k_accumulate_nbr(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
+                                                           unsigned total_blocks, const ScanState* __restrict__ st,
+                                                           double* __restrict__ partials, const RegParams rp) {
+    __shared__ double s_buf[16 * kBlock]; // 32 KB for the transpose reduction
+    const unsigned L = xcd_remap(blockIdx.x, total_blocks);
+    const int s = find_scan(scans, batch, L);
+    const ScanState& S = st[s];
+    if (S.done) return;
+    const ScanDesc sd = scans[s];
+    const unsigned i = (L - sd.blk_begin) * kBlock + threadIdx.x;
+    const bool valid = i < sd.n;
+    double acc[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc[k] = 0.0;
+    if (valid) {
+        const float4 pf = sd.pts[i];
+        const double px = pf.x, py = pf.y, pz = pf.z;
+        const double gx = ((S.T[0] * px + S.T[4] * py) + S.T[8] * pz) + S.T[12];
+        const double gy = ((S.T[1] * px + S.T[5] * py) + S.T[9] * pz) + S.T[13];
+        const double gz = ((S.T[2] * px + S.T[6] * py) + S.T[10] * pz) + S.T[14];
+        const int vx = floor_key(gx, m.voxel_size), vy = floor_key(gy, m.voxel_size), vz = floor_key(gz, m.voxel_size);
+        // query-voxel probe
+        unsigned start = 0, cnt = 0, nocc = 0;
+        {
+            unsigned h = hash3(vx, vy, vz) & m.qmask;
+            for (;;) {
+                const int4 key = *reinterpret_cast<const int4*>(&m.qslots[h]);
+                const uint4 rg = *reinterpret_cast<const uint4*>(&m.qslots[h].start);
+                if (key.w < 0) break;
+                if (key.x == vx && key.y == vy && key.z == vz) { start = rg.x; cnt = rg.y; nocc = rg.z; break; }
+                h = (h + 1) & m.qmask;
+            }
+        }
+        const float4* __restrict__ lp = m.nbr_pts + start;
+        double bd2 = DBL_MAX;
+        int bj = -1;
+        const int n = (int)cnt;
+        for (int j = 0; j < n; j += 8) {
+            float4 q[8];
+            int jj[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { jj[u] = min(j + u, n - 1); q[u] = lp[jj[u]]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double ex = (double)q[u].x - gx, ey = (double)q[u].y - gy, ez = (double)q[u].z - gz;
+                const double d2 = (ex * ex + ey * ey) + ez * ez;
+                if (d2 < bd2) { bd2 = d2; bj = jj[u]; } // in order, strict <; a clamped duplicate never beats itself
+            }
+        }
+        float bx = 0.f, by = 0.f, bz = 0.f;
+        int bidx = -1;
+        if (bj >= 0) {
+            const float4 q = lp[bj];
+            bx = q.x; by = q.y; bz = q.z;
+            bidx = (int)__float_as_uint(q.w);
+        }
+        finish_point_pair<METHOD>(acc, m, S, rp, px, py, pz, gx, gy, gz, bd2, bx, by, bz, bidx);
+        acc[29] = (double)cnt;
+        acc[30] = (double)nocc;
+        acc[31] = (double)cnt;
+    }
+    block_reduce_store_lds(acc, s_buf, partials + (size_t)L * kSums);
+}
+
+// map build: size and content of the neighbourhood list of every query voxel (init time)
+__global__ __launch_bounds__(256) void k_nbr_count(const DevMap m, const int32_t* __restrict__ qkeys, unsigned n_q,
+                                                   unsigned* __restrict__ counts, unsigned* __restrict__ nocc) {
+    const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_q) return;
+    const int vx = qkeys[3 * q], vy = qkeys[3 * q + 1], vz = qkeys[3 * q + 2];
+    unsigned c = 0, o = 0;
+    for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dz = -1; dz <= 1; ++dz) {
+                const Probe pr = probe_voxel(m, vx + dx, vy + dy, vz + dz);
+                if (pr.vid >= 0 && pr.cnt > 0) { c += pr.cnt; ++o; }
+            }
+    counts[q] = c;
+    nocc[q] = o;
+}
+__global__ __launch_bounds__(256) void k_nbr_fill(const DevMap m, const int32_t* __restrict__ qkeys, unsigned n_q,
+                                                  const unsigned* __restrict__ offsets, float4* __restrict__ out) {
+    const unsigned q = (blockIdx.x * blockDim.x + threadIdx.x) >> 5; // one 32-lane group per query voxel
+    const unsigned l = threadIdx.x & 31;
+    if (q >= n_q) return;
+    const int vx = qkeys[3 * q], vy = qkeys[3 * q + 1], vz = qkeys[3 * q + 2];
+    unsigned o = offsets[q];
+    for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dz = -1; dz <= 1; ++dz) {
+                const Probe pr = probe_voxel(m, vx + dx, vy + dy, vz + dz);
+                if (pr.vid < 0) continue;
+                for (unsigned j = l; j < pr.cnt; j += 32) {
+                    float4 p = m.pts[pr.start + j];
+                    p.w = __uint_as_float(pr.start + j);
+                    out[(size_t)o + j] = p;
+                }
+                o += pr.cnt;
+            }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // K2
 // ------------------------------------------------------------------------------------------------------
@@ -852,28 +959,35 @@ __global__ __launch_bounds__(64) void k_init_state(ScanState* st, const double* 
     S.iters = 0;
 }
 
-__global__ __launch_bounds__(64) void k_solve(const ScanDesc* __restrict__ scans, ScanState* st,
-                                              const double* __restrict__ partials, double* sums, const RegParams rp,
-                                              elm_iter_trace* trace, int mode) {
+constexpr int kSolveThreads = 256;
+__global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* __restrict__ scans, ScanState* st,
+                                                         const double* __restrict__ partials, double* sums,
+                                                         const RegParams rp, elm_iter_trace* trace, int mode) {
     const int s = blockIdx.x;
     ScanState& S = st[s];
     const int t = threadIdx.x;
     __shared__ double tot[kSums];
+    __shared__ double part[kSolveThreads / 32][kSums];
     const bool done = S.done != 0;
     if (mode != 2) {
-        // deterministic two-lane-per-entry reduction of this scan's per-block partial sums
-        const int k = t & 31, half = t >> 5;
+        // deterministic reduction of this scan's per-workgroup partial sums: 8 strided groups of 32 lanes read whole
+        // 256-byte records, then the 8 group sums are added in a fixed order
+        const int k = t & 31, g = t >> 5;
         double v = 0.0;
         if (!done) {
             const ScanDesc sd = scans[s];
-            for (unsigned b = sd.blk_begin + half; b < sd.blk_end; b += 2) v += partials[(size_t)b * kSums + k];
+            for (unsigned b = sd.blk_begin + g; b < sd.blk_end; b += kSolveThreads / 32) v += partials[(size_t)b * kSums + k];
         }
-        v += __shfl_xor(v, 32, 64);
-        if (mode == 1) {
-            if (t < 32) sums[(size_t)s * kSums + k] = v; // zeros for finished scans keep the all-reduce buffer defined
-            return;
+        part[g][k] = v;
+        __syncthreads();
+        if (t < 32) {
+            double a = part[0][t];
+#pragma unroll
+            for (int q = 1; q < kSolveThreads / 32; ++q) a += part[q][t];
+            if (mode == 1) sums[(size_t)s * kSums + t] = a; // zeros for finished scans keep the all-reduce buffer defined
+            else tot[t] = a;
         }
-        if (t < 32) tot[k] = v;
+        if (mode == 1) return;
     } else {
         if (t < 32) tot[t] = sums[(size_t)s * kSums + t];
     }
@@ -913,19 +1027,21 @@ __global__ __launch_bounds__(64) void k_solve(const ScanDesc* __restrict__ scans
     }
     S.fitness = tot[27] / n_corr; // d_fitness_score_ = d_residual_sum / source_global.size()
 
-    double H[36], b[6];
+    // working arrays live in LDS (dynamic indexing in registers would spill to scratch)
+    __shared__ double ws_H[36], ws_Hd[36], ws_m[36], ws_b[6], ws_x[6], ws_misc[32];
+    double* H = ws_H; double* b = ws_b;
     for (int i = 0; i < 6; ++i)
         for (int j = i; j < 6; ++j) {
             H[i * 6 + j] = tot[tri(i, j)];
             H[j * 6 + i] = tot[tri(i, j)];
         }
     for (int i = 0; i < 6; ++i) b[i] = tot[21 + i];
-    double Hd[36];
+    double* Hd = ws_Hd;
     for (int k = 0; k < 36; ++k) Hd[k] = H[k];
     for (int i = 0; i < 6; ++i) Hd[i * 7] = H[i * 7] + rp.lm_lambda * H[i * 7]; // JTJ + lambda * diag(JTJ)
-    double x[6];
-    ldlt_solve6(Hd, b, x);
-    if (rp.method == ELM_GICP) inv6(Hd, S.local_cov); // reg.cpp:141-142
+    double* x = ws_x;
+    ldlt_solve6_ws(Hd, b, x, ws_m, ws_misc);
+    if (rp.method == ELM_GICP) inv6_ws(Hd, S.local_cov, ws_m); // reg.cpp:141-142
 
     double dR[9];
     rotvec_to_matrix(&x[3], dR);
@@ -1145,9 +1261,25 @@ void launch_accumulate(hipStream_t s, const DevMap& m, const ScanDesc* scans, in
 #undef ELM_LAUNCH
 }
 
+void launch_accumulate_nbr(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
+                           ScanState* st, double* partials, const RegParams& rp) {
+    dim3 g(total_blocks), b(kBlock);
+    if (rp.method == ELM_P2P)
+        hipLaunchKernelGGL((k_accumulate_nbr<ELM_P2P>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
+    else
+        hipLaunchKernelGGL((k_accumulate_nbr<ELM_GICP>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
+}
+void launch_nbr_count(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, uint32_t* counts, uint32_t* nocc) {
+    hipLaunchKernelGGL(k_nbr_count, dim3((n_q + 255) / 256), dim3(256), 0, s, m, qkeys, n_q, counts, nocc);
+}
+void launch_nbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets, float4* out) {
+    const uint64_t threads = (uint64_t)n_q * 32;
+    hipLaunchKernelGGL(k_nbr_fill, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, m, qkeys, n_q, offsets, out);
+}
+
 void launch_solve(hipStream_t s, const ScanDesc* scans, int batch, ScanState* st, const double* partials,
                   double* sums, const RegParams& rp, elm_iter_trace* trace, int mode) {
-    hipLaunchKernelGGL(k_solve, dim3(batch), dim3(64), 0, s, scans, st, partials, sums, rp, trace, mode);
+    hipLaunchKernelGGL(k_solve, dim3(batch), dim3(kSolveThreads), 0, s, scans, st, partials, sums, rp, trace, mode);
 }
 
 void launch_voxel_cov(hipStream_t s, const DevMap& m, const uint2* ranges, double* vox_mean, double* vox_cov) {

@@ -227,13 +227,14 @@ ELM_HD void plane_regularize(const double cov[9], double cov_out[9], double norm
 // ---- 6x6 ------------------------------------------------------------------------------------------
 // Solve A x = b, A symmetric (row-major, only the lower triangle is read), by LDL^T with diagonal pivoting
 // (largest |diagonal| of the trailing block, symmetric row/column swap) as Eigen's LDLT does (reg.cpp:56).
-ELM_HD void ldlt_solve6(const double A[36], const double b[6], double x[6]) {
-    double m[36];
+ELM_HD void ldlt_solve6_ws(const double* A, const double* b, double* x, double* m, double* misc) {
+    // m: 36 doubles, misc: >= 24 doubles of caller-provided workspace (LDS on the device)
     for (int i = 0; i < 6; ++i)
         for (int j = 0; j < 6; ++j) m[i * 6 + j] = (j <= i) ? A[i * 6 + j] : A[j * 6 + i];
-    int perm[6];
-    for (int i = 0; i < 6; ++i) perm[i] = i;
-    double d[6];
+    double* d = misc;      // [6]
+    double* y = misc + 6;  // [6]
+    double* permd = misc + 12; // [6] permutation kept as doubles in the same workspace
+    for (int i = 0; i < 6; ++i) permd[i] = (double)i;
     for (int k = 0; k < 6; ++k) {
         // pivot = largest |diagonal| of the trailing Schur complement
         int p = k;
@@ -247,7 +248,7 @@ ELM_HD void ldlt_solve6(const double A[36], const double b[6], double x[6]) {
         if (p != k) { // symmetric swap of rows/cols k and p on the full matrix
             for (int j = 0; j < 6; ++j) { double q = m[k * 6 + j]; m[k * 6 + j] = m[p * 6 + j]; m[p * 6 + j] = q; }
             for (int i = 0; i < 6; ++i) { double q = m[i * 6 + k]; m[i * 6 + k] = m[i * 6 + p]; m[i * 6 + p] = q; }
-            int q = perm[k]; perm[k] = perm[p]; perm[p] = q;
+            double qd = permd[k]; permd[k] = permd[p]; permd[p] = qd;
         }
         // m[k][k] -= sum_{c<k} L[k][c]^2 d[c] ; L[i][k] = (m[i][k] - sum_c L[i][c] d[c] L[k][c]) / d[k]
         double dk = m[k * 6 + k];
@@ -259,19 +260,22 @@ ELM_HD void ldlt_solve6(const double A[36], const double b[6], double x[6]) {
             m[i * 6 + k] = (dk != 0.0) ? s / dk : s;
         }
     }
-    double y[6];
-    for (int i = 0; i < 6; ++i) y[i] = b[perm[i]];
+    for (int i = 0; i < 6; ++i) y[i] = b[(int)permd[i]];
     for (int i = 0; i < 6; ++i)
         for (int j = 0; j < i; ++j) y[i] -= m[i * 6 + j] * y[j];
     for (int i = 0; i < 6; ++i) y[i] = (fabs(d[i]) > 5.6e-309) ? y[i] / d[i] : 0.0;
     for (int i = 5; i >= 0; --i)
         for (int j = i + 1; j < 6; ++j) y[i] -= m[j * 6 + i] * y[j];
-    for (int i = 0; i < 6; ++i) x[perm[i]] = y[i];
+    for (int i = 0; i < 6; ++i) x[(int)permd[i]] = y[i];
+}
+
+ELM_HD void ldlt_solve6(const double A[36], const double b[6], double x[6]) {
+    double m[36], misc[24];
+    ldlt_solve6_ws(A, b, x, m, misc);
 }
 
 // General 6x6 inverse by Gauss-Jordan with partial pivoting (reg.cpp:141 uses PartialPivLU).
-ELM_HD void inv6(const double A[36], double R[36]) {
-    double m[36];
+ELM_HD void inv6_ws(const double* A, double* R, double* m) {
     for (int i = 0; i < 36; ++i) m[i] = A[i];
     for (int i = 0; i < 6; ++i)
         for (int j = 0; j < 6; ++j) R[i * 6 + j] = (i == j) ? 1.0 : 0.0;
@@ -296,6 +300,11 @@ ELM_HD void inv6(const double A[36], double R[36]) {
             for (int j = 0; j < 6; ++j) { m[i * 6 + j] -= f * m[k * 6 + j]; R[i * 6 + j] -= f * R[k * 6 + j]; }
         }
     }
+}
+
+ELM_HD void inv6(const double A[36], double R[36]) {
+    double m[36];
+    inv6_ws(A, R, m);
 }
 
 // ---- SO(3) ----------------------------------------------------------------------------------------

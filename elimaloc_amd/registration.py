@@ -186,6 +186,10 @@ class VoxelHashMap:
         else:
             self._handle()
 
+    def BuildNeighbourhoods(self):
+        """Pay the neighbourhood-list build (P2P/GICP streaming layout) now instead of on the first registration."""
+        check(_lib.lib().elm_map_build_neighbourhoods(self._handle()), self.ctx._h, "elm_map_build_neighbourhoods")
+
     def Empty(self):  # vhm.hpp:325
         return bool(_lib.lib().elm_map_empty(self._handle()))
 

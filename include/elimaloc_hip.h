@@ -108,6 +108,8 @@ typedef struct elm_map_info {
     int32_t has_point_cov;
     int32_t _pad;
     uint64_t device_bytes;
+    uint64_t n_query_voxels; /* neighbourhood lists (0 until built) */
+    uint64_t nbr_entries;
 } elm_map_info;
 
 /* ---------------------------------------------------------------- context ------------------------- */
@@ -141,6 +143,11 @@ void elm_map_destroy(elm_map* map);
 int elm_map_cal_voxel_cov_all(elm_map* map);
 /* VoxelHashMap::CalPointCovAll (vhm.hpp:252-257), HIP kernel over map points */
 int elm_map_cal_point_cov_all(elm_map* map, double d_search_dist);
+/* Precompute, for every floor-keyed voxel a query can fall into, the concatenation of its 27 neighbour buckets in
+ * the reference's visiting order (GetAdjacentVoxels order vhm.cpp:234-240, insertion order inside a bucket): 27x the
+ * map points in HBM, so the P2P/GICP correspondence search streams one contiguous list per point.  Called
+ * automatically by elm_register* on first use; exposed so the cost can be paid at map-build time. */
+int elm_map_build_neighbourhoods(elm_map* map);
 int elm_map_get_info(const elm_map* map, elm_map_info* info);
 /* VoxelHashMap::Empty (vhm.hpp:325) */
 int elm_map_empty(const elm_map* map);

@@ -7,6 +7,9 @@ import math
 import numpy as np
 
 
+DEGENERATE = set()  # keys of rank-deficient covariances met by voxel_covs / point_covs
+
+
 def build_map(points, voxel_size=1.0, max_points=30):
     """AddPoints: truncation keys, first point always kept, later ones iff < max_points stored and none within
     sqrt(vs^2/max_points) (strict <)."""
@@ -27,6 +30,13 @@ def regularize(cov):
     return U @ np.diag([1.0, 1.0, 1e-3]) @ Vt
 
 
+def is_rank_deficient(cov):
+    """Sample covariances of <= 3 distinct points: the reference's U diag(1,1,1e-3) V^T then depends on round-off
+    decided signs inside Eigen's Jacobi SVD and cannot be pinned by an independent SVD."""
+    sv = np.linalg.svd(cov, compute_uv=False)
+    return sv[2] <= 1e-9 * max(sv[0], 1e-300)
+
+
 def voxel_covs(vox):
     out = {}
     for k, b in vox.items():
@@ -38,6 +48,8 @@ def voxel_covs(vox):
             mean = P.mean(axis=0)
             D = P - mean
             out[k] = (regularize(D.T @ D / (n - 1)), mean)
+            if is_rank_deficient(D.T @ D / (n - 1)):
+                DEGENERATE.add(("v", k))
     return out
 
 
@@ -66,6 +78,8 @@ def point_covs(vox, voxel_size, dist):
                 mean = P.mean(axis=0)
                 D = P - mean
                 out[(k, idx)] = (regularize(D.T @ D / (len(nb) - 1)), mean)
+                if is_rank_deficient(D.T @ D / (len(nb) - 1)):
+                    DEGENERATE.add(("p", k, idx))
     return out
 
 

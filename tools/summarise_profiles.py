@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 databases written by tools/collect_profiles.sh into small text/JSON summaries
+(kernel_stats.csv, pmc.json) that are committed under profiles/."""
+import json, os, sqlite3, sys
+
+out = sys.argv[1]
+
+
+def db(name):
+    p = os.path.join(out, name, "b_results.db")
+    return sqlite3.connect(p) if os.path.exists(p) else None
+
+
+c = db("trace")
+if c:
+    rows = c.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels "
+                     "group by name order by 3 desc").fetchall()
+    tot = sum(r[2] for r in rows) or 1
+    with open(os.path.join(out, "kernel_stats.csv"), "w") as f:
+        f.write("Name,Calls,TotalDurationNs,AverageNs,MinNs,MaxNs,Percentage\n")
+        for r in rows:
+            f.write(f"\"{r[0]}\",{r[1]},{r[2]},{r[3]:.1f},{r[4]},{r[5]},{100.0 * r[2] / tot:.2f}\n")
+pmc = {}
+for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    c = db(name)
+    if not c:
+        continue
+    for k, cn, n, avg in c.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
+                                   "group by kernel_name, counter_name"):
+        pmc.setdefault(k, {})[cn] = {"launches": n, "avg": avg}
+summary = {"counters": pmc}
+try:
+    b = json.load(open(os.path.join(out, "bench_trace.json")))
+    kname = b["roofline"]["kernel"].split("<")[0]
+    for k, v in pmc.items():
+        if kname + "<" in k and "FETCH_SIZE" in v:
+            fetch_kb = v["FETCH_SIZE"]["avg"]
+            write_kb = v.get("WRITE_SIZE", {}).get("avg", 0.0)
+            # MI355X_MICROARCH.md (HBM): FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports exactly half of
+            # the bytes of a wide (16 B/lane) coalesced read stream -> doubled here; WRITE_SIZE is uncalibrated (tiny here)
+            summary.update({"kernel": b["roofline"]["kernel"], "method": {"P2P": 0, "GICP": 1, "VGICP": 2, "AVGICP": 3}[b["roofline"]["kernel"].split("<")[1].rstrip(">")],
+                            "batch": b["config"]["batch_per_gpu"], "scan_points": 131072,
+                            "fetch_size_kb_avg_raw": fetch_kb, "write_size_kb_avg": write_kb,
+                            "hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
+                            "launches": v["FETCH_SIZE"]["launches"],
+                            "algorithmic_bytes_per_launch": b["roofline"]["bytes_per_unit"] * b["roofline"]["units_per_launch"]})
+except Exception as e:  # noqa: BLE001
+    summary["error"] = repr(e)
+json.dump(summary, open(os.path.join(out, "pmc.json"), "w"), indent=1)
+print(json.dumps({k: v for k, v in summary.items() if k != "counters"}))
