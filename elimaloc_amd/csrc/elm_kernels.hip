@@ -853,6 +853,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_nbr(const DevMap m, const
         const int vx = floor_key(gx, m.voxel_size), vy = floor_key(gy, m.voxel_size), vz = floor_key(gz, m.voxel_size);
         // query-voxel probe
         unsigned start = 0, cnt = 0, nocc = 0;
+        double n_exact = 0.0;
         {
             unsigned h = hash3(vx, vy, vz) & m.qmask;
             for (;;) {
@@ -867,16 +868,56 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_nbr(const DevMap m, const
         double bd2 = DBL_MAX;
         int bj = -1;
         const int n = (int)cnt;
-        for (int j = 0; j < n; j += 8) {
+        // Pass 1, float32: best and second-best squared distance.  g is split into gh + gl (float32 each, gh + gl == g
+        // to ~2^-48), so (q - gh) - gl reproduces q - g to a few float32 ulps of |q - g| and the float32 distance is
+        // within ~5e-7 relative (+ a tiny absolute term) of the reference's float64 one.  When the runner-up is
+        // farther than that margin the float32 winner IS the float64 winner (it cannot even tie); otherwise -- exact
+        // or near ties, i.e. practically never -- the lane falls back to the full float64 walk below.
+        const float ghx = (float)gx, ghy = (float)gy, ghz = (float)gz;
+        const float glx = (float)(gx - (double)ghx), gly = (float)(gy - (double)ghy), glz = (float)(gz - (double)ghz);
+        float m1 = __builtin_inff(), m2 = __builtin_inff();
+        int j1 = -1;
+        int j = 0;
+        for (; j + 8 <= n; j += 8) {
             float4 q[8];
-            int jj[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { jj[u] = min(j + u, n - 1); q[u] = lp[jj[u]]; }
+            for (int u = 0; u < 8; ++u) q[u] = lp[j + u];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const double ex = (double)q[u].x - gx, ey = (double)q[u].y - gy, ez = (double)q[u].z - gz;
-                const double d2 = (ex * ex + ey * ey) + ez * ez;
-                if (d2 < bd2) { bd2 = d2; bj = jj[u]; } // in order, strict <; a clamped duplicate never beats itself
+                const float ex = (q[u].x - ghx) - glx, ey = (q[u].y - ghy) - gly, ez = (q[u].z - ghz) - glz;
+                const float d = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+                m2 = fminf(m2, fmaxf(d, m1));
+                const bool c = d < m1;
+                m1 = c ? d : m1;
+                j1 = c ? (j + u) : j1;
+            }
+        }
+        for (; j < n; ++j) {
+            const float4 q = lp[j];
+            const float ex = (q.x - ghx) - glx, ey = (q.y - ghy) - gly, ez = (q.z - ghz) - glz;
+            const float d = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+            m2 = fminf(m2, fmaxf(d, m1));
+            const bool c = d < m1;
+            m1 = c ? d : m1;
+            j1 = c ? j : j1;
+        }
+        if (j1 >= 0) {
+            const float slack = 4e-11f * (fabsf(ghx) + fabsf(ghy) + fabsf(ghz) + 1.0f);
+            const bool clear_winner = m2 > m1 + m1 * 1.9073486328125e-06f + slack; // 2^-19
+            if (clear_winner) {
+                const float4 q = lp[j1];
+                const double ex = (double)q.x - gx, ey = (double)q.y - gy, ez = (double)q.z - gz;
+                bd2 = (ex * ex + ey * ey) + ez * ez; // the reference's float64 value for the range test
+                bj = j1;
+            } else {
+                // exact walk (reference order, strict <)
+                for (int k = 0; k < n; ++k) {
+                    const float4 q = lp[k];
+                    const double ex = (double)q.x - gx, ey = (double)q.y - gy, ez = (double)q.z - gz;
+                    const double d2 = (ex * ex + ey * ey) + ez * ez;
+                    if (d2 < bd2) { bd2 = d2; bj = k; }
+                }
+                n_exact = 1.0;
             }
         }
         float bx = 0.f, by = 0.f, bz = 0.f;
@@ -889,7 +930,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_nbr(const DevMap m, const
         finish_point_pair<METHOD>(acc, m, S, rp, px, py, pz, gx, gy, gz, bd2, bx, by, bz, bidx);
         acc[29] = (double)cnt;
         acc[30] = (double)nocc;
-        acc[31] = (double)cnt;
+        acc[31] = (double)cnt + n_exact * kFallbackUnit; // high part: points that needed the exact float64 walk
     }
     block_reduce_store_lds(acc, s_buf, partials + (size_t)L * kSums);
 }

@@ -1,0 +1,41 @@
+// pcm_harness.cpp -- ROS-free replay of PcmMatching::Init + CallbackPointCloud's call sequence (pcm.cpp:81-101,
+// 238-299) through the drop-in shims.  Build: g++ -std=c++17 -Iinclude examples/pcm_harness.cpp
+//        -Lelimaloc_amd -lelimaloc_hip -Wl,-rpath,$PWD/elimaloc_amd -o pcm_harness ; needs an MI355X to run.
+#include <cmath>
+#include <cstdio>
+#include <random>
+
+#include "elimaloc/registration.hpp"
+
+int main() {
+    std::mt19937 rng(7);
+    std::uniform_real_distribution<float> jit(-0.004f, 0.004f);
+    std::vector<float> map_xyz;
+    for (int i = -200; i < 200; ++i)
+        for (int j = -200; j < 200; ++j) {
+            map_xyz.push_back((i + 0.5f) * 0.2f + jit(rng));
+            map_xyz.push_back((j + 0.5f) * 0.2f + jit(rng));
+            map_xyz.push_back(0.3f + jit(rng));
+        }
+    RegistrationConfig cfg;            // localization.ini defaults
+    cfg.icp_method = VGICP;
+    Registration registration_;
+    registration_.Init(cfg);
+    VoxelHashMap local_map_;
+    local_map_.Init(1.0, 30);          // pcm.cpp:87
+    local_map_.AddPoints(map_xyz.data(), map_xyz.size() / 3);
+    local_map_.CalVoxelCovAll();       // pcm.cpp:92-95
+    std::vector<PointStruct> scan;
+    for (size_t i = 0; i < map_xyz.size() / 3; i += 17) {
+        PointStruct p;
+        for (int k = 0; k < 3; ++k) p.pose[k] = p.local[k] = map_xyz[3 * i + k] - (k == 2 ? 1.8 : 0.0);
+        scan.push_back(p);
+    }
+    Matrix4dArr T0{{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0.08, -0.05, 1.8 + 0.03, 1}};
+    bool ok = false;
+    double fitness = 0.0;
+    Matrix6dArr cov;
+    Matrix4dArr T = registration_.RunRegister(scan, local_map_, T0, cfg, ok, fitness, cov); // pcm.cpp:280-282
+    std::printf("ok=%d fitness=%.4f t=(%.4f %.4f %.4f)\n", ok, fitness, T[12], T[13], T[14]);
+    return ok && std::fabs(T[12]) < 0.02 && std::fabs(T[13]) < 0.02 ? 0 : 1;
+}

@@ -66,6 +66,20 @@ int main(void) {
                          _lib.RegResult.is_success.offset, _lib.DeskewTables.vec_d_imu_time.offset]
 
 
+def test_cpp_shims_compile_and_link(L):
+    """The drop-in C++ shims (reference class names over the C ABI) and the ROS-free harness build with g++ and link
+    against the library (running them needs a GPU)."""
+    import subprocess
+    import tempfile
+    from elimaloc_amd import _lib
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "pcm_harness")
+        subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "examples", "pcm_harness.cpp"), "-L", os.path.dirname(_lib.LIB_PATH),
+                               "-lelimaloc_hip", "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH), "-o", exe])
+        assert os.path.exists(exe)
+
+
 def test_defaults_are_localization_ini(L):
     from elimaloc_amd.registration import RegistrationConfig, IcpMethod
     c = RegistrationConfig()

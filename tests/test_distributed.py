@@ -1,0 +1,128 @@
+"""N > 1 path on CPU: world_size-2 gloo processes run the sharded registration PROTOCOL -- contiguous scan shards, the
+32-double packed record per scan, ONE all-reduce per ICP iteration, gates evaluated after the reduce against n_total,
+pose recomputed redundantly and identically on every rank -- with the CPU oracle standing in for the per-shard
+accumulate kernel (the HIP kernels need a GPU; their own sharded path is covered by test_gpu_parity.py::
+test_sharded_hook_sums and by bench.py --gpus N on the MI355X node)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world_size, port, method, out_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from elimaloc_amd import synth
+    from elimaloc_amd.dist import shard_bounds, pack_sums, unpack_sums, PACKED_SUMS
+    from oracle import oracle as O
+    import np_ref
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    world = synth.make_world(20000, seed=5)
+    scans, T0s = [], []
+    for b in range(2):  # a batch of two scans, reduced together
+        sc, Tt = synth.make_scan(world, 3001 + 500 * b, seed=60 + b)
+        scans.append(sc)
+        T0s.append(synth.perturb(Tt, seed=70 + b, max_trans=0.2 + 0.2 * b, max_rot_deg=1.0))
+    m = O.Map(1.0, 30)
+    m.add_points(world)
+    if method in (2, 3):
+        m.cal_voxel_cov_all(2)
+    if method == 1:
+        m.cal_point_cov_all(0.4, 2)
+    cfg1 = O.default_config(method, max_iteration=1, min_overlap_ratio=0.0, max_fitness_score=1e300, max_thread=2)
+    full = O.default_config(method, max_thread=2)
+    B = len(scans)
+    T = [t.copy() for t in T0s]
+    done = [False] * B
+    iters = [0] * B
+    fitness = [0.0] * B
+    for it in range(full.max_iteration):
+        buf = np.zeros(B * PACKED_SUMS)
+        for b in range(B):
+            if done[b]:
+                continue
+            lo, hi = shard_bounds(len(scans[b]), rank, world_size)
+            if hi > lo:
+                r = O.register(m, scans[b][lo:hi], T[b], cfg1)["iters"][0]
+                if "JTJ" in r and r["n_corr"] > 0:
+                    buf[b * PACKED_SUMS:(b + 1) * PACKED_SUMS] = pack_sums(r["JTJ"], r["JTr"], r["residual_sum"], r["n_corr"])
+        t = torch.from_numpy(buf)
+        dist.all_reduce(t)  # ONE collective per ICP iteration for the whole batch
+        for b in range(B):
+            if done[b]:
+                continue
+            H, g, rs, n_corr = unpack_sums(buf[b * PACKED_SUMS:(b + 1) * PACKED_SUMS])
+            iters[b] += 1
+            if np.float32(n_corr) / np.float32(len(scans[b])) < full.min_overlap_ratio:  # gate on the WHOLE scan
+                done[b] = True
+                continue
+            fitness[b] = rs / n_corr
+            x = np.linalg.solve(H + full.lm_lambda * np.diag(np.diag(H)), g)
+            dT = np.eye(4); dT[:3, :3] = np_ref.exp_so3(x[3:]); dT[:3, 3] = x[:3]
+            T[b] = T[b] @ dT
+            if np_ref.rot_angle(dT[:3, :3]) + np.linalg.norm(x[:3]) < full.icp_termination_threshold_m:
+                done[b] = True
+        if all(done):
+            break
+    # every rank holds the same poses (bitwise: the all-reduced buffer is identical everywhere)
+    gathered = [None] * world_size
+    dist.all_gather_object(gathered, [t.tobytes() for t in T])
+    same = all(g == gathered[0] for g in gathered)
+    ref = [O.register(m, scans[b], T0s[b], full) for b in range(B)] if rank == 0 else None
+    if rank == 0:
+        out_q.put(dict(same=same, iters=iters, T=T, fitness=fitness,
+                       ref_iters=[r["iterations"] for r in ref], ref_T=[r["T"] for r in ref],
+                       ref_fitness=[r["fitness"] for r in ref]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("method", [0, 2])
+def test_sharded_protocol_world_size_2_gloo(method):
+    import torch.multiprocessing as mp
+    from elimaloc_amd import synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 400) + method
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, method, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res["same"]
+    assert res["iters"] == res["ref_iters"]
+    for T, Tr, f, fr in zip(res["T"], res["ref_T"], res["fitness"], res["ref_fitness"]):
+        dt, dr = synth.pose_error(Tr, T)
+        assert dt < 1e-9 and dr < 1e-10
+        assert abs(f - fr) < 1e-9
+
+
+def test_shard_bounds_partition():
+    from elimaloc_amd.dist import shard_bounds
+    for n in (0, 1, 7, 131072, 262144 + 5):
+        for w in (1, 2, 3, 8):
+            cuts = [shard_bounds(n, r, w) for r in range(w)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
+            assert max(hi - lo for lo, hi in cuts) - min(hi - lo for lo, hi in cuts) <= 1
+
+
+def test_pack_unpack_round_trip():
+    from elimaloc_amd.dist import pack_sums, unpack_sums, PACKED_SUMS
+    from elimaloc_amd import _lib
+    assert PACKED_SUMS == _lib.PACKED_SUMS == 32
+    rng = np.random.default_rng(0)
+    A = rng.normal(size=(6, 6)); H = A + A.T
+    g = rng.normal(size=6)
+    v = pack_sums(H, g, 3.5, 17.0)
+    H2, g2, rs, n = unpack_sums(v)
+    assert np.array_equal(H, H2) and np.array_equal(g, g2) and rs == 3.5 and n == 17.0

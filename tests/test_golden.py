@@ -1,0 +1,92 @@
+"""Committed golden vectors (tests/golden/golden_r01.npz, made by tests/golden/make_golden.py from the oracle).
+CPU: the oracle still reproduces them bit for bit.  GPU: the HIP path matches them without touching the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from elimaloc_amd import synth
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_r01.npz"))
+METHODS = ((0, "p2p"), (1, "gicp"), (2, "vgicp"), (3, "avgicp"))
+
+
+@pytest.mark.parametrize("method,name", METHODS)
+def test_oracle_reproduces_golden(oracle, method, name):
+    m = oracle.Map(1.0, 30)
+    m.add_points(G["world"])
+    if method in (2, 3):
+        m.cal_voxel_cov_all(3)
+    if method == 1:
+        m.cal_point_cov_all(0.4, 3)
+    r = oracle.register(m, G["scan"], G["T0"], oracle.default_config(method, max_thread=3))
+    assert [r["is_success"], r["iterations"], r["gate"]] == G[f"{name}_flags"].tolist()
+    assert np.array_equal(r["T"], G[f"{name}_T"])
+    assert np.array_equal(np.array([it["n_corr"] for it in r["iters"]]), G[f"{name}_ncorr"])
+    assert np.array_equal(np.array([it["JTJ"] for it in r["iters"]]), G[f"{name}_JTJ"])
+
+
+def test_oracle_map_and_deskew_golden(oracle):
+    m = oracle.Map(1.0, 30)
+    m.add_points(G["world"])
+    pts = m.pointcloud()[0]
+    assert np.array_equal(pts[np.lexsort(pts.T[::-1])].astype(np.float32), G["map_points_sorted"])
+    front = float(G["dk_time"][0]); scan_end = float(G["dk_stamp"][0]); scan_cur = scan_end + front
+    out = oracle.deskew_points(G["dk_xyz"], G["dk_time"] - np.float32(front), G["dk_tab_time"], G["dk_tab_rot"], scan_cur,
+                               scan_end, G["dk_incre"])
+    assert np.array_equal(out, G["dk_out"])
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from elimaloc_amd.registration import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,name", METHODS)
+def test_gpu_matches_golden(ctx, method, name):
+    from elimaloc_amd.registration import VoxelHashMap, Registration, RegistrationConfig, IcpMethod
+    vm = VoxelHashMap(1.0, 30, ctx)
+    vm.AddPoints(G["world"])
+    if method in (2, 3):
+        vm.CalVoxelCovAll()
+    if method == 1:
+        vm.CalPointCovAll(0.4)
+    pose, ok, fit, cov, det = Registration(RegistrationConfig(icp_method=IcpMethod(method)), ctx).RunRegister(
+        G["scan"], vm, G["T0"], trace=True)
+    assert [ok, det["iterations"], det["gate"]] == G[f"{name}_flags"].tolist()
+    assert np.array_equal(np.array([it["n_corr"] for it in det["iters"]]), G[f"{name}_ncorr"])
+    for k, it in enumerate(det["iters"]):
+        scale = np.abs(G[f"{name}_JTJ"][k]).max()
+        np.testing.assert_allclose(it["JTJ"], G[f"{name}_JTJ"][k], rtol=0, atol=1e-9 * scale)
+        np.testing.assert_allclose(it["T"], G[f"{name}_Titer"][k], rtol=0, atol=1e-9)
+    dt, dr = synth.pose_error(G[f"{name}_T"], pose)
+    assert dt <= 1e-4 and dr <= 1e-5  # north_star tolerance
+    np.testing.assert_allclose(cov, G[f"{name}_local_cov"], rtol=1e-7, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_gpu_map_deskew_c1_golden(ctx):
+    from elimaloc_amd.registration import VoxelHashMap, Registration, RegistrationConfig, IcpMethod
+    from elimaloc_amd.deskew import PcmDeskew
+    vm = VoxelHashMap(1.0, 30, ctx)
+    vm.AddPoints(G["world"])
+    pts = vm.Pointcloud()
+    assert np.array_equal(pts[np.lexsort(pts.T[::-1])].astype(np.float32), G["map_points_sorted"])
+    key, npts, _, _ = vm.Voxels()
+    kn = np.concatenate([key, npts[:, None]], axis=1)
+    assert np.array_equal(kn[np.lexsort(kn.T[::-1])], G["map_voxels_sorted"])
+    # C1: exactly 10 iterations
+    cfg = RegistrationConfig(icp_method=IcpMethod.P2P, icp_termination_threshold_m=0.0)
+    pose, ok, fit, cov, det = Registration(cfg, ctx).RunRegister(G["scan"], vm, G["T0"], trace=True)
+    assert det["iterations"] == int(G["c1_iterations"][0]) == 10
+    dt, dr = synth.pose_error(G["c1_T"], pose)
+    assert dt <= 1e-4 and dr <= 1e-5
+    # deskew
+    dk = PcmDeskew(ctx)
+    imu = np.concatenate([G["dk_imu_t"][:, None], G["dk_imu_w"]], axis=1)
+    ok, out = dk.DeskewPointCloud(G["dk_xyz"], G["dk_time"], float(G["dk_stamp"][0]), imu, G["dk_odom"])
+    assert ok and np.abs(out - G["dk_out"]).max() <= 2e-6

@@ -340,3 +340,27 @@ def test_full_size_properties(ctx, oracle):
     assert ref["iterations"] == a["iterations"]
     dt, dr = synth.pose_error(ref["T"], a["T"])
     assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
+
+
+def test_rccl_single_rank_allreduce_path(ctx, oracle, world100k):
+    """elm_comm_init with a 1-rank RCCL communicator: dlopen(librccl), ncclCommInitRank, and one
+    ncclAllReduce(double, sum) per ICP iteration between the reduce-only and solve-only launches.  (The multi-rank
+    protocol itself is covered on CPU by tests/test_distributed.py and on the 8-GPU node by bench.py --gpus N.)"""
+    from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, VoxelHashMap
+    c2 = Context(0)
+    try:
+        c2.comm_init(0, 1, Context.comm_unique_id())
+        vm = VoxelHashMap(1.0, 30, c2)
+        vm.AddPoints(world100k)
+        vm.CalVoxelCovAll()
+        om = oracle.Map(1.0, 30)
+        om.add_points(world100k)
+        om.cal_voxel_cov_all()
+        scan, T_true = synth.make_scan(world100k, 8192, seed=91)
+        T0 = synth.perturb(T_true, seed=92)
+        *_, det = Registration(RegistrationConfig(icp_method=IcpMethod.VGICP), c2).RunRegister(scan, vm, T0, trace=True)
+        ref = oracle.register(om, scan, T0, oracle.default_config(2))
+        _compare_run(det, ref)
+        c2.comm_destroy()
+    finally:
+        c2.close()
