@@ -56,13 +56,20 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency runs (profiling passes)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line: everything libraries print (RCCL banners, gloo notices) goes to stderr
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world_size > 1
+    # launched by torch.distributed.run (RANK set): take the collective path even for one rank, so that a 1-GPU box
+    # exercises exactly the code the 8-GPU node runs
+    distributed = world_size > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
     if args.gpus != world_size and distributed:
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world_size}")
     if not torch.cuda.is_available():
@@ -262,8 +269,10 @@ def main():
         }
         result["gpu_over_cpu"] = value / cpu_rate
 
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if distributed:
         ctx.comm_destroy()
         dist.destroy_process_group()

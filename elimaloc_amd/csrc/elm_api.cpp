@@ -488,6 +488,7 @@ extern "C" int elm_map_cal_voxel_cov_all(elm_map* m) {
         m->info.device_bytes += (size_t)m->dm.n_vox * 12 * sizeof(double);
     }
     if (m->dm.n_vox) {
+        (void)hipGetLastError(); // drop stale errors of other libraries (RCCL probes peer devices)
         launch_voxel_cov(ctx->stream, m->dm, m->d_ranges, m->d_vox_mean, m->d_vox_cov);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -509,6 +510,7 @@ extern "C" int elm_map_cal_point_cov_all(elm_map* m, double d_search_dist) {
         m->info.device_bytes += (size_t)m->dm.n_pts * 15 * sizeof(double);
     }
     if (m->dm.n_pts) {
+        (void)hipGetLastError();
         launch_point_cov(ctx->stream, m->dm, d_search_dist * d_search_dist, m->d_pt_mean, m->d_pt_cov, m->d_pt_nfit);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -575,6 +577,7 @@ extern "C" int elm_map_build_neighbourhoods(elm_map* m) {
     uint64_t total = 0;
     if (n_q) {
         NBR_CHK(hipMemcpy(d_qkeys, qkeys.data(), (size_t)n_q * 3 * sizeof(int32_t), hipMemcpyHostToDevice));
+        (void)hipGetLastError();
         launch_nbr_count(ctx->stream, m->dm, d_qkeys, n_q, d_counts, d_nocc);
         NBR_CHK(hipGetLastError());
         NBR_CHK(hipStreamSynchronize(ctx->stream));
@@ -593,6 +596,7 @@ extern "C" int elm_map_build_neighbourhoods(elm_map* m) {
     }
     NBR_CHK(hipMalloc((void**)&m->d_nbr_pts, std::max<size_t>((size_t)total * sizeof(float4), 256)));
     if (n_q) {
+        (void)hipGetLastError();
         launch_nbr_fill(ctx->stream, m->dm, d_qkeys, n_q, d_off, m->d_nbr_pts);
         NBR_CHK(hipGetLastError());
         NBR_CHK(hipStreamSynchronize(ctx->stream));
@@ -877,6 +881,7 @@ extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_
     }
     ScanState* st = (ScanState*)ctx->d_state.p;
     const ScanDesc* dsc = (const ScanDesc*)ctx->d_scans.p;
+    (void)hipGetLastError();
     launch_init_state(ctx->stream, st, (const double*)ctx->d_T0.p, batch, map_empty ? 1 : 0);
     const bool distributed = (ctx->comm != nullptr) || (ctx->hook != nullptr);
     ctx->events_used = 0;
@@ -1019,6 +1024,7 @@ extern "C" int elm_deskew(elm_ctx* ctx, const float* xyz, const float* rel_time,
     d.incre_x = tab->f_odom_incre_x; d.incre_y = tab->f_odom_incre_y; d.incre_z = tab->f_odom_incre_z;
     d._pad = 0.f;
     d.imu_time = d_tab; d.rot_x = d_tab + k; d.rot_y = d_tab + 2 * k; d.rot_z = d_tab + 3 * k;
+    (void)hipGetLastError();
     launch_deskew(ctx->stream, d_xyz, d_time, (uint32_t)n, d, d_out);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(xyz_out, d_out, n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));

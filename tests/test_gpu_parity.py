@@ -364,3 +364,49 @@ def test_rccl_single_rank_allreduce_path(ctx, oracle, world100k):
         c2.comm_destroy()
     finally:
         c2.close()
+
+
+def test_full_size_c3_gicp(ctx, oracle):
+    """BASELINE config C3 (GICP with per-point 3x3 covariances, 131072-pt scan vs 10M-pt map): the point-covariance
+    kernel over 10M points, the neighbourhood-list layout (270M entries), and the registration against the oracle run
+    on the part of the map the scan can reach."""
+    from elimaloc_amd.registration import Registration, RegistrationConfig, IcpMethod, VoxelHashMap
+    world = synth.make_world(10_000_000, seed=1001)
+    vm = VoxelHashMap(1.0, 30, ctx)
+    vm.AddPoints(world)
+    vm.CalPointCovAll(0.4)
+    scan, T_true = synth.make_scan(world, 131072, seed=2005)
+    T0 = synth.perturb(T_true, seed=3005)
+    pose, ok, fit, cov, det = Registration(RegistrationConfig(icp_method=IcpMethod.GICP), ctx).RunRegister(scan, vm, T0, trace=True)
+    info = vm.info()
+    assert info.nbr_entries > 26 * info.n_points  # 27 buckets per query voxel, built lazily by the first registration
+    near = world[np.linalg.norm(world[:, :2] - T_true[:2, 3], axis=1) < 75.0]
+    om = oracle.Map(1.0, 30)
+    om.add_points(near)
+    om.cal_point_cov_all(0.4)
+    ref = oracle.register(om, scan, T0, oracle.default_config(1))
+    _compare_run(det, ref)
+    np.testing.assert_allclose(cov, ref["local_cov"], rtol=1e-7, atol=1e-12)
+
+
+def test_full_size_c4_vgicp_shape(ctx, oracle):
+    """BASELINE config C4 sizes on ONE GPU (262144-pt scan vs 50M-pt map, VGICP; the 8-GPU sharding of the same call is
+    what bench.py --gpus 8 runs): map build + voxel covariances over 50M points, registration vs the oracle on the
+    reachable part of the map."""
+    from elimaloc_amd.registration import Registration, RegistrationConfig, IcpMethod, VoxelHashMap
+    world = synth.make_world(50_000_000, seed=1001)
+    vm = VoxelHashMap(1.0, 30, ctx)
+    vm.AddPoints(world)
+    vm.CalVoxelCovAll()
+    info = vm.info()
+    assert info.n_input_points == 50_000_000 and info.n_voxels > 1_600_000
+    scan, T_true = synth.make_scan(world, 262144, seed=2006)
+    T0 = synth.perturb(T_true, seed=3006)
+    pose, ok, fit, cov, det = Registration(RegistrationConfig(icp_method=IcpMethod.VGICP), ctx).RunRegister(scan, vm, T0, trace=True)
+    near = world[np.linalg.norm(world[:, :2] - T_true[:2, 3], axis=1) < 75.0]
+    del world
+    om = oracle.Map(1.0, 30)
+    om.add_points(near)
+    om.cal_voxel_cov_all()
+    ref = oracle.register(om, scan, T0, oracle.default_config(2))
+    _compare_run(det, ref)
