@@ -73,7 +73,9 @@ struct elm_ctx {
     hipStream_t stream = nullptr;
     std::string last_error;
     // scratch (grow-only; no allocation on the per-scan path after warm-up)
-    DevBuf d_scans, d_state, d_partials, d_sums, d_T0, d_trace, d_stage_pts;
+    DevBuf d_scans, d_state, d_partials, d_sums, d_T0, d_trace, d_stage_pts, d_active;
+    int* h_active = nullptr; // pinned: number of scans still iterating, read back at the early-stop checks
+    int iter_hint = 0;       // iterations the previous batch needed (0 = unknown): first early-stop check happens there
     void* h_state = nullptr; // pinned
     size_t h_state_cap = 0;
     void* h_trace = nullptr; // pinned
@@ -188,7 +190,8 @@ extern "C" void elm_ctx_destroy(elm_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm && g_rccl.comm_destroy) g_rccl.comm_destroy(ctx->comm);
-    DevBuf* bufs[] = {&ctx->d_scans, &ctx->d_state, &ctx->d_partials, &ctx->d_sums, &ctx->d_T0, &ctx->d_trace, &ctx->d_stage_pts};
+    DevBuf* bufs[] = {&ctx->d_scans, &ctx->d_state, &ctx->d_partials, &ctx->d_sums, &ctx->d_T0, &ctx->d_trace, &ctx->d_stage_pts, &ctx->d_active};
+    if (ctx->h_active) (void)hipHostFree(ctx->h_active);
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
@@ -881,8 +884,12 @@ extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_
     }
     ScanState* st = (ScanState*)ctx->d_state.p;
     const ScanDesc* dsc = (const ScanDesc*)ctx->d_scans.p;
+    if ((rc = dev_reserve(ctx, ctx->d_active, 256)) != ELM_OK) return rc;
+    if (!ctx->h_active) HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_active, 64, hipHostMallocDefault));
+    int* d_active = (int*)ctx->d_active.p;
+    HIPCHK(ctx, hipMemsetAsync(d_active, 0, sizeof(int), ctx->stream));
     (void)hipGetLastError();
-    launch_init_state(ctx->stream, st, (const double*)ctx->d_T0.p, batch, map_empty ? 1 : 0);
+    launch_init_state(ctx->stream, st, (const double*)ctx->d_T0.p, batch, map_empty ? 1 : 0, d_active);
     const bool distributed = (ctx->comm != nullptr) || (ctx->hook != nullptr);
     ctx->events_used = 0;
     if (!map_empty) {
@@ -895,11 +902,21 @@ extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_
             }
             if ((rc = prof_mark(ctx)) != ELM_OK) return rc;
             if (distributed) {
-                launch_solve(ctx->stream, dsc, batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 1);
+                launch_solve(ctx->stream, dsc, batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 1, d_active);
                 if ((rc = exchange(ctx, (double*)ctx->d_sums.p, (size_t)batch * kSums)) != ELM_OK) return rc;
-                launch_solve(ctx->stream, dsc, batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 2);
+                launch_solve(ctx->stream, dsc, batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 2, d_active);
             } else {
-                launch_solve(ctx->stream, dsc, batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 0);
+                launch_solve(ctx->stream, dsc, batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 0, d_active);
+            }
+            // Early stop: every scan of the batch has met the reference's termination rule (or a gate).  The counter is
+            // derived from the (all-reduced) sums, so every rank reads the same value and stops at the same iteration.
+            // The first check is placed where the previous batch finished; an unknown history never checks.
+            const int done_iters = it + 1;
+            if (ctx->iter_hint > 0 && done_iters >= ctx->iter_hint && done_iters < cfg->max_iteration &&
+                ((done_iters - ctx->iter_hint) % 2) == 0) {
+                HIPCHK(ctx, hipMemcpyAsync(ctx->h_active, d_active, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                if (*ctx->h_active == 0) break;
             }
         }
         if ((rc = prof_mark(ctx)) != ELM_OK) return rc;
@@ -950,6 +967,11 @@ extern "C" int elm_register_batch_finish(elm_ctx* ctx, elm_reg_result* results, 
         if (ctx->rp.max_iter <= 0 && hs[b].gate == 0) { // no iteration ran: fitness gate on the initial 0.0 passes
             r.is_success = 1;
         }
+    }
+    {
+        int mx = 0;
+        for (int b = 0; b < ctx->batch; ++b) mx = std::max(mx, (int)hs[b].iters);
+        ctx->iter_hint = mx; // where the next batch's first early-stop check goes
     }
     if (trace && ctx->want_trace)
         memcpy(trace, ctx->h_trace, (size_t)ctx->batch * ELM_MAX_ITER_TRACE * sizeof(elm_iter_trace));

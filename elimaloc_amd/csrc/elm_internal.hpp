@@ -90,12 +90,12 @@ constexpr int kSums = ELM_PACKED_SUMS; // 21 + 6 + 1 + 1 (+ n_cand, n_occ, pad)
 
 // ---- launchers (elm_kernels.hip) ----------------------------------------------------------------------
 int debug_phase_cycles(unsigned long long* out16, int reset); // 1 when built with -DELM_PHASE_TIMING
-void launch_init_state(hipStream_t s, ScanState* st, const double* T0, int batch, int map_empty);
+void launch_init_state(hipStream_t s, ScanState* st, const double* T0, int batch, int map_empty, int* active);
 void launch_accumulate(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                        ScanState* st, double* partials, const RegParams& rp, int direct);
 // mode 0: reduce + solve (single GPU); 1: reduce only -> sums; 2: solve only from sums
 void launch_solve(hipStream_t s, const ScanDesc* scans, int batch, ScanState* st, const double* partials,
-                  double* sums, const RegParams& rp, elm_iter_trace* trace, int mode);
+                  double* sums, const RegParams& rp, elm_iter_trace* trace, int mode, int* active);
 void launch_accumulate_nbr(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                            ScanState* st, double* partials, const RegParams& rp);
 void launch_nbr_count(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, uint32_t* counts, uint32_t* nocc);

@@ -984,9 +984,11 @@ __device__ void update_inverse(ScanState& S) {
         S.tinv[r] = -((S.Rinv[r * 3] * S.T[12] + S.Rinv[r * 3 + 1] * S.T[13]) + S.Rinv[r * 3 + 2] * S.T[14]);
 }
 
-__global__ __launch_bounds__(64) void k_init_state(ScanState* st, const double* __restrict__ T0, int batch, int map_empty) {
+__global__ __launch_bounds__(64) void k_init_state(ScanState* st, const double* __restrict__ T0, int batch, int map_empty,
+                                                   int* active) {
     const int s = blockIdx.x * 64 + threadIdx.x;
     if (s >= batch) return;
+    if (!map_empty) atomicAdd(active, 1); // scans still iterating (the host zeroed the counter)
     ScanState& S = st[s];
     for (int k = 0; k < 16; ++k) S.T[k] = T0[(size_t)s * 16 + k];
     update_inverse(S);
@@ -1003,7 +1005,7 @@ __global__ __launch_bounds__(64) void k_init_state(ScanState* st, const double* 
 constexpr int kSolveThreads = 256;
 __global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* __restrict__ scans, ScanState* st,
                                                          const double* __restrict__ partials, double* sums,
-                                                         const RegParams rp, elm_iter_trace* trace, int mode) {
+                                                         const RegParams rp, elm_iter_trace* trace, int mode, int* active) {
     const int s = blockIdx.x;
     ScanState& S = st[s];
     const int t = threadIdx.x;
@@ -1062,6 +1064,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* __restr
     }
     if ((double)ratio_f < rp.min_overlap) { // reg.cpp:352-356: fail, return the current pose, fitness untouched
         S.done = 1;
+        atomicSub(active, 1);
         S.success = 0;
         S.gate = 2;
         return;
@@ -1106,6 +1109,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* __restr
     }
     if (step < rp.term_thr || iter >= rp.max_iter) { // reg.cpp:385-387 / loop end
         S.done = 1;
+        atomicSub(active, 1);
         const bool bad = S.fitness > rp.max_fitness; // reg.cpp:405-409 (NaN compares false, like the reference)
         S.success = bad ? 0 : 1;
         S.gate = bad ? 3 : 0;
@@ -1276,8 +1280,8 @@ int debug_phase_cycles(unsigned long long* out16, int reset) {
 #endif
 }
 
-void launch_init_state(hipStream_t s, ScanState* st, const double* T0, int batch, int map_empty) {
-    hipLaunchKernelGGL(k_init_state, dim3((batch + 63) / 64), dim3(64), 0, s, st, T0, batch, map_empty);
+void launch_init_state(hipStream_t s, ScanState* st, const double* T0, int batch, int map_empty, int* active) {
+    hipLaunchKernelGGL(k_init_state, dim3((batch + 63) / 64), dim3(64), 0, s, st, T0, batch, map_empty, active);
 }
 
 void launch_accumulate(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
@@ -1319,8 +1323,8 @@ void launch_nbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint3
 }
 
 void launch_solve(hipStream_t s, const ScanDesc* scans, int batch, ScanState* st, const double* partials,
-                  double* sums, const RegParams& rp, elm_iter_trace* trace, int mode) {
-    hipLaunchKernelGGL(k_solve, dim3(batch), dim3(kSolveThreads), 0, s, scans, st, partials, sums, rp, trace, mode);
+                  double* sums, const RegParams& rp, elm_iter_trace* trace, int mode, int* active) {
+    hipLaunchKernelGGL(k_solve, dim3(batch), dim3(kSolveThreads), 0, s, scans, st, partials, sums, rp, trace, mode, active);
 }
 
 void launch_voxel_cov(hipStream_t s, const DevMap& m, const uint2* ranges, double* vox_mean, double* vox_cov) {
