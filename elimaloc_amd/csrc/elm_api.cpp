@@ -249,7 +249,8 @@ struct elm_map {
     double *d_vox_mean = nullptr, *d_vox_cov = nullptr;
     double *d_pt_mean = nullptr, *d_pt_cov = nullptr, *d_pt_nfit = nullptr;
     HashSlot* d_qslots = nullptr;
-    float4* d_nbr_pts = nullptr;
+    Pt3* d_nbr_pts = nullptr;
+    uint32_t* d_nbr_idx = nullptr;
     bool has_nbr = false;
     std::vector<int32_t> h_keys;
     std::vector<uint2> h_ranges;
@@ -402,7 +403,7 @@ static void build_host(const float* xyz, size_t n, double voxel_size, int max_po
 static void map_free(elm_map* m) {
     if (!m) return;
     (void)hipSetDevice(m->ctx->device);
-    void* ptrs[] = {m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_pt_mean, m->d_pt_cov, m->d_pt_nfit, m->d_qslots, m->d_nbr_pts};
+    void* ptrs[] = {m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_pt_mean, m->d_pt_cov, m->d_pt_nfit, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete m;
@@ -597,10 +598,11 @@ extern "C" int elm_map_build_neighbourhoods(elm_map* m) {
         }
         NBR_CHK(hipMemcpy(d_off, offs.data(), (size_t)n_q * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
-    NBR_CHK(hipMalloc((void**)&m->d_nbr_pts, std::max<size_t>((size_t)total * sizeof(float4), 256)));
+    NBR_CHK(hipMalloc((void**)&m->d_nbr_pts, std::max<size_t>((size_t)total * sizeof(Pt3), 256)));
+    NBR_CHK(hipMalloc((void**)&m->d_nbr_idx, std::max<size_t>((size_t)total * sizeof(uint32_t), 256)));
     if (n_q) {
         (void)hipGetLastError();
-        launch_nbr_fill(ctx->stream, m->dm, d_qkeys, n_q, d_off, m->d_nbr_pts);
+        launch_nbr_fill(ctx->stream, m->dm, d_qkeys, n_q, d_off, m->d_nbr_pts, m->d_nbr_idx);
         NBR_CHK(hipGetLastError());
         NBR_CHK(hipStreamSynchronize(ctx->stream));
     }
@@ -624,8 +626,9 @@ extern "C" int elm_map_build_neighbourhoods(elm_map* m) {
     m->dm.qmask = qcap - 1;
     m->dm.n_q = n_q;
     m->dm.nbr_pts = m->d_nbr_pts;
+    m->dm.nbr_idx = m->d_nbr_idx;
     m->has_nbr = true;
-    m->info.device_bytes += (size_t)total * sizeof(float4) + (size_t)qcap * sizeof(HashSlot);
+    m->info.device_bytes += (size_t)total * (sizeof(Pt3) + sizeof(uint32_t)) + (size_t)qcap * sizeof(HashSlot);
     m->info.n_query_voxels = n_q;
     m->info.nbr_entries = total;
     return ELM_OK;

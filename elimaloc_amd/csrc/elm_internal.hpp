@@ -18,6 +18,10 @@ struct __attribute__((aligned(32))) HashSlot {
     uint32_t pad0, pad1;
 };
 
+struct Pt3 { // 12-byte candidate of the neighbourhood lists
+    float x, y, z;
+};
+
 struct DevMap {
     const HashSlot* slots;
     uint32_t mask; // capacity - 1 (capacity is a power of two >= 4 * n_voxels)
@@ -37,7 +41,8 @@ struct DevMap {
     const HashSlot* qslots; // key = query voxel, vid = query id, start/cnt = its list, pad0 = occupied neighbours
     uint32_t qmask;
     uint32_t n_q;
-    const float4* nbr_pts;  // xyz + bit-cast global point index
+    const Pt3* nbr_pts;       // candidate coordinates, 12 bytes each
+    const uint32_t* nbr_idx;  // global point index of every candidate (read only for a GICP winner)
 };
 
 __host__ __device__ __forceinline__ uint32_t hash3(int32_t x, int32_t y, int32_t z) {
@@ -99,7 +104,8 @@ void launch_solve(hipStream_t s, const ScanDesc* scans, int batch, ScanState* st
 void launch_accumulate_nbr(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                            ScanState* st, double* partials, const RegParams& rp);
 void launch_nbr_count(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, uint32_t* counts, uint32_t* nocc);
-void launch_nbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets, float4* out);
+void launch_nbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets, Pt3* out,
+                     uint32_t* out_idx);
 void launch_voxel_cov(hipStream_t s, const DevMap& m, const uint2* ranges, double* vox_mean, double* vox_cov);
 void launch_point_cov(hipStream_t s, const DevMap& m, double d2max, double* pt_mean, double* pt_cov, double* pt_nfit);
 

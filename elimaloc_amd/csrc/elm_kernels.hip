@@ -864,7 +864,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_nbr(const DevMap m, const
                 h = (h + 1) & m.qmask;
             }
         }
-        const float4* __restrict__ lp = m.nbr_pts + start;
+        const Pt3* __restrict__ lp = m.nbr_pts + start;
         double bd2 = DBL_MAX;
         int bj = -1;
         const int n = (int)cnt;
@@ -879,7 +879,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_nbr(const DevMap m, const
         int j1 = -1;
         int j = 0;
         for (; j + 8 <= n; j += 8) {
-            float4 q[8];
+            Pt3 q[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) q[u] = lp[j + u];
 #pragma unroll
@@ -893,7 +893,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_nbr(const DevMap m, const
             }
         }
         for (; j < n; ++j) {
-            const float4 q = lp[j];
+            const Pt3 q = lp[j];
             const float ex = (q.x - ghx) - glx, ey = (q.y - ghy) - gly, ez = (q.z - ghz) - glz;
             const float d = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
             m2 = fminf(m2, fmaxf(d, m1));
@@ -905,14 +905,14 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_nbr(const DevMap m, const
             const float slack = 4e-11f * (fabsf(ghx) + fabsf(ghy) + fabsf(ghz) + 1.0f);
             const bool clear_winner = m2 > m1 + m1 * 1.9073486328125e-06f + slack; // 2^-19
             if (clear_winner) {
-                const float4 q = lp[j1];
+                const Pt3 q = lp[j1];
                 const double ex = (double)q.x - gx, ey = (double)q.y - gy, ez = (double)q.z - gz;
                 bd2 = (ex * ex + ey * ey) + ez * ez; // the reference's float64 value for the range test
                 bj = j1;
             } else {
                 // exact walk (reference order, strict <)
                 for (int k = 0; k < n; ++k) {
-                    const float4 q = lp[k];
+                    const Pt3 q = lp[k];
                     const double ex = (double)q.x - gx, ey = (double)q.y - gy, ez = (double)q.z - gz;
                     const double d2 = (ex * ex + ey * ey) + ez * ez;
                     if (d2 < bd2) { bd2 = d2; bj = k; }
@@ -923,9 +923,9 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_nbr(const DevMap m, const
         float bx = 0.f, by = 0.f, bz = 0.f;
         int bidx = -1;
         if (bj >= 0) {
-            const float4 q = lp[bj];
+            const Pt3 q = lp[bj];
             bx = q.x; by = q.y; bz = q.z;
-            bidx = (int)__float_as_uint(q.w);
+            bidx = (METHOD == ELM_GICP) ? (int)m.nbr_idx[(size_t)start + bj] : 0; // payload lookup only for GICP
         }
         finish_point_pair<METHOD>(acc, m, S, rp, px, py, pz, gx, gy, gz, bd2, bx, by, bz, bidx);
         acc[29] = (double)cnt;
@@ -952,7 +952,8 @@ __global__ __launch_bounds__(256) void k_nbr_count(const DevMap m, const int32_t
     nocc[q] = o;
 }
 __global__ __launch_bounds__(256) void k_nbr_fill(const DevMap m, const int32_t* __restrict__ qkeys, unsigned n_q,
-                                                  const unsigned* __restrict__ offsets, float4* __restrict__ out) {
+                                                  const unsigned* __restrict__ offsets, Pt3* __restrict__ out,
+                                                  unsigned* __restrict__ out_idx) {
     const unsigned q = (blockIdx.x * blockDim.x + threadIdx.x) >> 5; // one 32-lane group per query voxel
     const unsigned l = threadIdx.x & 31;
     if (q >= n_q) return;
@@ -964,9 +965,10 @@ __global__ __launch_bounds__(256) void k_nbr_fill(const DevMap m, const int32_t*
                 const Probe pr = probe_voxel(m, vx + dx, vy + dy, vz + dz);
                 if (pr.vid < 0) continue;
                 for (unsigned j = l; j < pr.cnt; j += 32) {
-                    float4 p = m.pts[pr.start + j];
-                    p.w = __uint_as_float(pr.start + j);
-                    out[(size_t)o + j] = p;
+                    const float4 p = m.pts[pr.start + j];
+                    Pt3 t; t.x = p.x; t.y = p.y; t.z = p.z;
+                    out[(size_t)o + j] = t;
+                    out_idx[(size_t)o + j] = pr.start + j;
                 }
                 o += pr.cnt;
             }
@@ -1317,9 +1319,10 @@ void launch_accumulate_nbr(hipStream_t s, const DevMap& m, const ScanDesc* scans
 void launch_nbr_count(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, uint32_t* counts, uint32_t* nocc) {
     hipLaunchKernelGGL(k_nbr_count, dim3((n_q + 255) / 256), dim3(256), 0, s, m, qkeys, n_q, counts, nocc);
 }
-void launch_nbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets, float4* out) {
+void launch_nbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets, Pt3* out,
+                     uint32_t* out_idx) {
     const uint64_t threads = (uint64_t)n_q * 32;
-    hipLaunchKernelGGL(k_nbr_fill, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, m, qkeys, n_q, offsets, out);
+    hipLaunchKernelGGL(k_nbr_fill, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, m, qkeys, n_q, offsets, out, out_idx);
 }
 
 void launch_solve(hipStream_t s, const ScanDesc* scans, int batch, ScanState* st, const double* partials,
