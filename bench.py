@@ -164,7 +164,7 @@ def main():
             pm = json.load(open(pmc_path))
             if (pm.get("method") == int(method) and pm.get("batch") == args.batch and pm.get("scan_points") == args.scan_points
                     and pm.get("kernel") == kernel_name):
-                traffic = pm.get("hbm_bytes_per_launch")
+                traffic = pm.get("hbm_bytes_per_unit") * units_per_launch  # measured HBM bytes per unit x this run's units
         except Exception:
             traffic = None
 

@@ -43,6 +43,10 @@ try:
                             "fetch_size_kb_avg_raw": fetch_kb, "write_size_kb_avg": write_kb,
                             "hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
                             "launches": v["FETCH_SIZE"]["launches"],
+                            # traffic per unit of work (scan point x iteration): launch mixes differ between runs (early-exit
+                            # launches move no data), so bench.py scales this by ITS units per launch
+                            "units_per_launch_profiled": b["roofline"]["units_per_launch"],
+                            "hbm_bytes_per_unit": (2.0 * fetch_kb + write_kb) * 1024.0 / max(b["roofline"]["units_per_launch"], 1.0),
                             "algorithmic_bytes_per_launch": b["roofline"]["bytes_per_unit"] * b["roofline"]["units_per_launch"]})
 except Exception as e:  # noqa: BLE001
     summary["error"] = repr(e)
