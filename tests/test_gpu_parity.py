@@ -410,3 +410,30 @@ def test_full_size_c4_vgicp_shape(ctx, oracle):
     om.cal_voxel_cov_all()
     ref = oracle.register(om, scan, T0, oracle.default_config(2))
     _compare_run(det, ref)
+
+
+@pytest.mark.parametrize("kernel_env", ["nbr", "staged", "direct"])
+@pytest.mark.parametrize("voxel_size,max_pts,th,method", [
+    (0.5, 30, 5.0, 0),    # finer voxels
+    (1.5, 50, 5.0, 1),    # README-recommended 50 points per voxel (buckets > 32 points), GICP
+    (1.0, 30, 0.6, 0),    # tight search radius: the range test rejects many pairs
+    (1.0, 30, 12.0, 2),   # th > 9: VGICP's `w < 0.01 -> continue` branch is live (reg.cpp:201)
+    (2.0, 8, 5.0, 3),     # coarse voxels, tiny capacity, AVGICP
+    (0.7, 30, 5.0, 2),    # voxel size that is not exactly representable
+])
+def test_config_variants(oracle, world100k, voxel_size, max_pts, th, method, kernel_env, monkeypatch):
+    """Non-default map / registration parameters, on every accumulate kernel generation (ELM_KERNEL)."""
+    from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod
+    monkeypatch.setenv("ELM_KERNEL", kernel_env)
+    c = Context(0)  # the kernel mode is read at context creation
+    try:
+        m = IcpMethod(method)
+        vm, om = _maps(c, oracle, world100k, m, voxel_size=voxel_size, max_pts=max_pts, cov_dist=0.4)
+        scan, T_true = synth.make_scan(world100k, 6000, seed=300 + method)
+        T0 = synth.perturb(T_true, seed=400 + method, max_trans=0.25, max_rot_deg=1.0)
+        cfg = RegistrationConfig(icp_method=m, max_search_dist=th, max_iteration=14)
+        *_, det = Registration(cfg, c).RunRegister(scan, vm, T0, trace=True)
+        ref = oracle.register(om, scan, T0, oracle.default_config(method, max_search_dist=th, max_iteration=14))
+        _compare_run(det, ref)
+    finally:
+        c.close()
