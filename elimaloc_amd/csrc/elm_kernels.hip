@@ -1004,7 +1004,105 @@ __global__ __launch_bounds__(64) void k_init_state(ScanState* st, const double* 
     S.iters = 0;
 }
 
-constexpr int kSolveThreads = 256;
+// Wave-parallel 6x6 LDL^T with diagonal pivoting (the pivot rule of Eigen's LDLT: largest |diagonal| of the trailing
+// Schur complement, symmetric exchange), right-looking, on a matrix spread over lanes: lane l < 36 holds A[l/6][l%6].
+// All 64 lanes execute it with uniform control flow.  Returns x = A^-1 b (uniform in every lane) and, when want_inv,
+// leaves A^-1[l/6][l%6] in `inv_elem` of lane l < 36.  ~3 us instead of ~25 us for the single-lane version.
+__device__ __forceinline__ void wave_ldlt6(double a, const double* b, double x[6], bool want_inv, double& inv_elem) {
+    const int lane = threadIdx.x & 63;
+    const int li = (lane < 36) ? lane / 6 : 0, lj = (lane < 36) ? lane % 6 : 0;
+    unsigned active = 0x3Fu;
+    int order[6];
+    double piv[6];
+    int rank_i = 6, rank_j = 6, rank_l = 6; // elimination step of row li / column lj / index `lane` (lane < 6)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        int p = 0;
+        double best = -1.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const double di = __shfl(a, i * 7, 64);
+            if (((active >> i) & 1u) && fabs(di) > best) { best = fabs(di); p = i; }
+        }
+        const double dp = __shfl(a, p * 7, 64);
+        const double aip = __shfl(a, li * 6 + p, 64), apj = __shfl(a, p * 6 + lj, 64);
+        const bool ai = ((active >> li) & 1u) && li != p, aj = ((active >> lj) & 1u) && lj != p;
+        if (dp != 0.0) {
+            const double lip = aip / dp;
+            if (ai && aj) a -= lip * apj;      // Schur complement of the remaining block
+            else if (ai && lj == p) a = lip;   // column p below/right of the pivot now holds L[i][p]
+            else if (li == p && aj) a = apj / dp;
+        } else {
+            if ((ai && lj == p) || (li == p && aj)) a = 0.0;
+        }
+        order[k] = p;
+        piv[k] = dp;
+        active &= ~(1u << p);
+        if (li == p) rank_i = k;
+        if (lj == p) rank_j = k;
+        if (lane == p) rank_l = k;
+    }
+    (void)rank_j;
+    // ---- solve A x = b with lanes 0..5 holding the vector
+    double y = (lane < 6) ? b[lane] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { // forward: L y' = P b
+        const int p = order[k];
+        const double yp = __shfl(y, p, 64);
+        const double lip = __shfl(a, (lane < 6 ? lane : 0) * 6 + p, 64);
+        if (lane < 6 && rank_l > k) y -= lip * yp;
+    }
+    {
+        double d = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d = (rank_l == k) ? piv[k] : d;
+        y = (fabs(d) > 5.6e-309) ? y / d : 0.0; // Eigen zeroes the components of (numerically) zero pivots
+    }
+#pragma unroll
+    for (int k = 5; k >= 0; --k) { // backward: L^T x = y
+        const int p = order[k];
+        const double lip = __shfl(a, (lane < 6 ? lane : 0) * 6 + p, 64);
+        double c = (lane < 6 && rank_l > k) ? lip * y : 0.0;
+        c += __shfl_xor(c, 1, 64);
+        c += __shfl_xor(c, 2, 64);
+        c += __shfl_xor(c, 4, 64);
+        const double tot = __shfl(c, 0, 64);
+        if (lane == p) y -= tot;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x[i] = __shfl(y, i, 64);
+    // ---- inverse: the same substitutions on the six unit vectors, one matrix element per lane
+    inv_elem = 0.0;
+    if (want_inv) {
+        double Y = (lane < 36 && li == lj) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int p = order[k];
+            const double ypc = __shfl(Y, p * 6 + lj, 64);
+            const double lip = __shfl(a, li * 6 + p, 64);
+            if (lane < 36 && rank_i > k) Y -= lip * ypc;
+        }
+        {
+            double d = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) d = (rank_i == k) ? piv[k] : d;
+            Y = (fabs(d) > 5.6e-309) ? Y / d : 0.0;
+        }
+#pragma unroll
+        for (int k = 5; k >= 0; --k) {
+            const int p = order[k];
+            const double lip = __shfl(a, li * 6 + p, 64);
+            const double c = (lane < 36 && rank_i > k) ? lip * Y : 0.0;
+            double colsum = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) colsum += __shfl(c, i * 6 + lj, 64);
+            if (lane < 36 && li == p) Y -= colsum;
+        }
+        inv_elem = Y;
+    }
+}
+
+constexpr int kSolveThreads = 1024;
 __global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* __restrict__ scans, ScanState* st,
                                                          const double* __restrict__ partials, double* sums,
                                                          const RegParams rp, elm_iter_trace* trace, int mode, int* active) {
@@ -1015,13 +1113,22 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* __restr
     __shared__ double part[kSolveThreads / 32][kSums];
     const bool done = S.done != 0;
     if (mode != 2) {
-        // deterministic reduction of this scan's per-workgroup partial sums: 8 strided groups of 32 lanes read whole
-        // 256-byte records, then the 8 group sums are added in a fixed order
+        // deterministic reduction of this scan's per-workgroup partial sums: 32 strided groups of 32 lanes read whole
+        // 256-byte records (four independent loads in flight per lane), then the group sums are added in a fixed order
         const int k = t & 31, g = t >> 5;
+        constexpr unsigned G = kSolveThreads / 32;
         double v = 0.0;
         if (!done) {
             const ScanDesc sd = scans[s];
-            for (unsigned b = sd.blk_begin + g; b < sd.blk_end; b += kSolveThreads / 32) v += partials[(size_t)b * kSums + k];
+            unsigned b = sd.blk_begin + g;
+            double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+            for (; b + 3 * G < sd.blk_end; b += 4 * G) {
+                const double a0 = partials[(size_t)b * kSums + k], a1 = partials[(size_t)(b + G) * kSums + k];
+                const double a2 = partials[(size_t)(b + 2 * G) * kSums + k], a3 = partials[(size_t)(b + 3 * G) * kSums + k];
+                v0 += a0; v1 += a1; v2 += a2; v3 += a3;
+            }
+            for (; b < sd.blk_end; b += G) v0 += partials[(size_t)b * kSums + k];
+            v = (v0 + v1) + (v2 + v3);
         }
         part[g][k] = v;
         __syncthreads();
@@ -1037,17 +1144,18 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* __restr
         if (t < 32) tot[t] = sums[(size_t)s * kSums + t];
     }
     __syncthreads();
-    if (done || t != 0) return;
+    if (done || t >= 64) return; // the first wave does the rest with uniform control flow; lane 0 owns the state
+    const bool lead = (t == 0);
 
     const ScanDesc sd = scans[s];
-    S.iters += 1; // i_iteration++ (reg.cpp:311)
-    const int iter = S.iters;
+    const int iter = S.iters + 1; // i_iteration++ (reg.cpp:311)
     const double n_corr = tot[28];
-    S.n_corr_last = n_corr;
-    S.pt_iters += (double)sd.n_total;
-    S.cand_total += tot[29];
-    S.occ_total += tot[30];
-    {
+    if (lead) {
+        S.iters = iter;
+        S.n_corr_last = n_corr;
+        S.pt_iters += (double)sd.n_total;
+        S.cand_total += tot[29];
+        S.occ_total += tot[30];
         const double fb = floor(tot[31] / 1099511627776.0);
         S.fallback_blocks += fb;
         S.tested_total += tot[31] - fb * 1099511627776.0;
@@ -1056,38 +1164,32 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* __restr
 
     // corres_ratio = (float)i_source_corr_num / i_source_total_num (reg.cpp:351): float division, compared as double
     const float ratio_f = (float)n_corr / (float)sd.n_total;
-    if (tr) {
-        for (int k = 0; k < 36; ++k) tr->JTJ[k] = 0.0;
-        for (int k = 0; k < 6; ++k) { tr->JTr[k] = 0.0; tr->x[k] = 0.0; }
-        tr->residual_sum = tot[27];
-        tr->n_corr = n_corr;
-        tr->step_norm = 0.0;
-        for (int k = 0; k < 16; ++k) tr->T[k] = S.T[k];
-    }
     if ((double)ratio_f < rp.min_overlap) { // reg.cpp:352-356: fail, return the current pose, fitness untouched
-        S.done = 1;
-        atomicSub(active, 1);
-        S.success = 0;
-        S.gate = 2;
+        if (lead) {
+            if (tr) {
+                for (int k = 0; k < 36; ++k) tr->JTJ[k] = 0.0;
+                for (int k = 0; k < 6; ++k) { tr->JTr[k] = 0.0; tr->x[k] = 0.0; }
+                tr->residual_sum = tot[27];
+                tr->n_corr = n_corr;
+                tr->step_norm = 0.0;
+                for (int k = 0; k < 16; ++k) tr->T[k] = S.T[k];
+            }
+            S.done = 1;
+            atomicSub(active, 1);
+            S.success = 0;
+            S.gate = 2;
+        }
         return;
     }
-    S.fitness = tot[27] / n_corr; // d_fitness_score_ = d_residual_sum / source_global.size()
+    const double fitness = tot[27] / n_corr; // d_fitness_score_ = d_residual_sum / source_global.size()
 
-    // working arrays live in LDS (dynamic indexing in registers would spill to scratch)
-    __shared__ double ws_H[36], ws_Hd[36], ws_m[36], ws_b[6], ws_x[6], ws_misc[32];
-    double* H = ws_H; double* b = ws_b;
-    for (int i = 0; i < 6; ++i)
-        for (int j = i; j < 6; ++j) {
-            H[i * 6 + j] = tot[tri(i, j)];
-            H[j * 6 + i] = tot[tri(i, j)];
-        }
-    for (int i = 0; i < 6; ++i) b[i] = tot[21 + i];
-    double* Hd = ws_Hd;
-    for (int k = 0; k < 36; ++k) Hd[k] = H[k];
-    for (int i = 0; i < 6; ++i) Hd[i * 7] = H[i * 7] + rp.lm_lambda * H[i * 7]; // JTJ + lambda * diag(JTJ)
-    double* x = ws_x;
-    ldlt_solve6_ws(Hd, b, x, ws_m, ws_misc);
-    if (rp.method == ELM_GICP) inv6_ws(Hd, S.local_cov, ws_m); // reg.cpp:141-142
+    // JTJ + lambda * diag(JTJ), one element per lane (reg.cpp:55-56 / 136-138 / 213-214)
+    const int li = (t < 36) ? t / 6 : 0, lj = (t < 36) ? t % 6 : 0;
+    const double hij = tot[tri(li < lj ? li : lj, li < lj ? lj : li)];
+    const double a = (li == lj) ? hij + rp.lm_lambda * hij : hij;
+    double x[6], inv_elem;
+    wave_ldlt6(a, &tot[21], x, rp.method == ELM_GICP, inv_elem);
+    if (rp.method == ELM_GICP && t < 36) S.local_cov[t] = inv_elem; // reg.cpp:141-142 (symmetric: layout-free)
 
     double dR[9];
     rotvec_to_matrix(&x[3], dR);
@@ -1099,20 +1201,23 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* __restr
         Tn[12 + r] = ((S.T[0 * 4 + r] * x[0] + S.T[1 * 4 + r] * x[1]) + S.T[2 * 4 + r] * x[2]) + S.T[12 + r];
     }
     Tn[3] = 0.0; Tn[7] = 0.0; Tn[11] = 0.0; Tn[15] = 1.0;
+    const double step = matrix_to_angle(dR) + sqrt((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2]); // reg.cpp:381-384
+    if (tr && t < 36) tr->JTJ[t] = hij; // symmetric
+    if (!lead) return;
+    S.fitness = fitness;
     for (int k = 0; k < 16; ++k) S.T[k] = Tn[k];
     update_inverse(S);
-
-    const double step = matrix_to_angle(dR) + sqrt((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2]); // reg.cpp:381-384
     if (tr) {
-        for (int k = 0; k < 36; ++k) tr->JTJ[k] = H[k];
-        for (int k = 0; k < 6; ++k) { tr->JTr[k] = b[k]; tr->x[k] = x[k]; }
+        for (int k = 0; k < 6; ++k) { tr->JTr[k] = tot[21 + k]; tr->x[k] = x[k]; }
+        tr->residual_sum = tot[27];
+        tr->n_corr = n_corr;
         tr->step_norm = step;
-        for (int k = 0; k < 16; ++k) tr->T[k] = S.T[k];
+        for (int k = 0; k < 16; ++k) tr->T[k] = Tn[k];
     }
     if (step < rp.term_thr || iter >= rp.max_iter) { // reg.cpp:385-387 / loop end
         S.done = 1;
         atomicSub(active, 1);
-        const bool bad = S.fitness > rp.max_fitness; // reg.cpp:405-409 (NaN compares false, like the reference)
+        const bool bad = fitness > rp.max_fitness; // reg.cpp:405-409 (NaN compares false, like the reference)
         S.success = bad ? 0 : 1;
         S.gate = bad ? 3 : 0;
     }
