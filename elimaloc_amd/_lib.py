@@ -130,7 +130,8 @@ EXPORTS = [
     "elm_map_download_voxels", "elm_map_find_ground_height", "elm_scan_upload", "elm_scan_destroy",
     "elm_scan_size", "elm_register", "elm_register_batch", "elm_register_batch_enqueue",
     "elm_register_batch_finish", "elm_deskew", "elm_deskew_prepare", "elm_comm_get_unique_id", "elm_comm_init",
-    "elm_comm_destroy", "elm_comm_set_hook",
+    "elm_comm_destroy", "elm_comm_set_hook", "elm_filter_points_by_distance", "elm_voxel_downsample",
+    "elm_get_interpolated_pose", "elm_shape_odom_covariance",
 ]
 
 _LIB = None
@@ -185,6 +186,10 @@ def lib():
     L.elm_deskew.argtypes = [vp, fp, fp, C.c_size_t, C.POINTER(DeskewTables), fp, ip]
     L.elm_deskew_prepare.argtypes = [dp, C.c_size_t, dp, C.c_size_t, C.c_double, C.c_float, C.c_float, C.c_int,
                                      C.c_int, dp, dp, dp, dp, C.c_size_t, C.POINTER(DeskewTables)]
+    L.elm_filter_points_by_distance.argtypes = [fp, fp, C.c_size_t, C.c_double, fp, fp, C.POINTER(C.c_size_t)]
+    L.elm_voxel_downsample.argtypes = [fp, C.c_size_t, C.c_double, C.POINTER(C.c_int64), C.POINTER(C.c_size_t)]
+    L.elm_get_interpolated_pose.argtypes = [dp, C.c_size_t, C.c_double, fp, ip]
+    L.elm_shape_odom_covariance.argtypes = [dp, dp, C.c_double, dp]
     L.elm_comm_get_unique_id.argtypes = [vp]
     L.elm_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.elm_comm_destroy.argtypes = [vp]

@@ -221,6 +221,23 @@ int elm_deskew_prepare(const double* imu4, size_t n_imu, const double* odom14, s
                        double* tab_time, double* tab_rx, double* tab_ry, double* tab_rz, size_t tab_cap,
                        elm_deskew_tables* out);
 
+/* ---------------------------------------------------------------- caller glue (host) -------------- */
+/* The steps of PcmMatching::CallbackPointCloud / CallbackInitialPose either side of the device path (SURVEY.md 8
+ * rows f2 / f4), in the reference's float32 / float64 arithmetic.  Host functions, no GPU needed. */
+/* FilterPointsByDistance (pcm.cpp:451-465): drops points farther than max_dist (float norm). time may be NULL. */
+int elm_filter_points_by_distance(const float* xyz, const float* time, size_t n, double max_dist, float* xyz_out,
+                                  float* time_out, size_t* n_out);
+/* VoxelHashMap::VoxelDownsample (vhm.hpp:260-283): index of the first point of every floor-keyed voxel, in input
+ * order (the reference emits unordered_map order; only the set is contractual). */
+int elm_voxel_downsample(const float* xyz, size_t n, double voxel_size, int64_t* keep_idx, size_t* n_keep);
+/* GetInterpolatedPose (pcm.cpp:933-1045): odom rows as in elm_deskew_prepare; T_out = Eigen::Affine3f matrix,
+ * column-major; *ok = 0 when no odometry at or before the time exists. */
+int elm_get_interpolated_pose(const double* odom14, size_t n_odom, double d_cur_time, float T_out[16], int* ok);
+/* Covariance of the published odometry (PublishPcmOdom pcm.cpp:1082-1098, NormalizeCovariance pcm.hpp:248-268):
+ * cov_out is the row-major 6x6 of nav_msgs/Odometry.pose.covariance. */
+int elm_shape_odom_covariance(const double local_cov[36], const double icp_ego_pose[16], double d_icp_pose_std_m,
+                              double cov_out[36]);
+
 /* ---------------------------------------------------------------- multi-GPU ----------------------- */
 /* One process per GPU.  Rank 0 obtains an id, the host distributes its bytes (e.g. torch.distributed
  * broadcast), every rank calls elm_comm_init.  Afterwards elm_register_batch* sums the packed normal

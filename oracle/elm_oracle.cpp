@@ -1586,6 +1586,207 @@ int orc_odom_deskew_info(const double* od, size_t n_odom, double scan_cur, doubl
     return 1;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// caller glue around RunRegister (pcm.cpp:451-465, 933-1101; pcm.hpp:222-290; lf.hpp:219-241)
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Q4f {
+    float w, x, y, z;
+};
+struct A3f { // Eigen::Affine3f as 4x4 float, row-major
+    float m[4][4];
+};
+A3f a3_identity() {
+    A3f a{};
+    for (int i = 0; i < 4; ++i) a.m[i][i] = 1.0f;
+    return a;
+}
+void q_to_rot(const Q4f& q, A3f& a) { // Quaternionf::toRotationMatrix into the linear block
+    const float tx = 2.0f * q.x, ty = 2.0f * q.y, tz = 2.0f * q.z;
+    const float twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+    const float txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+    const float tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    a.m[0][0] = 1.0f - (tyy + tzz); a.m[0][1] = txy - twz; a.m[0][2] = txz + twy;
+    a.m[1][0] = txy + twz; a.m[1][1] = 1.0f - (txx + tzz); a.m[1][2] = tyz - twx;
+    a.m[2][0] = txz - twy; a.m[2][1] = tyz + twx; a.m[2][2] = 1.0f - (txx + tyy);
+}
+Q4f rot_to_q(const A3f& a) { // Quaternionf(Matrix3f)
+    Q4f q;
+    float t = a.m[0][0] + a.m[1][1] + a.m[2][2];
+    if (t > 0.0f) {
+        t = std::sqrt(t + 1.0f);
+        q.w = 0.5f * t;
+        t = 0.5f / t;
+        q.x = (a.m[2][1] - a.m[1][2]) * t;
+        q.y = (a.m[0][2] - a.m[2][0]) * t;
+        q.z = (a.m[1][0] - a.m[0][1]) * t;
+    } else {
+        int i = 0;
+        if (a.m[1][1] > a.m[0][0]) i = 1;
+        if (a.m[2][2] > a.m[i][i]) i = 2;
+        int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(a.m[i][i] - a.m[j][j] - a.m[k][k] + 1.0f);
+        float v[3];
+        v[i] = 0.5f * t;
+        t = 0.5f / t;
+        q.w = (a.m[k][j] - a.m[j][k]) * t;
+        v[j] = (a.m[j][i] + a.m[i][j]) * t;
+        v[k] = (a.m[k][i] + a.m[i][k]) * t;
+        q.x = v[0]; q.y = v[1]; q.z = v[2];
+    }
+    return q;
+}
+A3f a3_inverse(const A3f& a) {
+    A3f r = a3_identity();
+    auto cof = [&](int i, int j) {
+        int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+        return a.m[i1][j1] * a.m[i2][j2] - a.m[i1][j2] * a.m[i2][j1];
+    };
+    float det = (cof(0, 0) * a.m[0][0] + cof(1, 0) * a.m[1][0]) + cof(2, 0) * a.m[2][0];
+    float invdet = 1.0f / det;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) r.m[i][j] = cof(j, i) * invdet;
+    for (int i = 0; i < 3; ++i)
+        r.m[i][3] = -((r.m[i][0] * a.m[0][3] + r.m[i][1] * a.m[1][3]) + r.m[i][2] * a.m[2][3]);
+    return r;
+}
+A3f a3_mul(const A3f& a, const A3f& b) {
+    A3f r = a3_identity();
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j)
+            r.m[i][j] = ((a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j]) + a.m[i][2] * b.m[2][j]) + a.m[i][3] * b.m[3][j];
+    return r;
+}
+// InterpolateTfWithTime (lf.hpp:219-241)
+A3f InterpolateTfWithTime(const A3f& between, double dt_scan, double dt_trans) {
+    if (dt_trans == 0.0) return a3_identity();
+    double ratio = dt_scan / dt_trans;
+    float fr = static_cast<float>(ratio);
+    A3f out = a3_identity();
+    Q4f rot = rot_to_q(between);
+    const float one = 1.0f - std::numeric_limits<float>::epsilon();
+    float d = ((0.0f * rot.x + 0.0f * rot.y) + 0.0f * rot.z) + 1.0f * rot.w; // Identity().dot(rotation)
+    float absD = std::fabs(d);
+    float scale0, scale1;
+    if (absD >= one) {
+        scale0 = 1.0f - fr;
+        scale1 = fr;
+    } else {
+        float theta = std::acos(absD);
+        float sinTheta = std::sin(theta);
+        scale0 = std::sin((1.0f - fr) * theta) / sinTheta;
+        scale1 = std::sin(fr * theta) / sinTheta;
+    }
+    if (d < 0.0f) scale1 = -scale1;
+    Q4f qi{scale0 * 1.0f + scale1 * rot.w, scale0 * 0.0f + scale1 * rot.x, scale0 * 0.0f + scale1 * rot.y,
+           scale0 * 0.0f + scale1 * rot.z};
+    for (int i = 0; i < 3; ++i) out.m[i][3] = between.m[i][3] * fr;
+    q_to_rot(qi, out);
+    return out;
+}
+} // namespace
+
+size_t orc_filter_points_by_distance(const float* xyz, size_t n, double max_dist, int64_t* keep_idx) { // pcm.cpp:451-465
+    size_t k = 0;
+    for (size_t i = 0; i < n; ++i) {
+        float px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+        double distance = std::sqrt(px * px + py * py + pz * pz);
+        if (!(distance > max_dist)) keep_idx[k++] = (int64_t)i;
+    }
+    return k;
+}
+
+int orc_get_interpolated_pose(const double* od, size_t n_odom, double d_cur_time, float T_out[16]) { // pcm.cpp:933-1045
+    bool b_found_before = false, b_found_after = false;
+    double before[14], after[14];
+    std::memset(before, 0, sizeof(before));
+    std::memset(after, 0, sizeof(after));
+    for (size_t i = 0; i < n_odom; ++i) {
+        if (od[14 * i] <= d_cur_time) {
+            std::memcpy(before, od + 14 * i, sizeof(before));
+            b_found_before = true;
+        }
+        if (od[14 * i] > d_cur_time) {
+            std::memcpy(after, od + 14 * i, sizeof(after));
+            b_found_after = true;
+            break;
+        }
+    }
+    if (!b_found_before) return 0;
+    if (!b_found_after) {
+        const double* latest = od + 14 * (n_odom - 1);
+        double dt = d_cur_time - latest[0];
+        double roll, pitch, yaw;
+        tf_quat_to_rpy(latest[4], latest[5], latest[6], latest[7], &roll, &pitch, &yaw);
+        double cy = std::cos(yaw), sy = std::sin(yaw), cp = std::cos(pitch), sp = std::sin(pitch), cr = std::cos(roll),
+               sr = std::sin(roll);
+        double R[3][3] = {{cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr},
+                          {sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr},
+                          {-sp, cp * sr, cp * cr}};
+        for (int i = 0; i < 3; ++i) after[1 + i] = latest[1 + i] + (R[i][0] * latest[8] + R[i][1] * latest[9] + R[i][2] * latest[10]) * dt;
+        roll += latest[11] * dt;
+        pitch += latest[12] * dt;
+        yaw += latest[13] * dt;
+        double hy = yaw * 0.5, hp = pitch * 0.5, hr = roll * 0.5;
+        double cY = std::cos(hy), sY = std::sin(hy), cP = std::cos(hp), sP = std::sin(hp), cR = std::cos(hr), sR = std::sin(hr);
+        after[4] = sR * cP * cY - cR * sP * sY;
+        after[5] = cR * sP * cY + sR * cP * sY;
+        after[6] = cR * cP * sY - sR * sP * cY;
+        after[7] = cR * cP * cY + sR * sP * sY;
+        after[0] = 0.0; // header.stamp of odom_after is left default on this branch
+    }
+    double dt_scan = d_cur_time - before[0];
+    double dt_trans = after[0] - before[0];
+    A3f pose_before = a3_identity(), pose_after = a3_identity();
+    for (int i = 0; i < 3; ++i) {
+        pose_before.m[i][3] = static_cast<float>(before[1 + i]);
+        pose_after.m[i][3] = static_cast<float>(after[1 + i]);
+    }
+    q_to_rot(Q4f{(float)before[7], (float)before[4], (float)before[5], (float)before[6]}, pose_before);
+    q_to_rot(Q4f{(float)after[7], (float)after[4], (float)after[5], (float)after[6]}, pose_after);
+    A3f between = a3_mul(a3_inverse(pose_before), pose_after);
+    A3f interp = InterpolateTfWithTime(between, dt_scan, dt_trans);
+    A3f res = a3_mul(pose_before, interp);
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) T_out[c * 4 + r] = res.m[r][c];
+    return 1;
+}
+
+void orc_shape_odom_covariance(const double local_cov[36], const double pose[16], double icp_pose_std_m, double cov_out[36]) {
+    // PublishPcmOdom (pcm.cpp:1082-1098), NormalizeCovariance (pcm.hpp:248-268), UpdateCovarianceField (pcm.hpp:270-290)
+    double d_icp_pose_std_m = std::max(icp_pose_std_m, 0.25);
+    M3 R, Ctt, Crr;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            R(r, c) = pose[c * 4 + r];
+            Ctt(r, c) = local_cov[c * 6 + r];
+            Crr(r, c) = local_cov[(c + 3) * 6 + (r + 3)];
+        }
+    M3 translation_covariance = m3_mul(m3_mul(R, Ctt), m3_transpose(R));
+    auto normalize = [](const M3& in) {
+        M3 c = in;
+        double min_diag = std::min({c(0, 0), c(1, 1), c(2, 2)});
+        const double min_threshold = 1e-9;
+        if (min_diag <= min_threshold) {
+            for (int i = 0; i < 9; ++i) c.m[i] *= 1e9;
+            min_diag = std::min({c(0, 0), c(1, 1), c(2, 2)});
+            if (min_diag < min_threshold) min_diag = min_threshold;
+        }
+        M3 o;
+        for (int i = 0; i < 9; ++i) o.m[i] = std::min(c.m[i] / min_diag, 5.0);
+        return o;
+    };
+    double angle_std = d_icp_pose_std_m * M_PI / 180.0;
+    M3 tn = normalize(translation_covariance), rn = normalize(Crr);
+    std::memset(cov_out, 0, 36 * sizeof(double));
+    for (int row = 0; row < 3; ++row)
+        for (int col = 0; col < 3; ++col) {
+            cov_out[row * 6 + col] = tn(row, col) * d_icp_pose_std_m * d_icp_pose_std_m;
+            cov_out[(row + 3) * 6 + (col + 3)] = rn(row, col) * angle_std * angle_std;
+        }
+}
+
 // ---- exported helpers --------------------------------------------------------------------------
 void orc_ldlt_solve6(const double A[36], const double b[6], double x[6]) {
     M6 a;

@@ -132,6 +132,12 @@ int orc_imu_deskew_info(const double* imu_t, const double* imu_w_xyz, size_t n_i
 int orc_odom_deskew_info(const double* odom14, size_t n_odom, double scan_cur, double scan_end,
                          float* incre_xyz);
 
+/* caller glue around RunRegister */
+size_t orc_filter_points_by_distance(const float* xyz, size_t n, double max_dist, int64_t* keep_idx); /* pcm.cpp:451-465 */
+int orc_get_interpolated_pose(const double* odom14, size_t n_odom, double d_cur_time, float T_out[16]); /* pcm.cpp:933-1045 */
+void orc_shape_odom_covariance(const double local_cov[36], const double pose[16], double icp_pose_std_m,
+                               double cov_out[36]);                                                  /* pcm.cpp:1082-1098 */
+
 /* small exported helpers so the tests can pin the linear-algebra kit */
 void orc_ldlt_solve6(const double A[36], const double b[6], double x[6]);
 void orc_inverse6(const double A[36], double Ainv[36]);

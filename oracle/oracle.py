@@ -122,6 +122,10 @@ def lib():
         L.orc_imu_deskew_info.argtypes = [dp, dp, C.c_size_t, C.c_double, C.c_double, dp, dp, dp, dp,
                                           C.POINTER(C.c_int32)]
         L.orc_odom_deskew_info.argtypes = [dp, C.c_size_t, C.c_double, C.c_double, fp]
+        L.orc_filter_points_by_distance.restype = C.c_size_t
+        L.orc_filter_points_by_distance.argtypes = [fp, C.c_size_t, C.c_double, C.POINTER(C.c_int64)]
+        L.orc_get_interpolated_pose.argtypes = [dp, C.c_size_t, C.c_double, fp]
+        L.orc_shape_odom_covariance.argtypes = [dp, dp, C.c_double, dp]
         L.orc_ldlt_solve6.argtypes = [dp, dp, dp]
         L.orc_inverse6.argtypes = [dp, dp]
         L.orc_jacobi_svd3.argtypes = [dp, dp, dp, dp]
@@ -317,3 +321,25 @@ def angle_axis_to_matrix(v):
 def matrix_to_angle(R):
     R = np.asarray(R, dtype=np.float64).ravel(order="F").copy()
     return lib().orc_matrix_to_angle(_dp(R))
+
+
+def filter_points_by_distance(xyz, max_dist):
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+    keep = np.empty(xyz.shape[0], np.int64)
+    k = lib().orc_filter_points_by_distance(_fp(xyz), xyz.shape[0], max_dist, keep.ctypes.data_as(C.POINTER(C.c_int64)))
+    return keep[:k].copy()
+
+
+def get_interpolated_pose(odom14, t):
+    od = np.ascontiguousarray(odom14, dtype=np.float64).reshape(-1, 14)
+    T = np.zeros(16, np.float32)
+    ok = lib().orc_get_interpolated_pose(_dp(od), od.shape[0], t, _fp(T))
+    return bool(ok), T.reshape(4, 4).T.copy()
+
+
+def shape_odom_covariance(local_cov, pose, std_m):
+    lc = np.asarray(local_cov, dtype=np.float64).ravel(order="F").copy()
+    ps = np.asarray(pose, dtype=np.float64).ravel(order="F").copy()
+    out = np.zeros(36)
+    lib().orc_shape_odom_covariance(_dp(lc), _dp(ps), std_m, _dp(out))
+    return out.reshape(6, 6)
