@@ -132,7 +132,35 @@ EXPORTS = [
     "elm_register_batch_finish", "elm_deskew", "elm_deskew_prepare", "elm_comm_get_unique_id", "elm_comm_init",
     "elm_comm_destroy", "elm_comm_set_hook", "elm_filter_points_by_distance", "elm_voxel_downsample",
     "elm_get_interpolated_pose", "elm_shape_odom_covariance",
+    "elm_ekf_config_default", "elm_ekf_create", "elm_ekf_destroy", "elm_ekf_predict_imu", "elm_ekf_update_pose",
+    "elm_ekf_update_pcm_odom", "elm_ekf_get_state", "elm_ekf_publish",
 ]
+
+
+class EkfConfig(C.Structure):
+    """elm_ekf_config (include/elimaloc_hip.h)."""
+    _fields_ = [("imu_gravity", C.c_double)] + [(n, C.c_int32) for n in (
+        "imu_estimate_gravity", "imu_estimate_calibration", "use_zupt", "use_complementary_filter", "gps_type", "_pad")] + [
+        (n, C.c_double) for n in (
+            "ekf_init_x_m", "ekf_init_y_m", "ekf_init_z_m", "ekf_init_roll_deg", "ekf_init_pitch_deg", "ekf_init_yaw_deg",
+            "state_std_pos_m", "state_std_rot_deg", "state_std_vel_mps", "state_std_gyro_dps", "state_std_acc_mps",
+            "imu_std_gyro_dps", "imu_std_acc_mps", "ekf_imu_bias_cov_gyro", "ekf_imu_bias_cov_acc",
+            "gnss_min_cov_x_m", "gnss_min_cov_y_m", "gnss_min_cov_z_m", "gnss_min_cov_roll_deg", "gnss_min_cov_pitch_deg",
+            "gnss_min_cov_yaw_deg")]
+
+
+class EkfStateC(C.Structure):
+    _fields_ = [("x", C.c_double * 27), ("rot_xyzw", C.c_double * 4), ("imu_rot_xyzw", C.c_double * 4),
+                ("P", C.c_double * 729), ("timestamp", C.c_double)] + [(n, C.c_int32) for n in (
+                    "b_state_initialized", "b_yaw_initialized", "b_rotation_stabilized", "b_state_stabilized",
+                    "b_pcm_init_on_going", "_pad")]
+
+
+class EgoStateC(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "timestamp", "x_m", "y_m", "z_m", "roll_rad", "pitch_rad", "yaw_rad", "roll_vel", "pitch_vel", "yaw_vel",
+        "vx", "vy", "vz", "ax", "ay", "az", "x_cov_m", "y_cov_m", "z_cov_m", "roll_cov_rad", "pitch_cov_rad", "yaw_cov_rad")]
+
 
 _LIB = None
 
@@ -190,6 +218,16 @@ def lib():
     L.elm_voxel_downsample.argtypes = [fp, C.c_size_t, C.c_double, C.POINTER(C.c_int64), C.POINTER(C.c_size_t)]
     L.elm_get_interpolated_pose.argtypes = [dp, C.c_size_t, C.c_double, fp, ip]
     L.elm_shape_odom_covariance.argtypes = [dp, dp, C.c_double, dp]
+    L.elm_ekf_config_default.argtypes = [C.POINTER(EkfConfig)]
+    L.elm_ekf_config_default.restype = None
+    L.elm_ekf_create.argtypes = [C.POINTER(EkfConfig), C.POINTER(vp)]
+    L.elm_ekf_destroy.argtypes = [vp]
+    L.elm_ekf_destroy.restype = None
+    L.elm_ekf_predict_imu.argtypes = [vp, C.c_double, dp, dp, ip]
+    L.elm_ekf_update_pose.argtypes = [vp, C.c_double, dp, dp, dp, dp, C.c_int, ip]
+    L.elm_ekf_update_pcm_odom.argtypes = [vp, C.c_double, dp, dp, dp, C.c_int, ip]
+    L.elm_ekf_get_state.argtypes = [vp, C.POINTER(EkfStateC)]
+    L.elm_ekf_publish.argtypes = [vp, C.POINTER(EgoStateC)]
     L.elm_comm_get_unique_id.argtypes = [vp]
     L.elm_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.elm_comm_destroy.argtypes = [vp]

@@ -238,6 +238,49 @@ int elm_get_interpolated_pose(const double* odom14, size_t n_odom, double d_cur_
 int elm_shape_odom_covariance(const double local_cov[36], const double icp_ego_pose[16], double d_icp_pose_std_m,
                               double cov_out[36]);
 
+/* ---------------------------------------------------------------- CPU EKF (host) ------------------ */
+/* Plain-CPU counterpart of the reference's 27-state EKF (ekf_localization/src/ekf_algorithm.cpp) -- SURVEY.md 8 row f1.
+ * north_star keeps the filter on the CPU; these calls close the config-5 stream (ICP pose -> EKF update -> next seed).
+ * Built: Init, RunPredictionImu (+ ComplementaryKalmanFilter), RunGnssUpdate (all sources incl. PCM / PCM_INIT),
+ * GetCurrentState, and the node's CallbackPcmOdom / GnssTimeCompensation / state deque.  ZUPT, CAN update and IMU-mount
+ * calibration (off in the shipped localization.ini) return ELM_ERR_UNSUPPORTED. */
+typedef struct elm_ekf elm_ekf;
+enum { ELM_GNSS_NOVATEL = 0, ELM_GNSS_NAVSATFIX = 1, ELM_GNSS_BESTPOS = 2, ELM_GNSS_PCM = 3, ELM_GNSS_PCM_INIT = 4 }; /* ls.hpp:28 */
+typedef struct elm_ekf_config { /* [ekf_localization] keys of config/localization.ini:15-75 */
+    double imu_gravity;
+    int32_t imu_estimate_gravity, imu_estimate_calibration, use_zupt, use_complementary_filter, gps_type, _pad;
+    double ekf_init_x_m, ekf_init_y_m, ekf_init_z_m, ekf_init_roll_deg, ekf_init_pitch_deg, ekf_init_yaw_deg;
+    double state_std_pos_m, state_std_rot_deg, state_std_vel_mps, state_std_gyro_dps, state_std_acc_mps;
+    double imu_std_gyro_dps, imu_std_acc_mps, ekf_imu_bias_cov_gyro, ekf_imu_bias_cov_acc;
+    double gnss_min_cov_x_m, gnss_min_cov_y_m, gnss_min_cov_z_m, gnss_min_cov_roll_deg, gnss_min_cov_pitch_deg, gnss_min_cov_yaw_deg;
+} elm_ekf_config;
+typedef struct elm_ekf_state { /* EkfState (ls.hpp) + covariance, state order of ekf_algorithm.hpp:41-69 */
+    double x[27];            /* rotation slots (3..5, 24..26) are 0: the attitude lives in the quaternions */
+    double rot_xyzw[4], imu_rot_xyzw[4];
+    double P[27 * 27];       /* row-major */
+    double timestamp;
+    int32_t b_state_initialized, b_yaw_initialized, b_rotation_stabilized, b_state_stabilized, b_pcm_init_on_going, _pad;
+} elm_ekf_state;
+typedef struct elm_ego_state { /* the EgoState fields GetCurrentState fills (ekfa.cpp:778-833) */
+    double timestamp, x_m, y_m, z_m, roll_rad, pitch_rad, yaw_rad, roll_vel, pitch_vel, yaw_vel, vx, vy, vz, ax, ay, az;
+    double x_cov_m, y_cov_m, z_cov_m, roll_cov_rad, pitch_cov_rad, yaw_cov_rad;
+} elm_ego_state;
+void elm_ekf_config_default(elm_ekf_config* cfg);
+int elm_ekf_create(const elm_ekf_config* cfg, elm_ekf** out);
+void elm_ekf_destroy(elm_ekf* ekf);
+/* RunPredictionImu (ekfa.cpp:167-316): gyro / acc already rotated into the ego frame (ImuStructConverter) */
+int elm_ekf_predict_imu(elm_ekf* ekf, double timestamp, const double gyro[3], const double acc[3], int* predicted);
+/* RunGnssUpdate (ekfa.cpp:318-432): pos_cov / rot_cov row-major 3x3 */
+int elm_ekf_update_pose(elm_ekf* ekf, double timestamp, const double pos[3], const double quat_xyzw[4], const double pos_cov[9],
+                        const double rot_cov[9], int source, int* updated);
+/* CallbackPcmOdom / CallbackPcmInitOdom (ekfl.cpp:147-220): odometry pose + row-major 6x6 covariance, time-compensated
+ * against the published state history (GnssTimeCompensation ekfl.cpp:323-394) */
+int elm_ekf_update_pcm_odom(elm_ekf* ekf, double stamp, const double pos[3], const double quat_xyzw[4],
+                            const double covariance36[36], int source, int* updated);
+int elm_ekf_get_state(elm_ekf* ekf, elm_ekf_state* out);
+/* GetCurrentState + the state-history upkeep of PublishInThread (ekfl.cpp:397-410); call after every prediction */
+int elm_ekf_publish(elm_ekf* ekf, elm_ego_state* out);
+
 /* ---------------------------------------------------------------- multi-GPU ----------------------- */
 /* One process per GPU.  Rank 0 obtains an id, the host distributes its bytes (e.g. torch.distributed
  * broadcast), every rank calls elm_comm_init.  Afterwards elm_register_batch* sums the packed normal

@@ -51,6 +51,8 @@ int main(void) {
          sizeof(elm_map_info), sizeof(elm_deskew_tables));
   printf("%zu %zu %zu %zu\n", offsetof(elm_reg_config, gicp_cov_search_dist), offsetof(elm_reg_config, ego_to_lidar_trans),
          offsetof(elm_reg_result, is_success), offsetof(elm_deskew_tables, vec_d_imu_time));
+  printf("%zu %zu %zu %zu %zu\n", sizeof(elm_ekf_config), sizeof(elm_ekf_state), sizeof(elm_ego_state),
+         offsetof(elm_ekf_config, ekf_init_x_m), offsetof(elm_ekf_state, b_state_initialized));
   return 0; }
 '''
     with tempfile.TemporaryDirectory() as d:
@@ -62,8 +64,10 @@ int main(void) {
     sizes = [int(x) for x in out]
     assert sizes[:5] == [C.sizeof(_lib.RegConfig), C.sizeof(_lib.IterTrace), C.sizeof(_lib.RegResult),
                          C.sizeof(_lib.MapInfo), C.sizeof(_lib.DeskewTables)]
-    assert sizes[5:] == [_lib.RegConfig.gicp_cov_search_dist.offset, _lib.RegConfig.ego_to_lidar_trans.offset,
-                         _lib.RegResult.is_success.offset, _lib.DeskewTables.vec_d_imu_time.offset]
+    assert sizes[5:9] == [_lib.RegConfig.gicp_cov_search_dist.offset, _lib.RegConfig.ego_to_lidar_trans.offset,
+                          _lib.RegResult.is_success.offset, _lib.DeskewTables.vec_d_imu_time.offset]
+    assert sizes[9:] == [C.sizeof(_lib.EkfConfig), C.sizeof(_lib.EkfStateC), C.sizeof(_lib.EgoStateC),
+                         _lib.EkfConfig.ekf_init_x_m.offset, _lib.EkfStateC.b_state_initialized.offset]
 
 
 def test_cpp_shims_compile_and_link(L):

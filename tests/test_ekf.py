@@ -1,0 +1,174 @@
+"""CPU EKF counterpart: csrc/elm_ekf.cpp against the independent numpy re-derivation tests/np_ekf.py.
+
+Runs without a GPU: the EKF is plain host code inside libelimaloc_hip.so (no device calls).  Tolerances: the two differ
+only in floating-point association order (K(HP) vs (KH)P, Gauss-Jordan vs LAPACK inverse), so 1e-9 relative on state
+and covariance over a several-thousand-step stream is a tight bar.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from elimaloc_amd import _lib
+from elimaloc_amd.ekf import EkfAlgorithm, EkfConfig, GnssSource
+
+import np_ekf
+
+
+def cfg_dict(cfg):
+    return {n: getattr(cfg.c, n) for n, _ in _lib.EkfConfig._fields_}
+
+
+def compare(e, r, tol=1e-9):
+    s = e.State()
+    x = s["x"]
+    ref = np.concatenate([r.pos, np.zeros(3), r.vel, r.gyro, r.acc, r.bg, r.ba, r.grav, np.zeros(3)])
+    np.testing.assert_allclose(x, ref, rtol=tol, atol=tol)
+    q = s["rot_xyzw"]
+    np.testing.assert_allclose([q[3], q[0], q[1], q[2]], r.rot, rtol=0, atol=tol)
+    q = s["imu_rot_xyzw"]
+    np.testing.assert_allclose([q[3], q[0], q[1], q[2]], r.imu_rot, rtol=0, atol=tol)
+    np.testing.assert_allclose(s["P"], r.P, rtol=tol, atol=1e-12)
+    assert (s["state_initialized"], s["yaw_initialized"], s["rotation_stabilized"], s["state_stabilized"], s["pcm_init_on_going"]) == (
+        r.state_init, r.yaw_init, r.rot_stab, r.state_stab, r.pcm_init)
+
+
+def trajectory(t):
+    """Smooth planar drive with gentle roll/pitch: returns position, ZYX euler, body gyro, body specific force."""
+    yaw = 0.3 * math.sin(0.2 * t)
+    pitch = 0.02 * math.sin(0.5 * t)
+    roll = 0.015 * math.cos(0.4 * t)
+    return yaw, pitch, roll
+
+
+def euler_quat_xyzw(roll, pitch, yaw):
+    q = np_ekf.quat_mul(np_ekf.quat_mul(np_ekf.aa_quat(yaw, [0, 0, 1]), np_ekf.aa_quat(pitch, [0, 1, 0])), np_ekf.aa_quat(roll, [1, 0, 0]))
+    return np.array([q[1], q[2], q[3], q[0]])
+
+
+def drive(n_sec=12.0, imu_hz=200, pcm_hz=10, seed=7, use_ckf=1, via_odom=True, lag=0.03):
+    """Init -> PCM_INIT -> IMU predictions + PCM pose updates; yields after every call for comparison."""
+    rng = np.random.default_rng(seed)
+    cfg = EkfConfig(use_complementary_filter=use_ckf)
+    e, r = EkfAlgorithm(cfg), np_ekf.NpEkf(cfg_dict(cfg))
+    dt = 1.0 / imu_hz
+    speed = 8.0
+    pos = np.array([3.0, -2.0, 0.5])
+    t0 = 100.0
+    steps = int(n_sec * imu_hz)
+    hist = []
+    for k in range(steps):
+        t = t0 + k * dt
+        yaw, pitch, roll = trajectory(t - t0)
+        R = np_ekf.quat_R(np.array([euler_quat_xyzw(roll, pitch, yaw)[3], *euler_quat_xyzw(roll, pitch, yaw)[:3]]))
+        vel = R @ np.array([speed, 0, 0])
+        pos = pos + vel * dt
+        hist.append((t, pos.copy(), roll, pitch, yaw))
+        y2, p2, r2 = trajectory(t - t0 + dt)
+        gyro = np.array([(r2 - roll) / dt, (p2 - pitch) / dt, (y2 - yaw) / dt]) + rng.normal(0, 1e-3, 3)
+        acc = R.T @ np.array([0, 0, 9.81]) + np.array([0, speed * gyro[2], 0]) + rng.normal(0, 1e-2, 3)
+        if k == 3:
+            q0 = euler_quat_xyzw(roll, pitch, yaw)
+            assert e.CallbackPcmInitOdom(t, pos, q0) and r.update_pcm_odom(t, pos, q0, np.eye(6) * 1e-9, np_ekf.PCM_INIT)
+            yield e, r
+        a, b = e.RunPredictionImu(t, gyro, acc), r.predict_imu(t, gyro, acc)
+        assert a == b
+        ego, ego_r = e.GetCurrentState(), r.publish()
+        for key, v in ego_r.items():
+            assert abs(ego[key] - v) <= 1e-9 * max(1.0, abs(v)), (key, ego[key], v)
+        yield e, r
+        if k > 3 and k % (imu_hz // pcm_hz) == 0:
+            # the ICP pose arrives `lag` seconds late and carries the scan's stamp
+            kk = max(0, k - int(lag * imu_hz))
+            ts, ps, rs, pis, ys = hist[kk]
+            meas_p = ps + rng.normal(0, 0.02, 3)
+            meas_q = euler_quat_xyzw(rs + rng.normal(0, 1e-3), pis + rng.normal(0, 1e-3), ys + rng.normal(0, 1e-3))
+            cov = np.diag([4e-4, 4e-4, 4e-4, 1e-6, 1e-6, 1e-6]) + 1e-7
+            if via_odom:
+                a, b = e.CallbackPcmOdom(ts, meas_p, meas_q, cov), r.update_pcm_odom(ts, meas_p, meas_q, cov, np_ekf.PCM)
+            else:
+                a = e.RunGnssUpdate(ts, meas_p, meas_q, cov[:3, :3], cov[3:, 3:], GnssSource.PCM)
+                b = r.update_pose(ts, meas_p, meas_q, cov[:3, :3], cov[3:, 3:], np_ekf.PCM)
+            assert a == b
+            yield e, r
+
+
+@pytest.mark.parametrize("use_ckf,via_odom", [(1, True), (0, True), (1, False)])
+def test_stream_matches_numpy(use_ckf, via_odom):
+    n = 0
+    for e, r in drive(use_ckf=use_ckf, via_odom=via_odom):
+        n += 1
+        if n % 7 == 0 or n < 50:
+            compare(e, r)
+    compare(e, r)
+    s = e.State()
+    assert s["state_initialized"] and not s["pcm_init_on_going"]
+    # the filter tracks the simulated drive: final position within a few cm of the last measurement
+    assert n > 2000
+
+
+def test_filter_converges_to_truth():
+    last = None
+    for e, r in drive(n_sec=10.0):
+        last = e
+    s = last.State()
+    assert math.sqrt(s["P"][0, 0]) < 0.05 and math.sqrt(s["P"][5, 5]) < 0.2 * math.pi / 180
+    assert s["rotation_stabilized"] and s["state_stabilized"]
+    assert abs(np.linalg.norm(s["x"][6:9]) - 8.0) < 0.3  # speed recovered from pose updates + IMU
+
+
+def test_init_state_and_flags():
+    e = EkfAlgorithm()
+    s = e.State()
+    c = e.cfg
+    assert s["x"][0] == c.ekf_init_x_m and s["x"][23] == c.imu_gravity
+    d = np.diag(s["P"])
+    assert (d[:15] == 100.0).all() and (d[15:] == 1e-4).all()
+    assert not s["state_initialized"]
+    # first IMU call only latches the timestamp (b_reset_for_init_prediction_)
+    assert e.RunPredictionImu(5.0, [0, 0, 0], [0, 0, 9.81]) is False
+    # not initialised -> no prediction, state untouched
+    assert e.RunPredictionImu(5.005, [0, 0, 0.1], [0, 0, 9.81]) is False
+    np.testing.assert_array_equal(e.State()["x"], s["x"])
+
+
+def test_pcm_init_resets_and_blocks_prediction():
+    e = EkfAlgorithm()
+    e.RunPredictionImu(1.0, [0, 0, 0], [0, 0, 9.81])
+    assert e.CallbackPcmInitOdom(1.0, [10, 20, 30], [0, 0, math.sin(0.25), math.cos(0.25)])
+    s = e.State()
+    np.testing.assert_array_equal(s["x"][:3], [10, 20, 30])
+    assert s["pcm_init_on_going"] and s["state_initialized"] and s["yaw_initialized"]
+    assert e.RunPredictionImu(1.005, [0, 0, 0], [0, 0, 9.81]) is False  # PCM init on going
+    # 12 PCM updates end the warm-up (count > 10 checked before the increment)
+    for i in range(12):
+        assert e.State()["pcm_init_on_going"]
+        e.RunGnssUpdate(1.1 + 0.1 * i, [10, 20, 30], [0, 0, math.sin(0.25), math.cos(0.25)], np.eye(3) * 1e-3, np.eye(3) * 1e-5)
+    assert not e.State()["pcm_init_on_going"]
+
+
+def test_position_only_sources_leave_attitude():
+    cfg = EkfConfig()
+    e, r = EkfAlgorithm(cfg), np_ekf.NpEkf(cfg_dict(cfg))
+    q = [0, 0, 0, 1]
+    for src in (GnssSource.NAVSATFIX, GnssSource.BESTPOS, GnssSource.NOVATEL):
+        assert e.RunGnssUpdate(2.0, [1, 2, 3], q, np.eye(3) * 0.01, np.eye(3) * 1e-4, src)
+        assert r.update_pose(2.0, [1, 2, 3], q, np.eye(3) * 0.01, np.eye(3) * 1e-4, int(src))
+        compare(e, r)
+
+
+def test_time_compensation_rejects_old_and_empty():
+    e = EkfAlgorithm()
+    cov = np.eye(6) * 1e-4
+    assert e.CallbackPcmOdom(1.0, [0, 0, 0], [0, 0, 0, 1], cov) is False  # empty state history
+    e.RunPredictionImu(10.0, [0, 0, 0], [0, 0, 9.81])
+    e.GetCurrentState()
+    assert e.CallbackPcmOdom(9.0, [0, 0, 0], [0, 0, 0, 1], cov) is False  # older than the whole history
+
+
+def test_unsupported_modes_fail_loudly():
+    with pytest.raises(_lib.ElmError):
+        EkfAlgorithm(EkfConfig(use_zupt=1))
+    with pytest.raises(_lib.ElmError):
+        EkfAlgorithm(EkfConfig(imu_estimate_calibration=1))
