@@ -134,7 +134,25 @@ EXPORTS = [
     "elm_get_interpolated_pose", "elm_shape_odom_covariance",
     "elm_ekf_config_default", "elm_ekf_create", "elm_ekf_destroy", "elm_ekf_predict_imu", "elm_ekf_update_pose",
     "elm_ekf_update_pcm_odom", "elm_ekf_get_state", "elm_ekf_publish",
+    "elm_ini_load", "elm_ini_destroy", "elm_ini_get_string", "elm_ini_get_int", "elm_ini_get_bool", "elm_ini_get_double",
+    "elm_ini_get_array", "elm_pcm_node_config_default", "elm_load_pcm_config", "elm_load_ekf_config", "elm_pcd_load_xyz",
+    "elm_free", "elm_scan_from_cloud",
 ]
+
+
+class PcmNodeConfig(C.Structure):
+    """elm_pcm_node_config (include/elimaloc_hip.h)."""
+    _fields_ = [("lidar_type", C.c_char * 32), ("lidar_scan_time_end", C.c_int32), ("pcm_voxel_max_point", C.c_int32),
+                ("run_deskew", C.c_int32), ("input_index_sampling", C.c_int32), ("lidar_time_delay", C.c_double),
+                ("pcm_voxel_size", C.c_double), ("input_max_dist", C.c_double), ("input_voxel_ds_m", C.c_double),
+                ("tf_ego_to_lidar", C.c_double * 16)]
+
+
+class CloudField(C.Structure):
+    _fields_ = [("name", C.c_char * 24), ("offset", C.c_uint32), ("datatype", C.c_int32)]
+
+
+FIELD_UINT16, FIELD_UINT32, FIELD_FLOAT32 = 4, 6, 7
 
 
 class EkfConfig(C.Structure):
@@ -228,6 +246,24 @@ def lib():
     L.elm_ekf_update_pcm_odom.argtypes = [vp, C.c_double, dp, dp, dp, C.c_int, ip]
     L.elm_ekf_get_state.argtypes = [vp, C.POINTER(EkfStateC)]
     L.elm_ekf_publish.argtypes = [vp, C.POINTER(EgoStateC)]
+    cp, szp = C.c_char_p, C.POINTER(C.c_size_t)
+    L.elm_ini_load.argtypes = [cp, C.POINTER(vp)]
+    L.elm_ini_destroy.argtypes = [vp]
+    L.elm_ini_destroy.restype = None
+    L.elm_ini_get_string.argtypes = [vp, cp, cp, C.c_char_p, C.c_size_t]
+    L.elm_ini_get_int.argtypes = [vp, cp, cp, ip]
+    L.elm_ini_get_bool.argtypes = [vp, cp, cp, ip]
+    L.elm_ini_get_double.argtypes = [vp, cp, cp, dp]
+    L.elm_ini_get_array.argtypes = [vp, cp, cp, dp, C.c_size_t, szp]
+    L.elm_pcm_node_config_default.argtypes = [C.POINTER(PcmNodeConfig)]
+    L.elm_pcm_node_config_default.restype = None
+    L.elm_load_pcm_config.argtypes = [cp, cp, C.POINTER(PcmNodeConfig), C.POINTER(RegConfig)]
+    L.elm_load_ekf_config.argtypes = [cp, C.POINTER(EkfConfig)]
+    L.elm_pcd_load_xyz.argtypes = [cp, C.POINTER(fp), szp]
+    L.elm_free.argtypes = [vp]
+    L.elm_free.restype = None
+    L.elm_scan_from_cloud.argtypes = [vp, C.c_size_t, C.c_size_t, C.POINTER(CloudField), C.c_int, C.c_int, C.c_int, fp, fp, fp,
+                                      C.c_size_t, szp]
     L.elm_comm_get_unique_id.argtypes = [vp]
     L.elm_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.elm_comm_destroy.argtypes = [vp]

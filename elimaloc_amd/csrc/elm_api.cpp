@@ -139,6 +139,8 @@ extern "C" const char* elm_strerror(int status) {
     case ELM_ERR_NO_DEVICE: return "no usable gfx950 device";
     case ELM_ERR_COMM: return "RCCL error";
     case ELM_ERR_UNSUPPORTED: return "unsupported configuration";
+    case ELM_ERR_IO: return "file missing or unreadable";
+    case ELM_ERR_ALLOC: return "host allocation failed";
     default: return "unknown status";
     }
 }

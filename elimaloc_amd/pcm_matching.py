@@ -20,6 +20,8 @@ from .registration import (Context, IcpMethod, Registration, RegistrationConfig,
 @dataclass
 class PcmMatchingConfig:
     """[common_variable] / [pcm_matching] keys of config/localization.ini (loc.ini:2-9, 80-105) + calibration."""
+    s_lidar_type: str = "velodyne"       # lidar_type ("ouster" -> OusterCloudmsg2cloud)
+    i_input_index_sampling: int = 5      # input_index_sampling (applied on the Ouster path only, pcm.cpp:910)
     b_lidar_scan_time_end: bool = True   # lidar_scan_time_end
     d_lidar_time_delay: float = 0.03     # lidar_time_delay
     d_pcm_voxel_size: float = 1.0
@@ -91,6 +93,14 @@ class PcmMatching:
         self.d_icp_pose_std_m = 0.0
         self.d_time_scan_end_ = 0.0
 
+    @classmethod
+    def FromFiles(cls, localization_ini, calibration_ini, map_pcd, ctx=None):
+        """Init() the way the node does it (pcm.cpp:22-101): ProcessINI on the two ini files, load the PCD map, build."""
+        from .formats import LoadPcdXyz, LoadPcmMatchingConfig
+        node = cls(LoadPcmMatchingConfig(localization_ini, calibration_ini), ctx)
+        node.Init(LoadPcdXyz(map_pcd))
+        return node
+
     def Init(self, map_xyz):  # pcm.cpp:81-101
         self.registration_.Init(self.cfg_.registration)
         self.local_map_.Init(self.cfg_.d_pcm_voxel_size, self.cfg_.i_pcm_voxel_max_point)
@@ -104,11 +114,23 @@ class PcmMatching:
     def CallbackPointCloud(self, xyz, point_time, stamp, imu, odom):
         """pcm.cpp:198-324.  Returns None when the reference would publish nothing (deskew / pose sync / ICP failure),
         else dict(pose_ego 4x4 float64, covariance 6x6 row-major, fitness, time)."""
+        import time
+        tm = self.timings_ = {}
+        t0 = time.perf_counter()
+
+        def lap(name):
+            nonlocal t0
+            t1 = time.perf_counter()
+            tm[name] = (t1 - t0) * 1e3
+            t0 = t1
+
         stamp = float(stamp) - self.cfg_.d_lidar_time_delay                                   # :216-217
         xyz, point_time = filter_points_by_distance(xyz, point_time, self.cfg_.d_input_max_dist)  # :235
+        lap("filter_ms")
         if xyz.shape[0] == 0:
             return None
         ok, undistorted = self.deskew_.DeskewPointCloud(xyz, point_time, stamp, imu, odom)    # :238
+        lap("deskew_ms")
         if not ok:
             return None
         self.d_time_scan_end_ = self.deskew_.d_time_scan_end_
@@ -116,15 +138,19 @@ class PcmMatching:
         if not ok:
             return None
         src, _ = voxel_downsample(undistorted, self.cfg_.d_input_voxel_ds_m)                  # :257-258
+        lap("sync_downsample_ms")
         sync_lidar_pose = sync_ego_affine.astype(np.float64) @ self.cfg_.tf_ego_to_lidar      # :266
         pose, ok, fit, cov = self.registration_.RunRegister(src, self.local_map_, sync_lidar_pose)  # :280-282
+        lap("register_ms")
         self.icp_local_cov_ = cov
         if not ok:
             return None                                                                       # :289-292
         self.d_icp_pose_std_m = fit                                                           # :295
         icp_ego_pose = pose @ np.linalg.inv(self.cfg_.tf_ego_to_lidar)                        # :298
-        return dict(pose_ego=icp_ego_pose, pose_lidar=pose, fitness=fit, time=self.d_time_scan_end_,
-                    covariance=shape_odom_covariance(cov, icp_ego_pose, fit), n_source=src.shape[0])
+        out = dict(pose_ego=icp_ego_pose, pose_lidar=pose, fitness=fit, time=self.d_time_scan_end_,
+                   covariance=shape_odom_covariance(cov, icp_ego_pose, fit), n_source=src.shape[0])
+        lap("publish_ms")
+        return out
 
     def CallbackInitialPose(self, rviz_pose, raw_scan_xyz):
         """pcm.cpp:356-447: ground height under the clicked pose, then RunRegister on the last RAW scan."""

@@ -161,3 +161,61 @@ def make_deskew_stream(n_points, seed, scan_period=0.1, imu_hz=200.0, odom_hz=10
     odom[:, 13] = yaw_rate
     return dict(xyz=np.ascontiguousarray(xyz.astype(np.float32)), time=t, stamp=stamp, imu_t=imu_t, imu_w=imu_w,
                 odom=odom)
+
+
+class Drive:
+    """Ground-truth ego trajectory for the config-5 stream: parked for `t_park` s (the PCM-init warm-up blocks prediction),
+    then accelerating to `speed` with a slow sinusoidal yaw rate.  Planar (roll = pitch = 0, constant z)."""
+
+    def __init__(self, start_xy=(3.0, -2.0), z=0.3, yaw0=0.4, t_park=1.5, accel=2.0, speed=8.0, yaw_amp=0.25, t_total=30.0):
+        self.dt = 5e-4
+        n = int(t_total / self.dt) + 2
+        self.t = np.arange(n) * self.dt
+        tm = np.clip(self.t - t_park, 0.0, None)
+        self.v = np.minimum(accel * tm, speed)
+        self.a = np.where((tm > 0) & (accel * tm < speed), accel, 0.0)
+        self.w = yaw_amp * np.sin(0.7 * tm) * (tm > 0)
+        self.yaw = yaw0 + np.concatenate([[0.0], np.cumsum(0.5 * (self.w[1:] + self.w[:-1]) * self.dt)])
+        vx, vy = self.v * np.cos(self.yaw), self.v * np.sin(self.yaw)
+        self.x = start_xy[0] + np.concatenate([[0.0], np.cumsum(0.5 * (vx[1:] + vx[:-1]) * self.dt)])
+        self.y = start_xy[1] + np.concatenate([[0.0], np.cumsum(0.5 * (vy[1:] + vy[:-1]) * self.dt)])
+        self.z = z
+
+    def at(self, t):
+        """-> x, y, yaw, speed, yaw_rate, accel at time(s) t (linear interpolation of the 2 kHz integration)."""
+        f = lambda arr: np.interp(t, self.t, arr)
+        return f(self.x), f(self.y), f(self.yaw), f(self.v), f(self.w), f(self.a)
+
+    def ego_pose(self, t):
+        x, y, yaw, *_ = self.at(float(t))
+        T = np.eye(4)
+        T[:3, :3] = rot_zyx(0.0, 0.0, float(yaw))
+        T[:3, 3] = [x, y, self.z]
+        return T
+
+    def imu(self, t, rng=None, gyro_noise=1e-3, acc_noise=1e-2, gravity=9.81):
+        """Ego-frame gyro and specific force at time t."""
+        _, _, _, v, w, a = self.at(float(t))
+        g = np.array([0.0, 0.0, float(w)])
+        f = np.array([float(a), float(v * w), gravity])
+        if rng is not None:
+            g = g + rng.normal(0, gyro_noise, 3)
+            f = f + rng.normal(0, acc_noise, 3)
+        return g, f
+
+    def scan(self, world, n_points, t_end, tf_ego_to_lidar, seed, period=0.1, max_range=40.0, noise=0.01):
+        """Raw (skewed) scan: point i is observed at its own time t_end - period .. t_end from the lidar pose of that instant.
+        Returns xyz float32 [n,3] in the lidar frame and the PointXYZIT `time` field (ramp -period .. 0, scan_time_end)."""
+        rng = np.random.default_rng(seed)
+        end = self.ego_pose(t_end) @ tf_ego_to_lidar
+        near = world[np.linalg.norm(world - end[:3, 3].astype(np.float32), axis=1) < max_range]
+        pick = near[rng.choice(len(near), n_points, replace=len(near) < n_points)].astype(np.float64)
+        rel = -period + period * (np.arange(n_points) + 0.5) / n_points
+        rel[-1] = 0.0
+        x, y, yaw, *_ = self.at(t_end + rel)
+        d = pick - np.stack([x, y, np.full_like(x, self.z)], 1)
+        c, s = np.cos(yaw), np.sin(yaw)
+        ego = np.stack([c * d[:, 0] + s * d[:, 1], -s * d[:, 0] + c * d[:, 1], d[:, 2]], 1)      # R_z(yaw)^T d
+        Rl, tl = tf_ego_to_lidar[:3, :3], tf_ego_to_lidar[:3, 3]
+        lidar = (ego - tl) @ Rl + rng.normal(0, noise, (n_points, 3))                             # Rl^T (ego - tl)
+        return np.ascontiguousarray(lidar.astype(np.float32)), rel.astype(np.float32)

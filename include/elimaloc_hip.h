@@ -31,6 +31,8 @@ extern "C" {
 #define ELM_ERR_NO_DEVICE -3   /* no usable gfx950 device */
 #define ELM_ERR_COMM -4        /* RCCL error / not initialised */
 #define ELM_ERR_UNSUPPORTED -5 /* e.g. use_radar_cov = 1 */
+#define ELM_ERR_IO -6          /* file missing / unreadable */
+#define ELM_ERR_ALLOC -7       /* host allocation failed */
 
 #define ELM_MAX_ITER_TRACE 64
 
@@ -280,6 +282,50 @@ int elm_ekf_update_pcm_odom(elm_ekf* ekf, double stamp, const double pos[3], con
 int elm_ekf_get_state(elm_ekf* ekf, elm_ekf_state* out);
 /* GetCurrentState + the state-history upkeep of PublishInThread (ekfl.cpp:397-410); call after every prediction */
 int elm_ekf_publish(elm_ekf* ekf, elm_ego_state* out);
+
+/* ---------------------------------------------------------------- formats (host) ------------------ */
+/* On-disk / wire formats either side of the path so the reference's own map, localization.ini and
+ * calibration.ini drive the drop-in. */
+typedef struct elm_ini elm_ini;
+/* IniParser::ParseConfig rules (bsw/system/ini_parser/ini_parser.cpp:41-225 over SimpleIni): getters return 1 = found,
+ * 0 = key missing (output untouched), <0 = error.  Numbers use atoi/atof, so "5.0 ; comment" reads as 5.0. */
+int elm_ini_load(const char* path, elm_ini** out);
+void elm_ini_destroy(elm_ini* ini);
+int elm_ini_get_string(const elm_ini* ini, const char* section, const char* key, char* buf, size_t cap);
+int elm_ini_get_int(const elm_ini* ini, const char* section, const char* key, int* out);
+int elm_ini_get_bool(const elm_ini* ini, const char* section, const char* key, int* out); /* atoi(v) > 0 */
+int elm_ini_get_double(const elm_ini* ini, const char* section, const char* key, double* out);
+int elm_ini_get_array(const elm_ini* ini, const char* section, const char* key, double* out, size_t cap, size_t* n);
+
+typedef struct elm_pcm_node_config { /* PcmMatchingConfig fields the pipeline reads (pcm_matching_config.hpp; pcm.cpp:152-170) */
+    char lidar_type[32];          /* "ouster" selects OusterCloudmsg2cloud */
+    int32_t lidar_scan_time_end, pcm_voxel_max_point, run_deskew, input_index_sampling;
+    double lidar_time_delay, pcm_voxel_size, input_max_dist, input_voxel_ds_m;
+    double tf_ego_to_lidar[16];   /* column-major */
+} elm_pcm_node_config;
+void elm_pcm_node_config_default(elm_pcm_node_config* cfg);
+/* ProcessINI (pcm.cpp:121-196): reads [common_variable] + [pcm_matching] from localization.ini and the "Rear To Main
+ * LiDAR" / "Rear To Imu" rows of calibration.ini (ZYX Euler, lf.hpp:340-345).  Call the *_default functions first; keys
+ * missing from the file leave their fields unchanged.  Either path may be NULL. */
+int elm_load_pcm_config(const char* localization_ini, const char* calibration_ini, elm_pcm_node_config* node,
+                        elm_reg_config* reg);
+int elm_load_ekf_config(const char* localization_ini, elm_ekf_config* cfg); /* ekfl.cpp:250-316 */
+
+/* pcl::io::loadPCDFile<PointXYZINormal> as used for the map (pcm.cpp:72-79): ascii / binary / binary_compressed PCD,
+ * x y z (float32, matched by field name) -> freshly malloc'ed xyz[3n]; release with elm_free. */
+int elm_pcd_load_xyz(const char* path, float** xyz_out, size_t* n_out);
+void elm_free(void* p);
+
+/* PointCloud2-style record unpack (pcm.hpp:81-106; pcm.cpp:900-930). */
+enum { ELM_FIELD_UINT16 = 4, ELM_FIELD_UINT32 = 6, ELM_FIELD_FLOAT32 = 7 }; /* sensor_msgs/PointField datatypes */
+typedef struct elm_cloud_field { char name[24]; uint32_t offset; int32_t datatype; } elm_cloud_field;
+/* is_ouster = 0: PointXYZIT (x y z intensity time, float32).  is_ouster = 1: OusterPointXYZIRT -- every
+ * index_sampling-th record, intensity = reflectivity, time = t * 1e-9f, and the output holds n/index_sampling + 1 slots
+ * (a trailing default point when n is a multiple of index_sampling, as in the reference).  cap = capacity of the outputs
+ * in points; intensity / rel_time may be NULL. */
+int elm_scan_from_cloud(const void* data, size_t n_points, size_t point_step, const elm_cloud_field* fields, int n_fields,
+                        int is_ouster, int index_sampling, float* xyz, float* intensity, float* rel_time, size_t cap,
+                        size_t* n_out);
 
 /* ---------------------------------------------------------------- multi-GPU ----------------------- */
 /* One process per GPU.  Rank 0 obtains an id, the host distributes its bytes (e.g. torch.distributed
