@@ -82,6 +82,8 @@ struct elm_ctx {
     size_t h_trace_cap = 0;
     void* h_stage = nullptr; // pinned staging for synchronous uploads (scan points, deskew tables)
     size_t h_stage_cap = 0;
+    std::vector<std::pair<void*, size_t>> scan_pool; // device buffers of destroyed scans, reused by the next upload (a scan per
+                                                     // LiDAR message: no hipMalloc / hipFree on the per-scan path after warm-up)
     void* h_desc = nullptr; // pinned staging of the batch descriptors (read by an async copy)
     size_t h_desc_cap = 0;
     // in-flight batch
@@ -196,6 +198,7 @@ extern "C" void elm_ctx_destroy(elm_ctx* ctx) {
     if (ctx->h_active) (void)hipHostFree(ctx->h_active);
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
+    for (auto& b : ctx->scan_pool) (void)hipFree(b.first);
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
     if (ctx->h_trace) (void)hipHostFree(ctx->h_trace);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
@@ -730,6 +733,7 @@ extern "C" int elm_map_find_ground_height(const elm_map* m, double x, double y, 
 struct elm_scan {
     elm_ctx* ctx = nullptr;
     float4* d_pts = nullptr;
+    size_t cap_bytes = 0;
     uint32_t n = 0, n_total = 0;
 };
 
@@ -755,25 +759,50 @@ extern "C" int elm_scan_upload(elm_ctx* ctx, const float* xyz, size_t n, size_t 
     // consecutive points -- hence every 256-point workgroup and, through the XCD-aware block mapping, every XCD's
     // L2 -- touch a few adjacent map voxels, and the curve has no long jumps.  Stable in the input index.
     const double cs = 2.0;
-    std::vector<uint64_t> keyidx(n);
+    // 20-bit keys: two stable 10-bit counting passes (LSD radix) over the index array, ~10x cheaper than a comparison sort
+    std::vector<uint32_t> key(n), ord(n), tmp(n);
     for (size_t i = 0; i < n; ++i) {
         const int cx = (int)floor((double)xyz[3 * i] / cs) + 512, cy = (int)floor((double)xyz[3 * i + 1] / cs) + 512;
         const uint32_t ux = (uint32_t)std::min(std::max(cx, 0), 1023), uy = (uint32_t)std::min(std::max(cy, 0), 1023);
-        keyidx[i] = ((uint64_t)hilbert_xy2d(10, ux, uy) << 32) | (uint64_t)i;
+        key[i] = hilbert_xy2d(10, ux, uy);
     }
-    std::sort(keyidx.begin(), keyidx.end());
+    {
+        uint32_t cnt[1025];
+        memset(cnt, 0, sizeof cnt);
+        for (size_t i = 0; i < n; ++i) cnt[(key[i] & 1023u) + 1]++;
+        for (int b = 0; b < 1024; ++b) cnt[b + 1] += cnt[b];
+        for (size_t i = 0; i < n; ++i) tmp[cnt[key[i] & 1023u]++] = (uint32_t)i;
+        memset(cnt, 0, sizeof cnt);
+        for (size_t i = 0; i < n; ++i) cnt[(key[i] >> 10) + 1]++;
+        for (int b = 0; b < 1024; ++b) cnt[b + 1] += cnt[b];
+        for (size_t k = 0; k < n; ++k) ord[cnt[key[tmp[k]] >> 10]++] = tmp[k];
+    }
     int rc = pinned_reserve(ctx, &ctx->h_stage, &ctx->h_stage_cap, std::max<size_t>(n * sizeof(float4), 4096));
     if (rc != ELM_OK) return rc;
     float4* hp = (float4*)ctx->h_stage;
     for (size_t k = 0; k < n; ++k) {
-        const size_t i = (size_t)(keyidx[k] & 0xFFFFFFFFull);
+        const size_t i = ord[k];
         hp[k] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.f);
     }
     elm_scan* s = new elm_scan();
     s->ctx = ctx;
     s->n = (uint32_t)n;
     s->n_total = (uint32_t)n_total;
-    hipError_t e = hipMalloc((void**)&s->d_pts, std::max<size_t>(n * sizeof(float4), 256));
+    const size_t need = std::max<size_t>(n * sizeof(float4), 256);
+    hipError_t e = hipSuccess;
+    {
+        int best = -1; // smallest pooled buffer that fits
+        for (int i = 0; i < (int)ctx->scan_pool.size(); ++i)
+            if (ctx->scan_pool[i].second >= need && (best < 0 || ctx->scan_pool[i].second < ctx->scan_pool[best].second)) best = i;
+        if (best >= 0) {
+            s->d_pts = (float4*)ctx->scan_pool[best].first;
+            s->cap_bytes = ctx->scan_pool[best].second;
+            ctx->scan_pool.erase(ctx->scan_pool.begin() + best);
+        } else {
+            s->cap_bytes = (need + 65535) & ~(size_t)65535;
+            e = hipMalloc((void**)&s->d_pts, s->cap_bytes);
+        }
+    }
     if (e == hipSuccess && n) e = hipMemcpyAsync(s->d_pts, hp, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
@@ -789,7 +818,14 @@ extern "C" int elm_scan_upload(elm_ctx* ctx, const float* xyz, size_t n, size_t 
 extern "C" void elm_scan_destroy(elm_scan* s) {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
-    if (s->d_pts) (void)hipFree(s->d_pts);
+    if (s->d_pts) {
+        if (s->ctx->scan_pool.size() < 64) {
+            // the stream is in order: a later upload into this buffer is queued behind every kernel that still reads it
+            s->ctx->scan_pool.emplace_back((void*)s->d_pts, s->cap_bytes);
+        } else {
+            (void)hipFree(s->d_pts);
+        }
+    }
     delete s;
 }
 extern "C" size_t elm_scan_size(const elm_scan* s) { return s ? s->n : 0; }

@@ -169,13 +169,36 @@ extern "C" int elm_filter_points_by_distance(const float* xyz, const float* time
 
 extern "C" int elm_voxel_downsample(const float* xyz, size_t n, double voxel_size, int64_t* keep_idx, size_t* n_keep) {
     if (!n_keep || !(voxel_size > 0.0) || (n && (!xyz || !keep_idx))) return ELM_ERR_INVALID;
+    size_t k = 0;
+    // fast path: keys within +-2^20 per axis pack into one 64-bit word -> flat open-addressing set (no node allocations)
+    std::vector<uint64_t> packed(n);
+    bool fits = true;
+    const int32_t lim = 1 << 20;
+    for (size_t i = 0; i < n && fits; ++i) {
+        const double fx = floor((double)xyz[3 * i] / voxel_size), fy = floor((double)xyz[3 * i + 1] / voxel_size),
+                     fz = floor((double)xyz[3 * i + 2] / voxel_size);
+        if (!(fx >= -lim && fx < lim && fy >= -lim && fy < lim && fz >= -lim && fz < lim)) { fits = false; break; }
+        packed[i] = ((uint64_t)((int32_t)fx + lim) << 42) | ((uint64_t)((int32_t)fy + lim) << 21) | (uint64_t)((int32_t)fz + lim);
+    }
+    if (fits) {
+        size_t cap = 64;
+        while (cap < 2 * n) cap <<= 1;
+        std::vector<uint64_t> table(cap, ~0ull);
+        for (size_t i = 0; i < n; ++i) {
+            const uint64_t key = packed[i];
+            size_t h = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 20) & (cap - 1);
+            while (table[h] != ~0ull && table[h] != key) h = (h + 1) & (cap - 1);
+            if (table[h] == ~0ull) { table[h] = key; keep_idx[k++] = (int64_t)i; } // first point of every voxel, input order
+        }
+        *n_keep = k;
+        return ELM_OK;
+    }
     std::unordered_map<Key3, int64_t, Key3Hash> grid;
     grid.reserve(n);
-    size_t k = 0;
     for (size_t i = 0; i < n; ++i) {
         const Key3 key{(int32_t)floor((double)xyz[3 * i] / voxel_size), (int32_t)floor((double)xyz[3 * i + 1] / voxel_size),
                        (int32_t)floor((double)xyz[3 * i + 2] / voxel_size)};
-        if (grid.emplace(key, (int64_t)i).second) keep_idx[k++] = (int64_t)i; // first point of every voxel, input order
+        if (grid.emplace(key, (int64_t)i).second) keep_idx[k++] = (int64_t)i;
     }
     *n_keep = k;
     return ELM_OK;

@@ -17,6 +17,9 @@ def test_filter_and_downsample_match_oracle(oracle):
     assert np.array_equal(out, xyz[keep]) and np.array_equal(tout, t[keep]) and 0 < len(keep) < len(xyz)
     ds, idx = voxel_downsample(out, 1.5)
     assert np.array_equal(idx, oracle.voxel_downsample(out, 1.5)) and np.array_equal(ds, out[idx])
+    for vs in (0.05, 0.3, 1e-5):  # 1e-5: keys beyond +-2^20 take the generic (node-based) path
+        _, idx = voxel_downsample(out, vs)
+        assert np.array_equal(idx, oracle.voxel_downsample(out, vs))
     e, ei = voxel_downsample(np.zeros((0, 3), np.float32), 1.5)
     assert e.shape == (0, 3) and ei.size == 0
 
