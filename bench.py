@@ -149,8 +149,9 @@ def main():
     C = float(sum(r["n_cand_total"] for r in out)) / max(pt_iters, 1)  # candidates tested per point-iteration
     V = float(sum(r["n_occ_total"] for r in out)) / max(pt_iters, 1)   # occupied neighbour voxels per point-iteration
     bytes_unit = b_alg(int(method), C, V)
-    kmode = os.environ.get("ELM_KERNEL", "nbr")
-    kernel_name = (f"k_accumulate_nbr<{METHOD_NAMES[int(method)]}>" if (kmode == "nbr" and int(method) in (0, 1)) else
+    kmode = os.environ.get("ELM_KERNEL", "cell")
+    kernel_name = (f"k_accumulate_cell<{METHOD_NAMES[int(method)]}>" if (kmode == "cell" and int(method) in (0, 1)) else
+                   f"k_accumulate_nbr<{METHOD_NAMES[int(method)]}>" if (kmode == "nbr" and int(method) in (0, 1)) else
                    f"k_accumulate_direct<{METHOD_NAMES[int(method)]}>" if kmode == "direct" else f"k_accumulate<{METHOD_NAMES[int(method)]}>")
     # dominant kernel: k_accumulate. Units one launch processes ON THIS GPU = its shard of the batch's live points.
     launches = max(prof["accumulate_launches"], 1)

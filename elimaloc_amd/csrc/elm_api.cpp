@@ -91,7 +91,8 @@ struct elm_ctx {
     bool want_trace = false;
     bool in_flight = false;
     RegParams rp{};
-    int kernel_mode = 0; // accumulate kernel for P2P/GICP: 0 neighbourhood lists (default), 1 LDS-staged, 2 direct (ELM_KERNEL=nbr|staged|direct)
+    int kernel_mode = 4; // accumulate kernel for P2P/GICP: 4 cell-indexed neighbourhood lists (default), 0 streamed lists, 1 LDS-staged,
+                         // 2 direct (ELM_KERNEL=cell|nbr|staged|direct)
     // optional hipEvent timing
     bool profiling = false;
     std::vector<hipEvent_t> events;
@@ -184,7 +185,7 @@ extern "C" int elm_ctx_create(int device_id, elm_ctx** out) {
         delete ctx;
         return ELM_ERR_DEVICE;
     }
-    if (const char* k = getenv("ELM_KERNEL")) ctx->kernel_mode = (strcmp(k, "direct") == 0) ? 2 : (strcmp(k, "staged") == 0) ? 1 : 0;
+    if (const char* k = getenv("ELM_KERNEL")) ctx->kernel_mode = (strcmp(k, "direct") == 0) ? 2 : (strcmp(k, "staged") == 0) ? 1 : (strcmp(k, "nbr") == 0) ? 0 : 4;
     *out = ctx;
     return ELM_OK;
 }
@@ -256,6 +257,8 @@ struct elm_map {
     HashSlot* d_qslots = nullptr;
     Pt3* d_nbr_pts = nullptr;
     uint32_t* d_nbr_idx = nullptr;
+    uint16_t* d_nbr_cell_off = nullptr;
+    bool has_cells = false; // lists sorted by half-voxel cell + offset tables (every list <= 1024 entries)
     bool has_nbr = false;
     std::vector<int32_t> h_keys;
     std::vector<uint2> h_ranges;
@@ -408,7 +411,7 @@ static void build_host(const float* xyz, size_t n, double voxel_size, int max_po
 static void map_free(elm_map* m) {
     if (!m) return;
     (void)hipSetDevice(m->ctx->device);
-    void* ptrs[] = {m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_pt_mean, m->d_pt_cov, m->d_pt_nfit, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx};
+    void* ptrs[] = {m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_pt_mean, m->d_pt_cov, m->d_pt_nfit, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete m;
@@ -611,6 +614,19 @@ extern "C" int elm_map_build_neighbourhoods(elm_map* m) {
         NBR_CHK(hipGetLastError());
         NBR_CHK(hipStreamSynchronize(ctx->stream));
     }
+    // sort every list by half-voxel cell and write the per-list offset tables (cell-indexed kernel)
+    uint32_t max_count = 0;
+    for (uint32_t q = 0; q < n_q; ++q) max_count = std::max(max_count, counts[q]);
+    const size_t cell_bytes = std::max<size_t>((size_t)n_q * nbr_cell_stride() * sizeof(uint16_t), 256);
+    NBR_CHK(hipMalloc((void**)&m->d_nbr_cell_off, cell_bytes));
+    NBR_CHK(hipMemsetAsync(m->d_nbr_cell_off, 0, cell_bytes, ctx->stream));
+    m->has_cells = max_count <= 1024;
+    if (n_q && m->has_cells) {
+        (void)hipGetLastError();
+        launch_nbr_cellsort(ctx->stream, m->dm, d_qkeys, n_q, d_off, d_counts, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off);
+        NBR_CHK(hipGetLastError());
+    }
+    NBR_CHK(hipStreamSynchronize(ctx->stream));
     const uint32_t qcap = next_pow2((uint64_t)n_q * 2);
     {
         std::vector<HashSlot> qs(qcap);
@@ -632,8 +648,9 @@ extern "C" int elm_map_build_neighbourhoods(elm_map* m) {
     m->dm.n_q = n_q;
     m->dm.nbr_pts = m->d_nbr_pts;
     m->dm.nbr_idx = m->d_nbr_idx;
+    m->dm.nbr_cell_off = m->d_nbr_cell_off;
     m->has_nbr = true;
-    m->info.device_bytes += (size_t)total * (sizeof(Pt3) + sizeof(uint32_t)) + (size_t)qcap * sizeof(HashSlot);
+    m->info.device_bytes += (size_t)total * (sizeof(Pt3) + sizeof(uint32_t)) + (size_t)qcap * sizeof(HashSlot) + cell_bytes;
     m->info.n_query_voxels = n_q;
     m->info.nbr_entries = total;
     return ELM_OK;
@@ -919,7 +936,7 @@ extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_
     ctx->rp = rp;
 
     // P2P / GICP default to the neighbourhood-list kernel; the lists are built on first use (init-time cost)
-    const bool use_nbr = !map_empty && ctx->kernel_mode == 0 && (method == ELM_P2P || method == ELM_GICP);
+    const bool use_nbr = !map_empty && (ctx->kernel_mode == 0 || ctx->kernel_mode == 4) && (method == ELM_P2P || method == ELM_GICP);
     if (use_nbr && !map->has_nbr) {
         if ((rc = elm_map_build_neighbourhoods(const_cast<elm_map*>(map))) != ELM_OK) return rc;
     }
@@ -937,7 +954,9 @@ extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_
         for (int it = 0; it < cfg->max_iteration; ++it) {
             if ((rc = prof_mark(ctx)) != ELM_OK) return rc;
             if (blocks) {
-                if (use_nbr) launch_accumulate_nbr(ctx->stream, map->dm, dsc, batch, (int)blocks, st, (double*)ctx->d_partials.p, rp);
+                if (use_nbr && ctx->kernel_mode == 4 && map->has_cells)
+                    launch_accumulate_cell(ctx->stream, map->dm, dsc, batch, (int)blocks, st, (double*)ctx->d_partials.p, rp);
+                else if (use_nbr) launch_accumulate_nbr(ctx->stream, map->dm, dsc, batch, (int)blocks, st, (double*)ctx->d_partials.p, rp);
                 else launch_accumulate(ctx->stream, map->dm, dsc, batch, (int)blocks, st, (double*)ctx->d_partials.p, rp,
                                        (ctx->kernel_mode == 2 || map->info.max_points_per_voxel > 255) ? 1 : 0);
             }

@@ -43,6 +43,8 @@ struct DevMap {
     uint32_t n_q;
     const Pt3* nbr_pts;       // candidate coordinates, 12 bytes each
     const uint32_t* nbr_idx;  // global point index of every candidate (read only for a GICP winner)
+    const uint16_t* nbr_cell_off; // [n_q][224]: every list is sorted by half-voxel cell (6x6x6 grid, clamped); cell c =
+                                  // entries [off[c], off[c+1]) of the list
 };
 
 __host__ __device__ __forceinline__ uint32_t hash3(int32_t x, int32_t y, int32_t z) {
@@ -104,6 +106,11 @@ void launch_solve(hipStream_t s, const ScanDesc* scans, int batch, ScanState* st
 void launch_accumulate_nbr(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                            ScanState* st, double* partials, const RegParams& rp);
 void launch_nbr_count(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, uint32_t* counts, uint32_t* nocc);
+void launch_accumulate_cell(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
+                            ScanState* st, double* partials, const RegParams& rp);
+void launch_nbr_cellsort(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets,
+                         const uint32_t* counts, Pt3* pts, uint32_t* idx, uint16_t* cell_off);
+size_t nbr_cell_stride();
 void launch_nbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets, Pt3* out,
                      uint32_t* out_idx);
 void launch_voxel_cov(hipStream_t s, const DevMap& m, const uint2* ranges, double* vox_mean, double* vox_cov);

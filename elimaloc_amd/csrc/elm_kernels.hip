@@ -910,12 +910,18 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_nbr(const DevMap m, const
                 bd2 = (ex * ex + ey * ey) + ez * ez; // the reference's float64 value for the range test
                 bj = j1;
             } else {
-                // exact walk (reference order, strict <)
+                // exact float64 walk; the list is cell-sorted, so equal distances are resolved explicitly towards the
+                // candidate the reference meets first (bucket visiting rank, then insertion order = global index)
+                unsigned brank = 0xFFFFFFFFu, bgi = 0xFFFFFFFFu;
                 for (int k = 0; k < n; ++k) {
                     const Pt3 q = lp[k];
                     const double ex = (double)q.x - gx, ey = (double)q.y - gy, ez = (double)q.z - gz;
                     const double d2 = (ex * ex + ey * ey) + ez * ez;
-                    if (d2 < bd2) { bd2 = d2; bj = k; }
+                    if (d2 > bd2) continue;
+                    const int kx = (int)((double)q.x / m.voxel_size), ky = (int)((double)q.y / m.voxel_size), kz = (int)((double)q.z / m.voxel_size);
+                    const unsigned rank = (unsigned)(((kx - vx + 1) * 3 + (ky - vy + 1)) * 3 + (kz - vz + 1));
+                    const unsigned gi = m.nbr_idx[(size_t)start + k];
+                    if (d2 < bd2 || rank < brank || (rank == brank && gi < bgi)) { bd2 = d2; bj = k; brank = rank; bgi = gi; }
                 }
                 n_exact = 1.0;
             }
@@ -933,6 +939,300 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_nbr(const DevMap m, const
         acc[31] = (double)cnt + n_exact * kFallbackUnit; // high part: points that needed the exact float64 walk
     }
     block_reduce_store_lds(acc, s_buf, partials + (size_t)L * kSums);
+}
+
+// ---- K1d: cell-indexed neighbourhood lists --------------------------------------------------------------
+// The candidate list of a query voxel is kept sorted by half-voxel cells: a 6x6x6 grid with origin (v - 1) * voxel_size
+// (per axis), edge voxel_size / 2, indices clamped to 0..5 so the outermost cells are unbounded outward (truncated keys
+// make the bucket of voxel key 0 two voxels wide).  cell_off[qid][c] .. cell_off[qid][c + 1] is cell c's range.  A thread
+//   1. probes its query voxel (as K1c),
+//   2. scans the cell that holds its own transformed point (a handful of candidates) -> a first best distance r,
+//   3. scans only the cells that intersect the axis-aligned box g +- r (r inflated by the float32 error margin).
+// Candidates in cells outside the box are provably farther than the winner plus that margin, so they can neither win
+// nor tie: the float32 best / runner-up logic of K1c decides among the visited candidates exactly as before, and the
+// rare near-tie falls back to an exact float64 walk over the WHOLE list.  Ties there are resolved as the reference
+// resolves them (first candidate in its visiting order, vhm.cpp:208-243 + insertion order) from the candidate's own
+// bucket rank and global index, so the list order is free.  ~10-20 candidates are distance-tested per point instead of ~240.
+constexpr int kCellAxis = 6;
+constexpr int kCells = kCellAxis * kCellAxis * kCellAxis; // 216
+constexpr int kCellStride = 224;                          // uint16 entries per query voxel (217 used), 448 B
+
+__device__ __forceinline__ int cell_of(double a, double o, double inv_h) {
+    const int c = (int)floor((a - o) * inv_h);
+    return c < 0 ? 0 : (c > kCellAxis - 1 ? kCellAxis - 1 : c);
+}
+
+template <int METHOD>
+__global__ __launch_bounds__(kBlock) void k_accumulate_cell(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
+                                                            unsigned total_blocks, const ScanState* __restrict__ st,
+                                                            double* __restrict__ partials, const RegParams rp) {
+    __shared__ double s_buf[16 * kBlock];
+    ELM_PHASE_BEGIN
+    const unsigned L = xcd_remap(blockIdx.x, total_blocks);
+    const int s = find_scan(scans, batch, L);
+    const ScanState& S = st[s];
+    if (S.done) return;
+    const ScanDesc sd = scans[s];
+    const unsigned i = (L - sd.blk_begin) * kBlock + threadIdx.x;
+    const bool valid = i < sd.n;
+    double acc[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc[k] = 0.0;
+    if (valid) {
+        const float4 pf = sd.pts[i];
+        const double px = pf.x, py = pf.y, pz = pf.z;
+        const double gx = ((S.T[0] * px + S.T[4] * py) + S.T[8] * pz) + S.T[12];
+        const double gy = ((S.T[1] * px + S.T[5] * py) + S.T[9] * pz) + S.T[13];
+        const double gz = ((S.T[2] * px + S.T[6] * py) + S.T[10] * pz) + S.T[14];
+        const int vx = floor_key(gx, m.voxel_size), vy = floor_key(gy, m.voxel_size), vz = floor_key(gz, m.voxel_size);
+        unsigned start = 0, cnt = 0, nocc = 0;
+        int qid = -1;
+        ELM_PHASE(8)
+        {
+            unsigned h = hash3(vx, vy, vz) & m.qmask;
+            for (;;) {
+                const int4 key = *reinterpret_cast<const int4*>(&m.qslots[h]);
+                const uint4 rg = *reinterpret_cast<const uint4*>(&m.qslots[h].start);
+                if (key.w < 0) break;
+                if (key.x == vx && key.y == vy && key.z == vz) { start = rg.x; cnt = rg.y; nocc = rg.z; qid = key.w; break; }
+                h = (h + 1) & m.qmask;
+            }
+        }
+        ELM_PHASE(9)
+        const Pt3* __restrict__ lp = m.nbr_pts + start;
+        const uint16_t* __restrict__ co = m.nbr_cell_off + (size_t)(qid < 0 ? 0 : qid) * kCellStride;
+        double bd2 = DBL_MAX;
+        int bj = -1;
+        double n_exact = 0.0;
+        int n_tested = 0;
+        if (cnt) {
+            const float ghx = (float)gx, ghy = (float)gy, ghz = (float)gz;
+            const float glx = (float)(gx - (double)ghx), gly = (float)(gy - (double)ghy), glz = (float)(gz - (double)ghz);
+            const float slack = 4e-11f * (fabsf(ghx) + fabsf(ghy) + fabsf(ghz) + 1.0f);
+            const double inv_h = 2.0 / m.voxel_size;
+            const double ox = (double)(vx - 1) * m.voxel_size, oy = (double)(vy - 1) * m.voxel_size, oz = (double)(vz - 1) * m.voxel_size;
+            float m1 = __builtin_inff(), m2 = __builtin_inff();
+            int j1 = -1;
+            // 8 candidates of one contiguous range at a time; out-of-range slots re-read the last valid one and are masked
+#define ELM_CELL_STEP(PTR, END)                                                                              \
+    {                                                                                                        \
+        Pt3 q[8];                                                                                            \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) q[u] = lp[min((PTR) + u, (END)-1)];                    \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                      \
+            const float ex = (q[u].x - ghx) - glx, ey = (q[u].y - ghy) - gly, ez = (q[u].z - ghz) - glz;     \
+            const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));                                            \
+            const float d = ((PTR) + u < (END)) ? dd : __builtin_inff();                                     \
+            m2 = fminf(m2, fmaxf(d, m1));                                                                    \
+            const bool c = d < m1;                                                                           \
+            m1 = c ? d : m1;                                                                                 \
+            j1 = c ? ((PTR) + u) : j1;                                                                       \
+        }                                                                                                    \
+        n_tested += min(8, (END) - (PTR));                                                                   \
+    }
+            // stage A: the cell that holds g
+            const int cx = cell_of(gx, ox, inv_h), cy = cell_of(gy, oy, inv_h), cz = cell_of(gz, oz, inv_h);
+            const int own = (cx * kCellAxis + cy) * kCellAxis + cz;
+            const int ob = co[own], oe = co[own + 1];
+            for (int ptr = ob; ptr < oe; ptr += 8) ELM_CELL_STEP(ptr, oe)
+            ELM_PHASE(10)
+            // stage B: the cells that intersect the box g +- r (r = current best distance + float32 error margin).  If the
+            // own cell was empty the box is own +- 1 cell instead.  Cells are ordered (ix, iy, iz)-major in the list, so
+            // the cells iz0..iz1 of one (ix, iy) column are ONE contiguous range; the own cell is cut out of its column.
+            int ix0, ix1, iy0, iy1, iz0, iz1;
+            const bool own_empty = j1 < 0;
+            if (!own_empty) {
+                const float r2 = m1 + m1 * 1.9073486328125e-06f + slack;
+                const double r = sqrt((double)r2) * 1.000001 + 1e-6;
+                ix0 = cell_of(gx - r, ox, inv_h); ix1 = cell_of(gx + r, ox, inv_h);
+                iy0 = cell_of(gy - r, oy, inv_h); iy1 = cell_of(gy + r, oy, inv_h);
+                iz0 = cell_of(gz - r, oz, inv_h); iz1 = cell_of(gz + r, oz, inv_h);
+            } else {
+                ix0 = max(cx - 1, 0); ix1 = min(cx + 1, kCellAxis - 1);
+                iy0 = max(cy - 1, 0); iy1 = min(cy + 1, kCellAxis - 1);
+                iz0 = max(cz - 1, 0); iz1 = min(cz + 1, kCellAxis - 1);
+            }
+            const int nx = ix1 - ix0 + 1, ny = iy1 - iy0 + 1;
+            if (nx <= 3 && ny <= 3) {
+                // fast path (practically always): <= 9 columns.  All column offsets are fetched at once, the ranges (own
+                // column split around the own cell -> 10 segments) are concatenated into one virtual range and streamed
+                // 8 candidates per step, so a lane needs 1 + ceil(total / 8) round trips however its box is shaped.
+                int dk[10], ck[11];
+                int e_own = 0;
+                const int ko = (cx - ix0) * 3 + (cy - iy0);
+                ck[0] = 0;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const int kx = k / 3, ky = k % 3;
+                    int bb = 0, ee = 0;
+                    if (kx < nx && ky < ny) {
+                        const int base = ((ix0 + kx) * kCellAxis + (iy0 + ky)) * kCellAxis;
+                        bb = co[base + iz0];
+                        ee = co[base + iz1 + 1];
+                    }
+                    if (k == ko) { e_own = ee; ee = ob; }
+                    dk[k] = bb - ck[k];
+                    ck[k + 1] = ck[k] + (ee - bb);
+                }
+                dk[9] = oe - ck[9];
+                ck[10] = ck[9] + (e_own - oe);
+                const int total = ck[10];
+                for (int v0 = 0; v0 < total; v0 += 8) {
+                    Pt3 q[8];
+                    int id[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int v = min(v0 + u, total - 1);
+                        int d = dk[9];
+#pragma unroll
+                        for (int k = 8; k >= 0; --k) d = (v < ck[k + 1]) ? dk[k] : d;
+                        id[u] = v + d;
+                        q[u] = lp[id[u]];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float ex = (q[u].x - ghx) - glx, ey = (q[u].y - ghy) - gly, ez = (q[u].z - ghz) - glz;
+                        const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+                        const float d = (v0 + u < total) ? dd : __builtin_inff();
+                        m2 = fminf(m2, fmaxf(d, m1));
+                        const bool c = d < m1;
+                        m1 = c ? d : m1;
+                        j1 = c ? id[u] : j1;
+                    }
+                    n_tested += min(8, total - v0);
+                }
+            } else {
+                int ix = ix0, iy = iy0; // next column of the box
+                bool more = true;
+                int ptr = 0, end = 0, ptr2 = 0, end2 = 0;
+                for (;;) {
+                    while (ptr >= end) {
+                        if (ptr2 < end2) { ptr = ptr2; end = end2; ptr2 = end2 = 0; continue; } // part of the own column above the own cell
+                        if (!more) break;
+                        const int base = (ix * kCellAxis + iy) * kCellAxis;
+                        const int b = co[base + iz0], e = co[base + iz1 + 1];
+                        const bool own_col = (ix == cx) && (iy == cy);
+                        if (++iy > iy1) { iy = iy0; if (++ix > ix1) more = false; }
+                        if (own_col) { ptr = b; end = ob; ptr2 = oe; end2 = e; }
+                        else { ptr = b; end = e; }
+                    }
+                    if (ptr >= end) break;
+                    ELM_CELL_STEP(ptr, end)
+                    ptr += 8;
+                }
+            }
+#undef ELM_CELL_STEP
+            ELM_PHASE(11)
+            bool need_exact = false;
+            if (own_empty) {
+                if (j1 < 0) {
+                    need_exact = true; // nothing within one cell: isolated point, let the exact walk scan the whole list
+                } else {
+                    // the visited box must contain the ball of the best distance, otherwise unvisited cells could hold the winner
+                    const float r2 = m1 + m1 * 1.9073486328125e-06f + slack;
+                    const double r = sqrt((double)r2) * 1.000001 + 1e-6;
+                    need_exact = cell_of(gx - r, ox, inv_h) < ix0 || cell_of(gx + r, ox, inv_h) > ix1 || cell_of(gy - r, oy, inv_h) < iy0 ||
+                                 cell_of(gy + r, oy, inv_h) > iy1 || cell_of(gz - r, oz, inv_h) < iz0 || cell_of(gz + r, oz, inv_h) > iz1;
+                }
+            }
+            {
+                const bool clear_winner = !need_exact && j1 >= 0 && m2 > m1 + m1 * 1.9073486328125e-06f + slack; // 2^-19
+                if (clear_winner) {
+                    const Pt3 q = lp[j1];
+                    const double ex = (double)q.x - gx, ey = (double)q.y - gy, ez = (double)q.z - gz;
+                    bd2 = (ex * ex + ey * ey) + ez * ez; // the reference's float64 value for the range test
+                    bj = j1;
+                } else {
+                    // exact float64 walk over the whole list; equal distances go to the candidate the reference meets first
+                    unsigned brank = 0xFFFFFFFFu, bgi = 0xFFFFFFFFu;
+                    for (int k = 0; k < (int)cnt; ++k) {
+                        const Pt3 q = lp[k];
+                        const double ex = (double)q.x - gx, ey = (double)q.y - gy, ez = (double)q.z - gz;
+                        const double d2 = (ex * ex + ey * ey) + ez * ez;
+                        if (d2 > bd2) continue;
+                        const int kx = (int)((double)q.x / m.voxel_size), ky = (int)((double)q.y / m.voxel_size), kz = (int)((double)q.z / m.voxel_size);
+                        const unsigned rank = (unsigned)(((kx - vx + 1) * 3 + (ky - vy + 1)) * 3 + (kz - vz + 1));
+                        const unsigned gi = m.nbr_idx[(size_t)start + k];
+                        if (d2 < bd2 || rank < brank || (rank == brank && gi < bgi)) { bd2 = d2; bj = k; brank = rank; bgi = gi; }
+                    }
+                    n_exact = 1.0;
+                }
+            }
+        }
+        ELM_PHASE(12)
+        float bx = 0.f, by = 0.f, bz = 0.f;
+        int bidx = -1;
+        if (bj >= 0) {
+            const Pt3 q = lp[bj];
+            bx = q.x; by = q.y; bz = q.z;
+            bidx = (METHOD == ELM_GICP) ? (int)m.nbr_idx[(size_t)start + bj] : 0;
+        }
+        finish_point_pair<METHOD>(acc, m, S, rp, px, py, pz, gx, gy, gz, bd2, bx, by, bz, bidx);
+        acc[29] = (double)cnt;  // candidates of the reference's walk
+        acc[30] = (double)nocc;
+        acc[31] = (double)n_tested + n_exact * kFallbackUnit;
+        ELM_PHASE(13)
+    }
+    block_reduce_store_lds(acc, s_buf, partials + (size_t)L * kSums);
+    ELM_PHASE(14)
+}
+
+// map build: sort every neighbourhood list by cell (stable: key = cell << 16 | position) and write its offset table.
+// One 64-lane workgroup per query voxel, bitonic sort of <= 1024 keys in LDS.
+__global__ __launch_bounds__(64) void k_nbr_cellsort(const DevMap m, const int32_t* __restrict__ qkeys, unsigned n_q,
+                                                     const unsigned* __restrict__ offsets, const unsigned* __restrict__ counts,
+                                                     Pt3* __restrict__ pts, unsigned* __restrict__ idx, uint16_t* __restrict__ cell_off) {
+    __shared__ unsigned s_key[1024];
+    __shared__ Pt3 s_pt[1024];
+    __shared__ unsigned s_idx[1024];
+    const unsigned q = blockIdx.x;
+    if (q >= n_q) return;
+    const unsigned l = threadIdx.x;
+    const unsigned n = counts[q], o = offsets[q];
+    uint16_t* co = cell_off + (size_t)q * kCellStride;
+    if (n == 0 || n > 1024) { // (n > 1024 cannot happen: 27 buckets of <= 30 points; the host refuses larger voxel caps)
+        for (unsigned c = l; c < (unsigned)kCellStride; c += 64) co[c] = 0;
+        return;
+    }
+    const int vx = qkeys[3 * q], vy = qkeys[3 * q + 1], vz = qkeys[3 * q + 2];
+    const double inv_h = 2.0 / m.voxel_size;
+    const double ox = (double)(vx - 1) * m.voxel_size, oy = (double)(vy - 1) * m.voxel_size, oz = (double)(vz - 1) * m.voxel_size;
+    unsigned np2 = 64;
+    while (np2 < n) np2 <<= 1;
+    for (unsigned j = l; j < np2; j += 64) {
+        if (j < n) {
+            const Pt3 p = pts[(size_t)o + j];
+            s_pt[j] = p;
+            s_idx[j] = idx[(size_t)o + j];
+            const unsigned cell = (unsigned)((cell_of((double)p.x, ox, inv_h) * kCellAxis + cell_of((double)p.y, oy, inv_h)) * kCellAxis +
+                                             cell_of((double)p.z, oz, inv_h));
+            s_key[j] = (cell << 16) | j;
+        } else {
+            s_key[j] = 0xFFFFFFFFu;
+        }
+    }
+    __syncthreads();
+    for (unsigned k = 2; k <= np2; k <<= 1)
+        for (unsigned jj = k >> 1; jj > 0; jj >>= 1) {
+            for (unsigned t = l; t < np2; t += 64) {
+                const unsigned p = t ^ jj;
+                if (p > t) {
+                    const unsigned a = s_key[t], b = s_key[p];
+                    const bool up = (t & k) == 0;
+                    if ((a > b) == up) { s_key[t] = b; s_key[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (unsigned j = l; j < n; j += 64) {
+        const unsigned src = s_key[j] & 0xFFFFu;
+        pts[(size_t)o + j] = s_pt[src];
+        idx[(size_t)o + j] = s_idx[src];
+        const int c = (int)(s_key[j] >> 16);
+        const int cprev = j ? (int)(s_key[j - 1] >> 16) : -1;
+        for (int cc = cprev + 1; cc <= c; ++cc) co[cc] = (uint16_t)j;
+        if (j == n - 1)
+            for (int cc = c + 1; cc <= kCells; ++cc) co[cc] = (uint16_t)n;
+    }
 }
 
 // map build: size and content of the neighbourhood list of every query voxel (init time)
@@ -1421,6 +1721,19 @@ void launch_accumulate_nbr(hipStream_t s, const DevMap& m, const ScanDesc* scans
     else
         hipLaunchKernelGGL((k_accumulate_nbr<ELM_GICP>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
 }
+void launch_accumulate_cell(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
+                            ScanState* st, double* partials, const RegParams& rp) {
+    dim3 g(total_blocks), b(kBlock);
+    if (rp.method == ELM_P2P)
+        hipLaunchKernelGGL((k_accumulate_cell<ELM_P2P>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
+    else
+        hipLaunchKernelGGL((k_accumulate_cell<ELM_GICP>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
+}
+void launch_nbr_cellsort(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets,
+                         const uint32_t* counts, Pt3* pts, uint32_t* idx, uint16_t* cell_off) {
+    hipLaunchKernelGGL(k_nbr_cellsort, dim3(n_q), dim3(64), 0, s, m, qkeys, n_q, offsets, counts, pts, idx, cell_off);
+}
+size_t nbr_cell_stride() { return (size_t)kCellStride; }
 void launch_nbr_count(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, uint32_t* counts, uint32_t* nocc) {
     hipLaunchKernelGGL(k_nbr_count, dim3((n_q + 255) / 256), dim3(256), 0, s, m, qkeys, n_q, counts, nocc);
 }

@@ -412,7 +412,7 @@ def test_full_size_c4_vgicp_shape(ctx, oracle):
     _compare_run(det, ref)
 
 
-@pytest.mark.parametrize("kernel_env", ["nbr", "staged", "direct"])
+@pytest.mark.parametrize("kernel_env", ["cell", "nbr", "staged", "direct"])
 @pytest.mark.parametrize("voxel_size,max_pts,th,method", [
     (0.5, 30, 5.0, 0),    # finer voxels
     (1.5, 50, 5.0, 1),    # README-recommended 50 points per voxel (buckets > 32 points), GICP
