@@ -943,30 +943,59 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_nbr(const DevMap m, const
 
 // ---- K1d: cell-indexed neighbourhood lists --------------------------------------------------------------
 // The candidate list of a query voxel is kept sorted by half-voxel cells: a 6x6x6 grid with origin (v - 1) * voxel_size
-// (per axis), edge voxel_size / 2, indices clamped to 0..5 so the outermost cells are unbounded outward (truncated keys
-// make the bucket of voxel key 0 two voxels wide).  cell_off[qid][c] .. cell_off[qid][c + 1] is cell c's range.  A thread
-//   1. probes its query voxel (as K1c),
-//   2. scans the cell that holds its own transformed point (a handful of candidates) -> a first best distance r,
-//   3. scans only the cells that intersect the axis-aligned box g +- r (r inflated by the float32 error margin).
-// Candidates in cells outside the box are provably farther than the winner plus that margin, so they can neither win
-// nor tie: the float32 best / runner-up logic of K1c decides among the visited candidates exactly as before, and the
-// rare near-tie falls back to an exact float64 walk over the WHOLE list.  Ties there are resolved as the reference
-// resolves them (first candidate in its visiting order, vhm.cpp:208-243 + insertion order) from the candidate's own
-// bucket rank and global index, so the list order is free.  ~10-20 candidates are distance-tested per point instead of ~240.
+// (per axis), edge h = voxel_size / 2, indices clamped to 0..5 so the outermost cells are unbounded outward (truncated
+// keys make the bucket of voxel key 0 two voxels wide).  Cells are ordered (ix, iy, iz)-major, so the cells iz0..iz1 of
+// one (ix, iy) column are one contiguous range; a 16-byte record per column holds its seven cell boundaries.
+//   stage 1, per lane: probe the query voxel (as K1c), then scan the 2x2x2 block of cells that g leans into (own cell +
+//     the neighbours on the nearer side of every axis; 4 column ranges, ~20 candidates) in float32 with the best /
+//     runner-up logic of K1c.  Every point of space within rho = distance(g, open faces of that block) >= h/2 lies in the
+//     block, so when the float32 winner is a clear one AND its distance (+ error margin) is below rho, no candidate outside
+//     the block can win or tie: the lane is done after three round trips (probe, 4 records, candidates).
+//   stage 2, per wave: the few lanes that could not decide (pose still far off, isolated points, near ties) are served one
+//     after the other by the whole wave: 64 lanes share the lane's complete list, compute the reference's float64
+//     distances and reduce (distance, visiting rank, global index) lexicographically -- exactly the reference's first
+//     strict minimum in its visiting order (vhm.cpp:208-243 + insertion order), whatever the order of the list.
 constexpr int kCellAxis = 6;
 constexpr int kCells = kCellAxis * kCellAxis * kCellAxis; // 216
-constexpr int kCellStride = 224;                          // uint16 entries per query voxel (217 used), 448 B
+constexpr int kCellCols = kCellAxis * kCellAxis;          // 36 (ix, iy) columns
+constexpr int kCellStride = kCellCols * 8;                // uint16 entries per query voxel: one 16-byte record per column =
+                                                          // offsets of its cells iz = 0..5, the column end, one pad -> 576 B
+
+// entry i (0..7) of a column record
+__device__ __forceinline__ int col_entry(const uint4 r, int i) {
+    const unsigned w = (i & 4) ? ((i & 2) ? r.w : r.z) : ((i & 2) ? r.y : r.x);
+    return (int)((i & 1) ? (w >> 16) : (w & 0xFFFFu));
+}
 
 __device__ __forceinline__ int cell_of(double a, double o, double inv_h) {
     const int c = (int)floor((a - o) * inv_h);
     return c < 0 ? 0 : (c > kCellAxis - 1 ? kCellAxis - 1 : c);
 }
 
+// first cell c0 of the two-cell span [c0, c0 + 1] that g leans into along one axis, and the distance from g to the open
+// faces of that span (faces of the clamped outermost cells do not exist: those cells are unbounded outward)
+__device__ __forceinline__ int lean_span(double g, double o, double h, double inv_h, double& rho) {
+    const double u = (g - o) * inv_h;
+    const double fl = floor(u);
+    int c = (int)fl;
+    c = c < 0 ? 0 : (c > kCellAxis - 1 ? kCellAxis - 1 : c);
+    int c0 = (u - fl >= 0.5) ? c : c - 1;
+    c0 = c0 < 0 ? 0 : (c0 > kCellAxis - 2 ? kCellAxis - 2 : c0);
+    const double lo = (c0 == 0) ? DBL_MAX : g - (o + (double)c0 * h);
+    const double hi = (c0 == kCellAxis - 2) ? DBL_MAX : (o + (double)(c0 + 2) * h) - g;
+    rho = fmin(rho, fmin(lo, hi));
+    return c0;
+}
+
 template <int METHOD>
 __global__ __launch_bounds__(kBlock) void k_accumulate_cell(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
                                                             unsigned total_blocks, const ScanState* __restrict__ st,
                                                             double* __restrict__ partials, const RegParams rp) {
+#ifdef ELM_OCC_TEST
+    __shared__ double s_buf[16 * kBlock * ELM_OCC_TEST];
+#else
     __shared__ double s_buf[16 * kBlock];
+#endif
     ELM_PHASE_BEGIN
     const unsigned L = xcd_remap(blockIdx.x, total_blocks);
     const int s = find_scan(scans, batch, L);
@@ -978,187 +1007,184 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_cell(const DevMap m, cons
     double acc[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) acc[k] = 0.0;
+    double px = 0.0, py = 0.0, pz = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
+    int vx = 0, vy = 0, vz = 0;
+    unsigned start = 0, cnt = 0, nocc = 0;
+    const Pt3* __restrict__ lp = m.nbr_pts;
+    double bd2 = DBL_MAX;
+    int bj = -1;
+    int n_tested = 0;
+    bool hard = false;
     if (valid) {
         const float4 pf = sd.pts[i];
-        const double px = pf.x, py = pf.y, pz = pf.z;
-        const double gx = ((S.T[0] * px + S.T[4] * py) + S.T[8] * pz) + S.T[12];
-        const double gy = ((S.T[1] * px + S.T[5] * py) + S.T[9] * pz) + S.T[13];
-        const double gz = ((S.T[2] * px + S.T[6] * py) + S.T[10] * pz) + S.T[14];
-        const int vx = floor_key(gx, m.voxel_size), vy = floor_key(gy, m.voxel_size), vz = floor_key(gz, m.voxel_size);
-        unsigned start = 0, cnt = 0, nocc = 0;
+        px = pf.x; py = pf.y; pz = pf.z;
+        gx = ((S.T[0] * px + S.T[4] * py) + S.T[8] * pz) + S.T[12];
+        gy = ((S.T[1] * px + S.T[5] * py) + S.T[9] * pz) + S.T[13];
+        gz = ((S.T[2] * px + S.T[6] * py) + S.T[10] * pz) + S.T[14];
+        vx = floor_key(gx, m.voxel_size); vy = floor_key(gy, m.voxel_size); vz = floor_key(gz, m.voxel_size);
         int qid = -1;
         ELM_PHASE(8)
         {
+            // linear probing, two slots per round trip (the table is kept at load <= 0.5: a third slot is rarely needed)
             unsigned h = hash3(vx, vy, vz) & m.qmask;
             for (;;) {
+                const unsigned h2 = (h + 1) & m.qmask;
                 const int4 key = *reinterpret_cast<const int4*>(&m.qslots[h]);
                 const uint4 rg = *reinterpret_cast<const uint4*>(&m.qslots[h].start);
+                const int4 key2 = *reinterpret_cast<const int4*>(&m.qslots[h2]);
+                const uint4 rg2 = *reinterpret_cast<const uint4*>(&m.qslots[h2].start);
                 if (key.w < 0) break;
                 if (key.x == vx && key.y == vy && key.z == vz) { start = rg.x; cnt = rg.y; nocc = rg.z; qid = key.w; break; }
-                h = (h + 1) & m.qmask;
+                if (key2.w < 0) break;
+                if (key2.x == vx && key2.y == vy && key2.z == vz) { start = rg2.x; cnt = rg2.y; nocc = rg2.z; qid = key2.w; break; }
+                h = (h + 2) & m.qmask;
             }
         }
         ELM_PHASE(9)
-        const Pt3* __restrict__ lp = m.nbr_pts + start;
-        const uint16_t* __restrict__ co = m.nbr_cell_off + (size_t)(qid < 0 ? 0 : qid) * kCellStride;
-        double bd2 = DBL_MAX;
-        int bj = -1;
-        double n_exact = 0.0;
-        int n_tested = 0;
+        lp = m.nbr_pts + start;
+#ifdef ELM_SKIP_STAGE1
+        if (false) {
+#else
         if (cnt) {
+#endif
+            const uint16_t* __restrict__ co = m.nbr_cell_off + (size_t)qid * kCellStride;
+            const double hc = 0.5 * m.voxel_size, inv_h = 2.0 / m.voxel_size;
+            const double ox = (double)(vx - 1) * m.voxel_size, oy = (double)(vy - 1) * m.voxel_size, oz = (double)(vz - 1) * m.voxel_size;
+            double rho = DBL_MAX;
+            const int c0x = lean_span(gx, ox, hc, inv_h, rho), c0y = lean_span(gy, oy, hc, inv_h, rho), c0z = lean_span(gz, oz, hc, inv_h, rho);
+            // the four (ix, iy) columns of the block: one contiguous range [cell c0z, cell c0z + 2) each
+            int sb[4], se[4], cb[5];
+            cb[0] = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint4 rec = *reinterpret_cast<const uint4*>(co + ((c0x + (k >> 1)) * kCellAxis + (c0y + (k & 1))) * 8);
+                sb[k] = col_entry(rec, c0z);
+                se[k] = col_entry(rec, c0z + 2);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cb[k + 1] = cb[k] + ((se[k] - sb[k] + 3) >> 2); // blocks of 4 candidates
+            const int nblk = cb[4];
             const float ghx = (float)gx, ghy = (float)gy, ghz = (float)gz;
             const float glx = (float)(gx - (double)ghx), gly = (float)(gy - (double)ghy), glz = (float)(gz - (double)ghz);
-            const float slack = 4e-11f * (fabsf(ghx) + fabsf(ghy) + fabsf(ghz) + 1.0f);
-            const double inv_h = 2.0 / m.voxel_size;
-            const double ox = (double)(vx - 1) * m.voxel_size, oy = (double)(vy - 1) * m.voxel_size, oz = (double)(vz - 1) * m.voxel_size;
             float m1 = __builtin_inff(), m2 = __builtin_inff();
             int j1 = -1;
-            // 8 candidates of one contiguous range at a time; out-of-range slots re-read the last valid one and are masked
-#define ELM_CELL_STEP(PTR, END)                                                                              \
-    {                                                                                                        \
-        Pt3 q[8];                                                                                            \
-        _Pragma("unroll") for (int u = 0; u < 8; ++u) q[u] = lp[min((PTR) + u, (END)-1)];                    \
-        _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                      \
-            const float ex = (q[u].x - ghx) - glx, ey = (q[u].y - ghy) - gly, ez = (q[u].z - ghz) - glz;     \
-            const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));                                            \
-            const float d = ((PTR) + u < (END)) ? dd : __builtin_inff();                                     \
-            m2 = fminf(m2, fmaxf(d, m1));                                                                    \
-            const bool c = d < m1;                                                                           \
-            m1 = c ? d : m1;                                                                                 \
-            j1 = c ? ((PTR) + u) : j1;                                                                       \
-        }                                                                                                    \
-        n_tested += min(8, (END) - (PTR));                                                                   \
-    }
-            // stage A: the cell that holds g
-            const int cx = cell_of(gx, ox, inv_h), cy = cell_of(gy, oy, inv_h), cz = cell_of(gz, oz, inv_h);
-            const int own = (cx * kCellAxis + cy) * kCellAxis + cz;
-            const int ob = co[own], oe = co[own + 1];
-            for (int ptr = ob; ptr < oe; ptr += 8) ELM_CELL_STEP(ptr, oe)
-            ELM_PHASE(10)
-            // stage B: the cells that intersect the box g +- r (r = current best distance + float32 error margin).  If the
-            // own cell was empty the box is own +- 1 cell instead.  Cells are ordered (ix, iy, iz)-major in the list, so
-            // the cells iz0..iz1 of one (ix, iy) column are ONE contiguous range; the own cell is cut out of its column.
-            int ix0, ix1, iy0, iy1, iz0, iz1;
-            const bool own_empty = j1 < 0;
-            if (!own_empty) {
-                const float r2 = m1 + m1 * 1.9073486328125e-06f + slack;
+            for (int t0 = 0; t0 < nblk; t0 += 2) { // two blocks = 8 independent loads per round trip
+                int pp[2], pe[2];
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const int t = t0 + w;
+                    int b_ = sb[3] - 4 * cb[3], e_ = se[3];
+#pragma unroll
+                    for (int k = 2; k >= 0; --k) {
+                        const bool lt = t < cb[k + 1];
+                        b_ = lt ? (sb[k] - 4 * cb[k]) : b_;
+                        e_ = lt ? se[k] : e_;
+                    }
+                    pp[w] = (t < nblk) ? b_ + 4 * t : 0;
+                    pe[w] = (t < nblk) ? e_ : 0; // empty block when past the end
+                }
+                Pt3 q[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) q[u] = lp[max(min(pp[u >> 2] + (u & 3), pe[u >> 2] - 1), 0)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int id = pp[u >> 2] + (u & 3);
+                    const float ex = (q[u].x - ghx) - glx, ey = (q[u].y - ghy) - gly, ez = (q[u].z - ghz) - glz;
+                    const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+                    const float d = (id < pe[u >> 2]) ? dd : __builtin_inff();
+                    m2 = fminf(m2, fmaxf(d, m1));
+                    const bool c = d < m1;
+                    m1 = c ? d : m1;
+                    j1 = c ? id : j1;
+                }
+                n_tested += max(min(4, pe[0] - pp[0]), 0) + max(min(4, pe[1] - pp[1]), 0);
+            }
+            // float32 distances are within 2^-20 relative (+ slack / 2) of the reference's float64 ones (see K1c)
+            hard = true;
+            if (j1 >= 0) {
+                const float slack = 4e-11f * (fabsf(ghx) + fabsf(ghy) + fabsf(ghz) + 1.0f);
+                const float r2 = m1 + m1 * 1.9073486328125e-06f + slack; // 2^-19
                 const double r = sqrt((double)r2) * 1.000001 + 1e-6;
-                ix0 = cell_of(gx - r, ox, inv_h); ix1 = cell_of(gx + r, ox, inv_h);
-                iy0 = cell_of(gy - r, oy, inv_h); iy1 = cell_of(gy + r, oy, inv_h);
-                iz0 = cell_of(gz - r, oz, inv_h); iz1 = cell_of(gz + r, oz, inv_h);
-            } else {
-                ix0 = max(cx - 1, 0); ix1 = min(cx + 1, kCellAxis - 1);
-                iy0 = max(cy - 1, 0); iy1 = min(cy + 1, kCellAxis - 1);
-                iz0 = max(cz - 1, 0); iz1 = min(cz + 1, kCellAxis - 1);
-            }
-            const int nx = ix1 - ix0 + 1, ny = iy1 - iy0 + 1;
-            if (nx <= 3 && ny <= 3) {
-                // fast path (practically always): <= 9 columns.  All column offsets are fetched at once, the ranges (own
-                // column split around the own cell -> 10 segments) are concatenated into one virtual range and streamed
-                // 8 candidates per step, so a lane needs 1 + ceil(total / 8) round trips however its box is shaped.
-                int dk[10], ck[11];
-                int e_own = 0;
-                const int ko = (cx - ix0) * 3 + (cy - iy0);
-                ck[0] = 0;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    const int kx = k / 3, ky = k % 3;
-                    int bb = 0, ee = 0;
-                    if (kx < nx && ky < ny) {
-                        const int base = ((ix0 + kx) * kCellAxis + (iy0 + ky)) * kCellAxis;
-                        bb = co[base + iz0];
-                        ee = co[base + iz1 + 1];
-                    }
-                    if (k == ko) { e_own = ee; ee = ob; }
-                    dk[k] = bb - ck[k];
-                    ck[k + 1] = ck[k] + (ee - bb);
-                }
-                dk[9] = oe - ck[9];
-                ck[10] = ck[9] + (e_own - oe);
-                const int total = ck[10];
-                for (int v0 = 0; v0 < total; v0 += 8) {
-                    Pt3 q[8];
-                    int id[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int v = min(v0 + u, total - 1);
-                        int d = dk[9];
-#pragma unroll
-                        for (int k = 8; k >= 0; --k) d = (v < ck[k + 1]) ? dk[k] : d;
-                        id[u] = v + d;
-                        q[u] = lp[id[u]];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const float ex = (q[u].x - ghx) - glx, ey = (q[u].y - ghy) - gly, ez = (q[u].z - ghz) - glz;
-                        const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-                        const float d = (v0 + u < total) ? dd : __builtin_inff();
-                        m2 = fminf(m2, fmaxf(d, m1));
-                        const bool c = d < m1;
-                        m1 = c ? d : m1;
-                        j1 = c ? id[u] : j1;
-                    }
-                    n_tested += min(8, total - v0);
-                }
-            } else {
-                int ix = ix0, iy = iy0; // next column of the box
-                bool more = true;
-                int ptr = 0, end = 0, ptr2 = 0, end2 = 0;
-                for (;;) {
-                    while (ptr >= end) {
-                        if (ptr2 < end2) { ptr = ptr2; end = end2; ptr2 = end2 = 0; continue; } // part of the own column above the own cell
-                        if (!more) break;
-                        const int base = (ix * kCellAxis + iy) * kCellAxis;
-                        const int b = co[base + iz0], e = co[base + iz1 + 1];
-                        const bool own_col = (ix == cx) && (iy == cy);
-                        if (++iy > iy1) { iy = iy0; if (++ix > ix1) more = false; }
-                        if (own_col) { ptr = b; end = ob; ptr2 = oe; end2 = e; }
-                        else { ptr = b; end = e; }
-                    }
-                    if (ptr >= end) break;
-                    ELM_CELL_STEP(ptr, end)
-                    ptr += 8;
-                }
-            }
-#undef ELM_CELL_STEP
-            ELM_PHASE(11)
-            bool need_exact = false;
-            if (own_empty) {
-                if (j1 < 0) {
-                    need_exact = true; // nothing within one cell: isolated point, let the exact walk scan the whole list
-                } else {
-                    // the visited box must contain the ball of the best distance, otherwise unvisited cells could hold the winner
-                    const float r2 = m1 + m1 * 1.9073486328125e-06f + slack;
-                    const double r = sqrt((double)r2) * 1.000001 + 1e-6;
-                    need_exact = cell_of(gx - r, ox, inv_h) < ix0 || cell_of(gx + r, ox, inv_h) > ix1 || cell_of(gy - r, oy, inv_h) < iy0 ||
-                                 cell_of(gy + r, oy, inv_h) > iy1 || cell_of(gz - r, oz, inv_h) < iz0 || cell_of(gz + r, oz, inv_h) > iz1;
-                }
-            }
-            {
-                const bool clear_winner = !need_exact && j1 >= 0 && m2 > m1 + m1 * 1.9073486328125e-06f + slack; // 2^-19
-                if (clear_winner) {
+                if (m2 > r2 && r < rho) {
                     const Pt3 q = lp[j1];
                     const double ex = (double)q.x - gx, ey = (double)q.y - gy, ez = (double)q.z - gz;
                     bd2 = (ex * ex + ey * ey) + ez * ez; // the reference's float64 value for the range test
                     bj = j1;
-                } else {
-                    // exact float64 walk over the whole list; equal distances go to the candidate the reference meets first
-                    unsigned brank = 0xFFFFFFFFu, bgi = 0xFFFFFFFFu;
-                    for (int k = 0; k < (int)cnt; ++k) {
-                        const Pt3 q = lp[k];
-                        const double ex = (double)q.x - gx, ey = (double)q.y - gy, ez = (double)q.z - gz;
-                        const double d2 = (ex * ex + ey * ey) + ez * ez;
-                        if (d2 > bd2) continue;
-                        const int kx = (int)((double)q.x / m.voxel_size), ky = (int)((double)q.y / m.voxel_size), kz = (int)((double)q.z / m.voxel_size);
-                        const unsigned rank = (unsigned)(((kx - vx + 1) * 3 + (ky - vy + 1)) * 3 + (kz - vz + 1));
-                        const unsigned gi = m.nbr_idx[(size_t)start + k];
-                        if (d2 < bd2 || rank < brank || (rank == brank && gi < bgi)) { bd2 = d2; bj = k; brank = rank; bgi = gi; }
-                    }
-                    n_exact = 1.0;
+                    hard = false;
                 }
             }
         }
-        ELM_PHASE(12)
+        ELM_PHASE(10)
+    }
+    // stage 2: the wave serves its undecided lanes one by one
+    double n_exact = 0.0;
+    {
+#ifdef ELM_SKIP_HARD
+        unsigned long long todo = 0;
+#else
+        unsigned long long todo = __ballot(hard);
+#endif
+        const int lane = (int)(threadIdx.x & 63);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const double hgx = __shfl(gx, src, 64), hgy = __shfl(gy, src, 64), hgz = __shfl(gz, src, 64);
+            const int hvx = __shfl(vx, src, 64), hvy = __shfl(vy, src, 64), hvz = __shfl(vz, src, 64);
+            const unsigned hstart = (unsigned)__shfl((int)start, src, 64), hcnt = (unsigned)__shfl((int)cnt, src, 64);
+            const Pt3* __restrict__ hp = m.nbr_pts + hstart;
+            // pass 1: the float64 minimum (the reference's arithmetic).  Equal distances are almost never seen; when one
+            // is, pass 2 below settles it by the reference's visiting order.
+            double d_best = DBL_MAX;
+            unsigned k_best = 0xFFFFFFFFu;
+            bool tie = false;
+            for (unsigned base = 0; base < hcnt; base += 256) { // four independent coalesced loads per lane and round trip
+                Pt3 q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q[u] = hp[min(base + (unsigned)lane + 64u * u, hcnt - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned k = base + (unsigned)lane + 64u * u;
+                    const double ex = (double)q[u].x - hgx, ey = (double)q[u].y - hgy, ez = (double)q[u].z - hgz;
+                    const double dd = (ex * ex + ey * ey) + ez * ez;
+                    const double d2 = (k < hcnt) ? dd : DBL_MAX;
+                    tie = (d2 == d_best && k < hcnt) ? true : ((d2 < d_best) ? false : tie);
+                    k_best = (d2 < d_best) ? k : k_best;
+                    d_best = fmin(d2, d_best);
+                }
+            }
+            double d_min = d_best;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) d_min = fmin(d_min, __shfl_xor(d_min, off, 64));
+            const unsigned long long at_min = __ballot(d_best == d_min);
+            const bool contested = (__popcll(at_min) != 1) || (__ballot(tie && d_best == d_min) != 0ull);
+            if (!contested) {
+                k_best = (unsigned)__shfl((int)k_best, __ffsll((long long)at_min) - 1, 64);
+            } else {
+                unsigned r_best = 0xFFFFFFFFu, g_best = 0xFFFFFFFFu;
+                k_best = 0xFFFFFFFFu;
+                for (unsigned k = (unsigned)lane; k < hcnt; k += 64) {
+                    const Pt3 q = hp[k];
+                    const double ex = (double)q.x - hgx, ey = (double)q.y - hgy, ez = (double)q.z - hgz;
+                    const double d2 = (ex * ex + ey * ey) + ez * ez;
+                    if (d2 != d_min) continue;
+                    const unsigned gi = m.nbr_idx[(size_t)hstart + k];
+                    const int kx = (int)((double)q.x / m.voxel_size), ky = (int)((double)q.y / m.voxel_size), kz = (int)((double)q.z / m.voxel_size);
+                    const unsigned rank = (unsigned)(((kx - hvx + 1) * 3 + (ky - hvy + 1)) * 3 + (kz - hvz + 1));
+                    if (rank < r_best || (rank == r_best && gi < g_best)) { r_best = rank; g_best = gi; k_best = k; }
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const unsigned orank = (unsigned)__shfl_xor((int)r_best, off, 64), og = (unsigned)__shfl_xor((int)g_best, off, 64),
+                                   ok = (unsigned)__shfl_xor((int)k_best, off, 64);
+                    if (orank < r_best || (orank == r_best && og < g_best)) { r_best = orank; g_best = og; k_best = ok; }
+                }
+            }
+            d_best = d_min;
+            if (lane == src) { bd2 = d_best; bj = (int)k_best; n_exact = 1.0; n_tested += (int)hcnt; }
+        }
+    }
+    ELM_PHASE(12)
+    if (valid) {
         float bx = 0.f, by = 0.f, bz = 0.f;
         int bidx = -1;
         if (bj >= 0) {
@@ -1166,13 +1192,21 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_cell(const DevMap m, cons
             bx = q.x; by = q.y; bz = q.z;
             bidx = (METHOD == ELM_GICP) ? (int)m.nbr_idx[(size_t)start + bj] : 0;
         }
+#ifndef ELM_SKIP_PAIR
         finish_point_pair<METHOD>(acc, m, S, rp, px, py, pz, gx, gy, gz, bd2, bx, by, bz, bidx);
+#else
+        acc[0] = bd2 + bx + by + bz + bidx;
+#endif
         acc[29] = (double)cnt;  // candidates of the reference's walk
         acc[30] = (double)nocc;
         acc[31] = (double)n_tested + n_exact * kFallbackUnit;
         ELM_PHASE(13)
     }
+#ifdef ELM_SKIP_REDUCE
+    if (acc[0] + acc[29] + acc[31] == -1.0) partials[(size_t)L * kSums + threadIdx.x] = acc[1] + s_buf[threadIdx.x];
+#else
     block_reduce_store_lds(acc, s_buf, partials + (size_t)L * kSums);
+#endif
     ELM_PHASE(14)
 }
 
@@ -1223,15 +1257,21 @@ __global__ __launch_bounds__(64) void k_nbr_cellsort(const DevMap m, const int32
             }
             __syncthreads();
         }
+    __shared__ uint16_t s_bnd[kCells + 1]; // s_bnd[c] = first sorted position whose cell is >= c
     for (unsigned j = l; j < n; j += 64) {
         const unsigned src = s_key[j] & 0xFFFFu;
         pts[(size_t)o + j] = s_pt[src];
         idx[(size_t)o + j] = s_idx[src];
         const int c = (int)(s_key[j] >> 16);
         const int cprev = j ? (int)(s_key[j - 1] >> 16) : -1;
-        for (int cc = cprev + 1; cc <= c; ++cc) co[cc] = (uint16_t)j;
+        for (int cc = cprev + 1; cc <= c; ++cc) s_bnd[cc] = (uint16_t)j;
         if (j == n - 1)
-            for (int cc = c + 1; cc <= kCells; ++cc) co[cc] = (uint16_t)n;
+            for (int cc = c + 1; cc <= kCells; ++cc) s_bnd[cc] = (uint16_t)n;
+    }
+    __syncthreads();
+    for (unsigned e = l; e < (unsigned)kCellStride; e += 64) {
+        const unsigned col = e >> 3, z = e & 7;
+        co[e] = (z <= (unsigned)kCellAxis) ? s_bnd[col * kCellAxis + z] : (uint16_t)0;
     }
 }
 
