@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="registrations in flight per GPU per step")
+    ap.add_argument("--batch", type=int, default=32, help="registrations in flight per GPU per step")
     ap.add_argument("--scan-points", type=int, default=131072)
     ap.add_argument("--map-points", type=int, default=10_000_000)
     ap.add_argument("--method", type=int, default=0, help="0 P2P (configs[1]), 1 GICP, 2 VGICP, 3 AVGICP")

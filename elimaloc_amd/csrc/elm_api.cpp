@@ -477,6 +477,10 @@ extern "C" int elm_map_build(elm_ctx* ctx, const float* xyz, size_t n, double vo
     m->dm.n_pts = n_pts;
     m->dm.pts = m->d_pts;
     m->dm.voxel_size = voxel_size;
+    {
+        int e2 = 0;
+        m->dm.inv_vs_exact = (frexp(voxel_size, &e2) == 0.5) ? 1.0 / voxel_size : 0.0;
+    }
     m->info.n_input_points = n;
     m->info.n_points = n_pts;
     m->info.n_voxels = n_vox;

@@ -35,6 +35,7 @@ struct DevMap {
     const double* pt_cov;   // [n_pts][9] row-major
     const double* pt_nfit;  // [n_pts][3] eigenvector of the smallest eigenvalue of pt_cov (reg.cpp:89-91)
     double voxel_size;
+    double inv_vs_exact; // 1 / voxel_size when voxel_size is a power of two (g * inv == g / voxel_size bit for bit), else 0
     // neighbourhood lists (optional): for every FLOOR-keyed query voxel that has at least one stored neighbour, the
     // points of its 27 trunc-keyed neighbour buckets concatenated in the reference's visiting order (x-major ..
     // z-minor, insertion order inside a bucket).  27x duplication of the map points, laid out for streaming.

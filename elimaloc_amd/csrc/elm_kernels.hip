@@ -73,6 +73,10 @@ __device__ __forceinline__ Probe probe_voxel(const DevMap& m, int kx, int ky, in
 }
 
 __device__ __forceinline__ int floor_key(double g, double vs) { return (int)floor(g / vs); } // vhm.hpp:176-180
+// same value without the float64 division when the voxel size is a power of two (uniform branch)
+__device__ __forceinline__ int floor_key(double g, const DevMap& m) {
+    return (m.inv_vs_exact != 0.0) ? (int)floor(g * m.inv_vs_exact) : (int)floor(g / m.voxel_size);
+}
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -991,11 +995,7 @@ template <int METHOD>
 __global__ __launch_bounds__(kBlock) void k_accumulate_cell(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
                                                             unsigned total_blocks, const ScanState* __restrict__ st,
                                                             double* __restrict__ partials, const RegParams rp) {
-#ifdef ELM_OCC_TEST
-    __shared__ double s_buf[16 * kBlock * ELM_OCC_TEST];
-#else
     __shared__ double s_buf[16 * kBlock];
-#endif
     ELM_PHASE_BEGIN
     const unsigned L = xcd_remap(blockIdx.x, total_blocks);
     const int s = find_scan(scans, batch, L);
@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_cell(const DevMap m, cons
         gx = ((S.T[0] * px + S.T[4] * py) + S.T[8] * pz) + S.T[12];
         gy = ((S.T[1] * px + S.T[5] * py) + S.T[9] * pz) + S.T[13];
         gz = ((S.T[2] * px + S.T[6] * py) + S.T[10] * pz) + S.T[14];
-        vx = floor_key(gx, m.voxel_size); vy = floor_key(gy, m.voxel_size); vz = floor_key(gz, m.voxel_size);
+        vx = floor_key(gx, m); vy = floor_key(gy, m); vz = floor_key(gz, m);
         int qid = -1;
         ELM_PHASE(8)
         {
@@ -1064,6 +1064,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_cell(const DevMap m, cons
 #pragma unroll
             for (int k = 0; k < 4; ++k) cb[k + 1] = cb[k] + ((se[k] - sb[k] + 3) >> 2); // blocks of 4 candidates
             const int nblk = cb[4];
+            n_tested = ((se[0] - sb[0]) + (se[1] - sb[1])) + ((se[2] - sb[2]) + (se[3] - sb[3]));
             const float ghx = (float)gx, ghy = (float)gy, ghz = (float)gz;
             const float glx = (float)(gx - (double)ghx), gly = (float)(gy - (double)ghy), glz = (float)(gz - (double)ghz);
             float m1 = __builtin_inff(), m2 = __builtin_inff();
@@ -1097,15 +1098,15 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_cell(const DevMap m, cons
                     m1 = c ? d : m1;
                     j1 = c ? id : j1;
                 }
-                n_tested += max(min(4, pe[0] - pp[0]), 0) + max(min(4, pe[1] - pp[1]), 0);
             }
             // float32 distances are within 2^-20 relative (+ slack / 2) of the reference's float64 ones (see K1c)
             hard = true;
             if (j1 >= 0) {
                 const float slack = 4e-11f * (fabsf(ghx) + fabsf(ghy) + fabsf(ghz) + 1.0f);
                 const float r2 = m1 + m1 * 1.9073486328125e-06f + slack; // 2^-19
-                const double r = sqrt((double)r2) * 1.000001 + 1e-6;
-                if (m2 > r2 && r < rho) {
+                // sqrt(r2) * 1.000001 + 1e-6 < rho, without the square root
+                const double rr = (rho - 1e-6) * 0.999999;
+                if (m2 > r2 && rr > 0.0 && (double)r2 < rr * rr) {
                     const Pt3 q = lp[j1];
                     const double ex = (double)q.x - gx, ey = (double)q.y - gy, ez = (double)q.z - gz;
                     bd2 = (ex * ex + ey * ey) + ez * ez; // the reference's float64 value for the range test
