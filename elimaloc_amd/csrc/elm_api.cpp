@@ -258,6 +258,9 @@ struct elm_map {
     Pt3* d_nbr_pts = nullptr;
     uint32_t* d_nbr_idx = nullptr;
     uint16_t* d_nbr_cell_off = nullptr;
+    HashSlot* d_vqslots = nullptr;
+    VoxRec* d_vnbr = nullptr;
+    bool has_vnbr = false; // voxel-mean lists (VGICP)
     bool has_cells = false; // lists sorted by half-voxel cell + offset tables (every list <= 1024 entries)
     bool has_nbr = false;
     std::vector<int32_t> h_keys;
@@ -411,7 +414,7 @@ static void build_host(const float* xyz, size_t n, double voxel_size, int max_po
 static void map_free(elm_map* m) {
     if (!m) return;
     (void)hipSetDevice(m->ctx->device);
-    void* ptrs[] = {m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_pt_mean, m->d_pt_cov, m->d_pt_nfit, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off};
+    void* ptrs[] = {m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_pt_mean, m->d_pt_cov, m->d_pt_nfit, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off, m->d_vqslots, m->d_vnbr};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete m;
@@ -538,34 +541,110 @@ extern "C" int elm_map_cal_point_cov_all(elm_map* m, double d_search_dist) {
     return ELM_OK;
 }
 
+// query voxels = every floor key within +-1 of a stored (trunc) key that holds points, first-seen order
+static void enumerate_query_keys(const elm_map* m, std::vector<int32_t>& qkeys) {
+    const uint32_t n_vox = m->dm.n_vox;
+    HostTable tab;
+    tab.init(next_pow2(std::max<uint64_t>(1024, (uint64_t)n_vox * 8)));
+    int32_t nq = 0;
+    for (uint32_t v = 0; v < n_vox; ++v) {
+        if (m->h_ranges[v].y == 0) continue;
+        const int32_t kx = m->h_keys[3 * v], ky = m->h_keys[3 * v + 1], kz = m->h_keys[3 * v + 2];
+        for (int dx = -1; dx <= 1; ++dx)
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dz = -1; dz <= 1; ++dz) {
+                    if (tab.used * 2 >= tab.mask) tab.grow();
+                    bool added;
+                    tab.find_or_add(kx + dx, ky + dy, kz + dz, nq, &added);
+                    if (added) {
+                        qkeys.push_back(kx + dx); qkeys.push_back(ky + dy); qkeys.push_back(kz + dz);
+                        ++nq;
+                    }
+                }
+    }
+}
+
+// Voxel-mean lists for VGICP (see DevMap::vnbr): built lazily at the first VGICP registration, after CalVoxelCovAll.
+static int build_voxel_neighbourhoods(elm_map* m) {
+    if (m->has_vnbr) return ELM_OK;
+    elm_ctx* ctx = m->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<int32_t> qkeys;
+    enumerate_query_keys(m, qkeys);
+    const uint32_t n_q = (uint32_t)(qkeys.size() / 3);
+    int32_t* d_qkeys = nullptr;
+    uint32_t *d_counts = nullptr, *d_nocc = nullptr, *d_off = nullptr;
+    auto cleanup = [&]() {
+        if (d_qkeys) (void)hipFree(d_qkeys);
+        if (d_counts) (void)hipFree(d_counts);
+        if (d_nocc) (void)hipFree(d_nocc);
+        if (d_off) (void)hipFree(d_off);
+    };
+#define VN_CHK(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            ctx->last_error = std::string(#call) + ": " + hipGetErrorString(e_);              \
+            cleanup();                                                                        \
+            return ELM_ERR_DEVICE;                                                            \
+        }                                                                                     \
+    } while (0)
+    const size_t nq_alloc = std::max<size_t>(n_q, 1);
+    VN_CHK(hipMalloc((void**)&d_qkeys, nq_alloc * 3 * sizeof(int32_t)));
+    VN_CHK(hipMalloc((void**)&d_counts, nq_alloc * sizeof(uint32_t)));
+    VN_CHK(hipMalloc((void**)&d_nocc, nq_alloc * sizeof(uint32_t)));
+    VN_CHK(hipMalloc((void**)&d_off, nq_alloc * sizeof(uint32_t)));
+    std::vector<uint32_t> nocc(n_q), offs(n_q);
+    uint64_t total = 0;
+    if (n_q) {
+        VN_CHK(hipMemcpy(d_qkeys, qkeys.data(), (size_t)n_q * 3 * sizeof(int32_t), hipMemcpyHostToDevice));
+        (void)hipGetLastError();
+        launch_nbr_count(ctx->stream, m->dm, d_qkeys, n_q, d_counts, d_nocc);
+        VN_CHK(hipGetLastError());
+        VN_CHK(hipStreamSynchronize(ctx->stream));
+        VN_CHK(hipMemcpy(nocc.data(), d_nocc, (size_t)n_q * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (uint32_t q = 0; q < n_q; ++q) { offs[q] = (uint32_t)total; total += nocc[q]; }
+        VN_CHK(hipMemcpy(d_off, offs.data(), (size_t)n_q * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    VN_CHK(hipMalloc((void**)&m->d_vnbr, std::max<size_t>((size_t)total * sizeof(VoxRec), 256)));
+    if (n_q) {
+        (void)hipGetLastError();
+        launch_vnbr_fill(ctx->stream, m->dm, d_qkeys, n_q, d_off, m->d_vnbr);
+        VN_CHK(hipGetLastError());
+        VN_CHK(hipStreamSynchronize(ctx->stream));
+    }
+    const uint32_t qcap = next_pow2((uint64_t)n_q * 2);
+    {
+        std::vector<HashSlot> qs(qcap);
+        for (auto& e : qs) { e.kx = e.ky = e.kz = 0; e.vid = -1; e.start = e.cnt = e.pad0 = e.pad1 = 0; }
+        for (uint32_t q = 0; q < n_q; ++q) {
+            uint32_t h = hash3(qkeys[3 * q], qkeys[3 * q + 1], qkeys[3 * q + 2]) & (qcap - 1);
+            while (qs[h].vid >= 0) h = (h + 1) & (qcap - 1);
+            qs[h].kx = qkeys[3 * q]; qs[h].ky = qkeys[3 * q + 1]; qs[h].kz = qkeys[3 * q + 2];
+            qs[h].vid = (int32_t)q;
+            qs[h].start = offs[q]; qs[h].cnt = nocc[q];
+        }
+        VN_CHK(hipMalloc((void**)&m->d_vqslots, (size_t)qcap * sizeof(HashSlot)));
+        VN_CHK(hipMemcpy(m->d_vqslots, qs.data(), (size_t)qcap * sizeof(HashSlot), hipMemcpyHostToDevice));
+    }
+#undef VN_CHK
+    cleanup();
+    m->dm.vqslots = m->d_vqslots;
+    m->dm.vqmask = qcap - 1;
+    m->dm.vnbr = m->d_vnbr;
+    m->has_vnbr = true;
+    m->info.device_bytes += (size_t)total * sizeof(VoxRec) + (size_t)qcap * sizeof(HashSlot);
+    return ELM_OK;
+}
+
 // Neighbourhood lists (see DevMap): query voxels = every floor key within +-1 of a stored (trunc) key.
 extern "C" int elm_map_build_neighbourhoods(elm_map* m) {
     if (!m) return ELM_ERR_INVALID;
     if (m->has_nbr) return ELM_OK;
     elm_ctx* ctx = m->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    const uint32_t n_vox = m->dm.n_vox;
     std::vector<int32_t> qkeys;
-    {
-        HostTable tab;
-        tab.init(next_pow2(std::max<uint64_t>(1024, (uint64_t)n_vox * 8)));
-        int32_t nq = 0;
-        for (uint32_t v = 0; v < n_vox; ++v) {
-            if (m->h_ranges[v].y == 0) continue;
-            const int32_t kx = m->h_keys[3 * v], ky = m->h_keys[3 * v + 1], kz = m->h_keys[3 * v + 2];
-            for (int dx = -1; dx <= 1; ++dx)
-                for (int dy = -1; dy <= 1; ++dy)
-                    for (int dz = -1; dz <= 1; ++dz) {
-                        if (tab.used * 2 >= tab.mask) tab.grow();
-                        bool added;
-                        tab.find_or_add(kx + dx, ky + dy, kz + dz, nq, &added);
-                        if (added) {
-                            qkeys.push_back(kx + dx); qkeys.push_back(ky + dy); qkeys.push_back(kz + dz);
-                            ++nq;
-                        }
-                    }
-        }
-    }
+    enumerate_query_keys(m, qkeys);
     const uint32_t n_q = (uint32_t)(qkeys.size() / 3);
     int32_t* d_qkeys = nullptr;
     uint32_t *d_counts = nullptr, *d_nocc = nullptr, *d_off = nullptr;
@@ -944,6 +1023,10 @@ extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_
     if (use_nbr && !map->has_nbr) {
         if ((rc = elm_map_build_neighbourhoods(const_cast<elm_map*>(map))) != ELM_OK) return rc;
     }
+    const bool use_vnbr = !map_empty && (ctx->kernel_mode == 0 || ctx->kernel_mode == 4) && method == ELM_VGICP;
+    if (use_vnbr && !map->has_vnbr) {
+        if ((rc = build_voxel_neighbourhoods(const_cast<elm_map*>(map))) != ELM_OK) return rc;
+    }
     ScanState* st = (ScanState*)ctx->d_state.p;
     const ScanDesc* dsc = (const ScanDesc*)ctx->d_scans.p;
     if ((rc = dev_reserve(ctx, ctx->d_active, 256)) != ELM_OK) return rc;
@@ -960,6 +1043,7 @@ extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_
             if (blocks) {
                 if (use_nbr && ctx->kernel_mode == 4 && map->has_cells)
                     launch_accumulate_cell(ctx->stream, map->dm, dsc, batch, (int)blocks, st, (double*)ctx->d_partials.p, rp);
+                else if (use_vnbr) launch_accumulate_vnbr(ctx->stream, map->dm, dsc, batch, (int)blocks, st, (double*)ctx->d_partials.p, rp);
                 else if (use_nbr) launch_accumulate_nbr(ctx->stream, map->dm, dsc, batch, (int)blocks, st, (double*)ctx->d_partials.p, rp);
                 else launch_accumulate(ctx->stream, map->dm, dsc, batch, (int)blocks, st, (double*)ctx->d_partials.p, rp,
                                        (ctx->kernel_mode == 2 || map->info.max_points_per_voxel > 255) ? 1 : 0);

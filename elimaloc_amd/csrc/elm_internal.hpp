@@ -22,6 +22,12 @@ struct Pt3 { // 12-byte candidate of the neighbourhood lists
     float x, y, z;
 };
 
+struct VoxRec { // one occupied neighbour voxel of a query voxel (VGICP lists): its mean (float64, vhm.hpp:114-148) and id
+    double mx, my, mz;
+    int32_t vid;
+    int32_t pad;
+};
+
 struct DevMap {
     const HashSlot* slots;
     uint32_t mask; // capacity - 1 (capacity is a power of two >= 4 * n_voxels)
@@ -44,6 +50,12 @@ struct DevMap {
     uint32_t n_q;
     const Pt3* nbr_pts;       // candidate coordinates, 12 bytes each
     const uint32_t* nbr_idx;  // global point index of every candidate (read only for a GICP winner)
+    // voxel-mean lists (VGICP, optional): the occupied voxels among the 27 neighbours of every query voxel in the
+    // reference's visiting order (vhm.cpp:208-243), 32-byte records; vqslots: query key -> (start, cnt)
+    const HashSlot* vqslots;
+    uint32_t vqmask;
+    uint32_t _pad2;
+    const VoxRec* vnbr;
     const uint16_t* nbr_cell_off; // [n_q][224]: every list is sorted by half-voxel cell (6x6x6 grid, clamped); cell c =
                                   // entries [off[c], off[c+1]) of the list
 };
@@ -107,6 +119,9 @@ void launch_solve(hipStream_t s, const ScanDesc* scans, int batch, ScanState* st
 void launch_accumulate_nbr(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                            ScanState* st, double* partials, const RegParams& rp);
 void launch_nbr_count(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, uint32_t* counts, uint32_t* nocc);
+void launch_accumulate_vnbr(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
+                            ScanState* st, double* partials, const RegParams& rp);
+void launch_vnbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets, VoxRec* out);
 void launch_accumulate_cell(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                             ScanState* st, double* partials, const RegParams& rp);
 void launch_nbr_cellsort(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets,

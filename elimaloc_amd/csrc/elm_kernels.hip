@@ -1276,6 +1276,88 @@ __global__ __launch_bounds__(64) void k_nbr_cellsort(const DevMap m, const int32
     }
 }
 
+// ---- K1e: voxel-mean lists (VGICP) ------------------------------------------------------------------------
+// GetCorrespondencesCov (vhm.cpp:90-151) visits the 27 neighbour voxels of the point's floor-keyed voxel and keeps the
+// nearest voxel MEAN (strict <, first met wins).  Here the occupied ones (~10 of 27) are precomputed per query voxel in
+// that visiting order as 32-byte (mean, id) records: one probe, then <= 27 contiguous records, float64 distances in the
+// reference's order -- no staging, no barriers before the block reduction.
+__global__ __launch_bounds__(kBlock) void k_accumulate_vnbr(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
+                                                            unsigned total_blocks, const ScanState* __restrict__ st,
+                                                            double* __restrict__ partials, const RegParams rp) {
+    __shared__ double s_buf[16 * kBlock];
+    const unsigned L = xcd_remap(blockIdx.x, total_blocks);
+    const int s = find_scan(scans, batch, L);
+    const ScanState& S = st[s];
+    if (S.done) return;
+    const ScanDesc sd = scans[s];
+    const unsigned i = (L - sd.blk_begin) * kBlock + threadIdx.x;
+    const bool valid = i < sd.n;
+    double acc[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc[k] = 0.0;
+    if (valid) {
+        const float4 pf = sd.pts[i];
+        const double px = pf.x, py = pf.y, pz = pf.z;
+        const double gx = ((S.T[0] * px + S.T[4] * py) + S.T[8] * pz) + S.T[12];
+        const double gy = ((S.T[1] * px + S.T[5] * py) + S.T[9] * pz) + S.T[13];
+        const double gz = ((S.T[2] * px + S.T[6] * py) + S.T[10] * pz) + S.T[14];
+        const int vx = floor_key(gx, m), vy = floor_key(gy, m), vz = floor_key(gz, m);
+        unsigned start = 0, cnt = 0;
+        {
+            unsigned h = hash3(vx, vy, vz) & m.vqmask;
+            for (;;) {
+                const unsigned h2 = (h + 1) & m.vqmask;
+                const int4 key = *reinterpret_cast<const int4*>(&m.vqslots[h]);
+                const uint4 rg = *reinterpret_cast<const uint4*>(&m.vqslots[h].start);
+                const int4 key2 = *reinterpret_cast<const int4*>(&m.vqslots[h2]);
+                const uint4 rg2 = *reinterpret_cast<const uint4*>(&m.vqslots[h2].start);
+                if (key.w < 0) break;
+                if (key.x == vx && key.y == vy && key.z == vz) { start = rg.x; cnt = rg.y; break; }
+                if (key2.w < 0) break;
+                if (key2.x == vx && key2.y == vy && key2.z == vz) { start = rg2.x; cnt = rg2.y; break; }
+                h = (h + 2) & m.vqmask;
+            }
+        }
+        const VoxRec* __restrict__ lp = m.vnbr + start;
+        double bd2 = DBL_MAX, bmx = 0.0, bmy = 0.0, bmz = 0.0;
+        int bvid = -1;
+        for (unsigned j = 0; j < cnt; j += 4) { // four records (eight 16-byte loads) per round trip
+            VoxRec r[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) r[u] = lp[min(j + u, cnt - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double ex = r[u].mx - gx, ey = r[u].my - gy, ez = r[u].mz - gz;
+                const double d2 = (ex * ex + ey * ey) + ez * ez;
+                if (j + u < cnt && d2 < bd2) { bd2 = d2; bvid = r[u].vid; bmx = r[u].mx; bmy = r[u].my; bmz = r[u].mz; }
+            }
+        }
+        finish_voxel_pair(acc, m, S, rp, px, py, pz, gx, gy, gz, bd2, bvid, bmx, bmy, bmz);
+        acc[29] = (double)cnt;
+        acc[30] = (double)cnt;
+        acc[31] = (double)cnt;
+    }
+    block_reduce_store_lds(acc, s_buf, partials + (size_t)L * kSums);
+}
+
+__global__ __launch_bounds__(256) void k_vnbr_fill(const DevMap m, const int32_t* __restrict__ qkeys, unsigned n_q,
+                                                   const unsigned* __restrict__ offsets, VoxRec* __restrict__ out) {
+    const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_q) return;
+    const int vx = qkeys[3 * q], vy = qkeys[3 * q + 1], vz = qkeys[3 * q + 2];
+    unsigned o = offsets[q];
+    for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dz = -1; dz <= 1; ++dz) {
+                const Probe pr = probe_voxel(m, vx + dx, vy + dy, vz + dz);
+                if (pr.vid < 0 || pr.cnt == 0) continue;
+                VoxRec r;
+                r.mx = m.vox_mean[(size_t)pr.vid * 3]; r.my = m.vox_mean[(size_t)pr.vid * 3 + 1]; r.mz = m.vox_mean[(size_t)pr.vid * 3 + 2];
+                r.vid = pr.vid; r.pad = 0;
+                out[o++] = r;
+            }
+}
+
 // map build: size and content of the neighbourhood list of every query voxel (init time)
 __global__ __launch_bounds__(256) void k_nbr_count(const DevMap m, const int32_t* __restrict__ qkeys, unsigned n_q,
                                                    unsigned* __restrict__ counts, unsigned* __restrict__ nocc) {
@@ -1769,6 +1851,13 @@ void launch_accumulate_cell(hipStream_t s, const DevMap& m, const ScanDesc* scan
         hipLaunchKernelGGL((k_accumulate_cell<ELM_P2P>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
     else
         hipLaunchKernelGGL((k_accumulate_cell<ELM_GICP>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
+}
+void launch_accumulate_vnbr(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
+                            ScanState* st, double* partials, const RegParams& rp) {
+    hipLaunchKernelGGL(k_accumulate_vnbr, dim3(total_blocks), dim3(kBlock), 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
+}
+void launch_vnbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets, VoxRec* out) {
+    hipLaunchKernelGGL(k_vnbr_fill, dim3((n_q + 255) / 256), dim3(256), 0, s, m, qkeys, n_q, offsets, out);
 }
 void launch_nbr_cellsort(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets,
                          const uint32_t* counts, Pt3* pts, uint32_t* idx, uint16_t* cell_off) {
