@@ -337,3 +337,35 @@ def test_ouster_records_sampling_and_trailing_default_point(n, sampling):
     np.testing.assert_array_equal(t[:k], sel["t"].astype(np.float32) * np.float32(1e-9))
     if k < total:                                  # the untouched slot is a default point at the sensor origin
         assert (xyz[k:] == 0).all() and (inten[k:] == 0).all() and (t[k:] == 0).all()
+
+
+@pytest.mark.gpu
+def test_node_from_reference_style_files(tmp_path, oracle):
+    """Init() the way the node does it (pcm.cpp:22-101): localization.ini + calibration.ini + a binary_compressed PCD map
+    -> ProcessINI -> loadPCDFile -> map build -> one registration, against the oracle fed the same file contents."""
+    from elimaloc_amd import synth
+    from elimaloc_amd.pcm_matching import PcmMatching
+    world = synth.make_world(60000, seed=1001)
+    rec = np.zeros(world.shape[0], dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("intensity", "<f4")])
+    rec["x"], rec["y"], rec["z"] = world.T
+    soa = b"".join(np.ascontiguousarray(rec[n]).tobytes() for n in rec.dtype.names)
+    comp = lzf_compress(soa)
+    pcd = tmp_path / "map.pcd"
+    pcd.write_bytes((f"VERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\nWIDTH {len(rec)}\nHEIGHT 1\n"
+                     f"POINTS {len(rec)}\nDATA binary_compressed\n").encode() + struct.pack("<II", len(comp), len(soa)) + comp)
+    loc, cal = tmp_path / "localization.ini", tmp_path / "calibration.ini"
+    loc.write_text("[pcm_matching]\nicp_method = 2 ; VGICP\npcm_voxel_size = 1.0\npcm_voxel_max_point = 30\nmax_iteration = 12 ; more than shipped\n")
+    cal.write_text("[Rear To Main LiDAR]\ntransform_xyz_m = 1.0 0.1 1.5\nrotation_rpy_deg = 0.2 -0.4 1.0\n[Rear To Imu]\nrotation_rpy_deg = 0 0 0\n")
+    node = PcmMatching.FromFiles(loc, cal, pcd)
+    assert node.local_map_.info().n_input_points == world.shape[0]
+    assert node.cfg_.registration.icp_method == 2 and node.cfg_.registration.max_iteration == 12
+    scan, T_true = synth.make_scan(world, 8000, seed=77)
+    T0 = synth.perturb(T_true, seed=78)
+    pose, ok, fit, cov = node.registration_.RunRegister(scan, node.local_map_, T0)
+    om = oracle.Map(1.0, 30)
+    om.add_points(formats.LoadPcdXyz(pcd))
+    om.cal_voxel_cov_all()
+    ref = oracle.register(om, scan, T0, oracle.default_config(2, max_iteration=12))
+    dt, dr = synth.pose_error(ref["T"], pose)
+    assert ok == ref["is_success"] and dt <= 1e-4 and dr <= 1e-5
+    node.ctx.close()
