@@ -437,3 +437,47 @@ def test_config_variants(oracle, world100k, voxel_size, max_pts, th, method, ker
         _compare_run(det, ref)
     finally:
         c.close()
+
+
+def _tie_world():
+    """Dyadic lattice (pitch 0.5, offset 0.125, symmetric about the origin) and scan points that sit EXACTLY half-way
+    between lattice points (in one, two or three axes): every such point has 2, 4 or 8 candidates at bit-identical float64
+    distance, some inside one bucket (insertion order decides), some across buckets (visiting order decides), on both
+    sides of the origin (stored keys truncate, query keys floor)."""
+    ax = np.arange(-8, 8) * 0.5 + 0.125
+    gx, gy, gz = np.meshgrid(ax, ax, ax[4:12], indexing="ij")
+    lattice = np.stack([gx.ravel(), gy.ravel(), gz.ravel()], 1)
+    rng = np.random.default_rng(5)
+    lattice = lattice[rng.permutation(len(lattice))].astype(np.float32)  # insertion order != spatial order
+    mids = []
+    for k, off in enumerate([(0.25, 1 / 64, 1 / 32), (1 / 64, 0.25, -1 / 32), (0.25, 0.25, 1 / 64), (0.25, 0.25, 0.25)]):
+        base = lattice[rng.choice(len(lattice), 400, replace=False)].astype(np.float64)
+        mids.append(base + np.array(off))
+    scan = np.concatenate(mids).astype(np.float32)
+    scan = scan[(np.abs(scan) < 3.4).all(axis=1)]
+    return lattice, scan
+
+
+@pytest.mark.parametrize("kernel_env", ["cell", "nbr", "staged", "direct"])
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_exact_ties_follow_the_reference_visiting_order(oracle, method, kernel_env, monkeypatch):
+    """Equal float64 distances: the reference keeps the FIRST strict minimum of its walk (27 voxels x-major..z-minor,
+    insertion order inside a bucket, vhm.cpp:31-88 / 208-243).  GICP's target is the matched point's neighbourhood mean
+    and VGICP's the matched voxel's mean, so a different pick among tied candidates changes the sums."""
+    from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod
+    monkeypatch.setenv("ELM_KERNEL", kernel_env)
+    c = Context(0)
+    try:
+        lattice, scan = _tie_world()
+        m = IcpMethod(method)
+        vm, om = _maps(c, oracle, lattice, m, voxel_size=1.0, max_pts=30, cov_dist=0.6)
+        T0 = np.eye(4)  # identity: g == p bit for bit, the ties are exact in the first iteration
+        cfg = RegistrationConfig(icp_method=m, max_iteration=3, icp_termination_threshold_m=0.0, min_overlap_ratio=0.0, max_fitness_score=10.0)
+        *_, det = Registration(cfg, c).RunRegister(scan, vm, T0, trace=True)
+        ref = oracle.register(om, scan, T0, oracle.default_config(method, max_iteration=3, icp_termination_threshold_m=0.0,
+                                                                  min_overlap_ratio=0.0, max_fitness_score=10.0))
+        _compare_run(det, ref)
+        if kernel_env == "cell" and method in (0, 1):
+            assert det["fallback_blocks"] > 0  # the tied points really went through the exact float64 stage
+    finally:
+        c.close()
