@@ -136,7 +136,7 @@ EXPORTS = [
     "elm_ekf_update_pcm_odom", "elm_ekf_get_state", "elm_ekf_publish",
     "elm_ini_load", "elm_ini_destroy", "elm_ini_get_string", "elm_ini_get_int", "elm_ini_get_bool", "elm_ini_get_double",
     "elm_ini_get_array", "elm_pcm_node_config_default", "elm_load_pcm_config", "elm_load_ekf_config", "elm_pcd_load_xyz",
-    "elm_free", "elm_scan_from_cloud",
+    "elm_free", "elm_scan_from_cloud", "elm_pcm_callback_point_cloud",
 ]
 
 
@@ -146,6 +146,13 @@ class PcmNodeConfig(C.Structure):
                 ("run_deskew", C.c_int32), ("input_index_sampling", C.c_int32), ("lidar_time_delay", C.c_double),
                 ("pcm_voxel_size", C.c_double), ("input_max_dist", C.c_double), ("input_voxel_ds_m", C.c_double),
                 ("tf_ego_to_lidar", C.c_double * 16)]
+
+
+class PcmScanOutput(C.Structure):
+    """elm_pcm_scan_output (include/elimaloc_hip.h)."""
+    _fields_ = [("pose_ego", C.c_double * 16), ("pose_lidar", C.c_double * 16), ("covariance", C.c_double * 36),
+                ("fitness_score", C.c_double), ("time_scan_end", C.c_double), ("n_filtered", C.c_uint64), ("n_source", C.c_uint64),
+                ("result", RegResult)]
 
 
 class CloudField(C.Structure):
@@ -264,6 +271,8 @@ def lib():
     L.elm_free.restype = None
     L.elm_scan_from_cloud.argtypes = [vp, C.c_size_t, C.c_size_t, C.POINTER(CloudField), C.c_int, C.c_int, C.c_int, fp, fp, fp,
                                       C.c_size_t, szp]
+    L.elm_pcm_callback_point_cloud.argtypes = [vp, vp, C.POINTER(PcmNodeConfig), C.POINTER(RegConfig), fp, fp, C.c_size_t, C.c_double,
+                                               dp, C.c_size_t, dp, C.c_size_t, C.POINTER(PcmScanOutput), ip]
     L.elm_comm_get_unique_id.argtypes = [vp]
     L.elm_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.elm_comm_destroy.argtypes = [vp]

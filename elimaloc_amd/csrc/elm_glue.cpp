@@ -170,23 +170,31 @@ extern "C" int elm_filter_points_by_distance(const float* xyz, const float* time
 extern "C" int elm_voxel_downsample(const float* xyz, size_t n, double voxel_size, int64_t* keep_idx, size_t* n_keep) {
     if (!n_keep || !(voxel_size > 0.0) || (n && (!xyz || !keep_idx))) return ELM_ERR_INVALID;
     size_t k = 0;
-    // fast path: keys within +-2^20 per axis pack into one 64-bit word -> flat open-addressing set (no node allocations)
-    std::vector<uint64_t> packed(n);
+    // fast path: keys within +-2^20 per axis pack into one 64-bit word -> flat open-addressing set (no node allocations).
+    // Scratch is kept per thread (no page faults per scan); table slots are prefetched 16 points ahead.
+    static thread_local std::vector<uint64_t> packed, table;
+    static thread_local std::vector<uint32_t> slot;
+    if (packed.size() < n) { packed.resize(n); slot.resize(n); }
     bool fits = true;
     const int32_t lim = 1 << 20;
-    for (size_t i = 0; i < n && fits; ++i) {
-        const double fx = floor((double)xyz[3 * i] / voxel_size), fy = floor((double)xyz[3 * i + 1] / voxel_size),
-                     fz = floor((double)xyz[3 * i + 2] / voxel_size);
-        if (!(fx >= -lim && fx < lim && fy >= -lim && fy < lim && fz >= -lim && fz < lim)) { fits = false; break; }
-        packed[i] = ((uint64_t)((int32_t)fx + lim) << 42) | ((uint64_t)((int32_t)fy + lim) << 21) | (uint64_t)((int32_t)fz + lim);
+    size_t cap = 64;
+    int cap_log2 = 6;
+    while (cap < 2 * n) { cap <<= 1; ++cap_log2; }
+    // floor(x / vs) by truncation + fix-up (no libm call): identical for every finite quotient inside the packing range
+    auto fl = [](double q) { const int32_t kk = (int32_t)q; return ((double)kk > q) ? kk - 1 : kk; };
+    for (size_t i = 0; i < n; ++i) {
+        const double qx = (double)xyz[3 * i] / voxel_size, qy = (double)xyz[3 * i + 1] / voxel_size, qz = (double)xyz[3 * i + 2] / voxel_size;
+        if (!(qx > -lim && qx < lim && qy > -lim && qy < lim && qz > -lim && qz < lim)) { fits = false; break; }
+        const uint64_t key = ((uint64_t)(fl(qx) + lim) << 42) | ((uint64_t)(fl(qy) + lim) << 21) | (uint64_t)(fl(qz) + lim);
+        packed[i] = key;
+        slot[i] = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64 - cap_log2)); // top bits: they depend on every key bit
     }
     if (fits) {
-        size_t cap = 64;
-        while (cap < 2 * n) cap <<= 1;
-        std::vector<uint64_t> table(cap, ~0ull);
+        table.assign(cap, ~0ull);
         for (size_t i = 0; i < n; ++i) {
+            if (i + 16 < n) __builtin_prefetch(&table[slot[i + 16]], 1);
             const uint64_t key = packed[i];
-            size_t h = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 20) & (cap - 1);
+            size_t h = slot[i];
             while (table[h] != ~0ull && table[h] != key) h = (h + 1) & (cap - 1);
             if (table[h] == ~0ull) { table[h] = key; keep_idx[k++] = (int64_t)i; } // first point of every voxel, input order
         }
@@ -278,5 +286,103 @@ extern "C" int elm_shape_odom_covariance(const double local_cov[36], const doubl
             cov_out[r * 6 + c] = tn[r * 3 + c] * std_m * std_m;
             cov_out[(r + 3) * 6 + (c + 3)] = rn[r * 3 + c] * angle_std * angle_std;
         }
+    return ELM_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------------
+// PcmMatching::CallbackPointCloud as one call (pcm.cpp:198-324)
+// ------------------------------------------------------------------------------------------------------
+static void mul4_cm(const double* A, const double* B, double* C) { // column-major 4x4
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) {
+            double s = 0.0;
+            for (int k = 0; k < 4; ++k) s += A[k * 4 + r] * B[c * 4 + k];
+            C[c * 4 + r] = s;
+        }
+}
+// general inverse of a column-major 4x4 by Gauss-Jordan with partial pivoting (the reference calls Matrix4d::inverse())
+static bool inv4_cm(const double* A, double* R) {
+    double a[4][8];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) { a[r][c] = A[c * 4 + r]; a[r][4 + c] = (r == c) ? 1.0 : 0.0; }
+    for (int k = 0; k < 4; ++k) {
+        int p = k;
+        for (int r = k + 1; r < 4; ++r)
+            if (fabs(a[r][k]) > fabs(a[p][k])) p = r;
+        if (a[p][k] == 0.0) return false;
+        if (p != k)
+            for (int c = 0; c < 8; ++c) std::swap(a[k][c], a[p][c]);
+        const double piv = 1.0 / a[k][k];
+        for (int c = 0; c < 8; ++c) a[k][c] *= piv;
+        for (int r = 0; r < 4; ++r) {
+            if (r == k) continue;
+            const double f = a[r][k];
+            for (int c = 0; c < 8; ++c) a[r][c] -= f * a[k][c];
+        }
+    }
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) R[c * 4 + r] = a[r][4 + c];
+    return true;
+}
+
+extern "C" int elm_pcm_callback_point_cloud(elm_ctx* ctx, const elm_map* map, const elm_pcm_node_config* node, const elm_reg_config* reg,
+                                            const float* xyz, const float* point_time, size_t n, double stamp, const double* imu4,
+                                            size_t n_imu, const double* odom14, size_t n_odom, elm_pcm_scan_output* out, int* published) {
+    if (!ctx || !map || !node || !reg || !out || !published || (n && (!xyz || !point_time))) return ELM_ERR_INVALID;
+    *published = 0;
+    memset(out, 0, sizeof(*out));
+    stamp -= node->lidar_time_delay; // pcm.cpp:216-217
+    if (n == 0) return ELM_OK;       // "Input Empty!" (pcm.cpp:226-229)
+    std::vector<float> fx(3 * n), ft(n);
+    size_t nf = 0;
+    int rc = elm_filter_points_by_distance(xyz, point_time, n, node->input_max_dist, fx.data(), ft.data(), &nf); // :235
+    if (rc != ELM_OK) return rc;
+    out->n_filtered = nf;
+    if (nf == 0) return ELM_OK;
+    // DeskewPointCloud (pcm.cpp:467-531)
+    const float front = ft[0], back = ft[nf - 1];
+    if (node->lidar_scan_time_end)
+        for (size_t i = 0; i < nf; ++i) ft[i] -= front; // :483-485
+    std::vector<double> tab(4 * 2000);
+    elm_deskew_tables tabs;
+    rc = elm_deskew_prepare(imu4, n_imu, odom14, n_odom, stamp, front, back, node->lidar_scan_time_end, node->run_deskew, tab.data(),
+                            tab.data() + 2000, tab.data() + 4000, tab.data() + 6000, 2000, &tabs);
+    if (rc != ELM_OK) return rc;
+    std::vector<float> und(3 * nf);
+    int ok = 0;
+    rc = elm_deskew(ctx, fx.data(), ft.data(), nf, &tabs, und.data(), &ok);
+    if (rc != ELM_OK) return rc;
+    if (!ok) return ELM_OK; // "Deskew fail!" (pcm.cpp:238-241)
+    out->time_scan_end = tabs.d_time_scan_end;
+    float sync[16];
+    rc = elm_get_interpolated_pose(odom14, n_odom, tabs.d_time_scan_end, sync, &ok); // :248-251
+    if (rc != ELM_OK) return rc;
+    if (!ok) return ELM_OK;
+    std::vector<int64_t> keep(nf);
+    size_t nk = 0;
+    rc = elm_voxel_downsample(und.data(), nf, node->input_voxel_ds_m, keep.data(), &nk); // :257-258
+    if (rc != ELM_OK) return rc;
+    std::vector<float> src(3 * std::max<size_t>(nk, 1));
+    for (size_t k = 0; k < nk; ++k) {
+        const size_t i = (size_t)keep[k];
+        src[3 * k] = und[3 * i]; src[3 * k + 1] = und[3 * i + 1]; src[3 * k + 2] = und[3 * i + 2];
+    }
+    out->n_source = nk;
+    double syncd[16], T0[16], cov6[36];
+    for (int i = 0; i < 16; ++i) syncd[i] = (double)sync[i];
+    mul4_cm(syncd, node->tf_ego_to_lidar, T0); // sync_lidar_pose (pcm.cpp:266)
+    int success = 0;
+    double fit = 0.0;
+    rc = elm_register(ctx, map, src.data(), nk, T0, reg, out->pose_lidar, &success, &fit, cov6, &out->result, nullptr); // :280-282
+    if (rc != ELM_OK) return rc;
+    if (!success) return ELM_OK; // pcm.cpp:289-292
+    out->fitness_score = fit;
+    double tinv[16];
+    if (!inv4_cm(node->tf_ego_to_lidar, tinv)) return ELM_ERR_INVALID;
+    mul4_cm(out->pose_lidar, tinv, out->pose_ego); // :298
+    rc = elm_shape_odom_covariance(cov6, out->pose_ego, fit, out->covariance);
+    if (rc != ELM_OK) return rc;
+    *published = 1;
     return ELM_OK;
 }

@@ -152,6 +152,38 @@ class PcmMatching:
         lap("publish_ms")
         return out
 
+    def _node_config(self):
+        c = self.cfg_
+        nc = _lib.PcmNodeConfig()
+        _lib.lib().elm_pcm_node_config_default(C.byref(nc))
+        nc.lidar_type = c.s_lidar_type.encode()
+        nc.lidar_scan_time_end, nc.run_deskew = int(c.b_lidar_scan_time_end), int(c.b_run_deskew)
+        nc.pcm_voxel_max_point, nc.input_index_sampling = c.i_pcm_voxel_max_point, c.i_input_index_sampling
+        nc.lidar_time_delay, nc.pcm_voxel_size = c.d_lidar_time_delay, c.d_pcm_voxel_size
+        nc.input_max_dist, nc.input_voxel_ds_m = c.d_input_max_dist, c.d_input_voxel_ds_m
+        nc.tf_ego_to_lidar = (C.c_double * 16)(*np.asarray(c.tf_ego_to_lidar, dtype=np.float64).T.ravel())
+        return nc
+
+    def CallbackPointCloudNative(self, xyz, point_time, stamp, imu, odom):
+        """The same callback through ONE C-ABI call (elm_pcm_callback_point_cloud): no Python between the stages."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        t = np.ascontiguousarray(point_time, dtype=np.float32)
+        imu = np.ascontiguousarray(imu, dtype=np.float64).reshape(-1, 4)
+        odom = np.ascontiguousarray(odom, dtype=np.float64).reshape(-1, 14)
+        if not hasattr(self, "_nc"):
+            self._nc = self._node_config()
+        out, pub = _lib.PcmScanOutput(), C.c_int(0)
+        check(_lib.lib().elm_pcm_callback_point_cloud(self.ctx._h, self.local_map_._h, C.byref(self._nc), C.byref(self.cfg_.registration),
+                                                      _fp(xyz), _fp(t), xyz.shape[0], float(stamp), _dp(imu), imu.shape[0], _dp(odom),
+                                                      odom.shape[0], C.byref(out), C.byref(pub)), self.ctx._h, "elm_pcm_callback_point_cloud")
+        if not pub.value:
+            return None
+        self.d_time_scan_end_ = out.time_scan_end
+        self.d_icp_pose_std_m = out.fitness_score
+        return dict(pose_ego=np.array(out.pose_ego).reshape(4, 4).T.copy(), pose_lidar=np.array(out.pose_lidar).reshape(4, 4).T.copy(),
+                    fitness=out.fitness_score, time=out.time_scan_end, covariance=np.array(out.covariance).reshape(6, 6),
+                    n_source=int(out.n_source))
+
     def CallbackInitialPose(self, rviz_pose, raw_scan_xyz):
         """pcm.cpp:356-447: ground height under the clicked pose, then RunRegister on the last RAW scan."""
         rviz_pose = np.asarray(rviz_pose, dtype=np.float64)

@@ -41,8 +41,9 @@ def euler_zyx_quat_xyzw(roll, pitch, yaw):  # UpdateEkfOdom (ekfl.cpp:523-525)
 
 
 class LocalizationStream:
-    def __init__(self, pcm_node, ekf=None):
+    def __init__(self, pcm_node, ekf=None, native=False):
         self.pcm = pcm_node
+        self.native = native  # True: the whole CallbackPointCloud is one C-ABI call
         self.ekf = ekf or EkfAlgorithm()
         self.deq_imu_ = collections.deque(maxlen=QUEUE_LENGTH * 4)
         self.deq_odom_ = collections.deque(maxlen=QUEUE_LENGTH * 4)
@@ -83,7 +84,7 @@ class LocalizationStream:
         if not self.deq_odom_:  # b_get_first_odom_ == false (pcm.cpp:208-211)
             return None
         imu, odom = self._windows(stamp)
-        out = self.pcm.CallbackPointCloud(xyz, point_time, stamp, imu, odom)
+        out = (self.pcm.CallbackPointCloudNative if self.native else self.pcm.CallbackPointCloud)(xyz, point_time, stamp, imu, odom)
         if out is None:
             return None
         self.n_ok += 1

@@ -327,6 +327,27 @@ int elm_scan_from_cloud(const void* data, size_t n_points, size_t point_step, co
                         int is_ouster, int index_sampling, float* xyz, float* intensity, float* rel_time, size_t cap,
                         size_t* n_out);
 
+/* ---------------------------------------------------------------- the node callback ---------------- */
+/* PcmMatching::CallbackPointCloud (pcm.cpp:198-324) as ONE call: stamp -= lidar_time_delay, FilterPointsByDistance,
+ * DeskewPointCloud (tables on the host, per-point loop on the GPU), GetInterpolatedPose at the scan end, VoxelDownsample,
+ * lidar pose = sync ego pose * tf_ego_to_lidar, RunRegister, ego pose = result * tf_ego_to_lidar^-1, covariance shaping.
+ * imu4 / odom14: the node's deq_imu_ / deq_odom_ contents as in elm_deskew_prepare.  *published = 0 reproduces the
+ * reference's silent returns (empty input, deskew data missing, no synced pose, registration failure: pcm.cpp:226-229,
+ * 238-241, 249-251, 289-292); the other outputs are then undefined except result. */
+typedef struct elm_pcm_scan_output {
+    double pose_ego[16];     /* icp_ego_pose, column-major */
+    double pose_lidar[16];   /* registration result, column-major */
+    double covariance[36];   /* nav_msgs/Odometry.pose.covariance, row-major (PublishPcmOdom) */
+    double fitness_score;
+    double time_scan_end;    /* d_time_scan_end_ = stamp of the published odometry */
+    uint64_t n_filtered;     /* points after the distance filter */
+    uint64_t n_source;       /* points after VoxelDownsample = registration source size */
+    elm_reg_result result;
+} elm_pcm_scan_output;
+int elm_pcm_callback_point_cloud(elm_ctx* ctx, const elm_map* map, const elm_pcm_node_config* node, const elm_reg_config* reg,
+                                 const float* xyz, const float* point_time, size_t n, double stamp, const double* imu4,
+                                 size_t n_imu, const double* odom14, size_t n_odom, elm_pcm_scan_output* out, int* published);
+
 /* ---------------------------------------------------------------- multi-GPU ----------------------- */
 /* One process per GPU.  Rank 0 obtains an id, the host distributes its bytes (e.g. torch.distributed
  * broadcast), every rank calls elm_comm_init.  Afterwards elm_register_batch* sums the packed normal

@@ -118,3 +118,36 @@ def test_pcm_pipeline_matches_oracle_pipeline(oracle):
     dt, dr = synth.pose_error(iref["T"] @ np.linalg.inv(tf), ip["pose_ego"])
     assert iref["is_success"] and dt <= 1e-4 and dr <= 1e-5
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_native_callback_equals_staged_python_callback(oracle):
+    """elm_pcm_callback_point_cloud (the whole CallbackPointCloud in one C-ABI call) against the stage-by-stage Python
+    mirror that test_pcm_pipeline_matches_oracle_pipeline pins to the oracle: same source size, pose within 1e-10 m."""
+    from elimaloc_amd.pcm_matching import PcmMatching, PcmMatchingConfig
+    from elimaloc_amd.registration import Context, RegistrationConfig, IcpMethod
+    world = synth.make_world(100000, seed=1001)
+    ctx = Context(0)
+    tf = np.eye(4); tf[:3, :3] = synth.rot_zyx(0.0, 0.01, 0.02); tf[:3, 3] = [1.2, 0.0, 1.6]
+    for method in (IcpMethod.VGICP, IcpMethod.GICP):
+        cfg = PcmMatchingConfig(tf_ego_to_lidar=tf, registration=RegistrationConfig(icp_method=method))
+        node = PcmMatching(cfg, ctx)
+        node.Init(world)
+        st = synth.make_deskew_stream(30000, seed=9, stamp=2000.0)
+        od = st["odom"].copy()
+        od[:, 1:4] += [-8.0, 3.0, 0.3]
+        rok, ego_end = oracle.get_interpolated_pose(od, st["stamp"] - cfg.d_lidar_time_delay)
+        lidar_end = ego_end.astype(np.float64) @ tf
+        near = world[np.linalg.norm(world - lidar_end[:3, 3].astype(np.float32), axis=1) < 40.0]
+        pick = near[np.random.default_rng(4).choice(len(near), 30000, replace=False)].astype(np.float64)
+        raw = ((pick - lidar_end[:3, 3]) @ lidar_end[:3, :3]).astype(np.float32)
+        imu = np.concatenate([st["imu_t"][:, None], st["imu_w"]], axis=1)
+        a = node.CallbackPointCloud(raw, st["time"], st["stamp"], imu, od)
+        b = node.CallbackPointCloudNative(raw, st["time"], st["stamp"], imu, od)
+        assert a is not None and b is not None and a["n_source"] == b["n_source"] and a["time"] == b["time"]
+        np.testing.assert_allclose(b["pose_ego"], a["pose_ego"], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(b["covariance"], a["covariance"], rtol=1e-8, atol=1e-14)
+        # silent returns: no odometry at all -> deskew data missing -> nothing published
+        assert node.CallbackPointCloudNative(raw, st["time"], st["stamp"], imu, np.zeros((0, 14))) is None
+        assert node.CallbackPointCloudNative(np.zeros((0, 3), np.float32), np.zeros(0, np.float32), st["stamp"], imu, od) is None
+    ctx.close()
