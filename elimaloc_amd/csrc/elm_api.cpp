@@ -73,7 +73,8 @@ struct elm_ctx {
     hipStream_t stream = nullptr;
     std::string last_error;
     // scratch (grow-only; no allocation on the per-scan path after warm-up)
-    DevBuf d_scans, d_state, d_partials, d_sums, d_T0, d_trace, d_stage_pts, d_active;
+    DevBuf d_scans, d_state, d_partials, d_sums, d_T0, d_trace, d_stage_pts, d_active, d_queue;
+    int stream_hint_count = 0, stream_hint_slots = 0, stream_hint_iters = 0; // iterations the last elm_register_stream call of that shape needed
     int* h_active = nullptr; // pinned: number of scans still iterating, read back at the early-stop checks
     int iter_hint = 0;       // iterations the previous batch needed (0 = unknown): first early-stop check happens there
     void* h_state = nullptr; // pinned
@@ -195,7 +196,7 @@ extern "C" void elm_ctx_destroy(elm_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm && g_rccl.comm_destroy) g_rccl.comm_destroy(ctx->comm);
-    DevBuf* bufs[] = {&ctx->d_scans, &ctx->d_state, &ctx->d_partials, &ctx->d_sums, &ctx->d_T0, &ctx->d_trace, &ctx->d_stage_pts, &ctx->d_active};
+    DevBuf* bufs[] = {&ctx->d_scans, &ctx->d_state, &ctx->d_partials, &ctx->d_sums, &ctx->d_T0, &ctx->d_trace, &ctx->d_stage_pts, &ctx->d_active, &ctx->d_queue};
     if (ctx->h_active) (void)hipHostFree(ctx->h_active);
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -1080,6 +1081,24 @@ extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_
     return ELM_OK;
 }
 
+static void state_to_result(const ScanState& h, const RegParams& rp, elm_reg_result& r) {
+    memset(&r, 0, sizeof(r));
+    memcpy(r.T, h.T, sizeof(r.T));
+    memcpy(r.local_cov, h.local_cov, sizeof(r.local_cov));
+    r.d_fitness = h.fitness;
+    r.is_success = h.success;
+    r.fitness_score = h.success ? h.fitness : 0.0; // written only on success (reg.cpp:415)
+    r.iterations = h.iters;
+    r.gate = h.gate;
+    r.n_corr_last = h.n_corr_last;
+    r.point_iterations = h.pt_iters;
+    r.n_cand_total = h.cand_total;
+    r.n_occ_total = h.occ_total;
+    r.fallback_blocks = h.fallback_blocks;
+    r.n_tested_total = h.tested_total;
+    if (rp.max_iter <= 0 && h.gate == 0) r.is_success = 1; // no iteration ran: fitness gate on the initial 0.0 passes
+}
+
 extern "C" int elm_register_batch_finish(elm_ctx* ctx, elm_reg_result* results, elm_iter_trace* trace) {
     if (!ctx || !ctx->in_flight) return ELM_ERR_INVALID;
     ctx->in_flight = false;
@@ -1096,26 +1115,7 @@ extern "C" int elm_register_batch_finish(elm_ctx* ctx, elm_reg_result* results, 
     }
     ctx->events_used = 0;
     const ScanState* hs = (const ScanState*)ctx->h_state;
-    for (int b = 0; results && b < ctx->batch; ++b) {
-        elm_reg_result& r = results[b];
-        memset(&r, 0, sizeof(r));
-        memcpy(r.T, hs[b].T, sizeof(r.T));
-        memcpy(r.local_cov, hs[b].local_cov, sizeof(r.local_cov));
-        r.d_fitness = hs[b].fitness;
-        r.is_success = hs[b].success;
-        r.fitness_score = hs[b].success ? hs[b].fitness : 0.0; // written only on success (reg.cpp:415)
-        r.iterations = hs[b].iters;
-        r.gate = hs[b].gate;
-        r.n_corr_last = hs[b].n_corr_last;
-        r.point_iterations = hs[b].pt_iters;
-        r.n_cand_total = hs[b].cand_total;
-        r.n_occ_total = hs[b].occ_total;
-        r.fallback_blocks = hs[b].fallback_blocks;
-        r.n_tested_total = hs[b].tested_total;
-        if (ctx->rp.max_iter <= 0 && hs[b].gate == 0) { // no iteration ran: fitness gate on the initial 0.0 passes
-            r.is_success = 1;
-        }
-    }
+    for (int b = 0; results && b < ctx->batch; ++b) state_to_result(hs[b], ctx->rp, results[b]);
     {
         int mx = 0;
         for (int b = 0; b < ctx->batch; ++b) mx = std::max(mx, (int)hs[b].iters);
@@ -1131,6 +1131,159 @@ extern "C" int elm_register_batch(elm_ctx* ctx, const elm_map* map, elm_scan* co
     int rc = elm_register_batch_enqueue(ctx, map, scans, batch, T0, cfg, trace != nullptr);
     if (rc != ELM_OK) return rc;
     return elm_register_batch_finish(ctx, results, trace);
+}
+
+// Continuous batching: `count` registrations through `slots` slots.  Every ICP iteration is one accumulate launch over the
+// slots, the solve, and a refill kernel that hands finished slots the next pending registration on the device -- so the
+// launches stay full until the queue is empty (a lockstep batch ends in launches with a handful of live scans, which are
+// latency bound).  Per-registration arithmetic is unchanged: results are bit-identical to elm_register_batch.
+extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* const* scans, int count, const double* T0,
+                                   const elm_reg_config* cfg, int slots, elm_reg_result* results, elm_iter_trace* trace) {
+    if (!ctx || !map || !scans || count <= 0 || !T0 || !cfg || slots <= 0) return ELM_ERR_INVALID;
+    if (map->dm.n_vox == 0 || cfg->max_iteration <= 0) // nothing iterates: the lockstep path handles the degenerate cases
+        return elm_register_batch(ctx, map, scans, count, T0, cfg, results, trace);
+    if (map->ctx != ctx) return ELM_ERR_INVALID;
+    if (cfg->use_radar_cov) return ELM_ERR_UNSUPPORTED;
+    if (cfg->icp_method < ELM_P2P || cfg->icp_method > ELM_AVGICP) return ELM_ERR_INVALID;
+    if (ctx->in_flight) return ELM_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int method = cfg->icp_method;
+    if ((method == ELM_VGICP || method == ELM_AVGICP) && !map->info.has_voxel_cov) {
+        ctx->last_error = "VGICP/AVGICP need elm_map_cal_voxel_cov_all() (pcm.cpp:92-95)";
+        return ELM_ERR_INVALID;
+    }
+    if (method == ELM_GICP && !map->info.has_point_cov) {
+        ctx->last_error = "GICP needs elm_map_cal_point_cov_all() (pcm.cpp:97-100)";
+        return ELM_ERR_INVALID;
+    }
+    const int S = std::min(std::min(slots, count), 1024);
+    int rc;
+    // queue (host staging): items, initial guesses; slot descriptors with fixed block ranges sized for the largest scan
+    uint32_t max_n = 0;
+    for (int b = 0; b < count; ++b) {
+        if (!scans[b] || scans[b]->ctx != ctx) return ELM_ERR_INVALID;
+        max_n = std::max(max_n, scans[b]->n);
+    }
+    const uint32_t cap_blocks = (max_n + kBlock - 1) / kBlock;
+    const uint32_t blocks = cap_blocks * (uint32_t)S;
+    const size_t q_bytes = (size_t)count * sizeof(QueueItem), t_bytes = (size_t)count * 16 * sizeof(double), d_bytes = (size_t)S * sizeof(ScanDesc);
+    const size_t stage_bytes = q_bytes + t_bytes + d_bytes + sizeof(StreamCtrl);
+    if ((rc = pinned_reserve(ctx, &ctx->h_desc, &ctx->h_desc_cap, std::max<size_t>(stage_bytes, 4096))) != ELM_OK) return rc;
+    QueueItem* hq = (QueueItem*)ctx->h_desc;
+    double* hT = (double*)((char*)ctx->h_desc + q_bytes);
+    ScanDesc* hd = (ScanDesc*)((char*)ctx->h_desc + q_bytes + t_bytes);
+    StreamCtrl* hc = (StreamCtrl*)((char*)ctx->h_desc + q_bytes + t_bytes + d_bytes);
+    for (int b = 0; b < count; ++b) { hq[b].pts = scans[b]->d_pts; hq[b].n = scans[b]->n; hq[b].n_total = scans[b]->n_total; }
+    memcpy(hT, T0, t_bytes);
+    for (int s = 0; s < S; ++s) { hd[s].pts = nullptr; hd[s].n = 0; hd[s].n_total = 0; hd[s].blk_begin = cap_blocks * (uint32_t)s; hd[s].blk_end = cap_blocks * (uint32_t)(s + 1); }
+    hc->next = 0; hc->completed = 0; hc->total = count; hc->_pad = 0;
+    if ((rc = dev_reserve(ctx, ctx->d_scans, d_bytes)) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_state, (size_t)S * sizeof(ScanState))) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_partials, (size_t)std::max<uint32_t>(blocks, 1) * kSums * sizeof(double))) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_sums, (size_t)S * kSums * sizeof(double))) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_queue, q_bytes + t_bytes + sizeof(StreamCtrl) + (size_t)count * sizeof(ScanState) + 64)) != ELM_OK) return rc;
+    if ((rc = pinned_reserve(ctx, &ctx->h_state, &ctx->h_state_cap, (size_t)count * sizeof(ScanState))) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_active, 256)) != ELM_OK) return rc;
+    if (!ctx->h_active) HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_active, 64, hipHostMallocDefault));
+    char* qb = (char*)ctx->d_queue.p;
+    QueueItem* d_q = (QueueItem*)qb;
+    double* d_qT0 = (double*)(qb + q_bytes);
+    StreamCtrl* d_ctrl = (StreamCtrl*)(qb + q_bytes + t_bytes);
+    ScanState* d_out = (ScanState*)(qb + q_bytes + t_bytes + ((sizeof(StreamCtrl) + 63) / 64) * 64);
+    elm_iter_trace* d_trace = nullptr;
+    if (trace) {
+        const size_t tb = (size_t)count * ELM_MAX_ITER_TRACE * sizeof(elm_iter_trace);
+        if ((rc = dev_reserve(ctx, ctx->d_trace, tb)) != ELM_OK) return rc;
+        if ((rc = pinned_reserve(ctx, &ctx->h_trace, &ctx->h_trace_cap, tb)) != ELM_OK) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_trace.p, 0, tb, ctx->stream));
+        d_trace = (elm_iter_trace*)ctx->d_trace.p;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(d_q, hq, q_bytes + t_bytes, hipMemcpyHostToDevice, ctx->stream)); // items + guesses are contiguous
+    HIPCHK(ctx, hipMemcpyAsync(d_ctrl, hc, sizeof(StreamCtrl), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_scans.p, hd, d_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_active.p, 0, sizeof(int), ctx->stream));
+
+    RegParams rp;
+    rp.th = cfg->max_search_dist;
+    rp.th2 = cfg->max_search_dist * cfg->max_search_dist;
+    rp.lm_lambda = cfg->lm_lambda;
+    rp.term_thr = cfg->icp_termination_threshold_m;
+    rp.min_overlap = cfg->min_overlap_ratio;
+    rp.max_fitness = cfg->max_fitness_score;
+    rp.method = method;
+    rp.max_iter = cfg->max_iteration;
+    ctx->rp = rp;
+    const bool use_nbr = (ctx->kernel_mode == 0 || ctx->kernel_mode == 4) && (method == ELM_P2P || method == ELM_GICP);
+    if (use_nbr && !map->has_nbr)
+        if ((rc = elm_map_build_neighbourhoods(const_cast<elm_map*>(map))) != ELM_OK) return rc;
+    const bool use_vnbr = (ctx->kernel_mode == 0 || ctx->kernel_mode == 4) && method == ELM_VGICP;
+    if (use_vnbr && !map->has_vnbr)
+        if ((rc = build_voxel_neighbourhoods(const_cast<elm_map*>(map))) != ELM_OK) return rc;
+
+    ScanState* st = (ScanState*)ctx->d_state.p;
+    ScanDesc* dsc = (ScanDesc*)ctx->d_scans.p;
+    int* d_active = (int*)ctx->d_active.p;
+    const bool distributed = (ctx->comm != nullptr) || (ctx->hook != nullptr);
+    (void)hipGetLastError();
+    launch_stream_refill(ctx->stream, dsc, st, S, d_q, d_qT0, d_out, d_ctrl, 1);
+    ctx->events_used = 0;
+    // Iterations needed: unknown in advance (it depends on when each registration converges).  The previous call with the
+    // same shape is the prediction: enqueue that many without looking, then read the completed counter after every
+    // further iteration.  All ranks read the same counter (it derives from all-reduced sums) and stop together.
+    const int hard_limit = ((count + S - 1) / S + 1) * cfg->max_iteration;
+    const bool same_shape = ctx->stream_hint_count == count && ctx->stream_hint_slots == S;
+    const int predicted = same_shape ? ctx->stream_hint_iters : 0;
+    int it = 0;
+    for (; it < hard_limit; ++it) {
+        if ((rc = prof_mark(ctx)) != ELM_OK) return rc;
+        if (blocks) {
+            if (use_nbr && ctx->kernel_mode == 4 && map->has_cells)
+                launch_accumulate_cell(ctx->stream, map->dm, dsc, S, (int)blocks, st, (double*)ctx->d_partials.p, rp);
+            else if (use_vnbr) launch_accumulate_vnbr(ctx->stream, map->dm, dsc, S, (int)blocks, st, (double*)ctx->d_partials.p, rp);
+            else if (use_nbr) launch_accumulate_nbr(ctx->stream, map->dm, dsc, S, (int)blocks, st, (double*)ctx->d_partials.p, rp);
+            else launch_accumulate(ctx->stream, map->dm, dsc, S, (int)blocks, st, (double*)ctx->d_partials.p, rp,
+                                   (ctx->kernel_mode == 2 || map->info.max_points_per_voxel > 255) ? 1 : 0);
+        }
+        if ((rc = prof_mark(ctx)) != ELM_OK) return rc;
+        if (distributed) {
+            launch_solve(ctx->stream, dsc, S, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 1, d_active);
+            if ((rc = exchange(ctx, (double*)ctx->d_sums.p, (size_t)S * kSums)) != ELM_OK) return rc;
+            launch_solve(ctx->stream, dsc, S, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 2, d_active);
+        } else {
+            launch_solve(ctx->stream, dsc, S, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 0, d_active);
+        }
+        launch_stream_refill(ctx->stream, dsc, st, S, d_q, d_qT0, d_out, d_ctrl, 0);
+        const int done_iters = it + 1;
+        const bool look = predicted > 0 ? done_iters >= predicted : (done_iters >= (count + S - 1) / S && (done_iters % 2) == 0);
+        if (look) {
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_active, &d_ctrl->completed, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            if (*ctx->h_active == count) { ++it; break; }
+        }
+    }
+    if ((rc = prof_mark(ctx)) != ELM_OK) return rc;
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_state, d_out, (size_t)count * sizeof(ScanState), hipMemcpyDeviceToHost, ctx->stream));
+    if (trace)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_trace, ctx->d_trace.p, (size_t)count * ELM_MAX_ITER_TRACE * sizeof(elm_iter_trace),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->profiling && ctx->events_used >= 3) {
+        for (int k = 0; k + 1 < ctx->events_used; ++k) {
+            float ms = 0.f;
+            HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->events[k], ctx->events[k + 1]));
+            if ((k & 1) == 0) { ctx->prof.accumulate_ms += ms; ctx->prof.accumulate_launches++; }
+            else { ctx->prof.solve_ms += ms; ctx->prof.solve_steps++; }
+        }
+    }
+    ctx->events_used = 0;
+    ctx->stream_hint_count = count;
+    ctx->stream_hint_slots = S;
+    ctx->stream_hint_iters = it;
+    const ScanState* hs = (const ScanState*)ctx->h_state;
+    for (int b = 0; results && b < count; ++b) state_to_result(hs[b], rp, results[b]);
+    if (trace) memcpy(trace, ctx->h_trace, (size_t)count * ELM_MAX_ITER_TRACE * sizeof(elm_iter_trace));
+    return ELM_OK;
 }
 
 extern "C" int elm_register(elm_ctx* ctx, const elm_map* map, const float* scan_xyz, size_t n, const double T0[16],

@@ -92,6 +92,20 @@ struct ScanState {
     int32_t success;
     int32_t gate;
     int32_t iters;
+    int32_t reg;  // registration this slot works on (== slot index in a lockstep batch; -1 = idle slot of a stream)
+    int32_t _pad;
+};
+
+// continuous batching (elm_register_stream): pending registrations and the device-side bookkeeping
+struct QueueItem {
+    const float4* pts;
+    uint32_t n, n_total;
+};
+struct StreamCtrl {
+    int32_t next;      // first registration not yet assigned to a slot
+    int32_t completed; // registrations whose final state has been saved
+    int32_t total;
+    int32_t _pad;
 };
 
 struct RegParams {
@@ -111,6 +125,8 @@ constexpr int kSums = ELM_PACKED_SUMS; // 21 + 6 + 1 + 1 (+ n_cand, n_occ, pad)
 // ---- launchers (elm_kernels.hip) ----------------------------------------------------------------------
 int debug_phase_cycles(unsigned long long* out16, int reset); // 1 when built with -DELM_PHASE_TIMING
 void launch_init_state(hipStream_t s, ScanState* st, const double* T0, int batch, int map_empty, int* active);
+void launch_stream_refill(hipStream_t s, ScanDesc* scans, ScanState* st, int slots, const QueueItem* queue, const double* qT0,
+                          ScanState* out_state, StreamCtrl* ctrl, int first);
 void launch_accumulate(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                        ScanState* st, double* partials, const RegParams& rp, int direct);
 // mode 0: reduce + solve (single GPU); 1: reduce only -> sums; 2: solve only from sums

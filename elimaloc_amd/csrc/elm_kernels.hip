@@ -1409,13 +1409,8 @@ __device__ void update_inverse(ScanState& S) {
         S.tinv[r] = -((S.Rinv[r * 3] * S.T[12] + S.Rinv[r * 3 + 1] * S.T[13]) + S.Rinv[r * 3 + 2] * S.T[14]);
 }
 
-__global__ __launch_bounds__(64) void k_init_state(ScanState* st, const double* __restrict__ T0, int batch, int map_empty,
-                                                   int* active) {
-    const int s = blockIdx.x * 64 + threadIdx.x;
-    if (s >= batch) return;
-    if (!map_empty) atomicAdd(active, 1); // scans still iterating (the host zeroed the counter)
-    ScanState& S = st[s];
-    for (int k = 0; k < 16; ++k) S.T[k] = T0[(size_t)s * 16 + k];
+__device__ void init_scan_state(ScanState& S, const double* __restrict__ T0, int reg, int map_empty) {
+    for (int k = 0; k < 16; ++k) S.T[k] = T0[k];
     update_inverse(S);
     S.fitness = 0.0;
     for (int k = 0; k < 36; ++k) S.local_cov[k] = (k % 7 == 0) ? 1.0 : 0.0; // reg.cpp:280
@@ -1425,6 +1420,64 @@ __global__ __launch_bounds__(64) void k_init_state(ScanState* st, const double* 
     S.success = 0;
     S.gate = map_empty ? 1 : 0;
     S.iters = 0;
+    S.reg = reg;
+    S._pad = 0;
+}
+
+__global__ __launch_bounds__(64) void k_init_state(ScanState* st, const double* __restrict__ T0, int batch, int map_empty,
+                                                   int* active) {
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= batch) return;
+    if (!map_empty) atomicAdd(active, 1); // scans still iterating (the host zeroed the counter)
+    init_scan_state(st[s], T0 + (size_t)s * 16, s, map_empty);
+}
+
+// Continuous batching: after the solve of an iteration, every slot whose registration has finished saves its final state
+// and takes the next pending registration (descriptor + initial guess), so every accumulate launch stays full until the
+// queue runs dry.  Slots are served in slot order by one thread: the assignment is deterministic (identical on every rank).
+constexpr int kMaxSlots = 1024;
+__global__ __launch_bounds__(256) void k_stream_refill(ScanDesc* scans, ScanState* st, int slots, const QueueItem* __restrict__ queue,
+                                                       const double* __restrict__ qT0, ScanState* out_state, StreamCtrl* ctrl, int first) {
+    __shared__ int s_assign[kMaxSlots]; // registration to start in the slot, -1 = slot keeps going, -2 = slot goes idle
+    __shared__ int s_save[kMaxSlots];   // registration whose final state is copied out, -1 = none
+    // the slots' flags are fetched by all threads at once; the serial part below only touches LDS
+    for (int s = threadIdx.x; s < slots; s += blockDim.x) s_save[s] = (!first && st[s].done && st[s].reg >= 0) ? st[s].reg : -1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int next = first ? 0 : ctrl->next, completed = first ? 0 : ctrl->completed;
+        const int total = ctrl->total;
+        for (int s = 0; s < slots; ++s) {
+            s_assign[s] = -1;
+            if (!first && s_save[s] < 0) continue; // still iterating, or already idle
+            if (!first) ++completed;
+            s_assign[s] = (next < total) ? next++ : -2;
+        }
+        ctrl->next = next;
+        ctrl->completed = completed;
+    }
+    __syncthreads();
+    constexpr int W = (int)(sizeof(ScanState) / sizeof(double));
+    for (int s = (int)(threadIdx.x >> 6); s < slots; s += (int)(blockDim.x >> 6)) { // one wavefront per slot
+        const int r = s_save[s];
+        if (r < 0) continue;
+        const double* src = reinterpret_cast<const double*>(&st[s]);
+        double* dst = reinterpret_cast<double*>(&out_state[r]);
+        for (int k = (int)(threadIdx.x & 63); k < W; k += 64) dst[k] = src[k];
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < slots; s += blockDim.x) {
+        const int r = s_assign[s];
+        if (r >= 0) {
+            const QueueItem q = queue[r];
+            scans[s].pts = q.pts;
+            scans[s].n = q.n;
+            scans[s].n_total = q.n_total;
+            init_scan_state(st[s], qT0 + (size_t)r * 16, r, 0);
+        } else if (r == -2) {
+            st[s].done = 1;
+            st[s].reg = -1;
+        }
+    }
 }
 
 // Wave-parallel 6x6 LDL^T with diagonal pivoting (the pivot rule of Eigen's LDLT: largest |diagonal| of the trailing
@@ -1550,7 +1603,11 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* __restr
                 const double a2 = partials[(size_t)(b + 2 * G) * kSums + k], a3 = partials[(size_t)(b + 3 * G) * kSums + k];
                 v0 += a0; v1 += a1; v2 += a2; v3 += a3;
             }
-            for (; b < sd.blk_end; b += G) v0 += partials[(size_t)b * kSums + k];
+            // the tail keeps the accumulator rotation of the unrolled loop, so trailing all-zero records (slots of a stream
+            // are sized for the largest scan) leave every sum bit-identical to the exact-size layout
+            if (b < sd.blk_end) { v0 += partials[(size_t)b * kSums + k]; b += G; }
+            if (b < sd.blk_end) { v1 += partials[(size_t)b * kSums + k]; b += G; }
+            if (b < sd.blk_end) { v2 += partials[(size_t)b * kSums + k]; b += G; }
             v = (v0 + v1) + (v2 + v3);
         }
         part[g][k] = v;
@@ -1583,7 +1640,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* __restr
         S.fallback_blocks += fb;
         S.tested_total += tot[31] - fb * 1099511627776.0;
     }
-    elm_iter_trace* tr = (trace && iter <= ELM_MAX_ITER_TRACE) ? &trace[(size_t)s * ELM_MAX_ITER_TRACE + (iter - 1)] : nullptr;
+    elm_iter_trace* tr = (trace && iter <= ELM_MAX_ITER_TRACE) ? &trace[(size_t)S.reg * ELM_MAX_ITER_TRACE + (iter - 1)] : nullptr;
 
     // corres_ratio = (float)i_source_corr_num / i_source_total_num (reg.cpp:351): float division, compared as double
     const float ratio_f = (float)n_corr / (float)sd.n_total;
@@ -1810,6 +1867,10 @@ int debug_phase_cycles(unsigned long long* out16, int reset) {
 #endif
 }
 
+void launch_stream_refill(hipStream_t s, ScanDesc* scans, ScanState* st, int slots, const QueueItem* queue, const double* qT0,
+                          ScanState* out_state, StreamCtrl* ctrl, int first) {
+    hipLaunchKernelGGL(k_stream_refill, dim3(1), dim3(256), 0, s, scans, st, slots, queue, qT0, out_state, ctrl, first);
+}
 void launch_init_state(hipStream_t s, ScanState* st, const double* T0, int batch, int map_empty, int* active) {
     hipLaunchKernelGGL(k_init_state, dim3((batch + 63) / 64), dim3(64), 0, s, st, T0, batch, map_empty, active);
 }

@@ -285,6 +285,10 @@ def _result_dict(r, trace=None):
     return d
 
 
+def results_from_raw(res):
+    return [_result_dict(r) for r in res]
+
+
 class Registration:
     """reg.hpp:101-230."""
 
@@ -320,6 +324,21 @@ class Registration:
         """Many resident scans against one map, iterated together. Returns a list of result dicts."""
         self.EnqueueBatch(scans, voxel_map, initial_guesses, m_config, trace)
         return self.FinishBatch()
+
+    def RunRegisterStream(self, scans, voxel_map, initial_guesses, slots=32, m_config=None, trace=False, raw=False):
+        """Continuous batching (elm_register_stream): len(scans) registrations through `slots` device slots that are
+        refilled on the device as registrations finish.  Same results as RunRegisterBatch, in input order."""
+        cfg = m_config if m_config is not None else self.config_
+        B = len(scans)
+        arr = (C.c_void_p * B)(*[s._h for s in scans])
+        T0 = np.concatenate([_colmajor16(T) for T in initial_guesses])
+        res = (RegResult * B)()
+        tr = (IterTrace * (_lib.MAX_ITER_TRACE * B))() if trace else None
+        check(_lib.lib().elm_register_stream(self.ctx._h, voxel_map._handle(), arr, B, _dp(T0), C.byref(cfg), int(slots), res, tr),
+              self.ctx._h, "elm_register_stream")
+        if raw:  # the elm_reg_result array as the library filled it; results_from_raw() turns it into dicts later
+            return res
+        return [_result_dict(res[b], tr[b * _lib.MAX_ITER_TRACE:(b + 1) * _lib.MAX_ITER_TRACE] if trace else None) for b in range(B)]
 
     def EnqueueBatch(self, scans, voxel_map, initial_guesses, m_config=None, trace=False):
         cfg = m_config if m_config is not None else self.config_

@@ -89,6 +89,40 @@ def make_pose(map_xyz, seed):
     return T
 
 
+_TILE_CACHE = {}
+
+
+def _near_indices(map_xyz, centre, max_range, tile=32.0):
+    """Ascending indices of the map points within max_range of centre -- the same set and order as the brute-force mask
+    over the whole map, but through a cached x/y tile index for large maps (many scans are cut from one 10 M-point world)."""
+    n = map_xyz.shape[0]
+    if n < 2_000_000:
+        d = map_xyz.astype(np.float64) - centre
+        return np.flatnonzero(np.einsum("ij,ij->i", d, d) < max_range * max_range)
+    key = (map_xyz.ctypes.data, n)
+    idx = _TILE_CACHE.get(key)
+    if idx is None:
+        tx = np.floor(map_xyz[:, 0] / tile).astype(np.int64)
+        ty = np.floor(map_xyz[:, 1] / tile).astype(np.int64)
+        x0, y0 = int(tx.min()), int(ty.min())
+        ny = int(ty.max()) - y0 + 1
+        code = (tx - x0) * ny + (ty - y0)
+        order = np.argsort(code, kind="stable")
+        starts = np.searchsorted(code[order], np.arange(int(code.max()) + 2))
+        idx = (order, starts, x0, y0, ny, int(tx.max()) - x0 + 1)
+        _TILE_CACHE.clear()
+        _TILE_CACHE[key] = idx
+    order, starts, x0, y0, ny, nx = idx
+    ax0 = max(int(math.floor((centre[0] - max_range) / tile)) - x0, 0)
+    ax1 = min(int(math.floor((centre[0] + max_range) / tile)) - x0, nx - 1)
+    ay0 = max(int(math.floor((centre[1] - max_range) / tile)) - y0, 0)
+    ay1 = min(int(math.floor((centre[1] + max_range) / tile)) - y0, ny - 1)
+    parts = [order[starts[ix * ny + ay0]:starts[ix * ny + ay1 + 1]] for ix in range(ax0, ax1 + 1)]
+    cand = np.sort(np.concatenate(parts)) if parts else np.zeros(0, np.int64)
+    d = map_xyz[cand].astype(np.float64) - centre
+    return cand[np.einsum("ij,ij->i", d, d) < max_range * max_range]
+
+
 def make_scan(map_xyz, n_scan, seed, T_true=None, max_range=60.0, noise=0.01):
     """Draw n_scan map points within max_range of the sensor, add N(0, noise), express in the sensor frame.
 
@@ -96,8 +130,7 @@ def make_scan(map_xyz, n_scan, seed, T_true=None, max_range=60.0, noise=0.01):
     if T_true is None:
         T_true = make_pose(map_xyz, seed)
     rng = np.random.default_rng(seed + 7919)
-    d = map_xyz.astype(np.float64) - T_true[:3, 3]
-    near = np.flatnonzero(np.einsum("ij,ij->i", d, d) < max_range * max_range)
+    near = _near_indices(map_xyz, T_true[:3, 3], max_range)
     if near.size >= n_scan:
         pick = rng.choice(near, size=n_scan, replace=False)
     else:  # small worlds: sample with replacement, the noise makes the points distinct

@@ -481,3 +481,57 @@ def test_exact_ties_follow_the_reference_visiting_order(oracle, method, kernel_e
             assert det["fallback_blocks"] > 0  # the tied points really went through the exact float64 stage
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("method,slots", [(0, 3), (2, 4), (1, 2), (3, 5), (0, 64)])
+def test_stream_equals_single(ctx, oracle, world100k, method, slots):
+    """Continuous batching (elm_register_stream): more registrations than slots, ragged sizes (incl. an empty scan), slots
+    refilled on the device as registrations finish -- every result bit-identical to the one-at-a-time call, traces too."""
+    from elimaloc_amd.registration import Registration, RegistrationConfig, IcpMethod, Scan
+    m = IcpMethod(method)
+    vm, om = _maps(ctx, oracle, world100k, m)
+    reg = Registration(RegistrationConfig(icp_method=m), ctx)
+    sizes = [6000, 1000, 0, 257, 5000, 3000, 256, 4097, 1, 2500, 7000]
+    scans, T0s, singles = [], [], []
+    for i, n in enumerate(sizes):
+        sc, Tt = synth.make_scan(world100k, max(n, 1), seed=500 + i)
+        sc = sc[:n]
+        T0 = synth.perturb(Tt, seed=600 + i, max_trans=0.05 + 0.04 * i, max_rot_deg=0.2 * (i + 1))
+        scans.append(Scan(ctx, sc)); T0s.append(T0)
+        singles.append(reg.RunRegister(sc, vm, T0, trace=True)[-1])
+    assert len({r["iterations"] for r in singles}) > 2  # registrations finish at different iterations
+    for rep in range(2):  # second call: the iteration count of the first is the prediction
+        out = reg.RunRegisterStream(scans, vm, T0s, slots=slots, trace=True)
+        for k, (b, s) in enumerate(zip(out, singles)):
+            assert (b["iterations"], b["is_success"], b["gate"]) == (s["iterations"], s["is_success"], s["gate"]), k
+            assert np.array_equal(b["T"], s["T"]) and np.array_equal(b["local_cov"], s["local_cov"]), k
+            assert np.array_equal(b["d_fitness"], s["d_fitness"], equal_nan=True) and b["n_corr_last"] == s["n_corr_last"]
+            for ib, is_ in zip(b["iters"], s["iters"]):
+                assert np.array_equal(ib["JTJ"], is_["JTJ"]) and np.array_equal(ib["T"], is_["T"]) and ib["n_corr"] == is_["n_corr"]
+    ref = oracle.register(om, np.zeros((0, 3), np.float32), T0s[2], oracle.default_config(method))
+    assert out[2]["is_success"] == ref["is_success"] and out[2]["iterations"] == ref["iterations"]
+
+
+def test_stream_through_exchange_hook(ctx, oracle, world100k):
+    """The multi-GPU control flow of a stream (reduce-only solve -> exchange of slots*32 sums -> solve-only, refill on the
+    device) with an identity exchange: same results as without, and one exchange per iteration."""
+    from elimaloc_amd.registration import Registration, RegistrationConfig, IcpMethod, Scan
+    vm, om = _maps(ctx, oracle, world100k, IcpMethod.VGICP)
+    reg = Registration(RegistrationConfig(icp_method=IcpMethod.VGICP), ctx)
+    scans, T0s = [], []
+    for i in range(7):
+        sc, Tt = synth.make_scan(world100k, 3000 + 500 * i, seed=700 + i)
+        scans.append(Scan(ctx, sc)); T0s.append(synth.perturb(Tt, seed=800 + i, max_trans=0.05 + 0.05 * i))
+    plain = reg.RunRegisterStream(scans, vm, T0s, slots=3)
+    calls = []
+    ctx.set_allreduce_hook(lambda p, n, s: (calls.append(n), 0)[1])
+    try:
+        hooked = reg.RunRegisterStream(scans, vm, T0s, slots=3)
+    finally:
+        ctx.set_allreduce_hook(None)
+    assert calls and all(n == 3 * 32 for n in calls)
+    for a, b in zip(plain, hooked):
+        assert a["iterations"] == b["iterations"] and np.array_equal(a["T"], b["T"])
+    ref = oracle.register(om, np.asarray(synth.make_scan(world100k, 3000, seed=700)[0]), T0s[0], oracle.default_config(2))
+    dt, dr = synth.pose_error(ref["T"], plain[0]["T"])
+    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD

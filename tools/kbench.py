@@ -15,6 +15,7 @@ ap.add_argument("--scan-points", type=int, default=131072)
 ap.add_argument("--map-points", type=int, default=10_000_000)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--term", type=float, default=0.02)
+ap.add_argument("--slots", type=int, default=0, help=">0: continuous batching (elm_register_stream) with that many slots")
 a = ap.parse_args()
 ctx = Context(0)
 world = synth.make_world(a.map_points, seed=1001)
@@ -27,10 +28,11 @@ for i in range(a.batch):
     sc, Tt = synth.make_scan(world, a.scan_points, seed=2002 + i)
     scans.append(Scan(ctx, sc)); T0s.append(synth.perturb(Tt, seed=3003 + i))
 reg = Registration(RegistrationConfig(icp_method=m, max_iteration=a.iters, icp_termination_threshold_m=a.term), ctx)
-for _ in range(2): out = reg.RunRegisterBatch(scans, vm, T0s)
+run = (lambda: reg.RunRegisterStream(scans, vm, T0s, slots=a.slots)) if a.slots > 0 else (lambda: reg.RunRegisterBatch(scans, vm, T0s))
+for _ in range(2): out = run()
 ctx.set_profiling(True); ctx.get_profile(reset=True)
 t0 = time.perf_counter()
-for _ in range(a.steps): out = reg.RunRegisterBatch(scans, vm, T0s)
+for _ in range(a.steps): out = run()
 el = time.perf_counter() - t0
 p = ctx.get_profile()
 pt_it = sum(r["point_iterations"] for r in out)
