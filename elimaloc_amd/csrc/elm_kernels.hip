@@ -1436,7 +1436,7 @@ __global__ __launch_bounds__(64) void k_init_state(ScanState* st, const double* 
 // and takes the next pending registration (descriptor + initial guess), so every accumulate launch stays full until the
 // queue runs dry.  Slots are served in slot order by one thread: the assignment is deterministic (identical on every rank).
 constexpr int kMaxSlots = 1024;
-__global__ __launch_bounds__(256) void k_stream_refill(ScanDesc* scans, ScanState* st, int slots, const QueueItem* __restrict__ queue,
+__global__ __launch_bounds__(1024) void k_stream_refill(ScanDesc* scans, ScanState* st, int slots, const QueueItem* __restrict__ queue,
                                                        const double* __restrict__ qT0, ScanState* out_state, StreamCtrl* ctrl, int first) {
     __shared__ int s_assign[kMaxSlots]; // registration to start in the slot, -1 = slot keeps going, -2 = slot goes idle
     __shared__ int s_save[kMaxSlots];   // registration whose final state is copied out, -1 = none
@@ -1869,7 +1869,7 @@ int debug_phase_cycles(unsigned long long* out16, int reset) {
 
 void launch_stream_refill(hipStream_t s, ScanDesc* scans, ScanState* st, int slots, const QueueItem* queue, const double* qT0,
                           ScanState* out_state, StreamCtrl* ctrl, int first) {
-    hipLaunchKernelGGL(k_stream_refill, dim3(1), dim3(256), 0, s, scans, st, slots, queue, qT0, out_state, ctrl, first);
+    hipLaunchKernelGGL(k_stream_refill, dim3(1), dim3(1024), 0, s, scans, st, slots, queue, qT0, out_state, ctrl, first);
 }
 void launch_init_state(hipStream_t s, ScanState* st, const double* T0, int batch, int map_empty, int* active) {
     hipLaunchKernelGGL(k_init_state, dim3((batch + 63) / 64), dim3(64), 0, s, st, T0, batch, map_empty, active);
