@@ -236,6 +236,11 @@ def main():
             "unit": "GB/s",
             "frac": achieved_gbs / HBM_PEAK_GBS,
             "traffic": traffic,
+            # the index lets the kernel touch a fraction of the bytes the reference's walk reads, so `frac` (algorithmic bytes of
+            # the REFERENCE algorithm) exceeds 1; the measured HBM stream is the physical utilisation
+            "measured_hbm_gbs": (traffic / (acc_ms_avg * 1e-3) / 1e9) if (traffic and acc_ms_avg > 0) else None,
+            "measured_hbm_frac": (traffic / (acc_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and acc_ms_avg > 0) else None,
+            "tested_candidates_per_point": float(sum(r["n_tested_total"] for r in out)) / max(pt_iters, 1),
             "bytes_per_unit": bytes_unit,
             "units_per_launch": units_per_launch,
             "avg_launch_ms": acc_ms_avg,
