@@ -535,3 +535,34 @@ def test_stream_through_exchange_hook(ctx, oracle, world100k):
     ref = oracle.register(om, np.asarray(synth.make_scan(world100k, 3000, seed=700)[0]), T0s[0], oracle.default_config(2))
     dt, dr = synth.pose_error(ref["T"], plain[0]["T"])
     assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_randomized_configs_default_kernels(ctx, oracle, seed):
+    """Differential sweep of the default kernels against the oracle: random voxel size (also not a power of two, also
+    larger than the lattice pitch allows for 30 points), bucket cap, search radius, map offset (negative / far-from-origin
+    coordinates), scan partly outside the map, initial errors from tiny to half a voxel (so the share of points that need
+    the exact wave-cooperative stage varies from ~0 to most of them)."""
+    from elimaloc_amd.registration import Registration, RegistrationConfig, IcpMethod
+    rng = np.random.default_rng(9000 + seed)
+    method = IcpMethod(int(rng.integers(0, 3)))
+    voxel = float(rng.choice([0.4, 0.5, 0.75, 1.0, 1.3, 2.0]))
+    max_pts = int(rng.choice([6, 12, 30, 60]))
+    th = float(rng.choice([0.8, 2.0, 5.0]))
+    offset = np.array([rng.choice([0.0, -37.25, 1234.5]), rng.choice([0.0, 15.125, -777.0]), rng.choice([0.0, -3.0])])
+    base = synth.make_world(60000, seed=1100 + seed)
+    world = (base.astype(np.float64) + offset).astype(np.float32)
+    vm, om = _maps(ctx, oracle, world, method, voxel_size=voxel, max_pts=max_pts, cov_dist=float(rng.choice([0.3, 0.4, 0.7])))
+    scan, T_true = synth.make_scan(base, 4000, seed=1200 + seed, max_range=float(rng.choice([12.0, 30.0])))
+    if seed % 3 == 0:  # push part of the scan outside the mapped area: points without any neighbour voxel
+        T_true = T_true.copy()
+        T_true[0, 3] = float(base[:, 0].max()) - 4.0
+        scan, _ = synth.make_scan(base, 4000, seed=1200 + seed, T_true=T_true, max_range=40.0)
+        scan = np.concatenate([scan, scan[:500] + np.float32([30.0, 0.0, 0.0])]).astype(np.float32)  # and some far beyond it
+    T_true = T_true.copy()
+    T_true[:3, 3] += offset
+    T0 = synth.perturb(T_true, seed=1300 + seed, max_trans=float(rng.choice([0.01, 0.1, 0.3, 0.5])), max_rot_deg=float(rng.choice([0.1, 1.0, 2.0])))
+    cfg = RegistrationConfig(icp_method=method, max_search_dist=th, max_iteration=8)
+    *_, det = Registration(cfg, ctx).RunRegister(scan, vm, T0, trace=True)
+    ref = oracle.register(om, scan, T0, oracle.default_config(int(method), max_search_dist=th, max_iteration=8))
+    _compare_run(det, ref)
