@@ -690,7 +690,7 @@ extern "C" int elm_map_build_neighbourhoods(elm_map* m) {
         }
         NBR_CHK(hipMemcpy(d_off, offs.data(), (size_t)n_q * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
-    NBR_CHK(hipMalloc((void**)&m->d_nbr_pts, std::max<size_t>((size_t)total * sizeof(Pt3), 256)));
+    NBR_CHK(hipMalloc((void**)&m->d_nbr_pts, std::max<size_t>((size_t)total * sizeof(Pt3), 256) + 64)); // + pad: blocks of 4 are read whole
     NBR_CHK(hipMalloc((void**)&m->d_nbr_idx, std::max<size_t>((size_t)total * sizeof(uint32_t), 256)));
     if (n_q) {
         (void)hipGetLastError();

@@ -965,6 +965,10 @@ constexpr int kCellCols = kCellAxis * kCellAxis;          // 36 (ix, iy) columns
 constexpr int kCellStride = kCellCols * 8;                // uint16 entries per query voxel: one 16-byte record per column =
                                                           // offsets of its cells iz = 0..5, the column end, one pad -> 576 B
 
+struct __attribute__((aligned(4))) Vec4u { // 16 bytes at dword alignment (global loads of 128 bits only need that)
+    unsigned x, y, z, w;
+};
+
 // entry i (0..7) of a column record
 __device__ __forceinline__ int col_entry(const uint4 r, int i) {
     const unsigned w = (i & 4) ? ((i & 2) ? r.w : r.z) : ((i & 2) ? r.y : r.x);
@@ -1084,13 +1088,25 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_cell(const DevMap m, cons
                     pp[w] = (t < nblk) ? b_ + 4 * t : 0;
                     pe[w] = (t < nblk) ? e_ : 0; // empty block when past the end
                 }
-                Pt3 q[8];
+                // a block = 4 consecutive 12-byte candidates = 48 contiguous bytes: three 16-byte loads (dword aligned) with one
+                // address computation.  Slots past the segment end hold the next cell's candidates (the arrays are padded
+                // at the very end) and are masked below.
+                float qf[2][12];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) q[u] = lp[max(min(pp[u >> 2] + (u & 3), pe[u >> 2] - 1), 0)];
+                for (int w = 0; w < 2; ++w) {
+                    const Vec4u* bp = reinterpret_cast<const Vec4u*>(lp + pp[w]);
+#pragma unroll
+                    for (int v = 0; v < 3; ++v) {
+                        const Vec4u r = bp[v];
+                        qf[w][4 * v] = __uint_as_float(r.x); qf[w][4 * v + 1] = __uint_as_float(r.y);
+                        qf[w][4 * v + 2] = __uint_as_float(r.z); qf[w][4 * v + 3] = __uint_as_float(r.w);
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int id = pp[u >> 2] + (u & 3);
-                    const float ex = (q[u].x - ghx) - glx, ey = (q[u].y - ghy) - gly, ez = (q[u].z - ghz) - glz;
+                    const float qx = qf[u >> 2][3 * (u & 3)], qy = qf[u >> 2][3 * (u & 3) + 1], qz = qf[u >> 2][3 * (u & 3) + 2];
+                    const float ex = (qx - ghx) - glx, ey = (qy - ghy) - gly, ez = (qz - ghz) - glz;
                     const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
                     const float d = (id < pe[u >> 2]) ? dd : __builtin_inff();
                     m2 = fminf(m2, fmaxf(d, m1));
