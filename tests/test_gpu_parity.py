@@ -340,6 +340,22 @@ def test_full_size_properties(ctx, oracle):
     assert ref["iterations"] == a["iterations"]
     dt, dr = synth.pose_error(ref["T"], a["T"])
     assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
+    # what bench.py runs: the same registration inside a continuous-batching stream (40 full-size P2P registrations through
+    # 8 slots) is bit-identical to the one-at-a-time call; the P2P oracle on the sub-map agrees within the tolerance
+    from elimaloc_amd.registration import Scan
+    regp = Registration(RegistrationConfig(icp_method=IcpMethod.P2P), ctx)
+    scans, T0s = [], []
+    for i in range(40):
+        sc, Tt = (scan_n, T_true) if i == 0 else synth.make_scan(world, 131072, seed=2100 + i)
+        scans.append(Scan(ctx, sc)); T0s.append(T0 if i == 0 else synth.perturb(Tt, seed=3100 + i))
+    out = regp.RunRegisterStream(scans, vm, T0s, slots=8)
+    single0 = regp.RunRegister(scan_n, vm, T0)
+    single7 = regp.RunRegisterBatch([scans[7]], vm, [T0s[7]])[0]
+    assert np.array_equal(out[0]["T"], single0[0]) and np.array_equal(out[7]["T"], single7["T"]) and out[7]["iterations"] == single7["iterations"]
+    assert all(r["is_success"] for r in out) and len({r["iterations"] for r in out}) > 1
+    refp = oracle.register(om, scan_n, T0, oracle.default_config(0))
+    dt, dr = synth.pose_error(refp["T"], out[0]["T"])
+    assert refp["iterations"] == out[0]["iterations"] and dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
 
 
 def test_rccl_single_rank_allreduce_path(ctx, oracle, world100k):
