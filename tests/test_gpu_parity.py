@@ -582,3 +582,73 @@ def test_randomized_configs_default_kernels(ctx, oracle, seed):
     *_, det = Registration(cfg, ctx).RunRegister(scan, vm, T0, trace=True)
     ref = oracle.register(om, scan, T0, oracle.default_config(int(method), max_search_dist=th, max_iteration=8))
     _compare_run(det, ref)
+
+
+@pytest.mark.parametrize("method,stream", [(0, True), (1, True), (2, False)])
+def test_two_ranks_on_one_gpu(oracle, world100k, method, stream):
+    """The multi-GPU data path with two REAL ranks: two contexts on this GPU (two host threads, two streams), every scan's
+    points sharded in two, the map replicated, and an exchange hook that adds the two ranks' packed sums (what the RCCL
+    all-reduce does between the reduce-only and the solve-only launch of every iteration).  Both ranks must reach
+    bit-identical poses (they solve the same all-reduced sums and refill their slots identically), and the poses must
+    agree with the unsharded run and the oracle."""
+    import ctypes as C
+    import threading
+    from elimaloc_amd.dist import shard_bounds
+    from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, Scan
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    m = IcpMethod(method)
+    full, T0s = [], []
+    for i in range(7):
+        sc, Tt = synth.make_scan(world100k, 3000 + 700 * i, seed=900 + i)
+        full.append(sc)
+        T0s.append(synth.perturb(Tt, seed=950 + i, max_trans=0.05 + 0.05 * i, max_rot_deg=0.3 + 0.2 * i))
+    # unsharded run on one context
+    c = Context(0)
+    vm, om = _maps(c, oracle, world100k, m)
+    single = Registration(RegistrationConfig(icp_method=m), c).RunRegisterBatch([Scan(c, s) for s in full], vm, T0s)
+    c.close()
+    barrier = threading.Barrier(2)
+    bufs, results, errors = [None, None], [None, None], []
+
+    def rank_main(r):
+        try:
+            ctx = Context(0)
+            vmr, _ = _maps(ctx, oracle, world100k, m)
+            scans = []
+            for s in full:
+                lo, hi = shard_bounds(len(s), r, 2)
+                scans.append(Scan(ctx, s[lo:hi], n_total=len(s)))
+
+            def hook(ptr, n, hip_stream):
+                ctx.synchronize()
+                mine = np.empty(n, np.float64)
+                assert hip.hipMemcpy(mine.ctypes.data, ptr, n * 8, 2) == 0  # device -> host
+                bufs[r] = mine
+                barrier.wait(timeout=60)
+                total = bufs[0] + bufs[1]  # the same operand order on both ranks
+                barrier.wait(timeout=60)
+                assert hip.hipMemcpy(ptr, total.ctypes.data, n * 8, 1) == 0  # host -> device
+                return 0
+
+            ctx.set_allreduce_hook(hook)
+            reg = Registration(RegistrationConfig(icp_method=m), ctx)
+            results[r] = reg.RunRegisterStream(scans, vmr, T0s, slots=3) if stream else reg.RunRegisterBatch(scans, vmr, T0s)
+            ctx.set_allreduce_hook(None)
+            ctx.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+            barrier.abort()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    assert not errors, errors
+    for a, b, s, sc, T0 in zip(results[0], results[1], single, full, T0s):
+        assert a["iterations"] == b["iterations"] == s["iterations"] and a["is_success"] == b["is_success"] == s["is_success"]
+        assert np.array_equal(a["T"], b["T"])                       # the ranks agree bit for bit
+        np.testing.assert_allclose(a["T"], s["T"], rtol=0, atol=1e-9)  # sharding only changes the summation tree
+        assert a["point_iterations"] == s["point_iterations"] and a["n_corr_last"] == s["n_corr_last"]
+    ref = oracle.register(om, full[3], T0s[3], oracle.default_config(method))
+    dt, dr = synth.pose_error(ref["T"], results[0][3]["T"])
+    assert ref["iterations"] == results[0][3]["iterations"] and dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
