@@ -254,7 +254,7 @@ struct elm_map {
     uint2* d_ranges = nullptr;
     int32_t* d_keys = nullptr; // [n_vox][3] stored keys (for downloads)
     double *d_vox_mean = nullptr, *d_vox_cov = nullptr;
-    double *d_pt_mean = nullptr, *d_pt_cov = nullptr, *d_pt_nfit = nullptr;
+    double* d_pt_gicp = nullptr; // [n_pts][16]: mean, covariance, fitness normal (DevMap::pt_gicp)
     HashSlot* d_qslots = nullptr;
     Pt3* d_nbr_pts = nullptr;
     uint32_t* d_nbr_idx = nullptr;
@@ -415,7 +415,7 @@ static void build_host(const float* xyz, size_t n, double voxel_size, int max_po
 static void map_free(elm_map* m) {
     if (!m) return;
     (void)hipSetDevice(m->ctx->device);
-    void* ptrs[] = {m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_pt_mean, m->d_pt_cov, m->d_pt_nfit, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off, m->d_vqslots, m->d_vnbr};
+    void* ptrs[] = {m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_pt_gicp, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off, m->d_vqslots, m->d_vnbr};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete m;
@@ -523,21 +523,17 @@ extern "C" int elm_map_cal_point_cov_all(elm_map* m, double d_search_dist) {
     if (!m) return ELM_ERR_INVALID;
     elm_ctx* ctx = m->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (!m->d_pt_mean) {
-        HIPCHK(ctx, hipMalloc((void**)&m->d_pt_mean, std::max<size_t>((size_t)m->dm.n_pts * 3 * sizeof(double), 256)));
-        HIPCHK(ctx, hipMalloc((void**)&m->d_pt_cov, std::max<size_t>((size_t)m->dm.n_pts * 9 * sizeof(double), 256)));
-        HIPCHK(ctx, hipMalloc((void**)&m->d_pt_nfit, std::max<size_t>((size_t)m->dm.n_pts * 3 * sizeof(double), 256)));
-        m->info.device_bytes += (size_t)m->dm.n_pts * 15 * sizeof(double);
+    if (!m->d_pt_gicp) {
+        HIPCHK(ctx, hipMalloc((void**)&m->d_pt_gicp, std::max<size_t>((size_t)m->dm.n_pts * 16 * sizeof(double), 256)));
+        m->info.device_bytes += (size_t)m->dm.n_pts * 16 * sizeof(double);
     }
     if (m->dm.n_pts) {
         (void)hipGetLastError();
-        launch_point_cov(ctx->stream, m->dm, d_search_dist * d_search_dist, m->d_pt_mean, m->d_pt_cov, m->d_pt_nfit);
+        launch_point_cov(ctx->stream, m->dm, d_search_dist * d_search_dist, m->d_pt_gicp);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
-    m->dm.pt_mean = m->d_pt_mean;
-    m->dm.pt_cov = m->d_pt_cov;
-    m->dm.pt_nfit = m->d_pt_nfit;
+    m->dm.pt_gicp = m->d_pt_gicp;
     m->info.has_point_cov = 1;
     return ELM_OK;
 }
@@ -772,12 +768,14 @@ extern "C" int elm_map_download_points(const elm_map* m, double* xyz, double* co
         }
         return ELM_OK;
     }
-    if (cov9 && n) {
-        std::vector<double> tmp(n * 9);
-        HIPCHK(ctx, hipMemcpy(tmp.data(), m->d_pt_cov, n * 9 * sizeof(double), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < n; ++i) rowmajor_to_colmajor3(&tmp[9 * i], &cov9[9 * i]);
+    if ((cov9 || mean3) && n) {
+        std::vector<double> tmp(n * 16);
+        HIPCHK(ctx, hipMemcpy(tmp.data(), m->d_pt_gicp, n * 16 * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) {
+            if (cov9) rowmajor_to_colmajor3(&tmp[16 * i + 3], &cov9[9 * i]);
+            if (mean3) memcpy(&mean3[3 * i], &tmp[16 * i], 3 * sizeof(double));
+        }
     }
-    if (mean3 && n) HIPCHK(ctx, hipMemcpy(mean3, m->d_pt_mean, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
     return ELM_OK;
 }
 

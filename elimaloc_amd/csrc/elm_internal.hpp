@@ -37,9 +37,10 @@ struct DevMap {
     const float4* pts;      // bucket-ordered map points, xyz + pad (w unused), insertion order inside a bucket
     const double* vox_mean; // [n_vox][3]            CalVoxelCov (vhm.hpp:114-148)
     const double* vox_cov;  // [n_vox][9] row-major
-    const double* pt_mean;  // [n_pts][3]            ProcessVoxelBlock (vhm.hpp:195-250)
-    const double* pt_cov;   // [n_pts][9] row-major
-    const double* pt_nfit;  // [n_pts][3] eigenvector of the smallest eigenvalue of pt_cov (reg.cpp:89-91)
+    // GICP payload of a map point, ONE 128-byte record (a matched point costs one cache line instead of three scattered
+    // ones): [0..2] neighbourhood mean, [3..11] covariance row-major (ProcessVoxelBlock vhm.hpp:195-250), [12..14]
+    // eigenvector of its smallest eigenvalue (reg.cpp:89-91, precomputed once), [15] pad
+    const double* pt_gicp;  // [n_pts][16]
     double voxel_size;
     double inv_vs_exact; // 1 / voxel_size when voxel_size is a power of two (g * inv == g / voxel_size bit for bit), else 0
     // neighbourhood lists (optional): for every FLOOR-keyed query voxel that has at least one stored neighbour, the
@@ -146,7 +147,7 @@ size_t nbr_cell_stride();
 void launch_nbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets, Pt3* out,
                      uint32_t* out_idx);
 void launch_voxel_cov(hipStream_t s, const DevMap& m, const uint2* ranges, double* vox_mean, double* vox_cov);
-void launch_point_cov(hipStream_t s, const DevMap& m, double d2max, double* pt_mean, double* pt_cov, double* pt_nfit);
+void launch_point_cov(hipStream_t s, const DevMap& m, double d2max, double* pt_gicp);
 
 struct DeskewDev {
     double time_scan_cur, time_scan_end;

@@ -232,9 +232,9 @@ __device__ __forceinline__ void finish_point_pair(double* acc, const DevMap& m, 
         double C[9], mean[3], nf[3];
         if (bidx >= 0) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) C[k] = m.pt_cov[(size_t)bidx * 9 + k];
+            for (int k = 0; k < 9; ++k) C[k] = m.pt_gicp[(size_t)bidx * 16 + 3 + k];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { mean[k] = m.pt_mean[(size_t)bidx * 3 + k]; nf[k] = m.pt_nfit[(size_t)bidx * 3 + k]; }
+            for (int k = 0; k < 3; ++k) { mean[k] = m.pt_gicp[(size_t)bidx * 16 + k]; nf[k] = m.pt_gicp[(size_t)bidx * 16 + 12 + k]; }
         } else {
             C[0] = 1; C[1] = 0; C[2] = 0; C[3] = 0; C[4] = 1; C[5] = 0; C[6] = 0; C[7] = 0; C[8] = 1;
             mean[0] = mean[1] = mean[2] = 0.0;
@@ -1755,8 +1755,7 @@ __global__ __launch_bounds__(256) void k_voxel_cov(const DevMap m, const uint2* 
     for (int k = 0; k < 9; ++k) vox_cov[(size_t)v * 9 + k] = C[k];
 }
 
-__global__ __launch_bounds__(256) void k_point_cov(const DevMap m, double d2max, double* pt_mean, double* pt_cov,
-                                                   double* pt_nfit) {
+__global__ __launch_bounds__(256) void k_point_cov(const DevMap m, double d2max, double* pt_gicp) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m.n_pts) return;
     const float4 pf = m.pts[i];
@@ -1809,8 +1808,10 @@ __global__ __launch_bounds__(256) void k_point_cov(const DevMap m, double d2max,
         for (int k = 0; k < 9; ++k) c[k] /= (double)(n - 1);
         plane_regularize(c, C, nf);
     }
-    for (int k = 0; k < 3; ++k) { pt_mean[(size_t)i * 3 + k] = mean[k]; pt_nfit[(size_t)i * 3 + k] = nf[k]; }
-    for (int k = 0; k < 9; ++k) pt_cov[(size_t)i * 9 + k] = C[k];
+    double* rec = pt_gicp + (size_t)i * 16;
+    for (int k = 0; k < 3; ++k) { rec[k] = mean[k]; rec[12 + k] = nf[k]; }
+    for (int k = 0; k < 9; ++k) rec[3 + k] = C[k];
+    rec[15] = 0.0;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1959,8 +1960,8 @@ void launch_voxel_cov(hipStream_t s, const DevMap& m, const uint2* ranges, doubl
     hipLaunchKernelGGL(k_voxel_cov, dim3((m.n_vox + 255) / 256), dim3(256), 0, s, m, ranges, vox_mean, vox_cov);
 }
 
-void launch_point_cov(hipStream_t s, const DevMap& m, double d2max, double* pt_mean, double* pt_cov, double* pt_nfit) {
-    hipLaunchKernelGGL(k_point_cov, dim3((m.n_pts + 255) / 256), dim3(256), 0, s, m, d2max, pt_mean, pt_cov, pt_nfit);
+void launch_point_cov(hipStream_t s, const DevMap& m, double d2max, double* pt_gicp) {
+    hipLaunchKernelGGL(k_point_cov, dim3((m.n_pts + 255) / 256), dim3(256), 0, s, m, d2max, pt_gicp);
 }
 
 void launch_deskew(hipStream_t s, const float* xyz, const float* rel_time, uint32_t n, const DeskewDev& d, float* xyz_out) {
