@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--scan-points", type=int, default=131072)
     ap.add_argument("--map-points", type=int, default=10_000_000)
     ap.add_argument("--method", type=int, default=0, help="0 P2P (configs[1]), 1 GICP, 2 VGICP, 3 AVGICP")
-    ap.add_argument("--cpu-sample", type=int, default=2, help="registrations timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=16, help="registrations timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency runs (profiling passes)")
     args = ap.parse_args()
