@@ -129,7 +129,7 @@ EXPORTS = [
     "elm_map_cal_point_cov_all", "elm_map_build_neighbourhoods", "elm_map_get_info", "elm_map_empty", "elm_map_download_points",
     "elm_map_download_voxels", "elm_map_find_ground_height", "elm_scan_upload", "elm_scan_destroy",
     "elm_scan_size", "elm_register", "elm_register_batch", "elm_register_stream", "elm_register_batch_enqueue",
-    "elm_register_batch_finish", "elm_deskew", "elm_deskew_prepare", "elm_comm_get_unique_id", "elm_comm_init",
+    "elm_register_batch_finish", "elm_deskew", "elm_deskew_downsample", "elm_deskew_prepare", "elm_comm_get_unique_id", "elm_comm_init",
     "elm_comm_destroy", "elm_comm_set_hook", "elm_filter_points_by_distance", "elm_voxel_downsample",
     "elm_get_interpolated_pose", "elm_shape_odom_covariance",
     "elm_ekf_config_default", "elm_ekf_create", "elm_ekf_destroy", "elm_ekf_predict_imu", "elm_ekf_update_pose",

@@ -73,7 +73,7 @@ struct elm_ctx {
     hipStream_t stream = nullptr;
     std::string last_error;
     // scratch (grow-only; no allocation on the per-scan path after warm-up)
-    DevBuf d_scans, d_state, d_partials, d_sums, d_T0, d_trace, d_stage_pts, d_active, d_queue;
+    DevBuf d_scans, d_state, d_partials, d_sums, d_T0, d_trace, d_stage_pts, d_active, d_queue, d_ds;
     int stream_hint_count = 0, stream_hint_slots = 0, stream_hint_iters = 0; // iterations the last elm_register_stream call of that shape needed
     int* h_active = nullptr; // pinned: number of scans still iterating, read back at the early-stop checks
     int iter_hint = 0;       // iterations the previous batch needed (0 = unknown): first early-stop check happens there
@@ -196,7 +196,7 @@ extern "C" void elm_ctx_destroy(elm_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm && g_rccl.comm_destroy) g_rccl.comm_destroy(ctx->comm);
-    DevBuf* bufs[] = {&ctx->d_scans, &ctx->d_state, &ctx->d_partials, &ctx->d_sums, &ctx->d_T0, &ctx->d_trace, &ctx->d_stage_pts, &ctx->d_active, &ctx->d_queue};
+    DevBuf* bufs[] = {&ctx->d_scans, &ctx->d_state, &ctx->d_partials, &ctx->d_sums, &ctx->d_T0, &ctx->d_trace, &ctx->d_stage_pts, &ctx->d_active, &ctx->d_queue, &ctx->d_ds};
     if (ctx->h_active) (void)hipHostFree(ctx->h_active);
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -1306,17 +1306,8 @@ extern "C" int elm_register(elm_ctx* ctx, const elm_map* map, const float* scan_
 // ------------------------------------------------------------------------------------------------------
 // deskew
 // ------------------------------------------------------------------------------------------------------
-extern "C" int elm_deskew(elm_ctx* ctx, const float* xyz, const float* rel_time, size_t n, const elm_deskew_tables* tab,
-                          float* xyz_out, int* ok) {
-    if (!ctx || !tab || !ok || (n && (!xyz || !rel_time || !xyz_out)) || n > 0x7FFFFFFFull) return ELM_ERR_INVALID;
-    *ok = 0;
-    if (!tab->b_is_imu_available || !tab->b_is_odom_available) return ELM_OK; // pcm.cpp:494-496
-    *ok = 1;
-    if (!tab->b_run_deskew) { // pcm.cpp:513-525: plain copy
-        memcpy(xyz_out, xyz, n * 3 * sizeof(float));
-        return ELM_OK;
-    }
-    if (n == 0) return ELM_OK;
+// uploads the raw points + tables and runs the deskew kernel; the undistorted points (3 floats each) stay on the device
+static int deskew_enqueue(elm_ctx* ctx, const float* xyz, const float* rel_time, size_t n, const elm_deskew_tables* tab, float** d_out_p) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t k = (size_t)tab->i_imu_pointer_cur + 1;
     const size_t in_bytes = n * 4 * sizeof(float);
@@ -1329,13 +1320,17 @@ extern "C" int elm_deskew(elm_ctx* ctx, const float* xyz, const float* rel_time,
     float* d_xyz = (float*)(base + ((tab_bytes + 63) / 64) * 64);
     float* d_time = d_xyz + 3 * n;
     float* d_out = d_time + n;
+    HIPCHK(ctx, hipMemcpyAsync(d_xyz, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (!tab->b_run_deskew) { // pcm.cpp:513-525: plain copy
+        *d_out_p = d_xyz;
+        return ELM_OK;
+    }
     double* ht = (double*)ctx->h_stage;
     memcpy(ht, tab->vec_d_imu_time, k * sizeof(double));
     memcpy(ht + k, tab->vec_d_imu_rot_x, k * sizeof(double));
     memcpy(ht + 2 * k, tab->vec_d_imu_rot_y, k * sizeof(double));
     memcpy(ht + 3 * k, tab->vec_d_imu_rot_z, k * sizeof(double));
     HIPCHK(ctx, hipMemcpyAsync(d_tab, ht, tab_bytes, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(d_xyz, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(d_time, rel_time, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     DeskewDev d;
     d.time_scan_cur = tab->d_time_scan_cur;
@@ -1348,8 +1343,95 @@ extern "C" int elm_deskew(elm_ctx* ctx, const float* xyz, const float* rel_time,
     (void)hipGetLastError();
     launch_deskew(ctx->stream, d_xyz, d_time, (uint32_t)n, d, d_out);
     HIPCHK(ctx, hipGetLastError());
+    *d_out_p = d_out;
+    return ELM_OK;
+}
+
+extern "C" int elm_deskew(elm_ctx* ctx, const float* xyz, const float* rel_time, size_t n, const elm_deskew_tables* tab,
+                          float* xyz_out, int* ok) {
+    if (!ctx || !tab || !ok || (n && (!xyz || !rel_time || !xyz_out)) || n > 0x7FFFFFFFull) return ELM_ERR_INVALID;
+    *ok = 0;
+    if (!tab->b_is_imu_available || !tab->b_is_odom_available) return ELM_OK; // pcm.cpp:494-496
+    *ok = 1;
+    if (!tab->b_run_deskew) { // pcm.cpp:513-525: plain copy
+        memcpy(xyz_out, xyz, n * 3 * sizeof(float));
+        return ELM_OK;
+    }
+    if (n == 0) return ELM_OK;
+    float* d_out = nullptr;
+    int rc = deskew_enqueue(ctx, xyz, rel_time, n, tab, &d_out);
+    if (rc != ELM_OK) return rc;
     HIPCHK(ctx, hipMemcpyAsync(xyz_out, d_out, n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ELM_OK;
+}
+
+// DeskewPointCloud's per-point loop + VoxelHashMap::VoxelDownsample fused on the device: the undistorted cloud never leaves
+// HBM, what comes out is a resident scan (the kept points in input order) ready for elm_register_batch.
+extern "C" int elm_deskew_downsample(elm_ctx* ctx, const float* xyz, const float* rel_time, size_t n, const elm_deskew_tables* tab,
+                                     double voxel_size, elm_scan** scan_out, int* ok) {
+    if (!ctx || !tab || !ok || !scan_out || !(voxel_size > 0.0) || (n && (!xyz || !rel_time)) || n > 0x7FFFFFFFull) return ELM_ERR_INVALID;
+    *ok = 0;
+    *scan_out = nullptr;
+    if (!tab->b_is_imu_available || !tab->b_is_odom_available) return ELM_OK; // pcm.cpp:494-496
+    *ok = 1;
+    int rc;
+    float* d_und = nullptr;
+    if (n) {
+        if ((rc = deskew_enqueue(ctx, xyz, rel_time, n, tab, &d_und)) != ELM_OK) return rc;
+    }
+    // table of 2^cap_log2 >= 2 n slots: keys (8 B) + first index (4 B); per point: slot (4 B); block counts; total + overflow
+    unsigned cap_log2 = 6;
+    while (((size_t)1 << cap_log2) < 2 * std::max<size_t>(n, 1)) ++cap_log2;
+    const size_t cap = (size_t)1 << cap_log2, nb = (n + 1023) / 1024;
+    const size_t bytes = cap * 12 + std::max<size_t>(n, 1) * 4 + (nb + 1) * 4 + 64;
+    if ((rc = dev_reserve(ctx, ctx->d_ds, bytes)) != ELM_OK) return rc;
+    char* base = (char*)ctx->d_ds.p;
+    unsigned long long* d_table = (unsigned long long*)base;
+    unsigned* d_first = (unsigned*)(base + cap * 8);
+    unsigned* d_slot = d_first + cap;
+    unsigned* d_bcount = d_slot + std::max<size_t>(n, 1);
+    unsigned* d_total = d_bcount + nb + 1; // [0] kept points, [1] overflow flag
+    elm_scan* sc = new elm_scan();
+    sc->ctx = ctx;
+    const size_t need = std::max<size_t>(n * sizeof(float4), 256);
+    hipError_t e = hipSuccess;
+    {
+        int best = -1;
+        for (int i = 0; i < (int)ctx->scan_pool.size(); ++i)
+            if (ctx->scan_pool[i].second >= need && (best < 0 || ctx->scan_pool[i].second < ctx->scan_pool[best].second)) best = i;
+        if (best >= 0) {
+            sc->d_pts = (float4*)ctx->scan_pool[best].first;
+            sc->cap_bytes = ctx->scan_pool[best].second;
+            ctx->scan_pool.erase(ctx->scan_pool.begin() + best);
+        } else {
+            sc->cap_bytes = (need + 65535) & ~(size_t)65535;
+            e = hipMalloc((void**)&sc->d_pts, sc->cap_bytes);
+        }
+    }
+    if (e != hipSuccess) { delete sc; ctx->last_error = "scan buffer allocation failed"; return ELM_ERR_DEVICE; }
+    unsigned h_total[2] = {0, 0};
+    if (n) {
+        e = hipMemsetAsync(d_table, 0xFF, cap * 12, ctx->stream); // keys and first indices: all ones
+        if (e == hipSuccess) e = hipMemsetAsync(d_total, 0, 8, ctx->stream);
+        if (e == hipSuccess) {
+            (void)hipGetLastError();
+            launch_voxel_downsample(ctx->stream, d_und, (uint32_t)n, voxel_size, d_table, d_first, cap_log2, d_slot, d_bcount, d_total,
+                                    (int*)(d_total + 1), sc->d_pts);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(h_total, d_total, 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    if (e != hipSuccess || h_total[1]) {
+        ctx->last_error = e != hipSuccess ? std::string("deskew + downsample: ") + hipGetErrorString(e)
+                                          : "a voxel key does not fit the packed device table (|coordinate / voxel size| >= 2^20)";
+        elm_scan_destroy(sc);
+        return e != hipSuccess ? ELM_ERR_DEVICE : ELM_ERR_UNSUPPORTED;
+    }
+    sc->n = h_total[0];
+    sc->n_total = h_total[0];
+    *scan_out = sc;
     return ELM_OK;
 }
 

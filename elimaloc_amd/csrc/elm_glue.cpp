@@ -2,6 +2,7 @@
 // PcmMatching::CallbackPointCloud either side of RunRegister, kept in the float32 / float64 arithmetic the reference uses.
 // Plain C++ (no device code); exported through the same C ABI.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -349,33 +350,55 @@ extern "C" int elm_pcm_callback_point_cloud(elm_ctx* ctx, const elm_map* map, co
     rc = elm_deskew_prepare(imu4, n_imu, odom14, n_odom, stamp, front, back, node->lidar_scan_time_end, node->run_deskew, tab.data(),
                             tab.data() + 2000, tab.data() + 4000, tab.data() + 6000, 2000, &tabs);
     if (rc != ELM_OK) return rc;
-    std::vector<float> und(3 * nf);
-    int ok = 0;
-    rc = elm_deskew(ctx, fx.data(), ft.data(), nf, &tabs, und.data(), &ok);
-    if (rc != ELM_OK) return rc;
-    if (!ok) return ELM_OK; // "Deskew fail!" (pcm.cpp:238-241)
-    out->time_scan_end = tabs.d_time_scan_end;
+    // Deskew + VoxelDownsample on the device (the undistorted cloud stays in HBM and becomes the registration source);
+    // ELM_CALLBACK=host, or voxel keys that do not pack, take the stage-by-stage host path with identical results.
+    static const bool host_path = [] { const char* e = getenv("ELM_CALLBACK"); return e && strcmp(e, "host") == 0; }();
+    int ok = 0, success = 0;
+    double fit = 0.0, cov6[36], syncd[16], T0[16];
     float sync[16];
-    rc = elm_get_interpolated_pose(odom14, n_odom, tabs.d_time_scan_end, sync, &ok); // :248-251
-    if (rc != ELM_OK) return rc;
-    if (!ok) return ELM_OK;
-    std::vector<int64_t> keep(nf);
-    size_t nk = 0;
-    rc = elm_voxel_downsample(und.data(), nf, node->input_voxel_ds_m, keep.data(), &nk); // :257-258
-    if (rc != ELM_OK) return rc;
-    std::vector<float> src(3 * std::max<size_t>(nk, 1));
-    for (size_t k = 0; k < nk; ++k) {
-        const size_t i = (size_t)keep[k];
-        src[3 * k] = und[3 * i]; src[3 * k + 1] = und[3 * i + 1]; src[3 * k + 2] = und[3 * i + 2];
+    elm_scan* dev_scan = nullptr;
+    rc = host_path ? ELM_ERR_UNSUPPORTED : elm_deskew_downsample(ctx, fx.data(), ft.data(), nf, &tabs, node->input_voxel_ds_m, &dev_scan, &ok);
+    if (rc == ELM_OK) {
+        if (!ok) return ELM_OK; // "Deskew fail!" (pcm.cpp:238-241)
+        out->time_scan_end = tabs.d_time_scan_end;
+        rc = elm_get_interpolated_pose(odom14, n_odom, tabs.d_time_scan_end, sync, &ok); // :248-251
+        if (rc != ELM_OK || !ok) { elm_scan_destroy(dev_scan); return rc; }
+        out->n_source = elm_scan_size(dev_scan);
+        for (int i = 0; i < 16; ++i) syncd[i] = (double)sync[i];
+        mul4_cm(syncd, node->tf_ego_to_lidar, T0); // sync_lidar_pose (pcm.cpp:266)
+        rc = elm_register_batch(ctx, map, &dev_scan, 1, T0, reg, &out->result, nullptr); // :280-282
+        elm_scan_destroy(dev_scan);
+        if (rc != ELM_OK) return rc;
+        memcpy(out->pose_lidar, out->result.T, sizeof(out->pose_lidar));
+        memcpy(cov6, out->result.local_cov, sizeof(cov6));
+        success = out->result.is_success;
+        fit = out->result.fitness_score;
+    } else if (rc == ELM_ERR_UNSUPPORTED) {
+        std::vector<float> und(3 * nf);
+        rc = elm_deskew(ctx, fx.data(), ft.data(), nf, &tabs, und.data(), &ok);
+        if (rc != ELM_OK) return rc;
+        if (!ok) return ELM_OK; // "Deskew fail!" (pcm.cpp:238-241)
+        out->time_scan_end = tabs.d_time_scan_end;
+        rc = elm_get_interpolated_pose(odom14, n_odom, tabs.d_time_scan_end, sync, &ok); // :248-251
+        if (rc != ELM_OK) return rc;
+        if (!ok) return ELM_OK;
+        std::vector<int64_t> keep(nf);
+        size_t nk = 0;
+        rc = elm_voxel_downsample(und.data(), nf, node->input_voxel_ds_m, keep.data(), &nk); // :257-258
+        if (rc != ELM_OK) return rc;
+        std::vector<float> src(3 * std::max<size_t>(nk, 1));
+        for (size_t k = 0; k < nk; ++k) {
+            const size_t i = (size_t)keep[k];
+            src[3 * k] = und[3 * i]; src[3 * k + 1] = und[3 * i + 1]; src[3 * k + 2] = und[3 * i + 2];
+        }
+        out->n_source = nk;
+        for (int i = 0; i < 16; ++i) syncd[i] = (double)sync[i];
+        mul4_cm(syncd, node->tf_ego_to_lidar, T0); // sync_lidar_pose (pcm.cpp:266)
+        rc = elm_register(ctx, map, src.data(), nk, T0, reg, out->pose_lidar, &success, &fit, cov6, &out->result, nullptr); // :280-282
+        if (rc != ELM_OK) return rc;
+    } else {
+        return rc;
     }
-    out->n_source = nk;
-    double syncd[16], T0[16], cov6[36];
-    for (int i = 0; i < 16; ++i) syncd[i] = (double)sync[i];
-    mul4_cm(syncd, node->tf_ego_to_lidar, T0); // sync_lidar_pose (pcm.cpp:266)
-    int success = 0;
-    double fit = 0.0;
-    rc = elm_register(ctx, map, src.data(), nk, T0, reg, out->pose_lidar, &success, &fit, cov6, &out->result, nullptr); // :280-282
-    if (rc != ELM_OK) return rc;
     if (!success) return ELM_OK; // pcm.cpp:289-292
     out->fitness_score = fit;
     double tinv[16];

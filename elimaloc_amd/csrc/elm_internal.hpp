@@ -160,6 +160,10 @@ struct DeskewDev {
     const double* rot_y;
     const double* rot_z;
 };
+// ordered device-side VoxelDownsample: table / first sized 2^cap_log2 (table = all ones, first = all ones before the call),
+// slot n entries, block_count ceil(n / 1024) entries; *total = kept points, *overflow = 1 when a key does not pack
+void launch_voxel_downsample(hipStream_t s, const float* xyz, uint32_t n, double vs, unsigned long long* table, unsigned* first,
+                             unsigned cap_log2, unsigned* slot, unsigned* block_count, unsigned* total, int* overflow, float4* out);
 void launch_deskew(hipStream_t s, const float* xyz, const float* rel_time, uint32_t n, const DeskewDev& d,
                    float* xyz_out);
 

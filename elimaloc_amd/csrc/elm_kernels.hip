@@ -1964,6 +1964,97 @@ void launch_point_cov(hipStream_t s, const DevMap& m, double d2max, double* pt_g
     hipLaunchKernelGGL(k_point_cov, dim3((m.n_pts + 255) / 256), dim3(256), 0, s, m, d2max, pt_gicp);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// VoxelDownsample on the device (vhm.hpp:260-283): the first point (smallest input index) of every floor-keyed voxel, kept
+// in input order.  Used by the node callback so that the deskewed scan never leaves HBM before it is registered.
+//   k_ds_insert: packed 64-bit key per point -> open-addressing table (CAS), atomicMin of the index per voxel
+//   k_ds_count / k_ds_offsets / k_ds_scatter: ordered compaction (block counts -> exclusive scan -> scatter)
+// ------------------------------------------------------------------------------------------------------
+constexpr int kDsBlock = 1024;
+__device__ __forceinline__ bool ds_key(const float* __restrict__ xyz, unsigned i, double vs, unsigned long long& key) {
+    const double qx = (double)xyz[3 * i] / vs, qy = (double)xyz[3 * i + 1] / vs, qz = (double)xyz[3 * i + 2] / vs;
+    const double lim = 1048576.0; // 2^20: three 21-bit fields
+    if (!(qx > -lim && qx < lim && qy > -lim && qy < lim && qz > -lim && qz < lim)) return false;
+    const long long kx = (long long)floor(qx) + 1048576, ky = (long long)floor(qy) + 1048576, kz = (long long)floor(qz) + 1048576;
+    key = ((unsigned long long)kx << 42) | ((unsigned long long)ky << 21) | (unsigned long long)kz;
+    return true;
+}
+__global__ __launch_bounds__(256) void k_ds_insert(const float* __restrict__ xyz, unsigned n, double vs, unsigned long long* table,
+                                                   unsigned* first, unsigned cap_log2, unsigned* __restrict__ slot, int* overflow) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long key;
+    if (!ds_key(xyz, i, vs, key)) { atomicExch(overflow, 1); slot[i] = 0; return; }
+    const unsigned mask = (1u << cap_log2) - 1u;
+    unsigned h = (unsigned)((key * 0x9E3779B97F4A7C15ull) >> (64 - cap_log2));
+    for (;;) {
+        const unsigned long long prev = atomicCAS(&table[h], ~0ull, key);
+        if (prev == ~0ull || prev == key) break;
+        h = (h + 1) & mask;
+    }
+    atomicMin(&first[h], i);
+    slot[i] = h;
+}
+__global__ __launch_bounds__(kDsBlock) void k_ds_count(const unsigned* __restrict__ first, const unsigned* __restrict__ slot, unsigned n,
+                                                       unsigned* __restrict__ block_count) {
+    __shared__ unsigned s_cnt[kDsBlock / 64];
+    const unsigned i = blockIdx.x * kDsBlock + threadIdx.x;
+    const bool keep = i < n && first[slot[i]] == i;
+    const unsigned long long b = __ballot(keep);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = (unsigned)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned t = 0;
+        for (int w = 0; w < kDsBlock / 64; ++w) t += s_cnt[w];
+        block_count[blockIdx.x] = t;
+    }
+}
+__global__ __launch_bounds__(1024) void k_ds_offsets(unsigned* block_count, unsigned n_blocks, unsigned* total) { // in-place exclusive scan
+    __shared__ unsigned s[1024];
+    unsigned carry = 0;
+    for (unsigned base = 0; base < n_blocks; base += 1024) {
+        const unsigned j = base + threadIdx.x;
+        const unsigned v = j < n_blocks ? block_count[j] : 0u;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (unsigned off = 1; off < 1024; off <<= 1) {
+            const unsigned t = threadIdx.x >= off ? s[threadIdx.x - off] : 0u;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (j < n_blocks) block_count[j] = carry + s[threadIdx.x] - v;
+        const unsigned chunk_total = s[1023];
+        __syncthreads();
+        carry += chunk_total;
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+__global__ __launch_bounds__(kDsBlock) void k_ds_scatter(const float* __restrict__ xyz, const unsigned* __restrict__ first,
+                                                         const unsigned* __restrict__ slot, unsigned n,
+                                                         const unsigned* __restrict__ block_offset, float4* __restrict__ out) {
+    __shared__ unsigned s_cnt[kDsBlock / 64];
+    const unsigned i = blockIdx.x * kDsBlock + threadIdx.x;
+    const bool keep = i < n && first[slot[i]] == i;
+    const unsigned long long b = __ballot(keep);
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[wave] = (unsigned)__popcll(b);
+    __syncthreads();
+    unsigned pos = block_offset[blockIdx.x];
+    for (unsigned w = 0; w < wave; ++w) pos += s_cnt[w];
+    pos += (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+    if (keep) out[pos] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.f);
+}
+
+void launch_voxel_downsample(hipStream_t s, const float* xyz, uint32_t n, double vs, unsigned long long* table, unsigned* first,
+                             unsigned cap_log2, unsigned* slot, unsigned* block_count, unsigned* total, int* overflow, float4* out) {
+    const unsigned nb = (n + kDsBlock - 1) / kDsBlock;
+    hipLaunchKernelGGL(k_ds_insert, dim3((n + 255) / 256), dim3(256), 0, s, xyz, n, vs, table, first, cap_log2, slot, overflow);
+    hipLaunchKernelGGL(k_ds_count, dim3(nb), dim3(kDsBlock), 0, s, first, slot, n, block_count);
+    hipLaunchKernelGGL(k_ds_offsets, dim3(1), dim3(1024), 0, s, block_count, nb, total);
+    hipLaunchKernelGGL(k_ds_scatter, dim3(nb), dim3(kDsBlock), 0, s, xyz, first, slot, n, block_count, out);
+}
+
 void launch_deskew(hipStream_t s, const float* xyz, const float* rel_time, uint32_t n, const DeskewDev& d, float* xyz_out) {
     hipLaunchKernelGGL(k_deskew, dim3((n + 255) / 256), dim3(256), 0, s, xyz, rel_time, n, d, xyz_out);
 }

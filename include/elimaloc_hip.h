@@ -219,6 +219,12 @@ typedef struct elm_deskew_tables {
  * Returns ELM_OK and *ok = 0 when IMU or odom tables are unavailable (pcm.cpp:494-496, nothing written). */
 int elm_deskew(elm_ctx* ctx, const float* xyz, const float* rel_time, size_t n, const elm_deskew_tables* tab,
                float* xyz_out, int* ok);
+/* The same per-point loop followed by VoxelHashMap::VoxelDownsample (vhm.hpp:260-283: the first point of every floor-keyed
+ * voxel of edge voxel_size) fused on the device: the undistorted cloud never leaves HBM and comes back as a resident scan
+ * (kept points in input order) for elm_register_batch; release it with elm_scan_destroy.  *ok as elm_deskew (*scan_out is
+ * NULL when 0).  ELM_ERR_UNSUPPORTED when |coordinate / voxel_size| >= 2^20 (use elm_deskew + elm_voxel_downsample). */
+int elm_deskew_downsample(elm_ctx* ctx, const float* xyz, const float* rel_time, size_t n, const elm_deskew_tables* tab,
+                          double voxel_size, elm_scan** scan_out, int* ok);
 /* Host-side table preparation, same arithmetic as the reference (doubles for the IMU table, float32
  * PCL/Eigen transforms for the odometry increment).
  * imu: n_imu rows (t, wx, wy, wz) already rotated into the ego frame (pcm.cpp:328).

@@ -129,8 +129,10 @@ def test_native_callback_equals_staged_python_callback(oracle):
     world = synth.make_world(100000, seed=1001)
     ctx = Context(0)
     tf = np.eye(4); tf[:3, :3] = synth.rot_zyx(0.0, 0.01, 0.02); tf[:3, 3] = [1.2, 0.0, 1.6]
-    for method in (IcpMethod.VGICP, IcpMethod.GICP):
-        cfg = PcmMatchingConfig(tf_ego_to_lidar=tf, registration=RegistrationConfig(icp_method=method))
+    # 1.5 m: the shipped downsample; 0.05 m: nearly every point kept; 2e-5 m: voxel keys beyond the device table's packing
+    # range -> the callback falls back to the host stages
+    for method, ds in ((IcpMethod.VGICP, 1.5), (IcpMethod.GICP, 1.5), (IcpMethod.P2P, 0.05), (IcpMethod.VGICP, 2e-5)):
+        cfg = PcmMatchingConfig(tf_ego_to_lidar=tf, d_input_voxel_ds_m=ds, registration=RegistrationConfig(icp_method=method))
         node = PcmMatching(cfg, ctx)
         node.Init(world)
         st = synth.make_deskew_stream(30000, seed=9, stamp=2000.0)
