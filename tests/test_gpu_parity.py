@@ -652,3 +652,31 @@ def test_two_ranks_on_one_gpu(oracle, world100k, method, stream):
     ref = oracle.register(om, full[3], T0s[3], oracle.default_config(method))
     dt, dr = synth.pose_error(ref["T"], results[0][3]["T"])
     assert ref["iterations"] == results[0][3]["iterations"] and dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
+
+
+def test_api_misuse_fails_loudly(ctx, oracle, world100k):
+    """Status codes instead of silent fall-backs: bad method, radar covariance, missing covariances, zero slots, a scan of
+    another context."""
+    from elimaloc_amd import _lib
+    from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, Scan, VoxelHashMap
+    vm = VoxelHashMap(1.0, 30, ctx)
+    vm.AddPoints(world100k)
+    scan, Tt = synth.make_scan(world100k, 2000, seed=5)
+    sc = Scan(ctx, scan)
+    for cfg in (RegistrationConfig(icp_method=7), RegistrationConfig(use_radar_cov=1),
+                RegistrationConfig(icp_method=IcpMethod.VGICP), RegistrationConfig(icp_method=IcpMethod.GICP)):
+        with pytest.raises(_lib.ElmError):  # VGICP / GICP: the covariances were never computed (pcm.cpp:92-100)
+            Registration(cfg, ctx).RunRegisterBatch([sc], vm, [Tt])
+        with pytest.raises(_lib.ElmError):
+            Registration(cfg, ctx).RunRegisterStream([sc], vm, [Tt], slots=4)
+    with pytest.raises(_lib.ElmError):
+        Registration(RegistrationConfig(icp_method=0), ctx).RunRegisterStream([sc], vm, [Tt], slots=0)
+    other = Context(0)
+    try:
+        with pytest.raises(_lib.ElmError):
+            Registration(RegistrationConfig(icp_method=0), other).RunRegisterBatch([sc], vm, [Tt])
+    finally:
+        other.close()
+    # and the context is still usable afterwards
+    out = Registration(RegistrationConfig(icp_method=0), ctx).RunRegisterStream([sc], vm, [Tt], slots=2)
+    assert out[0]["is_success"]
