@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950); run with -m gpu on the GPU box")
+    # a fresh checkout has no in-tree libelimaloc_hip.so (it is git-ignored): build it once (hipcc cross-compiles without a GPU)
+    lib = os.path.join(ROOT, "elimaloc_amd", "libelimaloc_hip.so")
+    if not os.path.exists(lib) and os.path.exists("/opt/rocm/bin/hipcc"):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "elimaloc_amd", "csrc")], stdout=subprocess.DEVNULL)
 
 
 @pytest.fixture(scope="session")
