@@ -283,6 +283,26 @@ __device__ __forceinline__ void block_reduce_store(double* acc, double (*red)[32
         out[threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
+// cross-lane helpers for the wave-cooperative stage: v_readlane for wave-uniform sources and DPP row operations instead of
+// ds_bpermute (__shfl), which goes through the LDS pipeline and costs ~100 cycles per dependent step
+__device__ __forceinline__ int lane_bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ unsigned lane_bcast(unsigned v, int src) { return (unsigned)__builtin_amdgcn_readlane((int)v, src); }
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double wave_min(double v) { // minimum over the 64 lanes, in every lane
+    v = fmin(v, dpp_move<0xB1>(v));  // quad_perm [1,0,3,2]
+    v = fmin(v, dpp_move<0x4E>(v));  // quad_perm [2,3,0,1]
+    v = fmin(v, dpp_move<0x124>(v)); // row_ror:4
+    v = fmin(v, dpp_move<0x128>(v)); // row_ror:8 -> every lane holds the minimum of its row of 16
+    return fmin(fmin(lane_bcast(v, 0), lane_bcast(v, 16)), fmin(lane_bcast(v, 32), lane_bcast(v, 48)));
+}
+
 // Block reduction of the 32 packed sums through an LDS transpose (two halves of 16 values, 32 KB each): every
 // thread stores its values column-wise, then 16 lanes per value add 16 strided columns each and finish with four
 // shuffle steps.  ~40 LDS/shuffle operations per thread instead of 192 dependent shuffles.  Deterministic.
@@ -299,10 +319,11 @@ __device__ __forceinline__ void block_reduce_store_lds(const double* acc, double
         double v = 0.0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) v += buf[k * kBlock + i * 16 + seg];
-        v += __shfl_xor(v, 8, 64);
-        v += __shfl_xor(v, 4, 64);
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 1, 64);
+        // the 16 lanes of a value are one DPP row: rotations and quad permutes instead of four ds_bpermute round trips
+        v += dpp_move<0x128>(v); // row_ror:8
+        v += dpp_move<0x124>(v); // row_ror:4
+        v += dpp_move<0x4E>(v);  // quad_perm [2,3,0,1]
+        v += dpp_move<0xB1>(v);  // quad_perm [1,0,3,2]
         if (seg == 0) out[h * 16 + k] = v;
     }
 }
@@ -1145,9 +1166,8 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_cell(const DevMap m, cons
         while (todo) {
             const int src = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
-            const double hgx = __shfl(gx, src, 64), hgy = __shfl(gy, src, 64), hgz = __shfl(gz, src, 64);
-            const int hvx = __shfl(vx, src, 64), hvy = __shfl(vy, src, 64), hvz = __shfl(vz, src, 64);
-            const unsigned hstart = (unsigned)__shfl((int)start, src, 64), hcnt = (unsigned)__shfl((int)cnt, src, 64);
+            const double hgx = lane_bcast(gx, src), hgy = lane_bcast(gy, src), hgz = lane_bcast(gz, src);
+            const unsigned hstart = lane_bcast(start, src), hcnt = lane_bcast(cnt, src);
             const Pt3* __restrict__ hp = m.nbr_pts + hstart;
             // pass 1: the float64 minimum (the reference's arithmetic).  Equal distances are almost never seen; when one
             // is, pass 2 below settles it by the reference's visiting order.
@@ -1169,14 +1189,13 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_cell(const DevMap m, cons
                     d_best = fmin(d2, d_best);
                 }
             }
-            double d_min = d_best;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) d_min = fmin(d_min, __shfl_xor(d_min, off, 64));
+            const double d_min = wave_min(d_best);
             const unsigned long long at_min = __ballot(d_best == d_min);
             const bool contested = (__popcll(at_min) != 1) || (__ballot(tie && d_best == d_min) != 0ull);
             if (!contested) {
-                k_best = (unsigned)__shfl((int)k_best, __ffsll((long long)at_min) - 1, 64);
+                k_best = lane_bcast(k_best, __ffsll((long long)at_min) - 1);
             } else {
+                const int hvx = lane_bcast(vx, src), hvy = lane_bcast(vy, src), hvz = lane_bcast(vz, src);
                 unsigned r_best = 0xFFFFFFFFu, g_best = 0xFFFFFFFFu;
                 k_best = 0xFFFFFFFFu;
                 for (unsigned k = (unsigned)lane; k < hcnt; k += 64) {
