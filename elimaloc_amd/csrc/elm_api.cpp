@@ -979,8 +979,10 @@ extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_
     ScanDesc* hd = (ScanDesc*)ctx->h_desc;
     double* hT = (double*)((char*)ctx->h_desc + (size_t)batch * sizeof(ScanDesc));
     uint32_t blocks = 0;
+    uint32_t uniform_blocks = batch > 0 && scans[0] ? (scans[0]->n + kBlock - 1) / kBlock : 0;
     for (int b = 0; b < batch; ++b) {
         if (!scans[b] || scans[b]->ctx != ctx) return ELM_ERR_INVALID;
+        if ((scans[b]->n + kBlock - 1) / kBlock != uniform_blocks) uniform_blocks = 0;
         hd[b].pts = scans[b]->d_pts;
         hd[b].n = scans[b]->n;
         hd[b].n_total = scans[b]->n_total;
@@ -1015,6 +1017,8 @@ extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_
     rp.max_fitness = cfg->max_fitness_score;
     rp.method = method;
     rp.max_iter = cfg->max_iteration;
+    rp.uniform_blocks = uniform_blocks;
+    rp._pad = 0;
     ctx->rp = rp;
 
     // P2P / GICP default to the neighbourhood-list kernel; the lists are built on first use (init-time cost)
@@ -1210,6 +1214,8 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     rp.max_fitness = cfg->max_fitness_score;
     rp.method = method;
     rp.max_iter = cfg->max_iteration;
+    rp.uniform_blocks = cap_blocks; // every slot owns cap_blocks workgroups
+    rp._pad = 0;
     ctx->rp = rp;
     const bool use_nbr = (ctx->kernel_mode == 0 || ctx->kernel_mode == 4) && (method == ELM_P2P || method == ELM_GICP);
     if (use_nbr && !map->has_nbr)

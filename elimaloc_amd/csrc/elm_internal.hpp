@@ -118,6 +118,8 @@ struct RegParams {
     double max_fitness;
     int32_t method;
     int32_t max_iter;
+    uint32_t uniform_blocks; // > 0: every scan / slot owns exactly that many consecutive workgroups (scan = block / uniform_blocks)
+    uint32_t _pad;
 };
 
 constexpr int kBlock = 256;

@@ -261,7 +261,8 @@ __device__ __forceinline__ void finish_voxel_pair(double* acc, const DevMap& m, 
 }
 
 // block -> (scan, first point) ; returns false when the scan is finished
-__device__ __forceinline__ int find_scan(const ScanDesc* __restrict__ scans, int batch, unsigned L) {
+__device__ __forceinline__ int find_scan(const ScanDesc* __restrict__ scans, int batch, unsigned L, const RegParams& rp) {
+    if (rp.uniform_blocks) return (int)(L / rp.uniform_blocks); // no dependent descriptor loads at the head of the workgroup
     int lo = 0, hi = batch - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_direct(const DevMap m, co
                                                               const ScanState* __restrict__ st,
                                                               double* __restrict__ partials, const RegParams rp) {
     const unsigned L = xcd_remap(blockIdx.x, total_blocks);
-    const int s = find_scan(scans, batch, L);
+    const int s = find_scan(scans, batch, L, rp);
     const ScanState& S = st[s];
     if (S.done) return; // uniform: the whole block leaves; k_solve skips this scan too
     const ScanDesc sd = scans[s];
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_accumulate(const DevMap m, const 
     uint2* const s_tmp = reinterpret_cast<uint2*>(s_xyz); // (global start, count) per cell while probing (16 KB, aliases s_x/s_y)
 
     const unsigned L = xcd_remap(blockIdx.x, total_blocks);
-    const int s = find_scan(scans, batch, L);
+    const int s = find_scan(scans, batch, L, rp);
     const ScanState& S = st[s];
     if (S.done) return;
     const ScanDesc sd = scans[s];
@@ -860,7 +861,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_nbr(const DevMap m, const
                                                            double* __restrict__ partials, const RegParams rp) {
     __shared__ double s_buf[16 * kBlock]; // 32 KB for the transpose reduction
     const unsigned L = xcd_remap(blockIdx.x, total_blocks);
-    const int s = find_scan(scans, batch, L);
+    const int s = find_scan(scans, batch, L, rp);
     const ScanState& S = st[s];
     if (S.done) return;
     const ScanDesc sd = scans[s];
@@ -1023,7 +1024,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_cell(const DevMap m, cons
     __shared__ double s_buf[16 * kBlock];
     ELM_PHASE_BEGIN
     const unsigned L = xcd_remap(blockIdx.x, total_blocks);
-    const int s = find_scan(scans, batch, L);
+    const int s = find_scan(scans, batch, L, rp);
     const ScanState& S = st[s];
     if (S.done) return;
     const ScanDesc sd = scans[s];
@@ -1321,7 +1322,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_vnbr(const DevMap m, cons
                                                             double* __restrict__ partials, const RegParams rp) {
     __shared__ double s_buf[16 * kBlock];
     const unsigned L = xcd_remap(blockIdx.x, total_blocks);
-    const int s = find_scan(scans, batch, L);
+    const int s = find_scan(scans, batch, L, rp);
     const ScanState& S = st[s];
     if (S.done) return;
     const ScanDesc sd = scans[s];
