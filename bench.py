@@ -166,7 +166,7 @@ def main():
     V = float(sum(r["n_occ_total"] for r in out)) / max(pt_iters, 1)   # occupied neighbour voxels per point-iteration
     bytes_unit = b_alg(int(method), C, V)
     kmode = os.environ.get("ELM_KERNEL", "cell")
-    kernel_name = ("k_accumulate_vnbr" if (kmode in ("cell", "nbr") and int(method) == 2) else
+    kernel_name = (f"k_accumulate_vnbr<{METHOD_NAMES[int(method)]}>" if (kmode in ("cell", "nbr") and int(method) in (2, 3)) else
                    f"k_accumulate_cell<{METHOD_NAMES[int(method)]}>" if (kmode == "cell" and int(method) in (0, 1)) else
                    f"k_accumulate_nbr<{METHOD_NAMES[int(method)]}>" if (kmode == "nbr" and int(method) in (0, 1)) else
                    f"k_accumulate_direct<{METHOD_NAMES[int(method)]}>" if kmode == "direct" else f"k_accumulate<{METHOD_NAMES[int(method)]}>")

@@ -1026,7 +1026,7 @@ extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_
     if (use_nbr && !map->has_nbr) {
         if ((rc = elm_map_build_neighbourhoods(const_cast<elm_map*>(map))) != ELM_OK) return rc;
     }
-    const bool use_vnbr = !map_empty && (ctx->kernel_mode == 0 || ctx->kernel_mode == 4) && method == ELM_VGICP;
+    const bool use_vnbr = !map_empty && (ctx->kernel_mode == 0 || ctx->kernel_mode == 4) && (method == ELM_VGICP || method == ELM_AVGICP);
     if (use_vnbr && !map->has_vnbr) {
         if ((rc = build_voxel_neighbourhoods(const_cast<elm_map*>(map))) != ELM_OK) return rc;
     }
@@ -1220,7 +1220,7 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     const bool use_nbr = (ctx->kernel_mode == 0 || ctx->kernel_mode == 4) && (method == ELM_P2P || method == ELM_GICP);
     if (use_nbr && !map->has_nbr)
         if ((rc = elm_map_build_neighbourhoods(const_cast<elm_map*>(map))) != ELM_OK) return rc;
-    const bool use_vnbr = (ctx->kernel_mode == 0 || ctx->kernel_mode == 4) && method == ELM_VGICP;
+    const bool use_vnbr = (ctx->kernel_mode == 0 || ctx->kernel_mode == 4) && (method == ELM_VGICP || method == ELM_AVGICP);
     if (use_vnbr && !map->has_vnbr)
         if ((rc = build_voxel_neighbourhoods(const_cast<elm_map*>(map))) != ELM_OK) return rc;
 

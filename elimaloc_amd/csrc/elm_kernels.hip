@@ -1317,6 +1317,7 @@ __global__ __launch_bounds__(64) void k_nbr_cellsort(const DevMap m, const int32
 // nearest voxel MEAN (strict <, first met wins).  Here the occupied ones (~10 of 27) are precomputed per query voxel in
 // that visiting order as 32-byte (mean, id) records: one probe, then <= 27 contiguous records, float64 distances in the
 // reference's order -- no staging, no barriers before the block reduction.
+template <int METHOD>
 __global__ __launch_bounds__(kBlock) void k_accumulate_vnbr(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
                                                             unsigned total_blocks, const ScanState* __restrict__ st,
                                                             double* __restrict__ partials, const RegParams rp) {
@@ -1355,23 +1356,48 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_vnbr(const DevMap m, cons
             }
         }
         const VoxRec* __restrict__ lp = m.vnbr + start;
-        double bd2 = DBL_MAX, bmx = 0.0, bmy = 0.0, bmz = 0.0;
-        int bvid = -1;
-        for (unsigned j = 0; j < cnt; j += 4) { // four records (eight 16-byte loads) per round trip
-            VoxRec r[4];
+        if (METHOD == ELM_VGICP) {
+            double bd2 = DBL_MAX, bmx = 0.0, bmy = 0.0, bmz = 0.0;
+            int bvid = -1;
+            for (unsigned j = 0; j < cnt; j += 4) { // four records (eight 16-byte loads) per round trip
+                VoxRec r[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) r[u] = lp[min(j + u, cnt - 1)];
+                for (int u = 0; u < 4; ++u) r[u] = lp[min(j + u, cnt - 1)];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const double ex = r[u].mx - gx, ey = r[u].my - gy, ez = r[u].mz - gz;
-                const double d2 = (ex * ex + ey * ey) + ez * ez;
-                if (j + u < cnt && d2 < bd2) { bd2 = d2; bvid = r[u].vid; bmx = r[u].mx; bmy = r[u].my; bmz = r[u].mz; }
+                for (int u = 0; u < 4; ++u) {
+                    const double ex = r[u].mx - gx, ey = r[u].my - gy, ez = r[u].mz - gz;
+                    const double d2 = (ex * ex + ey * ey) + ez * ez;
+                    if (j + u < cnt && d2 < bd2) { bd2 = d2; bvid = r[u].vid; bmx = r[u].mx; bmy = r[u].my; bmz = r[u].mz; }
+                }
             }
+            finish_voxel_pair(acc, m, S, rp, px, py, pz, gx, gy, gz, bd2, bvid, bmx, bmy, bmz);
+            acc[29] = (double)cnt;
+            acc[30] = (double)cnt;
+            acc[31] = (double)cnt;
+        } else {
+            // AVGICP, GetCorrespondencesAllCov (vhm.cpp:153-206): every existing FACE neighbour (and the voxel itself) whose
+            // mean is within range is a pair of its own.  The records carry the neighbour's position code (dx+1)*9+(dy+1)*3+
+            // (dz+1); the seven wanted ones are met in list order (-x, -y, -z, 0, +z, +y, +x) instead of the reference's
+            // (0, +x, -x, +y, -y, +z, -z): the same pairs, added in another order.
+            double n_pairs = 0.0;
+            for (unsigned j = 0; j < cnt; ++j) {
+                const VoxRec r = lp[j];
+                const int code = r.pad;
+                if (!(code == 13 || code == 22 || code == 4 || code == 16 || code == 10 || code == 14 || code == 12)) continue;
+                n_pairs += 1.0;
+                const double ex = r.mx - gx, ey = r.my - gy, ez = r.mz - gz;
+                const double d2 = (ex * ex + ey * ey) + ez * ez;
+                if (d2 < rp.th2) {
+                    double C[9];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) C[k] = m.vox_cov[(size_t)r.vid * 9 + k];
+                    add_pair<ELM_AVGICP>(acc, S.Rinv, S.tinv, px, py, pz, r.mx, r.my, r.mz, C, nullptr, rp);
+                }
+            }
+            acc[29] = n_pairs;
+            acc[30] = n_pairs;
+            acc[31] = n_pairs;
         }
-        finish_voxel_pair(acc, m, S, rp, px, py, pz, gx, gy, gz, bd2, bvid, bmx, bmy, bmz);
-        acc[29] = (double)cnt;
-        acc[30] = (double)cnt;
-        acc[31] = (double)cnt;
     }
     block_reduce_store_lds(acc, s_buf, partials + (size_t)L * kSums);
 }
@@ -1389,7 +1415,8 @@ __global__ __launch_bounds__(256) void k_vnbr_fill(const DevMap m, const int32_t
                 if (pr.vid < 0 || pr.cnt == 0) continue;
                 VoxRec r;
                 r.mx = m.vox_mean[(size_t)pr.vid * 3]; r.my = m.vox_mean[(size_t)pr.vid * 3 + 1]; r.mz = m.vox_mean[(size_t)pr.vid * 3 + 2];
-                r.vid = pr.vid; r.pad = 0;
+                r.vid = pr.vid;
+                r.pad = ((dx + 1) * 3 + (dy + 1)) * 3 + (dz + 1); // position code of this neighbour (AVGICP picks the face ones)
                 out[o++] = r;
             }
 }
@@ -1952,7 +1979,10 @@ void launch_accumulate_cell(hipStream_t s, const DevMap& m, const ScanDesc* scan
 }
 void launch_accumulate_vnbr(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                             ScanState* st, double* partials, const RegParams& rp) {
-    hipLaunchKernelGGL(k_accumulate_vnbr, dim3(total_blocks), dim3(kBlock), 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
+    if (rp.method == ELM_VGICP)
+        hipLaunchKernelGGL((k_accumulate_vnbr<ELM_VGICP>), dim3(total_blocks), dim3(kBlock), 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
+    else
+        hipLaunchKernelGGL((k_accumulate_vnbr<ELM_AVGICP>), dim3(total_blocks), dim3(kBlock), 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
 }
 void launch_vnbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets, VoxRec* out) {
     hipLaunchKernelGGL(k_vnbr_fill, dim3((n_q + 255) / 256), dim3(256), 0, s, m, qkeys, n_q, offsets, out);
