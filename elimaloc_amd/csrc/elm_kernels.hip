@@ -1089,7 +1089,11 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_cell(const DevMap m, cons
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) cb[k + 1] = cb[k] + ((se[k] - sb[k] + 3) >> 2); // blocks of 4 candidates
+#ifdef ELM_SKIP_CANDS
+            const int nblk = cb[4] > 100000 ? 1 : 0; // ablation: records only
+#else
             const int nblk = cb[4];
+#endif
             n_tested = ((se[0] - sb[0]) + (se[1] - sb[1])) + ((se[2] - sb[2]) + (se[3] - sb[3]));
             const float ghx = (float)gx, ghy = (float)gy, ghz = (float)gz;
             const float glx = (float)(gx - (double)ghx), gly = (float)(gy - (double)ghy), glz = (float)(gz - (double)ghz);
