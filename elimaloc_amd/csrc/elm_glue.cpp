@@ -335,7 +335,11 @@ extern "C" int elm_pcm_callback_point_cloud(elm_ctx* ctx, const elm_map* map, co
     memset(out, 0, sizeof(*out));
     stamp -= node->lidar_time_delay; // pcm.cpp:216-217
     if (n == 0) return ELM_OK;       // "Input Empty!" (pcm.cpp:226-229)
-    std::vector<float> fx(3 * n), ft(n);
+    // per-thread scratch that only grows: no host allocation on the per-scan path after warm-up
+    static thread_local std::vector<float> fx, ft;
+    static thread_local std::vector<double> tab;
+    if (fx.size() < 3 * n) { fx.resize(3 * n); ft.resize(n); }
+    if (tab.size() < 4 * 2000) tab.resize(4 * 2000);
     size_t nf = 0;
     int rc = elm_filter_points_by_distance(xyz, point_time, n, node->input_max_dist, fx.data(), ft.data(), &nf); // :235
     if (rc != ELM_OK) return rc;
@@ -345,7 +349,6 @@ extern "C" int elm_pcm_callback_point_cloud(elm_ctx* ctx, const elm_map* map, co
     const float front = ft[0], back = ft[nf - 1];
     if (node->lidar_scan_time_end)
         for (size_t i = 0; i < nf; ++i) ft[i] -= front; // :483-485
-    std::vector<double> tab(4 * 2000);
     elm_deskew_tables tabs;
     rc = elm_deskew_prepare(imu4, n_imu, odom14, n_odom, stamp, front, back, node->lidar_scan_time_end, node->run_deskew, tab.data(),
                             tab.data() + 2000, tab.data() + 4000, tab.data() + 6000, 2000, &tabs);
