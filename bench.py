@@ -9,13 +9,22 @@ already resident in HBM when the timed region starts.
 Workload (BASELINE.json configs[1]): P2P ICP, 131072-pt synthetic scans vs a 10M-pt voxel-hashed map, defaults of
 config/localization.ini.  N>1: every scan is sharded point-wise over the N GPUs (map replicated), ONE RCCL all-reduce
 of the packed normal equations of the whole batch per ICP iteration; the batch grows with N (weak scaling: per-GPU
-points per launch fixed).
+points per launch fixed).  With N>1 the same registrations are also timed in replica mode (whole registrations per GPU,
+no collective) and reported under "replica" (SURVEY.md 8e asks for both).
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel k_accumulate, algorithmic bytes / hipEvent-measured
-kernel time, against 8 TB/s HBM) and, at N=1, `cpu_baseline` (the CPU oracle timed on the host cores on a bounded
-sample of the same workload, reference's shipped max_thread = 10).
+Prints ONE JSON line on rank 0 with
+  * `inputs`: SHA-1 of every uploaded scan + initial guess (the workload is bit-reproducible: seeded, BLAS-free),
+  * `roofline`: dominant kernel, bytes/unit of THAT kernel's own data structures (model in DESIGN.md section 4) x units
+    per launch / hipEvent-measured launch time, against 8 TB/s HBM (a fraction <= 1); the SURVEY 8(d) figure of the
+    REFERENCE's walk is kept as `algorithmic_ref_*`; `traffic` is the HBM byte count of a separate rocprofv3 --pmc pass
+    of this command committed under profiles/ (counters cannot be read inside the timed run),
+  * at N=1 `cpu_baseline`: the CPU oracle on the host cores, SURVEY 8(d) protocol (3 warm-ups, >= 20 timed
+    registrations, median / p10 / p90, correspondence-vs-total split, 10 threads and all cores, a full-map sample),
+    `pose_err_vs_cpu`, `reference_api` (RunRegister on host buffers, one call at a time) and `hard_guess` (the 0.5 m /
+    2 deg initial-guess set timed the same way).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -29,10 +38,12 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 METHOD_NAMES = {0: "P2P", 1: "GICP", 2: "VGICP", 3: "AVGICP"}
+SCAN_RANGE_M = 60.0
+SCAN_NOISE_M = 0.01
 
 
-def b_alg(method, C, V):
-    """Algorithmic bytes per scan point per ICP iteration, compact-layout model of SURVEY.md 8(d)."""
+def b_alg_reference(method, C, V):
+    """Algorithmic bytes per scan point per ICP iteration of the REFERENCE's walk, compact-layout model of SURVEY.md 8(d)."""
     if method == 0:
         return 444.0 + 12.0 * C
     if method == 1:
@@ -40,6 +51,27 @@ def b_alg(method, C, V):
     if method == 2:
         return 468.0 + 12.0 * V
     return 124.0 + 36.0 * V
+
+
+def kernel_bytes_model(method, tested, V, pairs):
+    """Bytes one scan point needs from THIS kernel's own data structures in one ICP iteration.
+
+    P2P/GICP (k_accumulate_cell): 16 scan point (float4) + 32 query-voxel hash slot + 4 x 16 column records + 12 per
+    distance-tested candidate + 12 winner re-read (+ 4 global index + 128 covariance record for GICP) + 1 (256-byte
+    partial record per 256-point workgroup).
+    VGICP (k_accumulate_vnbr): 16 + 32 slot + 32 per voxel-mean record (V = occupied neighbours) + 72 winner covariance + 1.
+    AVGICP: 16 + 32 + 32 V + 72 per emitted pair + 1."""
+    if method == 0:
+        return 16.0 + 32.0 + 64.0 + 12.0 * tested + 12.0 + 1.0
+    if method == 1:
+        return 16.0 + 32.0 + 64.0 + 12.0 * tested + 12.0 + 4.0 + 128.0 + 1.0
+    if method == 2:
+        return 16.0 + 32.0 + 32.0 * V + 72.0 + 1.0
+    return 16.0 + 32.0 + 32.0 * V + 72.0 * pairs + 1.0
+
+
+def percentile(v, q):
+    return float(np.percentile(np.asarray(v, dtype=np.float64), q))
 
 
 def main():
@@ -53,10 +85,15 @@ def main():
     ap.add_argument("--scan-points", type=int, default=131072)
     ap.add_argument("--map-points", type=int, default=10_000_000)
     ap.add_argument("--method", type=int, default=0, help="0 P2P (configs[1]), 1 GICP, 2 VGICP, 3 AVGICP")
-    ap.add_argument("--cpu-sample", type=int, default=16, help="registrations timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--guess", choices=("easy", "hard"), default="easy", help="initial-guess set of SURVEY 8(d): easy = 0.15 m / 0.5 deg "
+                    "(the headline workload), hard = 0.5 m / 2 deg")
+    ap.add_argument("--cpu-sample", type=int, default=20, help="registrations timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-full-sample", type=int, default=3, help="of those, registrations repeated on the un-cropped map (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency runs (profiling passes)")
+    ap.add_argument("--no-extras", action="store_true", help="skip latency / reference-API / hard-guess / replica legs (profiling passes)")
+    ap.add_argument("--no-latency", action="store_true", help="alias of --no-extras")
     args = ap.parse_args()
+    extras = not (args.no_extras or args.no_latency)
 
     # stdout carries exactly ONE JSON line: everything libraries print (RCCL banners, gloo notices) goes to stderr
     sys.stdout.flush()
@@ -82,7 +119,7 @@ def main():
         dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world_size)
 
     from elimaloc_amd import synth
-    from elimaloc_amd.registration import (Context, VoxelHashMap, Registration, RegistrationConfig, IcpMethod, Scan)
+    from elimaloc_amd.registration import (Context, VoxelHashMap, Registration, RegistrationConfig, IcpMethod, Scan, results_from_raw)
 
     method = IcpMethod(args.method)
     ctx = Context(local_rank)
@@ -91,7 +128,7 @@ def main():
         dist.broadcast_object_list(ids, src=0)
         ctx.comm_init(rank, world_size, ids[0])
 
-    # ---------------- synthetic inputs (identical on every rank: seeded) ----------------
+    # ---------------- synthetic inputs (identical on every rank: seeded, BLAS-free arithmetic) ----------------
     t0 = time.time()
     world = synth.make_world(args.map_points, seed=1001)
     vm = VoxelHashMap(1.0, 30, ctx)
@@ -103,23 +140,39 @@ def main():
     info = vm.info()
     t_map = time.time() - t0
     n_batch = args.batch * world_size  # weak scaling: per-GPU points per launch fixed
-    scans_host, T_true, T0s, scans = [], [], [], []
+    n_keep = max(args.cpu_sample, 8) if rank == 0 else 0  # full host copies kept for the CPU / reference-API legs
+    guess = dict(max_trans=0.15, max_rot_deg=0.5) if args.guess == "easy" else dict(max_trans=0.5, max_rot_deg=2.0)
 
     def gen(i):
-        sc, Tt = synth.make_scan(world, args.scan_points, seed=2002 + i)
+        sc, Tt = synth.make_scan(world, args.scan_points, seed=2002 + i, max_range=SCAN_RANGE_M, noise=SCAN_NOISE_M)
+        T0 = synth.perturb(Tt, seed=3003 + i, **guess)
         n = sc.shape[0]
+        h = hashlib.sha1(sc.tobytes())
+        h.update(np.ascontiguousarray(T0).tobytes())
+        rmax = float(np.sqrt((sc.astype(np.float64) ** 2).sum(axis=1).max())) if n else 0.0
         lo, hi = n * rank // world_size, n * (rank + 1) // world_size  # contiguous shard of every scan
-        return (sc if i < max(args.cpu_sample, 1) else None), Tt, synth.perturb(Tt, seed=3003 + i), np.ascontiguousarray(sc[lo:hi]), n
+        return (sc if i < n_keep else None), Tt, T0, np.ascontiguousarray(sc[lo:hi]), n, h.digest(), rmax
 
     synth.make_scan(world, 16, seed=1)  # builds the (cached) tile index of the world before the threads start
+    scans_host, T_true, T0s, scans, digests, rmaxs = [], [], [], [], [], []
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=16) as pool:  # numpy releases the GIL in the heavy parts
-        for full, Tt, T0, shard, n in pool.map(gen, range(n_batch)):
+    with ThreadPoolExecutor(max_workers=16) as pool:  # numpy releases the GIL in the heavy parts; make_scan calls no BLAS
+        for full, Tt, T0, shard, n, dg, rmax in pool.map(gen, range(n_batch)):
             if full is not None:
                 scans_host.append(full)
             T_true.append(Tt)
             T0s.append(T0)
             scans.append(Scan(ctx, shard, n_total=n))
+            digests.append(dg)
+            rmaxs.append(rmax)
+    # the pooled generation must equal a sequential one (round 1's pool corrupted rows through concurrent OpenBLAS calls)
+    for i in sorted(set([0, n_batch // 3, n_batch - 1])):
+        if gen(i)[5] != digests[i]:
+            raise SystemExit(f"input generation is not deterministic (scan {i})")
+    # every scan point lies within the sensor range (+ 5 sigma of the noise on every axis)
+    if max(rmaxs) > SCAN_RANGE_M + 5.0 * SCAN_NOISE_M * 3 ** 0.5:
+        raise SystemExit(f"corrupted scan: max |p| = {max(rmaxs):.3f} m")
+    inputs_sha1 = hashlib.sha1(b"".join(digests)).hexdigest()
     t_in = time.time() - t0 - t_map
     cfg = RegistrationConfig(icp_method=method)
     reg = Registration(cfg, ctx)
@@ -151,7 +204,6 @@ def main():
     prof = ctx.get_profile(reset=True)
     ctx.set_profiling(False)
     if args.slots > 0:
-        from elimaloc_amd.registration import results_from_raw
         out = results_from_raw(out)
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -162,20 +214,19 @@ def main():
     value = regs / elapsed
     iters = np.array([r["iterations"] for r in out])
     pt_iters = float(sum(r["point_iterations"] for r in out))          # whole batch, all ranks (all-reduced sums)
-    C = float(sum(r["n_cand_total"] for r in out)) / max(pt_iters, 1)  # candidates tested per point-iteration
+    C = float(sum(r["n_cand_total"] for r in out)) / max(pt_iters, 1)  # candidates of the reference's walk per point-iteration
     V = float(sum(r["n_occ_total"] for r in out)) / max(pt_iters, 1)   # occupied neighbour voxels per point-iteration
-    bytes_unit = b_alg(int(method), C, V)
-    kmode = os.environ.get("ELM_KERNEL", "cell")
-    kernel_name = (f"k_accumulate_vnbr<{METHOD_NAMES[int(method)]}>" if (kmode in ("cell", "nbr") and int(method) in (2, 3)) else
-                   f"k_accumulate_cell<{METHOD_NAMES[int(method)]}>" if (kmode == "cell" and int(method) in (0, 1)) else
-                   f"k_accumulate_nbr<{METHOD_NAMES[int(method)]}>" if (kmode == "nbr" and int(method) in (0, 1)) else
-                   f"k_accumulate_direct<{METHOD_NAMES[int(method)]}>" if kmode == "direct" else f"k_accumulate<{METHOD_NAMES[int(method)]}>")
+    tested = float(sum(r["n_tested_total"] for r in out)) / max(pt_iters, 1)  # candidates this kernel distance-tests
+    bytes_ref = b_alg_reference(int(method), C, V)
+    bytes_unit = kernel_bytes_model(int(method), tested, V, C if int(method) == 3 else 0.0)
+    kernel_name = (f"k_accumulate_vnbr<{METHOD_NAMES[int(method)]}>" if int(method) in (2, 3) else f"k_accumulate_cell<{METHOD_NAMES[int(method)]}>")
     # dominant kernel: k_accumulate. Units one launch processes ON THIS GPU = its shard of the batch's live points.
     launches = max(prof["accumulate_launches"], 1)
     acc_ms_avg = prof["accumulate_ms"] / launches
     units_per_launch = (pt_iters / world_size) * args.steps / launches
     achieved_gbs = bytes_unit * units_per_launch / (acc_ms_avg * 1e-3) / 1e9 if acc_ms_avg > 0 else 0.0
-    traffic = None
+    ref_gbs = bytes_ref * units_per_launch / (acc_ms_avg * 1e-3) / 1e9 if acc_ms_avg > 0 else 0.0
+    traffic, traffic_src = None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_path):
         try:
@@ -183,16 +234,10 @@ def main():
             if (pm.get("method") == int(method) and pm.get("batch") == args.batch and pm.get("scan_points") == args.scan_points
                     and pm.get("kernel") == kernel_name):
                 traffic = pm.get("hbm_bytes_per_unit") * units_per_launch  # measured HBM bytes per unit x this run's units
-        except Exception:
+                traffic_src = ("profiles/pmc_latest.json: HBM bytes/unit of a separate rocprofv3 --pmc pass of this command "
+                               f"({pm.get('source', 'see profiles/README.md')}) x this run's units per launch; not measured in this run")
+        except Exception:  # noqa: BLE001
             traffic = None
-
-    # single-registration latency (B = 1), outside the timed region
-    lat = []
-    for _ in range(0 if args.no_latency else 5):
-        t1 = time.perf_counter()
-        reg.RunRegisterBatch(scans[:1], vm, T0s[:1])
-        lat.append(time.perf_counter() - t1)
-    latency_ms = 1e3 * float(np.median(lat)) if lat else None
 
     result = {
         "metric": "ICP registrations/sec, 128k-pt scan vs 10M-pt map; pose err vs CPU ref",
@@ -209,7 +254,8 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"{METHOD_NAMES[int(method)]} ICP, {args.scan_points}-pt scan vs {args.map_points}-pt voxel-hashed map "
-                        f"(BASELINE configs[1] when P2P/131072/10M), localization.ini defaults, full convergence",
+                        f"(BASELINE configs[1] when P2P/131072/10M), localization.ini defaults, full convergence, "
+                        f"initial guess {guess['max_trans']} m / {guess['max_rot_deg']} deg ({args.guess})",
             "batch_per_gpu": args.batch,
             "registrations_per_step": n_batch,
             "slots_per_gpu": args.slots,
@@ -225,9 +271,14 @@ def main():
             "map_voxels": int(info.n_voxels),
             "candidates_per_point_C": C,
             "occupied_voxels_per_point_V": V,
-            "latency_ms_batch1": latency_ms,
             "map_build_s": t_map,
             "input_gen_s": t_in,
+        },
+        "inputs": {
+            "sha1": inputs_sha1,
+            "what": f"sha1 over, per registration in order, sha1(float32 scan bytes + float64 row-major initial guess); {n_batch} registrations; "
+                    "seeds 1001 / 2002+i / 3003+i; pooled generation verified against sequential generation",
+            "max_abs_scan_m": max(rmaxs),
         },
         "roofline": {
             "bound": "hbm",
@@ -237,67 +288,221 @@ def main():
             "unit": "GB/s",
             "frac": achieved_gbs / HBM_PEAK_GBS,
             "traffic": traffic,
-            # the index lets the kernel touch a fraction of the bytes the reference's walk reads, so `frac` (algorithmic bytes of
-            # the REFERENCE algorithm) exceeds 1; the measured HBM stream is the physical utilisation
+            "traffic_source": traffic_src,
             "measured_hbm_gbs": (traffic / (acc_ms_avg * 1e-3) / 1e9) if (traffic and acc_ms_avg > 0) else None,
             "measured_hbm_frac": (traffic / (acc_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and acc_ms_avg > 0) else None,
-            "tested_candidates_per_point": float(sum(r["n_tested_total"] for r in out)) / max(pt_iters, 1),
             "bytes_per_unit": bytes_unit,
+            "bytes_model": "this kernel's own structures: scan point + query slot + column records + 12 B x tested candidates + winner "
+                           "(+ payload) + partial record; DESIGN.md section 4",
+            "tested_candidates_per_point": tested,
             "units_per_launch": units_per_launch,
             "avg_launch_ms": acc_ms_avg,
             "launches": prof["accumulate_launches"],
             "accumulate_ms_per_step": prof["accumulate_ms"] / args.steps,
             "solve_ms_per_step": prof["solve_ms"] / args.steps,
+            # the SURVEY 8(d) model of the REFERENCE's 27-voxel walk (all C candidates): a speed-up-vs-model figure, not a utilisation
+            "algorithmic_ref_bytes_per_unit": bytes_ref,
+            "algorithmic_ref_gbs": ref_gbs,
+            "algorithmic_ref_over_peak": ref_gbs / HBM_PEAK_GBS,
         },
     }
+
+    # ---------------- extras outside the timed region ----------------
+    if extras and args.slots > 0:
+        # single-registration latency on resident scans (B = 1)
+        lat = []
+        for _ in range(5):
+            t1 = time.perf_counter()
+            reg.RunRegisterBatch(scans[:1], vm, T0s[:1])
+            lat.append(time.perf_counter() - t1)
+        result["config"]["latency_ms_batch1"] = 1e3 * float(np.median(lat))
+
+    if extras and rank == 0 and world_size == 1 and scans_host:
+        # the reference's API: Registration::RunRegister on host buffers (pcm.cpp:280-282), one call at a time
+        k = min(8, len(scans_host))
+        for i in range(min(2, k)):
+            reg.RunRegister(scans_host[i], vm, T0s[i])
+        tt = []
+        same = True
+        for i in range(k):
+            t1 = time.perf_counter()
+            pose, ok, fit, cov = reg.RunRegister(scans_host[i], vm, T0s[i])
+            tt.append(time.perf_counter() - t1)
+            same = same and bool(np.array_equal(pose, out[i]["T"]))
+        result["reference_api"] = {
+            "what": "Registration::RunRegister-equivalent elm_register on HOST buffers (scan upload + all iterations + result download per call), "
+                    "sequential calls on one context",
+            "registrations_per_s": 1.0 / float(np.median(tt)),
+            "ms_per_call_median": 1e3 * float(np.median(tt)),
+            "n_calls": k,
+            "pose_bit_identical_to_stream": same,
+        }
+
+    if extras and args.slots > 0 and args.guess == "easy":
+        # the harder initial-guess set of SURVEY 8(d) through the same entry point (iteration-count dependence)
+        T0h = [synth.perturb(Tt, seed=3003 + i, max_trans=0.5, max_rot_deg=2.0) for i, Tt in enumerate(T_true)]
+        packed_h = reg.pack_inputs(scans, T0h)
+        reg.RunRegisterStream(packed_h[0], vm, packed_h[1], slots=n_slots, raw=True)
+        barrier()
+        t1 = time.perf_counter()
+        hsteps = 3
+        for _ in range(hsteps):
+            outh = reg.RunRegisterStream(packed_h[0], vm, packed_h[1], slots=n_slots, raw=True)
+        barrier()
+        th = time.perf_counter() - t1
+        if distributed:
+            t = torch.tensor([th], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            th = float(t.item())
+        outh = results_from_raw(outh)
+        ih = np.array([r["iterations"] for r in outh])
+        result["hard_guess"] = {
+            "workload": f"same scans and map, initial guess 0.5 m / 2 deg, {hsteps} steps of {n_batch} registrations",
+            "value": n_batch * hsteps / th,
+            "unit": "registrations/s",
+            "iterations_mean": float(ih.mean()),
+            "iterations_max": int(ih.max()),
+            "success_rate": float(np.mean([r["is_success"] for r in outh])),
+        }
+    else:
+        T0h, outh = None, None
+
+    if extras and distributed and world_size > 1 and args.slots > 0:
+        # replica mode: whole registrations per GPU, no collective (the comparison SURVEY 8e asks for)
+        rctx = Context(local_rank)
+        rvm = VoxelHashMap(1.0, 30, rctx)
+        rvm.AddPoints(world)
+        if method in (IcpMethod.VGICP, IcpMethod.AVGICP):
+            rvm.CalVoxelCovAll()
+        if method == IcpMethod.GICP:
+            rvm.CalPointCovAll(0.4)
+        mine = list(range(rank, n_batch, world_size))
+        rscans = [Scan(rctx, synth.make_scan(world, args.scan_points, seed=2002 + i)[0]) for i in mine]
+        rreg = Registration(cfg, rctx)
+        rp = rreg.pack_inputs(rscans, [T0s[i] for i in mine])
+        rreg.RunRegisterStream(rp[0], rvm, rp[1], slots=args.slots, raw=True)
+        barrier(); rctx.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            rout = rreg.RunRegisterStream(rp[0], rvm, rp[1], slots=args.slots, raw=True)
+        rctx.synchronize(); barrier()
+        tr = time.perf_counter() - t1
+        t = torch.tensor([tr], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tr = float(t.item())
+        # replica results must equal the sharded ones up to the summation tree
+        rout = results_from_raw(rout)
+        dmax = max(float(np.abs(r["T"] - out[i]["T"]).max()) for r, i in zip(rout, mine))
+        result["replica"] = {"what": "whole registrations per GPU, no collective; same registrations as `value`",
+                             "value": n_batch * args.steps / tr, "unit": "registrations/s",
+                             "max_abs_pose_diff_vs_sharded": dmax}
+        del rscans, rvm
+        rctx.close()
 
     # ---------------- CPU baseline + pose error vs the CPU reference (rank 0, N = 1 only) ----------------
     if rank == 0 and world_size == 1 and not args.no_cpu and args.cpu_sample > 0:
         from oracle import oracle as O
         threads = 10  # the reference's shipped max_thread (config/localization.ini:95)
         ncpu = os.cpu_count() or 1
-        t_cpu, t_cpu_all, errs, it_match = [], [], [], []
-        all_threads = min(ncpu, 128)
         cpu_model = "unknown"
+        phys = ncpu
         try:
             with open("/proc/cpuinfo") as f:
-                cpu_model = next(line.split(":", 1)[1].strip() for line in f if line.startswith("model name"))
+                txt = f.read()
+            cpu_model = next(line.split(":", 1)[1].strip() for line in txt.splitlines() if line.startswith("model name"))
+            cores = set()
+            pid = cid = None
+            for line in txt.splitlines():
+                if line.startswith("physical id"):
+                    pid = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    cid = line.split(":")[1].strip()
+                elif not line.strip():
+                    if pid is not None and cid is not None:
+                        cores.add((pid, cid))
+                    pid = cid = None
+            if cores:
+                phys = len(cores)
         except Exception:  # noqa: BLE001
             pass
-        for i in range(min(args.cpu_sample, len(scans_host))):
-            # the oracle's AoS/unordered_map map over the part of the world this scan can reach (75 m around the
-            # sensor; the 60 m scan cannot see further, results are identical to the full map)
-            Tt = T_true[i]
-            near = world[np.linalg.norm(world[:, :2].astype(np.float64) - Tt[:2, 3], axis=1) < 75.0]
+        all_threads = max(1, min(phys, ncpu))
+        n_s = min(args.cpu_sample, len(scans_host))
+
+        def crop_map(i, full=False):
+            """the oracle's AoS / unordered_map map over the part of the world scan i can reach: everything within the scan's
+            own extent + 15 m of the sensor (correspondences look at most 2 voxels + the initial-guess error away)."""
+            if full:
+                pts = world
+            else:
+                r = float(np.sqrt((scans_host[i].astype(np.float64) ** 2).sum(axis=1).max())) + 15.0
+                d = world[:, :2].astype(np.float64) - T_true[i][:2, 3]
+                pts = world[(d * d).sum(axis=1) < r * r]
             om = O.Map(1.0, 30)
-            om.add_points(near)
+            om.add_points(pts)
             if method in (IcpMethod.VGICP, IcpMethod.AVGICP):
                 om.cal_voxel_cov_all(threads)
             if method == IcpMethod.GICP:
                 om.cal_point_cov_all(0.4, threads)
-            ref = O.register(om, scans_host[i], T0s[i], O.default_config(int(method), max_thread=min(threads, ncpu)))
-            t_cpu.append(ref["elapsed_ms"] * 1e-3)
-            dt, dr = synth.pose_error(ref["T"], out[i]["T"])
-            errs.append((dt, dr))
+            return om
+
+        ocfg10 = O.default_config(int(method), max_thread=min(threads, ncpu))
+        ocfg_all = O.default_config(int(method), max_thread=all_threads)
+        om = crop_map(0)
+        for _ in range(3):  # warm-ups (SURVEY 8d)
+            O.register(om, scans_host[0], T0s[0], ocfg10)
+        t10, c10, tall, call, errs, it_match = [], [], [], [], [], []
+        refs = []
+        for i in range(n_s):
+            if i:
+                om = crop_map(i)
+            ref = O.register(om, scans_host[i], T0s[i], ocfg10)
+            refs.append(ref)
+            t10.append(ref["elapsed_ms"] * 1e-3)
+            c10.append(ref["correspondence_ms"] * 1e-3)
+            errs.append(synth.pose_error(ref["T"], out[i]["T"]))
             it_match.append(ref["iterations"] == out[i]["iterations"] and ref["is_success"] == out[i]["is_success"])
-            # the same registration with every core the host offers to the correspondence search; the
-            # accumulation stays serial, as in the reference
-            t_cpu_all.append(O.register(om, scans_host[i], T0s[i], O.default_config(int(method), max_thread=all_threads))["elapsed_ms"] * 1e-3)
+            ra = O.register(om, scans_host[i], T0s[i], ocfg_all)  # every physical core for the correspondence search; accumulation stays serial
+            tall.append(ra["elapsed_ms"] * 1e-3)
+            call.append(ra["correspondence_ms"] * 1e-3)
             del om
-        cpu_rate = 1.0 / float(np.mean(t_cpu))
+        full_info = None
+        if args.cpu_full_sample > 0:
+            tb = time.perf_counter()
+            omf = crop_map(0, full=True)
+            t_build = time.perf_counter() - tb
+            O.register(omf, scans_host[0], T0s[0], ocfg10)  # warm-up
+            tf, same = [], True
+            for i in range(min(args.cpu_full_sample, n_s)):
+                rf = O.register(omf, scans_host[i], T0s[i], ocfg10)
+                tf.append(rf["elapsed_ms"] * 1e-3)
+                same = same and bool(np.array_equal(rf["T"], refs[i]["T"])) and rf["iterations"] == refs[i]["iterations"]
+            del omf
+            full_info = {"n": len(tf), "seconds_per_registration_median": float(np.median(tf)),
+                         "cropped_seconds_same_scans_median": float(np.median(t10[:len(tf)])),
+                         "pose_bit_identical_to_cropped_map": same, "map_build_s": t_build,
+                         "what": f"the same registrations on the un-cropped {args.map_points}-point oracle map (std::unordered_map locality)"}
+        med10 = float(np.median(t10))
         result["cpu_baseline"] = {
-            "value": cpu_rate,
+            "value": 1.0 / med10,
             "unit": "registrations/s",
             "cores": min(threads, ncpu),
             "kind": "port",
-            "sample": f"{len(t_cpu)} registrations of the same batch (scans 0..{len(t_cpu) - 1}) by the CPU oracle "
-                      f"(faithful restatement: 168-B AoS points, std::unordered_map, {min(threads, ncpu)}-thread "
-                      f"correspondence search, serial accumulation), span of reg.cpp:307-394, host has {ncpu} logical CPUs; "
-                      f"map = world within 75 m of the sensor",
-            "seconds_per_registration": float(np.mean(t_cpu)),
+            "sample": f"{n_s} registrations of the same batch (scans 0..{n_s - 1}) after 3 warm-ups, by the CPU oracle (faithful restatement: "
+                      f"168-B AoS points, std::unordered_map, {min(threads, ncpu)}-thread correspondence search, serial accumulation), span of "
+                      f"reg.cpp:307-394; map = world within the scan's extent + 15 m of the sensor; value = 1 / median; host has {ncpu} logical / "
+                      f"{phys} physical CPUs",
+            "seconds_per_registration": med10,
+            "seconds_p10": percentile(t10, 10),
+            "seconds_p90": percentile(t10, 90),
+            "correspondence_seconds_median": float(np.median(c10)),
+            "correspondence_fraction": float(np.median(np.array(c10) / np.array(t10))),
             "cpu_model": cpu_model,
-            "value_all_cores": 1.0 / float(np.mean(t_cpu_all)),
+            "value_all_cores": 1.0 / float(np.median(tall)),
             "all_cores_threads": all_threads,
+            "all_cores_seconds_p10": percentile(tall, 10),
+            "all_cores_seconds_p90": percentile(tall, 90),
+            "all_cores_correspondence_fraction": float(np.median(np.array(call) / np.array(tall))),
+            "full_map": full_info,
         }
         result["pose_err_vs_cpu"] = {
             "max_trans_m": float(max(e[0] for e in errs)),
@@ -306,7 +511,18 @@ def main():
             "iterations_and_flags_match": bool(all(it_match)),
             "tolerance": "1e-4 m / 1e-5 rad",
         }
-        result["gpu_over_cpu"] = value / cpu_rate
+        result["gpu_over_cpu"] = value / (1.0 / med10)
+        if outh is not None:
+            # pose parity on the hard set as well (a few: up to 10 iterations each on the CPU)
+            eh, mh = [], []
+            for i in range(min(4, n_s)):
+                om = crop_map(i)
+                ref = O.register(om, scans_host[i], T0h[i], ocfg10)
+                eh.append(synth.pose_error(ref["T"], outh[i]["T"]))
+                mh.append(ref["iterations"] == outh[i]["iterations"] and ref["is_success"] == outh[i]["is_success"])
+                del om
+            result["hard_guess"]["pose_err_vs_cpu"] = {"max_trans_m": float(max(e[0] for e in eh)), "max_rot_rad": float(max(e[1] for e in eh)),
+                                                       "n_checked": len(eh), "iterations_and_flags_match": bool(all(mh))}
 
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)

@@ -76,6 +76,19 @@ def rotvec_to_matrix(v):
     return np.eye(3) + math.sin(th) * K + (1 - math.cos(th)) * (K @ K)
 
 
+def rows_times(d, R):
+    """d @ R for an (n,3) array and a 3x3 matrix as explicit column arithmetic (no BLAS call).
+
+    OpenBLAS's threaded dgemm is not safe to call from several Python threads at once on this image (rows came back
+    corrupted when scans were generated in a thread pool); this form is also bit-reproducible across BLAS builds."""
+    d = np.asarray(d, dtype=np.float64)
+    R = np.asarray(R, dtype=np.float64)
+    out = np.empty((d.shape[0], 3), dtype=np.float64)
+    for j in range(3):
+        out[:, j] = (d[:, 0] * R[0, j] + d[:, 1] * R[1, j]) + d[:, 2] * R[2, j]
+    return out
+
+
 def make_pose(map_xyz, seed):
     """Sensor pose T_true: translation uniform in the central half of the map, yaw uniform, roll/pitch +-2 deg."""
     rng = np.random.default_rng(seed)
@@ -137,7 +150,7 @@ def make_scan(map_xyz, n_scan, seed, T_true=None, max_range=60.0, noise=0.01):
         pick = rng.choice(near, size=n_scan, replace=True)
     pick.sort()
     world = map_xyz[pick].astype(np.float64) + rng.normal(0.0, noise, size=(n_scan, 3))
-    local = (world - T_true[:3, 3]) @ T_true[:3, :3]  # R^T (w - t)
+    local = rows_times(world - T_true[:3, 3], T_true[:3, :3])  # R^T (w - t), BLAS-free (deterministic, thread-safe)
     return np.ascontiguousarray(local.astype(np.float32)), T_true
 
 
@@ -250,5 +263,5 @@ class Drive:
         c, s = np.cos(yaw), np.sin(yaw)
         ego = np.stack([c * d[:, 0] + s * d[:, 1], -s * d[:, 0] + c * d[:, 1], d[:, 2]], 1)      # R_z(yaw)^T d
         Rl, tl = tf_ego_to_lidar[:3, :3], tf_ego_to_lidar[:3, 3]
-        lidar = (ego - tl) @ Rl + rng.normal(0, noise, (n_points, 3))                             # Rl^T (ego - tl)
+        lidar = rows_times(ego - tl, Rl) + rng.normal(0, noise, (n_points, 3))                             # Rl^T (ego - tl)
         return np.ascontiguousarray(lidar.astype(np.float32)), rel.astype(np.float32)

@@ -1,22 +1,19 @@
-// voxel_hash_map.hpp -- drop-in shim with the reference's class name and method names
+// voxel_hash_map.hpp -- drop-in shim with the reference's class name, member names and signatures
 // (pcm_matching/include/voxel_hash_map.hpp:41-335) over the C ABI in elimaloc_hip.h.
-// pcm_matching.cpp compiles against this header instead of the reference's; Eigen-typed members are provided when
-// <Eigen/Core> is available (it is not in the build image, so the plain-array forms are what the tests exercise).
+// pcm_matching.cpp / pcm_matching.hpp compile against this header instead of the reference's: with <Eigen/Core> present
+// every Eigen-typed member of the reference (PointStruct::pose/local, CovStruct::cov/mean, Voxel) has its Eigen type
+// (linalg_types.hpp); without Eigen (this repository's build image) the same members are minimal fixed-size stand-ins.
+// tests/test_shim_compile.py compiles the reference's literal call lines against this header with a test-only Eigen stub.
 #pragma once
-#include <array>
+#include <cmath>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../elimaloc_hip.h"
-
-#if defined(__has_include)
-#if __has_include(<Eigen/Core>)
-#include <Eigen/Core>
-#define ELM_HAVE_EIGEN 1
-#endif
-#endif
+#include "linalg_types.hpp"
 
 namespace elimaloc {
 inline elm_ctx* default_context() {
@@ -35,25 +32,49 @@ inline void check(int rc, elm_ctx* ctx, const char* what) {
 
 // vhm.hpp:41-53
 struct CovStruct {
-    std::array<double, 9> cov{{1, 0, 0, 0, 1, 0, 0, 0, 1}}; // column-major 3x3
-    std::array<double, 3> mean{{0, 0, 0}};
+    elimaloc::Matrix3d cov;  // 3x3 covariance matrix
+    elimaloc::Vector3d mean; // 3D mean vector
+    CovStruct() : cov(elimaloc::Matrix3d::Identity()), mean(elimaloc::Vector3d::Zero()) {}
+    CovStruct(const elimaloc::Matrix3d& c, const elimaloc::Vector3d& m) : cov(c), mean(m) {}
+    void reset() {
+        cov = elimaloc::Matrix3d::Identity();
+        mean = elimaloc::Vector3d::Zero();
+    }
 };
 
-// vhm.hpp:55-87 -- only the fields the path reads; pose/local are float32-exact in the reference (pcm.hpp:205-215)
+// vhm.hpp:55-87; pose/local are float32-exact in the reference (filled from float32 PCL points, pcm.hpp:205-215)
 struct PointStruct {
-    std::array<double, 3> pose{{0, 0, 0}};
-    std::array<double, 3> local{{0, 0, 0}};
+    elimaloc::Vector3d pose;
+    elimaloc::Vector3d local;
     CovStruct covariance;
-    float vel = 0, azi_angle = 0, ele_angle = 0;
-    double intensity = 0;
+    float vel;       // mps
+    float azi_angle; // deg
+    float ele_angle; // deg
+    double intensity;
+    PointStruct()
+        : pose(elimaloc::Vector3d::Zero()), local(elimaloc::Vector3d::Zero()), covariance(CovStruct()), vel(0.0), azi_angle(0.0),
+          ele_angle(0.0), intensity(0.0) {}
+    void reset() {
+        pose.setZero();
+        local.setZero();
+        covariance.reset();
+        vel = 0.0;
+        azi_angle = 0.0;
+        ele_angle = 0.0;
+        intensity = 0.0;
+    }
 };
 
 struct VoxelHashMap {
-    VoxelHashMap() = default;
+    using RadarPointVector = std::vector<PointStruct>;
+    using RadarPointVectorTuple = std::tuple<RadarPointVector, RadarPointVector>;
+    using Voxel = elimaloc::Vector3i;
+
+    VoxelHashMap() {}
     VoxelHashMap(double voxel_size, int max_points_per_voxel) { Init(voxel_size, max_points_per_voxel); }
-    VoxelHashMap(const VoxelHashMap&) = delete;
+    VoxelHashMap(const VoxelHashMap&) = delete; // owns device memory (the reference's node never copies its map either)
     VoxelHashMap& operator=(const VoxelHashMap&) = delete;
-    ~VoxelHashMap() { Clear(); }
+    ~VoxelHashMap() { Release(); }
 
     void Init(double voxel_size, int max_points_per_voxel) { // vhm.cpp:26-29
         voxel_size_ = voxel_size;
@@ -61,19 +82,20 @@ struct VoxelHashMap {
     }
     // vhm.cpp:270-285.  Repeated calls append (the device map is rebuilt from the concatenation, which is what
     // sequential AddPoints calls produce in the reference).
-    void AddPoints(const std::vector<PointStruct>& points) {
+    void AddPoints(const RadarPointVector& points) {
+        xyz_.reserve(xyz_.size() + 3 * points.size());
         for (const auto& p : points) {
-            xyz_.push_back((float)p.pose[0]);
-            xyz_.push_back((float)p.pose[1]);
-            xyz_.push_back((float)p.pose[2]);
+            xyz_.push_back((float)p.pose(0));
+            xyz_.push_back((float)p.pose(1));
+            xyz_.push_back((float)p.pose(2));
         }
         Release();
     }
-    void AddPoints(const float* xyz, size_t n) {
+    void AddPoints(const float* xyz, size_t n) { // float32 fast path for callers that hold the PCD's own arrays
         xyz_.insert(xyz_.end(), xyz, xyz + 3 * n);
         Release();
     }
-    void Update(const std::vector<PointStruct>& points, const std::array<double, 3>&) { AddPoints(points); } // vhm.cpp:268
+    void Update(const RadarPointVector& points, const elimaloc::Vector3d&) { AddPoints(points); } // vhm.cpp:268
     void CalVoxelCovAll() { // vhm.hpp:183-193
         want_voxel_cov_ = true;
         elimaloc::check(elm_map_cal_voxel_cov_all(handle()), ctx(), "CalVoxelCovAll");
@@ -82,51 +104,68 @@ struct VoxelHashMap {
         want_point_cov_ = d_search_dist;
         elimaloc::check(elm_map_cal_point_cov_all(handle(), d_search_dist), ctx(), "CalPointCovAll");
     }
-    bool Empty() const { return elm_map_empty(const_cast<VoxelHashMap*>(this)->handle()) != 0; } // vhm.hpp:325
-    void Clear() { // vhm.hpp:324
+    inline Voxel PointToVoxel(const elimaloc::Vector3d& point, const double voxel_size) const { // vhm.hpp:176-180
+        return Voxel(static_cast<int>(std::floor(point.x() / voxel_size)), static_cast<int>(std::floor(point.y() / voxel_size)),
+                     static_cast<int>(std::floor(point.z() / voxel_size)));
+    }
+    // vhm.hpp:260-283: the first point of every floor-keyed voxel.  The reference emits unordered_map iteration order (only
+    // the set is contractual); here the kept points come back in input order.
+    inline std::vector<PointStruct> VoxelDownsample(const std::vector<PointStruct>& points, const double voxel_size) const {
+        std::vector<float> xyz(3 * points.size());
+        for (size_t i = 0; i < points.size(); ++i)
+            for (int k = 0; k < 3; ++k) xyz[3 * i + k] = (float)points[i].pose(k);
+        std::vector<int64_t> keep(points.size());
+        size_t n_keep = 0;
+        elimaloc::check(elm_voxel_downsample(xyz.data(), points.size(), voxel_size, keep.data(), &n_keep), ctx(), "VoxelDownsample");
+        std::vector<PointStruct> points_downsampled;
+        points_downsampled.reserve(n_keep);
+        for (size_t k = 0; k < n_keep; ++k) points_downsampled.emplace_back(points[(size_t)keep[k]]);
+        return points_downsampled;
+    }
+    inline bool Empty() const { return elm_map_empty(handle()) != 0; } // vhm.hpp:325
+    inline void Clear() { // vhm.hpp:324
         Release();
         xyz_.clear();
     }
     std::vector<PointStruct> Pointcloud() const { // vhm.cpp:245-255
-        auto* self = const_cast<VoxelHashMap*>(this);
         elm_map_info mi;
-        elimaloc::check(elm_map_get_info(self->handle(), &mi), ctx(), "elm_map_get_info");
+        elimaloc::check(elm_map_get_info(handle(), &mi), ctx(), "elm_map_get_info");
         std::vector<double> xyz(3 * mi.n_points), cov(9 * mi.n_points), mean(3 * mi.n_points);
-        elimaloc::check(elm_map_download_points(self->handle(), xyz.data(), cov.data(), mean.data(), mi.n_points), ctx(), "Pointcloud");
+        elimaloc::check(elm_map_download_points(handle(), xyz.data(), cov.data(), mean.data(), mi.n_points), ctx(), "Pointcloud");
         std::vector<PointStruct> out(mi.n_points);
         for (size_t i = 0; i < out.size(); ++i) {
-            for (int k = 0; k < 3; ++k) { out[i].pose[k] = out[i].local[k] = xyz[3 * i + k]; out[i].covariance.mean[k] = mean[3 * i + k]; }
-            for (int k = 0; k < 9; ++k) out[i].covariance.cov[k] = cov[9 * i + k];
+            for (int k = 0; k < 3; ++k) {
+                out[i].pose(k) = out[i].local(k) = xyz[3 * i + k];
+                out[i].covariance.mean(k) = mean[3 * i + k];
+            }
+            for (int k = 0; k < 9; ++k) out[i].covariance.cov.data()[k] = cov[9 * i + k]; // both column-major
         }
         return out;
     }
     std::vector<CovStruct> Covariances() const { // vhm.cpp:257-265: voxels holding more than 2 points
-        auto* self = const_cast<VoxelHashMap*>(this);
         elm_map_info mi;
-        elimaloc::check(elm_map_get_info(self->handle(), &mi), ctx(), "elm_map_get_info");
+        elimaloc::check(elm_map_get_info(handle(), &mi), ctx(), "elm_map_get_info");
         std::vector<int32_t> npts(mi.n_voxels);
         std::vector<double> cov(9 * mi.n_voxels), mean(3 * mi.n_voxels);
-        elimaloc::check(elm_map_download_voxels(self->handle(), nullptr, npts.data(), cov.data(), mean.data(), mi.n_voxels), ctx(), "Covariances");
+        elimaloc::check(elm_map_download_voxels(handle(), nullptr, npts.data(), cov.data(), mean.data(), mi.n_voxels), ctx(), "Covariances");
         std::vector<CovStruct> out;
         for (size_t v = 0; v < mi.n_voxels; ++v)
             if (npts[v] > 2) {
                 CovStruct c;
-                for (int k = 0; k < 9; ++k) c.cov[k] = cov[9 * v + k];
-                for (int k = 0; k < 3; ++k) c.mean[k] = mean[3 * v + k];
+                for (int k = 0; k < 9; ++k) c.cov.data()[k] = cov[9 * v + k];
+                for (int k = 0; k < 3; ++k) c.mean(k) = mean[3 * v + k];
                 out.push_back(c);
             }
         return out;
     }
-    bool FindGroundHeight(double x, double y, double& ground_z) const { // vhm.hpp:285-322
+    inline bool FindGroundHeight(const elimaloc::Vector2d& position, double& ground_z) const { // vhm.hpp:285-322
         int found = 0;
-        elimaloc::check(elm_map_find_ground_height(const_cast<VoxelHashMap*>(this)->handle(), x, y, &ground_z, &found), ctx(), "FindGroundHeight");
+        elimaloc::check(elm_map_find_ground_height(handle(), position(0), position(1), &ground_z, &found), ctx(), "FindGroundHeight");
         return found != 0;
     }
-#ifdef ELM_HAVE_EIGEN
-    bool FindGroundHeight(const Eigen::Vector2d& position, double& ground_z) const { return FindGroundHeight(position.x(), position.y(), ground_z); }
-#endif
 
-    elm_map* handle() {
+    // the device-resident map (built lazily from the accumulated points on first use; const like the reference's read paths)
+    elm_map* handle() const {
         if (!map_) {
             elimaloc::check(elm_map_build(ctx(), xyz_.data(), xyz_.size() / 3, voxel_size_, max_points_per_voxel_, &map_), ctx(), "elm_map_build");
             if (want_voxel_cov_) elimaloc::check(elm_map_cal_voxel_cov_all(map_), ctx(), "CalVoxelCovAll");
@@ -145,7 +184,7 @@ private:
         map_ = nullptr;
     }
     std::vector<float> xyz_;
-    elm_map* map_ = nullptr;
+    mutable elm_map* map_ = nullptr;
     bool want_voxel_cov_ = false;
     double want_point_cov_ = -1.0;
 };
