@@ -28,14 +28,17 @@ int main() {
     std::vector<PointStruct> scan;
     for (size_t i = 0; i < map_xyz.size() / 3; i += 17) {
         PointStruct p;
-        for (int k = 0; k < 3; ++k) p.pose[k] = p.local[k] = map_xyz[3 * i + k] - (k == 2 ? 1.8 : 0.0);
+        for (int k = 0; k < 3; ++k) p.pose(k) = p.local(k) = map_xyz[3 * i + k] - (k == 2 ? 1.8 : 0.0);
         scan.push_back(p);
     }
-    Matrix4dArr T0{{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0.08, -0.05, 1.8 + 0.03, 1}};
+    std::vector<PointStruct> ds = local_map_.VoxelDownsample(scan, 0.5); // pcm.cpp:257-258
+    elimaloc::Matrix4d T0 = elimaloc::Matrix4d::Identity();               // Eigen::Matrix4d on a machine with Eigen
+    T0(0, 3) = 0.08; T0(1, 3) = -0.05; T0(2, 3) = 1.8 + 0.03;
     bool ok = false;
     double fitness = 0.0;
-    Matrix6dArr cov;
-    Matrix4dArr T = registration_.RunRegister(scan, local_map_, T0, cfg, ok, fitness, cov); // pcm.cpp:280-282
-    std::printf("ok=%d fitness=%.4f t=(%.4f %.4f %.4f)\n", ok, fitness, T[12], T[13], T[14]);
-    return ok && std::fabs(T[12]) < 0.02 && std::fabs(T[13]) < 0.02 ? 0 : 1;
+    elimaloc::Matrix6d cov;
+    elimaloc::Matrix4d T = registration_.RunRegister(ds, local_map_, T0, cfg, ok, fitness, cov); // pcm.cpp:280-282
+    registration_.TransformPoints(T, ds);                                                        // pcm.cpp:308
+    std::printf("ok=%d fitness=%.4f t=(%.4f %.4f %.4f) n=%zu\n", ok, fitness, T(0, 3), T(1, 3), T(2, 3), ds.size());
+    return ok && std::fabs(T(0, 3)) < 0.02 && std::fabs(T(1, 3)) < 0.02 ? 0 : 1;
 }

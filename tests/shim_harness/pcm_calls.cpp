@@ -1,0 +1,220 @@
+// Compile-proof of the drop-in shims in their Eigen-typed form (tests/test_shim_compile.py; test infrastructure).
+//
+// The bodies below are the call lines of the reference's pcm_matching.cpp / pcm_matching.hpp that touch Registration,
+// VoxelHashMap, PointStruct, CovStruct and RegistrationConfig -- pcm.cpp:82-105 (map build), :122-143 (ProcessINI's
+// Eigen-typed config assignments), :257-258 (VoxelDownsample), :266 + :280-282 (RunRegister), :298, :308-312 (in-place
+// TransformPoints), :387 (FindGroundHeight), :408-414 (init-pose registration); pcm.hpp:205-220 (Pcl2PointStruct) -- quoted
+// with the reference's own member and local names, inside a minimal stand-in for the node class (no ROS / PCL: the
+// point cloud is a plain struct with the fields the lines read).  Compiled with -I tests/fake_eigen (a test-only
+// <Eigen/Core> stub: Eigen is absent from the image) so that ELM_HAVE_EIGEN is defined and every member has its Eigen type.
+// With -DELM_RUN it is also run on the GPU by the -m gpu suite.
+#include <cmath>
+#include <cstdio>
+#include <iostream>
+#include <memory>
+#include <vector>
+
+#include "registration.hpp"     // resolves to include/elimaloc/registration.hpp (include path order)
+#include "voxel_hash_map.hpp"
+
+#ifndef ELM_HAVE_EIGEN
+#error "this harness must be compiled with an <Eigen/Core> on the include path"
+#endif
+
+struct PointType { float x, y, z, intensity; };
+struct Cloud { std::vector<PointType> points; using Ptr = std::shared_ptr<Cloud>; };
+
+inline Eigen::Matrix3d VecToRot(const Eigen::Vector3d& a) { // stand-in for lf.hpp:340-345 (ZYX Euler)
+    const double cr = std::cos(a.x()), sr = std::sin(a.x()), cp = std::cos(a.y()), sp = std::sin(a.y()), cy = std::cos(a.z()), sy = std::sin(a.z());
+    Eigen::Matrix3d R;
+    R(0, 0) = cy * cp; R(0, 1) = cy * sp * sr - sy * cr; R(0, 2) = cy * sp * cr + sy * sr;
+    R(1, 0) = sy * cp; R(1, 1) = sy * sp * sr + cy * cr; R(1, 2) = sy * sp * cr - cy * sr;
+    R(2, 0) = -sp;     R(2, 1) = cp * sr;                R(2, 2) = cp * cr;
+    return R;
+}
+
+struct PcmMatchingConfig {
+    double d_pcm_voxel_size = 1.0, d_input_voxel_ds_m = 1.5, d_icp_pose_std_m = 0.0;
+    int i_pcm_voxel_max_point = 30;
+    std::vector<double> vec_d_ego_to_lidar_trans{1.2, 0.0, 1.8}, vec_d_ego_to_lidar_rot{0.0, 0.0, 0.0}, vec_d_ego_to_imu_rot{0.0, 0.0, 0.0};
+    Eigen::Matrix4d tf_ego_to_lidar = Eigen::Matrix4d::Identity();
+};
+
+struct PcmMatching {
+    PcmMatchingConfig cfg_;
+    RegistrationConfig registration_config_;
+    Registration registration_;
+    VoxelHashMap local_map_;
+    Eigen::Matrix6d icp_local_cov_;
+    size_t n_map_points_ = 0, n_cov_ = 0;
+
+    // pcm.hpp:205-220
+    void Pcl2PointStruct(const Cloud::Ptr& pcl_points, std::vector<PointStruct>& vec_points) {
+        vec_points.clear();
+        vec_points.reserve(pcl_points->points.size());
+        for (const auto& pcl_point : pcl_points->points) {
+            PointStruct point_struct;
+            point_struct.pose = Eigen::Vector3d(pcl_point.x, pcl_point.y, pcl_point.z);
+            point_struct.local = point_struct.pose; // set same value
+            point_struct.intensity = pcl_point.intensity;
+            vec_points.emplace_back(std::move(point_struct));
+        }
+    }
+
+    // pcm.cpp:122-143
+    bool ProcessINI() {
+        if (cfg_.vec_d_ego_to_lidar_trans.size() == 3 && cfg_.vec_d_ego_to_lidar_rot.size() == 3 &&
+            cfg_.vec_d_ego_to_imu_rot.size() == 3) {
+            registration_config_.ego_to_lidar_trans =
+                    Eigen::Map<const Eigen::Vector3d>(cfg_.vec_d_ego_to_lidar_trans.data());
+
+            Eigen::Vector3d euler_ego_to_lidar = Eigen::Vector3d(cfg_.vec_d_ego_to_lidar_rot[0] * M_PI / 180.0,
+                                                                 cfg_.vec_d_ego_to_lidar_rot[1] * M_PI / 180.0,
+                                                                 cfg_.vec_d_ego_to_lidar_rot[2] * M_PI / 180.0);
+            Eigen::Vector3d euler_ego_to_imu = Eigen::Vector3d(cfg_.vec_d_ego_to_imu_rot[0] * M_PI / 180.0,
+                                                               cfg_.vec_d_ego_to_imu_rot[1] * M_PI / 180.0,
+                                                               cfg_.vec_d_ego_to_imu_rot[2] * M_PI / 180.0);
+            registration_config_.ego_to_lidar_rot = VecToRot(euler_ego_to_lidar);
+            registration_config_.ego_to_imu_rot = VecToRot(euler_ego_to_imu);
+        }
+        else {
+            return false;
+        }
+        cfg_.tf_ego_to_lidar = Eigen::Matrix4d::Identity();
+        for (int r = 0; r < 3; ++r) { // the reference writes these through .block<3,3>() / .block<3,1>() expressions (pcm.cpp:147-148)
+            for (int c = 0; c < 3; ++c) cfg_.tf_ego_to_lidar(r, c) = registration_config_.ego_to_lidar_rot(r, c);
+            cfg_.tf_ego_to_lidar(r, 3) = registration_config_.ego_to_lidar_trans(r);
+        }
+        return true;
+    }
+
+    // pcm.cpp:82-105
+    void Init(const Cloud::Ptr& map_pcptr) {
+        registration_.Init(registration_config_);
+        std::vector<PointStruct> vec_map_points;
+        Pcl2PointStruct(map_pcptr, vec_map_points);
+
+        local_map_.Init(cfg_.d_pcm_voxel_size, cfg_.i_pcm_voxel_max_point);
+        local_map_.AddPoints(vec_map_points);
+
+        if (registration_config_.icp_method == IcpMethod::VGICP || registration_config_.icp_method == IcpMethod::AVGICP) {
+            local_map_.CalVoxelCovAll();
+        }
+        else if (registration_config_.icp_method == IcpMethod::GICP) {
+            local_map_.CalPointCovAll(registration_config_.gicp_cov_search_dist);
+        }
+
+        std::vector<PointStruct> vec_point_map = local_map_.Pointcloud();
+        std::vector<CovStruct> vec_cov_map = local_map_.Covariances();
+        n_map_points_ = vec_point_map.size();
+        n_cov_ = vec_cov_map.size();
+    }
+
+    // pcm.cpp:253-313
+    bool CallbackPointCloud(const Cloud::Ptr& undistort_pcptr_, const Eigen::Matrix4d& sync_ego, Eigen::Matrix4d& icp_ego_pose_out,
+                            std::vector<PointStruct>& world_points_out) {
+        std::vector<PointStruct> vec_src_ori_lidar_points;
+        Pcl2PointStruct(undistort_pcptr_, vec_src_ori_lidar_points);
+
+        std::vector<PointStruct> vec_src_lidar_points =
+                local_map_.VoxelDownsample(vec_src_ori_lidar_points, cfg_.d_input_voxel_ds_m);
+
+        Eigen::Matrix4d sync_lidar_pose = sync_ego * cfg_.tf_ego_to_lidar;
+
+        bool b_icp_success = false;
+        double d_fitness_score = 0.0;
+        Eigen::Matrix4d icp_lidar_pose =
+                registration_.RunRegister(vec_src_lidar_points, local_map_, sync_lidar_pose, registration_config_,
+                                          b_icp_success, d_fitness_score, icp_local_cov_);
+
+        if (b_icp_success == false) {
+            return false;
+        }
+        cfg_.d_icp_pose_std_m = d_fitness_score;
+        icp_ego_pose_out = icp_lidar_pose; // (* tf_ego_to_lidar.inverse() in the reference, pcm.cpp:298)
+
+        // transform vec_src_lidar_points to world frame
+        registration_.TransformPoints(icp_lidar_pose, vec_src_lidar_points);
+
+        // transform vec_src_ori_lidar_points to world frame
+        registration_.TransformPoints(icp_lidar_pose, vec_src_ori_lidar_points);
+        world_points_out = vec_src_ori_lidar_points;
+        return true;
+    }
+
+    // pcm.cpp:385-414
+    bool CallbackInitialPose(const Eigen::Matrix4d& rviz_pose, const Cloud::Ptr& point_type_lidar, Eigen::Matrix4d& final_pose) {
+        Eigen::Matrix4d ground_pose = rviz_pose;
+        double z_ground = 0.0; // Default ground level
+        bool found_ground = local_map_.FindGroundHeight(rviz_pose.block<3, 1>(0, 3).head<2>(), z_ground);
+        if (found_ground) {
+            ground_pose(2, 3) = z_ground; // Update Z value with the ground height
+        }
+        else {
+            return false;
+        }
+        Eigen::Matrix4d init_lidar_pose = ground_pose * cfg_.tf_ego_to_lidar;
+
+        std::vector<PointStruct> vec_lidar_points;
+        Pcl2PointStruct(point_type_lidar, vec_lidar_points);
+
+        std::vector<PointStruct> vec_ds_lidar_points =
+                local_map_.VoxelDownsample(vec_lidar_points, cfg_.d_input_voxel_ds_m);
+
+        bool b_icp_success = false;
+        double fitness_score = 0.0;
+        Eigen::Matrix4d icp_lidar_pose =
+                registration_.RunRegister(vec_ds_lidar_points, local_map_, init_lidar_pose, registration_config_,
+                                          b_icp_success, fitness_score, icp_local_cov_);
+        final_pose = icp_lidar_pose;
+        return b_icp_success;
+    }
+};
+
+int main() {
+    // a jittered ground lattice + one wall as the map; the scan is a subset seen from a lidar 1.8 m above the ground
+    Cloud::Ptr map_pcptr(new Cloud), scan(new Cloud);
+    unsigned s = 12345u;
+    auto jit = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) / 16777216.0f - 0.5f) * 0.008f; };
+    for (int i = -150; i < 150; ++i)
+        for (int j = -150; j < 150; ++j) map_pcptr->points.push_back({(i + 0.5f) * 0.2f + jit(), (j + 0.5f) * 0.2f + jit(), 0.3f + jit(), 1.f});
+    for (int i = -150; i < 150; ++i)
+        for (int k = 0; k < 30; ++k) map_pcptr->points.push_back({(i + 0.5f) * 0.2f + jit(), 10.5f + jit(), 1.1f + 0.2f * k + jit(), 1.f});
+    PcmMatching node;
+    node.registration_config_.icp_method = IcpMethod::VGICP;
+    if (!node.ProcessINI()) return 2;
+#ifdef ELM_RUN
+    node.Init(map_pcptr);
+    std::printf("map points %zu covs %zu\n", node.n_map_points_, node.n_cov_);
+    // lidar pose = ego (0.5, -0.3, z, yaw 0) * tf_ego_to_lidar (1.2, 0, 1.8)
+    const double lx = 0.5 + 1.2, ly = -0.3, lz = 0.3 + 1.8;
+    for (size_t i = 0; i < map_pcptr->points.size(); i += 7) {
+        const PointType& p = map_pcptr->points[i];
+        scan->points.push_back({p.x - (float)lx, p.y - (float)ly, p.z - (float)lz, 1.f});
+    }
+    Eigen::Matrix4d rviz_pose = Eigen::Matrix4d::Identity();
+    rviz_pose(0, 3) = 0.5 + 0.06; rviz_pose(1, 3) = -0.3 - 0.04; rviz_pose(2, 3) = 5.0; // z comes from FindGroundHeight
+    Eigen::Matrix4d final_pose;
+    if (!node.CallbackInitialPose(rviz_pose, scan, final_pose)) return 3;
+    std::printf("init pose lidar t = (%.4f %.4f %.4f)\n", final_pose(0, 3), final_pose(1, 3), final_pose(2, 3));
+    Eigen::Matrix4d sync_ego = Eigen::Matrix4d::Identity();
+    sync_ego(0, 3) = 0.5 - 0.05; sync_ego(1, 3) = -0.3 + 0.07; sync_ego(2, 3) = 0.3 + 0.02;
+    Eigen::Matrix4d icp;
+    std::vector<PointStruct> world;
+    if (!node.CallbackPointCloud(scan, sync_ego, icp, world)) return 4;
+    std::printf("icp lidar t = (%.4f %.4f %.4f) fitness %.4f\n", icp(0, 3), icp(1, 3), icp(2, 3), node.cfg_.d_icp_pose_std_m);
+    // the in-place TransformPoints put the scan back onto the map it was cut from
+    double worst = 0.0;
+    for (size_t k = 0; k < world.size(); k += 101) {
+        const PointType& q = map_pcptr->points[7 * k];
+        worst = std::fmax(worst, std::fabs(world[k].pose.x() - q.x) + std::fabs(world[k].pose.y() - q.y) + std::fabs(world[k].pose.z() - q.z));
+    }
+    std::printf("worst |world - map| = %.4f\n", worst);
+    const bool ok = std::fabs(icp(0, 3) - lx) < 0.03 && std::fabs(icp(1, 3) - ly) < 0.03 && std::fabs(icp(2, 3) - lz) < 0.03 &&
+                    std::fabs(final_pose(0, 3) - lx) < 0.05 && std::fabs(final_pose(1, 3) - ly) < 0.05 && worst < 0.1;
+    return ok ? 0 : 1;
+#else
+    (void)map_pcptr; (void)scan;
+    return 0;
+#endif
+}
