@@ -92,8 +92,8 @@ struct elm_ctx {
     bool want_trace = false;
     bool in_flight = false;
     RegParams rp{};
-    int kernel_mode = 4; // accumulate kernel for P2P/GICP: 4 cell-indexed neighbourhood lists (default), 0 streamed lists, 1 LDS-staged,
-                         // 2 direct (ELM_KERNEL=cell|nbr|staged|direct)
+    int kernel_mode = 4; // accumulate kernels: 4 = cell-indexed neighbourhood lists (P2P/GICP) and voxel-mean lists (VGICP/AVGICP), the
+                         // default; 2 = the plain 27-probe walk of k_accumulate_direct (ELM_KERNEL=direct: in-kernel reference for tests)
     // optional hipEvent timing
     bool profiling = false;
     std::vector<hipEvent_t> events;
@@ -186,7 +186,7 @@ extern "C" int elm_ctx_create(int device_id, elm_ctx** out) {
         delete ctx;
         return ELM_ERR_DEVICE;
     }
-    if (const char* k = getenv("ELM_KERNEL")) ctx->kernel_mode = (strcmp(k, "direct") == 0) ? 2 : (strcmp(k, "staged") == 0) ? 1 : (strcmp(k, "nbr") == 0) ? 0 : 4;
+    if (const char* k = getenv("ELM_KERNEL")) ctx->kernel_mode = (strcmp(k, "direct") == 0) ? 2 : 4;
     *out = ctx;
     return ELM_OK;
 }
@@ -233,8 +233,6 @@ static int prof_mark(elm_ctx* ctx) { // records the next pooled event on the con
     HIPCHK(ctx, hipEventRecord(ctx->events[ctx->events_used++], ctx->stream));
     return ELM_OK;
 }
-// diagnostic builds only (-DELM_PHASE_TIMING): per-phase cycle totals of the staged accumulate kernel; not in the public header
-extern "C" int elm_debug_phase_cycles(unsigned long long* out16, int reset) { return debug_phase_cycles(out16, reset); }
 extern "C" int elm_ctx_synchronize(elm_ctx* ctx) {
     if (!ctx) return ELM_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -952,6 +950,34 @@ static int exchange(elm_ctx* ctx, double* d_sums, size_t count) {
     return ELM_OK;
 }
 
+// One ICP iteration's correspondence + accumulation launch for `n_scans` scans / slots, bracketed by two profiling marks (the
+// solve span starts at the second).
+static int enqueue_accumulate(elm_ctx* ctx, const elm_map* map, const ScanDesc* dsc, int n_scans, uint32_t blocks, ScanState* st,
+                              const RegParams& rp, bool use_cells, bool use_vnbr) {
+    int rc;
+    if ((rc = prof_mark(ctx)) != ELM_OK) return rc;
+    double* partials = (double*)ctx->d_partials.p;
+    if (blocks) {
+        if (use_cells) launch_accumulate_cell(ctx->stream, map->dm, dsc, n_scans, (int)blocks, st, partials, rp);
+        else if (use_vnbr) launch_accumulate_vnbr(ctx->stream, map->dm, dsc, n_scans, (int)blocks, st, partials, rp);
+        else launch_accumulate_direct(ctx->stream, map->dm, dsc, n_scans, (int)blocks, st, partials, rp);
+    }
+    return prof_mark(ctx);
+}
+// folds the recorded events [acc_0, solve_0, acc_1, solve_1, ..., end] into the profile totals
+static int prof_collect(elm_ctx* ctx) {
+    if (ctx->profiling && ctx->events_used >= 3) {
+        for (int k = 0; k + 1 < ctx->events_used; ++k) {
+            float ms = 0.f;
+            HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->events[k], ctx->events[k + 1]));
+            if ((k & 1) == 0) { ctx->prof.accumulate_ms += ms; ctx->prof.accumulate_launches++; }
+            else { ctx->prof.solve_ms += ms; ctx->prof.solve_steps++; }
+        }
+    }
+    ctx->events_used = 0;
+    return ELM_OK;
+}
+
 extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_scan* const* scans, int batch,
                                           const double* T0, const elm_reg_config* cfg, int want_trace) {
     if (!ctx || !map || !scans || batch <= 0 || !T0 || !cfg) return ELM_ERR_INVALID;
@@ -982,12 +1008,13 @@ extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_
     uint32_t uniform_blocks = batch > 0 && scans[0] ? (scans[0]->n + kBlock - 1) / kBlock : 0;
     for (int b = 0; b < batch; ++b) {
         if (!scans[b] || scans[b]->ctx != ctx) return ELM_ERR_INVALID;
-        if ((scans[b]->n + kBlock - 1) / kBlock != uniform_blocks) uniform_blocks = 0;
+        const uint32_t nb = (scans[b]->n + kBlock - 1) / kBlock;
+        if (nb != uniform_blocks) uniform_blocks = 0;
         hd[b].pts = scans[b]->d_pts;
         hd[b].n = scans[b]->n;
         hd[b].n_total = scans[b]->n_total;
         hd[b].blk_begin = blocks;
-        blocks += (scans[b]->n + kBlock - 1) / kBlock;
+        blocks += nb;
         hd[b].blk_end = blocks;
     }
     memcpy(hT, T0, (size_t)batch * 16 * sizeof(double));
@@ -1021,12 +1048,14 @@ extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_
     rp._pad = 0;
     ctx->rp = rp;
 
-    // P2P / GICP default to the neighbourhood-list kernel; the lists are built on first use (init-time cost)
-    const bool use_nbr = !map_empty && (ctx->kernel_mode == 0 || ctx->kernel_mode == 4) && (method == ELM_P2P || method == ELM_GICP);
+    // P2P / GICP default to the cell-indexed neighbourhood lists; the lists are built on first use (init-time cost).  Maps whose
+    // lists cannot be cell-sorted (a list beyond 1024 candidates: voxel caps above ~37 points) take the plain walk.
+    const bool use_nbr = !map_empty && ctx->kernel_mode == 4 && (method == ELM_P2P || method == ELM_GICP);
     if (use_nbr && !map->has_nbr) {
         if ((rc = elm_map_build_neighbourhoods(const_cast<elm_map*>(map))) != ELM_OK) return rc;
     }
-    const bool use_vnbr = !map_empty && (ctx->kernel_mode == 0 || ctx->kernel_mode == 4) && (method == ELM_VGICP || method == ELM_AVGICP);
+    const bool use_cells = use_nbr && map->has_cells;
+    const bool use_vnbr = !map_empty && ctx->kernel_mode == 4 && (method == ELM_VGICP || method == ELM_AVGICP);
     if (use_vnbr && !map->has_vnbr) {
         if ((rc = build_voxel_neighbourhoods(const_cast<elm_map*>(map))) != ELM_OK) return rc;
     }
@@ -1042,16 +1071,7 @@ extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_
     ctx->events_used = 0;
     if (!map_empty) {
         for (int it = 0; it < cfg->max_iteration; ++it) {
-            if ((rc = prof_mark(ctx)) != ELM_OK) return rc;
-            if (blocks) {
-                if (use_nbr && ctx->kernel_mode == 4 && map->has_cells)
-                    launch_accumulate_cell(ctx->stream, map->dm, dsc, batch, (int)blocks, st, (double*)ctx->d_partials.p, rp);
-                else if (use_vnbr) launch_accumulate_vnbr(ctx->stream, map->dm, dsc, batch, (int)blocks, st, (double*)ctx->d_partials.p, rp);
-                else if (use_nbr) launch_accumulate_nbr(ctx->stream, map->dm, dsc, batch, (int)blocks, st, (double*)ctx->d_partials.p, rp);
-                else launch_accumulate(ctx->stream, map->dm, dsc, batch, (int)blocks, st, (double*)ctx->d_partials.p, rp,
-                                       (ctx->kernel_mode == 2 || map->info.max_points_per_voxel > 255) ? 1 : 0);
-            }
-            if ((rc = prof_mark(ctx)) != ELM_OK) return rc;
+            if ((rc = enqueue_accumulate(ctx, map, dsc, batch, blocks, st, rp, use_cells, use_vnbr)) != ELM_OK) return rc;
             if (distributed) {
                 launch_solve(ctx->stream, dsc, batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 1, d_active);
                 if ((rc = exchange(ctx, (double*)ctx->d_sums.p, (size_t)batch * kSums)) != ELM_OK) return rc;
@@ -1106,16 +1126,10 @@ extern "C" int elm_register_batch_finish(elm_ctx* ctx, elm_reg_result* results, 
     ctx->in_flight = false;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->profiling && ctx->events_used >= 3) {
-        // events: [acc_0, solve_0, acc_1, solve_1, ..., end]
-        for (int k = 0; k + 1 < ctx->events_used; ++k) {
-            float ms = 0.f;
-            HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->events[k], ctx->events[k + 1]));
-            if ((k & 1) == 0) { ctx->prof.accumulate_ms += ms; ctx->prof.accumulate_launches++; }
-            else { ctx->prof.solve_ms += ms; ctx->prof.solve_steps++; }
-        }
+    {
+        int prc = prof_collect(ctx);
+        if (prc != ELM_OK) return prc;
     }
-    ctx->events_used = 0;
     const ScanState* hs = (const ScanState*)ctx->h_state;
     for (int b = 0; results && b < ctx->batch; ++b) state_to_result(hs[b], ctx->rp, results[b]);
     {
@@ -1158,7 +1172,7 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
         ctx->last_error = "GICP needs elm_map_cal_point_cov_all() (pcm.cpp:97-100)";
         return ELM_ERR_INVALID;
     }
-    const int S = std::min(std::min(slots, count), 1024);
+    const int S = std::min(std::min(slots, count), stream_max_slots());
     int rc;
     // queue (host staging): items, initial guesses; slot descriptors with fixed block ranges sized for the largest scan
     uint32_t max_n = 0;
@@ -1177,7 +1191,10 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     StreamCtrl* hc = (StreamCtrl*)((char*)ctx->h_desc + q_bytes + t_bytes + d_bytes);
     for (int b = 0; b < count; ++b) { hq[b].pts = scans[b]->d_pts; hq[b].n = scans[b]->n; hq[b].n_total = scans[b]->n_total; }
     memcpy(hT, T0, t_bytes);
-    for (int s = 0; s < S; ++s) { hd[s].pts = nullptr; hd[s].n = 0; hd[s].n_total = 0; hd[s].blk_begin = cap_blocks * (uint32_t)s; hd[s].blk_end = cap_blocks * (uint32_t)(s + 1); }
+    for (int s = 0; s < S; ++s) {
+        hd[s].pts = nullptr; hd[s].n = 0; hd[s].n_total = 0;
+        hd[s].blk_begin = cap_blocks * (uint32_t)s; hd[s].blk_end = cap_blocks * (uint32_t)(s + 1);
+    }
     hc->next = 0; hc->completed = 0; hc->total = count; hc->_pad = 0;
     if ((rc = dev_reserve(ctx, ctx->d_scans, d_bytes)) != ELM_OK) return rc;
     if ((rc = dev_reserve(ctx, ctx->d_state, (size_t)S * sizeof(ScanState))) != ELM_OK) return rc;
@@ -1217,10 +1234,11 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     rp.uniform_blocks = cap_blocks; // every slot owns cap_blocks workgroups
     rp._pad = 0;
     ctx->rp = rp;
-    const bool use_nbr = (ctx->kernel_mode == 0 || ctx->kernel_mode == 4) && (method == ELM_P2P || method == ELM_GICP);
+    const bool use_nbr = ctx->kernel_mode == 4 && (method == ELM_P2P || method == ELM_GICP);
     if (use_nbr && !map->has_nbr)
         if ((rc = elm_map_build_neighbourhoods(const_cast<elm_map*>(map))) != ELM_OK) return rc;
-    const bool use_vnbr = (ctx->kernel_mode == 0 || ctx->kernel_mode == 4) && (method == ELM_VGICP || method == ELM_AVGICP);
+    const bool use_cells = use_nbr && map->has_cells;
+    const bool use_vnbr = ctx->kernel_mode == 4 && (method == ELM_VGICP || method == ELM_AVGICP);
     if (use_vnbr && !map->has_vnbr)
         if ((rc = build_voxel_neighbourhoods(const_cast<elm_map*>(map))) != ELM_OK) return rc;
 
@@ -1239,16 +1257,7 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     const int predicted = same_shape ? ctx->stream_hint_iters : 0;
     int it = 0;
     for (; it < hard_limit; ++it) {
-        if ((rc = prof_mark(ctx)) != ELM_OK) return rc;
-        if (blocks) {
-            if (use_nbr && ctx->kernel_mode == 4 && map->has_cells)
-                launch_accumulate_cell(ctx->stream, map->dm, dsc, S, (int)blocks, st, (double*)ctx->d_partials.p, rp);
-            else if (use_vnbr) launch_accumulate_vnbr(ctx->stream, map->dm, dsc, S, (int)blocks, st, (double*)ctx->d_partials.p, rp);
-            else if (use_nbr) launch_accumulate_nbr(ctx->stream, map->dm, dsc, S, (int)blocks, st, (double*)ctx->d_partials.p, rp);
-            else launch_accumulate(ctx->stream, map->dm, dsc, S, (int)blocks, st, (double*)ctx->d_partials.p, rp,
-                                   (ctx->kernel_mode == 2 || map->info.max_points_per_voxel > 255) ? 1 : 0);
-        }
-        if ((rc = prof_mark(ctx)) != ELM_OK) return rc;
+        if ((rc = enqueue_accumulate(ctx, map, dsc, S, blocks, st, rp, use_cells, use_vnbr)) != ELM_OK) return rc;
         if (distributed) {
             launch_solve(ctx->stream, dsc, S, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 1, d_active);
             if ((rc = exchange(ctx, (double*)ctx->d_sums.p, (size_t)S * kSums)) != ELM_OK) return rc;
@@ -1272,15 +1281,7 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_trace, ctx->d_trace.p, (size_t)count * ELM_MAX_ITER_TRACE * sizeof(elm_iter_trace),
                                    hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->profiling && ctx->events_used >= 3) {
-        for (int k = 0; k + 1 < ctx->events_used; ++k) {
-            float ms = 0.f;
-            HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->events[k], ctx->events[k + 1]));
-            if ((k & 1) == 0) { ctx->prof.accumulate_ms += ms; ctx->prof.accumulate_launches++; }
-            else { ctx->prof.solve_ms += ms; ctx->prof.solve_steps++; }
-        }
-    }
-    ctx->events_used = 0;
+    if ((rc = prof_collect(ctx)) != ELM_OK) return rc;
     ctx->stream_hint_count = count;
     ctx->stream_hint_slots = S;
     ctx->stream_hint_iters = it;

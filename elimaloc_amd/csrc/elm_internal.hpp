@@ -126,23 +126,21 @@ constexpr int kBlock = 256;
 constexpr int kSums = ELM_PACKED_SUMS; // 21 + 6 + 1 + 1 (+ n_cand, n_occ, pad)
 
 // ---- launchers (elm_kernels.hip) ----------------------------------------------------------------------
-int debug_phase_cycles(unsigned long long* out16, int reset); // 1 when built with -DELM_PHASE_TIMING
 void launch_init_state(hipStream_t s, ScanState* st, const double* T0, int batch, int map_empty, int* active);
 void launch_stream_refill(hipStream_t s, ScanDesc* scans, ScanState* st, int slots, const QueueItem* queue, const double* qT0,
                           ScanState* out_state, StreamCtrl* ctrl, int first);
-void launch_accumulate(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
-                       ScanState* st, double* partials, const RegParams& rp, int direct);
+void launch_accumulate_direct(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
+                              ScanState* st, double* partials, const RegParams& rp);
 // mode 0: reduce + solve (single GPU); 1: reduce only -> sums; 2: solve only from sums
 void launch_solve(hipStream_t s, const ScanDesc* scans, int batch, ScanState* st, const double* partials,
                   double* sums, const RegParams& rp, elm_iter_trace* trace, int mode, int* active);
-void launch_accumulate_nbr(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
-                           ScanState* st, double* partials, const RegParams& rp);
 void launch_nbr_count(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, uint32_t* counts, uint32_t* nocc);
 void launch_accumulate_vnbr(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                             ScanState* st, double* partials, const RegParams& rp);
 void launch_vnbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets, VoxRec* out);
 void launch_accumulate_cell(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                             ScanState* st, double* partials, const RegParams& rp);
+int stream_max_slots(); // slots one elm_register_stream call can iterate concurrently
 void launch_nbr_cellsort(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets,
                          const uint32_t* counts, Pt3* pts, uint32_t* idx, uint16_t* cell_off);
 size_t nbr_cell_stride();

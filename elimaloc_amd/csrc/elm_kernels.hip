@@ -1,9 +1,11 @@
 // elm_kernels.hip -- hand-written HIP kernels for gfx950 (CDNA4 / MI355X).
 //
-//   K1  k_accumulate<METHOD>  fused  T*p -> floor key -> 27(7)-voxel hash probe -> nearest point / voxel mean
-//                             -> residual + Jacobian -> wave + block reduction of the packed normal equations
+//   K1  k_accumulate_*        fused  T*p -> floor key -> neighbourhood probe -> nearest point / voxel mean
+//                             -> residual + Jacobian -> block reduction of the packed normal equations
 //                             (replaces TransformPoints reg.hpp:136-148, GetCorrespondence* vhm.cpp:31-206 and
-//                             the serial loops of AlignCloudsLocal* reg.cpp:28-51, 85-132, 171-208)
+//                             the serial loops of AlignCloudsLocal* reg.cpp:28-51, 85-132, 171-208):
+//                             k_accumulate_cell (P2P / GICP), k_accumulate_vnbr (VGICP / AVGICP),
+//                             k_accumulate_direct (the plain 27-probe walk: in-kernel reference and fall-back)
 //   K2  k_solve               deterministic final reduction, overlap gate (reg.cpp:349-356), LM-damped LDLT solve,
 //                             exp, pose composition, termination and fitness gates (reg.cpp:55-65, 378-387, 405-417)
 //   K3  k_voxel_cov           VoxelBlock::CalVoxelCov for every voxel (vhm.hpp:114-148, 183-193)
@@ -21,21 +23,6 @@
 
 namespace elm {
 
-// Optional per-phase cycle accounting of the staged accumulate kernel (build with -DELM_PHASE_TIMING; thread 0 of
-// every workgroup adds its clock64() deltas).  Diagnostic builds only.
-#ifdef ELM_PHASE_TIMING
-__device__ unsigned long long g_phase[16];
-#define ELM_PHASE_BEGIN unsigned long long ph_t0_ = clock64();
-#define ELM_PHASE(k)                                                              \
-    if (threadIdx.x == 0) {                                                       \
-        const unsigned long long ph_t1_ = clock64();                              \
-        atomicAdd(&g_phase[k], ph_t1_ - ph_t0_);                                  \
-        ph_t0_ = ph_t1_;                                                          \
-    }
-#else
-#define ELM_PHASE_BEGIN
-#define ELM_PHASE(k)
-#endif
 
 // ------------------------------------------------------------------------------------------------------
 // helpers
@@ -394,579 +381,6 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_direct(const DevMap m, co
     block_reduce_store(acc, red, partials + (size_t)L * kSums);
 }
 
-// ---- K1b: staged kernel -----------------------------------------------------------------------------------
-// A workgroup owns 256 consecutive scan points; scans are stored along a Hilbert curve over 2 m sensor-frame cells,
-// so those points occupy a few adjacent map voxels.  The workgroup
-//   1. transforms its points and reduces the bounding box of their voxel keys (+1 voxel halo),
-//   2. probes every cell of the box ONCE (4 cells per thread; ~10x fewer hash probes than 27 per point),
-//   3. prefix-sums the bucket sizes and copies the buckets into LDS with coalesced 16-byte loads, in cell order
-//      (x-major .. z-minor) and insertion order inside a bucket, i.e. exactly the reference's visiting order,
-//   4. lets every thread scan its 3x3 columns as 9 contiguous LDS ranges (the three z-neighbours of a column are
-//      adjacent in the staged order), all lanes of a voxel reading the same LDS address (broadcast),
-//   5. reduces the packed normal equations.
-// Workgroups whose box is too large (> kMaxCell cells or > kMaxStage points) take the direct path instead; the
-// result is identical either way (same candidates, same order, same fp64 arithmetic).
-constexpr int kMaxCell = 2048;  // box cells (incl. halo) a workgroup may cover
-constexpr int kCellsPerThread = kMaxCell / kBlock;
-constexpr int kMaxStage = 2944; // bucket points a workgroup may stage (34.5 KB as SoA floats; 3 workgroups per CU fit in 160 KB)
-constexpr int kMaxList = 768;   // non-empty cells a workgroup may stage
-constexpr double kFallbackUnit = 1099511627776.0; // 2^40: slot 31 carries tested candidates + 2^40 * fall-back workgroups
-// bucket sizes are packed into 8 bits of the LDS cell table: maps with max_points_per_voxel > 255 use the direct kernel
-
-// marks the 3x3x3 (or the 7 face-neighbour) cells of this thread's voxel in the workgroup's box
-template <bool kSeven>
-__device__ __forceinline__ void mark_needed(unsigned char* s_need, int bx, int by, int bz, int ny, int nz) {
-    if (kSeven) {
-        const int c = (bx * ny + by) * nz + bz;
-        s_need[c] = 1; s_need[c + 1] = 1; s_need[c - 1] = 1;
-        s_need[c + nz] = 1; s_need[c - nz] = 1;
-        s_need[c + ny * nz] = 1; s_need[c - ny * nz] = 1;
-    } else {
-#pragma unroll
-        for (int dx = -1; dx <= 1; ++dx)
-#pragma unroll
-            for (int dy = -1; dy <= 1; ++dy) {
-                const int c0 = ((bx + dx) * ny + (by + dy)) * nz + (bz - 1);
-                s_need[c0] = 1; s_need[c0 + 1] = 1; s_need[c0 + 2] = 1;
-            }
-    }
-}
-
-// first-slot loads of up to kCellsPerThread probes are issued back to back, then resolved (collisions walk on)
-struct SlotLoad {
-    int4 key;
-    uint2 rg;
-    unsigned h;
-};
-__device__ __forceinline__ SlotLoad slot_load(const DevMap& m, unsigned h) {
-    SlotLoad r;
-    r.h = h;
-    r.key = *reinterpret_cast<const int4*>(&m.slots[h]);
-    r.rg = *reinterpret_cast<const uint2*>(&m.slots[h].start);
-    return r;
-}
-__device__ __forceinline__ Probe slot_resolve(const DevMap& m, SlotLoad sl, int kx, int ky, int kz) {
-    Probe p;
-    p.vid = -1; p.start = 0; p.cnt = 0;
-    for (;;) {
-        if (sl.key.w < 0) break;
-        if (sl.key.x == kx && sl.key.y == ky && sl.key.z == kz) {
-            p.vid = sl.key.w; p.start = sl.rg.x; p.cnt = sl.rg.y;
-            break;
-        }
-        sl = slot_load(m, (sl.h + 1) & m.mask);
-    }
-    return p;
-}
-
-template <int METHOD>
-__global__ __launch_bounds__(kBlock, 3) void k_accumulate(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
-                                                          unsigned total_blocks, const ScanState* __restrict__ st,
-                                                          double* __restrict__ partials, const RegParams rp) {
-    constexpr bool kPoints = (METHOD == ELM_P2P || METHOD == ELM_GICP);
-    // LDS (<= 53 KB -> 3 workgroups per CU): bucket points as SoA floats (36 KB) or voxel means; cell tables; scratch
-    __shared__ __attribute__((aligned(16))) float s_xyz[kPoints ? 3 * kMaxStage : 4];
-    __shared__ unsigned s_cell[kPoints ? kMaxCell : 1];   // (LDS offset << 8) | count; offsets are the running prefix
-    __shared__ uint2 s_list[kPoints ? kMaxList : 1];      // compacted non-empty cells: (cell, global start of its bucket), sorted by cell
-    __shared__ double s_mean[kPoints ? 1 : kMaxList][3];  // means of the non-empty needed cells (compact slots)
-    __shared__ int s_mvid[kPoints ? 1 : kMaxList];        // their voxel ids
-    __shared__ short s_slot[kPoints ? 1 : kMaxCell];      // cell -> slot, -1 = no voxel
-    __shared__ int s_nslot;
-    __shared__ unsigned char s_need[kMaxCell];
-    __shared__ double red[kBlock / 64][32];
-    __shared__ int s_bb[6];
-    __shared__ unsigned long long s_wsum[kBlock / 64];
-    float* const s_x = s_xyz;
-    float* const s_y = s_xyz + (kPoints ? kMaxStage : 0);
-    float* const s_z = s_xyz + (kPoints ? 2 * kMaxStage : 0);
-    uint2* const s_tmp = reinterpret_cast<uint2*>(s_xyz); // (global start, count) per cell while probing (16 KB, aliases s_x/s_y)
-
-    const unsigned L = xcd_remap(blockIdx.x, total_blocks);
-    const int s = find_scan(scans, batch, L, rp);
-    const ScanState& S = st[s];
-    if (S.done) return;
-    const ScanDesc sd = scans[s];
-    const unsigned tid = threadIdx.x;
-    const unsigned i = (L - sd.blk_begin) * kBlock + tid;
-    const bool valid = i < sd.n;
-    const int lane = tid & 63, wave = tid >> 6;
-    ELM_PHASE_BEGIN
-
-    double acc[32];
-#pragma unroll
-    for (int k = 0; k < 32; ++k) acc[k] = 0.0;
-
-    double px = 0, py = 0, pz = 0, gx = 0, gy = 0, gz = 0;
-    int vx = 0, vy = 0, vz = 0;
-    if (valid) {
-        const float4 pf = sd.pts[i];
-        px = pf.x; py = pf.y; pz = pf.z;
-        gx = ((S.T[0] * px + S.T[4] * py) + S.T[8] * pz) + S.T[12];
-        gy = ((S.T[1] * px + S.T[5] * py) + S.T[9] * pz) + S.T[13];
-        gz = ((S.T[2] * px + S.T[6] * py) + S.T[10] * pz) + S.T[14];
-        vx = floor_key(gx, m.voxel_size); vy = floor_key(gy, m.voxel_size); vz = floor_key(gz, m.voxel_size);
-    }
-    // ---- 1. bounding box of the voxel keys; clear the need map
-    if (tid < 3) s_bb[tid] = INT_MAX;
-    else if (tid < 6) s_bb[tid] = INT_MIN;
-    for (int k = tid; k < kMaxCell / 4; k += kBlock) reinterpret_cast<unsigned*>(s_need)[k] = 0u;
-    __syncthreads();
-    {
-        int mnx = valid ? vx : INT_MAX, mny = valid ? vy : INT_MAX, mnz = valid ? vz : INT_MAX;
-        int mxx = valid ? vx : INT_MIN, mxy = valid ? vy : INT_MIN, mxz = valid ? vz : INT_MIN;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            mnx = min(mnx, __shfl_xor(mnx, off, 64)); mny = min(mny, __shfl_xor(mny, off, 64)); mnz = min(mnz, __shfl_xor(mnz, off, 64));
-            mxx = max(mxx, __shfl_xor(mxx, off, 64)); mxy = max(mxy, __shfl_xor(mxy, off, 64)); mxz = max(mxz, __shfl_xor(mxz, off, 64));
-        }
-        if (lane == 0) {
-            atomicMin(&s_bb[0], mnx); atomicMin(&s_bb[1], mny); atomicMin(&s_bb[2], mnz);
-            atomicMax(&s_bb[3], mxx); atomicMax(&s_bb[4], mxy); atomicMax(&s_bb[5], mxz);
-        }
-    }
-    __syncthreads();
-    const int lox = s_bb[0] - 1, loy = s_bb[1] - 1, loz = s_bb[2] - 1;
-    const long long ex_ = (long long)s_bb[3] - s_bb[0] + 3, ey_ = (long long)s_bb[4] - s_bb[1] + 3, ez_ = (long long)s_bb[5] - s_bb[2] + 3;
-    bool staged = (ex_ <= kMaxCell && ey_ <= kMaxCell && ez_ <= kMaxCell && ex_ * ey_ * ez_ <= kMaxCell);
-    const int ny = (int)ey_, nz = (int)ez_;
-    const int ncell = staged ? (int)(ex_ * ey_ * ez_) : 0;
-    double n_cand = 0.0, n_occ = 0.0, n_tested = 0.0;
-    // cell index -> (cx, cy, cz) without integer division: floor(c / d) == (c * M) >> 22 for c < 2048, d <= 2048
-    const unsigned mg_nz = (1u << 22) / (unsigned)max(nz, 1) + 1u, mg_ny = (1u << 22) / (unsigned)max(ny, 1) + 1u;
-    // ---- 2a. mark the cells some point of the workgroup will visit
-    if (staged) {
-        if (valid) mark_needed<METHOD == ELM_AVGICP>(s_need, vx - lox, vy - loy, vz - loz, ny, nz);
-        __syncthreads();
-    }
-    ELM_PHASE(0)
-
-    if (kPoints) {
-        double bd2 = DBL_MAX;
-        float bx = 0.f, by = 0.f, bz = 0.f;
-        int bidx = -1;
-        if (staged) {
-            // ---- 2b. probe the needed cells: thread t takes cells t, t+256, ... (needed cells are clustered, the
-            //          stride spreads them over the threads); all first-slot loads are in flight together
-            {
-                SlotLoad sl[kCellsPerThread];
-                int kx[kCellsPerThread], ky[kCellsPerThread], kz[kCellsPerThread];
-                bool need[kCellsPerThread];
-#pragma unroll
-                for (int k = 0; k < kCellsPerThread; ++k) {
-                    const int c = (int)tid + k * kBlock;
-                    need[k] = (c < ncell) && s_need[c];
-                    const int cxy = (int)(((unsigned)c * mg_nz) >> 22), cz = c - cxy * nz;
-                    const int cx = (int)(((unsigned)cxy * mg_ny) >> 22), cy = cxy - cx * ny;
-                    kx[k] = lox + cx; ky[k] = loy + cy; kz[k] = loz + cz;
-                    if (need[k]) sl[k] = slot_load(m, hash3(kx[k], ky[k], kz[k]) & m.mask);
-                }
-#pragma unroll
-                for (int k = 0; k < kCellsPerThread; ++k) {
-                    const int c = (int)tid + k * kBlock;
-                    uint2 r = make_uint2(0u, 0u);
-                    if (need[k]) {
-                        const Probe pr = slot_resolve(m, sl[k], kx[k], ky[k], kz[k]);
-                        if (pr.vid >= 0) r = make_uint2(pr.start, pr.cnt);
-                    }
-                    if (c < ncell) s_tmp[c] = r;
-                }
-            }
-            __syncthreads();
-            ELM_PHASE(1)
-            // ---- 3a. block-wide exclusive prefix of (points, non-empty cells) in cell order
-            unsigned cstart[kCellsPerThread], ccnt[kCellsPerThread];
-            unsigned lsum = 0, lne = 0;
-#pragma unroll
-            for (int k = 0; k < kCellsPerThread; ++k) {
-                const int c = (int)tid * kCellsPerThread + k;
-                uint2 r = make_uint2(0u, 0u);
-                if (c < ncell) r = s_tmp[c];
-                cstart[k] = r.x; ccnt[k] = r.y;
-                lsum += r.y;
-                lne += (r.y > 0) ? 1u : 0u;
-            }
-            unsigned long long v = ((unsigned long long)lne << 32) | lsum, inc = v;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const unsigned long long t = __shfl_up(inc, off, 64);
-                if (lane >= off) inc += t;
-            }
-            if (lane == 63) s_wsum[wave] = inc;
-            __syncthreads(); // also: every s_tmp read is done before s_x/s_y are overwritten below
-            unsigned long long wbase = 0, total = 0;
-#pragma unroll
-            for (int w = 0; w < kBlock / 64; ++w) {
-                const unsigned long long t = s_wsum[w];
-                if (w < wave) wbase += t;
-                total += t;
-            }
-            const unsigned tot_pts = (unsigned)(total & 0xffffffffu), tot_ne = (unsigned)(total >> 32);
-            if (tot_pts > (unsigned)kMaxStage || tot_ne > (unsigned)kMaxList) staged = false; // uniform
-            if (staged) {
-                const unsigned long long excl = wbase + inc - v;
-                unsigned off = (unsigned)(excl & 0xffffffffu), lpos = (unsigned)(excl >> 32);
-#pragma unroll
-                for (int k = 0; k < kCellsPerThread; ++k) {
-                    const int c = (int)tid * kCellsPerThread + k;
-                    if (c < ncell) {
-                        s_cell[c] = (off << 8) | ccnt[k];
-                        if (ccnt[k] > 0) s_list[lpos++] = make_uint2((unsigned)c, cstart[k]);
-                        off += ccnt[k];
-                    }
-                }
-                __syncthreads();
-                ELM_PHASE(2)
-                // ---- 3b. copy the buckets: 16 lanes per non-empty cell (2 points per lane), 4 cells in flight per group
-                const unsigned grp = tid >> 4, l = tid & 15;
-                for (unsigned e0 = grp; e0 < tot_ne; e0 += 64) {
-                    float4 qa[4], qb[4];
-                    unsigned da[4];
-                    bool oka[4], okb[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const unsigned e = e0 + 16u * u;
-                        oka[u] = false; okb[u] = false; da[u] = 0;
-                        if (e < tot_ne) {
-                            const uint2 le = s_list[e];
-                            const unsigned ci = s_cell[le.x];
-                            const unsigned cnt = ci & 0xffu, o = ci >> 8;
-                            da[u] = o + l;
-                            if (l < cnt) { qa[u] = m.pts[le.y + l]; oka[u] = true; }
-                            if (l + 16 < cnt) { qb[u] = m.pts[le.y + l + 16]; okb[u] = true; }
-                            for (unsigned j = l + 32; j < cnt; j += 16) { // buckets larger than 32 points
-                                const float4 qq = m.pts[le.y + j];
-                                s_x[o + j] = qq.x; s_y[o + j] = qq.y; s_z[o + j] = qq.z;
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (oka[u]) { s_x[da[u]] = qa[u].x; s_y[da[u]] = qa[u].y; s_z[da[u]] = qa[u].z; }
-                        if (okb[u]) { s_x[da[u] + 16] = qb[u].x; s_y[da[u] + 16] = qb[u].y; s_z[da[u] + 16] = qb[u].z; }
-                    }
-                }
-                __syncthreads();
-                ELM_PHASE(3)
-                // ---- 4. nearest bucket point of the thread's 27 cells, staged in the reference's visiting order.
-                //      The thread's own cell is scanned first; every other cell is skipped when even the closest
-                //      point its key range could hold is STRICTLY farther than the best so far (it can neither win
-                //      nor tie), and ties are resolved towards the smaller staged index, i.e. the candidate the
-                //      reference's x-major / insertion-order walk meets first.  Same winner as the full walk.
-                int bj = -1, bcell = 0;
-                if (valid) {
-                    const int cown = ((vx - lox) * ny + (vy - loy)) * nz + (vz - loz);
-                    auto scan_cell = [&](int c, unsigned info) {
-                        const int beg = (int)(info >> 8), end = beg + (int)(info & 0xffu);
-                        for (int j = beg; j < end; j += 4) {
-                            const int j1 = min(j + 1, end - 1), j2 = min(j + 2, end - 1), j3 = min(j + 3, end - 1);
-                            const float x0 = s_x[j], y0 = s_y[j], z0 = s_z[j];
-                            const float x1 = s_x[j1], y1 = s_y[j1], z1 = s_z[j1];
-                            const float x2 = s_x[j2], y2 = s_y[j2], z2 = s_z[j2];
-                            const float x3 = s_x[j3], y3 = s_y[j3], z3 = s_z[j3];
-                            const double e0x = (double)x0 - gx, e0y = (double)y0 - gy, e0z = (double)z0 - gz;
-                            const double e1x = (double)x1 - gx, e1y = (double)y1 - gy, e1z = (double)z1 - gz;
-                            const double e2x = (double)x2 - gx, e2y = (double)y2 - gy, e2z = (double)z2 - gz;
-                            const double e3x = (double)x3 - gx, e3y = (double)y3 - gy, e3z = (double)z3 - gz;
-                            const double d0 = (e0x * e0x + e0y * e0y) + e0z * e0z;
-                            const double d1 = (e1x * e1x + e1y * e1y) + e1z * e1z;
-                            const double d2 = (e2x * e2x + e2y * e2y) + e2z * e2z;
-                            const double d3 = (e3x * e3x + e3y * e3y) + e3z * e3z;
-                            if (d0 < bd2 || (d0 == bd2 && j < bj)) { bd2 = d0; bj = j; bcell = c; }
-                            if (d1 < bd2 || (d1 == bd2 && j1 < bj)) { bd2 = d1; bj = j1; bcell = c; }
-                            if (d2 < bd2 || (d2 == bd2 && j2 < bj)) { bd2 = d2; bj = j2; bcell = c; }
-                            if (d3 < bd2 || (d3 == bd2 && j3 < bj)) { bd2 = d3; bj = j3; bcell = c; }
-                        }
-                    };
-                    const unsigned iown = s_cell[cown];
-                    scan_cell(cown, iown);
-                    n_tested += (double)(iown & 0xffu);
-                    const double vs = m.voxel_size, slack = 1e-9 * vs;
-                    for (int dx = -1; dx <= 1; ++dx) {
-                        // stored keys truncate toward zero (vhm.cpp:275): key k > 0 holds [k, k+1) vs, k < 0 holds (k-1, k] vs,
-                        // k == 0 holds (-1, 1) vs
-                        const int kx = vx + dx;
-                        const double lx = (double)(kx <= 0 ? kx - 1 : kx) * vs - slack, hx = (double)(kx >= 0 ? kx + 1 : kx) * vs + slack;
-                        const double ax = fmax(fmax(lx - gx, gx - hx), 0.0);
-                        for (int dy = -1; dy <= 1; ++dy) {
-                            const int ky = vy + dy;
-                            const double ly = (double)(ky <= 0 ? ky - 1 : ky) * vs - slack, hy = (double)(ky >= 0 ? ky + 1 : ky) * vs + slack;
-                            const double ay = fmax(fmax(ly - gy, gy - hy), 0.0);
-                            const double axy = ax * ax + ay * ay;
-                            const int c0 = ((kx - lox) * ny + (ky - loy)) * nz + (vz - 1 - loz);
-#pragma unroll
-                            for (int dz = 0; dz < 3; ++dz) {
-                                const int c = c0 + dz;
-                                const unsigned info = s_cell[c];
-                                const unsigned cnt = info & 0xffu;
-                                n_occ += (cnt > 0) ? 1.0 : 0.0;
-                                n_cand += (double)cnt;
-                                if (cnt == 0 || c == cown) continue;
-                                const int kz = vz - 1 + dz;
-                                const double lz = (double)(kz <= 0 ? kz - 1 : kz) * vs - slack, hz = (double)(kz >= 0 ? kz + 1 : kz) * vs + slack;
-                                const double az = fmax(fmax(lz - gz, gz - hz), 0.0);
-                                const double lb = (axy + az * az) * (1.0 - 1e-12);
-                                if (lb > bd2) continue; // every point of the cell is strictly farther than the current best
-                                n_tested += (double)cnt;
-                                scan_cell(c, info);
-                            }
-                        }
-                    }
-                    if (bj >= 0) {
-                        bx = s_x[bj]; by = s_y[bj]; bz = s_z[bj];
-                        bidx = 0;
-                        if (METHOD == ELM_GICP) { // global index of the winner (s_list is sorted by cell)
-                            int lo_ = 0, hi_ = (int)tot_ne - 1;
-                            while (lo_ < hi_) {
-                                const int mid = (lo_ + hi_) >> 1;
-                                if ((int)s_list[mid].x < bcell) lo_ = mid + 1; else hi_ = mid;
-                            }
-                            bidx = (int)(s_list[lo_].y + ((unsigned)bj - (s_cell[bcell] >> 8)));
-                        }
-                    }
-                }
-                ELM_PHASE(4)
-            }
-        }
-        if (!staged) {
-            if (valid) { nearest_point_direct(m, vx, vy, vz, gx, gy, gz, bd2, bx, by, bz, bidx, n_cand, n_occ); n_tested = n_cand; }
-            if (tid == 0) acc[31] = kFallbackUnit; // fall-back workgroups are counted (high part of slot 31)
-            ELM_PHASE(7)
-        }
-        if (valid) finish_point_pair<METHOD>(acc, m, S, rp, px, py, pz, gx, gy, gz, bd2, bx, by, bz, bidx);
-        ELM_PHASE(5)
-    } else {
-        // VGICP / AVGICP: stage the voxel MEANS of the needed cells (GetCorrespondencesCov / AllCov, vhm.cpp:90-206)
-        if (staged) {
-            if (tid == 0) s_nslot = 0;
-            __syncthreads();
-            {
-                SlotLoad sl[kCellsPerThread];
-                int kx[kCellsPerThread], ky[kCellsPerThread], kz[kCellsPerThread];
-                bool need[kCellsPerThread];
-#pragma unroll
-                for (int k = 0; k < kCellsPerThread; ++k) {
-                    const int c = (int)tid + k * kBlock;
-                    need[k] = (c < ncell) && s_need[c];
-                    const int cxy = (int)(((unsigned)c * mg_nz) >> 22), cz = c - cxy * nz;
-                    const int cx = (int)(((unsigned)cxy * mg_ny) >> 22), cy = cxy - cx * ny;
-                    kx[k] = lox + cx; ky[k] = loy + cy; kz[k] = loz + cz;
-                    if (need[k]) sl[k] = slot_load(m, hash3(kx[k], ky[k], kz[k]) & m.mask);
-                }
-#pragma unroll
-                for (int k = 0; k < kCellsPerThread; ++k) {
-                    const int c = (int)tid + k * kBlock;
-                    int slot = -1;
-                    if (need[k]) {
-                        const Probe pr = slot_resolve(m, sl[k], kx[k], ky[k], kz[k]);
-                        if (pr.vid >= 0 && pr.cnt > 0) {
-                            slot = atomicAdd(&s_nslot, 1);
-                            if (slot < kMaxList) {
-                                s_mean[slot][0] = m.vox_mean[(size_t)pr.vid * 3];
-                                s_mean[slot][1] = m.vox_mean[(size_t)pr.vid * 3 + 1];
-                                s_mean[slot][2] = m.vox_mean[(size_t)pr.vid * 3 + 2];
-                                s_mvid[slot] = pr.vid;
-                            }
-                        }
-                    }
-                    if (c < ncell) s_slot[c] = (short)slot;
-                }
-            }
-            __syncthreads();
-            if (s_nslot > kMaxList) staged = false; // uniform
-        }
-        if (!staged && tid == 0) acc[31] = kFallbackUnit;
-        ELM_PHASE(1)
-        if (valid) {
-            if (METHOD == ELM_VGICP) {
-                double bd2 = DBL_MAX, bmx = 0.0, bmy = 0.0, bmz = 0.0;
-                int bvid = -1;
-                if (staged) {
-                    for (int dx = -1; dx <= 1; ++dx)
-                        for (int dy = -1; dy <= 1; ++dy) {
-                            const int c0 = ((vx + dx - lox) * ny + (vy + dy - loy)) * nz + (vz - 1 - loz);
-#pragma unroll
-                            for (int dz = 0; dz < 3; ++dz) {
-                                const int sl = s_slot[c0 + dz];
-                                if (sl < 0) continue;
-                                const int vid = s_mvid[sl];
-                                n_occ += 1.0;
-                                n_cand += 1.0;
-                                const double cx = s_mean[sl][0], cy = s_mean[sl][1], cz = s_mean[sl][2];
-                                const double ex = cx - gx, ey = cy - gy, ez = cz - gz;
-                                const double d2 = (ex * ex + ey * ey) + ez * ez;
-                                if (d2 < bd2) { bd2 = d2; bvid = vid; bmx = cx; bmy = cy; bmz = cz; }
-                            }
-                        }
-                } else {
-                    nearest_voxel_direct(m, vx, vy, vz, gx, gy, gz, bd2, bvid, bmx, bmy, bmz, n_cand, n_occ);
-                }
-                ELM_PHASE(4)
-                finish_voxel_pair(acc, m, S, rp, px, py, pz, gx, gy, gz, bd2, bvid, bmx, bmy, bmz);
-            } else {
-                const int ox[7] = {0, 1, -1, 0, 0, 0, 0}, oy[7] = {0, 0, 0, 1, -1, 0, 0}, oz[7] = {0, 0, 0, 0, 0, 1, -1};
-#pragma unroll
-                for (int k7 = 0; k7 < 7; ++k7) {
-                    int vid;
-                    double cx, cy, cz;
-                    if (staged) {
-                        const int c = ((vx + ox[k7] - lox) * ny + (vy + oy[k7] - loy)) * nz + (vz + oz[k7] - loz);
-                        const int sl = s_slot[c];
-                        if (sl < 0) continue;
-                        vid = s_mvid[sl];
-                        cx = s_mean[sl][0]; cy = s_mean[sl][1]; cz = s_mean[sl][2];
-                    } else {
-                        const Probe pr = probe_voxel(m, vx + ox[k7], vy + oy[k7], vz + oz[k7]);
-                        if (pr.vid < 0 || pr.cnt == 0) continue;
-                        vid = pr.vid;
-                        cx = m.vox_mean[(size_t)vid * 3]; cy = m.vox_mean[(size_t)vid * 3 + 1]; cz = m.vox_mean[(size_t)vid * 3 + 2];
-                    }
-                    n_occ += 1.0;
-                    n_cand += 1.0;
-                    const double ex = cx - gx, ey = cy - gy, ez = cz - gz;
-                    const double d2 = (ex * ex + ey * ey) + ez * ez;
-                    if (d2 < rp.th2) {
-                        double C[9];
-#pragma unroll
-                        for (int k = 0; k < 9; ++k) C[k] = m.vox_cov[(size_t)vid * 9 + k];
-                        add_pair<ELM_AVGICP>(acc, S.Rinv, S.tinv, px, py, pz, cx, cy, cz, C, nullptr, rp);
-                    }
-                }
-            }
-        }
-        ELM_PHASE(5)
-    }
-    if (valid) {
-        acc[29] = n_cand;
-        acc[30] = n_occ;
-        acc[31] += n_tested; // low part of slot 31: candidates actually distance-tested after pruning
-    }
-    // ---- 5. reduce
-    if (kPoints) {
-        __syncthreads(); // every thread is done with the staged points: reuse their LDS
-        block_reduce_store_lds(acc, reinterpret_cast<double*>(s_xyz), partials + (size_t)L * kSums);
-    } else {
-        block_reduce_store(acc, red, partials + (size_t)L * kSums);
-    }
-    ELM_PHASE(6)
-}
-
-// ---- K1c: neighbourhood-list kernel -----------------------------------------------------------------------
-// One thread per scan point: ONE hash probe (floor key of the transformed point) finds the precomputed candidate
-// list of that query voxel -- the 27 neighbour buckets already concatenated in the reference's visiting order --
-// and the thread streams it with independent 16-byte loads (8 in flight).  Lanes of the same voxel read the same
-// addresses.  No workgroup cooperation, no barriers before the final reduction.
-template <int METHOD>
-__global__ __launch_bounds__(kBlock) void k_accumulate_nbr(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
-                                                           unsigned total_blocks, const ScanState* __restrict__ st,
-                                                           double* __restrict__ partials, const RegParams rp) {
-    __shared__ double s_buf[16 * kBlock]; // 32 KB for the transpose reduction
-    const unsigned L = xcd_remap(blockIdx.x, total_blocks);
-    const int s = find_scan(scans, batch, L, rp);
-    const ScanState& S = st[s];
-    if (S.done) return;
-    const ScanDesc sd = scans[s];
-    const unsigned i = (L - sd.blk_begin) * kBlock + threadIdx.x;
-    const bool valid = i < sd.n;
-    double acc[32];
-#pragma unroll
-    for (int k = 0; k < 32; ++k) acc[k] = 0.0;
-    if (valid) {
-        const float4 pf = sd.pts[i];
-        const double px = pf.x, py = pf.y, pz = pf.z;
-        const double gx = ((S.T[0] * px + S.T[4] * py) + S.T[8] * pz) + S.T[12];
-        const double gy = ((S.T[1] * px + S.T[5] * py) + S.T[9] * pz) + S.T[13];
-        const double gz = ((S.T[2] * px + S.T[6] * py) + S.T[10] * pz) + S.T[14];
-        const int vx = floor_key(gx, m.voxel_size), vy = floor_key(gy, m.voxel_size), vz = floor_key(gz, m.voxel_size);
-        // query-voxel probe
-        unsigned start = 0, cnt = 0, nocc = 0;
-        double n_exact = 0.0;
-        {
-            unsigned h = hash3(vx, vy, vz) & m.qmask;
-            for (;;) {
-                const int4 key = *reinterpret_cast<const int4*>(&m.qslots[h]);
-                const uint4 rg = *reinterpret_cast<const uint4*>(&m.qslots[h].start);
-                if (key.w < 0) break;
-                if (key.x == vx && key.y == vy && key.z == vz) { start = rg.x; cnt = rg.y; nocc = rg.z; break; }
-                h = (h + 1) & m.qmask;
-            }
-        }
-        const Pt3* __restrict__ lp = m.nbr_pts + start;
-        double bd2 = DBL_MAX;
-        int bj = -1;
-        const int n = (int)cnt;
-        // Pass 1, float32: best and second-best squared distance.  g is split into gh + gl (float32 each, gh + gl == g
-        // to ~2^-48), so (q - gh) - gl reproduces q - g to a few float32 ulps of |q - g| and the float32 distance is
-        // within ~5e-7 relative (+ a tiny absolute term) of the reference's float64 one.  When the runner-up is
-        // farther than that margin the float32 winner IS the float64 winner (it cannot even tie); otherwise -- exact
-        // or near ties, i.e. practically never -- the lane falls back to the full float64 walk below.
-        const float ghx = (float)gx, ghy = (float)gy, ghz = (float)gz;
-        const float glx = (float)(gx - (double)ghx), gly = (float)(gy - (double)ghy), glz = (float)(gz - (double)ghz);
-        float m1 = __builtin_inff(), m2 = __builtin_inff();
-        int j1 = -1;
-        int j = 0;
-        for (; j + 8 <= n; j += 8) {
-            Pt3 q[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) q[u] = lp[j + u];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float ex = (q[u].x - ghx) - glx, ey = (q[u].y - ghy) - gly, ez = (q[u].z - ghz) - glz;
-                const float d = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-                m2 = fminf(m2, fmaxf(d, m1));
-                const bool c = d < m1;
-                m1 = c ? d : m1;
-                j1 = c ? (j + u) : j1;
-            }
-        }
-        for (; j < n; ++j) {
-            const Pt3 q = lp[j];
-            const float ex = (q.x - ghx) - glx, ey = (q.y - ghy) - gly, ez = (q.z - ghz) - glz;
-            const float d = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-            m2 = fminf(m2, fmaxf(d, m1));
-            const bool c = d < m1;
-            m1 = c ? d : m1;
-            j1 = c ? j : j1;
-        }
-        if (j1 >= 0) {
-            const float slack = 4e-11f * (fabsf(ghx) + fabsf(ghy) + fabsf(ghz) + 1.0f);
-            const bool clear_winner = m2 > m1 + m1 * 1.9073486328125e-06f + slack; // 2^-19
-            if (clear_winner) {
-                const Pt3 q = lp[j1];
-                const double ex = (double)q.x - gx, ey = (double)q.y - gy, ez = (double)q.z - gz;
-                bd2 = (ex * ex + ey * ey) + ez * ez; // the reference's float64 value for the range test
-                bj = j1;
-            } else {
-                // exact float64 walk; the list is cell-sorted, so equal distances are resolved explicitly towards the
-                // candidate the reference meets first (bucket visiting rank, then insertion order = global index)
-                unsigned brank = 0xFFFFFFFFu, bgi = 0xFFFFFFFFu;
-                for (int k = 0; k < n; ++k) {
-                    const Pt3 q = lp[k];
-                    const double ex = (double)q.x - gx, ey = (double)q.y - gy, ez = (double)q.z - gz;
-                    const double d2 = (ex * ex + ey * ey) + ez * ez;
-                    if (d2 > bd2) continue;
-                    const int kx = (int)((double)q.x / m.voxel_size), ky = (int)((double)q.y / m.voxel_size), kz = (int)((double)q.z / m.voxel_size);
-                    const unsigned rank = (unsigned)(((kx - vx + 1) * 3 + (ky - vy + 1)) * 3 + (kz - vz + 1));
-                    const unsigned gi = m.nbr_idx[(size_t)start + k];
-                    if (d2 < bd2 || rank < brank || (rank == brank && gi < bgi)) { bd2 = d2; bj = k; brank = rank; bgi = gi; }
-                }
-                n_exact = 1.0;
-            }
-        }
-        float bx = 0.f, by = 0.f, bz = 0.f;
-        int bidx = -1;
-        if (bj >= 0) {
-            const Pt3 q = lp[bj];
-            bx = q.x; by = q.y; bz = q.z;
-            bidx = (METHOD == ELM_GICP) ? (int)m.nbr_idx[(size_t)start + bj] : 0; // payload lookup only for GICP
-        }
-        finish_point_pair<METHOD>(acc, m, S, rp, px, py, pz, gx, gy, gz, bd2, bx, by, bz, bidx);
-        acc[29] = (double)cnt;
-        acc[30] = (double)nocc;
-        acc[31] = (double)cnt + n_exact * kFallbackUnit; // high part: points that needed the exact float64 walk
-    }
-    block_reduce_store_lds(acc, s_buf, partials + (size_t)L * kSums);
-}
-
 // ---- K1d: cell-indexed neighbourhood lists --------------------------------------------------------------
 // The candidate list of a query voxel is kept sorted by half-voxel cells: a 6x6x6 grid with origin (v - 1) * voxel_size
 // (per axis), edge h = voxel_size / 2, indices clamped to 0..5 so the outermost cells are unbounded outward (truncated
@@ -1017,12 +431,177 @@ __device__ __forceinline__ int lean_span(double g, double o, double h, double in
     return c0;
 }
 
+
+constexpr double kFallbackUnit = 1099511627776.0; // 2^40: slot 31 carries tested candidates + 2^40 * points that took the exact search
+
+// ---- block reduction of N packed sums through an LDS transpose, PP values per pass (PP * kBlock doubles of LDS) ----------
+// Every thread stores PP of its values column-wise, then kBlock / PP lanes per value add PP strided columns each and finish
+// with DPP row operations (+ one cross-row exchange when a value owns 32 lanes).  Fixed summation order: deterministic.
+// Leaves the N block sums in red[0..N) (LDS), visible to every thread on return.
+template <int N, int PP>
+__device__ __forceinline__ void block_reduce_to_lds(const double* v, double* buf, double* red) {
+    static_assert(PP == 8 || PP == 16, "8 or 16 values per pass");
+    constexpr int LPV = kBlock / PP; // lanes per value: 32 or 16
+    const int tid = threadIdx.x;
+    const int k = tid / LPV, seg = tid % LPV;
+#pragma unroll
+    for (int h = 0; h * PP < N; ++h) {
+        if (h) __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PP; ++q)
+            if (h * PP + q < N) buf[q * kBlock + tid] = v[h * PP + q];
+        __syncthreads();
+        if (h * PP + k < N) {
+            double a = 0.0;
+#pragma unroll
+            for (int i = 0; i < PP; ++i) a += buf[k * kBlock + i * LPV + seg];
+            a += dpp_move<0x128>(a); // row_ror:8
+            a += dpp_move<0x124>(a); // row_ror:4
+            a += dpp_move<0x4E>(a);  // quad_perm [2,3,0,1]
+            a += dpp_move<0xB1>(a);  // quad_perm [1,0,3,2]   -> every lane holds the sum of its row of 16
+            if (LPV == 32) a += __shfl_xor(a, 16, 64);
+            if (seg == 0) red[h * PP + k] = a;
+        }
+    }
+    __syncthreads();
+}
+
+// ---- P2P pair in 18 sums ---------------------------------------------------------------------------------------------
+// AlignCloudsLocal (reg.cpp:28-51) has M = I and J = [I | -[p]x], so J^T w J and J^T w r are functions of
+//   w, w p (3), w p p^T (6 unique), w r (3), w (p x r) (3), |r|, pair count            (18 sums instead of 29)
+// with r = R^-1 (q - g): the reference's T^-1 q - p written on the world-frame residual e = q - g the search already holds
+// (equal up to the rounding of an orthonormal R, ~1e-16 relative; |r|^2 = |e|^2 = the search's float64 distance).
+constexpr int kP2PVals = 21; // 18 sums + the three work counters
+__device__ __forceinline__ void pair_p2p(double* v, const double* Rinv, double px, double py, double pz, double ex, double ey, double ez,
+                                         double d2, const RegParams& rp) {
+    const double rx = (Rinv[0] * ex + Rinv[1] * ey) + Rinv[2] * ez;
+    const double ry = (Rinv[3] * ex + Rinv[4] * ey) + Rinv[5] * ez;
+    const double rz = (Rinv[6] * ex + Rinv[7] * ey) + Rinv[8] * ez;
+    const double den = rp.th + d2;
+    const double w = rp.th2 / (den * den); // square(th) / square(th + |r|^2)  (reg.cpp:38-39)
+    const double wx = w * px, wy = w * py, wz = w * pz;
+    const double ax = w * rx, ay = w * ry, az = w * rz;
+    v[0] = w;
+    v[1] = wx; v[2] = wy; v[3] = wz;
+    v[4] = wx * px; v[5] = wx * py; v[6] = wx * pz; v[7] = wy * py; v[8] = wy * pz; v[9] = wz * pz;
+    v[10] = ax; v[11] = ay; v[12] = az;
+    v[13] = py * az - pz * ay; v[14] = pz * ax - px * az; v[15] = px * ay - py * ax;
+    v[16] = sqrt(d2);
+    v[17] = 1.0;
+}
+// slot k of the packed 32-sum record (21 upper JTJ, 6 JTr, residual, count, 3 counters) from the 21 reduced P2P values
+__device__ __forceinline__ double p2p_expand(const double* s, int k) {
+    switch (k) {
+    case tri(0, 0): case tri(1, 1): case tri(2, 2): return s[0];
+    case tri(0, 4): return s[3];       // -w [p]x, translation x rotation block
+    case tri(0, 5): return -s[2];
+    case tri(1, 3): return -s[3];
+    case tri(1, 5): return s[1];
+    case tri(2, 3): return s[2];
+    case tri(2, 4): return -s[1];
+    case tri(3, 3): return s[7] + s[9]; // w (|p|^2 I - p p^T), rotation block
+    case tri(3, 4): return -s[5];
+    case tri(3, 5): return -s[6];
+    case tri(4, 4): return s[4] + s[9];
+    case tri(4, 5): return -s[8];
+    case tri(5, 5): return s[4] + s[7];
+    case 21: return s[10];
+    case 22: return s[11];
+    case 23: return s[12];
+    case 24: return s[13];
+    case 25: return s[14];
+    case 26: return s[15];
+    case 27: return s[16];
+    case 28: return s[17];
+    case 29: return s[18];
+    case 30: return s[19];
+    case 31: return s[20];
+    default: return 0.0; // tri(0,1), tri(0,2), tri(1,2), tri(0,3), tri(1,4), tri(2,5)
+    }
+}
+
+// query-voxel probe of the neighbourhood-list table: linear probing, two slots per round trip (load <= 0.5)
+struct QProbe {
+    unsigned start, cnt, nocc;
+    int qid;
+};
+__device__ __forceinline__ QProbe probe_query(const DevMap& m, int vx, int vy, int vz) {
+    QProbe r;
+    r.start = 0; r.cnt = 0; r.nocc = 0; r.qid = -1;
+    unsigned h = hash3(vx, vy, vz) & m.qmask;
+    for (;;) {
+        const unsigned h2 = (h + 1) & m.qmask;
+        const int4 key = *reinterpret_cast<const int4*>(&m.qslots[h]);
+        const uint4 rg = *reinterpret_cast<const uint4*>(&m.qslots[h].start);
+        const int4 key2 = *reinterpret_cast<const int4*>(&m.qslots[h2]);
+        const uint4 rg2 = *reinterpret_cast<const uint4*>(&m.qslots[h2].start);
+        if (key.w < 0) break;
+        if (key.x == vx && key.y == vy && key.z == vz) { r.start = rg.x; r.cnt = rg.y; r.nocc = rg.z; r.qid = key.w; break; }
+        if (key2.w < 0) break;
+        if (key2.x == vx && key2.y == vy && key2.z == vz) { r.start = rg2.x; r.cnt = rg2.y; r.nocc = rg2.z; r.qid = key2.w; break; }
+        h = (h + 2) & m.qmask;
+    }
+    return r;
+}
+
+// rank of a stored point's bucket in the reference's visiting order of the 27 neighbours of query voxel (vx, vy, vz):
+// x-major .. z-minor (vhm.cpp:234-240); the bucket key is the truncated one (vhm.cpp:275)
+__device__ __forceinline__ unsigned visit_rank(const Pt3 q, int vx, int vy, int vz, double voxel_size) {
+    const int kx = (int)((double)q.x / voxel_size), ky = (int)((double)q.y / voxel_size), kz = (int)((double)q.z / voxel_size);
+    return (unsigned)(((kx - vx + 1) * 3 + (ky - vy + 1)) * 3 + (kz - vz + 1));
+}
+// minimum / integer sum over the 16 lanes of a DPP row, result in every lane of the row
+__device__ __forceinline__ double row_min(double v) {
+    v = fmin(v, dpp_move<0xB1>(v));  // quad_perm [1,0,3,2]
+    v = fmin(v, dpp_move<0x4E>(v));  // quad_perm [2,3,0,1]
+    v = fmin(v, dpp_move<0x124>(v)); // row_ror:4
+    v = fmin(v, dpp_move<0x128>(v)); // row_ror:8
+    return v;
+}
+__device__ __forceinline__ int row_sum_int(int v) {
+    v += __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false);
+    return v;
+}
+
+constexpr int kRedPass = 8;    // values per pass of the block reduction (16 KB of LDS per workgroup)
+
+#ifndef ELM_CELL_WAVES
+#define ELM_CELL_WAVES 5 // minimum waves per SIMD: caps the kernel at 96 VGPRs (measured: 5 -> 42.0k, unconstrained 4 -> 39.4k, 6 spills -> 36.5k registrations/s)
+#endif
+
+// an undecided point handed to the workgroup-cooperative exact stage of k_accumulate_cell
+struct HardRec {
+    double gx, gy, gz;   // the transformed point
+    unsigned start, cnt; // its candidate list
+    int qid;             // its query voxel (cell offset table)
+    float r2;            // upper bound of its squared nearest-neighbour distance (inf: nothing found yet)
+};
+
+// K1 (default for P2P / GICP).
+//   stage 1, per lane: probe the query voxel -> the 4 column records of the 2x2x2 block of half-voxel cells the point leans
+//     into -> its ~25 candidates in float32 (blocks of 4, two blocks = six 16-byte loads per round trip) -> decided when the winner
+//     is clear of the runner-up by the float32 error margin AND closer than rho, the distance to the block's open faces
+//     (nothing outside the block can win or tie).
+//   stage 2, per workgroup: the undecided points (pose still far off, isolated points, near ties: ~3 %, ~5 % in a first
+//     iteration) are compacted into LDS in thread order and served 16 at a time, 16 lanes (one DPP row) per point: the lanes
+//     take the columns of the cells that intersect the ball around the point with the stage-1 distance as radius (the whole list
+//     when stage 1 found nothing), walk them with the reference's float64 distances and reduce (distance, visiting rank,
+//     insertion order) lexicographically -- exactly the reference's first strict minimum in its visiting order (vhm.cpp:208-243).
+//   then every lane adds its pair and the workgroup reduces the packed sums.
 template <int METHOD>
-__global__ __launch_bounds__(kBlock) void k_accumulate_cell(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
-                                                            unsigned total_blocks, const ScanState* __restrict__ st,
-                                                            double* __restrict__ partials, const RegParams rp) {
-    __shared__ double s_buf[16 * kBlock];
-    ELM_PHASE_BEGIN
+__global__ __launch_bounds__(kBlock, ELM_CELL_WAVES) void k_accumulate_cell(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
+                                                                            unsigned total_blocks, const ScanState* __restrict__ st,
+                                                                            double* __restrict__ partials, const RegParams rp) {
+    constexpr int NV = (METHOD == ELM_P2P) ? kP2PVals : kSums;
+    __shared__ double s_buf[kRedPass * kBlock]; // stage 2: the HardRec queue; afterwards the transpose buffer of the reduction
+    __shared__ double s_red[kSums];
+    __shared__ int s_res[kBlock];               // stage 2 results: winning list index per queued point
+    __shared__ int s_tst[kBlock];               //                  candidates walked for it
+    __shared__ unsigned s_cnt[kBlock / 64];
+    static_assert(sizeof(HardRec) * kBlock <= sizeof(double) * kRedPass * kBlock, "HardRec queue must fit the reduction buffer");
     const unsigned L = xcd_remap(blockIdx.x, total_blocks);
     const int s = find_scan(scans, batch, L, rp);
     const ScanState& S = st[s];
@@ -1030,16 +609,15 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_cell(const DevMap m, cons
     const ScanDesc sd = scans[s];
     const unsigned i = (L - sd.blk_begin) * kBlock + threadIdx.x;
     const bool valid = i < sd.n;
-    double acc[32];
+    double v[NV];
 #pragma unroll
-    for (int k = 0; k < 32; ++k) acc[k] = 0.0;
+    for (int k = 0; k < NV; ++k) v[k] = 0.0;
     double px = 0.0, py = 0.0, pz = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
-    int vx = 0, vy = 0, vz = 0;
-    unsigned start = 0, cnt = 0, nocc = 0;
-    const Pt3* __restrict__ lp = m.nbr_pts;
-    double bd2 = DBL_MAX;
+    QProbe qp;
+    qp.start = 0; qp.cnt = 0; qp.nocc = 0; qp.qid = -1;
     int bj = -1;
     int n_tested = 0;
+    float hr2 = __builtin_inff();
     bool hard = false;
     if (valid) {
         const float4 pf = sd.pts[i];
@@ -1047,33 +625,11 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_cell(const DevMap m, cons
         gx = ((S.T[0] * px + S.T[4] * py) + S.T[8] * pz) + S.T[12];
         gy = ((S.T[1] * px + S.T[5] * py) + S.T[9] * pz) + S.T[13];
         gz = ((S.T[2] * px + S.T[6] * py) + S.T[10] * pz) + S.T[14];
-        vx = floor_key(gx, m); vy = floor_key(gy, m); vz = floor_key(gz, m);
-        int qid = -1;
-        ELM_PHASE(8)
-        {
-            // linear probing, two slots per round trip (the table is kept at load <= 0.5: a third slot is rarely needed)
-            unsigned h = hash3(vx, vy, vz) & m.qmask;
-            for (;;) {
-                const unsigned h2 = (h + 1) & m.qmask;
-                const int4 key = *reinterpret_cast<const int4*>(&m.qslots[h]);
-                const uint4 rg = *reinterpret_cast<const uint4*>(&m.qslots[h].start);
-                const int4 key2 = *reinterpret_cast<const int4*>(&m.qslots[h2]);
-                const uint4 rg2 = *reinterpret_cast<const uint4*>(&m.qslots[h2].start);
-                if (key.w < 0) break;
-                if (key.x == vx && key.y == vy && key.z == vz) { start = rg.x; cnt = rg.y; nocc = rg.z; qid = key.w; break; }
-                if (key2.w < 0) break;
-                if (key2.x == vx && key2.y == vy && key2.z == vz) { start = rg2.x; cnt = rg2.y; nocc = rg2.z; qid = key2.w; break; }
-                h = (h + 2) & m.qmask;
-            }
-        }
-        ELM_PHASE(9)
-        lp = m.nbr_pts + start;
-#ifdef ELM_SKIP_STAGE1
-        if (false) {
-#else
-        if (cnt) {
-#endif
-            const uint16_t* __restrict__ co = m.nbr_cell_off + (size_t)qid * kCellStride;
+        const int vx = floor_key(gx, m), vy = floor_key(gy, m), vz = floor_key(gz, m);
+        qp = probe_query(m, vx, vy, vz);
+        if (qp.cnt) {
+            const Pt3* __restrict__ lp = m.nbr_pts + qp.start;
+            const uint16_t* __restrict__ co = m.nbr_cell_off + (size_t)qp.qid * kCellStride;
             const double hc = 0.5 * m.voxel_size, inv_h = 2.0 / m.voxel_size;
             const double ox = (double)(vx - 1) * m.voxel_size, oy = (double)(vy - 1) * m.voxel_size, oz = (double)(vz - 1) * m.voxel_size;
             double rho = DBL_MAX;
@@ -1089,17 +645,15 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_cell(const DevMap m, cons
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) cb[k + 1] = cb[k] + ((se[k] - sb[k] + 3) >> 2); // blocks of 4 candidates
-#ifdef ELM_SKIP_CANDS
-            const int nblk = cb[4] > 100000 ? 1 : 0; // ablation: records only
-#else
             const int nblk = cb[4];
-#endif
             n_tested = ((se[0] - sb[0]) + (se[1] - sb[1])) + ((se[2] - sb[2]) + (se[3] - sb[3]));
+            // float32 filter: g = gh + gl (float32 each, gh + gl == g to ~2^-48), so (q - gh) - gl reproduces q - g to a few float32
+            // ulps of |q - g| and the float32 distance is within 2^-20 relative (+ slack / 2) of the reference's float64 one
             const float ghx = (float)gx, ghy = (float)gy, ghz = (float)gz;
             const float glx = (float)(gx - (double)ghx), gly = (float)(gy - (double)ghy), glz = (float)(gz - (double)ghz);
             float m1 = __builtin_inff(), m2 = __builtin_inff();
             int j1 = -1;
-            for (int t0 = 0; t0 < nblk; t0 += 2) { // two blocks = 8 independent loads per round trip
+            for (int t0 = 0; t0 < nblk; t0 += 2) { // two blocks = 8 candidates per round trip
                 int pp[2], pe[2];
 #pragma unroll
                 for (int w = 0; w < 2; ++w) {
@@ -1122,10 +676,10 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_cell(const DevMap m, cons
                 for (int w = 0; w < 2; ++w) {
                     const Vec4u* bp = reinterpret_cast<const Vec4u*>(lp + pp[w]);
 #pragma unroll
-                    for (int v = 0; v < 3; ++v) {
-                        const Vec4u r = bp[v];
-                        qf[w][4 * v] = __uint_as_float(r.x); qf[w][4 * v + 1] = __uint_as_float(r.y);
-                        qf[w][4 * v + 2] = __uint_as_float(r.z); qf[w][4 * v + 3] = __uint_as_float(r.w);
+                    for (int u = 0; u < 3; ++u) {
+                        const Vec4u r = bp[u];
+                        qf[w][4 * u] = __uint_as_float(r.x); qf[w][4 * u + 1] = __uint_as_float(r.y);
+                        qf[w][4 * u + 2] = __uint_as_float(r.z); qf[w][4 * u + 3] = __uint_as_float(r.w);
                     }
                 }
 #pragma unroll
@@ -1141,114 +695,154 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_cell(const DevMap m, cons
                     j1 = c ? id : j1;
                 }
             }
-            // float32 distances are within 2^-20 relative (+ slack / 2) of the reference's float64 ones (see K1c)
             hard = true;
             if (j1 >= 0) {
                 const float slack = 4e-11f * (fabsf(ghx) + fabsf(ghy) + fabsf(ghz) + 1.0f);
-                const float r2 = m1 + m1 * 1.9073486328125e-06f + slack; // 2^-19
+                const float r2 = m1 + m1 * 1.9073486328125e-06f + slack; // 2^-19: no float64 distance of a block candidate's rival is below this
+                hr2 = r2;
                 // sqrt(r2) * 1.000001 + 1e-6 < rho, without the square root
                 const double rr = (rho - 1e-6) * 0.999999;
                 if (m2 > r2 && rr > 0.0 && (double)r2 < rr * rr) {
-                    const Pt3 q = lp[j1];
-                    const double ex = (double)q.x - gx, ey = (double)q.y - gy, ez = (double)q.z - gz;
-                    bd2 = (ex * ex + ey * ey) + ez * ez; // the reference's float64 value for the range test
                     bj = j1;
                     hard = false;
                 }
             }
         }
-        ELM_PHASE(10)
     }
-    // stage 2: the wave serves its undecided lanes one by one
-    double n_exact = 0.0;
-    {
-#ifdef ELM_SKIP_HARD
-        unsigned long long todo = 0;
-#else
-        unsigned long long todo = __ballot(hard);
-#endif
-        const int lane = (int)(threadIdx.x & 63);
-        while (todo) {
-            const int src = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const double hgx = lane_bcast(gx, src), hgy = lane_bcast(gy, src), hgz = lane_bcast(gz, src);
-            const unsigned hstart = lane_bcast(start, src), hcnt = lane_bcast(cnt, src);
-            const Pt3* __restrict__ hp = m.nbr_pts + hstart;
-            // pass 1: the float64 minimum (the reference's arithmetic).  Equal distances are almost never seen; when one
-            // is, pass 2 below settles it by the reference's visiting order.
-            double d_best = DBL_MAX;
-            unsigned k_best = 0xFFFFFFFFu;
-            bool tie = false;
-            for (unsigned base = 0; base < hcnt; base += 256) { // four independent coalesced loads per lane and round trip
+    // ---- stage 2: queue the undecided points in thread order
+    const unsigned long long hm = __ballot(hard);
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[wave] = (unsigned)__popcll(hm);
+    __syncthreads();
+    unsigned n_hard = 0, my_slot = 0;
+#pragma unroll
+    for (unsigned w = 0; w < kBlock / 64; ++w) {
+        my_slot += (w < wave) ? s_cnt[w] : 0u;
+        n_hard += s_cnt[w];
+    }
+    my_slot += (unsigned)__popcll(hm & ((1ull << lane) - 1ull));
+    if (n_hard) { // uniform
+        HardRec* __restrict__ s_rec = reinterpret_cast<HardRec*>(s_buf);
+        if (hard) {
+            HardRec r;
+            r.gx = gx; r.gy = gy; r.gz = gz; r.start = qp.start; r.cnt = qp.cnt; r.qid = qp.qid; r.r2 = hr2;
+            s_rec[my_slot] = r;
+        }
+        __syncthreads();
+        const unsigned rl = threadIdx.x & 15u, row = threadIdx.x >> 4; // 16 rows of 16 lanes
+        const double hc = 0.5 * m.voxel_size, inv_h = 2.0 / m.voxel_size;
+        (void)hc;
+        for (unsigned it = row; it < n_hard; it += kBlock / 16) {
+            const HardRec R = s_rec[it];
+            const int hvx = floor_key(R.gx, m), hvy = floor_key(R.gy, m), hvz = floor_key(R.gz, m);
+            const Pt3* __restrict__ hp = m.nbr_pts + R.start;
+            int sb = 0, se = 0;
+            bool ball = false;
+            if (R.r2 < __builtin_inff()) {
+                // every candidate within sqrt(r2) of g -- the nearest one and whatever ties with it -- has its cell inside the
+                // per-axis cell range of [g - r, g + r] (cell_of is monotonic; the lists were sorted with the same expression)
+                const double r = sqrt((double)R.r2) * 1.000001 + 1e-6;
+                const double ox = (double)(hvx - 1) * m.voxel_size, oy = (double)(hvy - 1) * m.voxel_size, oz = (double)(hvz - 1) * m.voxel_size;
+                const int lox = cell_of(R.gx - r, ox, inv_h), hix = cell_of(R.gx + r, ox, inv_h);
+                const int loy = cell_of(R.gy - r, oy, inv_h), hiy = cell_of(R.gy + r, oy, inv_h);
+                const int loz = cell_of(R.gz - r, oz, inv_h), hiz = cell_of(R.gz + r, oz, inv_h);
+                const int ny = hiy - loy + 1, ncol = (hix - lox + 1) * ny;
+                if (ncol <= 16) {
+                    ball = true;
+                    if ((int)rl < ncol) {
+                        const int cx = lox + (int)rl / ny, cy = loy + (int)rl % ny;
+                        const uint4 rec = *reinterpret_cast<const uint4*>(m.nbr_cell_off + (size_t)R.qid * kCellStride + (cx * kCellAxis + cy) * 8);
+                        sb = col_entry(rec, loz);
+                        se = col_entry(rec, hiz + 1);
+                    }
+                }
+            }
+            if (!ball) { // nothing found in stage 1 (or a ball wider than 16 columns): the whole list, split 16 ways
+                sb = (int)((R.cnt * rl) >> 4);
+                se = (int)((R.cnt * (rl + 1u)) >> 4);
+            }
+            // the reference's float64 walk over this lane's share; equal distances are settled by its visiting order: bucket
+            // rank (vhm.cpp:234-240), then insertion order (= global index)
+            double bd = DBL_MAX;
+            int bk = -1;
+            unsigned brank = 0xFFFFFFFFu, bgi = 0xFFFFFFFFu;
+            for (int k0 = sb; k0 < se; k0 += 4) {
                 Pt3 q[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) q[u] = hp[min(base + (unsigned)lane + 64u * u, hcnt - 1)];
+                for (int u = 0; u < 4; ++u) q[u] = hp[min(k0 + u, se - 1)];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const unsigned k = base + (unsigned)lane + 64u * u;
-                    const double ex = (double)q[u].x - hgx, ey = (double)q[u].y - hgy, ez = (double)q[u].z - hgz;
-                    const double dd = (ex * ex + ey * ey) + ez * ez;
-                    const double d2 = (k < hcnt) ? dd : DBL_MAX;
-                    tie = (d2 == d_best && k < hcnt) ? true : ((d2 < d_best) ? false : tie);
-                    k_best = (d2 < d_best) ? k : k_best;
-                    d_best = fmin(d2, d_best);
+                    const int k = k0 + u;
+                    const double ex = (double)q[u].x - R.gx, ey = (double)q[u].y - R.gy, ez = (double)q[u].z - R.gz;
+                    const double d2 = (ex * ex + ey * ey) + ez * ez;
+                    if (k >= se) continue;
+                    if (d2 < bd) {
+                        bd = d2; bk = k; brank = 0xFFFFFFFFu;
+                    } else if (d2 == bd) {
+                        if (brank == 0xFFFFFFFFu) {
+                            const Pt3 b = hp[bk];
+                            brank = visit_rank(b, hvx, hvy, hvz, m.voxel_size);
+                            bgi = m.nbr_idx[(size_t)R.start + bk];
+                        }
+                        const unsigned rk = visit_rank(q[u], hvx, hvy, hvz, m.voxel_size), gi = m.nbr_idx[(size_t)R.start + k];
+                        if (rk < brank || (rk == brank && gi < bgi)) { bk = k; brank = rk; bgi = gi; }
+                    }
                 }
             }
-            const double d_min = wave_min(d_best);
-            const unsigned long long at_min = __ballot(d_best == d_min);
-            const bool contested = (__popcll(at_min) != 1) || (__ballot(tie && d_best == d_min) != 0ull);
-            if (!contested) {
-                k_best = lane_bcast(k_best, __ffsll((long long)at_min) - 1);
-            } else {
-                const int hvx = lane_bcast(vx, src), hvy = lane_bcast(vy, src), hvz = lane_bcast(vz, src);
-                unsigned r_best = 0xFFFFFFFFu, g_best = 0xFFFFFFFFu;
-                k_best = 0xFFFFFFFFu;
-                for (unsigned k = (unsigned)lane; k < hcnt; k += 64) {
-                    const Pt3 q = hp[k];
-                    const double ex = (double)q.x - hgx, ey = (double)q.y - hgy, ez = (double)q.z - hgz;
-                    const double d2 = (ex * ex + ey * ey) + ez * ez;
-                    if (d2 != d_min) continue;
-                    const unsigned gi = m.nbr_idx[(size_t)hstart + k];
-                    const int kx = (int)((double)q.x / m.voxel_size), ky = (int)((double)q.y / m.voxel_size), kz = (int)((double)q.z / m.voxel_size);
-                    const unsigned rank = (unsigned)(((kx - hvx + 1) * 3 + (ky - hvy + 1)) * 3 + (kz - hvz + 1));
-                    if (rank < r_best || (rank == r_best && gi < g_best)) { r_best = rank; g_best = gi; k_best = k; }
+            const double dmin = row_min(bd);
+            const unsigned at = (unsigned)((__ballot(bk >= 0 && bd == dmin) >> (16u * ((threadIdx.x >> 4) & 3u))) & 0xFFFFull);
+            int win;
+            if (__popc(at) <= 1) {
+                win = __shfl(bk, (int)((threadIdx.x & 48u) + (unsigned)(__ffs((int)at) - 1)), 64);
+                if (at == 0u) win = -1;
+            } else { // the same float64 distance in several lanes: visiting order decides
+                if (bk >= 0 && bd == dmin) {
+                    if (brank == 0xFFFFFFFFu) {
+                        const Pt3 b = hp[bk];
+                        brank = visit_rank(b, hvx, hvy, hvz, m.voxel_size);
+                        bgi = m.nbr_idx[(size_t)R.start + bk];
+                    }
+                } else {
+                    brank = 0xFFFFFFFFu; bgi = 0xFFFFFFFFu; bk = -1;
                 }
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    const unsigned orank = (unsigned)__shfl_xor((int)r_best, off, 64), og = (unsigned)__shfl_xor((int)g_best, off, 64),
-                                   ok = (unsigned)__shfl_xor((int)k_best, off, 64);
-                    if (orank < r_best || (orank == r_best && og < g_best)) { r_best = orank; g_best = og; k_best = ok; }
+                for (int off = 8; off > 0; off >>= 1) {
+                    const unsigned orank = (unsigned)__shfl_xor((int)brank, off, 64), og = (unsigned)__shfl_xor((int)bgi, off, 64);
+                    const int ok = __shfl_xor(bk, off, 64);
+                    if (orank < brank || (orank == brank && og < bgi)) { brank = orank; bgi = og; bk = ok; }
                 }
+                win = bk;
             }
-            d_best = d_min;
-            if (lane == src) { bd2 = d_best; bj = (int)k_best; n_exact = 1.0; n_tested += (int)hcnt; }
+            const int walked = row_sum_int(se - sb);
+            if (rl == 0) { s_res[it] = win; s_tst[it] = walked; }
         }
+        __syncthreads();
+        if (hard) { bj = s_res[my_slot]; n_tested += s_tst[my_slot]; }
+        __syncthreads(); // the queue is dead: the reduction may overwrite it
     }
-    ELM_PHASE(12)
     if (valid) {
+        // the winner's float64 distance in the reference's arithmetic (range test, weight); no bucket at all: the reference's
+        // default PointStruct at the origin (vhm.cpp:37, QUIRK)
         float bx = 0.f, by = 0.f, bz = 0.f;
         int bidx = -1;
         if (bj >= 0) {
-            const Pt3 q = lp[bj];
+            const Pt3 q = m.nbr_pts[(size_t)qp.start + bj];
             bx = q.x; by = q.y; bz = q.z;
-            bidx = (METHOD == ELM_GICP) ? (int)m.nbr_idx[(size_t)start + bj] : 0;
+            bidx = (METHOD == ELM_GICP) ? (int)m.nbr_idx[(size_t)qp.start + bj] : 0;
         }
-#ifndef ELM_SKIP_PAIR
-        finish_point_pair<METHOD>(acc, m, S, rp, px, py, pz, gx, gy, gz, bd2, bx, by, bz, bidx);
-#else
-        acc[0] = bd2 + bx + by + bz + bidx;
-#endif
-        acc[29] = (double)cnt;  // candidates of the reference's walk
-        acc[30] = (double)nocc;
-        acc[31] = (double)n_tested + n_exact * kFallbackUnit;
-        ELM_PHASE(13)
+        const double ex = (double)bx - gx, ey = (double)by - gy, ez = (double)bz - gz;
+        const double bd2 = (ex * ex + ey * ey) + ez * ez;
+        if (METHOD == ELM_P2P) {
+            if (bd2 < rp.th2) pair_p2p(v, S.Rinv, px, py, pz, ex, ey, ez, bd2, rp);
+        } else {
+            finish_point_pair<METHOD>(v, m, S, rp, px, py, pz, gx, gy, gz, bd2, bx, by, bz, bidx);
+        }
+        v[NV - 3] = (double)qp.cnt;  // candidates of the reference's walk
+        v[NV - 2] = (double)qp.nocc; // occupied neighbour voxels
+        v[NV - 1] = (double)n_tested + (hard ? kFallbackUnit : 0.0); // high part: points served by stage 2
     }
-#ifdef ELM_SKIP_REDUCE
-    if (acc[0] + acc[29] + acc[31] == -1.0) partials[(size_t)L * kSums + threadIdx.x] = acc[1] + s_buf[threadIdx.x];
-#else
-    block_reduce_store_lds(acc, s_buf, partials + (size_t)L * kSums);
-#endif
-    ELM_PHASE(14)
+    block_reduce_to_lds<NV, kRedPass>(v, s_buf, s_red);
+    if (threadIdx.x < kSums) partials[(size_t)L * kSums + threadIdx.x] = (METHOD == ELM_P2P) ? p2p_expand(s_red, (int)threadIdx.x) : s_red[threadIdx.x];
 }
 
 // map build: sort every neighbourhood list by cell (stable: key = cell << 16 | position) and write its offset table.
@@ -1502,7 +1096,7 @@ __global__ __launch_bounds__(64) void k_init_state(ScanState* st, const double* 
 // Continuous batching: after the solve of an iteration, every slot whose registration has finished saves its final state
 // and takes the next pending registration (descriptor + initial guess), so every accumulate launch stays full until the
 // queue runs dry.  Slots are served in slot order by one thread: the assignment is deterministic (identical on every rank).
-constexpr int kMaxSlots = 1024;
+constexpr int kMaxSlots = 4096; // 32 KB of LDS for the two slot tables
 __global__ __launch_bounds__(1024) void k_stream_refill(ScanDesc* scans, ScanState* st, int slots, const QueueItem* __restrict__ queue,
                                                        const double* __restrict__ qT0, ScanState* out_state, StreamCtrl* ctrl, int first) {
     __shared__ int s_assign[kMaxSlots]; // registration to start in the slot, -1 = slot keeps going, -2 = slot goes idle
@@ -1921,20 +1515,6 @@ __global__ __launch_bounds__(256) void k_deskew(const float* __restrict__ xyz, c
 // ------------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------------
-int debug_phase_cycles(unsigned long long* out16, int reset) {
-#ifdef ELM_PHASE_TIMING
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[16] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) != hipSuccess) return -1;
-    }
-    return 1;
-#else
-    (void)out16; (void)reset;
-    return 0;
-#endif
-}
-
 void launch_stream_refill(hipStream_t s, ScanDesc* scans, ScanState* st, int slots, const QueueItem* queue, const double* qT0,
                           ScanState* out_state, StreamCtrl* ctrl, int first) {
     hipLaunchKernelGGL(k_stream_refill, dim3(1), dim3(1024), 0, s, scans, st, slots, queue, qT0, out_state, ctrl, first);
@@ -1943,36 +1523,19 @@ void launch_init_state(hipStream_t s, ScanState* st, const double* T0, int batch
     hipLaunchKernelGGL(k_init_state, dim3((batch + 63) / 64), dim3(64), 0, s, st, T0, batch, map_empty, active);
 }
 
-void launch_accumulate(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
-                       ScanState* st, double* partials, const RegParams& rp, int direct) {
+void launch_accumulate_direct(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
+                              ScanState* st, double* partials, const RegParams& rp) {
     dim3 g(total_blocks), b(kBlock);
 #define ELM_LAUNCH(K, M) hipLaunchKernelGGL((K<M>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp)
-    if (direct) {
-        switch (rp.method) {
-        case ELM_P2P: ELM_LAUNCH(k_accumulate_direct, ELM_P2P); break;
-        case ELM_GICP: ELM_LAUNCH(k_accumulate_direct, ELM_GICP); break;
-        case ELM_VGICP: ELM_LAUNCH(k_accumulate_direct, ELM_VGICP); break;
-        default: ELM_LAUNCH(k_accumulate_direct, ELM_AVGICP); break;
-        }
-    } else {
-        switch (rp.method) {
-        case ELM_P2P: ELM_LAUNCH(k_accumulate, ELM_P2P); break;
-        case ELM_GICP: ELM_LAUNCH(k_accumulate, ELM_GICP); break;
-        case ELM_VGICP: ELM_LAUNCH(k_accumulate, ELM_VGICP); break;
-        default: ELM_LAUNCH(k_accumulate, ELM_AVGICP); break;
-        }
+    switch (rp.method) {
+    case ELM_P2P: ELM_LAUNCH(k_accumulate_direct, ELM_P2P); break;
+    case ELM_GICP: ELM_LAUNCH(k_accumulate_direct, ELM_GICP); break;
+    case ELM_VGICP: ELM_LAUNCH(k_accumulate_direct, ELM_VGICP); break;
+    default: ELM_LAUNCH(k_accumulate_direct, ELM_AVGICP); break;
     }
 #undef ELM_LAUNCH
 }
 
-void launch_accumulate_nbr(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
-                           ScanState* st, double* partials, const RegParams& rp) {
-    dim3 g(total_blocks), b(kBlock);
-    if (rp.method == ELM_P2P)
-        hipLaunchKernelGGL((k_accumulate_nbr<ELM_P2P>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
-    else
-        hipLaunchKernelGGL((k_accumulate_nbr<ELM_GICP>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
-}
 void launch_accumulate_cell(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                             ScanState* st, double* partials, const RegParams& rp) {
     dim3 g(total_blocks), b(kBlock);
@@ -1981,6 +1544,7 @@ void launch_accumulate_cell(hipStream_t s, const DevMap& m, const ScanDesc* scan
     else
         hipLaunchKernelGGL((k_accumulate_cell<ELM_GICP>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
 }
+int stream_max_slots() { return kMaxSlots; }
 void launch_accumulate_vnbr(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                             ScanState* st, double* partials, const RegParams& rp) {
     if (rp.method == ELM_VGICP)

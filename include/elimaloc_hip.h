@@ -124,12 +124,12 @@ int elm_ctx_synchronize(elm_ctx* ctx);
 void* elm_ctx_stream(elm_ctx* ctx);
 
 /* Optional per-kernel timing with hipEvents recorded on the context stream around every accumulate launch and
- * every solve(+exchange) step of elm_register_batch*.  Totals accumulate until reset. */
+ * every solve(+exchange) step of elm_register_batch* / _stream.  Totals accumulate until reset. */
 typedef struct elm_profile {
     uint64_t accumulate_launches;
     uint64_t solve_steps;
-    double accumulate_ms; /* sum of the accumulate kernel spans */
-    double solve_ms;      /* sum of the reduce/solve (+ all-reduce) spans */
+    double accumulate_ms; /* sum of the spans of the main accumulate kernel (k_accumulate_cell / _vnbr / _direct) */
+    double solve_ms;      /* sum of the reduce/solve (+ all-reduce, + slot refill) spans */
 } elm_profile;
 int elm_ctx_set_profiling(elm_ctx* ctx, int enable);
 int elm_ctx_get_profile(elm_ctx* ctx, elm_profile* out, int reset);

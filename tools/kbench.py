@@ -42,13 +42,3 @@ print(f"kernel={os.environ.get('ELM_KERNEL','cell')} method={m.name} B={a.batch}
 print(f"  step {1e3*el/a.steps:.3f} ms  accumulate {p['accumulate_ms']/a.steps:.3f} ms  solve {p['solve_ms']/a.steps:.3f} ms  "
       f"ns/point-iter {1e6*p['accumulate_ms']/a.steps/pt_it:.3f}  us/scan-iter(131072) {1e3*p['accumulate_ms']/a.steps/pt_it*131072:.1f}  "
       f"fallback {fb:.0f}/{blocks:.0f} = {fb/blocks:.3f}  C={sum(r['n_cand_total'] for r in out)/pt_it:.1f} tested={sum(r['n_tested_total'] for r in out)/pt_it:.1f}")
-import ctypes as C
-from elimaloc_amd import _lib
-L = _lib.lib()
-if hasattr(L, "elm_debug_phase_cycles"):
-    buf = (C.c_ulonglong * 16)()
-    if L.elm_debug_phase_cycles(buf, 1) == 1:
-        tot = sum(buf) or 1
-        names = ["xform+bbox+mark", "probe", "prefix", "copy", "scan", "pair", "reduce", "fallback",
-                 "cell:xform", "cell:probe", "cell:own", "cell:box", "cell:decide", "cell:pair", "cell:reduce", "-"]
-        print("  phases (share of thread-0 cycles): " + "  ".join(f"{n} {100.0*buf[i]/tot:.1f}%" for i, n in enumerate(names)))
