@@ -53,18 +53,20 @@ def b_alg_reference(method, C, V):
     return 124.0 + 36.0 * V
 
 
-def kernel_bytes_model(method, tested, V, pairs):
-    """Bytes one scan point needs from THIS kernel's own data structures in one ICP iteration.
+def kernel_bytes_model(method, tested, V, pairs, grid=True):
+    """Bytes one scan point REQUESTS from this kernel's own data structures in one ICP iteration.
 
-    P2P/GICP (k_accumulate_cell): 16 scan point (float4) + 32 query-voxel hash slot + 4 x 16 column records + 12 per
-    distance-tested candidate + 12 winner re-read (+ 4 global index + 128 covariance record for GICP) + 1 (256-byte
-    partial record per 256-point workgroup).
+    P2P/GICP on the dense cell grid (k_accumulate_grid): 16 scan point (float4) + 4 walk-statistics word + 4 x 12 column
+    offset triples + 12 per distance-tested candidate + 12 winner re-read (+ 4 bucket index + 128 covariance record for
+    GICP) + 1 (256-byte partial record per 256-point workgroup).  On the neighbourhood lists (k_accumulate_cell): 32 hash
+    slot + 4 x 16 column records instead of the statistics word and the offset triples.
     VGICP (k_accumulate_vnbr): 16 + 32 slot + 32 per voxel-mean record (V = occupied neighbours) + 72 winner covariance + 1.
     AVGICP: 16 + 32 + 32 V + 72 per emitted pair + 1."""
+    index = (4.0 + 48.0) if grid else (32.0 + 64.0)
     if method == 0:
-        return 16.0 + 32.0 + 64.0 + 12.0 * tested + 12.0 + 1.0
+        return 16.0 + index + 12.0 * tested + 12.0 + 1.0
     if method == 1:
-        return 16.0 + 32.0 + 64.0 + 12.0 * tested + 12.0 + 4.0 + 128.0 + 1.0
+        return 16.0 + index + 12.0 * tested + 12.0 + 4.0 + 128.0 + 1.0
     if method == 2:
         return 16.0 + 32.0 + 32.0 * V + 72.0 + 1.0
     return 16.0 + 32.0 + 32.0 * V + 72.0 * pairs + 1.0
@@ -218,8 +220,11 @@ def main():
     V = float(sum(r["n_occ_total"] for r in out)) / max(pt_iters, 1)   # occupied neighbour voxels per point-iteration
     tested = float(sum(r["n_tested_total"] for r in out)) / max(pt_iters, 1)  # candidates this kernel distance-tests
     bytes_ref = b_alg_reference(int(method), C, V)
-    bytes_unit = kernel_bytes_model(int(method), tested, V, C if int(method) == 3 else 0.0)
-    kernel_name = (f"k_accumulate_vnbr<{METHOD_NAMES[int(method)]}>" if int(method) in (2, 3) else f"k_accumulate_cell<{METHOD_NAMES[int(method)]}>")
+    info = vm.info()
+    grid = int(info.nbr_entries) == int(info.n_points)  # the dense cell grid holds every map point once (the lists: 27 times)
+    bytes_unit = kernel_bytes_model(int(method), tested, V, C if int(method) == 3 else 0.0, grid)
+    kernel_name = (f"k_accumulate_vnbr<{METHOD_NAMES[int(method)]}>" if int(method) in (2, 3) else
+                   f"k_accumulate_{'grid' if grid else 'cell'}<{METHOD_NAMES[int(method)]}>")
     # dominant kernel: k_accumulate. Units one launch processes ON THIS GPU = its shard of the batch's live points.
     launches = max(prof["accumulate_launches"], 1)
     acc_ms_avg = prof["accumulate_ms"] / launches
@@ -292,8 +297,10 @@ def main():
             "measured_hbm_gbs": (traffic / (acc_ms_avg * 1e-3) / 1e9) if (traffic and acc_ms_avg > 0) else None,
             "measured_hbm_frac": (traffic / (acc_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and acc_ms_avg > 0) else None,
             "bytes_per_unit": bytes_unit,
-            "bytes_model": "this kernel's own structures: scan point + query slot + column records + 12 B x tested candidates + winner "
-                           "(+ payload) + partial record; DESIGN.md section 4",
+            "bytes_model": "bytes a point requests from this kernel's own structures: scan point + index words (cell offsets / hash slot + column "
+                           "records) + 12 B x tested candidates + winner (+ payload) + partial record; DESIGN.md section 4",
+            "search_index": "dense cell grid" if grid else "neighbourhood lists",
+            "index_bytes": int(info.device_bytes),
             "tested_candidates_per_point": tested,
             "units_per_launch": units_per_launch,
             "avg_launch_ms": acc_ms_avg,

@@ -92,8 +92,9 @@ struct elm_ctx {
     bool want_trace = false;
     bool in_flight = false;
     RegParams rp{};
-    int kernel_mode = 4; // accumulate kernels: 4 = cell-indexed neighbourhood lists (P2P/GICP) and voxel-mean lists (VGICP/AVGICP), the
-                         // default; 2 = the plain 27-probe walk of k_accumulate_direct (ELM_KERNEL=direct: in-kernel reference for tests)
+    int kernel_mode = 4; // accumulate kernels: 4 = dense cell grid, or cell-indexed neighbourhood lists when the grid does not fit
+                         // (P2P/GICP), voxel-mean lists (VGICP/AVGICP): the default; 3 = neighbourhood lists forced (ELM_KERNEL=lists);
+                         // 2 = the plain 27-probe walk of k_accumulate_direct (ELM_KERNEL=direct: in-kernel reference for tests)
     // optional hipEvent timing
     bool profiling = false;
     std::vector<hipEvent_t> events;
@@ -186,7 +187,7 @@ extern "C" int elm_ctx_create(int device_id, elm_ctx** out) {
         delete ctx;
         return ELM_ERR_DEVICE;
     }
-    if (const char* k = getenv("ELM_KERNEL")) ctx->kernel_mode = (strcmp(k, "direct") == 0) ? 2 : 4;
+    if (const char* k = getenv("ELM_KERNEL")) ctx->kernel_mode = (strcmp(k, "direct") == 0) ? 2 : (strcmp(k, "lists") == 0) ? 3 : 4;
     *out = ctx;
     return ELM_OK;
 }
@@ -259,6 +260,12 @@ struct elm_map {
     uint16_t* d_nbr_cell_off = nullptr;
     HashSlot* d_vqslots = nullptr;
     VoxRec* d_vnbr = nullptr;
+    Pt3* d_grid_pts = nullptr;        // dense cell grid (DevMap::grid_*), the default P2P / GICP search index
+    uint32_t* d_grid_idx = nullptr;
+    uint32_t* d_grid_start = nullptr;
+    uint32_t* d_vox_stat = nullptr;
+    bool has_grid = false;
+    bool grid_refused = false; // the bounding box needs more cells than the budget: neighbourhood lists instead
     bool has_vnbr = false; // voxel-mean lists (VGICP)
     bool has_cells = false; // lists sorted by half-voxel cell + offset tables (every list <= 1024 entries)
     bool has_nbr = false;
@@ -413,7 +420,8 @@ static void build_host(const float* xyz, size_t n, double voxel_size, int max_po
 static void map_free(elm_map* m) {
     if (!m) return;
     (void)hipSetDevice(m->ctx->device);
-    void* ptrs[] = {m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_pt_gicp, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off, m->d_vqslots, m->d_vnbr};
+    void* ptrs[] = {m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_pt_gicp, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off, m->d_vqslots, m->d_vnbr,
+                    m->d_grid_pts, m->d_grid_idx, m->d_grid_start, m->d_vox_stat};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete m;
@@ -632,8 +640,112 @@ static int build_voxel_neighbourhoods(elm_map* m) {
     return ELM_OK;
 }
 
+// Dense half-voxel cell grid (see DevMap::grid_*): the map points once, counting-sorted by cell on the host (init time), the
+// offsets of every cell of the bounding box (+ 2 cells of margin), and the dense voxel box of walk statistics.
+// ELM_ERR_UNSUPPORTED when the box needs more than max_cells cells (sparse or very large maps: the caller builds the
+// neighbourhood lists instead).
+static int build_cell_grid(elm_map* m, uint64_t max_cells) {
+    if (m->has_grid) return ELM_OK;
+    elm_ctx* ctx = m->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t n = m->dm.n_pts;
+    const double vs = m->dm.voxel_size;
+    if (n == 0 || m->dm.n_vox == 0) return ELM_ERR_UNSUPPORTED;
+    std::vector<float4> pts(n);
+    HIPCHK(ctx, hipMemcpy(pts.data(), m->d_pts, n * sizeof(float4), hipMemcpyDeviceToHost));
+    int32_t lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    std::vector<int32_t> cell(3 * n);
+    for (size_t i = 0; i < n; ++i) {
+        const float c3[3] = {pts[i].x, pts[i].y, pts[i].z};
+        for (int a = 0; a < 3; ++a) {
+            const int32_t c = grid_cell_of((double)c3[a], vs);
+            cell[3 * i + a] = c;
+            lo[a] = std::min(lo[a], c);
+            hi[a] = std::max(hi[a], c);
+        }
+    }
+    int64_t dim[3];
+    for (int a = 0; a < 3; ++a) {
+        lo[a] -= 2; hi[a] += 2; // a block or ball that reaches just past the outermost points stays inside the grid
+        dim[a] = (int64_t)hi[a] - lo[a] + 1;
+    }
+    const uint64_t cells = (uint64_t)dim[0] * (uint64_t)dim[1] * (uint64_t)dim[2];
+    if (dim[0] > 0x7FFFFFF0ll || dim[1] > 0x7FFFFFF0ll || dim[2] > 0x7FFFFFF0ll || cells > max_cells || cells > 0xFFFFFFF0ull) {
+        m->grid_refused = true;
+        return ELM_ERR_UNSUPPORTED;
+    }
+    std::vector<uint32_t> start(cells + 4, 0u), lin(n);
+    for (size_t i = 0; i < n; ++i) {
+        const uint64_t l = ((uint64_t)(cell[3 * i] - lo[0]) * (uint64_t)dim[1] + (uint64_t)(cell[3 * i + 1] - lo[1])) * (uint64_t)dim[2] + (uint64_t)(cell[3 * i + 2] - lo[2]);
+        lin[i] = (uint32_t)l;
+        start[l + 1]++;
+    }
+    std::vector<int32_t>().swap(cell);
+    for (uint64_t c = 0; c < cells; ++c) start[c + 1] += start[c]; // start[c] = first point of cell c, start[c + 1] = its end
+    for (uint64_t c = cells + 1; c < cells + 4; ++c) start[c] = (uint32_t)n;
+    std::vector<Pt3> gp(n + 4);
+    std::vector<uint32_t> gi(n);
+    {
+        std::vector<uint32_t> cur(start.begin(), start.begin() + cells);
+        for (size_t i = 0; i < n; ++i) { // bucket order in, so a cell keeps its points in bucket (= insertion) order
+            const uint32_t pos = cur[lin[i]]++;
+            gp[pos].x = pts[i].x; gp[pos].y = pts[i].y; gp[pos].z = pts[i].z;
+            gi[pos] = (uint32_t)i;
+        }
+    }
+    for (size_t k = n; k < n + 4; ++k) gp[k] = gp[n - 1]; // padding read (and masked) by the last block of four
+    std::vector<float4>().swap(pts);
+    std::vector<uint32_t>().swap(lin);
+    // dense voxel box of floor keys: a query with floor key f walks the stored keys f-1 .. f+1
+    int32_t klo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, khi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    for (uint32_t v = 0; v < m->dm.n_vox; ++v)
+        for (int a = 0; a < 3; ++a) {
+            klo[a] = std::min(klo[a], m->h_keys[3 * v + a]);
+            khi[a] = std::max(khi[a], m->h_keys[3 * v + a]);
+        }
+    const int64_t vd[3] = {(int64_t)khi[0] - klo[0] + 3, (int64_t)khi[1] - klo[1] + 3, (int64_t)khi[2] - klo[2] + 3};
+    const uint64_t vcells = (uint64_t)vd[0] * (uint64_t)vd[1] * (uint64_t)vd[2];
+    if (vcells > max_cells) {
+        m->grid_refused = true;
+        return ELM_ERR_UNSUPPORTED;
+    }
+#define GRID_CHK(call)                                                                        \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            ctx->last_error = std::string(#call) + ": " + hipGetErrorString(e_);              \
+            return ELM_ERR_DEVICE;                                                            \
+        }                                                                                     \
+    } while (0)
+    GRID_CHK(hipMalloc((void**)&m->d_grid_pts, (n + 4) * sizeof(Pt3)));
+    GRID_CHK(hipMalloc((void**)&m->d_grid_idx, std::max<size_t>(n * sizeof(uint32_t), 256)));
+    GRID_CHK(hipMalloc((void**)&m->d_grid_start, (cells + 4) * sizeof(uint32_t)));
+    GRID_CHK(hipMalloc((void**)&m->d_vox_stat, std::max<size_t>(vcells * sizeof(uint32_t), 256)));
+    GRID_CHK(hipMemcpy(m->d_grid_pts, gp.data(), (n + 4) * sizeof(Pt3), hipMemcpyHostToDevice));
+    GRID_CHK(hipMemcpy(m->d_grid_idx, gi.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    GRID_CHK(hipMemcpy(m->d_grid_start, start.data(), (cells + 4) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    m->dm.grid_pts = m->d_grid_pts;
+    m->dm.grid_idx = m->d_grid_idx;
+    m->dm.grid_start = m->d_grid_start;
+    m->dm.gx0 = lo[0]; m->dm.gy0 = lo[1]; m->dm.gz0 = lo[2];
+    m->dm.gnx = (int32_t)dim[0]; m->dm.gny = (int32_t)dim[1]; m->dm.gnz = (int32_t)dim[2];
+    m->dm.vox_stat = m->d_vox_stat;
+    m->dm.vx0 = klo[0] - 1; m->dm.vy0 = klo[1] - 1; m->dm.vz0 = klo[2] - 1;
+    m->dm.vnx = (int32_t)vd[0]; m->dm.vny = (int32_t)vd[1]; m->dm.vnz = (int32_t)vd[2];
+    (void)hipGetLastError();
+    launch_vox_stat(ctx->stream, m->dm, m->d_vox_stat);
+    GRID_CHK(hipGetLastError());
+    GRID_CHK(hipStreamSynchronize(ctx->stream));
+#undef GRID_CHK
+    m->has_grid = true;
+    m->info.device_bytes += (n + 4) * sizeof(Pt3) + n * sizeof(uint32_t) + (cells + 4) * sizeof(uint32_t) + vcells * sizeof(uint32_t);
+    m->info.n_query_voxels = vcells;
+    m->info.nbr_entries = n;
+    return ELM_OK;
+}
+
 // Neighbourhood lists (see DevMap): query voxels = every floor key within +-1 of a stored (trunc) key.
-extern "C" int elm_map_build_neighbourhoods(elm_map* m) {
+static int build_neighbourhood_lists(elm_map* m) {
     if (!m) return ELM_ERR_INVALID;
     if (m->has_nbr) return ELM_OK;
     elm_ctx* ctx = m->ctx;
@@ -732,6 +844,31 @@ extern "C" int elm_map_build_neighbourhoods(elm_map* m) {
     m->info.n_query_voxels = n_q;
     m->info.nbr_entries = total;
     return ELM_OK;
+}
+
+// The P2P / GICP search index of a map: the dense cell grid when its bounding box fits the cell budget (ELM_GRID_MAX_CELLS,
+// default 1.5e9 = 6 GB of offsets), the per-query-voxel neighbourhood lists otherwise (or with ELM_KERNEL=lists).
+static uint64_t grid_max_cells() {
+    if (const char* e = getenv("ELM_GRID_MAX_CELLS")) return strtoull(e, nullptr, 10);
+    return 1500000000ull;
+}
+static int build_search_index(elm_map* m, bool* use_grid) {
+    *use_grid = false;
+    elm_ctx* ctx = m->ctx;
+    if (ctx->kernel_mode == 4 && !m->grid_refused && m->dm.n_pts) {
+        const int rc = build_cell_grid(m, grid_max_cells());
+        if (rc == ELM_OK) {
+            *use_grid = true;
+            return ELM_OK;
+        }
+        if (rc != ELM_ERR_UNSUPPORTED) return rc;
+    }
+    return build_neighbourhood_lists(m);
+}
+extern "C" int elm_map_build_neighbourhoods(elm_map* m) {
+    if (!m) return ELM_ERR_INVALID;
+    bool g;
+    return build_search_index(m, &g);
 }
 
 extern "C" int elm_map_get_info(const elm_map* m, elm_map_info* info) {
@@ -953,12 +1090,13 @@ static int exchange(elm_ctx* ctx, double* d_sums, size_t count) {
 // One ICP iteration's correspondence + accumulation launch for `n_scans` scans / slots, bracketed by two profiling marks (the
 // solve span starts at the second).
 static int enqueue_accumulate(elm_ctx* ctx, const elm_map* map, const ScanDesc* dsc, int n_scans, uint32_t blocks, ScanState* st,
-                              const RegParams& rp, bool use_cells, bool use_vnbr) {
+                              const RegParams& rp, bool use_grid, bool use_cells, bool use_vnbr) {
     int rc;
     if ((rc = prof_mark(ctx)) != ELM_OK) return rc;
     double* partials = (double*)ctx->d_partials.p;
     if (blocks) {
-        if (use_cells) launch_accumulate_cell(ctx->stream, map->dm, dsc, n_scans, (int)blocks, st, partials, rp);
+        if (use_grid) launch_accumulate_grid(ctx->stream, map->dm, dsc, n_scans, (int)blocks, st, partials, rp);
+        else if (use_cells) launch_accumulate_cell(ctx->stream, map->dm, dsc, n_scans, (int)blocks, st, partials, rp);
         else if (use_vnbr) launch_accumulate_vnbr(ctx->stream, map->dm, dsc, n_scans, (int)blocks, st, partials, rp);
         else launch_accumulate_direct(ctx->stream, map->dm, dsc, n_scans, (int)blocks, st, partials, rp);
     }
@@ -1050,12 +1188,13 @@ extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_
 
     // P2P / GICP default to the cell-indexed neighbourhood lists; the lists are built on first use (init-time cost).  Maps whose
     // lists cannot be cell-sorted (a list beyond 1024 candidates: voxel caps above ~37 points) take the plain walk.
-    const bool use_nbr = !map_empty && ctx->kernel_mode == 4 && (method == ELM_P2P || method == ELM_GICP);
-    if (use_nbr && !map->has_nbr) {
-        if ((rc = elm_map_build_neighbourhoods(const_cast<elm_map*>(map))) != ELM_OK) return rc;
+    const bool use_nbr = !map_empty && ctx->kernel_mode != 2 && (method == ELM_P2P || method == ELM_GICP);
+    bool use_grid = use_nbr && ctx->kernel_mode == 4 && map->has_grid;
+    if (use_nbr && !use_grid && !map->has_nbr) {
+        if ((rc = build_search_index(const_cast<elm_map*>(map), &use_grid)) != ELM_OK) return rc;
     }
-    const bool use_cells = use_nbr && map->has_cells;
-    const bool use_vnbr = !map_empty && ctx->kernel_mode == 4 && (method == ELM_VGICP || method == ELM_AVGICP);
+    const bool use_cells = use_nbr && !use_grid && map->has_cells;
+    const bool use_vnbr = !map_empty && ctx->kernel_mode != 2 && (method == ELM_VGICP || method == ELM_AVGICP);
     if (use_vnbr && !map->has_vnbr) {
         if ((rc = build_voxel_neighbourhoods(const_cast<elm_map*>(map))) != ELM_OK) return rc;
     }
@@ -1071,7 +1210,7 @@ extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_
     ctx->events_used = 0;
     if (!map_empty) {
         for (int it = 0; it < cfg->max_iteration; ++it) {
-            if ((rc = enqueue_accumulate(ctx, map, dsc, batch, blocks, st, rp, use_cells, use_vnbr)) != ELM_OK) return rc;
+            if ((rc = enqueue_accumulate(ctx, map, dsc, batch, blocks, st, rp, use_grid, use_cells, use_vnbr)) != ELM_OK) return rc;
             if (distributed) {
                 launch_solve(ctx->stream, dsc, batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 1, d_active);
                 if ((rc = exchange(ctx, (double*)ctx->d_sums.p, (size_t)batch * kSums)) != ELM_OK) return rc;
@@ -1234,11 +1373,12 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     rp.uniform_blocks = cap_blocks; // every slot owns cap_blocks workgroups
     rp._pad = 0;
     ctx->rp = rp;
-    const bool use_nbr = ctx->kernel_mode == 4 && (method == ELM_P2P || method == ELM_GICP);
-    if (use_nbr && !map->has_nbr)
-        if ((rc = elm_map_build_neighbourhoods(const_cast<elm_map*>(map))) != ELM_OK) return rc;
-    const bool use_cells = use_nbr && map->has_cells;
-    const bool use_vnbr = ctx->kernel_mode == 4 && (method == ELM_VGICP || method == ELM_AVGICP);
+    const bool use_nbr = ctx->kernel_mode != 2 && (method == ELM_P2P || method == ELM_GICP);
+    bool use_grid = use_nbr && ctx->kernel_mode == 4 && map->has_grid;
+    if (use_nbr && !use_grid && !map->has_nbr)
+        if ((rc = build_search_index(const_cast<elm_map*>(map), &use_grid)) != ELM_OK) return rc;
+    const bool use_cells = use_nbr && !use_grid && map->has_cells;
+    const bool use_vnbr = ctx->kernel_mode != 2 && (method == ELM_VGICP || method == ELM_AVGICP);
     if (use_vnbr && !map->has_vnbr)
         if ((rc = build_voxel_neighbourhoods(const_cast<elm_map*>(map))) != ELM_OK) return rc;
 
@@ -1257,7 +1397,7 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     const int predicted = same_shape ? ctx->stream_hint_iters : 0;
     int it = 0;
     for (; it < hard_limit; ++it) {
-        if ((rc = enqueue_accumulate(ctx, map, dsc, S, blocks, st, rp, use_cells, use_vnbr)) != ELM_OK) return rc;
+        if ((rc = enqueue_accumulate(ctx, map, dsc, S, blocks, st, rp, use_grid, use_cells, use_vnbr)) != ELM_OK) return rc;
         if (distributed) {
             launch_solve(ctx->stream, dsc, S, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 1, d_active);
             if ((rc = exchange(ctx, (double*)ctx->d_sums.p, (size_t)S * kSums)) != ELM_OK) return rc;

@@ -59,6 +59,21 @@ struct DevMap {
     const VoxRec* vnbr;
     const uint16_t* nbr_cell_off; // [n_q][224]: every list is sorted by half-voxel cell (6x6x6 grid, clamped); cell c =
                                   // entries [off[c], off[c+1]) of the list
+    // dense half-voxel cell grid over the map's bounding box (optional; default search index when it fits the memory budget):
+    // the map points ONCE, sorted by cell (x-major, y, z fastest -- the cells iz0..iz1 of one (ix, iy) column are one contiguous
+    // range), 12 bytes each; grid_start[linear cell] = first point of the cell, the next entry = its end.  Cells follow the
+    // STORED (truncated) voxel keys: bucket k > 0 is cells {2k, 2k+1}, bucket 0 (two voxels wide) is {-2,-1,0,1}, bucket k < 0 is
+    // {2k-2, 2k-1}; geometrically cell c is [c h, (c+1) h], h = voxel_size / 2.
+    const Pt3* grid_pts;        // [n_pts + 4]
+    const uint32_t* grid_idx;   // [n_pts] bucket-order index of every grid point (GICP payload, insertion order for exact ties)
+    const uint32_t* grid_start; // [gnx * gny * gnz + 4]
+    int32_t gx0, gy0, gz0;      // cell coordinates of grid entry (0, 0, 0)
+    int32_t gnx, gny, gnz;
+    // dense voxel box of the floor keys a query can have near the map: cnt27 | nocc27 << 16 of the reference's 27-voxel walk
+    // (the work counters, and cnt27 == 0 -> no neighbour bucket at all -> the reference's origin default, vhm.cpp:37)
+    const uint32_t* vox_stat;   // [vnx * vny * vnz]
+    int32_t vx0, vy0, vz0;
+    int32_t vnx, vny, vnz;
 };
 
 __host__ __device__ __forceinline__ uint32_t hash3(int32_t x, int32_t y, int32_t z) {
@@ -141,6 +156,18 @@ void launch_vnbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint
 void launch_accumulate_cell(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                             ScanState* st, double* partials, const RegParams& rp);
 int stream_max_slots(); // slots one elm_register_stream call can iterate concurrently
+void launch_accumulate_grid(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
+                            ScanState* st, double* partials, const RegParams& rp);
+void launch_vox_stat(hipStream_t s, const DevMap& m, uint32_t* out); // fills DevMap::vox_stat's box (m.vx0.., m.vnx..)
+// half-voxel cell of a stored coordinate (host + device; the binning of DevMap::grid_pts)
+__host__ __device__ inline int grid_cell_of(double a, double voxel_size) {
+    const double t = a / voxel_size; // the reference's own key arithmetic (vhm.cpp:275), truncated below
+    const int k = (int)t;
+    if (k > 0) return 2 * k + ((t - (double)k >= 0.5) ? 1 : 0);
+    if (k < 0) return 2 * k - 2 + ((t - (double)k > -0.5) ? 1 : 0);
+    if (t >= 0.0) return (t >= 0.5) ? 1 : 0;
+    return (t > -0.5) ? -1 : -2;
+}
 void launch_nbr_cellsort(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets,
                          const uint32_t* counts, Pt3* pts, uint32_t* idx, uint16_t* cell_off);
 size_t nbr_cell_stride();

@@ -845,6 +845,317 @@ __global__ __launch_bounds__(kBlock, ELM_CELL_WAVES) void k_accumulate_cell(cons
     if (threadIdx.x < kSums) partials[(size_t)L * kSums + threadIdx.x] = (METHOD == ELM_P2P) ? p2p_expand(s_red, (int)threadIdx.x) : s_red[threadIdx.x];
 }
 
+// ---- K1g: dense cell grid (default search index for P2P / GICP) ---------------------------------------------------------
+// The same two stages as k_accumulate_cell on DevMap::grid_*: the map points stored ONCE, sorted by half-voxel cell, addressed
+// without a hash probe -- the query's cell coordinates ARE the address of its column's offsets -- so a point costs its scan
+// record, four 12-byte offset triples and its ~25 candidates, and neighbouring queries share every line they touch.
+// The reference's candidate set is not the geometric neighbourhood: a query with floor key f sees the buckets with STORED
+// (truncated) keys f-1..f+1 (vhm.hpp:176-180 vs vhm.cpp:275), i.e. (f-2, f+1] voxel sizes on a negative axis.  The grid's cells
+// follow the stored keys, so that set is a cell range [alo, ahi] per axis: blocks and balls are clipped to it, and a clipped
+// face does not bound rho (nothing eligible lies beyond it).
+
+// per axis: the query's floor key f, the allowed cell range of the reference's walk, and 2 g / voxel_size (cell coordinate)
+struct GridAxis {
+    int f, alo, ahi;
+    double t;
+};
+__device__ __forceinline__ GridAxis grid_axis(double g, const DevMap& m) {
+    GridAxis a;
+    const double q = (m.inv_vs_exact != 0.0) ? g * m.inv_vs_exact : g / m.voxel_size; // == g / voxel_size bit for bit
+    a.f = (int)floor(q); // PointToVoxel (vhm.hpp:176-180)
+    a.t = q + q;         // exact: cell coordinate, floor(t) in {2f, 2f+1}
+    const int kl = a.f - 1, kh = a.f + 1;
+    a.alo = kl > 0 ? 2 * kl : (kl == 0 ? -2 : 2 * kl - 2);
+    a.ahi = kh > 0 ? 2 * kh + 1 : (kh == 0 ? 1 : 2 * kh - 1);
+    return a;
+}
+// the (clipped) two-cell span the query leans into and the distance to its open faces
+__device__ __forceinline__ void grid_lean(const GridAxis& a, double g, double h, int& blo, int& bhi, double& rho) {
+    const double fl = floor(a.t);
+    const int cg = (int)fl;
+    const int c0 = (a.t - fl >= 0.5) ? cg : cg - 1;
+    blo = max(c0, a.alo);
+    bhi = min(c0 + 1, a.ahi);
+    const double dlo = (blo == a.alo) ? DBL_MAX : g - (double)blo * h;
+    const double dhi = (bhi == a.ahi) ? DBL_MAX : (double)(bhi + 1) * h - g;
+    rho = fmin(rho, fmin(dlo, dhi));
+}
+
+struct GridHardRec {
+    double gx, gy, gz;
+    float r2; // upper bound of the squared nearest-neighbour distance (inf: nothing found yet)
+    float _pad;
+};
+
+template <int METHOD>
+__global__ __launch_bounds__(kBlock, ELM_CELL_WAVES) void k_accumulate_grid(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
+                                                                            unsigned total_blocks, const ScanState* __restrict__ st,
+                                                                            double* __restrict__ partials, const RegParams rp) {
+    constexpr int NV = (METHOD == ELM_P2P) ? kP2PVals : kSums;
+    __shared__ double s_buf[kRedPass * kBlock]; // stage 2: the queue of undecided points; afterwards the reduction's transpose buffer
+    __shared__ double s_red[kSums];
+    __shared__ int s_res[kBlock];
+    __shared__ int s_tst[kBlock];
+    __shared__ unsigned s_cnt[kBlock / 64];
+    const unsigned L = xcd_remap(blockIdx.x, total_blocks);
+    const int s = find_scan(scans, batch, L, rp);
+    const ScanState& S = st[s];
+    if (S.done) return;
+    const ScanDesc sd = scans[s];
+    const unsigned i = (L - sd.blk_begin) * kBlock + threadIdx.x;
+    const bool valid = i < sd.n;
+    double v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = 0.0;
+    double px = 0.0, py = 0.0, pz = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
+    unsigned stat = 0;
+    int bj = -1;
+    int n_tested = 0;
+    float hr2 = __builtin_inff();
+    bool hard = false;
+    const double h = 0.5 * m.voxel_size;
+    const Pt3* __restrict__ lp = m.grid_pts;
+    if (valid) {
+        const float4 pf = sd.pts[i];
+        px = pf.x; py = pf.y; pz = pf.z;
+        gx = ((S.T[0] * px + S.T[4] * py) + S.T[8] * pz) + S.T[12];
+        gy = ((S.T[1] * px + S.T[5] * py) + S.T[9] * pz) + S.T[13];
+        gz = ((S.T[2] * px + S.T[6] * py) + S.T[10] * pz) + S.T[14];
+        const GridAxis ax = grid_axis(gx, m), ay = grid_axis(gy, m), az = grid_axis(gz, m);
+        {
+            const int ux = ax.f - m.vx0, uy = ay.f - m.vy0, uz = az.f - m.vz0;
+            if ((unsigned)ux < (unsigned)m.vnx && (unsigned)uy < (unsigned)m.vny && (unsigned)uz < (unsigned)m.vnz)
+                stat = m.vox_stat[((size_t)ux * m.vny + uy) * m.vnz + uz];
+        }
+        double rho = DBL_MAX;
+        int bx0, bx1, by0, by1, bz0, bz1;
+        grid_lean(ax, gx, h, bx0, bx1, rho);
+        grid_lean(ay, gy, h, by0, by1, rho);
+        grid_lean(az, gz, h, bz0, bz1, rho);
+        // block cells relative to the grid; a block that leaves the grid (or came out empty) goes to stage 2, which clamps
+        const int rx0 = bx0 - m.gx0, rx1 = bx1 - m.gx0, ry0 = by0 - m.gy0, ry1 = by1 - m.gy0, rz0 = bz0 - m.gz0, rz1 = bz1 - m.gz0;
+        const bool inside = rx0 >= 0 && rx1 < m.gnx && rx0 <= rx1 && ry0 >= 0 && ry1 < m.gny && ry0 <= ry1 && rz0 >= 0 && rz1 < m.gnz && rz0 <= rz1;
+        // the four (ix, iy) columns of the block: one contiguous range [cell bz0, cell bz1] each
+        int sb[4], se[4], cb[5];
+        cb[0] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cx = (k >> 1) ? rx1 : rx0, cy = (k & 1) ? ry1 : ry0;
+            const bool dup = ((k >> 1) && rx1 == rx0) || ((k & 1) && ry1 == ry0); // a span clipped to one cell
+            sb[k] = 0; se[k] = 0;
+            if (inside && !dup) {
+                const uint32_t* e = m.grid_start + (((size_t)cx * m.gny + cy) * m.gnz + rz0);
+                const unsigned s0 = e[0], s1 = e[1], s2 = e[2]; // one 12-byte load
+                sb[k] = (int)s0;
+                se[k] = (int)((rz1 > rz0) ? s2 : s1);
+            }
+        }
+        if (stat & 0xFFFFu) { // some bucket among the 27: search (else the reference's origin default, vhm.cpp:37)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cb[k + 1] = cb[k] + ((se[k] - sb[k] + 3) >> 2); // blocks of 4 candidates
+            const int nblk = cb[4];
+            n_tested = ((se[0] - sb[0]) + (se[1] - sb[1])) + ((se[2] - sb[2]) + (se[3] - sb[3]));
+            const float ghx = (float)gx, ghy = (float)gy, ghz = (float)gz;
+            const float glx = (float)(gx - (double)ghx), gly = (float)(gy - (double)ghy), glz = (float)(gz - (double)ghz);
+            float m1 = __builtin_inff(), m2 = __builtin_inff();
+            int j1 = -1;
+            for (int t0 = 0; t0 < nblk; t0 += 2) { // two blocks = 8 candidates per round trip
+                int pp[2], pe[2];
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const int t = t0 + w;
+                    int b_ = sb[3] - 4 * cb[3], e_ = se[3];
+#pragma unroll
+                    for (int k = 2; k >= 0; --k) {
+                        const bool lt = t < cb[k + 1];
+                        b_ = lt ? (sb[k] - 4 * cb[k]) : b_;
+                        e_ = lt ? se[k] : e_;
+                    }
+                    pp[w] = (t < nblk) ? b_ + 4 * t : 0;
+                    pe[w] = (t < nblk) ? e_ : 0; // empty block when past the end
+                }
+                float qf[2][12];
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const Vec4u* bp = reinterpret_cast<const Vec4u*>(lp + pp[w]);
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        const Vec4u r = bp[u];
+                        qf[w][4 * u] = __uint_as_float(r.x); qf[w][4 * u + 1] = __uint_as_float(r.y);
+                        qf[w][4 * u + 2] = __uint_as_float(r.z); qf[w][4 * u + 3] = __uint_as_float(r.w);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int id = pp[u >> 2] + (u & 3);
+                    const float qx = qf[u >> 2][3 * (u & 3)], qy = qf[u >> 2][3 * (u & 3) + 1], qz = qf[u >> 2][3 * (u & 3) + 2];
+                    const float ex = (qx - ghx) - glx, ey = (qy - ghy) - gly, ez = (qz - ghz) - glz;
+                    const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+                    const float d = (id < pe[u >> 2]) ? dd : __builtin_inff();
+                    m2 = fminf(m2, fmaxf(d, m1));
+                    const bool c = d < m1;
+                    m1 = c ? d : m1;
+                    j1 = c ? id : j1;
+                }
+            }
+            hard = true;
+            if (j1 >= 0) {
+                const float slack = 4e-11f * (fabsf(ghx) + fabsf(ghy) + fabsf(ghz) + 1.0f);
+                const float r2 = m1 + m1 * 1.9073486328125e-06f + slack; // 2^-19
+                hr2 = r2;
+                const double rr = (rho - 1e-6) * 0.999999; // sqrt(r2) * 1.000001 + 1e-6 < rho, without the square root
+                if (m2 > r2 && rr > 0.0 && (double)r2 < rr * rr) {
+                    bj = j1;
+                    hard = false;
+                }
+            }
+        }
+    }
+    // ---- stage 2: queue the undecided points in thread order, 16 lanes per point
+    const unsigned long long hm = __ballot(hard);
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[wave] = (unsigned)__popcll(hm);
+    __syncthreads();
+    unsigned n_hard = 0, my_slot = 0;
+#pragma unroll
+    for (unsigned w = 0; w < kBlock / 64; ++w) {
+        my_slot += (w < wave) ? s_cnt[w] : 0u;
+        n_hard += s_cnt[w];
+    }
+    my_slot += (unsigned)__popcll(hm & ((1ull << lane) - 1ull));
+    if (n_hard) { // uniform
+        GridHardRec* __restrict__ s_rec = reinterpret_cast<GridHardRec*>(s_buf);
+        if (hard) {
+            GridHardRec r;
+            r.gx = gx; r.gy = gy; r.gz = gz; r.r2 = hr2; r._pad = 0.f;
+            s_rec[my_slot] = r;
+        }
+        __syncthreads();
+        const unsigned rl = threadIdx.x & 15u, row = threadIdx.x >> 4; // 16 rows of 16 lanes
+        for (unsigned it = row; it < n_hard; it += kBlock / 16) {
+            const GridHardRec R = s_rec[it];
+            const GridAxis ax = grid_axis(R.gx, m), ay = grid_axis(R.gy, m), az = grid_axis(R.gz, m);
+            int lox = ax.alo, hix = ax.ahi, loy = ay.alo, hiy = ay.ahi, loz = az.alo, hiz = az.ahi;
+            if (R.r2 < __builtin_inff()) {
+                // every candidate within sqrt(r2) of g -- the nearest one and whatever ties with it -- has its cell inside the
+                // per-axis cell range of [g - r, g + r] (1e-6 of margin: a stored coordinate exactly on a cell face counts to the
+                // cell further from zero, grid_cell_of)
+                const double r = sqrt((double)R.r2) * 1.000001 + 1e-6;
+                const double inv_h = 2.0 / m.voxel_size;
+                lox = max(lox, (int)floor((R.gx - r) * inv_h) - 0); hix = min(hix, (int)floor((R.gx + r) * inv_h));
+                loy = max(loy, (int)floor((R.gy - r) * inv_h) - 0); hiy = min(hiy, (int)floor((R.gy + r) * inv_h));
+                loz = max(loz, (int)floor((R.gz - r) * inv_h) - 0); hiz = min(hiz, (int)floor((R.gz + r) * inv_h));
+            }
+            lox = max(lox - m.gx0, 0); hix = min(hix - m.gx0, m.gnx - 1);
+            loy = max(loy - m.gy0, 0); hiy = min(hiy - m.gy0, m.gny - 1);
+            loz = max(loz - m.gz0, 0); hiz = min(hiz - m.gz0, m.gnz - 1);
+            const int nx = hix - lox + 1, ny = hiy - loy + 1, nz = hiz - loz + 1;
+            const int ncol = (nx > 0 && ny > 0 && nz > 0) ? nx * ny : 0;
+            // the reference's float64 walk over this lane's columns; equal distances are settled by its visiting order: bucket
+            // rank (vhm.cpp:234-240), then insertion order (= bucket-order index)
+            double bd = DBL_MAX;
+            int bk = -1, walked = 0;
+            unsigned brank = 0xFFFFFFFFu, bgi = 0xFFFFFFFFu;
+            for (int c = (int)rl; c < ncol; c += 16) {
+                const int cx = lox + c / ny, cy = loy + c % ny;
+                const uint32_t* e = m.grid_start + (((size_t)cx * m.gny + cy) * m.gnz + loz);
+                const int sb = (int)e[0], se = (int)e[nz];
+                walked += se - sb;
+                for (int k0 = sb; k0 < se; k0 += 4) {
+                    Pt3 q[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) q[u] = lp[min(k0 + u, se - 1)];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = k0 + u;
+                        const double ex = (double)q[u].x - R.gx, ey = (double)q[u].y - R.gy, ez = (double)q[u].z - R.gz;
+                        const double d2 = (ex * ex + ey * ey) + ez * ez;
+                        if (k >= se) continue;
+                        if (d2 < bd) {
+                            bd = d2; bk = k; brank = 0xFFFFFFFFu;
+                        } else if (d2 == bd) {
+                            if (brank == 0xFFFFFFFFu) {
+                                brank = visit_rank(lp[bk], ax.f, ay.f, az.f, m.voxel_size);
+                                bgi = m.grid_idx[bk];
+                            }
+                            const unsigned rk = visit_rank(q[u], ax.f, ay.f, az.f, m.voxel_size), gi = m.grid_idx[k];
+                            if (rk < brank || (rk == brank && gi < bgi)) { bk = k; brank = rk; bgi = gi; }
+                        }
+                    }
+                }
+            }
+            const double dmin = row_min(bd);
+            const unsigned at = (unsigned)((__ballot(bk >= 0 && bd == dmin) >> (16u * ((threadIdx.x >> 4) & 3u))) & 0xFFFFull);
+            int win;
+            if (__popc(at) <= 1) {
+                win = __shfl(bk, (int)((threadIdx.x & 48u) + (unsigned)(__ffs((int)at) - 1)), 64);
+                if (at == 0u) win = -1;
+            } else { // the same float64 distance in several lanes: visiting order decides
+                if (bk >= 0 && bd == dmin) {
+                    if (brank == 0xFFFFFFFFu) {
+                        brank = visit_rank(lp[bk], ax.f, ay.f, az.f, m.voxel_size);
+                        bgi = m.grid_idx[bk];
+                    }
+                } else {
+                    brank = 0xFFFFFFFFu; bgi = 0xFFFFFFFFu; bk = -1;
+                }
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) {
+                    const unsigned orank = (unsigned)__shfl_xor((int)brank, off, 64), og = (unsigned)__shfl_xor((int)bgi, off, 64);
+                    const int ok = __shfl_xor(bk, off, 64);
+                    if (orank < brank || (orank == brank && og < bgi)) { brank = orank; bgi = og; bk = ok; }
+                }
+                win = bk;
+            }
+            walked = row_sum_int(walked);
+            if (rl == 0) { s_res[it] = win; s_tst[it] = walked; }
+        }
+        __syncthreads();
+        if (hard) { bj = s_res[my_slot]; n_tested += s_tst[my_slot]; }
+        __syncthreads(); // the queue is dead: the reduction may overwrite it
+    }
+    if (valid) {
+        // the winner's float64 distance in the reference's arithmetic (range test, weight); no bucket at all: the reference's
+        // default PointStruct at the origin (vhm.cpp:37, QUIRK)
+        float bx = 0.f, by = 0.f, bz = 0.f;
+        int bidx = -1;
+        if (bj >= 0) {
+            const Pt3 q = lp[bj];
+            bx = q.x; by = q.y; bz = q.z;
+            bidx = (METHOD == ELM_GICP) ? (int)m.grid_idx[bj] : 0;
+        }
+        const double ex = (double)bx - gx, ey = (double)by - gy, ez = (double)bz - gz;
+        const double bd2 = (ex * ex + ey * ey) + ez * ez;
+        if (METHOD == ELM_P2P) {
+            if (bd2 < rp.th2) pair_p2p(v, S.Rinv, px, py, pz, ex, ey, ez, bd2, rp);
+        } else {
+            finish_point_pair<METHOD>(v, m, S, rp, px, py, pz, gx, gy, gz, bd2, bx, by, bz, bidx);
+        }
+        v[NV - 3] = (double)(stat & 0xFFFFu); // candidates of the reference's walk
+        v[NV - 2] = (double)(stat >> 16);     // occupied neighbour voxels
+        v[NV - 1] = (double)n_tested + (hard ? kFallbackUnit : 0.0); // high part: points served by stage 2
+    }
+    block_reduce_to_lds<NV, kRedPass>(v, s_buf, s_red);
+    if (threadIdx.x < kSums) partials[(size_t)L * kSums + threadIdx.x] = (METHOD == ELM_P2P) ? p2p_expand(s_red, (int)threadIdx.x) : s_red[threadIdx.x];
+}
+
+// map build: cnt27 | nocc27 << 16 for every voxel of the dense floor-key box (see DevMap::vox_stat)
+__global__ __launch_bounds__(256) void k_vox_stat(const DevMap m, uint32_t* __restrict__ out) {
+    const size_t n = (size_t)m.vnx * m.vny * m.vnz;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int uz = (int)(idx % m.vnz), uy = (int)((idx / m.vnz) % m.vny), ux = (int)(idx / ((size_t)m.vnz * m.vny));
+    const int vx = ux + m.vx0, vy = uy + m.vy0, vz = uz + m.vz0;
+    unsigned c = 0, o = 0;
+    for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dz = -1; dz <= 1; ++dz) {
+                const Probe pr = probe_voxel(m, vx + dx, vy + dy, vz + dz);
+                if (pr.vid >= 0 && pr.cnt > 0) { c += pr.cnt; ++o; }
+            }
+    out[idx] = (c > 0xFFFFu ? 0xFFFFu : c) | (o << 16);
+}
+
 // map build: sort every neighbourhood list by cell (stable: key = cell << 16 | position) and write its offset table.
 // One 64-lane workgroup per query voxel, bitonic sort of <= 1024 keys in LDS.
 __global__ __launch_bounds__(64) void k_nbr_cellsort(const DevMap m, const int32_t* __restrict__ qkeys, unsigned n_q,
@@ -1543,6 +1854,18 @@ void launch_accumulate_cell(hipStream_t s, const DevMap& m, const ScanDesc* scan
         hipLaunchKernelGGL((k_accumulate_cell<ELM_P2P>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
     else
         hipLaunchKernelGGL((k_accumulate_cell<ELM_GICP>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
+}
+void launch_accumulate_grid(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
+                            ScanState* st, double* partials, const RegParams& rp) {
+    dim3 g(total_blocks), b(kBlock);
+    if (rp.method == ELM_P2P)
+        hipLaunchKernelGGL((k_accumulate_grid<ELM_P2P>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
+    else
+        hipLaunchKernelGGL((k_accumulate_grid<ELM_GICP>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
+}
+void launch_vox_stat(hipStream_t s, const DevMap& m, uint32_t* out) {
+    const size_t n = (size_t)m.vnx * m.vny * m.vnz;
+    hipLaunchKernelGGL(k_vox_stat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, m, out);
 }
 int stream_max_slots() { return kMaxSlots; }
 void launch_accumulate_vnbr(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,

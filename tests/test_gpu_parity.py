@@ -384,8 +384,8 @@ def test_rccl_single_rank_allreduce_path(ctx, oracle, world100k):
 
 def test_full_size_c3_gicp(ctx, oracle):
     """BASELINE config C3 (GICP with per-point 3x3 covariances, 131072-pt scan vs 10M-pt map): the point-covariance
-    kernel over 10M points, the neighbourhood-list layout (270M entries), and the registration against the oracle run
-    on the part of the map the scan can reach."""
+    kernel over 10M points, the dense cell grid over the whole map, and the registration against the oracle run on the
+    part of the map the scan can reach."""
     from elimaloc_amd.registration import Registration, RegistrationConfig, IcpMethod, VoxelHashMap
     world = synth.make_world(10_000_000, seed=1001)
     vm = VoxelHashMap(1.0, 30, ctx)
@@ -395,7 +395,7 @@ def test_full_size_c3_gicp(ctx, oracle):
     T0 = synth.perturb(T_true, seed=3005)
     pose, ok, fit, cov, det = Registration(RegistrationConfig(icp_method=IcpMethod.GICP), ctx).RunRegister(scan, vm, T0, trace=True)
     info = vm.info()
-    assert info.nbr_entries > 26 * info.n_points  # 27 buckets per query voxel, built lazily by the first registration
+    assert info.nbr_entries == info.n_points  # the dense cell grid (every map point once), built lazily by the first registration
     near = world[np.linalg.norm(world[:, :2] - T_true[:2, 3], axis=1) < 75.0]
     om = oracle.Map(1.0, 30)
     om.add_points(near)
@@ -428,7 +428,7 @@ def test_full_size_c4_vgicp_shape(ctx, oracle):
     _compare_run(det, ref)
 
 
-@pytest.mark.parametrize("kernel_env", ["cell", "direct"])
+@pytest.mark.parametrize("kernel_env", ["grid", "lists", "direct"])
 @pytest.mark.parametrize("voxel_size,max_pts,th,method", [
     (0.5, 30, 5.0, 0),    # finer voxels
     (1.5, 50, 5.0, 1),    # README-recommended 50 points per voxel (buckets > 32 points), GICP
@@ -474,7 +474,7 @@ def _tie_world():
     return lattice, scan
 
 
-@pytest.mark.parametrize("kernel_env", ["cell", "direct"])
+@pytest.mark.parametrize("kernel_env", ["grid", "lists", "direct"])
 @pytest.mark.parametrize("method", [0, 1, 2])
 def test_exact_ties_follow_the_reference_visiting_order(oracle, method, kernel_env, monkeypatch):
     """Equal float64 distances: the reference keeps the FIRST strict minimum of its walk (27 voxels x-major..z-minor,
@@ -493,7 +493,7 @@ def test_exact_ties_follow_the_reference_visiting_order(oracle, method, kernel_e
         ref = oracle.register(om, scan, T0, oracle.default_config(method, max_iteration=3, icp_termination_threshold_m=0.0,
                                                                   min_overlap_ratio=0.0, max_fitness_score=10.0))
         _compare_run(det, ref)
-        if kernel_env == "cell" and method in (0, 1):
+        if kernel_env in ("grid", "lists") and method in (0, 1):
             assert det["fallback_blocks"] > 0  # the tied points really went through the exact float64 stage
     finally:
         c.close()
@@ -553,8 +553,7 @@ def test_stream_through_exchange_hook(ctx, oracle, world100k):
     assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
 
 
-@pytest.mark.parametrize("seed", range(32))
-def test_randomized_configs_default_kernels(ctx, oracle, seed):
+def _randomized_case(ctx, oracle, seed):
     """Differential sweep of the default kernels against the oracle: random voxel size (also not a power of two, also
     larger than the lattice pitch allows for 30 points), bucket cap, search radius, map offset (negative / far-from-origin
     coordinates), scan partly outside the map, initial errors from tiny to half a voxel (so the share of points that need
@@ -582,6 +581,39 @@ def test_randomized_configs_default_kernels(ctx, oracle, seed):
     *_, det = Registration(cfg, ctx).RunRegister(scan, vm, T0, trace=True)
     ref = oracle.register(om, scan, T0, oracle.default_config(int(method), max_search_dist=th, max_iteration=8))
     _compare_run(det, ref)
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_randomized_configs_default_kernels(ctx, oracle, seed):
+    _randomized_case(ctx, oracle, seed)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_randomized_configs_list_kernels(oracle, seed, monkeypatch):
+    """The same sweep on the neighbourhood-list kernels (the search index of maps whose bounding box does not fit the cell grid)."""
+    from elimaloc_amd.registration import Context
+    monkeypatch.setenv("ELM_KERNEL", "lists")
+    c = Context(0)
+    try:
+        _randomized_case(c, oracle, seed)
+    finally:
+        c.close()
+
+
+def test_grid_budget_falls_back_to_lists(oracle, world100k, monkeypatch):
+    """A map whose bounding box exceeds the cell budget gets the neighbourhood lists instead: same results."""
+    from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod
+    monkeypatch.setenv("ELM_GRID_MAX_CELLS", "1000")
+    c = Context(0)
+    try:
+        vm, om = _maps(c, oracle, world100k, IcpMethod.P2P)
+        scan, T_true = synth.make_scan(world100k, 5000, seed=77)
+        T0 = synth.perturb(T_true, seed=78, max_trans=0.2, max_rot_deg=1.0)
+        *_, det = Registration(RegistrationConfig(icp_method=IcpMethod.P2P), c).RunRegister(scan, vm, T0, trace=True)
+        assert vm.info().nbr_entries > 20 * vm.info().n_points  # the 27-bucket lists were built
+        _compare_run(det, oracle.register(om, scan, T0, oracle.default_config(0)))
+    finally:
+        c.close()
 
 
 @pytest.mark.parametrize("method,stream", [(0, True), (1, True), (2, False)])
