@@ -260,7 +260,7 @@ struct elm_map {
     uint16_t* d_nbr_cell_off = nullptr;
     HashSlot* d_vqslots = nullptr;
     VoxRec* d_vnbr = nullptr;
-    Pt3* d_grid_pts = nullptr;        // dense cell grid (DevMap::grid_*), the default P2P / GICP search index
+    GridBlk* d_grid_blk = nullptr;    // dense cell grid (DevMap::grid_*), the default P2P / GICP search index
     uint32_t* d_grid_idx = nullptr;
     uint32_t* d_grid_start = nullptr;
     uint32_t* d_vox_stat = nullptr;
@@ -421,7 +421,7 @@ static void map_free(elm_map* m) {
     if (!m) return;
     (void)hipSetDevice(m->ctx->device);
     void* ptrs[] = {m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_pt_gicp, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off, m->d_vqslots, m->d_vnbr,
-                    m->d_grid_pts, m->d_grid_idx, m->d_grid_start, m->d_vox_stat};
+                    m->d_grid_blk, m->d_grid_idx, m->d_grid_start, m->d_vox_stat};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete m;
@@ -681,19 +681,28 @@ static int build_cell_grid(elm_map* m, uint64_t max_cells) {
         start[l + 1]++;
     }
     std::vector<int32_t>().swap(cell);
-    for (uint64_t c = 0; c < cells; ++c) start[c + 1] += start[c]; // start[c] = first point of cell c, start[c + 1] = its end
-    for (uint64_t c = cells + 1; c < cells + 4; ++c) start[c] = (uint32_t)n;
-    std::vector<Pt3> gp(n + 4);
-    std::vector<uint32_t> gi(n);
-    {
-        std::vector<uint32_t> cur(start.begin(), start.begin() + cells);
-        for (size_t i = 0; i < n; ++i) { // bucket order in, so a cell keeps its points in bucket (= insertion) order
-            const uint32_t pos = cur[lin[i]]++;
-            gp[pos].x = pts[i].x; gp[pos].y = pts[i].y; gp[pos].z = pts[i].z;
-            gi[pos] = (uint32_t)i;
-        }
+    // points per cell -> blocks of four per cell -> exclusive scan: start[c] = first block of cell c, start[c + 1] = its end
+    std::vector<uint32_t> fill(cells); // points placed so far in each cell
+    uint64_t n_blk = 1; // block 0: four padding slots, read by masked-off loads
+    for (uint64_t c = 0; c < cells; ++c) {
+        const uint32_t cnt = start[c + 1];
+        fill[c] = 0;
+        start[c] = (uint32_t)n_blk;
+        n_blk += (cnt + 3) / 4;
+        if (n_blk > 0x3FFFFFF0ull) { m->grid_refused = true; return ELM_ERR_UNSUPPORTED; }
     }
-    for (size_t k = n; k < n + 4; ++k) gp[k] = gp[n - 1]; // padding read (and masked) by the last block of four
+    for (uint64_t c = cells; c < cells + 4; ++c) start[c] = (uint32_t)n_blk;
+    std::vector<GridBlk> gb(std::max<uint64_t>(n_blk, 1));
+    std::vector<uint32_t> gi(std::max<uint64_t>(4 * n_blk, 4), 0xFFFFFFFFu);
+    for (auto& b : gb)
+        for (int u = 0; u < 4; ++u) b.x[u] = b.y[u] = b.z[u] = 1e18f; // padding: never the nearest, never within range
+    for (size_t i = 0; i < n; ++i) { // bucket order in, so a cell keeps its points in bucket (= insertion) order
+        const uint32_t c = lin[i];
+        const uint32_t pos = start[c] * 4 + fill[c]++;
+        gb[pos >> 2].x[pos & 3] = pts[i].x; gb[pos >> 2].y[pos & 3] = pts[i].y; gb[pos >> 2].z[pos & 3] = pts[i].z;
+        gi[pos] = (uint32_t)i;
+    }
+    std::vector<uint32_t>().swap(fill);
     std::vector<float4>().swap(pts);
     std::vector<uint32_t>().swap(lin);
     // dense voxel box of floor keys: a query with floor key f walks the stored keys f-1 .. f+1
@@ -717,14 +726,14 @@ static int build_cell_grid(elm_map* m, uint64_t max_cells) {
             return ELM_ERR_DEVICE;                                                            \
         }                                                                                     \
     } while (0)
-    GRID_CHK(hipMalloc((void**)&m->d_grid_pts, (n + 4) * sizeof(Pt3)));
-    GRID_CHK(hipMalloc((void**)&m->d_grid_idx, std::max<size_t>(n * sizeof(uint32_t), 256)));
+    GRID_CHK(hipMalloc((void**)&m->d_grid_blk, gb.size() * sizeof(GridBlk)));
+    GRID_CHK(hipMalloc((void**)&m->d_grid_idx, gi.size() * sizeof(uint32_t)));
     GRID_CHK(hipMalloc((void**)&m->d_grid_start, (cells + 4) * sizeof(uint32_t)));
     GRID_CHK(hipMalloc((void**)&m->d_vox_stat, std::max<size_t>(vcells * sizeof(uint32_t), 256)));
-    GRID_CHK(hipMemcpy(m->d_grid_pts, gp.data(), (n + 4) * sizeof(Pt3), hipMemcpyHostToDevice));
-    GRID_CHK(hipMemcpy(m->d_grid_idx, gi.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    GRID_CHK(hipMemcpy(m->d_grid_blk, gb.data(), gb.size() * sizeof(GridBlk), hipMemcpyHostToDevice));
+    GRID_CHK(hipMemcpy(m->d_grid_idx, gi.data(), gi.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     GRID_CHK(hipMemcpy(m->d_grid_start, start.data(), (cells + 4) * sizeof(uint32_t), hipMemcpyHostToDevice));
-    m->dm.grid_pts = m->d_grid_pts;
+    m->dm.grid_blk = m->d_grid_blk;
     m->dm.grid_idx = m->d_grid_idx;
     m->dm.grid_start = m->d_grid_start;
     m->dm.gx0 = lo[0]; m->dm.gy0 = lo[1]; m->dm.gz0 = lo[2];
@@ -738,7 +747,7 @@ static int build_cell_grid(elm_map* m, uint64_t max_cells) {
     GRID_CHK(hipStreamSynchronize(ctx->stream));
 #undef GRID_CHK
     m->has_grid = true;
-    m->info.device_bytes += (n + 4) * sizeof(Pt3) + n * sizeof(uint32_t) + (cells + 4) * sizeof(uint32_t) + vcells * sizeof(uint32_t);
+    m->info.device_bytes += gb.size() * sizeof(GridBlk) + gi.size() * sizeof(uint32_t) + (cells + 4) * sizeof(uint32_t) + vcells * sizeof(uint32_t);
     m->info.n_query_voxels = vcells;
     m->info.nbr_entries = n;
     return ELM_OK;

@@ -22,6 +22,10 @@ struct Pt3 { // 12-byte candidate of the neighbourhood lists
     float x, y, z;
 };
 
+struct __attribute__((aligned(16))) GridBlk { // four candidates of the cell grid, structure of arrays (48 bytes = three 16-byte loads)
+    float x[4], y[4], z[4];
+};
+
 struct VoxRec { // one occupied neighbour voxel of a query voxel (VGICP lists): its mean (float64, vhm.hpp:114-148) and id
     double mx, my, mz;
     int32_t vid;
@@ -61,11 +65,14 @@ struct DevMap {
                                   // entries [off[c], off[c+1]) of the list
     // dense half-voxel cell grid over the map's bounding box (optional; default search index when it fits the memory budget):
     // the map points ONCE, sorted by cell (x-major, y, z fastest -- the cells iz0..iz1 of one (ix, iy) column are one contiguous
-    // range), 12 bytes each; grid_start[linear cell] = first point of the cell, the next entry = its end.  Cells follow the
+    // run), in 48-byte blocks of four (x[4], y[4], z[4]); every cell is padded to whole blocks with far-away points (1e18), so a
+    // block never straddles cells and no candidate needs masking.  grid_start[linear cell] = first BLOCK of the cell, the next
+    // entry = its end.  Candidate id = block * 4 + slot.  Cells follow the
     // STORED (truncated) voxel keys: bucket k > 0 is cells {2k, 2k+1}, bucket 0 (two voxels wide) is {-2,-1,0,1}, bucket k < 0 is
     // {2k-2, 2k-1}; geometrically cell c is [c h, (c+1) h], h = voxel_size / 2.
-    const Pt3* grid_pts;        // [n_pts + 4]
-    const uint32_t* grid_idx;   // [n_pts] bucket-order index of every grid point (GICP payload, insertion order for exact ties)
+    const GridBlk* grid_blk;    // [n_blk]; block 0 is all padding (the target of masked-off loads), cells start at block 1
+    const uint32_t* grid_idx;   // [4 * n_blk] bucket-order index of every candidate slot (GICP payload, insertion order for exact
+                                // ties); 0xFFFFFFFF in padding slots
     const uint32_t* grid_start; // [gnx * gny * gnz + 4]
     int32_t gx0, gy0, gz0;      // cell coordinates of grid entry (0, 0, 0)
     int32_t gnx, gny, gnz;

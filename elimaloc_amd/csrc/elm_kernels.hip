@@ -558,6 +558,23 @@ __device__ __forceinline__ double row_min(double v) {
     v = fmin(v, dpp_move<0x128>(v)); // row_ror:8
     return v;
 }
+// the same over aligned groups of LPI = 1, 2, 4, 8 or 16 lanes
+template <unsigned LPI>
+__device__ __forceinline__ double group_min(double v) {
+    if (LPI >= 2) v = fmin(v, dpp_move<0xB1>(v));   // quad_perm [1,0,3,2]
+    if (LPI >= 4) v = fmin(v, dpp_move<0x4E>(v));   // quad_perm [2,3,0,1]: quads done
+    if (LPI >= 8) v = fmin(v, dpp_move<0x141>(v));  // row_half_mirror: lane i <-> 7 - i inside each half row
+    if (LPI >= 16) v = fmin(v, dpp_move<0x140>(v)); // row_mirror: lane i <-> 15 - i
+    return v;
+}
+template <unsigned LPI>
+__device__ __forceinline__ int group_sum_int(int v) {
+    if (LPI >= 2) v += __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);
+    if (LPI >= 4) v += __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);
+    if (LPI >= 8) v += __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false);
+    if (LPI >= 16) v += __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false);
+    return v;
+}
 __device__ __forceinline__ int row_sum_int(int v) {
     v += __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);
     v += __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);
@@ -568,6 +585,12 @@ __device__ __forceinline__ int row_sum_int(int v) {
 
 constexpr int kRedPass = 8;    // values per pass of the block reduction (16 KB of LDS per workgroup)
 
+#ifndef ELM_BLOCKS_PER_TRIP
+#define ELM_BLOCKS_PER_TRIP 2
+#endif
+#ifndef ELM_HARD_LANES
+#define ELM_HARD_LANES 4 // measured: 16 -> 56.9k, 8 -> 55.6k, 4 -> 63.0k, 2 -> 60.3k, 1 -> 55.2k registrations/s
+#endif
 #ifndef ELM_CELL_WAVES
 #define ELM_CELL_WAVES 5 // minimum waves per SIMD: caps the kernel at 96 VGPRs (measured: 5 -> 42.0k, unconstrained 4 -> 39.4k, 6 spills -> 36.5k registrations/s)
 #endif
@@ -854,6 +877,14 @@ __global__ __launch_bounds__(kBlock, ELM_CELL_WAVES) void k_accumulate_cell(cons
 // follow the stored keys, so that set is a cell range [alo, ahi] per axis: blocks and balls are clipped to it, and a clipped
 // face does not bound rho (nothing eligible lies beyond it).
 
+// candidate k = block k / 4, slot k % 4 of the grid's structure-of-arrays blocks
+__device__ __forceinline__ Pt3 blk_point(const GridBlk* __restrict__ blk, int k) {
+    const float* b = reinterpret_cast<const float*>(blk + (k >> 2)) + (k & 3);
+    Pt3 q;
+    q.x = b[0]; q.y = b[4]; q.z = b[8];
+    return q;
+}
+
 // per axis: the query's floor key f, the allowed cell range of the reference's walk, and 2 g / voxel_size (cell coordinate)
 struct GridAxis {
     int f, alo, ahi;
@@ -887,8 +918,30 @@ struct GridHardRec {
     float _pad;
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// squared float32 distances of a block's four candidates to g = gh + gl: packed two-wide arithmetic (v_pk_add/mul/fma_f32)
+__device__ __forceinline__ void blk_dist(const GridBlk& B, f32x2 ghx, f32x2 ghy, f32x2 ghz, f32x2 glx, f32x2 gly, f32x2 glz, f32x2& d01, f32x2& d23) {
+    const f32x2 x01 = {B.x[0], B.x[1]}, x23 = {B.x[2], B.x[3]}, y01 = {B.y[0], B.y[1]}, y23 = {B.y[2], B.y[3]}, z01 = {B.z[0], B.z[1]}, z23 = {B.z[2], B.z[3]};
+    const f32x2 ex01 = (x01 - ghx) - glx, ex23 = (x23 - ghx) - glx;
+    const f32x2 ey01 = (y01 - ghy) - gly, ey23 = (y23 - ghy) - gly;
+    const f32x2 ez01 = (z01 - ghz) - glz, ez23 = (z23 - ghz) - glz;
+    d01 = __builtin_elementwise_fma(ez01, ez01, __builtin_elementwise_fma(ey01, ey01, ex01 * ex01));
+    d23 = __builtin_elementwise_fma(ez23, ez23, __builtin_elementwise_fma(ey23, ey23, ex23 * ex23));
+}
+// (m1, m2) = the two smallest distances seen so far (m1 <= m2), j1 = slot of m1: one new distance
+__device__ __forceinline__ void two_smallest(float d, int id, float& m1, float& m2, int& j1) {
+    m2 = __builtin_amdgcn_fmed3f(m1, m2, d); // the median of (m1 <= m2, d) is the new runner-up
+    const bool c = d < m1;
+    m1 = fminf(m1, d);
+    j1 = c ? id : j1;
+}
+
+#ifndef ELM_GRID_WAVES
+#define ELM_GRID_WAVES 7 // minimum waves per SIMD = a 72-VGPR cap (2 spilled registers).  Measured registrations/s: 5 -> 59.8k, 6 -> 63.9k, 7 -> 65.6k,
+                         // 8 (35 spills) -> 54.2k: the kernel is bound by memory latency, not by VALU issue (67 % busy) or HBM bandwidth
+#endif
 template <int METHOD>
-__global__ __launch_bounds__(kBlock, ELM_CELL_WAVES) void k_accumulate_grid(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
+__global__ __launch_bounds__(kBlock, ELM_GRID_WAVES) void k_accumulate_grid(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
                                                                             unsigned total_blocks, const ScanState* __restrict__ st,
                                                                             double* __restrict__ partials, const RegParams rp) {
     constexpr int NV = (METHOD == ELM_P2P) ? kP2PVals : kSums;
@@ -907,26 +960,25 @@ __global__ __launch_bounds__(kBlock, ELM_CELL_WAVES) void k_accumulate_grid(cons
     double v[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) v[k] = 0.0;
-    double px = 0.0, py = 0.0, pz = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
-    unsigned stat = 0;
-    int bj = -1;
+    int bj = -1; // winning candidate: block * 4 + slot
     int n_tested = 0;
     float hr2 = __builtin_inff();
     bool hard = false;
     const double h = 0.5 * m.voxel_size;
-    const Pt3* __restrict__ lp = m.grid_pts;
-    if (valid) {
+    const GridBlk* __restrict__ lp = m.grid_blk;
+    // the point and its transform are cheap to redo (one 16-byte load that hits L1/L2 + 18 float64 operations): they are NOT kept
+    // in registers across the candidate loop and the cooperative stage -- the kernel is bound by latency, i.e. by occupancy
+    auto transform = [&](double& px, double& py, double& pz, double& gx, double& gy, double& gz) {
         const float4 pf = sd.pts[i];
         px = pf.x; py = pf.y; pz = pf.z;
-        gx = ((S.T[0] * px + S.T[4] * py) + S.T[8] * pz) + S.T[12];
+        gx = ((S.T[0] * px + S.T[4] * py) + S.T[8] * pz) + S.T[12]; // g = T * [p, 1] (reg.hpp:141-146), the reference's association
         gy = ((S.T[1] * px + S.T[5] * py) + S.T[9] * pz) + S.T[13];
         gz = ((S.T[2] * px + S.T[6] * py) + S.T[10] * pz) + S.T[14];
+    };
+    if (valid) {
+        double px, py, pz, gx, gy, gz;
+        transform(px, py, pz, gx, gy, gz);
         const GridAxis ax = grid_axis(gx, m), ay = grid_axis(gy, m), az = grid_axis(gz, m);
-        {
-            const int ux = ax.f - m.vx0, uy = ay.f - m.vy0, uz = az.f - m.vz0;
-            if ((unsigned)ux < (unsigned)m.vnx && (unsigned)uy < (unsigned)m.vny && (unsigned)uz < (unsigned)m.vnz)
-                stat = m.vox_stat[((size_t)ux * m.vny + uy) * m.vnz + uz];
-        }
         double rho = DBL_MAX;
         int bx0, bx1, by0, by1, bz0, bz1;
         grid_lean(ax, gx, h, bx0, bx1, rho);
@@ -935,83 +987,73 @@ __global__ __launch_bounds__(kBlock, ELM_CELL_WAVES) void k_accumulate_grid(cons
         // block cells relative to the grid; a block that leaves the grid (or came out empty) goes to stage 2, which clamps
         const int rx0 = bx0 - m.gx0, rx1 = bx1 - m.gx0, ry0 = by0 - m.gy0, ry1 = by1 - m.gy0, rz0 = bz0 - m.gz0, rz1 = bz1 - m.gz0;
         const bool inside = rx0 >= 0 && rx1 < m.gnx && rx0 <= rx1 && ry0 >= 0 && ry1 < m.gny && ry0 <= ry1 && rz0 >= 0 && rz1 < m.gnz && rz0 <= rz1;
-        // the four (ix, iy) columns of the block: one contiguous range [cell bz0, cell bz1] each
-        int sb[4], se[4], cb[5];
+        // the four (ix, iy) columns of the block: one contiguous run of candidate blocks [cell bz0, cell bz1] each
+        int sb[4], cb[5];
         cb[0] = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int cx = (k >> 1) ? rx1 : rx0, cy = (k & 1) ? ry1 : ry0;
             const bool dup = ((k >> 1) && rx1 == rx0) || ((k & 1) && ry1 == ry0); // a span clipped to one cell
-            sb[k] = 0; se[k] = 0;
+            int b0 = 0, b1 = 0;
             if (inside && !dup) {
                 const uint32_t* e = m.grid_start + (((size_t)cx * m.gny + cy) * m.gnz + rz0);
                 const unsigned s0 = e[0], s1 = e[1], s2 = e[2]; // one 12-byte load
-                sb[k] = (int)s0;
-                se[k] = (int)((rz1 > rz0) ? s2 : s1);
+                b0 = (int)s0;
+                b1 = (int)((rz1 > rz0) ? s2 : s1);
             }
+            sb[k] = b0 - cb[k]; // block t of the flattened sequence lives at sb[k] + t for cb[k] <= t < cb[k + 1]
+            cb[k + 1] = cb[k] + (b1 - b0);
         }
-        if (stat & 0xFFFFu) { // some bucket among the 27: search (else the reference's origin default, vhm.cpp:37)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) cb[k + 1] = cb[k] + ((se[k] - sb[k] + 3) >> 2); // blocks of 4 candidates
+        // decided <=> squared float32 winner distance (+ margins) < rr2, i.e. sqrt(r2) * 1.000001 + 1e-6 < rho
+        const double rr = (rho - 1e-6) * 0.999999;
+        const float rr2 = (rr > 0.0) ? (float)(rr * rr) * 0.9999998f : -1.f;
+        {
             const int nblk = cb[4];
-            n_tested = ((se[0] - sb[0]) + (se[1] - sb[1])) + ((se[2] - sb[2]) + (se[3] - sb[3]));
+            n_tested = 4 * nblk;
+            // float32 filter: g = gh + gl (float32 each, gh + gl == g to ~2^-48), so (q - gh) - gl reproduces q - g to a few float32
+            // ulps of |q - g| and the float32 distance is within 2^-20 relative (+ slack / 2) of the reference's float64 one
             const float ghx = (float)gx, ghy = (float)gy, ghz = (float)gz;
             const float glx = (float)(gx - (double)ghx), gly = (float)(gy - (double)ghy), glz = (float)(gz - (double)ghz);
+            const f32x2 hx = {ghx, ghx}, hy = {ghy, ghy}, hz = {ghz, ghz}, lx = {glx, glx}, ly = {gly, gly}, lz = {glz, glz};
             float m1 = __builtin_inff(), m2 = __builtin_inff();
             int j1 = -1;
-            for (int t0 = 0; t0 < nblk; t0 += 2) { // two blocks = 8 candidates per round trip
-                int pp[2], pe[2];
+            for (int t0 = 0; t0 < nblk; t0 += ELM_BLOCKS_PER_TRIP) { // ELM_BLOCKS_PER_TRIP blocks (three 16-byte loads each) per round trip
+                int pb[ELM_BLOCKS_PER_TRIP];
 #pragma unroll
-                for (int w = 0; w < 2; ++w) {
+                for (int w = 0; w < ELM_BLOCKS_PER_TRIP; ++w) {
                     const int t = t0 + w;
-                    int b_ = sb[3] - 4 * cb[3], e_ = se[3];
+                    int b_ = sb[3];
 #pragma unroll
-                    for (int k = 2; k >= 0; --k) {
-                        const bool lt = t < cb[k + 1];
-                        b_ = lt ? (sb[k] - 4 * cb[k]) : b_;
-                        e_ = lt ? se[k] : e_;
-                    }
-                    pp[w] = (t < nblk) ? b_ + 4 * t : 0;
-                    pe[w] = (t < nblk) ? e_ : 0; // empty block when past the end
+                    for (int k = 2; k >= 0; --k) b_ = (t < cb[k + 1]) ? sb[k] : b_;
+                    pb[w] = (t < nblk) ? b_ + t : 0; // past the end: block 0, four padding slots
                 }
-                float qf[2][12];
+                GridBlk B[ELM_BLOCKS_PER_TRIP];
 #pragma unroll
-                for (int w = 0; w < 2; ++w) {
-                    const Vec4u* bp = reinterpret_cast<const Vec4u*>(lp + pp[w]);
+                for (int w = 0; w < ELM_BLOCKS_PER_TRIP; ++w) B[w] = lp[pb[w]];
 #pragma unroll
-                    for (int u = 0; u < 3; ++u) {
-                        const Vec4u r = bp[u];
-                        qf[w][4 * u] = __uint_as_float(r.x); qf[w][4 * u + 1] = __uint_as_float(r.y);
-                        qf[w][4 * u + 2] = __uint_as_float(r.z); qf[w][4 * u + 3] = __uint_as_float(r.w);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int id = pp[u >> 2] + (u & 3);
-                    const float qx = qf[u >> 2][3 * (u & 3)], qy = qf[u >> 2][3 * (u & 3) + 1], qz = qf[u >> 2][3 * (u & 3) + 2];
-                    const float ex = (qx - ghx) - glx, ey = (qy - ghy) - gly, ez = (qz - ghz) - glz;
-                    const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-                    const float d = (id < pe[u >> 2]) ? dd : __builtin_inff();
-                    m2 = fminf(m2, fmaxf(d, m1));
-                    const bool c = d < m1;
-                    m1 = c ? d : m1;
-                    j1 = c ? id : j1;
+                for (int w = 0; w < ELM_BLOCKS_PER_TRIP; ++w) {
+                    f32x2 da, db;
+                    blk_dist(B[w], hx, hy, hz, lx, ly, lz, da, db);
+                    const int i0 = pb[w] * 4;
+                    two_smallest(da.x, i0, m1, m2, j1);
+                    two_smallest(da.y, i0 + 1, m1, m2, j1);
+                    two_smallest(db.x, i0 + 2, m1, m2, j1);
+                    two_smallest(db.y, i0 + 3, m1, m2, j1);
                 }
             }
             hard = true;
-            if (j1 >= 0) {
+            if (j1 >= 4) { // a real candidate (slots 0..3 are block 0's padding)
                 const float slack = 4e-11f * (fabsf(ghx) + fabsf(ghy) + fabsf(ghz) + 1.0f);
                 const float r2 = m1 + m1 * 1.9073486328125e-06f + slack; // 2^-19
                 hr2 = r2;
-                const double rr = (rho - 1e-6) * 0.999999; // sqrt(r2) * 1.000001 + 1e-6 < rho, without the square root
-                if (m2 > r2 && rr > 0.0 && (double)r2 < rr * rr) {
+                if (m2 > r2 && r2 < rr2) {
                     bj = j1;
                     hard = false;
                 }
             }
         }
     }
-    // ---- stage 2: queue the undecided points in thread order, 16 lanes per point
+    // ---- stage 2: queue the undecided points in thread order, ELM_HARD_LANES lanes per point
     const unsigned long long hm = __ballot(hard);
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (lane == 0) s_cnt[wave] = (unsigned)__popcll(hm);
@@ -1026,14 +1068,20 @@ __global__ __launch_bounds__(kBlock, ELM_CELL_WAVES) void k_accumulate_grid(cons
     if (n_hard) { // uniform
         GridHardRec* __restrict__ s_rec = reinterpret_cast<GridHardRec*>(s_buf);
         if (hard) {
+            double px, py, pz;
             GridHardRec r;
-            r.gx = gx; r.gy = gy; r.gz = gz; r.r2 = hr2; r._pad = 0.f;
+            transform(px, py, pz, r.gx, r.gy, r.gz);
+            r.r2 = hr2; r._pad = 0.f;
             s_rec[my_slot] = r;
         }
         __syncthreads();
-        const unsigned rl = threadIdx.x & 15u, row = threadIdx.x >> 4; // 16 rows of 16 lanes
-        for (unsigned it = row; it < n_hard; it += kBlock / 16) {
-            const GridHardRec R = s_rec[it];
+        constexpr unsigned LPI = ELM_HARD_LANES; // lanes per undecided point (a power of two <= 16: one DPP row holds 16 / LPI points)
+        const unsigned rl = threadIdx.x & (LPI - 1u), row = threadIdx.x / LPI;
+        for (unsigned it0 = 0; it0 < n_hard; it0 += kBlock / LPI) {
+            const unsigned it = it0 + row;
+            if (it0 + (threadIdx.x & ~63u) / LPI >= n_hard) break; // wave-uniform: this wavefront has no point in this pass
+            const bool live = it < n_hard;
+            const GridHardRec R = s_rec[live ? it : 0];
             const GridAxis ax = grid_axis(R.gx, m), ay = grid_axis(R.gy, m), az = grid_axis(R.gz, m);
             int lox = ax.alo, hix = ax.ahi, loy = ay.alo, hiy = ay.ahi, loz = az.alo, hiz = az.ahi;
             if (R.r2 < __builtin_inff()) {
@@ -1042,85 +1090,102 @@ __global__ __launch_bounds__(kBlock, ELM_CELL_WAVES) void k_accumulate_grid(cons
                 // cell further from zero, grid_cell_of)
                 const double r = sqrt((double)R.r2) * 1.000001 + 1e-6;
                 const double inv_h = 2.0 / m.voxel_size;
-                lox = max(lox, (int)floor((R.gx - r) * inv_h) - 0); hix = min(hix, (int)floor((R.gx + r) * inv_h));
-                loy = max(loy, (int)floor((R.gy - r) * inv_h) - 0); hiy = min(hiy, (int)floor((R.gy + r) * inv_h));
-                loz = max(loz, (int)floor((R.gz - r) * inv_h) - 0); hiz = min(hiz, (int)floor((R.gz + r) * inv_h));
+                lox = max(lox, (int)floor((R.gx - r) * inv_h)); hix = min(hix, (int)floor((R.gx + r) * inv_h));
+                loy = max(loy, (int)floor((R.gy - r) * inv_h)); hiy = min(hiy, (int)floor((R.gy + r) * inv_h));
+                loz = max(loz, (int)floor((R.gz - r) * inv_h)); hiz = min(hiz, (int)floor((R.gz + r) * inv_h));
             }
             lox = max(lox - m.gx0, 0); hix = min(hix - m.gx0, m.gnx - 1);
             loy = max(loy - m.gy0, 0); hiy = min(hiy - m.gy0, m.gny - 1);
             loz = max(loz - m.gz0, 0); hiz = min(hiz - m.gz0, m.gnz - 1);
             const int nx = hix - lox + 1, ny = hiy - loy + 1, nz = hiz - loz + 1;
-            const int ncol = (nx > 0 && ny > 0 && nz > 0) ? nx * ny : 0;
-            // the reference's float64 walk over this lane's columns; equal distances are settled by its visiting order: bucket
-            // rank (vhm.cpp:234-240), then insertion order (= bucket-order index)
+            const int ncol = (live && nx > 0 && ny > 0 && nz > 0) ? nx * ny : 0;
+            // the reference's float64 walk over this lane's columns (padding slots sit ~1e18 m away)
             double bd = DBL_MAX;
             int bk = -1, walked = 0;
-            unsigned brank = 0xFFFFFFFFu, bgi = 0xFFFFFFFFu;
-            for (int c = (int)rl; c < ncol; c += 16) {
+            bool tie = false; // the minimum was met more than once in this lane
+            for (int c = (int)rl; c < ncol; c += (int)LPI) {
                 const int cx = lox + c / ny, cy = loy + c % ny;
                 const uint32_t* e = m.grid_start + (((size_t)cx * m.gny + cy) * m.gnz + loz);
-                const int sb = (int)e[0], se = (int)e[nz];
-                walked += se - sb;
-                for (int k0 = sb; k0 < se; k0 += 4) {
-                    Pt3 q[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) q[u] = lp[min(k0 + u, se - 1)];
+                const int b0 = (int)e[0], b1 = (int)e[nz];
+                walked += 4 * (b1 - b0);
+                for (int b = b0; b < b1; ++b) {
+                    const GridBlk B = lp[b];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const int k = k0 + u;
-                        const double ex = (double)q[u].x - R.gx, ey = (double)q[u].y - R.gy, ez = (double)q[u].z - R.gz;
+                        const double ex = (double)B.x[u] - R.gx, ey = (double)B.y[u] - R.gy, ez = (double)B.z[u] - R.gz;
                         const double d2 = (ex * ex + ey * ey) + ez * ez;
-                        if (k >= se) continue;
-                        if (d2 < bd) {
-                            bd = d2; bk = k; brank = 0xFFFFFFFFu;
-                        } else if (d2 == bd) {
-                            if (brank == 0xFFFFFFFFu) {
-                                brank = visit_rank(lp[bk], ax.f, ay.f, az.f, m.voxel_size);
-                                bgi = m.grid_idx[bk];
-                            }
-                            const unsigned rk = visit_rank(q[u], ax.f, ay.f, az.f, m.voxel_size), gi = m.grid_idx[k];
-                            if (rk < brank || (rk == brank && gi < bgi)) { bk = k; brank = rk; bgi = gi; }
-                        }
+                        tie = (d2 == bd) ? true : ((d2 < bd) ? false : tie);
+                        bk = (d2 < bd) ? 4 * b + u : bk;
+                        bd = fmin(d2, bd);
                     }
                 }
             }
-            const double dmin = row_min(bd);
-            const unsigned at = (unsigned)((__ballot(bk >= 0 && bd == dmin) >> (16u * ((threadIdx.x >> 4) & 3u))) & 0xFFFFull);
-            int win;
-            if (__popc(at) <= 1) {
-                win = __shfl(bk, (int)((threadIdx.x & 48u) + (unsigned)(__ffs((int)at) - 1)), 64);
-                if (at == 0u) win = -1;
-            } else { // the same float64 distance in several lanes: visiting order decides
-                if (bk >= 0 && bd == dmin) {
-                    if (brank == 0xFFFFFFFFu) {
-                        brank = visit_rank(lp[bk], ax.f, ay.f, az.f, m.voxel_size);
-                        bgi = m.grid_idx[bk];
+            const double dmin = group_min<LPI>(bd);
+            const unsigned gsh = threadIdx.x & 63u & ~(LPI - 1u);
+            const unsigned long long gmask = ((1ull << LPI) - 1ull) << gsh;
+            const unsigned long long at_all = __ballot(bk >= 0 && bd == dmin), tie_all = __ballot(tie && bd == dmin);
+            const unsigned at = (unsigned)((at_all & gmask) >> gsh);
+            int win = -1;
+            if (__popc(at) == 1 && (tie_all & gmask) == 0ull) {
+                win = __shfl(bk, (int)(gsh + (unsigned)(__ffs((int)at) - 1)), 64);
+            } else if (at != 0u) {
+                // the same float64 distance more than once (practically never): the reference keeps the candidate it meets first --
+                // bucket visiting rank (vhm.cpp:234-240: x-major .. z-minor over the stored keys f-1..f+1), then insertion order
+                // (= bucket-order index).  The bucket of a cell: c >= 2 -> c >> 1, -2 <= c <= 1 -> 0, c <= -3 -> (c + 2) >> 1.
+                unsigned brank = 0xFFFFFFFFu, bgi = 0xFFFFFFFFu;
+                bk = -1;
+#pragma unroll 1
+                for (int c = (int)rl; c < ncol; c += (int)LPI) {
+                    const int cx = lox + c / ny, cy = loy + c % ny;
+                    const int ccx = cx + m.gx0, ccy = cy + m.gy0;
+                    const int kx = ccx >= 2 ? ccx >> 1 : (ccx >= -2 ? 0 : (ccx + 2) >> 1), ky = ccy >= 2 ? ccy >> 1 : (ccy >= -2 ? 0 : (ccy + 2) >> 1);
+                    const uint32_t* e = m.grid_start + (((size_t)cx * m.gny + cy) * m.gnz + loz);
+#pragma unroll 1
+                    for (int z = 0; z < nz; ++z) {
+                        const int ccz = loz + z + m.gz0;
+                        const int kz = ccz >= 2 ? ccz >> 1 : (ccz >= -2 ? 0 : (ccz + 2) >> 1);
+                        const unsigned rank = (unsigned)(((kx - ax.f + 1) * 3 + (ky - ay.f + 1)) * 3 + (kz - az.f + 1));
+#pragma unroll 1
+                        for (int k = 4 * (int)e[z]; k < 4 * (int)e[z + 1]; ++k) {
+                            const Pt3 q = blk_point(lp, k);
+                            const double ex = (double)q.x - R.gx, ey = (double)q.y - R.gy, ez = (double)q.z - R.gz;
+                            if ((ex * ex + ey * ey) + ez * ez != dmin) continue;
+                            const unsigned gi = m.grid_idx[k];
+                            if (rank < brank || (rank == brank && gi < bgi)) { brank = rank; bgi = gi; bk = k; }
+                        }
                     }
-                } else {
-                    brank = 0xFFFFFFFFu; bgi = 0xFFFFFFFFu; bk = -1;
                 }
 #pragma unroll
-                for (int off = 8; off > 0; off >>= 1) {
+                for (int off = (int)LPI / 2; off > 0; off >>= 1) {
                     const unsigned orank = (unsigned)__shfl_xor((int)brank, off, 64), og = (unsigned)__shfl_xor((int)bgi, off, 64);
                     const int ok = __shfl_xor(bk, off, 64);
                     if (orank < brank || (orank == brank && og < bgi)) { brank = orank; bgi = og; bk = ok; }
                 }
                 win = bk;
             }
-            walked = row_sum_int(walked);
-            if (rl == 0) { s_res[it] = win; s_tst[it] = walked; }
+            walked = group_sum_int<LPI>(walked);
+            if (rl == 0 && live) { s_res[it] = win; s_tst[it] = walked; }
         }
         __syncthreads();
         if (hard) { bj = s_res[my_slot]; n_tested += s_tst[my_slot]; }
         __syncthreads(); // the queue is dead: the reduction may overwrite it
     }
     if (valid) {
-        // the winner's float64 distance in the reference's arithmetic (range test, weight); no bucket at all: the reference's
-        // default PointStruct at the origin (vhm.cpp:37, QUIRK)
+        double px, py, pz, gx, gy, gz;
+        transform(px, py, pz, gx, gy, gz);
+        // statistics of the reference's walk for this query voxel: candidates and occupied buckets among the 27
+        unsigned stat = 0;
+        {
+            const int ux = floor_key(gx, m) - m.vx0, uy = floor_key(gy, m) - m.vy0, uz = floor_key(gz, m) - m.vz0;
+            if ((unsigned)ux < (unsigned)m.vnx && (unsigned)uy < (unsigned)m.vny && (unsigned)uz < (unsigned)m.vnz)
+                stat = m.vox_stat[((size_t)ux * m.vny + uy) * m.vnz + uz];
+        }
+        // the winner's float64 distance in the reference's arithmetic (range test, weight); no bucket at all (the search came
+        // back empty): the reference's default PointStruct at the origin (vhm.cpp:37, QUIRK)
         float bx = 0.f, by = 0.f, bz = 0.f;
         int bidx = -1;
         if (bj >= 0) {
-            const Pt3 q = lp[bj];
+            const Pt3 q = blk_point(lp, bj);
             bx = q.x; by = q.y; bz = q.z;
             bidx = (METHOD == ELM_GICP) ? (int)m.grid_idx[bj] : 0;
         }
