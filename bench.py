@@ -335,14 +335,14 @@ def main():
             t1 = time.perf_counter()
             pose, ok, fit, cov = reg.RunRegister(scans_host[i], vm, T0s[i])
             tt.append(time.perf_counter() - t1)
-            same = same and bool(np.array_equal(pose, out[i]["T"]))
+            same = same and float(np.abs(pose - out[i]["T"]).max()) < 1e-9  # caller's point order vs the Hilbert-ordered resident scan
         result["reference_api"] = {
-            "what": "Registration::RunRegister-equivalent elm_register on HOST buffers (scan upload + all iterations + result download per call), "
-                    "sequential calls on one context",
+            "what": "Registration::RunRegister-equivalent elm_register on HOST buffers (scan upload in the caller's point order + all iterations "
+                    "+ result download per call), sequential calls on one context",
             "registrations_per_s": 1.0 / float(np.median(tt)),
             "ms_per_call_median": 1e3 * float(np.median(tt)),
             "n_calls": k,
-            "pose_bit_identical_to_stream": same,
+            "pose_equals_stream_to_1e-9": same,
         }
 
     if extras and args.slots > 0 and args.guess == "easy":

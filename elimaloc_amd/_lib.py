@@ -128,7 +128,7 @@ EXPORTS = [
     "elm_ctx_synchronize", "elm_ctx_stream", "elm_ctx_set_profiling", "elm_ctx_get_profile", "elm_map_build", "elm_map_destroy", "elm_map_cal_voxel_cov_all",
     "elm_map_cal_point_cov_all", "elm_map_build_neighbourhoods", "elm_map_get_info", "elm_map_empty", "elm_map_download_points",
     "elm_map_download_voxels", "elm_map_find_ground_height", "elm_scan_upload", "elm_scan_destroy",
-    "elm_scan_size", "elm_register", "elm_register_batch", "elm_register_stream", "elm_register_batch_enqueue",
+    "elm_scan_size", "elm_scan_download", "elm_register", "elm_register_batch", "elm_register_stream", "elm_register_batch_enqueue",
     "elm_register_batch_finish", "elm_deskew", "elm_deskew_downsample", "elm_deskew_prepare", "elm_comm_get_unique_id", "elm_comm_init",
     "elm_comm_destroy", "elm_comm_set_hook", "elm_filter_points_by_distance", "elm_voxel_downsample",
     "elm_get_interpolated_pose", "elm_shape_odom_covariance",
@@ -230,6 +230,8 @@ def lib():
     L.elm_scan_destroy.restype = None
     L.elm_scan_size.argtypes = [vp]
     L.elm_scan_size.restype = C.c_size_t
+    L.elm_scan_download.argtypes = [vp, fp, C.c_size_t]
+    L.elm_deskew_downsample.argtypes = [vp, fp, fp, C.c_size_t, C.POINTER(DeskewTables), C.c_double, C.POINTER(vp), ip]
     L.elm_register.argtypes = [vp, vp, fp, C.c_size_t, dp, C.POINTER(RegConfig), dp, ip, dp, dp,
                                C.POINTER(RegResult), C.POINTER(IterTrace)]
     L.elm_register_stream.argtypes = [vp, vp, C.POINTER(vp), C.c_int, dp, C.POINTER(RegConfig), C.c_int, C.POINTER(RegResult),

@@ -7,6 +7,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -22,6 +24,13 @@ using namespace elm;
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+};
+
+struct elm_scan {
+    elm_ctx* ctx = nullptr;
+    float4* d_pts = nullptr;
+    size_t cap_bytes = 0;
+    uint32_t n = 0, n_total = 0;
 };
 
 typedef int (*nccl_get_unique_id_t)(void*);
@@ -83,6 +92,8 @@ struct elm_ctx {
     size_t h_trace_cap = 0;
     void* h_stage = nullptr; // pinned staging for synchronous uploads (scan points, deskew tables)
     size_t h_stage_cap = 0;
+    std::vector<uint32_t> h_key, h_ord, h_tmp; // scratch of the scan ordering (grow-only)
+    std::vector<struct elm_scan*> scan_free;   // recycled scan handles
     std::vector<std::pair<void*, size_t>> scan_pool; // device buffers of destroyed scans, reused by the next upload (a scan per
                                                      // LiDAR message: no hipMalloc / hipFree on the per-scan path after warm-up)
     void* h_desc = nullptr; // pinned staging of the batch descriptors (read by an async copy)
@@ -92,6 +103,7 @@ struct elm_ctx {
     bool want_trace = false;
     bool in_flight = false;
     RegParams rp{};
+    int scan_order = 1;  // 1: order uploaded scans along a Hilbert curve (elm_scan_upload), 0: keep the caller's order (ELM_SCAN_ORDER=none)
     int kernel_mode = 4; // accumulate kernels: 4 = dense cell grid, or cell-indexed neighbourhood lists when the grid does not fit
                          // (P2P/GICP), voxel-mean lists (VGICP/AVGICP): the default; 3 = neighbourhood lists forced (ELM_KERNEL=lists);
                          // 2 = the plain 27-probe walk of k_accumulate_direct (ELM_KERNEL=direct: in-kernel reference for tests)
@@ -106,6 +118,15 @@ struct elm_ctx {
     elm_allreduce_fn hook = nullptr;
     void* hook_user = nullptr;
 };
+
+// Contexts that are alive.  Maps and scans hold a pointer to their context; destroying the context first is legal (e.g. Python
+// object finalisation order): a child destroyed later finds its context gone and only releases its own device memory.
+static std::mutex g_live_mu;
+static std::set<const elm_ctx*> g_live_ctx;
+static bool ctx_alive(const elm_ctx* ctx) {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    return g_live_ctx.count(ctx) != 0;
+}
 
 #define HIPCHK(ctx, call)                                                                              \
     do {                                                                                               \
@@ -188,12 +209,21 @@ extern "C" int elm_ctx_create(int device_id, elm_ctx** out) {
         return ELM_ERR_DEVICE;
     }
     if (const char* k = getenv("ELM_KERNEL")) ctx->kernel_mode = (strcmp(k, "direct") == 0) ? 2 : (strcmp(k, "lists") == 0) ? 3 : 4;
+    if (const char* o = getenv("ELM_SCAN_ORDER")) ctx->scan_order = (strcmp(o, "none") == 0) ? 0 : 1;
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        g_live_ctx.insert(ctx);
+    }
     *out = ctx;
     return ELM_OK;
 }
 
 extern "C" void elm_ctx_destroy(elm_ctx* ctx) {
     if (!ctx) return;
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        if (!g_live_ctx.erase(ctx)) return; // not a live context (double destroy)
+    }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm && g_rccl.comm_destroy) g_rccl.comm_destroy(ctx->comm);
@@ -202,6 +232,7 @@ extern "C" void elm_ctx_destroy(elm_ctx* ctx) {
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& b : ctx->scan_pool) (void)hipFree(b.first);
+    for (elm_scan* f : ctx->scan_free) delete f;
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
     if (ctx->h_trace) (void)hipHostFree(ctx->h_trace);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
@@ -419,7 +450,7 @@ static void build_host(const float* xyz, size_t n, double voxel_size, int max_po
 
 static void map_free(elm_map* m) {
     if (!m) return;
-    (void)hipSetDevice(m->ctx->device);
+    if (ctx_alive(m->ctx)) (void)hipSetDevice(m->ctx->device); // a context destroyed first: just release the device memory
     void* ptrs[] = {m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_pt_gicp, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off, m->d_vqslots, m->d_vnbr,
                     m->d_grid_blk, m->d_grid_idx, m->d_grid_start, m->d_vox_stat};
     for (void* p : ptrs)
@@ -973,12 +1004,6 @@ extern "C" int elm_map_find_ground_height(const elm_map* m, double x, double y, 
 // ------------------------------------------------------------------------------------------------------
 // scans
 // ------------------------------------------------------------------------------------------------------
-struct elm_scan {
-    elm_ctx* ctx = nullptr;
-    float4* d_pts = nullptr;
-    size_t cap_bytes = 0;
-    uint32_t n = 0, n_total = 0;
-};
 
 // index of cell (x, y) along a Hilbert curve over a 2^order x 2^order grid
 static inline uint32_t hilbert_xy2d(uint32_t order, uint32_t x, uint32_t y) {
@@ -994,22 +1019,30 @@ static inline uint32_t hilbert_xy2d(uint32_t order, uint32_t x, uint32_t y) {
     return d;
 }
 
-extern "C" int elm_scan_upload(elm_ctx* ctx, const float* xyz, size_t n, size_t n_total, elm_scan** out) {
+// Uploads one scan.  order = true: the points are ordered along a Hilbert curve over 2 m x 2 m sensor-frame cells (all heights of
+// a cell together) -- consecutive points, hence every 256-point workgroup and, through the XCD-aware block mapping, every XCD's
+// L2, touch a few adjacent map cells: +13 % registrations/s on resident scans (65.2k vs 57.7k).  The ordering costs ~1.3 ms of
+// host time for 131 072 points, far more than it saves on ONE registration, so elm_register keeps the caller's order.
+// No allocation after warm-up: ordering scratch, pinned staging, scan handles and device buffers are pooled in the context.
+static int scan_upload_impl(elm_ctx* ctx, const float* xyz, size_t n, size_t n_total, bool order, elm_scan** out) {
     if (!ctx || !out || (!xyz && n) || n > 0x7FFFFFFFull || n_total > 0x7FFFFFFFull || n_total < n) return ELM_ERR_INVALID;
     *out = nullptr;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    // Order the points along a Hilbert curve over 2 m x 2 m sensor-frame cells (all heights of a cell together):
-    // consecutive points -- hence every 256-point workgroup and, through the XCD-aware block mapping, every XCD's
-    // L2 -- touch a few adjacent map voxels, and the curve has no long jumps.  Stable in the input index.
-    const double cs = 2.0;
-    // 20-bit keys: two stable 10-bit counting passes (LSD radix) over the index array, ~10x cheaper than a comparison sort
-    std::vector<uint32_t> key(n), ord(n), tmp(n);
-    for (size_t i = 0; i < n; ++i) {
-        const int cx = (int)floor((double)xyz[3 * i] / cs) + 512, cy = (int)floor((double)xyz[3 * i + 1] / cs) + 512;
-        const uint32_t ux = (uint32_t)std::min(std::max(cx, 0), 1023), uy = (uint32_t)std::min(std::max(cy, 0), 1023);
-        key[i] = hilbert_xy2d(10, ux, uy);
-    }
-    {
+    int rc = pinned_reserve(ctx, &ctx->h_stage, &ctx->h_stage_cap, std::max<size_t>(n * sizeof(float4), 4096));
+    if (rc != ELM_OK) return rc;
+    float4* hp = (float4*)ctx->h_stage;
+    if (!order || !ctx->scan_order) {
+        for (size_t i = 0; i < n; ++i) hp[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.f);
+    } else {
+        const double cs = 2.0;
+        // 20-bit keys: two stable 10-bit counting passes (LSD radix) over the index array, ~10x cheaper than a comparison sort
+        if (ctx->h_key.size() < n) { ctx->h_key.resize(n); ctx->h_ord.resize(n); ctx->h_tmp.resize(n); }
+        uint32_t *key = ctx->h_key.data(), *ord = ctx->h_ord.data(), *tmp = ctx->h_tmp.data();
+        for (size_t i = 0; i < n; ++i) {
+            const int cx = (int)floor((double)xyz[3 * i] / cs) + 512, cy = (int)floor((double)xyz[3 * i + 1] / cs) + 512;
+            const uint32_t ux = (uint32_t)std::min(std::max(cx, 0), 1023), uy = (uint32_t)std::min(std::max(cy, 0), 1023);
+            key[i] = hilbert_xy2d(10, ux, uy);
+        }
         uint32_t cnt[1025];
         memset(cnt, 0, sizeof cnt);
         for (size_t i = 0; i < n; ++i) cnt[(key[i] & 1023u) + 1]++;
@@ -1019,15 +1052,19 @@ extern "C" int elm_scan_upload(elm_ctx* ctx, const float* xyz, size_t n, size_t 
         for (size_t i = 0; i < n; ++i) cnt[(key[i] >> 10) + 1]++;
         for (int b = 0; b < 1024; ++b) cnt[b + 1] += cnt[b];
         for (size_t k = 0; k < n; ++k) ord[cnt[key[tmp[k]] >> 10]++] = tmp[k];
+        for (size_t k = 0; k < n; ++k) {
+            const size_t i = ord[k];
+            hp[k] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.f);
+        }
     }
-    int rc = pinned_reserve(ctx, &ctx->h_stage, &ctx->h_stage_cap, std::max<size_t>(n * sizeof(float4), 4096));
-    if (rc != ELM_OK) return rc;
-    float4* hp = (float4*)ctx->h_stage;
-    for (size_t k = 0; k < n; ++k) {
-        const size_t i = ord[k];
-        hp[k] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.f);
+    elm_scan* s;
+    if (!ctx->scan_free.empty()) {
+        s = ctx->scan_free.back();
+        ctx->scan_free.pop_back();
+        *s = elm_scan();
+    } else {
+        s = new elm_scan();
     }
-    elm_scan* s = new elm_scan();
     s->ctx = ctx;
     s->n = (uint32_t)n;
     s->n_total = (uint32_t)n_total;
@@ -1047,7 +1084,7 @@ extern "C" int elm_scan_upload(elm_ctx* ctx, const float* xyz, size_t n, size_t 
         }
     }
     if (e == hipSuccess && n) e = hipMemcpyAsync(s->d_pts, hp, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream); // the pinned staging buffer is reused by the next upload
     if (e != hipSuccess) {
         ctx->last_error = std::string("scan upload: ") + hipGetErrorString(e);
         if (s->d_pts) (void)hipFree(s->d_pts);
@@ -1058,20 +1095,43 @@ extern "C" int elm_scan_upload(elm_ctx* ctx, const float* xyz, size_t n, size_t 
     return ELM_OK;
 }
 
+extern "C" int elm_scan_upload(elm_ctx* ctx, const float* xyz, size_t n, size_t n_total, elm_scan** out) {
+    return scan_upload_impl(ctx, xyz, n, n_total, true, out);
+}
+
 extern "C" void elm_scan_destroy(elm_scan* s) {
     if (!s) return;
-    (void)hipSetDevice(s->ctx->device);
+    if (!ctx_alive(s->ctx)) { // the context went first: release the device buffer, nothing to pool
+        if (s->d_pts) (void)hipFree(s->d_pts);
+        delete s;
+        return;
+    }
+    elm_ctx* ctx = s->ctx;
+    (void)hipSetDevice(ctx->device);
     if (s->d_pts) {
-        if (s->ctx->scan_pool.size() < 64) {
+        if (ctx->scan_pool.size() < 64) {
             // the stream is in order: a later upload into this buffer is queued behind every kernel that still reads it
-            s->ctx->scan_pool.emplace_back((void*)s->d_pts, s->cap_bytes);
+            ctx->scan_pool.emplace_back((void*)s->d_pts, s->cap_bytes);
         } else {
             (void)hipFree(s->d_pts);
         }
     }
-    delete s;
+    if (ctx->scan_free.size() < 64) ctx->scan_free.push_back(s);
+    else delete s;
 }
 extern "C" size_t elm_scan_size(const elm_scan* s) { return s ? s->n : 0; }
+extern "C" int elm_scan_download(const elm_scan* s, float* xyz, size_t cap) {
+    if (!s || (!xyz && cap)) return ELM_ERR_INVALID;
+    elm_ctx* ctx = s->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t n = std::min<size_t>(cap, s->n);
+    if (!n) return ELM_OK;
+    std::vector<float4> tmp(n);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // the kernels that fill the scan run on the context stream
+    HIPCHK(ctx, hipMemcpy(tmp.data(), s->d_pts, n * sizeof(float4), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) { xyz[3 * i] = tmp[i].x; xyz[3 * i + 1] = tmp[i].y; xyz[3 * i + 2] = tmp[i].z; }
+    return ELM_OK;
+}
 
 // ------------------------------------------------------------------------------------------------------
 // registration
@@ -1445,7 +1505,7 @@ extern "C" int elm_register(elm_ctx* ctx, const elm_map* map, const float* scan_
                             double local_cov[36], elm_reg_result* result, elm_iter_trace* trace) {
     if (!ctx || !map || !T0 || !cfg) return ELM_ERR_INVALID;
     elm_scan* s = nullptr;
-    int rc = elm_scan_upload(ctx, scan_xyz, n, n, &s);
+    int rc = scan_upload_impl(ctx, scan_xyz, n, n, false, &s); // the caller's point order (see scan_upload_impl)
     if (rc != ELM_OK) return rc;
     elm_reg_result res;
     rc = elm_register_batch(ctx, map, &s, 1, T0, cfg, &res, trace);

@@ -63,3 +63,27 @@ class PcmDeskew:
         if not ok.value:
             return False, None
         return True, out
+
+    def DeskewDownsample(self, xyz, point_time, timestamp, imu, odom, voxel_size):
+        """DeskewPointCloud + VoxelHashMap::VoxelDownsample (pcm.cpp:238 + 257-258) fused on the device
+        (elm_deskew_downsample): returns (ok, kept undistorted points (k,3) float32 in input order)."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        t = np.ascontiguousarray(point_time, dtype=np.float32).copy()
+        front, back = float(t[0]), float(t[-1])
+        if self.b_lidar_scan_time_end:
+            t -= np.float32(front)
+        tab = self.prepare(imu, odom, timestamp, front, back)
+        scan, ok = C.c_void_p(), C.c_int(0)
+        fp = C.POINTER(C.c_float)
+        L = _lib.lib()
+        check(L.elm_deskew_downsample(self.ctx._h, xyz.ctypes.data_as(fp), t.ctypes.data_as(fp), xyz.shape[0], C.byref(tab),
+                                      float(voxel_size), C.byref(scan), C.byref(ok)), self.ctx._h, "elm_deskew_downsample")
+        if not ok.value:
+            return False, None
+        n = int(L.elm_scan_size(scan))
+        out = np.empty((n, 3), np.float32)
+        try:
+            check(L.elm_scan_download(scan, out.ctypes.data_as(fp), n), self.ctx._h, "elm_scan_download")
+        finally:
+            L.elm_scan_destroy(scan)
+        return True, out

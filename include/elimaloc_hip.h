@@ -172,6 +172,9 @@ int elm_map_find_ground_height(const elm_map* map, double x, double y, double* g
 int elm_scan_upload(elm_ctx* ctx, const float* xyz, size_t n, size_t n_total, elm_scan** out);
 void elm_scan_destroy(elm_scan* scan);
 size_t elm_scan_size(const elm_scan* scan);
+/* The resident points of a scan (xyz[3 * min(cap, size)] float32, in the device order): e.g. the undistorted, downsampled
+ * cloud elm_deskew_downsample produced -- what the node publishes as its debug clouds (pcm.cpp:308-316). */
+int elm_scan_download(const elm_scan* scan, float* xyz, size_t cap);
 
 /* ---------------------------------------------------------------- registration -------------------- */
 /* Registration::RunRegister (reg.hpp:122-124, reg.cpp:274-418; call sites pcm.cpp:280-282, 412-414) on host

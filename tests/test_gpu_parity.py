@@ -232,7 +232,7 @@ def test_negative_coordinate_keys(ctx, oracle):
 
 
 def test_batch_equals_single(ctx, oracle, world100k):
-    """elm_register_batch on resident scans == one-at-a-time elm_register; ragged batch (different sizes, an
+    """elm_register_batch on resident scans == the same scans registered one at a time; ragged batch (different sizes, an
     empty scan, scans that stop at different iterations)."""
     from elimaloc_amd.registration import Registration, RegistrationConfig, IcpMethod, Scan
     vm, om = _maps(ctx, oracle, world100k, IcpMethod.VGICP)
@@ -244,7 +244,12 @@ def test_batch_equals_single(ctx, oracle, world100k):
         sc = sc[:n]
         T0 = synth.perturb(Tt, seed=200 + i, max_trans=0.05 + 0.1 * i, max_rot_deg=0.3 * (i + 1))
         scans.append(Scan(ctx, sc)); T0s.append(T0)
-        singles.append(reg.RunRegister(sc, vm, T0, trace=True)[-1])
+        singles.append(reg.RunRegisterBatch([scans[-1]], vm, [T0], trace=True)[0])
+        # elm_register on the host buffer keeps the caller's point order (the resident scans are Hilbert-ordered): the same
+        # registration up to the summation order
+        host = reg.RunRegister(sc, vm, T0, trace=True)[-1]
+        assert host["iterations"] == singles[-1]["iterations"] and host["is_success"] == singles[-1]["is_success"]
+        np.testing.assert_allclose(host["T"], singles[-1]["T"], rtol=0, atol=1e-9)
     out = reg.RunRegisterBatch(scans, vm, T0s, trace=True)
     assert len({r["iterations"] for r in out}) > 1
     for b, s in zip(out, singles):
@@ -349,9 +354,11 @@ def test_full_size_properties(ctx, oracle):
         sc, Tt = (scan_n, T_true) if i == 0 else synth.make_scan(world, 131072, seed=2100 + i)
         scans.append(Scan(ctx, sc)); T0s.append(T0 if i == 0 else synth.perturb(Tt, seed=3100 + i))
     out = regp.RunRegisterStream(scans, vm, T0s, slots=8)
-    single0 = regp.RunRegister(scan_n, vm, T0)
+    single0 = regp.RunRegisterBatch([scans[0]], vm, [T0s[0]])[0]
     single7 = regp.RunRegisterBatch([scans[7]], vm, [T0s[7]])[0]
-    assert np.array_equal(out[0]["T"], single0[0]) and np.array_equal(out[7]["T"], single7["T"]) and out[7]["iterations"] == single7["iterations"]
+    assert np.array_equal(out[0]["T"], single0["T"]) and np.array_equal(out[7]["T"], single7["T"]) and out[7]["iterations"] == single7["iterations"]
+    host0 = regp.RunRegister(scan_n, vm, T0)  # elm_register keeps the caller's point order: equal up to the summation order
+    assert np.abs(host0[0] - out[0]["T"]).max() < 1e-9
     assert all(r["is_success"] for r in out) and len({r["iterations"] for r in out}) > 1
     refp = oracle.register(om, scan_n, T0, oracle.default_config(0))
     dt, dr = synth.pose_error(refp["T"], out[0]["T"])
@@ -514,7 +521,7 @@ def test_stream_equals_single(ctx, oracle, world100k, method, slots):
         sc = sc[:n]
         T0 = synth.perturb(Tt, seed=600 + i, max_trans=0.05 + 0.04 * i, max_rot_deg=0.2 * (i + 1))
         scans.append(Scan(ctx, sc)); T0s.append(T0)
-        singles.append(reg.RunRegister(sc, vm, T0, trace=True)[-1])
+        singles.append(reg.RunRegisterBatch([scans[-1]], vm, [T0], trace=True)[0])
     assert len({r["iterations"] for r in singles}) > 2  # registrations finish at different iterations
     for rep in range(2):  # second call: the iteration count of the first is the prediction
         out = reg.RunRegisterStream(scans, vm, T0s, slots=slots, trace=True)
@@ -616,19 +623,67 @@ def test_grid_budget_falls_back_to_lists(oracle, world100k, monkeypatch):
         c.close()
 
 
-@pytest.mark.parametrize("method,stream", [(0, True), (1, True), (2, False)])
-def test_two_ranks_on_one_gpu(oracle, world100k, method, stream):
-    """The multi-GPU data path with two REAL ranks: two contexts on this GPU (two host threads, two streams), every scan's
-    points sharded in two, the map replicated, and an exchange hook that adds the two ranks' packed sums (what the RCCL
-    all-reduce does between the reduce-only and the solve-only launch of every iteration).  Both ranks must reach
-    bit-identical poses (they solve the same all-reduced sums and refill their slots identically), and the poses must
-    agree with the unsharded run and the oracle."""
+def _run_two_ranks(world, full, T0s, m, stream, slots=3, cov_dist=0.4):
+    """Two REAL ranks on this GPU: two contexts (two host threads, two streams), every scan's points sharded in two, the map
+    replicated, and an exchange hook that adds the two ranks' packed sums -- what the RCCL all-reduce does between the
+    reduce-only and the solve-only launch of every iteration.  Returns the two ranks' result lists."""
     import ctypes as C
     import threading
     from elimaloc_amd.dist import shard_bounds
-    from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, Scan
+    from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, Scan, VoxelHashMap
     hip = C.CDLL("libamdhip64.so")
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    barrier = threading.Barrier(2)
+    bufs, results, errors = [None, None], [None, None], []
+
+    def rank_main(r):
+        try:
+            ctx = Context(0)
+            vmr = VoxelHashMap(1.0, 30, ctx)
+            vmr.AddPoints(world)
+            if m in (IcpMethod.VGICP, IcpMethod.AVGICP):
+                vmr.CalVoxelCovAll()
+            if m == IcpMethod.GICP:
+                vmr.CalPointCovAll(cov_dist)
+            scans = []
+            for s in full:
+                lo, hi = shard_bounds(len(s), r, 2)
+                scans.append(Scan(ctx, s[lo:hi], n_total=len(s)))
+
+            def hook(ptr, n, hip_stream):
+                ctx.synchronize()
+                mine = np.empty(n, np.float64)
+                assert hip.hipMemcpy(mine.ctypes.data, ptr, n * 8, 2) == 0  # device -> host
+                bufs[r] = mine
+                barrier.wait(timeout=120)
+                total = bufs[0] + bufs[1]  # the same operand order on both ranks
+                barrier.wait(timeout=120)
+                assert hip.hipMemcpy(ptr, total.ctypes.data, n * 8, 1) == 0  # host -> device
+                return 0
+
+            ctx.set_allreduce_hook(hook)
+            reg = Registration(RegistrationConfig(icp_method=m), ctx)
+            results[r] = reg.RunRegisterStream(scans, vmr, T0s, slots=slots) if stream else reg.RunRegisterBatch(scans, vmr, T0s)
+            ctx.set_allreduce_hook(None)
+            del scans, vmr
+            ctx.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+            barrier.abort()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    [t.start() for t in th]
+    [t.join(timeout=900) for t in th]
+    assert not errors, errors
+    return results
+
+
+@pytest.mark.parametrize("method,stream", [(0, True), (1, True), (2, False)])
+def test_two_ranks_on_one_gpu(oracle, world100k, method, stream):
+    """The multi-GPU data path with two real ranks on one GPU (_run_two_ranks).  Both ranks must reach bit-identical poses (they
+    solve the same all-reduced sums and refill their slots identically), and the poses must agree with the unsharded run and the
+    oracle."""
+    from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, Scan
     m = IcpMethod(method)
     full, T0s = [], []
     for i in range(7):
@@ -640,42 +695,7 @@ def test_two_ranks_on_one_gpu(oracle, world100k, method, stream):
     vm, om = _maps(c, oracle, world100k, m)
     single = Registration(RegistrationConfig(icp_method=m), c).RunRegisterBatch([Scan(c, s) for s in full], vm, T0s)
     c.close()
-    barrier = threading.Barrier(2)
-    bufs, results, errors = [None, None], [None, None], []
-
-    def rank_main(r):
-        try:
-            ctx = Context(0)
-            vmr, _ = _maps(ctx, oracle, world100k, m)
-            scans = []
-            for s in full:
-                lo, hi = shard_bounds(len(s), r, 2)
-                scans.append(Scan(ctx, s[lo:hi], n_total=len(s)))
-
-            def hook(ptr, n, hip_stream):
-                ctx.synchronize()
-                mine = np.empty(n, np.float64)
-                assert hip.hipMemcpy(mine.ctypes.data, ptr, n * 8, 2) == 0  # device -> host
-                bufs[r] = mine
-                barrier.wait(timeout=60)
-                total = bufs[0] + bufs[1]  # the same operand order on both ranks
-                barrier.wait(timeout=60)
-                assert hip.hipMemcpy(ptr, total.ctypes.data, n * 8, 1) == 0  # host -> device
-                return 0
-
-            ctx.set_allreduce_hook(hook)
-            reg = Registration(RegistrationConfig(icp_method=m), ctx)
-            results[r] = reg.RunRegisterStream(scans, vmr, T0s, slots=3) if stream else reg.RunRegisterBatch(scans, vmr, T0s)
-            ctx.set_allreduce_hook(None)
-            ctx.close()
-        except Exception as e:  # noqa: BLE001
-            errors.append(repr(e))
-            barrier.abort()
-
-    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
-    [t.start() for t in th]
-    [t.join(timeout=300) for t in th]
-    assert not errors, errors
+    results = _run_two_ranks(world100k, full, T0s, m, stream)
     for a, b, s, sc, T0 in zip(results[0], results[1], single, full, T0s):
         assert a["iterations"] == b["iterations"] == s["iterations"] and a["is_success"] == b["is_success"] == s["is_success"]
         assert np.array_equal(a["T"], b["T"])                       # the ranks agree bit for bit
@@ -684,6 +704,33 @@ def test_two_ranks_on_one_gpu(oracle, world100k, method, stream):
     ref = oracle.register(om, full[3], T0s[3], oracle.default_config(method))
     dt, dr = synth.pose_error(ref["T"], results[0][3]["T"])
     assert ref["iterations"] == results[0][3]["iterations"] and dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
+
+
+def test_full_size_c4_two_shards(oracle):
+    """BASELINE config C4 at its stated sizes with the scan SHARDED: VGICP, 262 144-point scans against the 50 M-point map, two
+    real ranks on this GPU holding half of every scan each and exchanging the packed normal equations every iteration (the
+    8-GPU run does the same with 8 shards over RCCL).  The ranks agree bit for bit; every pose agrees with the CPU oracle run on
+    the part of the map the scan can reach."""
+    from elimaloc_amd.registration import IcpMethod
+    world = synth.make_world(50_000_000, seed=1001)
+    full, T0s, Tts = [], [], []
+    for i in range(3):
+        sc, Tt = synth.make_scan(world, 262144, seed=2100 + i)
+        full.append(sc); Tts.append(Tt)
+        T0s.append(synth.perturb(Tt, seed=3100 + i))
+    results = _run_two_ranks(world, full, T0s, IcpMethod.VGICP, stream=True, slots=2)
+    for i, (a, b) in enumerate(zip(results[0], results[1])):
+        assert a["iterations"] == b["iterations"] and np.array_equal(a["T"], b["T"])
+        r = float(np.sqrt((full[i].astype(np.float64) ** 2).sum(axis=1).max())) + 15.0
+        d = world[:, :2].astype(np.float64) - Tts[i][:2, 3]
+        om = oracle.Map(1.0, 30)
+        om.add_points(world[(d * d).sum(axis=1) < r * r])
+        om.cal_voxel_cov_all()
+        ref = oracle.register(om, full[i], T0s[i], oracle.default_config(2))
+        dt, dr = synth.pose_error(ref["T"], a["T"])
+        assert ref["iterations"] == a["iterations"] and ref["is_success"] == a["is_success"]
+        assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (i, dt, dr)
+        del om
 
 
 def test_api_misuse_fails_loudly(ctx, oracle, world100k):

@@ -75,13 +75,13 @@ class OracleStream:
         return dict(pose_ego=ego, time=scan_end, n_source=len(src))
 
 
-def test_closed_loop_stream_matches_checker_chain(oracle):
+def _closed_loop(oracle, map_points, n_pts, n_scans, native, max_range=40.0, crop_m=None):
     from elimaloc_amd import _lib
     from elimaloc_amd.ekf import EkfAlgorithm, EkfConfig
     from elimaloc_amd.pcm_matching import PcmMatching, PcmMatchingConfig
     from elimaloc_amd.registration import Context, IcpMethod, RegistrationConfig
     from elimaloc_amd.stream import LocalizationStream, rot_to_quat_xyzw
-    world = synth.make_world(100000, seed=1001)
+    world = synth.make_world(map_points, seed=1001)
     tf = np.eye(4)
     tf[:3, :3] = synth.rot_zyx(0.0, 0.01, 0.02)
     tf[:3, 3] = [1.2, 0.0, 1.6]
@@ -90,11 +90,17 @@ def test_closed_loop_stream_matches_checker_chain(oracle):
     node = PcmMatching(cfg, ctx)
     node.Init(world)
     ecfg = EkfConfig()
-    prod = LocalizationStream(node, EkfAlgorithm(ecfg))
-    chk = OracleStream(oracle, world, cfg, {n: getattr(ecfg.c, n) for n, _ in _lib.EkfConfig._fields_})
+    prod = LocalizationStream(node, EkfAlgorithm(ecfg), native=native)
     drive = synth.Drive()
+    # the checker's CPU map: the whole world, or (full-size runs) the part of it the drive's scans can reach
+    cworld = world
+    if crop_m is not None:
+        x0, y0, *_ = drive.at(0.0)
+        d = world[:, :2].astype(np.float64) - np.array([float(x0), float(y0)])
+        cworld = world[(d * d).sum(axis=1) < crop_m * crop_m]
+    chk = OracleStream(oracle, cworld, cfg, {n: getattr(ecfg.c, n) for n, _ in _lib.EkfConfig._fields_})
     rng = np.random.default_rng(42)
-    imu_hz, t0, n_scans, n_pts = 200, 500.0, 32, 20000
+    imu_hz, t0 = 200, 500.0
     # initial pose: the truth (what a converged CallbackInitialPose hands over), as PCM_INIT to both filters
     P0 = drive.ego_pose(0.0)
     q0 = rot_to_quat_xyzw(P0[:3, :3])
@@ -109,7 +115,7 @@ def test_closed_loop_stream_matches_checker_chain(oracle):
         chk.CallbackImu(t0 + t, g, f)
         if k > 10 and k % (imu_hz // 10) == 0:
             t_end = t - cfg.d_lidar_time_delay - 0.005   # the scan ended a sensor delay ago
-            raw, rel = drive.scan(world, n_pts, t_end, tf, seed=7000 + k)
+            raw, rel = drive.scan(world, n_pts, t_end, tf, seed=7000 + k, max_range=max_range)
             stamp = t0 + t_end + cfg.d_lidar_time_delay
             a = prod.CallbackPointCloud(raw, rel, stamp)
             b = chk.CallbackPointCloud(raw, rel, stamp)
@@ -133,4 +139,51 @@ def test_closed_loop_stream_matches_checker_chain(oracle):
     # the filter follows the drive: final speed and position close to truth
     x, y, yaw, v, *_ = drive.at(k / imu_hz)
     assert abs(np.linalg.norm(s["x"][6:9]) - v) < 0.5 and np.hypot(s["x"][0] - x, s["x"][1] - y) < 0.2
+    ctx.close()
+
+
+def test_closed_loop_stream_matches_checker_chain(oracle):
+    _closed_loop(oracle, 100000, 20000, 32, native=False)
+
+
+def test_closed_loop_stream_native_callback(oracle):
+    """The same loop with the node callback as ONE C-ABI call (deskew + VoxelDownsample fused on the device)."""
+    _closed_loop(oracle, 100000, 20000, 32, native=True)
+
+
+def test_closed_loop_stream_full_size_c5(oracle):
+    """BASELINE config 5 at its stated size: 131 072-point raw scans against the 10 M-point map, 24 scans in closed loop through
+    elm_pcm_callback_point_cloud; the checker chain registers against the part of the map within 90 m of the drive (the scans
+    reach 60 m, the drive moves a few metres)."""
+    _closed_loop(oracle, 10_000_000, 131072, 24, native=True, max_range=60.0, crop_m=90.0)
+
+
+def test_deskew_downsample_full_size_kept_set(oracle):
+    """elm_deskew_downsample on a 131 072-point scan: the kept SET equals the oracle's deskew -> VoxelDownsample (the reference
+    emits unordered_map order, only the set is contractual), at the shipped 1.5 m and at a fine 0.2 m voxel."""
+    from elimaloc_amd.deskew import PcmDeskew
+    from elimaloc_amd.registration import Context
+    st = synth.make_deskew_stream(131072, seed=77)
+    ctx = Context(0)
+    dk = PcmDeskew(ctx)
+    front = float(st["time"][0])
+    scan_end = st["stamp"]
+    scan_cur = scan_end + front
+    imu = np.concatenate([st["imu_t"][:, None], st["imu_w"]], axis=1)
+    ok_i, itime, irot = oracle.imu_deskew_info(st["imu_t"], st["imu_w"], scan_cur, scan_end)
+    ok_o, inc = oracle.odom_deskew_info(st["odom"], scan_cur, scan_end)
+    assert ok_i and ok_o
+    und = oracle.deskew_points(st["xyz"], st["time"] - np.float32(front), itime, irot, scan_cur, scan_end, inc)
+    ok, und_gpu = dk.DeskewPointCloud(st["xyz"], st["time"], st["stamp"], imu, st["odom"])
+    assert ok
+    same = np.all(und_gpu == und, axis=1)
+    # float32 sin/cos: a few outputs differ by one unit in the last place of the point's largest coordinate (80 m range: 7.6e-6 m)
+    assert same.mean() > 0.97 and np.all(np.abs(und_gpu - und) <= np.spacing(np.abs(und).max(axis=1, keepdims=True)))
+    for vs in (1.5, 0.2):
+        ok, kept = dk.DeskewDownsample(st["xyz"], st["time"], st["stamp"], imu, st["odom"], vs)
+        assert ok
+        # the device downsamples ITS undistorted cloud: compare with the oracle's rule applied to the same cloud
+        ref = und_gpu[oracle.voxel_downsample(und_gpu, vs)]
+        assert kept.shape == ref.shape
+        assert np.array_equal(kept[np.lexsort(kept.T[::-1])], ref[np.lexsort(ref.T[::-1])])
     ctx.close()
