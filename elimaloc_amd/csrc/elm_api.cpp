@@ -283,8 +283,9 @@ struct elm_map {
     float4* d_pts = nullptr;
     uint2* d_ranges = nullptr;
     int32_t* d_keys = nullptr; // [n_vox][3] stored keys (for downloads)
-    double *d_vox_mean = nullptr, *d_vox_cov = nullptr;
-    double* d_pt_gicp = nullptr; // [n_pts][16]: mean, covariance, fitness normal (DevMap::pt_gicp)
+    double *d_vox_mean = nullptr, *d_vox_cov = nullptr, *d_vox_cinv = nullptr;
+    double* d_pt_gicp = nullptr; // [n_pts][16]: mean, inverse covariance, fitness normal (DevMap::pt_gicp)
+    double* d_pt_cov = nullptr;  // [n_pts][9]: the covariances themselves (Pointcloud() read-back only)
     HashSlot* d_qslots = nullptr;
     Pt3* d_nbr_pts = nullptr;
     uint32_t* d_nbr_idx = nullptr;
@@ -451,7 +452,7 @@ static void build_host(const float* xyz, size_t n, double voxel_size, int max_po
 static void map_free(elm_map* m) {
     if (!m) return;
     if (ctx_alive(m->ctx)) (void)hipSetDevice(m->ctx->device); // a context destroyed first: just release the device memory
-    void* ptrs[] = {m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_pt_gicp, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off, m->d_vqslots, m->d_vnbr,
+    void* ptrs[] = {m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_vox_cinv, m->d_pt_gicp, m->d_pt_cov, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off, m->d_vqslots, m->d_vnbr,
                     m->d_grid_blk, m->d_grid_idx, m->d_grid_start, m->d_vox_stat};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -542,16 +543,18 @@ extern "C" int elm_map_cal_voxel_cov_all(elm_map* m) {
     if (!m->d_vox_mean) {
         HIPCHK(ctx, hipMalloc((void**)&m->d_vox_mean, std::max<size_t>((size_t)m->dm.n_vox * 3 * sizeof(double), 256)));
         HIPCHK(ctx, hipMalloc((void**)&m->d_vox_cov, std::max<size_t>((size_t)m->dm.n_vox * 9 * sizeof(double), 256)));
-        m->info.device_bytes += (size_t)m->dm.n_vox * 12 * sizeof(double);
+        HIPCHK(ctx, hipMalloc((void**)&m->d_vox_cinv, std::max<size_t>((size_t)m->dm.n_vox * 9 * sizeof(double), 256)));
+        m->info.device_bytes += (size_t)m->dm.n_vox * 21 * sizeof(double);
     }
     if (m->dm.n_vox) {
         (void)hipGetLastError(); // drop stale errors of other libraries (RCCL probes peer devices)
-        launch_voxel_cov(ctx->stream, m->dm, m->d_ranges, m->d_vox_mean, m->d_vox_cov);
+        launch_voxel_cov(ctx->stream, m->dm, m->d_ranges, m->d_vox_mean, m->d_vox_cov, m->d_vox_cinv);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     m->dm.vox_mean = m->d_vox_mean;
     m->dm.vox_cov = m->d_vox_cov;
+    m->dm.vox_cinv = m->d_vox_cinv;
     m->info.has_voxel_cov = 1;
     return ELM_OK;
 }
@@ -562,11 +565,12 @@ extern "C" int elm_map_cal_point_cov_all(elm_map* m, double d_search_dist) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (!m->d_pt_gicp) {
         HIPCHK(ctx, hipMalloc((void**)&m->d_pt_gicp, std::max<size_t>((size_t)m->dm.n_pts * 16 * sizeof(double), 256)));
-        m->info.device_bytes += (size_t)m->dm.n_pts * 16 * sizeof(double);
+        HIPCHK(ctx, hipMalloc((void**)&m->d_pt_cov, std::max<size_t>((size_t)m->dm.n_pts * 9 * sizeof(double), 256)));
+        m->info.device_bytes += (size_t)m->dm.n_pts * 25 * sizeof(double);
     }
     if (m->dm.n_pts) {
         (void)hipGetLastError();
-        launch_point_cov(ctx->stream, m->dm, d_search_dist * d_search_dist, m->d_pt_gicp);
+        launch_point_cov(ctx->stream, m->dm, d_search_dist * d_search_dist, m->d_pt_gicp, m->d_pt_cov);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
@@ -946,9 +950,13 @@ extern "C" int elm_map_download_points(const elm_map* m, double* xyz, double* co
     if ((cov9 || mean3) && n) {
         std::vector<double> tmp(n * 16);
         HIPCHK(ctx, hipMemcpy(tmp.data(), m->d_pt_gicp, n * 16 * sizeof(double), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < n; ++i) {
-            if (cov9) rowmajor_to_colmajor3(&tmp[16 * i + 3], &cov9[9 * i]);
+        for (size_t i = 0; i < n; ++i)
             if (mean3) memcpy(&mean3[3 * i], &tmp[16 * i], 3 * sizeof(double));
+        if (cov9) {
+            std::vector<double>().swap(tmp);
+            tmp.resize(n * 9);
+            HIPCHK(ctx, hipMemcpy(tmp.data(), m->d_pt_cov, n * 9 * sizeof(double), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < n; ++i) rowmajor_to_colmajor3(&tmp[9 * i], &cov9[9 * i]);
         }
     }
     return ELM_OK;

@@ -40,10 +40,11 @@ struct DevMap {
     uint32_t _pad;
     const float4* pts;      // bucket-ordered map points, xyz + pad (w unused), insertion order inside a bucket
     const double* vox_mean; // [n_vox][3]            CalVoxelCov (vhm.hpp:114-148)
-    const double* vox_cov;  // [n_vox][9] row-major
+    const double* vox_cov;  // [n_vox][9] row-major (read-backs: Covariances())
+    const double* vox_cinv; // [n_vox][9] its inverse: what the VGICP / AVGICP pairs use (add_pair_world)
     // GICP payload of a map point, ONE 128-byte record (a matched point costs one cache line instead of three scattered
-    // ones): [0..2] neighbourhood mean, [3..11] covariance row-major (ProcessVoxelBlock vhm.hpp:195-250), [12..14]
-    // eigenvector of its smallest eigenvalue (reg.cpp:89-91, precomputed once), [15] pad
+    // ones): [0..2] neighbourhood mean, [3..11] INVERSE of the covariance of ProcessVoxelBlock (vhm.hpp:195-250), row-major,
+    // [12..14] eigenvector of the covariance's smallest eigenvalue (reg.cpp:89-91, precomputed once), [15] pad
     const double* pt_gicp;  // [n_pts][16]
     double voxel_size;
     double inv_vs_exact; // 1 / voxel_size when voxel_size is a power of two (g * inv == g / voxel_size bit for bit), else 0
@@ -180,8 +181,8 @@ void launch_nbr_cellsort(hipStream_t s, const DevMap& m, const int32_t* qkeys, u
 size_t nbr_cell_stride();
 void launch_nbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets, Pt3* out,
                      uint32_t* out_idx);
-void launch_voxel_cov(hipStream_t s, const DevMap& m, const uint2* ranges, double* vox_mean, double* vox_cov);
-void launch_point_cov(hipStream_t s, const DevMap& m, double d2max, double* pt_gicp);
+void launch_voxel_cov(hipStream_t s, const DevMap& m, const uint2* ranges, double* vox_mean, double* vox_cov, double* vox_cinv);
+void launch_point_cov(hipStream_t s, const DevMap& m, double d2max, double* pt_gicp, double* pt_cov); // pt_cov [n_pts][9]: read-backs
 
 struct DeskewDev {
     double time_scan_cur, time_scan_end;

@@ -157,6 +157,64 @@ __device__ __forceinline__ void add_pair(double* acc, const double* Rinv, const 
     }
 }
 
+// The covariance-weighted methods in the WORLD frame.  With a = R p = g - t and the world residual e = m - g:
+//   r_l = R^-1 e,   M_l = (R^-1 C R^-T)^-1 = R^T C^-1 R,   R [p]x R^T = [a]x
+//   =>  J_l^T M_l J_l = P^T (J_w^T C^-1 J_w) P,   J_l^T M_l r_l = P^T (J_w^T C^-1 e),   J_w = [I | -[a]x],  P = diag(R, R)
+// so the per-pair 3x3 products and the 3x3 inverse of reg.cpp:107-113 / 187-191 disappear: C^-1 is computed once per map point /
+// voxel at map build, the pairs are accumulated in the world frame and k_solve applies the one congruence with P per
+// iteration.  Equal to the reference's sums up to rounding (R orthonormal to ~1e-16).  |r_l| = |e|.
+//   acc[0..20] upper J^T M J, acc[21..26] J^T M r, acc[27] residual sum, acc[28] pair count  -- world frame
+template <int METHOD>
+__device__ __forceinline__ void add_pair_world(double* acc, double ax, double ay, double az, double ex, double ey, double ez,
+                                               const double* Cinv, const double* nfit, const RegParams& rp) {
+    const double r2 = (ex * ex + ey * ey) + ez * ez;
+    const double den = rp.th + r2;
+    double w = rp.th2 / (den * den); // square(th) / square(th + |r|^2)
+    if (METHOD == ELM_GICP) w = w * 0.8 + 0.2;
+    acc[28] += 1.0;
+    if (METHOD == ELM_VGICP || METHOD == ELM_AVGICP) {
+        if (w < 0.01) return; // reg.cpp:201 -- skipped pairs stay in the fitness denominator
+    }
+    double A[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) A[i] = w * Cinv[i];
+    // B = -[a]x
+    double AB[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        AB[i * 3 + 0] = A[i * 3 + 2] * ay - A[i * 3 + 1] * az;
+        AB[i * 3 + 1] = A[i * 3 + 0] * az - A[i * 3 + 2] * ax;
+        AB[i * 3 + 2] = A[i * 3 + 1] * ax - A[i * 3 + 0] * ay;
+    }
+    acc[tri(0, 0)] += A[0]; acc[tri(0, 1)] += A[1]; acc[tri(0, 2)] += A[2];
+    acc[tri(1, 1)] += A[4]; acc[tri(1, 2)] += A[5]; acc[tri(2, 2)] += A[8];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[tri(i, 3 + j)] += AB[i * 3 + j];
+    acc[tri(3, 3)] += ay * AB[6] - az * AB[3];
+    acc[tri(3, 4)] += ay * AB[7] - az * AB[4];
+    acc[tri(3, 5)] += ay * AB[8] - az * AB[5];
+    acc[tri(4, 4)] += az * AB[1] - ax * AB[7];
+    acc[tri(4, 5)] += az * AB[2] - ax * AB[8];
+    acc[tri(5, 5)] += ax * AB[5] - ay * AB[2];
+    const double bx = (A[0] * ex + A[1] * ey) + A[2] * ez;
+    const double by = (A[3] * ex + A[4] * ey) + A[5] * ez;
+    const double bz = (A[6] * ex + A[7] * ey) + A[8] * ez;
+    acc[21] += bx; acc[22] += by; acc[23] += bz;
+    acc[24] += ay * bz - az * by;
+    acc[25] += az * bx - ax * bz;
+    acc[26] += ax * by - ay * bx;
+    if (METHOD == ELM_GICP) {
+        // |r_l . n_l| with n_l the normalised R^-1 n (reg.cpp:91-95, 128) = |e . n| / |n|
+        const double nn2 = (nfit[0] * nfit[0] + nfit[1] * nfit[1]) + nfit[2] * nfit[2];
+        const double dot = (ex * nfit[0] + ey * nfit[1]) + ez * nfit[2];
+        acc[27] += (nn2 > 0.0) ? fabs(dot) / sqrt(nn2) : fabs(dot);
+    } else {
+        acc[27] += sqrt(r2);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // K1
 // ------------------------------------------------------------------------------------------------------
@@ -204,7 +262,7 @@ __device__ __forceinline__ void nearest_voxel_direct(const DevMap& m, int vx, in
             }
 }
 
-// pair payloads shared by both kernels
+// pair payloads shared by the kernels
 template <int METHOD>
 __device__ __forceinline__ void finish_point_pair(double* acc, const DevMap& m, const ScanState& S, const RegParams& rp,
                                                   double px, double py, double pz, double gx, double gy, double gz,
@@ -216,35 +274,40 @@ __device__ __forceinline__ void finish_point_pair(double* acc, const DevMap& m, 
         if (bidx < 0) { bx = 0.f; by = 0.f; bz = 0.f; }
         add_pair<ELM_P2P>(acc, S.Rinv, S.tinv, px, py, pz, (double)bx, (double)by, (double)bz, nullptr, nullptr, rp);
     } else {
-        double C[9], mean[3], nf[3];
+        double Ci[9], mean[3], nf[3];
         if (bidx >= 0) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) C[k] = m.pt_gicp[(size_t)bidx * 16 + 3 + k];
+            for (int k = 0; k < 9; ++k) Ci[k] = m.pt_gicp[(size_t)bidx * 16 + 3 + k];
 #pragma unroll
             for (int k = 0; k < 3; ++k) { mean[k] = m.pt_gicp[(size_t)bidx * 16 + k]; nf[k] = m.pt_gicp[(size_t)bidx * 16 + 12 + k]; }
         } else {
-            C[0] = 1; C[1] = 0; C[2] = 0; C[3] = 0; C[4] = 1; C[5] = 0; C[6] = 0; C[7] = 0; C[8] = 1;
+            Ci[0] = 1; Ci[1] = 0; Ci[2] = 0; Ci[3] = 0; Ci[4] = 1; Ci[5] = 0; Ci[6] = 0; Ci[7] = 0; Ci[8] = 1;
             mean[0] = mean[1] = mean[2] = 0.0;
             nf[0] = 1.0; nf[1] = 0.0; nf[2] = 0.0;
         }
         // GICP's target position is the neighbourhood MEAN of the matched point (reg.cpp:97)
-        add_pair<ELM_GICP>(acc, S.Rinv, S.tinv, px, py, pz, mean[0], mean[1], mean[2], C, nf, rp);
+        add_pair_world<ELM_GICP>(acc, gx - S.T[12], gy - S.T[13], gz - S.T[14], mean[0] - gx, mean[1] - gy, mean[2] - gz, Ci, nf, rp);
     }
+}
+template <int METHOD>
+__device__ __forceinline__ void voxel_pair(double* acc, const DevMap& m, const ScanState& S, const RegParams& rp, double gx, double gy,
+                                           double gz, int vid, double mx, double my, double mz) {
+    double Ci[9];
+    if (vid >= 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Ci[k] = m.vox_cinv[(size_t)vid * 9 + k];
+    } else {
+        Ci[0] = 1; Ci[1] = 0; Ci[2] = 0; Ci[3] = 0; Ci[4] = 1; Ci[5] = 0; Ci[6] = 0; Ci[7] = 0; Ci[8] = 1;
+    }
+    add_pair_world<METHOD>(acc, gx - S.T[12], gy - S.T[13], gz - S.T[14], mx - gx, my - gy, mz - gz, Ci, nullptr, rp);
 }
 __device__ __forceinline__ void finish_voxel_pair(double* acc, const DevMap& m, const ScanState& S, const RegParams& rp,
                                                   double px, double py, double pz, double gx, double gy, double gz,
                                                   double bd2, int bvid, double bmx, double bmy, double bmz) {
     const double dfin = (bvid >= 0) ? bd2 : (gx * gx + gy * gy) + gz * gz;
     if (!(dfin < rp.th2)) return;
-    double C[9];
-    if (bvid >= 0) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) C[k] = m.vox_cov[(size_t)bvid * 9 + k];
-    } else {
-        C[0] = 1; C[1] = 0; C[2] = 0; C[3] = 0; C[4] = 1; C[5] = 0; C[6] = 0; C[7] = 0; C[8] = 1;
-        bmx = bmy = bmz = 0.0;
-    }
-    add_pair<ELM_VGICP>(acc, S.Rinv, S.tinv, px, py, pz, bmx, bmy, bmz, C, nullptr, rp);
+    if (bvid < 0) bmx = bmy = bmz = 0.0;
+    voxel_pair<ELM_VGICP>(acc, m, S, rp, gx, gy, gz, bvid, bmx, bmy, bmz);
 }
 
 // block -> (scan, first point) ; returns false when the scan is finished
@@ -365,12 +428,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_direct(const DevMap m, co
                 const double cx = m.vox_mean[(size_t)pr.vid * 3], cy = m.vox_mean[(size_t)pr.vid * 3 + 1], cz = m.vox_mean[(size_t)pr.vid * 3 + 2];
                 const double ex = cx - gx, ey = cy - gy, ez = cz - gz;
                 const double d2 = (ex * ex + ey * ey) + ez * ez;
-                if (d2 < rp.th2) {
-                    double C[9];
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) C[k] = m.vox_cov[(size_t)pr.vid * 9 + k];
-                    add_pair<ELM_AVGICP>(acc, S.Rinv, S.tinv, px, py, pz, cx, cy, cz, C, nullptr, rp);
-                }
+                if (d2 < rp.th2) voxel_pair<ELM_AVGICP>(acc, m, S, rp, gx, gy, gz, pr.vid, cx, cy, cz);
             }
         }
         acc[29] = n_cand;
@@ -940,8 +998,11 @@ __device__ __forceinline__ void two_smallest(float d, int id, float& m1, float& 
 #define ELM_GRID_WAVES 7 // minimum waves per SIMD = a 72-VGPR cap (2 spilled registers).  Measured registrations/s: 5 -> 59.8k, 6 -> 63.9k, 7 -> 65.6k,
                          // 8 (35 spills) -> 54.2k: the kernel is bound by memory latency, not by VALU issue (67 % busy) or HBM bandwidth
 #endif
+#ifndef ELM_GICP_WAVES
+#define ELM_GICP_WAVES 5
+#endif
 template <int METHOD>
-__global__ __launch_bounds__(kBlock, ELM_GRID_WAVES) void k_accumulate_grid(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
+__global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_GICP_WAVES)) void k_accumulate_grid(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
                                                                             unsigned total_blocks, const ScanState* __restrict__ st,
                                                                             double* __restrict__ partials, const RegParams rp) {
     constexpr int NV = (METHOD == ELM_P2P) ? kP2PVals : kSums;
@@ -1291,11 +1352,15 @@ __global__ __launch_bounds__(64) void k_nbr_cellsort(const DevMap m, const int32
 // nearest voxel MEAN (strict <, first met wins).  Here the occupied ones (~10 of 27) are precomputed per query voxel in
 // that visiting order as 32-byte (mean, id) records: one probe, then <= 27 contiguous records, float64 distances in the
 // reference's order -- no staging, no barriers before the block reduction.
+#ifndef ELM_VNBR_WAVES
+#define ELM_VNBR_WAVES 1
+#endif
 template <int METHOD>
-__global__ __launch_bounds__(kBlock) void k_accumulate_vnbr(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
+__global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
                                                             unsigned total_blocks, const ScanState* __restrict__ st,
                                                             double* __restrict__ partials, const RegParams rp) {
-    __shared__ double s_buf[16 * kBlock];
+    __shared__ double s_buf[kRedPass * kBlock];
+    __shared__ double s_red[kSums];
     const unsigned L = xcd_remap(blockIdx.x, total_blocks);
     const int s = find_scan(scans, batch, L, rp);
     const ScanState& S = st[s];
@@ -1361,19 +1426,15 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_vnbr(const DevMap m, cons
                 n_pairs += 1.0;
                 const double ex = r.mx - gx, ey = r.my - gy, ez = r.mz - gz;
                 const double d2 = (ex * ex + ey * ey) + ez * ez;
-                if (d2 < rp.th2) {
-                    double C[9];
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) C[k] = m.vox_cov[(size_t)r.vid * 9 + k];
-                    add_pair<ELM_AVGICP>(acc, S.Rinv, S.tinv, px, py, pz, r.mx, r.my, r.mz, C, nullptr, rp);
-                }
+                if (d2 < rp.th2) voxel_pair<ELM_AVGICP>(acc, m, S, rp, gx, gy, gz, r.vid, r.mx, r.my, r.mz);
             }
             acc[29] = n_pairs;
             acc[30] = n_pairs;
             acc[31] = n_pairs;
         }
     }
-    block_reduce_store_lds(acc, s_buf, partials + (size_t)L * kSums);
+    block_reduce_to_lds<kSums, kRedPass>(acc, s_buf, s_red);
+    if (threadIdx.x < kSums) partials[(size_t)L * kSums + threadIdx.x] = s_red[threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void k_vnbr_fill(const DevMap m, const int32_t* __restrict__ qkeys, unsigned n_q,
@@ -1664,6 +1725,36 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* __restr
     if (done || t >= 64) return; // the first wave does the rest with uniform control flow; lane 0 owns the state
     const bool lead = (t == 0);
 
+    if (rp.method != ELM_P2P) {
+        // the covariance-weighted kernels accumulate in the world frame (add_pair_world): H_l = P^T H_w P, b_l = P^T b_w with
+        // P = diag(R, R), R the rotation the pairs were formed with (S.T is updated further down)
+        __shared__ double hw[36], bw[6];
+        if (t < 36) {
+            const int i = t / 6, j = t % 6;
+            hw[t] = tot[tri(i < j ? i : j, i < j ? j : i)];
+        }
+        if (t < 6) bw[t] = tot[21 + t];
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        // R(r, c) = S.T[c * 4 + r].  H_l(i, j) = sum_{k, l} P(k, i) H_w(k, l) P(l, j): only the 3x3 block of (i, j) contributes
+        if (t < 36) {
+            const int i = t / 6, j = t % 6, bi = (i / 3) * 3, bj = (j / 3) * 3, ii = i % 3, jj = j % 3;
+            double h = 0.0;
+            for (int k = 0; k < 3; ++k) {
+                double row = 0.0;
+                for (int l = 0; l < 3; ++l) row += hw[(bi + k) * 6 + (bj + l)] * S.T[jj * 4 + l];
+                h += S.T[ii * 4 + k] * row;
+            }
+            if (i <= j) tot[tri(i, j)] = h;
+        }
+        if (t < 6) {
+            const int bi = (t / 3) * 3, ii = t % 3;
+            tot[21 + t] = (S.T[ii * 4 + 0] * bw[bi] + S.T[ii * 4 + 1] * bw[bi + 1]) + S.T[ii * 4 + 2] * bw[bi + 2];
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+    }
+
     const ScanDesc sd = scans[s];
     const int iter = S.iters + 1; // i_iteration++ (reg.cpp:311)
     const double n_corr = tot[28];
@@ -1744,7 +1835,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* __restr
 // K3 / K4: map covariances
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_voxel_cov(const DevMap m, const uint2* __restrict__ ranges, double* vox_mean,
-                                                   double* vox_cov) {
+                                                   double* vox_cov, double* vox_cinv) {
     const unsigned v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= m.n_vox) return;
     const uint2 rg = ranges[v];
@@ -1774,9 +1865,12 @@ __global__ __launch_bounds__(256) void k_voxel_cov(const DevMap m, const uint2* 
     }
     for (int k = 0; k < 3; ++k) vox_mean[(size_t)v * 3 + k] = mean[k];
     for (int k = 0; k < 9; ++k) vox_cov[(size_t)v * 9 + k] = C[k];
+    double Ci[9];
+    inv3(C, Ci); // the inverse the registration needs (add_pair_world), by the cofactor form Eigen uses for Matrix3d::inverse()
+    for (int k = 0; k < 9; ++k) vox_cinv[(size_t)v * 9 + k] = Ci[k];
 }
 
-__global__ __launch_bounds__(256) void k_point_cov(const DevMap m, double d2max, double* pt_gicp) {
+__global__ __launch_bounds__(256) void k_point_cov(const DevMap m, double d2max, double* pt_gicp, double* pt_cov) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m.n_pts) return;
     const float4 pf = m.pts[i];
@@ -1829,10 +1923,13 @@ __global__ __launch_bounds__(256) void k_point_cov(const DevMap m, double d2max,
         for (int k = 0; k < 9; ++k) c[k] /= (double)(n - 1);
         plane_regularize(c, C, nf);
     }
+    double Ci[9];
+    inv3(C, Ci); // what the registration needs (add_pair_world); the covariance itself goes to pt_cov for the read-backs
     double* rec = pt_gicp + (size_t)i * 16;
     for (int k = 0; k < 3; ++k) { rec[k] = mean[k]; rec[12 + k] = nf[k]; }
-    for (int k = 0; k < 9; ++k) rec[3 + k] = C[k];
+    for (int k = 0; k < 9; ++k) rec[3 + k] = Ci[k];
     rec[15] = 0.0;
+    for (int k = 0; k < 9; ++k) pt_cov[(size_t)i * 9 + k] = C[k];
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1962,12 +2059,12 @@ void launch_solve(hipStream_t s, const ScanDesc* scans, int batch, ScanState* st
     hipLaunchKernelGGL(k_solve, dim3(batch), dim3(kSolveThreads), 0, s, scans, st, partials, sums, rp, trace, mode, active);
 }
 
-void launch_voxel_cov(hipStream_t s, const DevMap& m, const uint2* ranges, double* vox_mean, double* vox_cov) {
-    hipLaunchKernelGGL(k_voxel_cov, dim3((m.n_vox + 255) / 256), dim3(256), 0, s, m, ranges, vox_mean, vox_cov);
+void launch_voxel_cov(hipStream_t s, const DevMap& m, const uint2* ranges, double* vox_mean, double* vox_cov, double* vox_cinv) {
+    hipLaunchKernelGGL(k_voxel_cov, dim3((m.n_vox + 255) / 256), dim3(256), 0, s, m, ranges, vox_mean, vox_cov, vox_cinv);
 }
 
-void launch_point_cov(hipStream_t s, const DevMap& m, double d2max, double* pt_gicp) {
-    hipLaunchKernelGGL(k_point_cov, dim3((m.n_pts + 255) / 256), dim3(256), 0, s, m, d2max, pt_gicp);
+void launch_point_cov(hipStream_t s, const DevMap& m, double d2max, double* pt_gicp, double* pt_cov) {
+    hipLaunchKernelGGL(k_point_cov, dim3((m.n_pts + 255) / 256), dim3(256), 0, s, m, d2max, pt_gicp, pt_cov);
 }
 
 // ------------------------------------------------------------------------------------------------------
