@@ -98,6 +98,7 @@ class MapInfo(C.Structure):
         ("device_bytes", C.c_uint64),
         ("n_query_voxels", C.c_uint64),
         ("nbr_entries", C.c_uint64),
+        ("index_bytes", C.c_uint64),
     ]
 
 

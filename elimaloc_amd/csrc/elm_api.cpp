@@ -672,6 +672,7 @@ static int build_voxel_neighbourhoods(elm_map* m) {
     m->dm.vnbr = m->d_vnbr;
     m->has_vnbr = true;
     m->info.device_bytes += (size_t)total * sizeof(VoxRec) + (size_t)qcap * sizeof(HashSlot);
+    m->info.index_bytes += (size_t)total * sizeof(VoxRec) + (size_t)qcap * sizeof(HashSlot) + (size_t)m->dm.n_vox * 9 * sizeof(double);
     return ELM_OK;
 }
 
@@ -785,6 +786,7 @@ static int build_cell_grid(elm_map* m, uint64_t max_cells) {
     m->info.device_bytes += gb.size() * sizeof(GridBlk) + gi.size() * sizeof(uint32_t) + (cells + 4) * sizeof(uint32_t) + vcells * sizeof(uint32_t);
     m->info.n_query_voxels = vcells;
     m->info.nbr_entries = n;
+    m->info.index_bytes += gb.size() * sizeof(GridBlk) + (cells + 4) * sizeof(uint32_t) + vcells * sizeof(uint32_t);
     return ELM_OK;
 }
 
@@ -887,6 +889,7 @@ static int build_neighbourhood_lists(elm_map* m) {
     m->info.device_bytes += (size_t)total * (sizeof(Pt3) + sizeof(uint32_t)) + (size_t)qcap * sizeof(HashSlot) + cell_bytes;
     m->info.n_query_voxels = n_q;
     m->info.nbr_entries = total;
+    m->info.index_bytes += (size_t)total * sizeof(Pt3) + (size_t)qcap * sizeof(HashSlot) + cell_bytes;
     return ELM_OK;
 }
 

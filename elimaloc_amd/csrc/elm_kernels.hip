@@ -977,12 +977,25 @@ struct GridHardRec {
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// squared float32 distances of a block's four candidates to g = gh + gl: packed two-wide arithmetic (v_pk_add/mul/fma_f32)
-__device__ __forceinline__ void blk_dist(const GridBlk& B, f32x2 ghx, f32x2 ghy, f32x2 ghz, f32x2 glx, f32x2 gly, f32x2 glz, f32x2& d01, f32x2& d23) {
+// a - splat(b.x) / a - splat(b.y) as ONE packed instruction: the op_sel bits broadcast one half of the second operand, so the six
+// per-point scalars (gh, gl) live in three register pairs instead of six (the compiler does not fold the splat by itself)
+__device__ __forceinline__ f32x2 pk_sub_lo(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_sub_hi(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// squared float32 distances of a block's four candidates to g = gh + gl (gxy = (ghx, ghy), gzl = (ghz, glx), gl2 = (gly, glz)):
+// packed two-wide arithmetic (v_pk_add/mul/fma_f32)
+__device__ __forceinline__ void blk_dist(const GridBlk& B, f32x2 gxy, f32x2 gzl, f32x2 gl2, f32x2& d01, f32x2& d23) {
     const f32x2 x01 = {B.x[0], B.x[1]}, x23 = {B.x[2], B.x[3]}, y01 = {B.y[0], B.y[1]}, y23 = {B.y[2], B.y[3]}, z01 = {B.z[0], B.z[1]}, z23 = {B.z[2], B.z[3]};
-    const f32x2 ex01 = (x01 - ghx) - glx, ex23 = (x23 - ghx) - glx;
-    const f32x2 ey01 = (y01 - ghy) - gly, ey23 = (y23 - ghy) - gly;
-    const f32x2 ez01 = (z01 - ghz) - glz, ez23 = (z23 - ghz) - glz;
+    const f32x2 ex01 = pk_sub_hi(pk_sub_lo(x01, gxy), gzl), ex23 = pk_sub_hi(pk_sub_lo(x23, gxy), gzl);
+    const f32x2 ey01 = pk_sub_lo(pk_sub_hi(y01, gxy), gl2), ey23 = pk_sub_lo(pk_sub_hi(y23, gxy), gl2);
+    const f32x2 ez01 = pk_sub_hi(pk_sub_lo(z01, gzl), gl2), ez23 = pk_sub_hi(pk_sub_lo(z23, gzl), gl2);
     d01 = __builtin_elementwise_fma(ez01, ez01, __builtin_elementwise_fma(ey01, ey01, ex01 * ex01));
     d23 = __builtin_elementwise_fma(ez23, ez23, __builtin_elementwise_fma(ey23, ey23, ex23 * ex23));
 }
@@ -1075,7 +1088,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
             // ulps of |q - g| and the float32 distance is within 2^-20 relative (+ slack / 2) of the reference's float64 one
             const float ghx = (float)gx, ghy = (float)gy, ghz = (float)gz;
             const float glx = (float)(gx - (double)ghx), gly = (float)(gy - (double)ghy), glz = (float)(gz - (double)ghz);
-            const f32x2 hx = {ghx, ghx}, hy = {ghy, ghy}, hz = {ghz, ghz}, lx = {glx, glx}, ly = {gly, gly}, lz = {glz, glz};
+            const f32x2 gxy = {ghx, ghy}, gzl = {ghz, glx}, gl2 = {gly, glz};
             float m1 = __builtin_inff(), m2 = __builtin_inff();
             int j1 = -1;
             for (int t0 = 0; t0 < nblk; t0 += ELM_BLOCKS_PER_TRIP) { // ELM_BLOCKS_PER_TRIP blocks (three 16-byte loads each) per round trip
@@ -1094,7 +1107,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
 #pragma unroll
                 for (int w = 0; w < ELM_BLOCKS_PER_TRIP; ++w) {
                     f32x2 da, db;
-                    blk_dist(B[w], hx, hy, hz, lx, ly, lz, da, db);
+                    blk_dist(B[w], gxy, gzl, gl2, da, db);
                     const int i0 = pb[w] * 4;
                     two_smallest(da.x, i0, m1, m2, j1);
                     two_smallest(da.y, i0 + 1, m1, m2, j1);

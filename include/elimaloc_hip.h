@@ -110,8 +110,9 @@ typedef struct elm_map_info {
     int32_t has_point_cov;
     int32_t _pad;
     uint64_t device_bytes;
-    uint64_t n_query_voxels; /* neighbourhood lists (0 until built) */
-    uint64_t nbr_entries;
+    uint64_t n_query_voxels; /* cell grid: voxels of the dense statistics box; neighbourhood lists: query voxels (0 until built) */
+    uint64_t nbr_entries;    /* cell grid: == n_points (every map point once); neighbourhood lists: ~27 x n_points */
+    uint64_t index_bytes;    /* device bytes of the search structures the accumulate kernels read (built on first use) */
 } elm_map_info;
 
 /* ---------------------------------------------------------------- context ------------------------- */

@@ -48,7 +48,13 @@ try:
                             # launches move no data), so bench.py scales this by ITS units per launch
                             "units_per_launch_profiled": b["roofline"]["units_per_launch"],
                             "hbm_bytes_per_unit": (2.0 * fetch_kb + write_kb) * 1024.0 / max(b["roofline"]["units_per_launch"], 1.0),
-                            "algorithmic_bytes_per_launch": b["roofline"]["bytes_per_unit"] * b["roofline"]["units_per_launch"]})
+                            "requested_bytes_per_unit": b["roofline"].get("requested_bytes_per_unit")})
+            if "SQ_ACTIVE_INST_VALU" in v and "GRBM_GUI_ACTIVE" in v:
+                cyc = v["GRBM_GUI_ACTIVE"]["avg"] / 8.0  # summed over the 8 XCDs
+                summary["valu_busy"] = 4.0 * v["SQ_ACTIVE_INST_VALU"]["avg"] / (1024.0 * cyc)  # 4 cycles per wave64 instruction, 1024 SIMDs
+                summary["valu_insts_per_wave"] = v["SQ_INSTS_VALU"]["avg"] / v["SQ_WAVES"]["avg"]
+            if "TCC_HIT_sum" in v:
+                summary["l2_hit"] = v["TCC_HIT_sum"]["avg"] / (v["TCC_HIT_sum"]["avg"] + v["TCC_MISS_sum"]["avg"])
 except Exception as e:  # noqa: BLE001
     summary["error"] = repr(e)
 json.dump(summary, open(os.path.join(out, "pmc.json"), "w"), indent=1)
