@@ -11,6 +11,7 @@
 //     pcm.cpp:900-930) including the Ouster index sampling and its trailing default point.
 #include <ctype.h>
 #include <math.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -362,6 +363,11 @@ extern "C" int elm_pcd_load_xyz(const char* path, float** xyz_out, size_t* n_out
     for (int a = 0; a < 3; ++a)
         if (!fx[a] || fx[a]->type != 'F' || fx[a]->size != 4 || fx[a]->count != 1) return ELM_ERR_INVALID;
     const size_t n = h.points;
+    // header values are untrusted: no product below may wrap, and a binary body must really hold n records
+    if (h.point_step == 0 || h.point_step > (1u << 20) || (h.data != 2 && n > buf.size()) || n > (SIZE_MAX / 16) / (h.point_step > 12 ? h.point_step : 12))
+        return ELM_ERR_INVALID; // (every ascii / binary record takes at least one byte of the file; a compressed body is checked below)
+    for (int a = 0; a < 3; ++a)
+        if ((size_t)fx[a]->offset + 4 > h.point_step) return ELM_ERR_INVALID;
     float* xyz = (float*)malloc(sizeof(float) * 3 * (n ? n : 1));
     if (!xyz) return ELM_ERR_ALLOC;
     if (h.data == 0) {
@@ -378,7 +384,7 @@ extern "C" int elm_pcd_load_xyz(const char* path, float** xyz_out, size_t* n_out
         }
         if (i != n) { free(xyz); return ELM_ERR_INVALID; }
     } else if (h.data == 1) {
-        if (buf.size() < h.data_pos + n * h.point_step) { free(xyz); return ELM_ERR_INVALID; }
+        if (buf.size() < h.data_pos || buf.size() - h.data_pos < n * h.point_step) { free(xyz); return ELM_ERR_INVALID; }
         const unsigned char* d = (const unsigned char*)buf.data() + h.data_pos;
         for (size_t i = 0; i < n; ++i)
             for (int a = 0; a < 3; ++a) memcpy(&xyz[i * 3 + a], d + i * h.point_step + fx[a]->offset, 4);
@@ -387,7 +393,7 @@ extern "C" int elm_pcd_load_xyz(const char* path, float** xyz_out, size_t* n_out
         uint32_t comp = 0, uncomp = 0;
         memcpy(&comp, buf.data() + h.data_pos, 4);
         memcpy(&uncomp, buf.data() + h.data_pos + 4, 4);
-        if (buf.size() < h.data_pos + 8 + comp || (size_t)uncomp != n * h.point_step) { free(xyz); return ELM_ERR_INVALID; }
+        if (buf.size() - h.data_pos - 8 < (size_t)comp || (size_t)uncomp != n * h.point_step) { free(xyz); return ELM_ERR_INVALID; }
         std::vector<unsigned char> raw(uncomp ? uncomp : 1);
         if (!lzf_decompress((const unsigned char*)buf.data() + h.data_pos + 8, comp, raw.data(), uncomp)) { free(xyz); return ELM_ERR_INVALID; }
         // structure-of-arrays inside: field f occupies bytes [offset_f * n, (offset_f + size_f*count_f) * n)

@@ -287,6 +287,15 @@ def test_pcd_errors(tmp_path):
     h.write_text("FIELDS x y\nSIZE 4 4\nTYPE F F\nCOUNT 1 1\nWIDTH 1\nHEIGHT 1\nDATA ascii\n1 2\n")
     with pytest.raises(_lib.ElmError):
         LoadPcdXyz(h)
+    # hostile headers: POINTS * point_step wraps 64 bits (2^62 * 16), or POINTS far beyond what the file can hold -- refused
+    # before any allocation or copy, for every DATA kind
+    for kind in ("ascii", "binary", "binary_compressed"):
+        for pts in (1 << 62, 1 << 40, 10**12):
+            w = tmp_path / f"wrap_{kind}_{pts}.pcd"
+            w.write_bytes(f"FIELDS x y z w\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\nWIDTH {pts}\nHEIGHT 1\nPOINTS {pts}\nDATA {kind}\n".encode()
+                          + b"\0" * 64)
+            with pytest.raises(_lib.ElmError):
+                LoadPcdXyz(w)
 
 
 # ---------------------------------------------------------------------------------------------- scan records
