@@ -396,7 +396,7 @@ def main():
     else:
         T0h, outh = None, None
 
-    if extras and distributed and world_size > 1 and args.slots > 0:
+    if extras and distributed and args.slots > 0 and (world_size > 1 or os.environ.get("ELM_BENCH_FORCE_REPLICA")):
         # replica mode: whole registrations per GPU, no collective (the comparison SURVEY 8e asks for)
         rctx = Context(local_rank)
         rvm = VoxelHashMap(1.0, 30, rctx)
