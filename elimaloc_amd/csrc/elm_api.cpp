@@ -296,6 +296,8 @@ struct elm_map {
     uint32_t* d_grid_idx = nullptr;
     uint32_t* d_grid_start = nullptr;
     uint32_t* d_vox_stat = nullptr;
+    double* d_grid_gicp = nullptr; // the GICP records in grid slot order (built with the grid / refreshed by CalPointCovAll)
+    size_t grid_slots = 0;
     bool has_grid = false;
     bool grid_refused = false; // the bounding box needs more cells than the budget: neighbourhood lists instead
     bool has_vnbr = false; // voxel-mean lists (VGICP)
@@ -453,7 +455,7 @@ static void map_free(elm_map* m) {
     if (!m) return;
     if (ctx_alive(m->ctx)) (void)hipSetDevice(m->ctx->device); // a context destroyed first: just release the device memory
     void* ptrs[] = {m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_vox_cinv, m->d_pt_gicp, m->d_pt_cov, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off, m->d_vqslots, m->d_vnbr,
-                    m->d_grid_blk, m->d_grid_idx, m->d_grid_start, m->d_vox_stat};
+                    m->d_grid_blk, m->d_grid_idx, m->d_grid_start, m->d_vox_stat, m->d_grid_gicp};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete m;
@@ -559,6 +561,7 @@ extern "C" int elm_map_cal_voxel_cov_all(elm_map* m) {
     return ELM_OK;
 }
 
+static int refresh_grid_gicp(elm_map* m);
 extern "C" int elm_map_cal_point_cov_all(elm_map* m, double d_search_dist) {
     if (!m) return ELM_ERR_INVALID;
     elm_ctx* ctx = m->ctx;
@@ -576,7 +579,7 @@ extern "C" int elm_map_cal_point_cov_all(elm_map* m, double d_search_dist) {
     }
     m->dm.pt_gicp = m->d_pt_gicp;
     m->info.has_point_cov = 1;
-    return ELM_OK;
+    return refresh_grid_gicp(m); // a grid built before the covariances (or a new search radius): regather
 }
 
 // query voxels = every floor key within +-1 of a stored (trunc) key that holds points, first-seen order
@@ -673,6 +676,22 @@ static int build_voxel_neighbourhoods(elm_map* m) {
     m->has_vnbr = true;
     m->info.device_bytes += (size_t)total * sizeof(VoxRec) + (size_t)qcap * sizeof(HashSlot);
     m->info.index_bytes += (size_t)total * sizeof(VoxRec) + (size_t)qcap * sizeof(HashSlot) + (size_t)m->dm.n_vox * 9 * sizeof(double);
+    return ELM_OK;
+}
+
+// The GICP payload in grid slot order (DevMap::grid_gicp): needs the grid and the point covariances, whichever comes last.
+static int refresh_grid_gicp(elm_map* m) {
+    if (!m->has_grid || !m->info.has_point_cov || !m->grid_slots) return ELM_OK;
+    elm_ctx* ctx = m->ctx;
+    if (!m->d_grid_gicp) {
+        HIPCHK(ctx, hipMalloc((void**)&m->d_grid_gicp, m->grid_slots * 16 * sizeof(double)));
+        m->info.device_bytes += m->grid_slots * 16 * sizeof(double);
+    }
+    (void)hipGetLastError();
+    launch_gather_gicp(ctx->stream, m->dm, m->grid_slots, m->d_grid_gicp);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    m->dm.grid_gicp = m->d_grid_gicp;
     return ELM_OK;
 }
 
@@ -783,6 +802,11 @@ static int build_cell_grid(elm_map* m, uint64_t max_cells) {
     GRID_CHK(hipStreamSynchronize(ctx->stream));
 #undef GRID_CHK
     m->has_grid = true;
+    m->grid_slots = gi.size();
+    {
+        const int rc2 = refresh_grid_gicp(m);
+        if (rc2 != ELM_OK) return rc2;
+    }
     m->info.device_bytes += gb.size() * sizeof(GridBlk) + gi.size() * sizeof(uint32_t) + (cells + 4) * sizeof(uint32_t) + vcells * sizeof(uint32_t);
     m->info.n_query_voxels = vcells;
     m->info.nbr_entries = n;

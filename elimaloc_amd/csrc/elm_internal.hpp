@@ -75,6 +75,7 @@ struct DevMap {
     const uint32_t* grid_idx;   // [4 * n_blk] bucket-order index of every candidate slot (GICP payload, insertion order for exact
                                 // ties); 0xFFFFFFFF in padding slots
     const uint32_t* grid_start; // [gnx * gny * gnz + 4]
+    const double* grid_gicp;    // [4 * n_blk][16]: pt_gicp gathered into slot order -- a GICP match reads its record without the index hop
     int32_t gx0, gy0, gz0;      // cell coordinates of grid entry (0, 0, 0)
     int32_t gnx, gny, gnz;
     // dense voxel box of the floor keys a query can have near the map: cnt27 | nocc27 << 16 of the reference's 27-voxel walk
@@ -167,6 +168,7 @@ int stream_max_slots(); // slots one elm_register_stream call can iterate concur
 void launch_accumulate_grid(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                             ScanState* st, double* partials, const RegParams& rp);
 void launch_vox_stat(hipStream_t s, const DevMap& m, uint32_t* out); // fills DevMap::vox_stat's box (m.vx0.., m.vnx..)
+void launch_gather_gicp(hipStream_t s, const DevMap& m, size_t n_slots, double* out); // pt_gicp[grid_idx[slot]] -> out[slot]
 // half-voxel cell of a stored coordinate (host + device; the binning of DevMap::grid_pts)
 __host__ __device__ inline int grid_cell_of(double a, double voxel_size) {
     const double t = a / voxel_size; // the reference's own key arithmetic (vhm.cpp:275), truncated below

@@ -266,7 +266,7 @@ __device__ __forceinline__ void nearest_voxel_direct(const DevMap& m, int vx, in
 template <int METHOD>
 __device__ __forceinline__ void finish_point_pair(double* acc, const DevMap& m, const ScanState& S, const RegParams& rp,
                                                   double px, double py, double pz, double gx, double gy, double gz,
-                                                  double bd2, float bx, float by, float bz, int bidx) {
+                                                  double bd2, float bx, float by, float bz, int bidx, const double* __restrict__ payload) {
     // no bucket at all: the reference's default PointStruct at the origin with cov I (vhm.cpp:37, QUIRK)
     const double dfin = (bidx >= 0) ? bd2 : (gx * gx + gy * gy) + gz * gz;
     if (!(dfin < rp.th2)) return;
@@ -276,10 +276,11 @@ __device__ __forceinline__ void finish_point_pair(double* acc, const DevMap& m, 
     } else {
         double Ci[9], mean[3], nf[3];
         if (bidx >= 0) {
+            const double* __restrict__ rec = payload + (size_t)bidx * 16;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) Ci[k] = m.pt_gicp[(size_t)bidx * 16 + 3 + k];
+            for (int k = 0; k < 9; ++k) Ci[k] = rec[3 + k];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { mean[k] = m.pt_gicp[(size_t)bidx * 16 + k]; nf[k] = m.pt_gicp[(size_t)bidx * 16 + 12 + k]; }
+            for (int k = 0; k < 3; ++k) { mean[k] = rec[k]; nf[k] = rec[12 + k]; }
         } else {
             Ci[0] = 1; Ci[1] = 0; Ci[2] = 0; Ci[3] = 0; Ci[4] = 1; Ci[5] = 0; Ci[6] = 0; Ci[7] = 0; Ci[8] = 1;
             mean[0] = mean[1] = mean[2] = 0.0;
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_direct(const DevMap m, co
             float bx = 0.f, by = 0.f, bz = 0.f;
             int bidx = -1;
             nearest_point_direct(m, vx, vy, vz, gx, gy, gz, bd2, bx, by, bz, bidx, n_cand, n_occ);
-            finish_point_pair<METHOD>(acc, m, S, rp, px, py, pz, gx, gy, gz, bd2, bx, by, bz, bidx);
+            finish_point_pair<METHOD>(acc, m, S, rp, px, py, pz, gx, gy, gz, bd2, bx, by, bz, bidx, m.pt_gicp);
         } else if (METHOD == ELM_VGICP) {
             double bd2 = DBL_MAX, bmx = 0.0, bmy = 0.0, bmz = 0.0;
             int bvid = -1;
@@ -916,7 +917,7 @@ __global__ __launch_bounds__(kBlock, ELM_CELL_WAVES) void k_accumulate_cell(cons
         if (METHOD == ELM_P2P) {
             if (bd2 < rp.th2) pair_p2p(v, S.Rinv, px, py, pz, ex, ey, ez, bd2, rp);
         } else {
-            finish_point_pair<METHOD>(v, m, S, rp, px, py, pz, gx, gy, gz, bd2, bx, by, bz, bidx);
+            finish_point_pair<METHOD>(v, m, S, rp, px, py, pz, gx, gy, gz, bd2, bx, by, bz, bidx, m.pt_gicp);
         }
         v[NV - 3] = (double)qp.cnt;  // candidates of the reference's walk
         v[NV - 2] = (double)qp.nocc; // occupied neighbour voxels
@@ -1261,14 +1262,14 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
         if (bj >= 0) {
             const Pt3 q = blk_point(lp, bj);
             bx = q.x; by = q.y; bz = q.z;
-            bidx = (METHOD == ELM_GICP) ? (int)m.grid_idx[bj] : 0;
+            bidx = bj; // GICP: the payload records are stored in slot order (DevMap::grid_gicp)
         }
         const double ex = (double)bx - gx, ey = (double)by - gy, ez = (double)bz - gz;
         const double bd2 = (ex * ex + ey * ey) + ez * ez;
         if (METHOD == ELM_P2P) {
             if (bd2 < rp.th2) pair_p2p(v, S.Rinv, px, py, pz, ex, ey, ez, bd2, rp);
         } else {
-            finish_point_pair<METHOD>(v, m, S, rp, px, py, pz, gx, gy, gz, bd2, bx, by, bz, bidx);
+            finish_point_pair<METHOD>(v, m, S, rp, px, py, pz, gx, gy, gz, bd2, bx, by, bz, bidx, m.grid_gicp);
         }
         v[NV - 3] = (double)(stat & 0xFFFFu); // candidates of the reference's walk
         v[NV - 2] = (double)(stat >> 16);     // occupied neighbour voxels
@@ -1276,6 +1277,15 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
     }
     block_reduce_to_lds<NV, kRedPass>(v, s_buf, s_red);
     if (threadIdx.x < kSums) partials[(size_t)L * kSums + threadIdx.x] = (METHOD == ELM_P2P) ? p2p_expand(s_red, (int)threadIdx.x) : s_red[threadIdx.x];
+}
+
+// map build: the GICP payload records in grid slot order (16 lanes per record, one 8-byte word each)
+__global__ __launch_bounds__(256) void k_gather_gicp(const DevMap m, size_t n_slots, double* __restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t slot = t >> 4;
+    if (slot >= n_slots) return;
+    const unsigned src = m.grid_idx[slot];
+    out[t] = (src == 0xFFFFFFFFu) ? 0.0 : m.pt_gicp[(size_t)src * 16 + (t & 15)];
 }
 
 // map build: cnt27 | nocc27 << 16 for every voxel of the dense floor-key box (see DevMap::vox_stat)
@@ -2037,6 +2047,10 @@ void launch_accumulate_grid(hipStream_t s, const DevMap& m, const ScanDesc* scan
         hipLaunchKernelGGL((k_accumulate_grid<ELM_P2P>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
     else
         hipLaunchKernelGGL((k_accumulate_grid<ELM_GICP>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
+}
+void launch_gather_gicp(hipStream_t s, const DevMap& m, size_t n_slots, double* out) {
+    const size_t threads = n_slots * 16;
+    hipLaunchKernelGGL(k_gather_gicp, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, m, n_slots, out);
 }
 void launch_vox_stat(hipStream_t s, const DevMap& m, uint32_t* out) {
     const size_t n = (size_t)m.vnx * m.vny * m.vnz;

@@ -196,7 +196,10 @@ int elm_register_batch(elm_ctx* ctx, const elm_map* map, elm_scan* const* scans,
  * elm_register_batch / elm_register on the same inputs.  trace: NULL or count*ELM_MAX_ITER_TRACE entries. */
 int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* const* scans, int count, const double* T0,
                         const elm_reg_config* cfg, int slots, elm_reg_result* results, elm_iter_trace* trace);
-/* Asynchronous halves of the above: enqueue everything on the context stream / wait and fetch results. */
+/* Asynchronous halves of the above: enqueue everything on the context stream / wait and fetch results.  enqueue returns
+ * without waiting for the device on the first batch of a context; afterwards it polls the device-side count of still-iterating
+ * scans (one 4-byte read-back where the previous batch finished, then every second iteration) so that it can stop enqueueing
+ * iterations early -- i.e. it may block for the iterations enqueued so far.  Exactly one batch may be in flight per context. */
 int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_scan* const* scans, int batch,
                                const double* T0, const elm_reg_config* cfg, int want_trace);
 int elm_register_batch_finish(elm_ctx* ctx, elm_reg_result* results, elm_iter_trace* trace);
