@@ -291,6 +291,7 @@ struct elm_map {
     uint32_t* d_nbr_idx = nullptr;
     uint16_t* d_nbr_cell_off = nullptr;
     HashSlot* d_vqslots = nullptr;
+    uint32_t* d_vq_dense = nullptr;
     VoxRec* d_vnbr = nullptr;
     GridBlk* d_grid_blk = nullptr;    // dense cell grid (DevMap::grid_*), the default P2P / GICP search index
     uint32_t* d_grid_idx = nullptr;
@@ -454,7 +455,7 @@ static void build_host(const float* xyz, size_t n, double voxel_size, int max_po
 static void map_free(elm_map* m) {
     if (!m) return;
     if (ctx_alive(m->ctx)) (void)hipSetDevice(m->ctx->device); // a context destroyed first: just release the device memory
-    void* ptrs[] = {m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_vox_cinv, m->d_pt_gicp, m->d_pt_cov, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off, m->d_vqslots, m->d_vnbr,
+    void* ptrs[] = {m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_vox_cinv, m->d_pt_gicp, m->d_pt_cov, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off, m->d_vqslots, m->d_vq_dense, m->d_vnbr,
                     m->d_grid_blk, m->d_grid_idx, m->d_grid_start, m->d_vox_stat, m->d_grid_gicp};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -605,6 +606,7 @@ static void enumerate_query_keys(const elm_map* m, std::vector<int32_t>& qkeys) 
     }
 }
 
+static uint64_t grid_max_cells();
 // Voxel-mean lists for VGICP (see DevMap::vnbr): built lazily at the first VGICP registration, after CalVoxelCovAll.
 static int build_voxel_neighbourhoods(elm_map* m) {
     if (m->has_vnbr) return ELM_OK;
@@ -667,6 +669,33 @@ static int build_voxel_neighbourhoods(elm_map* m) {
         }
         VN_CHK(hipMalloc((void**)&m->d_vqslots, (size_t)qcap * sizeof(HashSlot)));
         VN_CHK(hipMemcpy(m->d_vqslots, qs.data(), (size_t)qcap * sizeof(HashSlot), hipMemcpyHostToDevice));
+    }
+    // the same table addressed directly by the dense box of floor keys (when the box fits the cell budget and the packed word
+    // holds the offsets): the kernel then needs no hash probe -- one 4-byte load at a computed, spatially coherent address
+    if (n_q && total < (1ull << 27)) {
+        int32_t klo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, khi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+        for (uint32_t q = 0; q < n_q; ++q)
+            for (int a = 0; a < 3; ++a) {
+                klo[a] = std::min(klo[a], qkeys[3 * q + a]);
+                khi[a] = std::max(khi[a], qkeys[3 * q + a]);
+            }
+        const int64_t vd[3] = {(int64_t)khi[0] - klo[0] + 1, (int64_t)khi[1] - klo[1] + 1, (int64_t)khi[2] - klo[2] + 1};
+        const uint64_t vcells = (uint64_t)vd[0] * (uint64_t)vd[1] * (uint64_t)vd[2];
+        if (vcells <= grid_max_cells() && m->ctx->kernel_mode == 4) {
+            std::vector<uint32_t> dense(vcells, 0u);
+            for (uint32_t q = 0; q < n_q; ++q) {
+                const uint64_t idx = ((uint64_t)(qkeys[3 * q] - klo[0]) * (uint64_t)vd[1] + (uint64_t)(qkeys[3 * q + 1] - klo[1])) * (uint64_t)vd[2] +
+                                     (uint64_t)(qkeys[3 * q + 2] - klo[2]);
+                dense[idx] = (offs[q] << 5) | nocc[q]; // nocc <= 27
+            }
+            VN_CHK(hipMalloc((void**)&m->d_vq_dense, vcells * sizeof(uint32_t)));
+            VN_CHK(hipMemcpy(m->d_vq_dense, dense.data(), vcells * sizeof(uint32_t), hipMemcpyHostToDevice));
+            m->dm.vq_dense = m->d_vq_dense;
+            m->dm.vq_x0 = klo[0]; m->dm.vq_y0 = klo[1]; m->dm.vq_z0 = klo[2];
+            m->dm.vq_nx = (int32_t)vd[0]; m->dm.vq_ny = (int32_t)vd[1]; m->dm.vq_nz = (int32_t)vd[2];
+            m->info.device_bytes += vcells * sizeof(uint32_t);
+            m->info.index_bytes += vcells * sizeof(uint32_t);
+        }
     }
 #undef VN_CHK
     cleanup();

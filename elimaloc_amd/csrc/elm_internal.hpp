@@ -62,6 +62,9 @@ struct DevMap {
     uint32_t vqmask;
     uint32_t _pad2;
     const VoxRec* vnbr;
+    const uint32_t* vq_dense; // optional: the same (start << 5 | cnt) addressed by the dense floor-key box (vq_x0.., no hash probe)
+    int32_t vq_x0, vq_y0, vq_z0;
+    int32_t vq_nx, vq_ny, vq_nz;
     const uint16_t* nbr_cell_off; // [n_q][224]: every list is sorted by half-voxel cell (6x6x6 grid, clamped); cell c =
                                   // entries [off[c], off[c+1]) of the list
     // dense half-voxel cell grid over the map's bounding box (optional; default search index when it fits the memory budget):

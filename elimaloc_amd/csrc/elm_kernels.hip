@@ -1402,7 +1402,13 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
         const double gz = ((S.T[2] * px + S.T[6] * py) + S.T[10] * pz) + S.T[14];
         const int vx = floor_key(gx, m), vy = floor_key(gy, m), vz = floor_key(gz, m);
         unsigned start = 0, cnt = 0;
-        {
+        if (m.vq_dense) { // the dense floor-key box: no probe
+            const int ux = vx - m.vq_x0, uy = vy - m.vq_y0, uz = vz - m.vq_z0;
+            if ((unsigned)ux < (unsigned)m.vq_nx && (unsigned)uy < (unsigned)m.vq_ny && (unsigned)uz < (unsigned)m.vq_nz) {
+                const unsigned w = m.vq_dense[((size_t)ux * m.vq_ny + uy) * m.vq_nz + uz];
+                start = w >> 5; cnt = w & 31u;
+            }
+        } else {
             unsigned h = hash3(vx, vy, vz) & m.vqmask;
             for (;;) {
                 const unsigned h2 = (h + 1) & m.vqmask;
