@@ -164,14 +164,17 @@ __device__ __forceinline__ void add_pair(double* acc, const double* Rinv, const 
 // voxel at map build, the pairs are accumulated in the world frame and k_solve applies the one congruence with P per
 // iteration.  Equal to the reference's sums up to rounding (R orthonormal to ~1e-16).  |r_l| = |e|.
 //   acc[0..20] upper J^T M J, acc[21..26] J^T M r, acc[27] residual sum, acc[28] pair count  -- world frame
-template <int METHOD>
+// ASSIGN: the caller adds exactly one pair to all-zero sums (plain stores instead of additions: 0.0 + x cannot be folded by the
+// compiler, and the zeros cost registers)
+template <int METHOD, bool ASSIGN>
 __device__ __forceinline__ void add_pair_world(double* acc, double ax, double ay, double az, double ex, double ey, double ez,
                                                const double* Cinv, const double* nfit, const RegParams& rp) {
+#define ELM_ACC(k, x) do { if (ASSIGN) acc[k] = (x); else acc[k] += (x); } while (0)
     const double r2 = (ex * ex + ey * ey) + ez * ez;
     const double den = rp.th + r2;
     double w = rp.th2 / (den * den); // square(th) / square(th + |r|^2)
     if (METHOD == ELM_GICP) w = w * 0.8 + 0.2;
-    acc[28] += 1.0;
+    ELM_ACC(28, 1.0);
     if (METHOD == ELM_VGICP || METHOD == ELM_AVGICP) {
         if (w < 0.01) return; // reg.cpp:201 -- skipped pairs stay in the fitness denominator
     }
@@ -186,34 +189,35 @@ __device__ __forceinline__ void add_pair_world(double* acc, double ax, double ay
         AB[i * 3 + 1] = A[i * 3 + 0] * az - A[i * 3 + 2] * ax;
         AB[i * 3 + 2] = A[i * 3 + 1] * ax - A[i * 3 + 0] * ay;
     }
-    acc[tri(0, 0)] += A[0]; acc[tri(0, 1)] += A[1]; acc[tri(0, 2)] += A[2];
-    acc[tri(1, 1)] += A[4]; acc[tri(1, 2)] += A[5]; acc[tri(2, 2)] += A[8];
+    ELM_ACC(tri(0, 0), A[0]); ELM_ACC(tri(0, 1), A[1]); ELM_ACC(tri(0, 2), A[2]);
+    ELM_ACC(tri(1, 1), A[4]); ELM_ACC(tri(1, 2), A[5]); ELM_ACC(tri(2, 2), A[8]);
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) acc[tri(i, 3 + j)] += AB[i * 3 + j];
-    acc[tri(3, 3)] += ay * AB[6] - az * AB[3];
-    acc[tri(3, 4)] += ay * AB[7] - az * AB[4];
-    acc[tri(3, 5)] += ay * AB[8] - az * AB[5];
-    acc[tri(4, 4)] += az * AB[1] - ax * AB[7];
-    acc[tri(4, 5)] += az * AB[2] - ax * AB[8];
-    acc[tri(5, 5)] += ax * AB[5] - ay * AB[2];
+        for (int j = 0; j < 3; ++j) ELM_ACC(tri(i, 3 + j), AB[i * 3 + j]);
+    ELM_ACC(tri(3, 3), ay * AB[6] - az * AB[3]);
+    ELM_ACC(tri(3, 4), ay * AB[7] - az * AB[4]);
+    ELM_ACC(tri(3, 5), ay * AB[8] - az * AB[5]);
+    ELM_ACC(tri(4, 4), az * AB[1] - ax * AB[7]);
+    ELM_ACC(tri(4, 5), az * AB[2] - ax * AB[8]);
+    ELM_ACC(tri(5, 5), ax * AB[5] - ay * AB[2]);
     const double bx = (A[0] * ex + A[1] * ey) + A[2] * ez;
     const double by = (A[3] * ex + A[4] * ey) + A[5] * ez;
     const double bz = (A[6] * ex + A[7] * ey) + A[8] * ez;
-    acc[21] += bx; acc[22] += by; acc[23] += bz;
-    acc[24] += ay * bz - az * by;
-    acc[25] += az * bx - ax * bz;
-    acc[26] += ax * by - ay * bx;
+    ELM_ACC(21, bx); ELM_ACC(22, by); ELM_ACC(23, bz);
+    ELM_ACC(24, ay * bz - az * by);
+    ELM_ACC(25, az * bx - ax * bz);
+    ELM_ACC(26, ax * by - ay * bx);
     if (METHOD == ELM_GICP) {
         // |r_l . n_l| with n_l the normalised R^-1 n (reg.cpp:91-95, 128) = |e . n| / |n|
         const double nn2 = (nfit[0] * nfit[0] + nfit[1] * nfit[1]) + nfit[2] * nfit[2];
         const double dot = (ex * nfit[0] + ey * nfit[1]) + ez * nfit[2];
-        acc[27] += (nn2 > 0.0) ? fabs(dot) / sqrt(nn2) : fabs(dot);
+        ELM_ACC(27, (nn2 > 0.0) ? fabs(dot) / sqrt(nn2) : fabs(dot));
     } else {
-        acc[27] += sqrt(r2);
+        ELM_ACC(27, sqrt(r2));
     }
 }
+#undef ELM_ACC
 
 // ------------------------------------------------------------------------------------------------------
 // K1
@@ -263,7 +267,7 @@ __device__ __forceinline__ void nearest_voxel_direct(const DevMap& m, int vx, in
 }
 
 // pair payloads shared by the kernels
-template <int METHOD>
+template <int METHOD, bool ASSIGN = false>
 __device__ __forceinline__ void finish_point_pair(double* acc, const DevMap& m, const ScanState& S, const RegParams& rp,
                                                   double px, double py, double pz, double gx, double gy, double gz,
                                                   double bd2, float bx, float by, float bz, int bidx, const double* __restrict__ payload) {
@@ -287,10 +291,10 @@ __device__ __forceinline__ void finish_point_pair(double* acc, const DevMap& m, 
             nf[0] = 1.0; nf[1] = 0.0; nf[2] = 0.0;
         }
         // GICP's target position is the neighbourhood MEAN of the matched point (reg.cpp:97)
-        add_pair_world<ELM_GICP>(acc, gx - S.T[12], gy - S.T[13], gz - S.T[14], mean[0] - gx, mean[1] - gy, mean[2] - gz, Ci, nf, rp);
+        add_pair_world<ELM_GICP, ASSIGN>(acc, gx - S.T[12], gy - S.T[13], gz - S.T[14], mean[0] - gx, mean[1] - gy, mean[2] - gz, Ci, nf, rp);
     }
 }
-template <int METHOD>
+template <int METHOD, bool ASSIGN = false>
 __device__ __forceinline__ void voxel_pair(double* acc, const DevMap& m, const ScanState& S, const RegParams& rp, double gx, double gy,
                                            double gz, int vid, double mx, double my, double mz) {
     double Ci[9];
@@ -300,15 +304,16 @@ __device__ __forceinline__ void voxel_pair(double* acc, const DevMap& m, const S
     } else {
         Ci[0] = 1; Ci[1] = 0; Ci[2] = 0; Ci[3] = 0; Ci[4] = 1; Ci[5] = 0; Ci[6] = 0; Ci[7] = 0; Ci[8] = 1;
     }
-    add_pair_world<METHOD>(acc, gx - S.T[12], gy - S.T[13], gz - S.T[14], mx - gx, my - gy, mz - gz, Ci, nullptr, rp);
+    add_pair_world<METHOD, ASSIGN>(acc, gx - S.T[12], gy - S.T[13], gz - S.T[14], mx - gx, my - gy, mz - gz, Ci, nullptr, rp);
 }
+template <bool ASSIGN = false>
 __device__ __forceinline__ void finish_voxel_pair(double* acc, const DevMap& m, const ScanState& S, const RegParams& rp,
                                                   double px, double py, double pz, double gx, double gy, double gz,
                                                   double bd2, int bvid, double bmx, double bmy, double bmz) {
     const double dfin = (bvid >= 0) ? bd2 : (gx * gx + gy * gy) + gz * gz;
     if (!(dfin < rp.th2)) return;
     if (bvid < 0) bmx = bmy = bmz = 0.0;
-    voxel_pair<ELM_VGICP>(acc, m, S, rp, gx, gy, gz, bvid, bmx, bmy, bmz);
+    voxel_pair<ELM_VGICP, ASSIGN>(acc, m, S, rp, gx, gy, gz, bvid, bmx, bmy, bmz);
 }
 
 // block -> (scan, first point) ; returns false when the scan is finished
@@ -917,7 +922,7 @@ __global__ __launch_bounds__(kBlock, ELM_CELL_WAVES) void k_accumulate_cell(cons
         if (METHOD == ELM_P2P) {
             if (bd2 < rp.th2) pair_p2p(v, S.Rinv, px, py, pz, ex, ey, ez, bd2, rp);
         } else {
-            finish_point_pair<METHOD>(v, m, S, rp, px, py, pz, gx, gy, gz, bd2, bx, by, bz, bidx, m.pt_gicp);
+            finish_point_pair<METHOD, true>(v, m, S, rp, px, py, pz, gx, gy, gz, bd2, bx, by, bz, bidx, m.pt_gicp);
         }
         v[NV - 3] = (double)qp.cnt;  // candidates of the reference's walk
         v[NV - 2] = (double)qp.nocc; // occupied neighbour voxels
@@ -1269,7 +1274,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
         if (METHOD == ELM_P2P) {
             if (bd2 < rp.th2) pair_p2p(v, S.Rinv, px, py, pz, ex, ey, ez, bd2, rp);
         } else {
-            finish_point_pair<METHOD>(v, m, S, rp, px, py, pz, gx, gy, gz, bd2, bx, by, bz, bidx, m.grid_gicp);
+            finish_point_pair<METHOD, true>(v, m, S, rp, px, py, pz, gx, gy, gz, bd2, bx, by, bz, bidx, m.grid_gicp);
         }
         v[NV - 3] = (double)(stat & 0xFFFFu); // candidates of the reference's walk
         v[NV - 2] = (double)(stat >> 16);     // occupied neighbour voxels
@@ -1375,6 +1380,9 @@ __global__ __launch_bounds__(64) void k_nbr_cellsort(const DevMap m, const int32
 // nearest voxel MEAN (strict <, first met wins).  Here the occupied ones (~10 of 27) are precomputed per query voxel in
 // that visiting order as 32-byte (mean, id) records: one probe, then <= 27 contiguous records, float64 distances in the
 // reference's order -- no staging, no barriers before the block reduction.
+#ifndef ELM_VNBR_RECS
+#define ELM_VNBR_RECS 4
+#endif
 #ifndef ELM_VNBR_WAVES
 #define ELM_VNBR_WAVES 1
 #endif
@@ -1427,18 +1435,25 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
         if (METHOD == ELM_VGICP) {
             double bd2 = DBL_MAX, bmx = 0.0, bmy = 0.0, bmz = 0.0;
             int bvid = -1;
-            for (unsigned j = 0; j < cnt; j += 4) { // four records (eight 16-byte loads) per round trip
-                VoxRec r[4];
+            unsigned bj = 0;
+            for (unsigned j = 0; j < cnt; j += ELM_VNBR_RECS) { // ELM_VNBR_RECS records (two 16-byte loads each) per round trip
+                VoxRec r[ELM_VNBR_RECS];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) r[u] = lp[min(j + u, cnt - 1)];
+                for (int u = 0; u < ELM_VNBR_RECS; ++u) r[u] = lp[min(j + u, cnt - 1)]; // past the end: the last record again (never < itself)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < ELM_VNBR_RECS; ++u) {
                     const double ex = r[u].mx - gx, ey = r[u].my - gy, ez = r[u].mz - gz;
                     const double d2 = (ex * ex + ey * ey) + ez * ez;
-                    if (j + u < cnt && d2 < bd2) { bd2 = d2; bvid = r[u].vid; bmx = r[u].mx; bmy = r[u].my; bmz = r[u].mz; }
+                    const bool c = d2 < bd2; // strict: the first met keeps a tie (vhm.cpp:128)
+                    bj = c ? j + u : bj;
+                    bd2 = c ? d2 : bd2;
                 }
             }
-            finish_voxel_pair(acc, m, S, rp, px, py, pz, gx, gy, gz, bd2, bvid, bmx, bmy, bmz);
+            if (cnt) { // the winner's record again (an L1 hit) instead of five registers carried through the loop
+                const VoxRec w = lp[min(bj, cnt - 1)];
+                bvid = w.vid; bmx = w.mx; bmy = w.my; bmz = w.mz;
+            }
+            finish_voxel_pair<true>(acc, m, S, rp, px, py, pz, gx, gy, gz, bd2, bvid, bmx, bmy, bmz);
             acc[29] = (double)cnt;
             acc[30] = (double)cnt;
             acc[31] = (double)cnt;
