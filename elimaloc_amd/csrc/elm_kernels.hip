@@ -209,10 +209,8 @@ __device__ __forceinline__ void add_pair_world(double* acc, double ax, double ay
     ELM_ACC(25, az * bx - ax * bz);
     ELM_ACC(26, ax * by - ay * bx);
     if (METHOD == ELM_GICP) {
-        // |r_l . n_l| with n_l the normalised R^-1 n (reg.cpp:91-95, 128) = |e . n| / |n|
-        const double nn2 = (nfit[0] * nfit[0] + nfit[1] * nfit[1]) + nfit[2] * nfit[2];
-        const double dot = (ex * nfit[0] + ey * nfit[1]) + ez * nfit[2];
-        ELM_ACC(27, (nn2 > 0.0) ? fabs(dot) / sqrt(nn2) : fabs(dot));
+        // |r_l . n_l| with n_l the normalised R^-1 n (reg.cpp:91-95, 128) = |e . n| for the unit normal the map build stores
+        ELM_ACC(27, fabs((ex * nfit[0] + ey * nfit[1]) + ez * nfit[2]));
     } else {
         ELM_ACC(27, sqrt(r2));
     }
@@ -1969,6 +1967,11 @@ __global__ __launch_bounds__(256) void k_point_cov(const DevMap m, double d2max,
     }
     double Ci[9];
     inv3(C, Ci); // what the registration needs (add_pair_world); the covariance itself goes to pt_cov for the read-backs
+    {
+        // the fitness normal as a unit vector (the reference normalises R^-1 n per pair, reg.cpp:93-95)
+        const double nn = sqrt((nf[0] * nf[0] + nf[1] * nf[1]) + nf[2] * nf[2]);
+        if (nn > 0.0) { nf[0] /= nn; nf[1] /= nn; nf[2] /= nn; }
+    }
     double* rec = pt_gicp + (size_t)i * 16;
     for (int k = 0; k < 3; ++k) { rec[k] = mean[k]; rec[12 + k] = nf[k]; }
     for (int k = 0; k < 9; ++k) rec[3 + k] = Ci[k];
