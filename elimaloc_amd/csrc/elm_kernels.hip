@@ -220,8 +220,7 @@ __device__ __forceinline__ void add_pair_world(double* acc, double ax, double ay
 // ------------------------------------------------------------------------------------------------------
 // K1
 // ------------------------------------------------------------------------------------------------------
-// Nearest bucket point straight from global memory (one thread walks its 27 voxels).  Used by the "direct" kernel
-// and as the fall-back of the staged kernel for workgroups whose points are too spread out to stage.
+// Nearest bucket point straight from global memory (one thread walks its 27 voxels): the "direct" kernel.
 // GetCorrespondencePoints (vhm.cpp:31-88): strict-< minimum over every bucket point of the 27 voxels, voxels
 // visited x-major .. z-minor (vhm.cpp:234-240), bucket in insertion order.
 __device__ __forceinline__ void nearest_point_direct(const DevMap& m, int vx, int vy, int vz, double gx, double gy,
@@ -338,49 +337,11 @@ __device__ __forceinline__ void block_reduce_store(double* acc, double (*red)[32
         out[threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
-// cross-lane helpers for the wave-cooperative stage: v_readlane for wave-uniform sources and DPP row operations instead of
-// ds_bpermute (__shfl), which goes through the LDS pipeline and costs ~100 cycles per dependent step
-__device__ __forceinline__ int lane_bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
-__device__ __forceinline__ unsigned lane_bcast(unsigned v, int src) { return (unsigned)__builtin_amdgcn_readlane((int)v, src); }
-__device__ __forceinline__ double lane_bcast(double v, int src) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
-}
+// DPP row operations (quad permutes, row rotations / mirrors) instead of ds_bpermute (__shfl), which goes through the LDS pipeline
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v) {
     const int lo = __double2loint(v), hi = __double2hiint(v);
     return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false));
-}
-__device__ __forceinline__ double wave_min(double v) { // minimum over the 64 lanes, in every lane
-    v = fmin(v, dpp_move<0xB1>(v));  // quad_perm [1,0,3,2]
-    v = fmin(v, dpp_move<0x4E>(v));  // quad_perm [2,3,0,1]
-    v = fmin(v, dpp_move<0x124>(v)); // row_ror:4
-    v = fmin(v, dpp_move<0x128>(v)); // row_ror:8 -> every lane holds the minimum of its row of 16
-    return fmin(fmin(lane_bcast(v, 0), lane_bcast(v, 16)), fmin(lane_bcast(v, 32), lane_bcast(v, 48)));
-}
-
-// Block reduction of the 32 packed sums through an LDS transpose (two halves of 16 values, 32 KB each): every
-// thread stores its values column-wise, then 16 lanes per value add 16 strided columns each and finish with four
-// shuffle steps.  ~40 LDS/shuffle operations per thread instead of 192 dependent shuffles.  Deterministic.
-// buf must hold 16 * kBlock doubles and must not be in use by anybody (callers sync before).
-__device__ __forceinline__ void block_reduce_store_lds(const double* acc, double* buf, double* __restrict__ out) {
-    const int tid = threadIdx.x;
-    const int k = tid >> 4, seg = tid & 15;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        if (h) __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 16; ++q) buf[q * kBlock + tid] = acc[h * 16 + q];
-        __syncthreads();
-        double v = 0.0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v += buf[k * kBlock + i * 16 + seg];
-        // the 16 lanes of a value are one DPP row: rotations and quad permutes instead of four ds_bpermute round trips
-        v += dpp_move<0x128>(v); // row_ror:8
-        v += dpp_move<0x124>(v); // row_ror:4
-        v += dpp_move<0x4E>(v);  // quad_perm [2,3,0,1]
-        v += dpp_move<0xB1>(v);  // quad_perm [1,0,3,2]
-        if (seg == 0) out[h * 16 + k] = v;
-    }
 }
 
 // ---- K1a: direct kernel (first correct version; kept for A/B measurements, ELM_KERNEL=direct) --------------
@@ -443,20 +404,12 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_direct(const DevMap m, co
     block_reduce_store(acc, red, partials + (size_t)L * kSums);
 }
 
-// ---- K1d: cell-indexed neighbourhood lists --------------------------------------------------------------
-// The candidate list of a query voxel is kept sorted by half-voxel cells: a 6x6x6 grid with origin (v - 1) * voxel_size
-// (per axis), edge h = voxel_size / 2, indices clamped to 0..5 so the outermost cells are unbounded outward (truncated
-// keys make the bucket of voxel key 0 two voxels wide).  Cells are ordered (ix, iy, iz)-major, so the cells iz0..iz1 of
-// one (ix, iy) column are one contiguous range; a 16-byte record per column holds its seven cell boundaries.
-//   stage 1, per lane: probe the query voxel (as K1c), then scan the 2x2x2 block of cells that g leans into (own cell +
-//     the neighbours on the nearer side of every axis; 4 column ranges, ~20 candidates) in float32 with the best /
-//     runner-up logic of K1c.  Every point of space within rho = distance(g, open faces of that block) >= h/2 lies in the
-//     block, so when the float32 winner is a clear one AND its distance (+ error margin) is below rho, no candidate outside
-//     the block can win or tie: the lane is done after three round trips (probe, 4 records, candidates).
-//   stage 2, per wave: the few lanes that could not decide (pose still far off, isolated points, near ties) are served one
-//     after the other by the whole wave: 64 lanes share the lane's complete list, compute the reference's float64
-//     distances and reduce (distance, visiting rank, global index) lexicographically -- exactly the reference's first
-//     strict minimum in its visiting order (vhm.cpp:208-243 + insertion order), whatever the order of the list.
+// ---- K1 on the neighbourhood lists (fall-back search index) ---------------------------------------------------------
+// The candidate list of a query voxel (the points of its 27 buckets) is kept sorted by half-voxel cells: a 6x6x6 grid with origin
+// (v - 1) * voxel_size (per axis), edge h = voxel_size / 2, indices clamped to 0..5 so the outermost cells are unbounded outward
+// (truncated keys make the bucket of voxel key 0 two voxels wide).  Cells are ordered (ix, iy, iz)-major, so the cells iz0..iz1
+// of one (ix, iy) column are one contiguous range; a 16-byte record per column holds its seven cell boundaries.  The two stages
+// are those of k_accumulate_grid (below), on one list per query voxel instead of the global grid.
 constexpr int kCellAxis = 6;
 constexpr int kCells = kCellAxis * kCellAxis * kCellAxis; // 216
 constexpr int kCellCols = kCellAxis * kCellAxis;          // 36 (ix, iy) columns
