@@ -406,7 +406,9 @@ def main():
         if method == IcpMethod.GICP:
             rvm.CalPointCovAll(0.4)
         mine = list(range(rank, n_batch, world_size))
-        rscans = [Scan(rctx, synth.make_scan(world, args.scan_points, seed=2002 + i)[0]) for i in mine]
+        with ThreadPoolExecutor(max_workers=16) as pool:  # the same scans as above (seeded), whole instead of sharded
+            rscans = [Scan(rctx, sc) for sc in pool.map(lambda i: synth.make_scan(world, args.scan_points, seed=2002 + i, max_range=SCAN_RANGE_M,
+                                                                                   noise=SCAN_NOISE_M)[0], mine)]
         rreg = Registration(cfg, rctx)
         rp = rreg.pack_inputs(rscans, [T0s[i] for i in mine])
         rreg.RunRegisterStream(rp[0], rvm, rp[1], slots=args.slots, raw=True)
