@@ -915,16 +915,18 @@ __device__ __forceinline__ GridAxis grid_axis(double g, const DevMap& m) {
     a.ahi = kh > 0 ? 2 * kh + 1 : (kh == 0 ? 1 : 2 * kh - 1);
     return a;
 }
-// the (clipped) two-cell span the query leans into and the distance to its open faces
-__device__ __forceinline__ void grid_lean(const GridAxis& a, double g, double h, int& blo, int& bhi, double& rho) {
+// the (clipped) two-cell span the query leans into and the distance to its open faces IN CELL UNITS (float: the fraction of g in
+// its own cell plus small integers; the 3e-8 m of rounding sit inside the 1e-6 m margin of the decision)
+__device__ __forceinline__ void grid_lean(const GridAxis& a, int& blo, int& bhi, float& rho_u) {
     const double fl = floor(a.t);
     const int cg = (int)fl;
-    const int c0 = (a.t - fl >= 0.5) ? cg : cg - 1;
+    const float fr = (float)(a.t - fl); // position inside the own cell, [0, 1)
+    const int c0 = (fr >= 0.5f) ? cg : cg - 1;
     blo = max(c0, a.alo);
     bhi = min(c0 + 1, a.ahi);
-    const double dlo = (blo == a.alo) ? DBL_MAX : g - (double)blo * h;
-    const double dhi = (bhi == a.ahi) ? DBL_MAX : (double)(bhi + 1) * h - g;
-    rho = fmin(rho, fmin(dlo, dhi));
+    const float dlo = (blo == a.alo) ? 3e38f : (float)(cg - blo) + fr;
+    const float dhi = (bhi == a.ahi) ? 3e38f : (float)(bhi + 1 - cg) - fr;
+    rho_u = fminf(rho_u, fminf(dlo, dhi));
 }
 
 struct GridHardRec {
@@ -1010,11 +1012,11 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
         double px, py, pz, gx, gy, gz;
         transform(px, py, pz, gx, gy, gz);
         const GridAxis ax = grid_axis(gx, m), ay = grid_axis(gy, m), az = grid_axis(gz, m);
-        double rho = DBL_MAX;
+        float rho_u = 3e38f; // distance to the block's open faces, cell units
         int bx0, bx1, by0, by1, bz0, bz1;
-        grid_lean(ax, gx, h, bx0, bx1, rho);
-        grid_lean(ay, gy, h, by0, by1, rho);
-        grid_lean(az, gz, h, bz0, bz1, rho);
+        grid_lean(ax, bx0, bx1, rho_u);
+        grid_lean(ay, by0, by1, rho_u);
+        grid_lean(az, bz0, bz1, rho_u);
         // block cells relative to the grid; a block that leaves the grid (or came out empty) goes to stage 2, which clamps
         const int rx0 = bx0 - m.gx0, rx1 = bx1 - m.gx0, ry0 = by0 - m.gy0, ry1 = by1 - m.gy0, rz0 = bz0 - m.gz0, rz1 = bz1 - m.gz0;
         const bool inside = rx0 >= 0 && rx1 < m.gnx && rx0 <= rx1 && ry0 >= 0 && ry1 < m.gny && ry0 <= ry1 && rz0 >= 0 && rz1 < m.gnz && rz0 <= rz1;
@@ -1036,8 +1038,8 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
             cb[k + 1] = cb[k] + (b1 - b0);
         }
         // decided <=> squared float32 winner distance (+ margins) < rr2, i.e. sqrt(r2) * 1.000001 + 1e-6 < rho
-        const double rr = (rho - 1e-6) * 0.999999;
-        const float rr2 = (rr > 0.0) ? (float)(rr * rr) * 0.9999998f : -1.f;
+        const float rr = (rho_u < 1e30f) ? (rho_u * (float)h - 1.1e-6f) * 0.999998f : 1e18f;
+        const float rr2 = (rr > 0.f) ? rr * rr * 0.999999f : -1.f;
         {
             const int nblk = cb[4];
             n_tested = 4 * nblk;
