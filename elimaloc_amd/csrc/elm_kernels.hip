@@ -630,7 +630,7 @@ struct HardRec {
 //     insertion order) lexicographically -- exactly the reference's first strict minimum in its visiting order (vhm.cpp:208-243).
 //   then every lane adds its pair and the workgroup reduces the packed sums.
 template <int METHOD>
-__global__ __launch_bounds__(kBlock, ELM_CELL_WAVES) void k_accumulate_cell(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
+__global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_CELL_WAVES : ELM_CELL_WAVES - 1)) void k_accumulate_cell(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
                                                                             unsigned total_blocks, const ScanState* __restrict__ st,
                                                                             double* __restrict__ partials, const RegParams rp) {
     constexpr int NV = (METHOD == ELM_P2P) ? kP2PVals : kSums;

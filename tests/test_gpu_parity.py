@@ -607,6 +607,23 @@ def test_randomized_configs_list_kernels(oracle, seed, monkeypatch):
         c.close()
 
 
+def test_grid_budget_voxel_lists_use_the_hash(oracle, world100k, monkeypatch):
+    """VGICP / AVGICP on a map whose floor-key box exceeds the cell budget: the voxel-mean lists are found through the query hash
+    instead of the dense table: same results."""
+    from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod
+    monkeypatch.setenv("ELM_GRID_MAX_CELLS", "1000")
+    c = Context(0)
+    try:
+        for method in (IcpMethod.VGICP, IcpMethod.AVGICP):
+            vm, om = _maps(c, oracle, world100k, method)
+            scan, T_true = synth.make_scan(world100k, 5000, seed=87)
+            T0 = synth.perturb(T_true, seed=88, max_trans=0.2, max_rot_deg=1.0)
+            *_, det = Registration(RegistrationConfig(icp_method=method), c).RunRegister(scan, vm, T0, trace=True)
+            _compare_run(det, oracle.register(om, scan, T0, oracle.default_config(int(method))))
+    finally:
+        c.close()
+
+
 def test_grid_budget_falls_back_to_lists(oracle, world100k, monkeypatch):
     """A map whose bounding box exceeds the cell budget gets the neighbourhood lists instead: same results."""
     from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod
