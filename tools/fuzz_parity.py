@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Randomised differential campaign of the HIP path against the CPU oracle (developer tool; the fixed-seed subset lives in
+tests/test_gpu_parity.py).  Exotic on purpose: coordinates exactly on voxel / cell boundaries (integers, half-integers, negative),
+duplicated points, tiny and single-voxel maps, maps far from the origin, voxel sizes that are not representable, scans partly
+or wholly outside the map, search radii below the voxel size.
+
+    python tools/fuzz_parity.py [--cases 200] [--seed0 0] [--kernel grid|lists|direct]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ap = argparse.ArgumentParser()
+ap.add_argument("--cases", type=int, default=200)
+ap.add_argument("--seed0", type=int, default=0)
+ap.add_argument("--kernel", default="grid")
+a = ap.parse_args()
+os.environ["ELM_KERNEL"] = a.kernel
+from elimaloc_amd import synth  # noqa: E402
+from elimaloc_amd.registration import Context, VoxelHashMap, Registration, RegistrationConfig, IcpMethod  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+ctx = Context(0)
+bad = 0
+for case in range(a.seed0, a.seed0 + a.cases):
+    rng = np.random.default_rng(50_000 + case)
+    method = int(rng.integers(0, 4))
+    voxel = float(rng.choice([0.25, 0.4, 0.5, 0.7, 1.0, 1.0, 1.3, 2.0, 3.0]))
+    max_pts = int(rng.choice([1, 4, 12, 30, 30, 60]))
+    th = float(rng.choice([0.3, 0.8, 2.0, 5.0, 5.0, 12.0]))
+    kind = int(rng.integers(0, 6))
+    if kind == 0:    # exact lattice on boundaries: multiples of voxel / 2 around the origin (negative side included)
+        ax = np.arange(-12, 13) * (voxel / 2)
+        gx, gy, gz = np.meshgrid(ax, ax, ax[8:17], indexing="ij")
+        world = np.stack([gx.ravel(), gy.ravel(), gz.ravel()], 1)
+        world = world[rng.permutation(len(world))]
+    elif kind == 1:  # tiny map
+        world = rng.uniform(-1.5, 1.5, size=(int(rng.integers(1, 40)), 3))
+    elif kind == 2:  # duplicated points + a dense blob
+        blob = rng.normal(0, 0.7, size=(3000, 3)) + np.array([3.0, -2.0, 0.5])
+        world = np.concatenate([blob, blob[:500], np.round(blob[:300])])
+    else:            # the planar world, possibly far from the origin
+        base = synth.make_world(int(rng.choice([5000, 20000, 60000])), seed=7000 + case)
+        off = np.array([rng.choice([0.0, -37.25, 1234.5, -50000.0]), rng.choice([0.0, 15.125, -777.0]), rng.choice([0.0, -3.0, 100.0])])
+        world = base.astype(np.float64) + off
+    world = np.ascontiguousarray(world.astype(np.float32))
+    n_scan = int(rng.choice([1, 7, 300, 3000]))
+    pick = world[rng.integers(0, len(world), n_scan)].astype(np.float64)
+    noise = float(rng.choice([0.0, 0.0, 0.01, 0.2]))
+    c = world.astype(np.float64).mean(axis=0)
+    T_true = np.eye(4)
+    T_true[:3, :3] = synth.rot_zyx(*np.deg2rad(rng.uniform(-3, 3, 2)), rng.uniform(-3.14, 3.14))
+    T_true[:3, 3] = c + rng.normal(0, 2.0, 3)
+    scan = synth.rows_times(pick + rng.normal(0, noise, pick.shape) - T_true[:3, 3], T_true[:3, :3]) if noise else \
+        synth.rows_times(pick - T_true[:3, 3], T_true[:3, :3])
+    if rng.random() < 0.3:  # part of the scan far outside the map
+        scan = np.concatenate([scan, scan[: max(1, n_scan // 4)] + np.array([80.0, 0.0, 0.0])])
+    scan = np.ascontiguousarray(scan.astype(np.float32))
+    T0 = synth.perturb(T_true, seed=60_000 + case, max_trans=float(rng.choice([0.0, 0.05, 0.3, 1.0])), max_rot_deg=float(rng.choice([0.0, 0.5, 3.0])))
+    if rng.random() < 0.15:
+        T0 = np.eye(4)  # g == p bit for bit: exact ties where the scan sits on lattice points
+        scan = np.ascontiguousarray((pick + (voxel / 4 if rng.random() < 0.5 else 0.0)).astype(np.float32))
+    cov = float(rng.choice([0.3, 0.4, 0.9]))
+    vm = VoxelHashMap(voxel, max_pts, ctx); vm.AddPoints(world)
+    om = O.Map(voxel, max_pts); om.add_points(world)
+    if method in (2, 3):
+        vm.CalVoxelCovAll(); om.cal_voxel_cov_all()
+    if method == 1:
+        vm.CalPointCovAll(cov); om.cal_point_cov_all(cov)
+    kw = dict(max_search_dist=th, max_iteration=6, min_overlap_ratio=float(rng.choice([0.0, 0.4])), max_fitness_score=float(rng.choice([0.5, 100.0])))
+    try:
+        *_, det = Registration(RegistrationConfig(icp_method=IcpMethod(method), **kw), ctx).RunRegister(scan, vm, T0, trace=True)
+        ref = O.register(om, scan, T0, O.default_config(method, **kw))
+        ok = det["iterations"] == ref["iterations"] and det["is_success"] == ref["is_success"] and det["gate"] == ref["gate"]
+        for g, r in zip(det["iters"], ref["iters"]):
+            ok = ok and g["n_corr"] == r["n_corr"]
+            if not (ref["gate"] == 2 and g is det["iters"][ref["iterations"] - 1]):
+                scale = max(np.abs(r["JTJ"]).max(), 1e-300)
+                ok = ok and np.abs(g["JTJ"] - r["JTJ"]).max() <= 1e-9 * scale
+        dt, dr = synth.pose_error(ref["T"], det["T"])
+        finite = np.isfinite(ref["T"]).all()
+        ok = ok and ((dt <= 1e-4 and dr <= 1e-5) if finite else True)
+    except Exception as e:  # noqa: BLE001
+        ok = False
+        print("case", case, "raised", repr(e))
+    if not ok:
+        bad += 1
+        print(f"MISMATCH case {case}: method {method} voxel {voxel} max_pts {max_pts} th {th} kind {kind} n_scan {len(scan)} "
+              f"iters {det.get('iterations')} vs {ref.get('iterations')} gate {det.get('gate')} vs {ref.get('gate')}")
+print(f"{a.cases - bad}/{a.cases} cases agree (kernel {a.kernel})")
+sys.exit(1 if bad else 0)
