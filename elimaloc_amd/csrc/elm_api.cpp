@@ -773,7 +773,7 @@ static int build_cell_grid(elm_map* m, uint64_t max_cells) {
         fill[c] = 0;
         start[c] = (uint32_t)n_blk;
         n_blk += (cnt + 3) / 4;
-        if (n_blk > 0x3FFFFFF0ull) { m->grid_refused = true; return ELM_ERR_UNSUPPORTED; }
+        if (n_blk * sizeof(GridBlk) > 0xFFFFFF00ull) { m->grid_refused = true; return ELM_ERR_UNSUPPORTED; } // the kernel addresses blocks by 32-bit byte offsets
     }
     for (uint64_t c = cells; c < cells + 4; ++c) start[c] = (uint32_t)n_blk;
     std::vector<GridBlk> gb(std::max<uint64_t>(n_blk, 1));

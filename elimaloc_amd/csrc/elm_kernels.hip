@@ -958,12 +958,15 @@ __device__ __forceinline__ void blk_dist(const GridBlk& B, f32x2 gxy, f32x2 gzl,
     d01 = __builtin_elementwise_fma(ez01, ez01, __builtin_elementwise_fma(ey01, ey01, ex01 * ex01));
     d23 = __builtin_elementwise_fma(ez23, ez23, __builtin_elementwise_fma(ey23, ey23, ex23 * ex23));
 }
-// (m1, m2) = the two smallest distances seen so far (m1 <= m2), j1 = slot of m1: one new distance
-__device__ __forceinline__ void two_smallest(float d, int id, float& m1, float& m2, int& j1) {
-    m2 = __builtin_amdgcn_fmed3f(m1, m2, d); // the median of (m1 <= m2, d) is the new runner-up
-    const bool c = d < m1;
-    m1 = fminf(m1, d);
-    j1 = c ? id : j1;
+// (m1, m2) = the two smallest candidate keys seen so far (m1 <= m2): one new distance from slot u of its block.  A key is the
+// distance's bit pattern (non-negative floats order like unsigned integers) with the two lowest mantissa bits replaced by the
+// slot, so the winner's slot rides along for free: and_or + med3 + min per candidate
+__device__ __forceinline__ void two_smallest(float d, unsigned u, unsigned& m1, unsigned& m2) {
+    const unsigned key = (__float_as_uint(d) & ~3u) | u;
+    unsigned med;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(med) : "v"(m1), "v"(m2), "v"(key)); // the median of (m1 <= m2, key) is the new runner-up
+    m2 = med;
+    m1 = min(m1, key);
 }
 
 #ifndef ELM_GRID_WAVES
@@ -1021,7 +1024,8 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
         const int rx0 = bx0 - m.gx0, rx1 = bx1 - m.gx0, ry0 = by0 - m.gy0, ry1 = by1 - m.gy0, rz0 = bz0 - m.gz0, rz1 = bz1 - m.gz0;
         const bool inside = rx0 >= 0 && rx1 < m.gnx && rx0 <= rx1 && ry0 >= 0 && ry1 < m.gny && ry0 <= ry1 && rz0 >= 0 && rz1 < m.gnz && rz0 <= rz1;
         // the four (ix, iy) columns of the block: one contiguous run of candidate blocks [cell bz0, cell bz1] each
-        int sb[4], cb[5];
+        unsigned sb[4]; // byte offsets modulo 2^32 (build_cell_grid keeps the block array below 4 GB)
+        int cb[5];
         cb[0] = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1034,7 +1038,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
                 b0 = (int)s0;
                 b1 = (int)((rz1 > rz0) ? s2 : s1);
             }
-            sb[k] = b0 - cb[k]; // block t of the flattened sequence lives at sb[k] + t for cb[k] <= t < cb[k + 1]
+            sb[k] = (unsigned)(b0 - cb[k]) * (unsigned)sizeof(GridBlk); // block t of the flattened sequence lives at byte sb[k] + 48 t for cb[k] <= t < cb[k + 1]
             cb[k + 1] = cb[k] + (b1 - b0);
         }
         // decided <=> squared float32 winner distance (+ margins) < rr2, i.e. sqrt(r2) * 1.000001 + 1e-6 < rho
@@ -1048,39 +1052,43 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
             const float ghx = (float)gx, ghy = (float)gy, ghz = (float)gz;
             const float glx = (float)(gx - (double)ghx), gly = (float)(gy - (double)ghy), glz = (float)(gz - (double)ghz);
             const f32x2 gxy = {ghx, ghy}, gzl = {ghz, glx}, gl2 = {gly, glz};
-            float m1 = __builtin_inff(), m2 = __builtin_inff();
-            int j1 = -1;
+            unsigned m1 = 0x7F800000u, m2 = 0x7F800000u; // +inf
+            unsigned jb = 0;                             // byte offset of m1's block (block 0 = padding = none yet)
             for (int t0 = 0; t0 < nblk; t0 += ELM_BLOCKS_PER_TRIP) { // ELM_BLOCKS_PER_TRIP blocks (three 16-byte loads each) per round trip
-                int pb[ELM_BLOCKS_PER_TRIP];
+                unsigned pb[ELM_BLOCKS_PER_TRIP]; // byte offsets (32-bit: the loads take the scalar base + this lane's offset)
 #pragma unroll
                 for (int w = 0; w < ELM_BLOCKS_PER_TRIP; ++w) {
                     const int t = t0 + w;
-                    int b_ = sb[3];
+                    unsigned b_ = sb[3];
 #pragma unroll
                     for (int k = 2; k >= 0; --k) b_ = (t < cb[k + 1]) ? sb[k] : b_;
-                    pb[w] = (t < nblk) ? b_ + t : 0; // past the end: block 0, four padding slots
+                    pb[w] = (t < nblk) ? b_ + (unsigned)t * (unsigned)sizeof(GridBlk) : 0u; // past the end: block 0, four padding slots
                 }
                 GridBlk B[ELM_BLOCKS_PER_TRIP];
 #pragma unroll
-                for (int w = 0; w < ELM_BLOCKS_PER_TRIP; ++w) B[w] = lp[pb[w]];
+                for (int w = 0; w < ELM_BLOCKS_PER_TRIP; ++w) B[w] = *reinterpret_cast<const GridBlk*>(reinterpret_cast<const char*>(lp) + pb[w]);
 #pragma unroll
                 for (int w = 0; w < ELM_BLOCKS_PER_TRIP; ++w) {
                     f32x2 da, db;
                     blk_dist(B[w], gxy, gzl, gl2, da, db);
-                    const int i0 = pb[w] * 4;
-                    two_smallest(da.x, i0, m1, m2, j1);
-                    two_smallest(da.y, i0 + 1, m1, m2, j1);
-                    two_smallest(db.x, i0 + 2, m1, m2, j1);
-                    two_smallest(db.y, i0 + 3, m1, m2, j1);
+                    const unsigned was = m1;
+                    two_smallest(da.x, 0u, m1, m2);
+                    two_smallest(da.y, 1u, m1, m2);
+                    two_smallest(db.x, 2u, m1, m2);
+                    two_smallest(db.y, 3u, m1, m2);
+                    jb = (m1 != was) ? pb[w] : jb;
                 }
             }
             hard = true;
-            if (j1 >= 4) { // a real candidate (slots 0..3 are block 0's padding)
+            if (jb > 0) { // a real candidate (block 0 is padding)
+                // the keys drop two mantissa bits (< 3.6e-7 relative, downwards) on top of the float32 distance's 2^-20: 2^-18 covers
+                // both sides of the comparison
+                const float d1 = __uint_as_float(m1 & ~3u), d2 = __uint_as_float(m2 & ~3u);
                 const float slack = 4e-11f * (fabsf(ghx) + fabsf(ghy) + fabsf(ghz) + 1.0f);
-                const float r2 = m1 + m1 * 1.9073486328125e-06f + slack; // 2^-19
+                const float r2 = d1 + d1 * 3.814697265625e-06f + slack; // 2^-18
                 hr2 = r2;
-                if (m2 > r2 && r2 < rr2) {
-                    bj = j1;
+                if (d2 > r2 && r2 < rr2) {
+                    bj = (int)(jb / (unsigned)sizeof(GridBlk)) * 4 + (int)(m1 & 3u);
                     hard = false;
                 }
             }
