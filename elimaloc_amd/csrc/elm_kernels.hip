@@ -1027,17 +1027,23 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
         unsigned sb[4]; // byte offsets modulo 2^32 (build_cell_grid keeps the block array below 4 GB)
         int cb[5];
         cb[0] = 0;
+        // all four 12-byte loads are issued before the first is used (a column that is clipped away or outside reads cell 0 and is
+        // masked afterwards); cell indices fit 32 bits (build_cell_grid)
+        unsigned s0[4], s1[4], s2[4];
+        bool ok[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int cx = (k >> 1) ? rx1 : rx0, cy = (k & 1) ? ry1 : ry0;
             const bool dup = ((k >> 1) && rx1 == rx0) || ((k & 1) && ry1 == ry0); // a span clipped to one cell
-            int b0 = 0, b1 = 0;
-            if (inside && !dup) {
-                const uint32_t* e = m.grid_start + (((size_t)cx * m.gny + cy) * m.gnz + rz0);
-                const unsigned s0 = e[0], s1 = e[1], s2 = e[2]; // one 12-byte load
-                b0 = (int)s0;
-                b1 = (int)((rz1 > rz0) ? s2 : s1);
-            }
+            ok[k] = inside && !dup;
+            const unsigned cell = ok[k] ? ((unsigned)cx * (unsigned)m.gny + (unsigned)cy) * (unsigned)m.gnz + (unsigned)rz0 : 0u;
+            const uint32_t* e = m.grid_start + cell;
+            s0[k] = e[0]; s1[k] = e[1]; s2[k] = e[2];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int b0 = ok[k] ? (int)s0[k] : 0;
+            const int b1 = ok[k] ? (int)((rz1 > rz0) ? s2[k] : s1[k]) : 0;
             sb[k] = (unsigned)(b0 - cb[k]) * (unsigned)sizeof(GridBlk); // block t of the flattened sequence lives at byte sb[k] + 48 t for cb[k] <= t < cb[k + 1]
             cb[k + 1] = cb[k] + (b1 - b0);
         }
