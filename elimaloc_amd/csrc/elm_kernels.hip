@@ -1004,8 +1004,11 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
     const GridBlk* __restrict__ lp = m.grid_blk;
     // the point and its transform are cheap to redo (one 16-byte load that hits L1/L2 + 18 float64 operations): they are NOT kept
     // in registers across the candidate loop and the cooperative stage -- the kernel is bound by latency, i.e. by occupancy
-    auto transform = [&](double& px, double& py, double& pz, double& gx, double& gy, double& gz) {
-        const float4 pf = sd.pts[i];
+    // the point and the walk statistics of its query voxel wait in LDS, in the upper half of the reduction buffer (the queue of
+    // stage 2 takes at most the lower half), at the 16 bytes this thread's own wavefront overwrites first in the reduction
+    // (values 4 and 5 of the first pass): no barrier is needed between the last read of the stash and the reduction
+    float4* __restrict__ s_stash = reinterpret_cast<float4*>(s_buf) + ((4u + ((threadIdx.x >> 5) & 1u)) * (kBlock / 2) + (threadIdx.x >> 6) * 32u + (threadIdx.x & 31u));
+    auto transform = [&](const float4 pf, double& px, double& py, double& pz, double& gx, double& gy, double& gz) {
         px = pf.x; py = pf.y; pz = pf.z;
         gx = ((S.T[0] * px + S.T[4] * py) + S.T[8] * pz) + S.T[12]; // g = T * [p, 1] (reg.hpp:141-146), the reference's association
         gy = ((S.T[1] * px + S.T[5] * py) + S.T[9] * pz) + S.T[13];
@@ -1013,8 +1016,18 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
     };
     if (valid) {
         double px, py, pz, gx, gy, gz;
-        transform(px, py, pz, gx, gy, gz);
+        float4 pf = sd.pts[i];
+        transform(pf, px, py, pz, gx, gy, gz);
         const GridAxis ax = grid_axis(gx, m), ay = grid_axis(gy, m), az = grid_axis(gz, m);
+        // statistics of the reference's walk for this query voxel: candidates and occupied buckets among the 27
+        unsigned stat = 0;
+        {
+            const int ux = ax.f - m.vx0, uy = ay.f - m.vy0, uz = az.f - m.vz0;
+            const bool in_box = (unsigned)ux < (unsigned)m.vnx && (unsigned)uy < (unsigned)m.vny && (unsigned)uz < (unsigned)m.vnz;
+            const unsigned sidx = in_box ? ((unsigned)ux * (unsigned)m.vny + (unsigned)uy) * (unsigned)m.vnz + (unsigned)uz : 0u;
+            stat = m.vox_stat[sidx];
+            stat = in_box ? stat : 0u;
+        }
         float rho_u = 3e38f; // distance to the block's open faces, cell units
         int bx0, bx1, by0, by1, bz0, bz1;
         grid_lean(ax, bx0, bx1, rho_u);
@@ -1040,6 +1053,8 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
             const uint32_t* e = m.grid_start + cell;
             s0[k] = e[0]; s1[k] = e[1]; s2[k] = e[2];
         }
+        pf.w = __uint_as_float(stat);
+        s_stash[0] = pf;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int b0 = ok[k] ? (int)s0[k] : 0;
@@ -1117,7 +1132,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
         if (hard) {
             double px, py, pz;
             GridHardRec r;
-            transform(px, py, pz, r.gx, r.gy, r.gz);
+            transform(s_stash[0], px, py, pz, r.gx, r.gy, r.gz);
             r.r2 = hr2; r._pad = 0.f;
             s_rec[my_slot] = r;
         }
@@ -1219,14 +1234,9 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
     }
     if (valid) {
         double px, py, pz, gx, gy, gz;
-        transform(px, py, pz, gx, gy, gz);
-        // statistics of the reference's walk for this query voxel: candidates and occupied buckets among the 27
-        unsigned stat = 0;
-        {
-            const int ux = floor_key(gx, m) - m.vx0, uy = floor_key(gy, m) - m.vy0, uz = floor_key(gz, m) - m.vz0;
-            if ((unsigned)ux < (unsigned)m.vnx && (unsigned)uy < (unsigned)m.vny && (unsigned)uz < (unsigned)m.vnz)
-                stat = m.vox_stat[((size_t)ux * m.vny + uy) * m.vnz + uz];
-        }
+        const float4 pf = s_stash[0];
+        transform(pf, px, py, pz, gx, gy, gz);
+        const unsigned stat = __float_as_uint(pf.w);
         // the winner's float64 distance in the reference's arithmetic (range test, weight); no bucket at all (the search came
         // back empty): the reference's default PointStruct at the origin (vhm.cpp:37, QUIRK)
         float bx = 0.f, by = 0.f, bz = 0.f;
