@@ -583,6 +583,14 @@ __device__ __forceinline__ double group_min(double v) {
     return v;
 }
 template <unsigned LPI>
+__device__ __forceinline__ unsigned group_min_u32(unsigned v) {
+    if (LPI >= 2) v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false));
+    if (LPI >= 4) v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false));
+    if (LPI >= 8) v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false));
+    if (LPI >= 16) v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xf, 0xf, false));
+    return v;
+}
+template <unsigned LPI>
 __device__ __forceinline__ int group_sum_int(int v) {
     if (LPI >= 2) v += __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);
     if (LPI >= 4) v += __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);
@@ -1007,7 +1015,11 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
     // the point and the walk statistics of its query voxel wait in LDS, in the upper half of the reduction buffer (the queue of
     // stage 2 takes at most the lower half), at the 16 bytes this thread's own wavefront overwrites first in the reduction
     // (values 4 and 5 of the first pass): no barrier is needed between the last read of the stash and the reduction
-    float4* __restrict__ s_stash = reinterpret_cast<float4*>(s_buf) + ((4u + ((threadIdx.x >> 5) & 1u)) * (kBlock / 2) + (threadIdx.x >> 6) * 32u + (threadIdx.x & 31u));
+    auto stash = [&]() -> float4* { // recomputed at each of its three uses (an address held across the kernel costs a register)
+        unsigned t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        return reinterpret_cast<float4*>(s_buf) + ((4u + ((t >> 5) & 1u)) * (kBlock / 2) + (t >> 6) * 32u + (t & 31u));
+    };
     auto transform = [&](const float4 pf, double& px, double& py, double& pz, double& gx, double& gy, double& gz) {
         px = pf.x; py = pf.y; pz = pf.z;
         gx = ((S.T[0] * px + S.T[4] * py) + S.T[8] * pz) + S.T[12]; // g = T * [p, 1] (reg.hpp:141-146), the reference's association
@@ -1054,7 +1066,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
             s0[k] = e[0]; s1[k] = e[1]; s2[k] = e[2];
         }
         pf.w = __uint_as_float(stat);
-        s_stash[0] = pf;
+        *stash() = pf;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int b0 = ok[k] ? (int)s0[k] : 0;
@@ -1132,7 +1144,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
         if (hard) {
             double px, py, pz;
             GridHardRec r;
-            transform(s_stash[0], px, py, pz, r.gx, r.gy, r.gz);
+            transform(*stash(), px, py, pz, r.gx, r.gy, r.gz);
             r.r2 = hr2; r._pad = 0.f;
             s_rec[my_slot] = r;
         }
@@ -1161,43 +1173,68 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
             loz = max(loz - m.gz0, 0); hiz = min(hiz - m.gz0, m.gnz - 1);
             const int nx = hix - lox + 1, ny = hiy - loy + 1, nz = hiz - loz + 1;
             const int ncol = (live && nx > 0 && ny > 0 && nz > 0) ? nx * ny : 0;
-            // the reference's float64 walk over this lane's columns (padding slots sit ~1e18 m away)
-            double bd = DBL_MAX;
-            int bk = -1, walked = 0;
-            bool tie = false; // the minimum was met more than once in this lane
-            for (int c = (int)rl; c < ncol; c += (int)LPI) {
-                const int cx = lox + c / ny, cy = loy + c % ny;
-                const uint32_t* e = m.grid_start + (((size_t)cx * m.gny + cy) * m.gnz + loz);
-                const int b0 = (int)e[0], b1 = (int)e[nz];
-                walked += 4 * (b1 - b0);
-                for (int b = b0; b < b1; ++b) {
-                    const GridBlk B = lp[b];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const double ex = (double)B.x[u] - R.gx, ey = (double)B.y[u] - R.gy, ez = (double)B.z[u] - R.gz;
-                        const double d2 = (ex * ex + ey * ey) + ez * ez;
-                        tie = (d2 == bd) ? true : ((d2 < bd) ? false : tie);
-                        bk = (d2 < bd) ? 4 * b + u : bk;
-                        bd = fmin(d2, bd);
-                    }
-                }
-            }
-            const double dmin = group_min<LPI>(bd);
+            // float32 pass over this lane's columns first (the arithmetic of stage 1): a winner that leads the runner-up of the
+            // whole ball by the margin is the float64 winner as well
             const unsigned gsh = threadIdx.x & 63u & ~(LPI - 1u);
             const unsigned long long gmask = ((1ull << LPI) - 1ull) << gsh;
-            const unsigned long long at_all = __ballot(bk >= 0 && bd == dmin), tie_all = __ballot(tie && bd == dmin);
-            const unsigned at = (unsigned)((at_all & gmask) >> gsh);
-            int win = -1;
-            if (__popc(at) == 1 && (tie_all & gmask) == 0ull) {
-                win = __shfl(bk, (int)(gsh + (unsigned)(__ffs((int)at) - 1)), 64);
-            } else if (at != 0u) {
-                // the same float64 distance more than once (practically never): the reference keeps the candidate it meets first --
-                // bucket visiting rank (vhm.cpp:234-240: x-major .. z-minor over the stored keys f-1..f+1), then insertion order
-                // (= bucket-order index).  The bucket of a cell: c >= 2 -> c >> 1, -2 <= c <= 1 -> 0, c <= -3 -> (c + 2) >> 1.
-                unsigned brank = 0xFFFFFFFFu, bgi = 0xFFFFFFFFu;
-                bk = -1;
-#pragma unroll 1
+            int win = -1, walked = 0;
+            bool need64 = false;
+            {
+                const float ghx = (float)R.gx, ghy = (float)R.gy, ghz = (float)R.gz;
+                const float glx = (float)(R.gx - (double)ghx), gly = (float)(R.gy - (double)ghy), glz = (float)(R.gz - (double)ghz);
+                const f32x2 gxy = {ghx, ghy}, gzl = {ghz, glx}, gl2 = {gly, glz};
+                unsigned m1 = 0x7F800000u, m2 = 0x7F800000u;
+                int jb = 0;
                 for (int c = (int)rl; c < ncol; c += (int)LPI) {
+                    const int cx = lox + c / ny, cy = loy + c % ny;
+                    const uint32_t* e = m.grid_start + (((size_t)cx * m.gny + cy) * m.gnz + loz);
+                    const int b0 = (int)e[0], b1 = (int)e[nz];
+                    walked += 4 * (b1 - b0);
+                    for (int b = b0; b < b1; ++b) {
+                        const GridBlk B = lp[b];
+                        f32x2 da, db;
+                        blk_dist(B, gxy, gzl, gl2, da, db);
+                        const unsigned was = m1;
+                        two_smallest(da.x, 0u, m1, m2);
+                        two_smallest(da.y, 1u, m1, m2);
+                        two_smallest(db.x, 2u, m1, m2);
+                        two_smallest(db.y, 3u, m1, m2);
+                        jb = (m1 != was) ? b : jb;
+                    }
+                }
+                const unsigned m1g = group_min_u32<LPI>(m1);
+                const unsigned long long holders = __ballot(m1 == m1g) & gmask;
+                const unsigned hl = (unsigned)__ffsll((long long)holders) - 1u; // first lane of the group that holds the minimum
+                const unsigned m2g = group_min_u32<LPI>((lane == hl) ? m2 : m1); // a second holder of the same key counts as a tie
+                const int jw = __shfl(jb * 4 + (int)(m1 & 3u), (int)hl, 64);
+                const float d1 = __uint_as_float(m1g & ~3u), d2 = __uint_as_float(m2g & ~3u);
+                const float slack = 4e-11f * (fabsf(ghx) + fabsf(ghy) + fabsf(ghz) + 1.0f);
+                if (jw >= 4 && d2 > d1 + d1 * 3.814697265625e-06f + slack) win = jw; // clear float32 winner (2^-18, see stage 1)
+                else need64 = live && jw >= 4;                                         // near tie: the float64 walk below decides
+            }
+            if (__any(need64)) { // wave-uniform; practically never taken
+                // near tie in float32: the reference's float64 arithmetic decides.  First the float64 minimum over the ball, then,
+                // among the candidates that meet it (usually one), the one the reference meets first -- bucket visiting rank
+                // (vhm.cpp:234-240: x-major .. z-minor over the stored keys f-1..f+1), then insertion order (= bucket-order index).
+                // The bucket of a cell: c >= 2 -> c >> 1, -2 <= c <= 1 -> 0, c <= -3 -> (c + 2) >> 1.
+                const int ncol64 = need64 ? ncol : 0;
+                double bd = DBL_MAX;
+#pragma unroll 1
+                for (int c = (int)rl; c < ncol64; c += (int)LPI) {
+                    const int cx = lox + c / ny, cy = loy + c % ny;
+                    const uint32_t* e = m.grid_start + (((size_t)cx * m.gny + cy) * m.gnz + loz);
+#pragma unroll 1
+                    for (int k = 4 * (int)e[0]; k < 4 * (int)e[nz]; ++k) {
+                        const Pt3 q = blk_point(lp, k);
+                        const double ex = (double)q.x - R.gx, ey = (double)q.y - R.gy, ez = (double)q.z - R.gz;
+                        bd = fmin((ex * ex + ey * ey) + ez * ez, bd);
+                    }
+                }
+                const double dmin = group_min<LPI>(bd);
+                unsigned brank = 0xFFFFFFFFu, bgi = 0xFFFFFFFFu;
+                int bk = -1;
+#pragma unroll 1
+                for (int c = (int)rl; c < ncol64; c += (int)LPI) {
                     const int cx = lox + c / ny, cy = loy + c % ny;
                     const int ccx = cx + m.gx0, ccy = cy + m.gy0;
                     const int kx = ccx >= 2 ? ccx >> 1 : (ccx >= -2 ? 0 : (ccx + 2) >> 1), ky = ccy >= 2 ? ccy >> 1 : (ccy >= -2 ? 0 : (ccy + 2) >> 1);
@@ -1223,7 +1260,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
                     const int ok = __shfl_xor(bk, off, 64);
                     if (orank < brank || (orank == brank && og < bgi)) { brank = orank; bgi = og; bk = ok; }
                 }
-                win = bk;
+                win = need64 ? bk : win;
             }
             walked = group_sum_int<LPI>(walked);
             if (rl == 0 && live) { s_res[it] = win; s_tst[it] = walked; }
@@ -1234,7 +1271,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
     }
     if (valid) {
         double px, py, pz, gx, gy, gz;
-        const float4 pf = s_stash[0];
+        const float4 pf = *stash();
         transform(pf, px, py, pz, gx, gy, gz);
         const unsigned stat = __float_as_uint(pf.w);
         // the winner's float64 distance in the reference's arithmetic (range test, weight); no bucket at all (the search came
