@@ -1162,7 +1162,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
                 // every candidate within sqrt(r2) of g -- the nearest one and whatever ties with it -- has its cell inside the
                 // per-axis cell range of [g - r, g + r] (1e-6 of margin: a stored coordinate exactly on a cell face counts to the
                 // cell further from zero, grid_cell_of)
-                const double r = sqrt((double)R.r2) * 1.000001 + 1e-6;
+                const double r = (double)(__builtin_sqrtf(R.r2) * 1.000001f) + 1e-6; // float32 root (1 ulp) inside the margin
                 const double inv_h = 2.0 / m.voxel_size;
                 lox = max(lox, (int)floor((R.gx - r) * inv_h)); hix = min(hix, (int)floor((R.gx + r) * inv_h));
                 loy = max(loy, (int)floor((R.gy - r) * inv_h)); hiy = min(hiy, (int)floor((R.gy + r) * inv_h));
@@ -1185,9 +1185,11 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
                 const f32x2 gxy = {ghx, ghy}, gzl = {ghz, glx}, gl2 = {gly, glz};
                 unsigned m1 = 0x7F800000u, m2 = 0x7F800000u;
                 int jb = 0;
+                const float rny = __builtin_amdgcn_rcpf((float)ny); // c / ny for the few dozen columns of a ball: exact via float32
                 for (int c = (int)rl; c < ncol; c += (int)LPI) {
-                    const int cx = lox + c / ny, cy = loy + c % ny;
-                    const uint32_t* e = m.grid_start + (((size_t)cx * m.gny + cy) * m.gnz + loz);
+                    const int qx = (int)(((float)c + 0.5f) * rny);
+                    const int cx = lox + qx, cy = loy + (c - qx * ny);
+                    const uint32_t* e = m.grid_start + (((unsigned)cx * (unsigned)m.gny + (unsigned)cy) * (unsigned)m.gnz + (unsigned)loz);
                     const int b0 = (int)e[0], b1 = (int)e[nz];
                     walked += 4 * (b1 - b0);
                     for (int b = b0; b < b1; ++b) {
