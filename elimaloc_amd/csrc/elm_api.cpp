@@ -259,7 +259,7 @@ static int prof_mark(elm_ctx* ctx) { // records the next pooled event on the con
     if (!ctx->profiling) return ELM_OK;
     if (ctx->events_used == (int)ctx->events.size()) {
         hipEvent_t e;
-        HIPCHK(ctx, hipEventCreate(&e));
+        HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableSystemFence)); // timing only: no system-scope fence between launches
         ctx->events.push_back(e);
     }
     HIPCHK(ctx, hipEventRecord(ctx->events[ctx->events_used++], ctx->stream));
@@ -1535,10 +1535,12 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
             launch_solve(ctx->stream, dsc, S, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 1, d_active);
             if ((rc = exchange(ctx, (double*)ctx->d_sums.p, (size_t)S * kSums)) != ELM_OK) return rc;
             launch_solve(ctx->stream, dsc, S, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 2, d_active);
+            launch_stream_refill(ctx->stream, dsc, st, S, d_q, d_qT0, d_out, d_ctrl, 0); // slot assignment identical on every rank
         } else {
-            launch_solve(ctx->stream, dsc, S, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 0, d_active);
+            // single rank: the solve hands finished slots their next registration itself (no refill launch)
+            const StreamArgs sa = {dsc, d_q, d_qT0, d_out, d_ctrl};
+            launch_solve(ctx->stream, dsc, S, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 0, d_active, &sa);
         }
-        launch_stream_refill(ctx->stream, dsc, st, S, d_q, d_qT0, d_out, d_ctrl, 0);
         const int done_iters = it + 1;
         const bool look = predicted > 0 ? done_iters >= predicted : (done_iters >= (count + S - 1) / S && (done_iters % 2) == 0);
         if (look) {

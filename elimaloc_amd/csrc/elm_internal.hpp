@@ -136,6 +136,15 @@ struct StreamCtrl {
     int32_t _pad;
 };
 
+// in-solve refill of finished slots (single-rank streams, see finish_slot in elm_kernels.hip)
+struct StreamArgs {
+    ScanDesc* scans;
+    const QueueItem* queue;
+    const double* qT0;
+    ScanState* out_state;
+    StreamCtrl* ctrl; // nullptr: no refill in the solve
+};
+
 struct RegParams {
     double th;  // max_search_dist
     double th2; // th * th
@@ -160,7 +169,7 @@ void launch_accumulate_direct(hipStream_t s, const DevMap& m, const ScanDesc* sc
                               ScanState* st, double* partials, const RegParams& rp);
 // mode 0: reduce + solve (single GPU); 1: reduce only -> sums; 2: solve only from sums
 void launch_solve(hipStream_t s, const ScanDesc* scans, int batch, ScanState* st, const double* partials,
-                  double* sums, const RegParams& rp, elm_iter_trace* trace, int mode, int* active);
+                  double* sums, const RegParams& rp, elm_iter_trace* trace, int mode, int* active, const StreamArgs* refill = nullptr);
 void launch_nbr_count(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, uint32_t* counts, uint32_t* nocc);
 void launch_accumulate_vnbr(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                             ScanState* st, double* partials, const RegParams& rp);

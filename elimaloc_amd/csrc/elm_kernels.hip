@@ -1736,10 +1736,61 @@ __device__ __forceinline__ void wave_ldlt6(double a, const double* b, double x[6
     }
 }
 
+// Continuous batching inside the solve (single-rank streams): the lane that has just finished a registration saves its final
+// state and takes the next pending registration for the slot -- what k_stream_refill does, without the extra launch.  The
+// queue position comes from an atomic counter, so WHICH slot serves a registration depends on the order the workgroups get
+// here; a registration's arithmetic does not depend on its slot (uniform slot sizes, partial sums in block order), so every
+// result is unchanged.  Multi-rank streams keep k_stream_refill: there the slot assignment must be identical on every rank.
+// All 64 lanes of the solve's first wavefront call it (uniform); the lead lane's stores to S are complete and re-read with
+// agent-scope loads (they bypass this CU's vector cache).
+__device__ __forceinline__ void finish_slot(const StreamArgs& sa, ScanState& S, int s) {
+    constexpr int W = (int)(sizeof(ScanState) / sizeof(double));
+    const int lane = threadIdx.x & 63;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    const int reg_old = __hip_atomic_load(&S.reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double* src = reinterpret_cast<const double*>(&S);
+    double* dst = reinterpret_cast<double*>(&sa.out_state[reg_old]);
+    for (int k = lane; k < W; k += 64) dst[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int r = 0;
+    if (lane == 0) {
+        atomicAdd(&sa.ctrl->completed, 1);
+        r = atomicAdd(&sa.ctrl->next, 1);
+    }
+    r = __shfl(r, 0, 64);
+    __builtin_amdgcn_s_waitcnt(0); // the copy's loads are done before the state is overwritten
+    __builtin_amdgcn_wave_barrier();
+    if (r < sa.ctrl->total) {
+        const double* T0 = sa.qT0 + (size_t)r * 16;
+        if (lane >= 1 && lane < 37) S.local_cov[lane - 1] = ((lane - 1) % 7 == 0) ? 1.0 : 0.0; // reg.cpp:280
+        if (lane == 0) { // the scalar part of init_scan_state, same arithmetic
+            const QueueItem q = sa.queue[r];
+            sa.scans[s].pts = q.pts;
+            sa.scans[s].n = q.n;
+            sa.scans[s].n_total = q.n_total;
+            for (int k = 0; k < 16; ++k) S.T[k] = T0[k];
+            update_inverse(S);
+            S.fitness = 0.0;
+            S.n_corr_last = 0.0;
+            S.pt_iters = 0.0; S.cand_total = 0.0; S.occ_total = 0.0; S.fallback_blocks = 0.0; S.tested_total = 0.0;
+            S.done = 0;
+            S.success = 0;
+            S.gate = 0;
+            S.iters = 0;
+            S.reg = r;
+            S._pad = 0;
+        }
+    } else if (lane == 0) {
+        S.done = 1; // idle slot
+        S.reg = -1;
+    }
+}
+
 constexpr int kSolveThreads = 1024;
-__global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* __restrict__ scans, ScanState* st,
+__global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* scans, ScanState* st,
                                                          const double* __restrict__ partials, double* sums,
-                                                         const RegParams rp, elm_iter_trace* trace, int mode, int* active) {
+                                                         const RegParams rp, elm_iter_trace* trace, int mode, int* active,
+                                                         const StreamArgs sa) {
     const int s = blockIdx.x;
     ScanState& S = st[s];
     const int t = threadIdx.x;
@@ -1756,6 +1807,13 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* __restr
             const ScanDesc sd = scans[s];
             unsigned b = sd.blk_begin + g;
             double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+            for (; b + 15 * G < sd.blk_end; b += 16 * G) { // sixteen loads in flight, summed in the order of the loop below
+                double a[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) a[q] = partials[(size_t)(b + q * G) * kSums + k];
+#pragma unroll
+                for (int q = 0; q < 16; q += 4) { v0 += a[q]; v1 += a[q + 1]; v2 += a[q + 2]; v3 += a[q + 3]; }
+            }
             for (; b + 3 * G < sd.blk_end; b += 4 * G) {
                 const double a0 = partials[(size_t)b * kSums + k], a1 = partials[(size_t)(b + G) * kSums + k];
                 const double a2 = partials[(size_t)(b + 2 * G) * kSums + k], a3 = partials[(size_t)(b + 3 * G) * kSums + k];
@@ -1847,6 +1905,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* __restr
             S.success = 0;
             S.gate = 2;
         }
+        if (sa.ctrl) finish_slot(sa, S, s); // uniform: every lane took this branch
         return;
     }
     const double fitness = tot[27] / n_corr; // d_fitness_score_ = d_residual_sum / source_global.size()
@@ -1871,24 +1930,28 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* __restr
     Tn[3] = 0.0; Tn[7] = 0.0; Tn[11] = 0.0; Tn[15] = 1.0;
     const double step = matrix_to_angle(dR) + sqrt((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2]); // reg.cpp:381-384
     if (tr && t < 36) tr->JTJ[t] = hij; // symmetric
-    if (!lead) return;
-    S.fitness = fitness;
-    for (int k = 0; k < 16; ++k) S.T[k] = Tn[k];
-    update_inverse(S);
-    if (tr) {
-        for (int k = 0; k < 6; ++k) { tr->JTr[k] = tot[21 + k]; tr->x[k] = x[k]; }
-        tr->residual_sum = tot[27];
-        tr->n_corr = n_corr;
-        tr->step_norm = step;
-        for (int k = 0; k < 16; ++k) tr->T[k] = Tn[k];
+    bool fin = false;
+    if (lead) {
+        S.fitness = fitness;
+        for (int k = 0; k < 16; ++k) S.T[k] = Tn[k];
+        update_inverse(S);
+        if (tr) {
+            for (int k = 0; k < 6; ++k) { tr->JTr[k] = tot[21 + k]; tr->x[k] = x[k]; }
+            tr->residual_sum = tot[27];
+            tr->n_corr = n_corr;
+            tr->step_norm = step;
+            for (int k = 0; k < 16; ++k) tr->T[k] = Tn[k];
+        }
+        if (step < rp.term_thr || iter >= rp.max_iter) { // reg.cpp:385-387 / loop end
+            S.done = 1;
+            atomicSub(active, 1);
+            const bool bad = fitness > rp.max_fitness; // reg.cpp:405-409 (NaN compares false, like the reference)
+            S.success = bad ? 0 : 1;
+            S.gate = bad ? 3 : 0;
+            fin = true;
+        }
     }
-    if (step < rp.term_thr || iter >= rp.max_iter) { // reg.cpp:385-387 / loop end
-        S.done = 1;
-        atomicSub(active, 1);
-        const bool bad = fitness > rp.max_fitness; // reg.cpp:405-409 (NaN compares false, like the reference)
-        S.success = bad ? 0 : 1;
-        S.gate = bad ? 3 : 0;
-    }
+    if (sa.ctrl && __shfl((int)fin, 0, 64)) finish_slot(sa, S, s);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -2124,8 +2187,10 @@ void launch_nbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint3
 }
 
 void launch_solve(hipStream_t s, const ScanDesc* scans, int batch, ScanState* st, const double* partials,
-                  double* sums, const RegParams& rp, elm_iter_trace* trace, int mode, int* active) {
-    hipLaunchKernelGGL(k_solve, dim3(batch), dim3(kSolveThreads), 0, s, scans, st, partials, sums, rp, trace, mode, active);
+                  double* sums, const RegParams& rp, elm_iter_trace* trace, int mode, int* active, const StreamArgs* refill) {
+    StreamArgs sa = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (refill) sa = *refill;
+    hipLaunchKernelGGL(k_solve, dim3(batch), dim3(kSolveThreads), 0, s, scans, st, partials, sums, rp, trace, mode, active, sa);
 }
 
 void launch_voxel_cov(hipStream_t s, const DevMap& m, const uint2* ranges, double* vox_mean, double* vox_cov, double* vox_cinv) {
