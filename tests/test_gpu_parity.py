@@ -535,6 +535,30 @@ def test_stream_equals_single(ctx, oracle, world100k, method, slots):
     assert out[2]["is_success"] == ref["is_success"] and out[2]["iterations"] == ref["iterations"]
 
 
+def test_stream_many_registrations_refilled_in_the_solve(ctx, oracle, world100k):
+    """A long queue through few slots (dozens of refill generations; on one rank the solve kernel hands a finished slot its next
+    registration through an atomic queue position, so WHICH slot serves a registration varies with timing): every result is
+    bit-identical to the lockstep batch of the same scans, three times in a row, gated registrations included."""
+    from elimaloc_amd.registration import Registration, RegistrationConfig, IcpMethod, Scan
+    vm, om = _maps(ctx, oracle, world100k, IcpMethod.P2P)
+    reg = Registration(RegistrationConfig(icp_method=IcpMethod.P2P, min_overlap_ratio=0.5), ctx)
+    scans, T0s = [], []
+    for i in range(150):
+        sc, Tt = synth.make_scan(world100k, 300 + 37 * (i % 11), seed=2000 + i)
+        if i % 13 == 5:
+            sc = sc + np.float32(500.0)  # far outside the map: fails the overlap gate in its first iteration
+        scans.append(Scan(ctx, sc))
+        T0s.append(synth.perturb(Tt, seed=3000 + i, max_trans=0.02 + 0.01 * (i % 17), max_rot_deg=0.1 * (i % 9)))
+    batch = reg.RunRegisterBatch(scans, vm, T0s)
+    assert any(not b["is_success"] for b in batch) and any(b["is_success"] for b in batch)
+    assert len({b["iterations"] for b in batch}) > 3
+    for slots in (7, 7, 32):
+        out = reg.RunRegisterStream(scans, vm, T0s, slots=slots)
+        for k, (a, b) in enumerate(zip(out, batch)):
+            assert (a["iterations"], a["is_success"], a["gate"]) == (b["iterations"], b["is_success"], b["gate"]), k
+            assert np.array_equal(a["T"], b["T"]) and a["n_corr_last"] == b["n_corr_last"], k
+
+
 def test_stream_through_exchange_hook(ctx, oracle, world100k):
     """The multi-GPU control flow of a stream (reduce-only solve -> exchange of slots*32 sums -> solve-only, refill on the
     device) with an identity exchange: same results as without, and one exchange per iteration."""
