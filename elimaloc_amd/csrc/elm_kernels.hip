@@ -1065,6 +1065,16 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
             const uint32_t* e = m.grid_start + cell;
             s0[k] = e[0]; s1[k] = e[1]; s2[k] = e[2];
         }
+        // everything that does not need the loads goes HERE, in their shadow (the asm is a scheduling barrier: left alone the
+        // compiler waits for the offsets first and does this arithmetic on the critical path -- 7 % of the kernel)
+        float rr = (rho_u < 1e30f) ? (rho_u * (float)h - 1.1e-6f) * 0.999998f : 1e18f;
+        float rr2 = (rr > 0.f) ? rr * rr * 0.999999f : -1.f;
+        // float32 filter: g = gh + gl (float32 each, gh + gl == g to ~2^-48), so (q - gh) - gl reproduces q - g to a few float32
+        // ulps of |q - g| and the float32 distance is within 2^-20 relative (+ slack / 2) of the reference's float64 one
+        float ghx = (float)gx, ghy = (float)gy, ghz = (float)gz;
+        float glx = (float)(gx - (double)ghx), gly = (float)(gy - (double)ghy), glz = (float)(gz - (double)ghz);
+        float slack = 4e-11f * (fabsf(ghx) + fabsf(ghy) + fabsf(ghz) + 1.0f);
+        asm volatile("" : "+v"(rr2), "+v"(ghx), "+v"(ghy), "+v"(ghz), "+v"(glx), "+v"(gly), "+v"(glz), "+v"(slack));
         pf.w = __uint_as_float(stat);
         *stash() = pf;
 #pragma unroll
@@ -1075,15 +1085,9 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
             cb[k + 1] = cb[k] + (b1 - b0);
         }
         // decided <=> squared float32 winner distance (+ margins) < rr2, i.e. sqrt(r2) * 1.000001 + 1e-6 < rho
-        const float rr = (rho_u < 1e30f) ? (rho_u * (float)h - 1.1e-6f) * 0.999998f : 1e18f;
-        const float rr2 = (rr > 0.f) ? rr * rr * 0.999999f : -1.f;
         {
             const int nblk = cb[4];
             n_tested = 4 * nblk;
-            // float32 filter: g = gh + gl (float32 each, gh + gl == g to ~2^-48), so (q - gh) - gl reproduces q - g to a few float32
-            // ulps of |q - g| and the float32 distance is within 2^-20 relative (+ slack / 2) of the reference's float64 one
-            const float ghx = (float)gx, ghy = (float)gy, ghz = (float)gz;
-            const float glx = (float)(gx - (double)ghx), gly = (float)(gy - (double)ghy), glz = (float)(gz - (double)ghz);
             const f32x2 gxy = {ghx, ghy}, gzl = {ghz, glx}, gl2 = {gly, glz};
             unsigned m1 = 0x7F800000u, m2 = 0x7F800000u; // +inf
             unsigned jb = 0;                             // byte offset of m1's block (block 0 = padding = none yet)
@@ -1100,6 +1104,8 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
                 GridBlk B[ELM_BLOCKS_PER_TRIP];
 #pragma unroll
                 for (int w = 0; w < ELM_BLOCKS_PER_TRIP; ++w) B[w] = *reinterpret_cast<const GridBlk*>(reinterpret_cast<const char*>(lp) + pb[w]);
+                __builtin_amdgcn_sched_barrier(0); // all six loads are in flight before the first is waited for (the scheduler otherwise
+                                                   // sometimes starts on the first block between the two blocks' loads)
 #pragma unroll
                 for (int w = 0; w < ELM_BLOCKS_PER_TRIP; ++w) {
                     f32x2 da, db;
@@ -1117,7 +1123,6 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
                 // the keys drop two mantissa bits (< 3.6e-7 relative, downwards) on top of the float32 distance's 2^-20: 2^-18 covers
                 // both sides of the comparison
                 const float d1 = __uint_as_float(m1 & ~3u), d2 = __uint_as_float(m2 & ~3u);
-                const float slack = 4e-11f * (fabsf(ghx) + fabsf(ghy) + fabsf(ghz) + 1.0f);
                 const float r2 = d1 + d1 * 3.814697265625e-06f + slack; // 2^-18
                 hr2 = r2;
                 if (d2 > r2 && r2 < rr2) {
