@@ -487,13 +487,39 @@ __device__ __forceinline__ void block_reduce_to_lds(const double* v, double* buf
 // with r = R^-1 (q - g): the reference's T^-1 q - p written on the world-frame residual e = q - g the search already holds
 // (equal up to the rounding of an orthonormal R, ~1e-16 relative; |r|^2 = |e|^2 = the search's float64 distance).
 constexpr int kP2PVals = 21; // 18 sums + the three work counters
+// sqrt of a squared distance (0 or a normal number well inside the exponent range): the core of the compiler's own expansion
+// (v_rsq_f64 + the same seven fused steps) without its scaling / class handling for denormals, infinities and NaNs
+__device__ __forceinline__ double sqrt_dist2(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    double d = __builtin_fma(-g, g, x);
+    h = __builtin_fma(h, r, h);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return (x > 0.0) ? g : 0.0;
+}
+// a / b for normal b well inside the exponent range: reciprocal + two Newton steps + the final residual correction (the compiler's
+// expansion without v_div_scale / v_div_fixup)
+__device__ __forceinline__ double div_normal(double a, double b) {
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    const double q = a * y;
+    const double r = __builtin_fma(-b, q, a);
+    return __builtin_fma(r, y, q);
+}
 __device__ __forceinline__ void pair_p2p(double* v, const double* Rinv, double px, double py, double pz, double ex, double ey, double ez,
                                          double d2, const RegParams& rp) {
     const double rx = (Rinv[0] * ex + Rinv[1] * ey) + Rinv[2] * ez;
     const double ry = (Rinv[3] * ex + Rinv[4] * ey) + Rinv[5] * ez;
     const double rz = (Rinv[6] * ex + Rinv[7] * ey) + Rinv[8] * ez;
     const double den = rp.th + d2;
-    const double w = rp.th2 / (den * den); // square(th) / square(th + |r|^2)  (reg.cpp:38-39)
+    const double w = div_normal(rp.th2, den * den); // square(th) / square(th + |r|^2)  (reg.cpp:38-39)
     const double wx = w * px, wy = w * py, wz = w * pz;
     const double ax = w * rx, ay = w * ry, az = w * rz;
     v[0] = w;
@@ -501,7 +527,7 @@ __device__ __forceinline__ void pair_p2p(double* v, const double* Rinv, double p
     v[4] = wx * px; v[5] = wx * py; v[6] = wx * pz; v[7] = wy * py; v[8] = wy * pz; v[9] = wz * pz;
     v[10] = ax; v[11] = ay; v[12] = az;
     v[13] = py * az - pz * ay; v[14] = pz * ax - px * az; v[15] = px * ay - py * ax;
-    v[16] = sqrt(d2);
+    v[16] = sqrt_dist2(d2);
     v[17] = 1.0;
 }
 // slot k of the packed 32-sum record (21 upper JTJ, 6 JTr, residual, count, 3 counters) from the 21 reduced P2P values
@@ -918,14 +944,15 @@ __device__ __forceinline__ GridAxis grid_axis(double g, const DevMap& m) {
     const double q = (m.inv_vs_exact != 0.0) ? g * m.inv_vs_exact : g / m.voxel_size; // == g / voxel_size bit for bit
     a.f = (int)floor(q); // PointToVoxel (vhm.hpp:176-180)
     a.t = q + q;         // exact: cell coordinate, floor(t) in {2f, 2f+1}
+    // stored keys f-1 .. f+1 -> cells: key k > 0 owns cells {2k, 2k+1}, key 0 owns {-2 .. 1}, key k < 0 owns {2k-2, 2k-1}
     const int kl = a.f - 1, kh = a.f + 1;
-    a.alo = kl > 0 ? 2 * kl : (kl == 0 ? -2 : 2 * kl - 2);
-    a.ahi = kh > 0 ? 2 * kh + 1 : (kh == 0 ? 1 : 2 * kh - 1);
+    a.alo = 2 * kl - ((kl <= 0) ? 2 : 0);
+    a.ahi = 2 * kh + ((kh < 0) ? -1 : 1);
     return a;
 }
 // the (clipped) two-cell span the query leans into and the distance to its open faces IN CELL UNITS (float: the fraction of g in
 // its own cell plus small integers; the 3e-8 m of rounding sit inside the 1e-6 m margin of the decision)
-__device__ __forceinline__ void grid_lean(const GridAxis& a, int& blo, int& bhi, float& rho_u) {
+__device__ __forceinline__ void grid_lean(const GridAxis& a, int& blo, int& bhi, float& rho_u, int& own, float& d_other) {
     const double fl = floor(a.t);
     const int cg = (int)fl;
     const float fr = (float)(a.t - fl); // position inside the own cell, [0, 1)
@@ -935,6 +962,8 @@ __device__ __forceinline__ void grid_lean(const GridAxis& a, int& blo, int& bhi,
     const float dlo = (blo == a.alo) ? 3e38f : (float)(cg - blo) + fr;
     const float dhi = (bhi == a.ahi) ? 3e38f : (float)(bhi + 1 - cg) - fr;
     rho_u = fminf(rho_u, fminf(dlo, dhi));
+    own = cg - blo;                                                  // the own cell is the span's first (0) or second (1) cell
+    d_other = (bhi > blo) ? ((own == 0) ? 1.0f - fr : fr) : 3e18f;   // distance to the span's other cell, cell units
 }
 
 struct GridHardRec {
@@ -1042,9 +1071,12 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
         }
         float rho_u = 3e38f; // distance to the block's open faces, cell units
         int bx0, bx1, by0, by1, bz0, bz1;
-        grid_lean(ax, bx0, bx1, rho_u);
-        grid_lean(ay, by0, by1, rho_u);
-        grid_lean(az, bz0, bz1, rho_u);
+        int ox, oy, oz;
+        float dxo, dyo, dzo;
+        grid_lean(ax, bx0, bx1, rho_u, ox, dxo);
+        grid_lean(ay, by0, by1, rho_u, oy, dyo);
+        grid_lean(az, bz0, bz1, rho_u, oz, dzo);
+        (void)oz; (void)dzo;
         // block cells relative to the grid; a block that leaves the grid (or came out empty) goes to stage 2, which clamps
         const int rx0 = bx0 - m.gx0, rx1 = bx1 - m.gx0, ry0 = by0 - m.gy0, ry1 = by1 - m.gy0, rz0 = bz0 - m.gz0, rz1 = bz1 - m.gz0;
         const bool inside = rx0 >= 0 && rx1 < m.gnx && rx0 <= rx1 && ry0 >= 0 && ry1 < m.gny && ry0 <= ry1 && rz0 >= 0 && rz1 < m.gnz && rz0 <= rz1;
@@ -1074,20 +1106,40 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
         float ghx = (float)gx, ghy = (float)gy, ghz = (float)gz;
         float glx = (float)(gx - (double)ghx), gly = (float)(gy - (double)ghy), glz = (float)(gz - (double)ghz);
         float slack = 4e-11f * (fabsf(ghx) + fabsf(ghy) + fabsf(ghz) + 1.0f);
-        asm volatile("" : "+v"(rr2), "+v"(ghx), "+v"(ghy), "+v"(ghz), "+v"(glx), "+v"(gly), "+v"(glz), "+v"(slack));
+        // the columns are visited nearest first -- own, the nearer of the x / y neighbour, the other, the diagonal one -- and a lane
+        // stops at the first column that lies farther than its current winner: lower bounds of the squared distance to the three
+        // neighbour columns (1e-6 m off each face distance for the float32 cell coordinate)
+        const float ex_ = fmaxf(dxo * (float)h - 1e-6f, 0.f), ey_ = fmaxf(dyo * (float)h - 1e-6f, 0.f);
+        const float Bx = fminf(ex_ * ex_, 1e36f), By = fminf(ey_ * ey_, 1e36f);
+        float L1 = fminf(Bx, By), L2 = fmaxf(Bx, By), L3 = (Bx + By) * 0.999999f;
+        asm volatile("" : "+v"(rr2), "+v"(ghx), "+v"(ghy), "+v"(ghz), "+v"(glx), "+v"(gly), "+v"(glz), "+v"(slack), "+v"(L1), "+v"(L2), "+v"(L3));
         pf.w = __uint_as_float(stat);
         *stash() = pf;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int b0 = ok[k] ? (int)s0[k] : 0;
-            const int b1 = ok[k] ? (int)((rz1 > rz0) ? s2[k] : s1[k]) : 0;
-            sb[k] = (unsigned)(b0 - cb[k]) * (unsigned)sizeof(GridBlk); // block t of the flattened sequence lives at byte sb[k] + 48 t for cb[k] <= t < cb[k + 1]
-            cb[k + 1] = cb[k] + (b1 - b0);
-        }
-        // decided <=> squared float32 winner distance (+ margins) < rr2, i.e. sqrt(r2) * 1.000001 + 1e-6 < rho
         {
-            const int nblk = cb[4];
-            n_tested = 4 * nblk;
+            int b0a[4], b1a[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                b0a[k] = ok[k] ? (int)s0[k] : 0;
+                b1a[k] = ok[k] ? (int)((rz1 > rz0) ? s2[k] : s1[k]) : 0;
+            }
+            // column k = (ix << 1) | iy; own column o, y neighbour o ^ 1, x neighbour o ^ 2, diagonal o ^ 3
+            const bool o0 = oy != 0, o1 = ox != 0, xfirst = Bx <= By;
+            int b0v[4], b1v[4];
+            auto visit_order = [&](const int* A, int* V) {
+                const int lo0 = o0 ? A[1] : A[0], lo1 = o0 ? A[0] : A[1], hi0 = o0 ? A[3] : A[2], hi1 = o0 ? A[2] : A[3];
+                const int P = o1 ? hi0 : lo0, Q = o1 ? hi1 : lo1, R = o1 ? lo0 : hi0, S = o1 ? lo1 : hi1;
+                V[0] = P; V[1] = xfirst ? R : Q; V[2] = xfirst ? Q : R; V[3] = S;
+            };
+            visit_order(b0a, b0v);
+            visit_order(b1a, b1v);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                sb[k] = (unsigned)(b0v[k] - cb[k]) * (unsigned)sizeof(GridBlk); // block t of the flattened sequence lives at byte sb[k] + 48 t for cb[k] <= t < cb[k + 1]
+                cb[k + 1] = cb[k] + (b1v[k] - b0v[k]);
+            }
+        }
+        {
+            int nblk = cb[4];
             const f32x2 gxy = {ghx, ghy}, gzl = {ghz, glx}, gl2 = {gly, glz};
             unsigned m1 = 0x7F800000u, m2 = 0x7F800000u; // +inf
             unsigned jb = 0;                             // byte offset of m1's block (block 0 = padding = none yet)
@@ -1117,7 +1169,13 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
                     two_smallest(db.y, 3u, m1, m2);
                     jb = (m1 != was) ? pb[w] : jb;
                 }
+                // the first column that lies beyond the current winner (2^-17 relative: outside the margins of the decision below)
+                // ends this lane's sequence: it and the columns after it cannot win or tie
+                const float dbest = __uint_as_float(m1 & ~3u);
+                const float best = (dbest + dbest * 7.62939453125e-06f + 2.0f * slack) * 1.000001f;
+                nblk = (L1 > best) ? cb[1] : ((L2 > best) ? cb[2] : ((L3 > best) ? cb[3] : nblk));
             }
+            n_tested = 4 * nblk;
             hard = true;
             if (jb > 0) { // a real candidate (block 0 is padding)
                 // the keys drop two mantissa bits (< 3.6e-7 relative, downwards) on top of the float32 distance's 2^-20: 2^-18 covers
