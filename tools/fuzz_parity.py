@@ -76,11 +76,14 @@ for case in range(a.seed0, a.seed0 + a.cases):
         *_, det = Registration(RegistrationConfig(icp_method=IcpMethod(method), **kw), ctx).RunRegister(scan, vm, T0, trace=True)
         ref = O.register(om, scan, T0, O.default_config(method, **kw))
         ok = det["iterations"] == ref["iterations"] and det["is_success"] == ref["is_success"] and det["gate"] == ref["gate"]
-        for g, r in zip(det["iters"], ref["iters"]):
+        for k, (g, r) in enumerate(zip(det["iters"], ref["iters"])):
             ok = ok and g["n_corr"] == r["n_corr"]
             if not (ref["gate"] == 2 and g is det["iters"][ref["iterations"] - 1]):
                 scale = max(np.abs(r["JTJ"]).max(), 1e-300)
-                ok = ok and np.abs(g["JTJ"] - r["JTJ"]).max() <= 1e-9 * scale
+                # iteration 0 sees identical inputs; later ones see poses that differ by the rounding of the earlier solves, which an
+                # ill-conditioned problem (few points per voxel) amplifies ~30x per iteration (case 7405: 1.6e-14 -> 1.7e-9 in six
+                # iterations on every kernel, the plain walk included; final pose 5e-7 m apart)
+                ok = ok and np.abs(g["JTJ"] - r["JTJ"]).max() <= min(1e-9 * 30.0 ** k, 1e-5) * scale
         dt, dr = synth.pose_error(ref["T"], det["T"])
         finite = np.isfinite(ref["T"]).all()
         ok = ok and ((dt <= 1e-4 and dr <= 1e-5) if finite else True)
@@ -89,6 +92,13 @@ for case in range(a.seed0, a.seed0 + a.cases):
         print("case", case, "raised", repr(e))
     if not ok:
         bad += 1
+        try:
+            for k, (g, r) in enumerate(zip(det["iters"], ref["iters"])):
+                scale = max(np.abs(r["JTJ"]).max(), 1e-300)
+                print(f"   iter {k}: n_corr {g['n_corr']} vs {r['n_corr']}  max|dJTJ|/scale {np.abs(g['JTJ'] - r['JTJ']).max() / scale:.3e}")
+            print("   pose error", synth.pose_error(ref["T"], det["T"]))
+        except Exception as e:  # noqa: BLE001
+            print("   (no detail:", repr(e), ")")
         print(f"MISMATCH case {case}: method {method} voxel {voxel} max_pts {max_pts} th {th} kind {kind} n_scan {len(scan)} "
               f"iters {det.get('iterations')} vs {ref.get('iterations')} gate {det.get('gate')} vs {ref.get('gate')}")
 print(f"{a.cases - bad}/{a.cases} cases agree (kernel {a.kernel})")
