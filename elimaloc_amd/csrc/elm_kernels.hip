@@ -1522,6 +1522,9 @@ __global__ __launch_bounds__(64) void k_nbr_cellsort(const DevMap m, const int32
 #ifndef ELM_VNBR_RECS
 #define ELM_VNBR_RECS 4
 #endif
+#ifndef ELM_AVG_RECS
+#define ELM_AVG_RECS 1 // AVGICP: records per round trip (each brings a 72-byte inverse covariance along): 1 -> 78 VGPRs, 50.5k registrations/s; 2 -> 106, 43.2k; 3 -> 130, 42.0k
+#endif
 #ifndef ELM_VNBR_WAVES
 #define ELM_VNBR_WAVES 1
 #endif
@@ -1604,14 +1607,29 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
             double n_pairs = 0.0;
             AvgPairSum P;
             avg_pair_init(P);
-            for (unsigned j = 0; j < cnt; ++j) {
-                const VoxRec r = lp[j];
-                const int code = r.pad;
-                if (!(code == 13 || code == 22 || code == 4 || code == 16 || code == 10 || code == 14 || code == 12)) continue;
-                n_pairs += 1.0;
-                const double ex = r.mx - gx, ey = r.my - gy, ez = r.mz - gz;
-                const double d2 = (ex * ex + ey * ey) + ez * ez;
-                if (d2 < rp.th2) avg_pair_add(P, ex, ey, ez, m.vox_cinv + (size_t)r.vid * 9, rp);
+            for (unsigned j = 0; j < cnt; j += ELM_AVG_RECS) { // ELM_AVG_RECS records (two 16-byte loads each) per round trip
+                VoxRec r[ELM_AVG_RECS];
+#pragma unroll
+                for (int u = 0; u < ELM_AVG_RECS; ++u) r[u] = lp[min(j + u, cnt - 1)];
+                // the face neighbours among them: their inverse covariances are requested together, before the first is used
+                bool use[ELM_AVG_RECS];
+                double Ci[ELM_AVG_RECS][9];
+#pragma unroll
+                for (int u = 0; u < ELM_AVG_RECS; ++u) {
+                    const int code = r[u].pad;
+                    use[u] = j + u < cnt && (code == 13 || code == 22 || code == 4 || code == 16 || code == 10 || code == 14 || code == 12);
+                    const double* __restrict__ cp = m.vox_cinv + (size_t)(use[u] ? r[u].vid : 0) * 9;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) Ci[u][k] = cp[k];
+                }
+#pragma unroll
+                for (int u = 0; u < ELM_AVG_RECS; ++u) {
+                    if (!use[u]) continue;
+                    n_pairs += 1.0;
+                    const double ex = r[u].mx - gx, ey = r[u].my - gy, ez = r[u].mz - gz;
+                    const double d2 = (ex * ex + ey * ey) + ez * ez;
+                    if (d2 < rp.th2) avg_pair_add(P, ex, ey, ez, Ci[u], rp);
+                }
             }
             store_pair_sum(acc, P, gx - S.T[12], gy - S.T[13], gz - S.T[14]);
             acc[29] = n_pairs;
