@@ -292,7 +292,9 @@ struct elm_map {
     uint16_t* d_nbr_cell_off = nullptr;
     HashSlot* d_vqslots = nullptr;
     uint32_t* d_vq_dense = nullptr;
+    uint32_t* d_vqf_dense = nullptr;
     VoxRec* d_vnbr = nullptr;
+    VoxRec* d_vface = nullptr;
     GridBlk* d_grid_blk = nullptr;    // dense cell grid (DevMap::grid_*), the default P2P / GICP search index
     uint32_t* d_grid_idx = nullptr;
     uint32_t* d_grid_start = nullptr;
@@ -455,7 +457,7 @@ static void build_host(const float* xyz, size_t n, double voxel_size, int max_po
 static void map_free(elm_map* m) {
     if (!m) return;
     if (ctx_alive(m->ctx)) (void)hipSetDevice(m->ctx->device); // a context destroyed first: just release the device memory
-    void* ptrs[] = {m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_vox_cinv, m->d_pt_gicp, m->d_pt_cov, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off, m->d_vqslots, m->d_vq_dense, m->d_vnbr,
+    void* ptrs[] = {m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_vox_cinv, m->d_pt_gicp, m->d_pt_cov, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off, m->d_vqslots, m->d_vq_dense, m->d_vqf_dense, m->d_vface, m->d_vnbr,
                     m->d_grid_blk, m->d_grid_idx, m->d_grid_start, m->d_vox_stat, m->d_grid_gicp};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -695,6 +697,47 @@ static int build_voxel_neighbourhoods(elm_map* m) {
             m->dm.vq_nx = (int32_t)vd[0]; m->dm.vq_ny = (int32_t)vd[1]; m->dm.vq_nz = (int32_t)vd[2];
             m->info.device_bytes += vcells * sizeof(uint32_t);
             m->info.index_bytes += vcells * sizeof(uint32_t);
+            // AVGICP pairs with the face neighbours only (<= 7 of a list's <= 27 records): their sublists, addressed the same way
+            uint32_t* d_fcnt = nullptr;
+            uint32_t* d_foff = nullptr;
+            VN_CHK(hipMalloc((void**)&d_fcnt, nq_alloc * sizeof(uint32_t)));
+            hipError_t fe = hipMalloc((void**)&d_foff, nq_alloc * sizeof(uint32_t));
+            if (fe != hipSuccess) { (void)hipFree(d_fcnt); VN_CHK(fe); }
+            auto face_cleanup = [&]() { (void)hipFree(d_fcnt); (void)hipFree(d_foff); };
+#define VF_CHK(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e2_ = (call);                                                              \
+        if (e2_ != hipSuccess) { face_cleanup(); VN_CHK(e2_); }                               \
+    } while (0)
+            (void)hipGetLastError();
+            launch_vface(ctx->stream, m->d_vnbr, d_off, d_nocc, n_q, d_fcnt, nullptr, nullptr);
+            VF_CHK(hipGetLastError());
+            VF_CHK(hipStreamSynchronize(ctx->stream));
+            std::vector<uint32_t> fcnt(n_q), foff(n_q);
+            VF_CHK(hipMemcpy(fcnt.data(), d_fcnt, (size_t)n_q * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            uint64_t ftotal = 0;
+            for (uint32_t q = 0; q < n_q; ++q) { foff[q] = (uint32_t)ftotal; ftotal += fcnt[q]; }
+            if (ftotal < (1ull << 29)) {
+                VF_CHK(hipMemcpy(d_foff, foff.data(), (size_t)n_q * sizeof(uint32_t), hipMemcpyHostToDevice));
+                VF_CHK(hipMalloc((void**)&m->d_vface, std::max<size_t>((size_t)ftotal * sizeof(VoxRec), 256)));
+                launch_vface(ctx->stream, m->d_vnbr, d_off, d_nocc, n_q, d_fcnt, d_foff, m->d_vface);
+                VF_CHK(hipGetLastError());
+                VF_CHK(hipStreamSynchronize(ctx->stream));
+                std::fill(dense.begin(), dense.end(), 0u);
+                for (uint32_t q = 0; q < n_q; ++q) {
+                    const uint64_t idx = ((uint64_t)(qkeys[3 * q] - klo[0]) * (uint64_t)vd[1] + (uint64_t)(qkeys[3 * q + 1] - klo[1])) * (uint64_t)vd[2] +
+                                         (uint64_t)(qkeys[3 * q + 2] - klo[2]);
+                    dense[idx] = (foff[q] << 3) | fcnt[q]; // fcnt <= 7
+                }
+                VF_CHK(hipMalloc((void**)&m->d_vqf_dense, vcells * sizeof(uint32_t)));
+                VF_CHK(hipMemcpy(m->d_vqf_dense, dense.data(), vcells * sizeof(uint32_t), hipMemcpyHostToDevice));
+                m->dm.vface = m->d_vface;
+                m->dm.vqf_dense = m->d_vqf_dense;
+                m->info.device_bytes += vcells * sizeof(uint32_t) + (size_t)ftotal * sizeof(VoxRec);
+                m->info.index_bytes += vcells * sizeof(uint32_t) + (size_t)ftotal * sizeof(VoxRec);
+            }
+            face_cleanup();
+#undef VF_CHK
         }
     }
 #undef VN_CHK

@@ -63,6 +63,9 @@ struct DevMap {
     uint32_t _pad2;
     const VoxRec* vnbr;
     const uint32_t* vq_dense; // optional: the same (start << 5 | cnt) addressed by the dense floor-key box (vq_x0.., no hash probe)
+    const VoxRec* vface;        // optional (with vq_dense): the FACE neighbours (+ the voxel itself) of every query voxel, in list order --
+                                // what AVGICP pairs with (vhm.cpp:153-206) -- and
+    const uint32_t* vqf_dense;  // (start << 3 | count) of those, addressed like vq_dense
     int32_t vq_x0, vq_y0, vq_z0;
     int32_t vq_nx, vq_ny, vq_nz;
     const uint16_t* nbr_cell_off; // [n_q][224]: every list is sorted by half-voxel cell (6x6x6 grid, clamped); cell c =
@@ -174,6 +177,9 @@ void launch_nbr_count(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint
 void launch_accumulate_vnbr(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                             ScanState* st, double* partials, const RegParams& rp);
 void launch_vnbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets, VoxRec* out);
+// face-neighbour sublists of the voxel-mean lists: counts (out == nullptr) or the records at face_off
+void launch_vface(hipStream_t s, const VoxRec* vnbr, const uint32_t* offsets, const uint32_t* counts, uint32_t n_q, uint32_t* face_cnt,
+                  const uint32_t* face_off, VoxRec* out);
 void launch_accumulate_cell(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                             ScanState* st, double* partials, const RegParams& rp);
 int stream_max_slots(); // slots one elm_register_stream call can iterate concurrently

@@ -1555,8 +1555,14 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
         if (m.vq_dense) { // the dense floor-key box: no probe
             const int ux = vx - m.vq_x0, uy = vy - m.vq_y0, uz = vz - m.vq_z0;
             if ((unsigned)ux < (unsigned)m.vq_nx && (unsigned)uy < (unsigned)m.vq_ny && (unsigned)uz < (unsigned)m.vq_nz) {
-                const unsigned w = m.vq_dense[((size_t)ux * m.vq_ny + uy) * m.vq_nz + uz];
-                start = w >> 5; cnt = w & 31u;
+                const size_t vidx = ((size_t)ux * m.vq_ny + uy) * m.vq_nz + uz;
+                if (METHOD == ELM_AVGICP && m.vqf_dense) { // the face neighbours only
+                    const unsigned w = m.vqf_dense[vidx];
+                    start = w >> 3; cnt = w & 7u;
+                } else {
+                    const unsigned w = m.vq_dense[vidx];
+                    start = w >> 5; cnt = w & 31u;
+                }
             }
         } else {
             unsigned h = hash3(vx, vy, vz) & m.vqmask;
@@ -1573,7 +1579,7 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
                 h = (h + 2) & m.vqmask;
             }
         }
-        const VoxRec* __restrict__ lp = m.vnbr + start;
+        const VoxRec* __restrict__ lp = ((METHOD == ELM_AVGICP && m.vq_dense && m.vqf_dense) ? m.vface : m.vnbr) + start;
         if (METHOD == ELM_VGICP) {
             double bd2 = DBL_MAX, bmx = 0.0, bmy = 0.0, bmz = 0.0;
             int bvid = -1;
@@ -2312,6 +2318,30 @@ void launch_accumulate_vnbr(hipStream_t s, const DevMap& m, const ScanDesc* scan
         hipLaunchKernelGGL((k_accumulate_vnbr<ELM_VGICP>), dim3(total_blocks), dim3(kBlock), 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
     else
         hipLaunchKernelGGL((k_accumulate_vnbr<ELM_AVGICP>), dim3(total_blocks), dim3(kBlock), 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
+}
+// map build: the face neighbours (and the voxel itself) of every voxel-mean list, in list order (AVGICP's pairs)
+__device__ __forceinline__ bool is_face_code(int code) {
+    return code == 13 || code == 22 || code == 4 || code == 16 || code == 10 || code == 14 || code == 12;
+}
+__global__ __launch_bounds__(256) void k_vface(const VoxRec* __restrict__ vnbr, const uint32_t* __restrict__ offsets,
+                                               const uint32_t* __restrict__ counts, unsigned n_q, uint32_t* __restrict__ face_cnt,
+                                               const uint32_t* __restrict__ face_off, VoxRec* __restrict__ out) {
+    const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_q) return;
+    const VoxRec* lp = vnbr + offsets[q];
+    unsigned n = 0;
+    const unsigned o = out ? face_off[q] : 0u;
+    for (unsigned j = 0; j < counts[q]; ++j) {
+        const VoxRec r = lp[j];
+        if (!is_face_code(r.pad)) continue;
+        if (out) out[o + n] = r;
+        ++n;
+    }
+    if (!out) face_cnt[q] = n;
+}
+void launch_vface(hipStream_t s, const VoxRec* vnbr, const uint32_t* offsets, const uint32_t* counts, uint32_t n_q, uint32_t* face_cnt,
+                  const uint32_t* face_off, VoxRec* out) {
+    if (n_q) hipLaunchKernelGGL(k_vface, dim3((n_q + 255) / 256), dim3(256), 0, s, vnbr, offsets, counts, n_q, face_cnt, face_off, out);
 }
 void launch_vnbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets, VoxRec* out) {
     hipLaunchKernelGGL(k_vnbr_fill, dim3((n_q + 255) / 256), dim3(256), 0, s, m, qkeys, n_q, offsets, out);
