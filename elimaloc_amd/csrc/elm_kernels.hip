@@ -541,6 +541,128 @@ __device__ __forceinline__ void block_reduce_to_lds(const double* v, double* buf
     __syncthreads();
 }
 
+// ---- the 29 world-frame sums of one scan point, kept factored until the reduction needs them ---------------------------------
+// add_pair_world's sums are functions of A = sum w C^-1 (3x3), b = sum A e (3), a = R p (3), the residual sum and the pair count
+// (one pair: VGICP / GICP; up to seven with one common a: AVGICP).  Holding those 17 numbers and expanding EIGHT sums at a time,
+// right before each pass of the block reduction writes them to LDS, keeps ~20 double registers alive instead of 32 + temporaries
+// (k_accumulate_vnbr<VGICP>: 92 -> VGPRs of a 7-wave kernel).  The formulas and their operand order are add_pair_world's.
+struct PairSum {
+    double A[9], b[3], ax, ay, az, rsum, n, c29, c30, c31;
+};
+__device__ __forceinline__ void pair_sum_zero(PairSum& P) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) P.A[i] = 0.0;
+    P.b[0] = P.b[1] = P.b[2] = 0.0;
+    P.ax = P.ay = P.az = 0.0;
+    P.rsum = 0.0; P.n = 0.0; P.c29 = 0.0; P.c30 = 0.0; P.c31 = 0.0;
+}
+// entry (i, j) of A * (-[a]x)
+template <int I, int J>
+__device__ __forceinline__ double pair_ab(const PairSum& P) {
+    if (J == 0) return P.A[I * 3 + 2] * P.ay - P.A[I * 3 + 1] * P.az;
+    if (J == 1) return P.A[I * 3 + 0] * P.az - P.A[I * 3 + 2] * P.ax;
+    return P.A[I * 3 + 1] * P.ax - P.A[I * 3 + 0] * P.ay;
+}
+template <int K>
+__device__ __forceinline__ double pair_sum_value(const PairSum& P) {
+    if (K == tri(0, 0)) return P.A[0];
+    if (K == tri(0, 1)) return P.A[1];
+    if (K == tri(0, 2)) return P.A[2];
+    if (K == tri(1, 1)) return P.A[4];
+    if (K == tri(1, 2)) return P.A[5];
+    if (K == tri(2, 2)) return P.A[8];
+    if (K == tri(0, 3)) return pair_ab<0, 0>(P);
+    if (K == tri(0, 4)) return pair_ab<0, 1>(P);
+    if (K == tri(0, 5)) return pair_ab<0, 2>(P);
+    if (K == tri(1, 3)) return pair_ab<1, 0>(P);
+    if (K == tri(1, 4)) return pair_ab<1, 1>(P);
+    if (K == tri(1, 5)) return pair_ab<1, 2>(P);
+    if (K == tri(2, 3)) return pair_ab<2, 0>(P);
+    if (K == tri(2, 4)) return pair_ab<2, 1>(P);
+    if (K == tri(2, 5)) return pair_ab<2, 2>(P);
+    if (K == tri(3, 3)) return P.ay * pair_ab<2, 0>(P) - P.az * pair_ab<1, 0>(P);
+    if (K == tri(3, 4)) return P.ay * pair_ab<2, 1>(P) - P.az * pair_ab<1, 1>(P);
+    if (K == tri(3, 5)) return P.ay * pair_ab<2, 2>(P) - P.az * pair_ab<1, 2>(P);
+    if (K == tri(4, 4)) return P.az * pair_ab<0, 1>(P) - P.ax * pair_ab<2, 1>(P);
+    if (K == tri(4, 5)) return P.az * pair_ab<0, 2>(P) - P.ax * pair_ab<2, 2>(P);
+    if (K == tri(5, 5)) return P.ax * pair_ab<1, 2>(P) - P.ay * pair_ab<0, 2>(P);
+    if (K == 21) return P.b[0];
+    if (K == 22) return P.b[1];
+    if (K == 23) return P.b[2];
+    if (K == 24) return P.ay * P.b[2] - P.az * P.b[1];
+    if (K == 25) return P.az * P.b[0] - P.ax * P.b[2];
+    if (K == 26) return P.ax * P.b[1] - P.ay * P.b[0];
+    if (K == 27) return P.rsum;
+    if (K == 28) return P.n;
+    if (K == 29) return P.c29;
+    if (K == 30) return P.c30;
+    if (K == 31) return P.c31;
+    return 0.0;
+}
+template <int H, int PP, int Q>
+struct PairPassWriter {
+    static __device__ __forceinline__ void run(const PairSum& P, double* buf, int tid) {
+        if (H * PP + Q < kSums) buf[Q * kBlock + tid] = pair_sum_value<H * PP + Q>(P);
+        PairPassWriter<H, PP, Q + 1>::run(P, buf, tid);
+    }
+};
+template <int H, int PP>
+struct PairPassWriter<H, PP, PP> {
+    static __device__ __forceinline__ void run(const PairSum&, double*, int) {}
+};
+template <int PP, int H>
+struct PairReducePass {
+    static __device__ __forceinline__ void run(const PairSum& P, double* buf, double* red) {
+        constexpr int LPV = kBlock / PP;
+        const int tid = threadIdx.x;
+        const int k = tid / LPV, seg = tid % LPV;
+        if (H) __syncthreads();
+        PairPassWriter<H, PP, 0>::run(P, buf, tid);
+        __syncthreads();
+        if (H * PP + k < kSums) {
+            double a = 0.0;
+#pragma unroll
+            for (int i = 0; i < PP; ++i) a += buf[k * kBlock + i * LPV + seg];
+            a += dpp_move<0x128>(a); // row_ror:8
+            a += dpp_move<0x124>(a); // row_ror:4
+            a += dpp_move<0x4E>(a);  // quad_perm [2,3,0,1]
+            a += dpp_move<0xB1>(a);  // quad_perm [1,0,3,2]
+            if (LPV == 32) a += __shfl_xor(a, 16, 64);
+            if (seg == 0) red[H * PP + k] = a;
+        }
+        PairReducePass<PP, H + 1>::run(P, buf, red);
+    }
+};
+template <int PP>
+struct PairReducePass<PP, (kSums + PP - 1) / PP> {
+    static __device__ __forceinline__ void run(const PairSum&, double*, double*) {}
+};
+// block_reduce_to_lds<kSums, PP> on the factored sums: same passes, same tree, same values
+template <int PP>
+__device__ __forceinline__ void block_reduce_pair_sum(const PairSum& P, double* buf, double* red) {
+    PairReducePass<PP, 0>::run(P, buf, red);
+    __syncthreads();
+}
+// one pair into the factored form (add_pair_world's weight, threshold and residual rules)
+template <int METHOD>
+__device__ __forceinline__ void pair_sum_single(PairSum& P, double ex, double ey, double ez, const double* Cinv, const double* nfit, const RegParams& rp) {
+    const double r2 = (ex * ex + ey * ey) + ez * ez;
+    const double den = rp.th + r2;
+    double w = rp.th2 / (den * den); // square(th) / square(th + |r|^2)
+    if (METHOD == ELM_GICP) w = w * 0.8 + 0.2;
+    P.n = 1.0;
+    if (METHOD == ELM_VGICP || METHOD == ELM_AVGICP) {
+        if (w < 0.01) return; // reg.cpp:201 -- skipped pairs stay in the fitness denominator
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) P.A[i] = w * Cinv[i];
+    P.b[0] = (P.A[0] * ex + P.A[1] * ey) + P.A[2] * ez;
+    P.b[1] = (P.A[3] * ex + P.A[4] * ey) + P.A[5] * ez;
+    P.b[2] = (P.A[6] * ex + P.A[7] * ey) + P.A[8] * ez;
+    if (METHOD == ELM_GICP) P.rsum = fabs((ex * nfit[0] + ey * nfit[1]) + ez * nfit[2]);
+    else P.rsum = sqrt(r2);
+}
+
 // ---- P2P pair in 18 sums ---------------------------------------------------------------------------------------------
 // AlignCloudsLocal (reg.cpp:28-51) has M = I and J = [I | -[p]x], so J^T w J and J^T w r are functions of
 //   w, w p (3), w p p^T (6 unique), w r (3), w (p x r) (3), |r|, pair count            (18 sums instead of 29)
@@ -1541,9 +1663,8 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
     const ScanDesc sd = scans[s];
     const unsigned i = (L - sd.blk_begin) * kBlock + threadIdx.x;
     const bool valid = i < sd.n;
-    double acc[32];
-#pragma unroll
-    for (int k = 0; k < 32; ++k) acc[k] = 0.0;
+    PairSum P;
+    pair_sum_zero(P);
     if (valid) {
         const float4 pf = sd.pts[i];
         const double px = pf.x, py = pf.y, pz = pf.z;
@@ -1601,18 +1722,32 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
                 const VoxRec w = lp[min(bj, cnt - 1)];
                 bvid = w.vid; bmx = w.mx; bmy = w.my; bmz = w.mz;
             }
-            finish_voxel_pair<true>(acc, m, S, rp, px, py, pz, gx, gy, gz, bd2, bvid, bmx, bmy, bmz);
-            acc[29] = (double)cnt;
-            acc[30] = (double)cnt;
-            acc[31] = (double)cnt;
+            // finish_voxel_pair: no voxel at all -> the reference's default VoxelStruct at the origin with covariance I (QUIRK)
+            const double dfin = (bvid >= 0) ? bd2 : (gx * gx + gy * gy) + gz * gz;
+            if (dfin < rp.th2) {
+                if (bvid < 0) bmx = bmy = bmz = 0.0;
+                double Ci[9];
+                if (bvid >= 0) {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) Ci[k] = m.vox_cinv[(size_t)bvid * 9 + k];
+                } else {
+                    Ci[0] = 1; Ci[1] = 0; Ci[2] = 0; Ci[3] = 0; Ci[4] = 1; Ci[5] = 0; Ci[6] = 0; Ci[7] = 0; Ci[8] = 1;
+                }
+                pair_sum_single<ELM_VGICP>(P, bmx - gx, bmy - gy, bmz - gz, Ci, nullptr, rp);
+                P.ax = gx - S.T[12]; P.ay = gy - S.T[13]; P.az = gz - S.T[14];
+            }
+            (void)px; (void)py; (void)pz;
+            P.c29 = (double)cnt;
+            P.c30 = (double)cnt;
+            P.c31 = (double)cnt;
         } else {
             // AVGICP, GetCorrespondencesAllCov (vhm.cpp:153-206): every existing FACE neighbour (and the voxel itself) whose
             // mean is within range is a pair of its own.  The records carry the neighbour's position code (dx+1)*9+(dy+1)*3+
             // (dz+1); the seven wanted ones are met in list order (-x, -y, -z, 0, +z, +y, +x) instead of the reference's
             // (0, +x, -x, +y, -y, +z, -z): the same pairs, added in another order.
             double n_pairs = 0.0;
-            AvgPairSum P;
-            avg_pair_init(P);
+            AvgPairSum Q;
+            avg_pair_init(Q);
             for (unsigned j = 0; j < cnt; j += ELM_AVG_RECS) { // ELM_AVG_RECS records (two 16-byte loads each) per round trip
                 VoxRec r[ELM_AVG_RECS];
 #pragma unroll
@@ -1634,16 +1769,20 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
                     n_pairs += 1.0;
                     const double ex = r[u].mx - gx, ey = r[u].my - gy, ez = r[u].mz - gz;
                     const double d2 = (ex * ex + ey * ey) + ez * ez;
-                    if (d2 < rp.th2) avg_pair_add(P, ex, ey, ez, Ci[u], rp);
+                    if (d2 < rp.th2) avg_pair_add(Q, ex, ey, ez, Ci[u], rp);
                 }
             }
-            store_pair_sum(acc, P, gx - S.T[12], gy - S.T[13], gz - S.T[14]);
-            acc[29] = n_pairs;
-            acc[30] = n_pairs;
-            acc[31] = n_pairs;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) P.A[k] = Q.A[k];
+            P.b[0] = Q.b[0]; P.b[1] = Q.b[1]; P.b[2] = Q.b[2];
+            P.rsum = Q.rsum; P.n = Q.n;
+            P.ax = gx - S.T[12]; P.ay = gy - S.T[13]; P.az = gz - S.T[14];
+            P.c29 = n_pairs;
+            P.c30 = n_pairs;
+            P.c31 = n_pairs;
         }
     }
-    block_reduce_to_lds<kSums, kRedPass>(acc, s_buf, s_red);
+    block_reduce_pair_sum<kRedPass>(P, s_buf, s_red);
     if (threadIdx.x < kSums) partials[(size_t)L * kSums + threadIdx.x] = s_red[threadIdx.x];
 }
 
