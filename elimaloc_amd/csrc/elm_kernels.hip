@@ -1642,7 +1642,7 @@ __global__ __launch_bounds__(64) void k_nbr_cellsort(const DevMap m, const int32
 // that visiting order as 32-byte (mean, id) records: one probe, then <= 27 contiguous records, float64 distances in the
 // reference's order -- no staging, no barriers before the block reduction.
 #ifndef ELM_VNBR_RECS
-#define ELM_VNBR_RECS 4
+#define ELM_VNBR_RECS 3 // VGICP: list records per round trip (measured 2 / 3 / 4 / 6 / 8: 105.9 / 110.5 / 102.3 / 99.3 / 92.3 k registrations/s)
 #endif
 #ifndef ELM_AVG_RECS
 #define ELM_AVG_RECS 1 // AVGICP: records per round trip (each brings a 72-byte inverse covariance along): 1 -> 78 VGPRs, 50.5k registrations/s; 2 -> 106, 43.2k; 3 -> 130, 42.0k
