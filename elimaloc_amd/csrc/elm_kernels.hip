@@ -1212,9 +1212,11 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
     const ScanDesc sd = scans[s];
     const unsigned i = (L - sd.blk_begin) * kBlock + threadIdx.x;
     const bool valid = i < sd.n;
-    double v[NV];
+    double v[(METHOD == ELM_P2P) ? NV : 1]; // P2P: its 18 sums + 3 counters; GICP: the factored form P below
 #pragma unroll
-    for (int k = 0; k < NV; ++k) v[k] = 0.0;
+    for (int k = 0; k < ((METHOD == ELM_P2P) ? NV : 1); ++k) v[k] = 0.0;
+    PairSum P;
+    if (METHOD != ELM_P2P) pair_sum_zero(P);
     int bj = -1; // winning candidate: block * 4 + slot
     int n_tested = 0;
     float hr2 = __builtin_inff();
@@ -1532,16 +1534,37 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
         }
         const double ex = (double)bx - gx, ey = (double)by - gy, ez = (double)bz - gz;
         const double bd2 = (ex * ex + ey * ey) + ez * ez;
+        const double c_cand = (double)(stat & 0xFFFFu); // candidates of the reference's walk
+        const double c_occ = (double)(stat >> 16);     // occupied neighbour voxels
+        const double c_tested = (double)n_tested + (hard ? kFallbackUnit : 0.0); // high part: points served by stage 2
         if (METHOD == ELM_P2P) {
             if (bd2 < rp.th2) pair_p2p(v, S.Rinv, px, py, pz, ex, ey, ez, bd2, rp);
+            v[NV - 3] = c_cand; v[NV - 2] = c_occ; v[NV - 1] = c_tested;
         } else {
-            finish_point_pair<METHOD, true>(v, m, S, rp, px, py, pz, gx, gy, gz, bd2, bx, by, bz, bidx, m.grid_gicp);
+            // finish_point_pair: no bucket at all -> the reference's default PointStruct at the origin with covariance I (QUIRK);
+            // GICP's target position is the neighbourhood MEAN of the matched point (reg.cpp:97)
+            const double dfin = (bidx >= 0) ? bd2 : (gx * gx + gy * gy) + gz * gz;
+            if (dfin < rp.th2) {
+                double Ci[9], mean[3], nf[3];
+                if (bidx >= 0) {
+                    const double* __restrict__ rec = m.grid_gicp + (size_t)bidx * 16;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) Ci[k] = rec[3 + k];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { mean[k] = rec[k]; nf[k] = rec[12 + k]; }
+                } else {
+                    Ci[0] = 1; Ci[1] = 0; Ci[2] = 0; Ci[3] = 0; Ci[4] = 1; Ci[5] = 0; Ci[6] = 0; Ci[7] = 0; Ci[8] = 1;
+                    mean[0] = mean[1] = mean[2] = 0.0;
+                    nf[0] = 1.0; nf[1] = 0.0; nf[2] = 0.0;
+                }
+                pair_sum_single<ELM_GICP>(P, mean[0] - gx, mean[1] - gy, mean[2] - gz, Ci, nf, rp);
+                P.ax = gx - S.T[12]; P.ay = gy - S.T[13]; P.az = gz - S.T[14];
+            }
+            P.c29 = c_cand; P.c30 = c_occ; P.c31 = c_tested;
         }
-        v[NV - 3] = (double)(stat & 0xFFFFu); // candidates of the reference's walk
-        v[NV - 2] = (double)(stat >> 16);     // occupied neighbour voxels
-        v[NV - 1] = (double)n_tested + (hard ? kFallbackUnit : 0.0); // high part: points served by stage 2
     }
-    block_reduce_to_lds<NV, kRedPass>(v, s_buf, s_red);
+    if (METHOD == ELM_P2P) block_reduce_to_lds<NV, kRedPass>(v, s_buf, s_red);
+    else block_reduce_pair_sum<kRedPass>(P, s_buf, s_red);
     if (threadIdx.x < kSums) partials[(size_t)L * kSums + threadIdx.x] = (METHOD == ELM_P2P) ? p2p_expand(s_red, (int)threadIdx.x) : s_red[threadIdx.x];
 }
 
