@@ -412,6 +412,32 @@ def test_full_size_c3_gicp(ctx, oracle):
     np.testing.assert_allclose(cov, ref["local_cov"], rtol=1e-7, atol=1e-12)
 
 
+def test_full_size_avgicp(ctx, oracle):
+    """AVGICP at BASELINE configs[1] sizes (131072-pt scan vs 10M-pt map): the face-neighbour sublists and their dense
+    table over the whole map, the registration against the oracle run on the part of the map the scan can reach, and the
+    stream path bit-identical to the single call."""
+    from elimaloc_amd.registration import Registration, RegistrationConfig, IcpMethod, VoxelHashMap, Scan
+    world = synth.make_world(10_000_000, seed=1001)
+    vm = VoxelHashMap(1.0, 30, ctx)
+    vm.AddPoints(world)
+    vm.CalVoxelCovAll()
+    scan, T_true = synth.make_scan(world, 131072, seed=2006)
+    T0 = synth.perturb(T_true, seed=3006)
+    reg = Registration(RegistrationConfig(icp_method=IcpMethod.AVGICP), ctx)
+    *_, det = reg.RunRegister(scan, vm, T0, trace=True)
+    near = world[np.linalg.norm(world[:, :2] - T_true[:2, 3], axis=1) < 75.0]
+    om = oracle.Map(1.0, 30)
+    om.add_points(near)
+    om.cal_voxel_cov_all()
+    ref = oracle.register(om, scan, T0, oracle.default_config(3))
+    _compare_run(det, ref)
+    sc = Scan(ctx, scan)
+    one = reg.RunRegisterBatch([sc], vm, [T0])[0]
+    two = reg.RunRegisterStream([sc, sc, sc], vm, [T0, T0, T0], slots=2)
+    for r in two:
+        assert r["iterations"] == one["iterations"] and np.array_equal(r["T"], one["T"])
+
+
 def test_full_size_c4_vgicp_shape(ctx, oracle):
     """BASELINE config C4 sizes on ONE GPU (262144-pt scan vs 50M-pt map, VGICP; the 8-GPU sharding of the same call is
     what bench.py --gpus 8 runs): map build + voxel covariances over 50M points, registration vs the oracle on the
