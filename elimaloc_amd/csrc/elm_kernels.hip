@@ -219,8 +219,8 @@ __device__ __forceinline__ void add_pair_world(double* acc, double ax, double ay
 
 // AVGICP forms up to seven pairs per scan point, all with the same Jacobian J_w = [I | -[a]x] (a = R p): sum_v J^T A_v J =
 // J^T (sum_v A_v) J and sum_v J^T A_v e_v = J^T sum_v (A_v e_v) with A_v = w_v C_v^-1.  The pairs are therefore gathered into
-// one 3x3 + one 3-vector per point (AvgPairSum, 27 registers) and expanded ONCE (store_pair_sum) -- the same sums as seven
-// add_pair_world calls up to the order of the additions.
+// one 3x3 + one 3-vector per point (AvgPairSum, 27 registers) and expanded ONCE (by the block reduction, PairSum below) -- the
+// same sums as seven add_pair_world calls up to the order of the additions.
 struct AvgPairSum {
     double A[9], b[3], rsum, n;
 };
@@ -247,34 +247,6 @@ __device__ __forceinline__ void avg_pair_add(AvgPairSum& P, double ex, double ey
     P.b[1] += (A[3] * ex + A[4] * ey) + A[5] * ez;
     P.b[2] += (A[6] * ex + A[7] * ey) + A[8] * ez;
     P.rsum += sqrt(r2);
-}
-__device__ __forceinline__ void store_pair_sum(double* acc, const AvgPairSum& P, double ax, double ay, double az) {
-    const double* A = P.A;
-    double AB[9]; // A * (-[a]x)
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        AB[i * 3 + 0] = A[i * 3 + 2] * ay - A[i * 3 + 1] * az;
-        AB[i * 3 + 1] = A[i * 3 + 0] * az - A[i * 3 + 2] * ax;
-        AB[i * 3 + 2] = A[i * 3 + 1] * ax - A[i * 3 + 0] * ay;
-    }
-    acc[tri(0, 0)] = A[0]; acc[tri(0, 1)] = A[1]; acc[tri(0, 2)] = A[2];
-    acc[tri(1, 1)] = A[4]; acc[tri(1, 2)] = A[5]; acc[tri(2, 2)] = A[8];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc[tri(i, 3 + j)] = AB[i * 3 + j];
-    acc[tri(3, 3)] = ay * AB[6] - az * AB[3];
-    acc[tri(3, 4)] = ay * AB[7] - az * AB[4];
-    acc[tri(3, 5)] = ay * AB[8] - az * AB[5];
-    acc[tri(4, 4)] = az * AB[1] - ax * AB[7];
-    acc[tri(4, 5)] = az * AB[2] - ax * AB[8];
-    acc[tri(5, 5)] = ax * AB[5] - ay * AB[2];
-    acc[21] = P.b[0]; acc[22] = P.b[1]; acc[23] = P.b[2];
-    acc[24] = ay * P.b[2] - az * P.b[1];
-    acc[25] = az * P.b[0] - ax * P.b[2];
-    acc[26] = ax * P.b[1] - ay * P.b[0];
-    acc[27] = P.rsum;
-    acc[28] = P.n;
 }
 
 // ------------------------------------------------------------------------------------------------------
