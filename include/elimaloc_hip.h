@@ -193,7 +193,10 @@ int elm_register_batch(elm_ctx* ctx, const elm_map* map, elm_scan* const* scans,
 /* Continuous batching: `count` registrations through `slots` device slots.  Finished slots are refilled on the device with
  * the next pending registration after every ICP iteration, so every launch stays full until the queue is empty (throughput
  * mode for many more registrations than can usefully iterate in lockstep).  Results are bit-identical to
- * elm_register_batch / elm_register on the same inputs.  trace: NULL or count*ELM_MAX_ITER_TRACE entries. */
+ * elm_register_batch / elm_register on the same inputs (which slot serves a registration may vary from call to call on one
+ * rank -- the solve kernel hands out the queue positions -- but a registration's arithmetic does not depend on its slot; with a
+ * communicator attached the assignment is in slot order, identical on every rank).  trace: NULL or count*ELM_MAX_ITER_TRACE
+ * entries. */
 int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* const* scans, int count, const double* T0,
                         const elm_reg_config* cfg, int slots, elm_reg_result* results, elm_iter_trace* trace);
 /* Asynchronous halves of the above: enqueue everything on the context stream / wait and fetch results.  enqueue returns
