@@ -224,7 +224,9 @@ def main():
     info = vm.info()
     grid = int(info.nbr_entries) == int(info.n_points)  # the dense cell grid holds every map point once (the lists: 27 times)
     bytes_unit = kernel_bytes_model(int(method), tested, V, C if int(method) == 3 else 0.0, grid)
-    kernel_name = (f"k_accumulate_vnbr<{METHOD_NAMES[int(method)]}>" if int(method) in (2, 3) else
+    forced = os.environ.get("ELM_KERNEL", "")  # developer switch: "direct" = the plain 27-probe walk for every method
+    kernel_name = (f"k_accumulate_direct<{METHOD_NAMES[int(method)]}>" if forced == "direct" else
+                   f"k_accumulate_vnbr<{METHOD_NAMES[int(method)]}>" if int(method) in (2, 3) else
                    f"k_accumulate_{'grid' if grid else 'cell'}<{METHOD_NAMES[int(method)]}>")
     # dominant kernel: k_accumulate. Units one launch processes ON THIS GPU = its shard of the batch's live points.
     launches = max(prof["accumulate_launches"], 1)
