@@ -252,7 +252,7 @@ def main():
                 traffic = pm.get("hbm_bytes_per_unit") * units_per_launch
                 traffic_src = (f"profiles/pmc_latest.json[{kernel_name}]: HBM bytes/unit of separate rocprofv3 --pmc passes of this command "
                                f"({pm.get('source', 'see profiles/README.md')}) x this run's units per launch; counters cannot be read in the timed run")
-                pmc_extra = {k: pm[k] for k in ("valu_busy", "l2_hit", "valu_insts_per_wave", "waves_per_simd") if k in pm}
+                pmc_extra = {k: pm[k] for k in ("valu_busy", "ta_busy", "l1_line_accesses_per_cu_cycle", "l1_hit", "l2_hit", "valu_insts_per_wave", "waves_per_simd") if k in pm}
         except Exception:  # noqa: BLE001
             traffic = None
     measured_gbs = (traffic / sec / 1e9) if (traffic and sec > 0) else None

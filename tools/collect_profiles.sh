@@ -13,5 +13,6 @@ timeout 240 rocprofv3 --kernel-trace --stats -d $OUT/trace -o b -- python $R/ben
 timeout 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o b -- python $R/bench.py $ARGS > /dev/null 2> $OUT/pmc_fetch.err
 timeout 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_write -o b -- python $R/bench.py $ARGS > /dev/null 2> $OUT/pmc_write.err
 timeout 240 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_sq -o b -- python $R/bench.py $ARGS > /dev/null 2> $OUT/pmc_sq.err
+timeout 240 rocprofv3 --kernel-trace --pmc TA_TA_BUSY_sum TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE -d $OUT/pmc_ta -o b -- python $R/bench.py $ARGS > /dev/null 2> $OUT/pmc_ta.err
 python $R/bench.py ${BENCH_ARGS:-} > $OUT/bench.json 2> $OUT/bench.err
 python $R/tools/summarise_profiles.py $OUT

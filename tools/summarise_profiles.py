@@ -21,7 +21,7 @@ if c:
         for r in rows:
             f.write(f"\"{r[0]}\",{r[1]},{r[2]},{r[3]:.1f},{r[4]},{r[5]},{100.0 * r[2] / tot:.2f}\n")
 pmc = {}
-for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
+for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_ta"):
     c = db(name)
     if not c:
         continue
@@ -53,6 +53,11 @@ try:
                 cyc = v["GRBM_GUI_ACTIVE"]["avg"] / 8.0  # summed over the 8 XCDs
                 summary["valu_busy"] = 4.0 * v["SQ_ACTIVE_INST_VALU"]["avg"] / (1024.0 * cyc)  # 4 cycles per wave64 instruction, 1024 SIMDs
                 summary["valu_insts_per_wave"] = v["SQ_INSTS_VALU"]["avg"] / v["SQ_WAVES"]["avg"]
+            if "TA_TA_BUSY_sum" in v and "GRBM_GUI_ACTIVE" in v:
+                cyc = v["GRBM_GUI_ACTIVE"]["avg"] / 8.0
+                summary["ta_busy"] = v["TA_TA_BUSY_sum"]["avg"] / 256.0 / cyc  # 256 CUs
+                summary["l1_line_accesses_per_cu_cycle"] = v["TCP_TOTAL_CACHE_ACCESSES_sum"]["avg"] / 256.0 / cyc
+                summary["l1_hit"] = 1.0 - v["TCP_TCC_READ_REQ_sum"]["avg"] / max(v["TCP_TOTAL_CACHE_ACCESSES_sum"]["avg"], 1.0)
             if "TCC_HIT_sum" in v:
                 summary["l2_hit"] = v["TCC_HIT_sum"]["avg"] / (v["TCC_HIT_sum"]["avg"] + v["TCC_MISS_sum"]["avg"])
 except Exception as e:  # noqa: BLE001
