@@ -294,6 +294,7 @@ struct elm_map {
     uint32_t* d_vq_dense = nullptr;
     uint32_t* d_vqf_dense = nullptr;
     VoxRec* d_vnbr = nullptr;
+    GridBlk* d_vnbr_blk = nullptr;
     VoxRec* d_vface = nullptr;
     GridBlk* d_grid_blk = nullptr;    // dense cell grid (DevMap::grid_*), the default P2P / GICP search index
     uint32_t* d_grid_idx = nullptr;
@@ -457,7 +458,7 @@ static void build_host(const float* xyz, size_t n, double voxel_size, int max_po
 static void map_free(elm_map* m) {
     if (!m) return;
     if (ctx_alive(m->ctx)) (void)hipSetDevice(m->ctx->device); // a context destroyed first: just release the device memory
-    void* ptrs[] = {m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_vox_cinv, m->d_pt_gicp, m->d_pt_cov, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off, m->d_vqslots, m->d_vq_dense, m->d_vqf_dense, m->d_vface, m->d_vnbr,
+    void* ptrs[] = {m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_vox_cinv, m->d_pt_gicp, m->d_pt_cov, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off, m->d_vqslots, m->d_vq_dense, m->d_vqf_dense, m->d_vface, m->d_vnbr, m->d_vnbr_blk,
                     m->d_grid_blk, m->d_grid_idx, m->d_grid_start, m->d_vox_stat, m->d_grid_gicp};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -648,13 +649,23 @@ static int build_voxel_neighbourhoods(elm_map* m) {
         VN_CHK(hipGetLastError());
         VN_CHK(hipStreamSynchronize(ctx->stream));
         VN_CHK(hipMemcpy(nocc.data(), d_nocc, (size_t)n_q * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        for (uint32_t q = 0; q < n_q; ++q) { offs[q] = (uint32_t)total; total += nocc[q]; }
+        for (uint32_t q = 0; q < n_q; ++q) { offs[q] = (uint32_t)total; total += (nocc[q] + 3u) & ~3u; } // list starts: multiples of four records
         VN_CHK(hipMemcpy(d_off, offs.data(), (size_t)n_q * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
+    if (total >= (1ull << 32)) { ctx->last_error = "voxel-mean lists exceed 2^32 records"; cleanup(); return ELM_ERR_UNSUPPORTED; }
     VN_CHK(hipMalloc((void**)&m->d_vnbr, std::max<size_t>((size_t)total * sizeof(VoxRec), 256)));
+    VN_CHK(hipMemsetAsync(m->d_vnbr, 0, std::max<size_t>((size_t)total * sizeof(VoxRec), 256), ctx->stream)); // the padding records are never read
+    {   // + one block of padding slots at the end: the target of the filter's loads past a list's last block
+        const size_t nb = (size_t)(total / 4) + 1;
+        VN_CHK(hipMalloc((void**)&m->d_vnbr_blk, nb * sizeof(GridBlk)));
+        std::vector<GridBlk> padblk(1);
+        for (int u = 0; u < 4; ++u) padblk[0].x[u] = padblk[0].y[u] = padblk[0].z[u] = 1e18f;
+        VN_CHK(hipMemcpy(m->d_vnbr_blk + (nb - 1), padblk.data(), sizeof(GridBlk), hipMemcpyHostToDevice));
+        m->dm.vnbr_pad_blk = (uint32_t)(nb - 1);
+    }
     if (n_q) {
         (void)hipGetLastError();
-        launch_vnbr_fill(ctx->stream, m->dm, d_qkeys, n_q, d_off, m->d_vnbr);
+        launch_vnbr_fill(ctx->stream, m->dm, d_qkeys, n_q, d_off, m->d_vnbr, m->d_vnbr_blk);
         VN_CHK(hipGetLastError());
         VN_CHK(hipStreamSynchronize(ctx->stream));
     }
@@ -674,7 +685,7 @@ static int build_voxel_neighbourhoods(elm_map* m) {
     }
     // the same table addressed directly by the dense box of floor keys (when the box fits the cell budget and the packed word
     // holds the offsets): the kernel then needs no hash probe -- one 4-byte load at a computed, spatially coherent address
-    if (n_q && total < (1ull << 27)) {
+    if (n_q && total / 4 < (1ull << 27)) {
         int32_t klo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, khi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
         for (uint32_t q = 0; q < n_q; ++q)
             for (int a = 0; a < 3; ++a) {
@@ -688,7 +699,7 @@ static int build_voxel_neighbourhoods(elm_map* m) {
             for (uint32_t q = 0; q < n_q; ++q) {
                 const uint64_t idx = ((uint64_t)(qkeys[3 * q] - klo[0]) * (uint64_t)vd[1] + (uint64_t)(qkeys[3 * q + 1] - klo[1])) * (uint64_t)vd[2] +
                                      (uint64_t)(qkeys[3 * q + 2] - klo[2]);
-                dense[idx] = (offs[q] << 5) | nocc[q]; // nocc <= 27
+                dense[idx] = ((offs[q] >> 2) << 5) | nocc[q]; // first block of four records, nocc <= 27
             }
             VN_CHK(hipMalloc((void**)&m->d_vq_dense, vcells * sizeof(uint32_t)));
             VN_CHK(hipMemcpy(m->d_vq_dense, dense.data(), vcells * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -745,8 +756,9 @@ static int build_voxel_neighbourhoods(elm_map* m) {
     m->dm.vqslots = m->d_vqslots;
     m->dm.vqmask = qcap - 1;
     m->dm.vnbr = m->d_vnbr;
+    m->dm.vnbr_blk = m->d_vnbr_blk;
     m->has_vnbr = true;
-    m->info.device_bytes += (size_t)total * sizeof(VoxRec) + (size_t)qcap * sizeof(HashSlot);
+    m->info.device_bytes += (size_t)total * sizeof(VoxRec) + ((size_t)(total / 4) + 1) * sizeof(GridBlk) + (size_t)qcap * sizeof(HashSlot);
     m->info.index_bytes += (size_t)total * sizeof(VoxRec) + (size_t)qcap * sizeof(HashSlot) + (size_t)m->dm.n_vox * 9 * sizeof(double);
     return ELM_OK;
 }

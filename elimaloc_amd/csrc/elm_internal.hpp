@@ -63,6 +63,9 @@ struct DevMap {
     uint32_t _pad2;
     const VoxRec* vnbr;
     const uint32_t* vq_dense; // optional: the same (start << 5 | cnt) addressed by the dense floor-key box (vq_x0.., no hash probe)
+    const GridBlk* vnbr_blk;    // the lists' means once more as float32 blocks of four (the filter of the VGICP walk): list q starts at block
+                                // start(q) / 4 (list starts are multiples of four records), padding slots 1e18
+    uint32_t vnbr_pad_blk;      // index of the all-padding block at the end of vnbr_blk
     const VoxRec* vface;        // optional (with vq_dense): the FACE neighbours (+ the voxel itself) of every query voxel, in list order --
                                 // what AVGICP pairs with (vhm.cpp:153-206) -- and
     const uint32_t* vqf_dense;  // (start << 3 | count) of those, addressed like vq_dense
@@ -176,7 +179,7 @@ void launch_solve(hipStream_t s, const ScanDesc* scans, int batch, ScanState* st
 void launch_nbr_count(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, uint32_t* counts, uint32_t* nocc);
 void launch_accumulate_vnbr(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                             ScanState* st, double* partials, const RegParams& rp);
-void launch_vnbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets, VoxRec* out);
+void launch_vnbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets, VoxRec* out, GridBlk* out_blk);
 // face-neighbour sublists of the voxel-mean lists: counts (out == nullptr) or the records at face_off
 void launch_vface(hipStream_t s, const VoxRec* vnbr, const uint32_t* offsets, const uint32_t* counts, uint32_t n_q, uint32_t* face_cnt,
                   const uint32_t* face_off, VoxRec* out);

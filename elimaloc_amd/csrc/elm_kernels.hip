@@ -1642,6 +1642,9 @@ __global__ __launch_bounds__(64) void k_nbr_cellsort(const DevMap m, const int32
 #ifndef ELM_AVG_RECS
 #define ELM_AVG_RECS 1 // AVGICP: records per round trip (each brings a 72-byte inverse covariance along): 1 -> 78 VGPRs, 50.5k registrations/s; 2 -> 106, 43.2k; 3 -> 130, 42.0k
 #endif
+#ifndef ELM_VNBR_BLKS
+#define ELM_VNBR_BLKS 2 // VGICP filter: float32 blocks of four means per round trip
+#endif
 #ifndef ELM_VNBR_WAVES
 #define ELM_VNBR_WAVES 1
 #endif
@@ -1677,7 +1680,7 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
                     start = w >> 3; cnt = w & 7u;
                 } else {
                     const unsigned w = m.vq_dense[vidx];
-                    start = w >> 5; cnt = w & 31u;
+                    start = (w >> 5) << 2; cnt = w & 31u; // lists start at multiples of four records
                 }
             }
         } else {
@@ -1700,22 +1703,61 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
             double bd2 = DBL_MAX, bmx = 0.0, bmy = 0.0, bmz = 0.0;
             int bvid = -1;
             unsigned bj = 0;
-            for (unsigned j = 0; j < cnt; j += ELM_VNBR_RECS) { // ELM_VNBR_RECS records (two 16-byte loads each) per round trip
-                VoxRec r[ELM_VNBR_RECS];
+            // float32 filter over the means (blocks of four, three 16-byte loads each instead of eight for the float64 records):
+            // a winner that is clear of the runner-up by the rounding of the stored means and of the arithmetic is the strict
+            // float64 minimum as well; its float64 record is read afterwards.  Near ties (practically never) take the float64 walk.
+            bool exact = cnt != 0u;
+            if (cnt != 0u && m.vnbr_blk) {
+                const unsigned nblk = (cnt + 3u) >> 2, blk0 = start >> 2;
+                const float ghx = (float)gx, ghy = (float)gy, ghz = (float)gz;
+                const float glx = (float)(gx - (double)ghx), gly = (float)(gy - (double)ghy), glz = (float)(gz - (double)ghz);
+                const f32x2 gxy = {ghx, ghy}, gzl = {ghz, glx}, gl2 = {gly, glz};
+                unsigned m1 = 0x7F800000u, m2 = 0x7F800000u, jb = 0u;
+                for (unsigned b0 = 0; b0 < nblk; b0 += ELM_VNBR_BLKS) {
+                    GridBlk B[ELM_VNBR_BLKS];
 #pragma unroll
-                for (int u = 0; u < ELM_VNBR_RECS; ++u) r[u] = lp[min(j + u, cnt - 1)]; // past the end: the last record again (never < itself)
+                    for (int u = 0; u < ELM_VNBR_BLKS; ++u) B[u] = m.vnbr_blk[(b0 + u < nblk) ? blk0 + b0 + u : m.vnbr_pad_blk];
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < ELM_VNBR_RECS; ++u) {
-                    const double ex = r[u].mx - gx, ey = r[u].my - gy, ez = r[u].mz - gz;
-                    const double d2 = (ex * ex + ey * ey) + ez * ez;
-                    const bool c = d2 < bd2; // strict: the first met keeps a tie (vhm.cpp:128)
-                    bj = c ? j + u : bj;
-                    bd2 = c ? d2 : bd2;
+                    for (int u = 0; u < ELM_VNBR_BLKS; ++u) {
+                        f32x2 da, db;
+                        blk_dist(B[u], gxy, gzl, gl2, da, db);
+                        const unsigned was = m1;
+                        two_smallest(da.x, 0u, m1, m2);
+                        two_smallest(da.y, 1u, m1, m2);
+                        two_smallest(db.x, 2u, m1, m2);
+                        two_smallest(db.y, 3u, m1, m2);
+                        jb = (m1 != was) ? b0 + (unsigned)u : jb;
+                    }
+                }
+                // |float32(mean) - mean| <= 2^-24 |mean|_1 <= 6.5e-8 (|g|_1 + 6 voxel sizes); float32 arithmetic + key bits: 2^-18
+                const float em = 6.5e-8f * (fabsf(ghx) + fabsf(ghy) + fabsf(ghz) + 6.0f * (float)m.voxel_size);
+                const float s1 = __builtin_sqrtf(__uint_as_float(m1 & ~3u)), s2 = __builtin_sqrtf(__uint_as_float(m2 & ~3u));
+                if (s2 - s2 * 3.814697265625e-06f - em > s1 + s1 * 3.814697265625e-06f + em) {
+                    bj = jb * 4u + (m1 & 3u);
+                    exact = false;
                 }
             }
-            if (cnt) { // the winner's record again (an L1 hit) instead of five registers carried through the loop
+            if (exact) {
+                for (unsigned j = 0; j < cnt; j += ELM_VNBR_RECS) { // ELM_VNBR_RECS records (two 16-byte loads each) per round trip
+                    VoxRec r[ELM_VNBR_RECS];
+#pragma unroll
+                    for (int u = 0; u < ELM_VNBR_RECS; ++u) r[u] = lp[min(j + u, cnt - 1)]; // past the end: the last record again (never < itself)
+#pragma unroll
+                    for (int u = 0; u < ELM_VNBR_RECS; ++u) {
+                        const double ex = r[u].mx - gx, ey = r[u].my - gy, ez = r[u].mz - gz;
+                        const double d2 = (ex * ex + ey * ey) + ez * ez;
+                        const bool c = d2 < bd2; // strict: the first met keeps a tie (vhm.cpp:128)
+                        bj = c ? j + u : bj;
+                        bd2 = c ? d2 : bd2;
+                    }
+                }
+            }
+            if (cnt) { // the winner's float64 record (after the float64 walk: an L1 hit instead of five registers carried through it)
                 const VoxRec w = lp[min(bj, cnt - 1)];
                 bvid = w.vid; bmx = w.mx; bmy = w.my; bmz = w.mz;
+                const double ex = w.mx - gx, ey = w.my - gy, ez = w.mz - gz;
+                bd2 = (ex * ex + ey * ey) + ez * ez; // the walk's own arithmetic for this record
             }
             // finish_voxel_pair: no voxel at all -> the reference's default VoxelStruct at the origin with covariance I (QUIRK)
             const double dfin = (bvid >= 0) ? bd2 : (gx * gx + gy * gy) + gz * gz;
@@ -1782,11 +1824,13 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
 }
 
 __global__ __launch_bounds__(256) void k_vnbr_fill(const DevMap m, const int32_t* __restrict__ qkeys, unsigned n_q,
-                                                   const unsigned* __restrict__ offsets, VoxRec* __restrict__ out) {
+                                                   const unsigned* __restrict__ offsets, VoxRec* __restrict__ out,
+                                                   GridBlk* __restrict__ out_blk) {
     const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n_q) return;
     const int vx = qkeys[3 * q], vy = qkeys[3 * q + 1], vz = qkeys[3 * q + 2];
-    unsigned o = offsets[q];
+    unsigned o = offsets[q]; // a multiple of four
+    const unsigned o0 = o;
     for (int dx = -1; dx <= 1; ++dx)
         for (int dy = -1; dy <= 1; ++dy)
             for (int dz = -1; dz <= 1; ++dz) {
@@ -1796,8 +1840,17 @@ __global__ __launch_bounds__(256) void k_vnbr_fill(const DevMap m, const int32_t
                 r.mx = m.vox_mean[(size_t)pr.vid * 3]; r.my = m.vox_mean[(size_t)pr.vid * 3 + 1]; r.mz = m.vox_mean[(size_t)pr.vid * 3 + 2];
                 r.vid = pr.vid;
                 r.pad = ((dx + 1) * 3 + (dy + 1)) * 3 + (dz + 1); // position code of this neighbour (AVGICP picks the face ones)
+                if (out_blk) { // the float32 filter copy: slot o % 4 of block o / 4
+                    GridBlk& B = out_blk[o >> 2];
+                    B.x[o & 3u] = (float)r.mx; B.y[o & 3u] = (float)r.my; B.z[o & 3u] = (float)r.mz;
+                }
                 out[o++] = r;
             }
+    if (out_blk)
+        for (; ((o - o0) & 3u) != 0u; ++o) { // padding slots of the last block: never the nearest
+            GridBlk& B = out_blk[o >> 2];
+            B.x[o & 3u] = 1e18f; B.y[o & 3u] = 1e18f; B.z[o & 3u] = 1e18f;
+        }
 }
 
 // map build: size and content of the neighbourhood list of every query voxel (init time)
@@ -2477,8 +2530,8 @@ void launch_vface(hipStream_t s, const VoxRec* vnbr, const uint32_t* offsets, co
                   const uint32_t* face_off, VoxRec* out) {
     if (n_q) hipLaunchKernelGGL(k_vface, dim3((n_q + 255) / 256), dim3(256), 0, s, vnbr, offsets, counts, n_q, face_cnt, face_off, out);
 }
-void launch_vnbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets, VoxRec* out) {
-    hipLaunchKernelGGL(k_vnbr_fill, dim3((n_q + 255) / 256), dim3(256), 0, s, m, qkeys, n_q, offsets, out);
+void launch_vnbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets, VoxRec* out, GridBlk* out_blk) {
+    hipLaunchKernelGGL(k_vnbr_fill, dim3((n_q + 255) / 256), dim3(256), 0, s, m, qkeys, n_q, offsets, out, out_blk);
 }
 void launch_nbr_cellsort(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets,
                          const uint32_t* counts, Pt3* pts, uint32_t* idx, uint16_t* cell_off) {
