@@ -1643,7 +1643,7 @@ __global__ __launch_bounds__(64) void k_nbr_cellsort(const DevMap m, const int32
 #define ELM_AVG_RECS 1 // AVGICP: records per round trip (each brings a 72-byte inverse covariance along): 1 -> 78 VGPRs, 50.5k registrations/s; 2 -> 106, 43.2k; 3 -> 130, 42.0k
 #endif
 #ifndef ELM_VNBR_BLKS
-#define ELM_VNBR_BLKS 2 // VGICP filter: float32 blocks of four means per round trip
+#define ELM_VNBR_BLKS 1 // VGICP filter: float32 blocks of four means per round trip (1 / 2 / 3: 123.4 / 121.0 / 120.5 k registrations/s)
 #endif
 #ifndef ELM_VNBR_WAVES
 #define ELM_VNBR_WAVES 1
