@@ -74,6 +74,33 @@ __device__ __forceinline__ double wave_sum(double v) {
 // upper-triangle packing of the symmetric 6x6: idx(i,j), i <= j
 __host__ __device__ constexpr int tri(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
 
+// sqrt of a squared distance (0 or a normal number well inside the exponent range): the core of the compiler's own expansion
+// (v_rsq_f64 + the same seven fused steps) without its scaling / class handling for denormals, infinities and NaNs
+__device__ __forceinline__ double sqrt_dist2(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    double d = __builtin_fma(-g, g, x);
+    h = __builtin_fma(h, r, h);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return (x > 0.0) ? g : 0.0;
+}
+// a / b for normal b well inside the exponent range: reciprocal + two Newton steps + the final residual correction (the compiler's
+// expansion without v_div_scale / v_div_fixup)
+__device__ __forceinline__ double div_normal(double a, double b) {
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    const double q = a * y;
+    const double r = __builtin_fma(-b, q, a);
+    return __builtin_fma(r, y, q);
+}
+
 // Adds one (source point, target) pair to the thread's packed sums.
 //   acc[0..20] upper JTJ, acc[21..26] JTr, acc[27] residual sum, acc[28] pair count
 // p = source point in the sensor frame, (mx,my,mz) = target position in the world frame,
@@ -234,7 +261,7 @@ __device__ __forceinline__ void avg_pair_init(AvgPairSum& P) {
 __device__ __forceinline__ void avg_pair_add(AvgPairSum& P, double ex, double ey, double ez, const double* __restrict__ Cinv, const RegParams& rp) {
     const double r2 = (ex * ex + ey * ey) + ez * ez;
     const double den = rp.th + r2;
-    const double w = rp.th2 / (den * den); // square(th) / square(th + |r|^2)
+    const double w = div_normal(rp.th2, den * den); // square(th) / square(th + |r|^2)
     P.n += 1.0;
     if (w < 0.01) return; // reg.cpp:201 -- skipped pairs stay in the fitness denominator
     double A[9];
@@ -246,7 +273,7 @@ __device__ __forceinline__ void avg_pair_add(AvgPairSum& P, double ex, double ey
     P.b[0] += (A[0] * ex + A[1] * ey) + A[2] * ez;
     P.b[1] += (A[3] * ex + A[4] * ey) + A[5] * ez;
     P.b[2] += (A[6] * ex + A[7] * ey) + A[8] * ez;
-    P.rsum += sqrt(r2);
+    P.rsum += sqrt_dist2(r2);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -620,7 +647,7 @@ template <int METHOD>
 __device__ __forceinline__ void pair_sum_single(PairSum& P, double ex, double ey, double ez, const double* Cinv, const double* nfit, const RegParams& rp) {
     const double r2 = (ex * ex + ey * ey) + ez * ez;
     const double den = rp.th + r2;
-    double w = rp.th2 / (den * den); // square(th) / square(th + |r|^2)
+    double w = div_normal(rp.th2, den * den); // square(th) / square(th + |r|^2)
     if (METHOD == ELM_GICP) w = w * 0.8 + 0.2;
     P.n = 1.0;
     if (METHOD == ELM_VGICP || METHOD == ELM_AVGICP) {
@@ -632,7 +659,7 @@ __device__ __forceinline__ void pair_sum_single(PairSum& P, double ex, double ey
     P.b[1] = (P.A[3] * ex + P.A[4] * ey) + P.A[5] * ez;
     P.b[2] = (P.A[6] * ex + P.A[7] * ey) + P.A[8] * ez;
     if (METHOD == ELM_GICP) P.rsum = fabs((ex * nfit[0] + ey * nfit[1]) + ez * nfit[2]);
-    else P.rsum = sqrt(r2);
+    else P.rsum = sqrt_dist2(r2);
 }
 
 // ---- P2P pair in 18 sums ---------------------------------------------------------------------------------------------
@@ -641,32 +668,6 @@ __device__ __forceinline__ void pair_sum_single(PairSum& P, double ex, double ey
 // with r = R^-1 (q - g): the reference's T^-1 q - p written on the world-frame residual e = q - g the search already holds
 // (equal up to the rounding of an orthonormal R, ~1e-16 relative; |r|^2 = |e|^2 = the search's float64 distance).
 constexpr int kP2PVals = 21; // 18 sums + the three work counters
-// sqrt of a squared distance (0 or a normal number well inside the exponent range): the core of the compiler's own expansion
-// (v_rsq_f64 + the same seven fused steps) without its scaling / class handling for denormals, infinities and NaNs
-__device__ __forceinline__ double sqrt_dist2(double x) {
-    const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y, h = y * 0.5;
-    double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    double d = __builtin_fma(-g, g, x);
-    h = __builtin_fma(h, r, h);
-    g = __builtin_fma(d, h, g);
-    d = __builtin_fma(-g, g, x);
-    g = __builtin_fma(d, h, g);
-    return (x > 0.0) ? g : 0.0;
-}
-// a / b for normal b well inside the exponent range: reciprocal + two Newton steps + the final residual correction (the compiler's
-// expansion without v_div_scale / v_div_fixup)
-__device__ __forceinline__ double div_normal(double a, double b) {
-    double y = __builtin_amdgcn_rcp(b);
-    double e = __builtin_fma(-b, y, 1.0);
-    y = __builtin_fma(y, e, y);
-    e = __builtin_fma(-b, y, 1.0);
-    y = __builtin_fma(y, e, y);
-    const double q = a * y;
-    const double r = __builtin_fma(-b, q, a);
-    return __builtin_fma(r, y, q);
-}
 __device__ __forceinline__ void pair_p2p(double* v, const double* Rinv, double px, double py, double pz, double ex, double ey, double ez,
                                          double d2, const RegParams& rp) {
     const double rx = (Rinv[0] * ex + Rinv[1] * ey) + Rinv[2] * ez;
