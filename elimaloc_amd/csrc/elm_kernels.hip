@@ -1150,6 +1150,15 @@ __device__ __forceinline__ void blk_dist(const GridBlk& B, f32x2 gxy, f32x2 gzl,
     d01 = __builtin_elementwise_fma(ez01, ez01, __builtin_elementwise_fma(ey01, ey01, ex01 * ex01));
     d23 = __builtin_elementwise_fma(ez23, ez23, __builtin_elementwise_fma(ey23, ey23, ex23 * ex23));
 }
+// the same on gh = float32(g) alone (gzz = (ghz, -)): six subtractions fewer; |g - gh| then has to be part of the caller's margin
+__device__ __forceinline__ void blk_dist_h(const GridBlk& B, f32x2 gxy, f32x2 gzz, f32x2& d01, f32x2& d23) {
+    const f32x2 x01 = {B.x[0], B.x[1]}, x23 = {B.x[2], B.x[3]}, y01 = {B.y[0], B.y[1]}, y23 = {B.y[2], B.y[3]}, z01 = {B.z[0], B.z[1]}, z23 = {B.z[2], B.z[3]};
+    const f32x2 ex01 = pk_sub_lo(x01, gxy), ex23 = pk_sub_lo(x23, gxy);
+    const f32x2 ey01 = pk_sub_hi(y01, gxy), ey23 = pk_sub_hi(y23, gxy);
+    const f32x2 ez01 = pk_sub_lo(z01, gzz), ez23 = pk_sub_lo(z23, gzz);
+    d01 = __builtin_elementwise_fma(ez01, ez01, __builtin_elementwise_fma(ey01, ey01, ex01 * ex01));
+    d23 = __builtin_elementwise_fma(ez23, ez23, __builtin_elementwise_fma(ey23, ey23, ex23 * ex23));
+}
 // (m1, m2) = the two smallest candidate keys seen so far (m1 <= m2): one new distance from slot u of its block.  A key is the
 // distance's bit pattern (non-negative floats order like unsigned integers) with the two lowest mantissa bits replaced by the
 // slot, so the winner's slot rides along for free: and_or + med3 + min per candidate
@@ -1710,9 +1719,10 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
             bool exact = cnt != 0u;
             if (cnt != 0u && m.vnbr_blk) {
                 const unsigned nblk = (cnt + 3u) >> 2, blk0 = start >> 2;
+                // distances to gh = float32(g): |g - gh| joins the stored means' rounding in the margin of the decision
                 const float ghx = (float)gx, ghy = (float)gy, ghz = (float)gz;
-                const float glx = (float)(gx - (double)ghx), gly = (float)(gy - (double)ghy), glz = (float)(gz - (double)ghz);
-                const f32x2 gxy = {ghx, ghy}, gzl = {ghz, glx}, gl2 = {gly, glz};
+                const float eg = (fabsf((float)(gx - (double)ghx)) + fabsf((float)(gy - (double)ghy)) + fabsf((float)(gz - (double)ghz))) * 1.000001f;
+                const f32x2 gxy = {ghx, ghy}, gzz = {ghz, 0.f};
                 unsigned m1 = 0x7F800000u, m2 = 0x7F800000u, jb = 0u;
                 for (unsigned b0 = 0; b0 < nblk; b0 += ELM_VNBR_BLKS) {
                     GridBlk B[ELM_VNBR_BLKS];
@@ -1722,7 +1732,7 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
 #pragma unroll
                     for (int u = 0; u < ELM_VNBR_BLKS; ++u) {
                         f32x2 da, db;
-                        blk_dist(B[u], gxy, gzl, gl2, da, db);
+                        blk_dist_h(B[u], gxy, gzz, da, db);
                         const unsigned was = m1;
                         two_smallest(da.x, 0u, m1, m2);
                         two_smallest(da.y, 1u, m1, m2);
@@ -1732,7 +1742,7 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
                     }
                 }
                 // |float32(mean) - mean| <= 2^-24 |mean|_1 <= 6.5e-8 (|g|_1 + 6 voxel sizes); float32 arithmetic + key bits: 2^-18
-                const float em = 6.5e-8f * (fabsf(ghx) + fabsf(ghy) + fabsf(ghz) + 6.0f * (float)m.voxel_size);
+                const float em = 6.5e-8f * (fabsf(ghx) + fabsf(ghy) + fabsf(ghz) + 6.0f * (float)m.voxel_size) + eg;
                 const float s1 = __builtin_sqrtf(__uint_as_float(m1 & ~3u)), s2 = __builtin_sqrtf(__uint_as_float(m2 & ~3u));
                 if (s2 - s2 * 3.814697265625e-06f - em > s1 + s1 * 3.814697265625e-06f + em) {
                     bj = jb * 4u + (m1 & 3u);
