@@ -1267,18 +1267,21 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
         // compiler waits for the offsets first and does this arithmetic on the critical path -- 7 % of the kernel)
         float rr = (rho_u < 1e30f) ? (rho_u * (float)h - 1.1e-6f) * 0.999998f : 1e18f;
         float rr2 = (rr > 0.f) ? rr * rr * 0.999999f : -1.f;
-        // float32 filter: g = gh + gl (float32 each, gh + gl == g to ~2^-48), so (q - gh) - gl reproduces q - g to a few float32
-        // ulps of |q - g| and the float32 distance is within 2^-20 relative (+ slack / 2) of the reference's float64 one
+        // float32 filter on gh = float32(g): a float32 distance to gh is within 2^-20 relative of the exact one, and exact distances
+        // to gh and to g differ by at most eg = |g - gh|_1.  Everything the decision compares lies below rr (a winner at rr or
+        // beyond is undecided anyway), so (sqrt(d) + eg)^2 <= d + egrr with egrr = 2 eg rr + eg^2: margins without a root.
         float ghx = (float)gx, ghy = (float)gy, ghz = (float)gz;
-        float glx = (float)(gx - (double)ghx), gly = (float)(gy - (double)ghy), glz = (float)(gz - (double)ghz);
-        float slack = 4e-11f * (fabsf(ghx) + fabsf(ghy) + fabsf(ghz) + 1.0f);
+        const float eg = (fabsf((float)(gx - (double)ghx)) + fabsf((float)(gy - (double)ghy)) + fabsf((float)(gz - (double)ghz))) * 1.000001f;
+        float egrr = (2.0f * eg * fmaxf(rr, 0.f) + eg * eg) * 1.000001f;
+        // for the ball of an undecided point: any block candidate is within 3.5 h of g
+        float egblk = (7.0f * eg * (float)h + eg * eg) * 1.000001f;
         // the columns are visited nearest first -- own, the nearer of the x / y neighbour, the other, the diagonal one -- and a lane
         // stops at the first column that lies farther than its current winner: lower bounds of the squared distance to the three
         // neighbour columns (1e-6 m off each face distance for the float32 cell coordinate)
         const float ex_ = fmaxf(dxo * (float)h - 1e-6f, 0.f), ey_ = fmaxf(dyo * (float)h - 1e-6f, 0.f);
         const float Bx = fminf(ex_ * ex_, 1e36f), By = fminf(ey_ * ey_, 1e36f);
         float L1 = fminf(Bx, By), L2 = fmaxf(Bx, By), L3 = (Bx + By) * 0.999999f;
-        asm volatile("" : "+v"(rr2), "+v"(ghx), "+v"(ghy), "+v"(ghz), "+v"(glx), "+v"(gly), "+v"(glz), "+v"(slack), "+v"(L1), "+v"(L2), "+v"(L3));
+        asm volatile("" : "+v"(rr2), "+v"(ghx), "+v"(ghy), "+v"(ghz), "+v"(egrr), "+v"(egblk), "+v"(L1), "+v"(L2), "+v"(L3));
         pf.w = __uint_as_float(stat);
         *stash() = pf;
         {
@@ -1306,7 +1309,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
         }
         {
             int nblk = cb[4];
-            const f32x2 gxy = {ghx, ghy}, gzl = {ghz, glx}, gl2 = {gly, glz};
+            const f32x2 gxy = {ghx, ghy}, gzz = {ghz, 0.f};
             unsigned m1 = 0x7F800000u, m2 = 0x7F800000u; // +inf
             unsigned jb = 0;                             // byte offset of m1's block (block 0 = padding = none yet)
             for (int t0 = 0; t0 < nblk; t0 += ELM_BLOCKS_PER_TRIP) { // ELM_BLOCKS_PER_TRIP blocks (three 16-byte loads each) per round trip
@@ -1327,7 +1330,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
 #pragma unroll
                 for (int w = 0; w < ELM_BLOCKS_PER_TRIP; ++w) {
                     f32x2 da, db;
-                    blk_dist(B[w], gxy, gzl, gl2, da, db);
+                    blk_dist_h(B[w], gxy, gzz, da, db);
                     const unsigned was = m1;
                     two_smallest(da.x, 0u, m1, m2);
                     two_smallest(da.y, 1u, m1, m2);
@@ -1338,7 +1341,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
                 // the first column that lies beyond the current winner (2^-17 relative: outside the margins of the decision below)
                 // ends this lane's sequence: it and the columns after it cannot win or tie
                 const float dbest = __uint_as_float(m1 & ~3u);
-                const float best = (dbest + dbest * 7.62939453125e-06f + 2.0f * slack) * 1.000001f;
+                const float best = (dbest < rr2) ? (dbest + dbest * 7.62939453125e-06f + 2.0f * egrr) * 1.000001f : __builtin_inff();
                 nblk = (L1 > best) ? cb[1] : ((L2 > best) ? cb[2] : ((L3 > best) ? cb[3] : nblk));
             }
             n_tested = 4 * nblk;
@@ -1347,9 +1350,9 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
                 // the keys drop two mantissa bits (< 3.6e-7 relative, downwards) on top of the float32 distance's 2^-20: 2^-18 covers
                 // both sides of the comparison
                 const float d1 = __uint_as_float(m1 & ~3u), d2 = __uint_as_float(m2 & ~3u);
-                const float r2 = d1 + d1 * 3.814697265625e-06f + slack; // 2^-18
-                hr2 = r2;
-                if (d2 > r2 && r2 < rr2) {
+                const float r2 = d1 + d1 * 3.814697265625e-06f + egrr; // >= the winner's exact squared distance when it lies below rr
+                hr2 = d1 + d1 * 3.814697265625e-06f + egblk;           // the same bound for any block candidate: stage 2's ball
+                if (d2 - d2 * 3.814697265625e-06f > r2 + egrr && r2 < rr2) {
                     bj = (int)(jb / (unsigned)sizeof(GridBlk)) * 4 + (int)(m1 & 3u);
                     hard = false;
                 }
