@@ -4,7 +4,10 @@
 Contract: `python bench.py --gpus N --steps K --warmup W` (N>1: launched by torch.distributed.run, one rank per GPU).
 One STEP = one pass of the hot path over one batch of synthetic input: `--batch` (per GPU) full RunRegister-equivalent
 registrations (initial transform -> iterate to the reference's own termination rule or max_iteration), all scans
-already resident in HBM when the timed region starts.
+already resident in HBM -- uploaded as packed float32 xyz and ordered ON THE DEVICE (k_scan_order) -- when the timed region
+starts.  What `value` does NOT time: the H2D upload and the ordering kernel of every scan.  The `host_fed` object (N = 1) times
+exactly that as well: every scan starts in (page-locked) HOST memory and is uploaded, ordered and registered inside the timed
+region (elm_register_stream_host), reported beside the PCIe rate it sits under.
 
 Workload (BASELINE.json configs[1]): P2P ICP, 131072-pt synthetic scans vs a 10M-pt voxel-hashed map, defaults of
 config/localization.ini.  N>1: every scan is sharded point-wise over the N GPUs (map replicated), ONE RCCL all-reduce
@@ -82,7 +85,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="registrations per GPU per step")
+    ap.add_argument("--batch", type=int, default=0, help="registrations per GPU per step (0 = 4096 on one GPU -- a timed region of ~1 s at 20 steps, "
+                    "five draining launches per ~110 -- and 1024 per GPU on several)")
+    ap.add_argument("--hostfed-batch", type=int, default=1024, help="registrations per step of the host-fed leg (N = 1; 0 = skip)")
+    ap.add_argument("--hostfed-steps", type=int, default=5)
     ap.add_argument("--slots", type=int, default=128, help="registrations iterating concurrently per GPU (continuous batching: "
                     "finished slots take the next pending registration on the device); 0 = lockstep batch of --batch")
     ap.add_argument("--scan-points", type=int, default=131072)
@@ -107,6 +113,8 @@ def main():
     import torch.distributed as dist
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.batch <= 0:
+        args.batch = 4096 if world_size == 1 else 1024
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # launched by torch.distributed.run (RANK set): take the collective path even for one rank, so that a 1-GPU box
@@ -122,7 +130,8 @@ def main():
         dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world_size)
 
     from elimaloc_amd import synth
-    from elimaloc_amd.registration import (Context, VoxelHashMap, Registration, RegistrationConfig, IcpMethod, Scan, results_from_raw)
+    from elimaloc_amd.registration import (Context, VoxelHashMap, Registration, RegistrationConfig, IcpMethod, Scan, PinnedBuffer,
+                                           results_from_raw)
 
     method = IcpMethod(args.method)
     ctx = Context(local_rank)
@@ -158,11 +167,19 @@ def main():
 
     synth.make_scan(world, 16, seed=1)  # builds the (cached) tile index of the world before the threads start
     scans_host, T_true, T0s, scans, digests, rmaxs = [], [], [], [], [], []
+    # host-fed leg (N = 1): the first `n_fed` scans once more in ONE page-locked buffer, back to back (what a driver's DMA ring holds)
+    n_fed = min(args.hostfed_batch, n_batch) if (world_size == 1 and extras and args.slots > 0) else 0
+    pin = PinnedBuffer(max(1, n_fed * args.scan_points * 3)) if n_fed else None
+    fed_sizes = []
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=16) as pool:  # numpy releases the GIL in the heavy parts; make_scan calls no BLAS
-        for full, Tt, T0, shard, n, dg, rmax in pool.map(gen, range(n_batch)):
+        for i, (full, Tt, T0, shard, n, dg, rmax) in enumerate(pool.map(gen, range(n_batch))):
             if full is not None:
                 scans_host.append(full)
+            if i < n_fed:
+                o = sum(fed_sizes) * 3
+                pin.array[o:o + shard.size] = shard.ravel()
+                fed_sizes.append(shard.shape[0])
             T_true.append(Tt)
             T0s.append(T0)
             scans.append(Scan(ctx, shard, n_total=n))
@@ -248,7 +265,7 @@ def main():
     if os.path.exists(pmc_path):
         try:
             pm = json.load(open(pmc_path)).get(kernel_name)
-            if pm and pm.get("batch") == args.batch and pm.get("scan_points") == args.scan_points:
+            if pm and pm.get("scan_points") == args.scan_points and args.map_points == 10_000_000 and args.guess == "easy":
                 traffic = pm.get("hbm_bytes_per_unit") * units_per_launch
                 traffic_src = (f"profiles/pmc_latest.json[{kernel_name}]: HBM bytes/unit of separate rocprofv3 --pmc passes of this command "
                                f"({pm.get('source', 'see profiles/README.md')}) x this run's units per launch; counters cannot be read in the timed run")
@@ -258,6 +275,65 @@ def main():
     measured_gbs = (traffic / sec / 1e9) if (traffic and sec > 0) else None
     # `achieved`: the measured HBM stream when a matching counter pass is committed, else the compulsory stream
     achieved_gbs = measured_gbs if measured_gbs is not None else compulsory_gbs
+
+    hbm = {
+        "achieved": achieved_gbs,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved_gbs / HBM_PEAK_GBS,
+        "achieved_is": "measured HBM traffic (committed counter pass: 2 x FETCH_SIZE + WRITE_SIZE -- an UPPER bound on DRAM bytes, FETCH_SIZE also "
+                       "counts Infinity-Cache hits; tools/probes/gather_probe calibrates the x2 for this gather pattern) / hipEvent launch time"
+                       if measured_gbs is not None else "compulsory HBM bytes / hipEvent launch time (no matching counter pass committed)",
+        "traffic": traffic,
+        "traffic_source": traffic_src,
+        "compulsory_bytes_per_unit": compulsory_unit,
+        "compulsory_gbs": compulsory_gbs,
+        "compulsory_frac": compulsory_gbs / HBM_PEAK_GBS,
+        # what the points ask the memory hierarchy for (L1 / L2 / Infinity Cache serve most of it: the index is cache-resident)
+        "requested_bytes_per_unit": bytes_unit,
+        "requested_gbs": requested_gbs,
+        "requested_over_hbm_peak": requested_gbs / HBM_PEAK_GBS,
+        "bytes_model": "requested: scan point + index words (cell offsets / hash slot + column records) + 12 B x tested candidate slots + "
+                       "winner (+ payload) + partial record; compulsory: scan point + partial record (+ GICP record) + the index once per "
+                       "launch; DESIGN.md section 4",
+        # the SURVEY 8(d) model of the REFERENCE's 27-voxel walk (all C candidates): a speed-up-vs-model figure, not a utilisation
+        "algorithmic_ref_bytes_per_unit": bytes_ref,
+        "algorithmic_ref_gbs": ref_gbs,
+        "algorithmic_ref_over_peak": ref_gbs / HBM_PEAK_GBS,
+    }
+    # The binding roof.  The committed SQ counter pass of this command says which unit the kernel keeps busiest: VALU issue
+    # (SQ_ACTIVE_INST_VALU x 4 cycles / SIMD cycles) for the grid and the VGICP kernels, the vector-memory front end (TA busy) for
+    # GICP / AVGICP; HBM carries a smaller share.  Without a matching pass the line falls back to the HBM stream.
+    clock_ghz = 2.4  # MI355X_MICROARCH.md: max clock
+    simd_cycles = 1024 * clock_ghz  # G SIMD-cycles/s over the chip (256 CUs x 4 SIMDs)
+    roofline = dict(hbm)
+    roofline["bound"] = "hbm"
+    if pmc_extra.get("valu_busy") is not None:
+        vb, tb = float(pmc_extra["valu_busy"]), float(pmc_extra.get("ta_busy", 0.0))
+        if vb >= tb and vb > hbm["frac"]:
+            roofline = {"bound": "valu_issue", "achieved": vb * simd_cycles, "peak": simd_cycles, "unit": "G SIMD-cycles/s (VALU-busy)", "frac": vb,
+                        "achieved_is": "SQ_ACTIVE_INST_VALU x 4 cycles per wave64 instruction / (1024 SIMDs x kernel cycles), committed rocprofv3 --pmc "
+                                       "pass of this command (profiles/); the launch time it belongs to is measured live below",
+                        "traffic": traffic}
+        elif tb > hbm["frac"]:
+            roofline = {"bound": "vector_memory_issue", "achieved": tb * 256 * clock_ghz, "peak": 256 * clock_ghz, "unit": "G CU-cycles/s (TA-busy)", "frac": tb,
+                        "achieved_is": "TA_TA_BUSY / (256 CUs x kernel cycles), committed rocprofv3 --pmc pass of this command (profiles/)",
+                        "traffic": traffic}
+        roofline["hbm"] = hbm
+    roofline.update({
+        "kernel": kernel_name,
+        "counters": pmc_extra,
+        "search_index": "dense cell grid" if grid else "neighbourhood lists",
+        "index_bytes": int(info.index_bytes),
+        "map_device_bytes": int(info.device_bytes),
+        "tested_candidates_per_point": tested,
+        "units_per_launch": units_per_launch,
+        "avg_launch_ms": acc_ms_avg,
+        "launches": prof["accumulate_launches"],
+        "accumulate_ms_per_step": prof["accumulate_ms"] / args.steps,
+        "solve_ms_per_step": prof["solve_ms"] / args.steps,
+        "timed_region_s": elapsed,
+    })
 
     result = {
         "metric": "ICP registrations/sec, 128k-pt scan vs 10M-pt map; pose err vs CPU ref",
@@ -300,42 +376,10 @@ def main():
                     "seeds 1001 / 2002+i / 3003+i; pooled generation verified against sequential generation",
             "max_abs_scan_m": max(rmaxs),
         },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": kernel_name,
-            "achieved": achieved_gbs,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved_gbs / HBM_PEAK_GBS,
-            "achieved_is": "measured HBM traffic (committed counter pass) / hipEvent launch time" if measured_gbs is not None else
-                           "compulsory HBM bytes / hipEvent launch time (no matching counter pass committed)",
-            "traffic": traffic,
-            "traffic_source": traffic_src,
-            "compulsory_bytes_per_unit": compulsory_unit,
-            "compulsory_gbs": compulsory_gbs,
-            "compulsory_frac": compulsory_gbs / HBM_PEAK_GBS,
-            # what the points ask the memory hierarchy for (L1 / L2 / Infinity Cache serve most of it: the index is cache-resident)
-            "requested_bytes_per_unit": bytes_unit,
-            "requested_gbs": requested_gbs,
-            "requested_over_hbm_peak": requested_gbs / HBM_PEAK_GBS,
-            "bytes_model": "requested: scan point + index words (cell offsets / hash slot + column records) + 12 B x tested candidate slots + "
-                           "winner (+ payload) + partial record; compulsory: scan point + partial record (+ GICP record) + the index once per "
-                           "launch; DESIGN.md section 4",
-            "counters": pmc_extra,
-            "search_index": "dense cell grid" if grid else "neighbourhood lists",
-            "index_bytes": int(info.index_bytes),
-            "map_device_bytes": int(info.device_bytes),
-            "tested_candidates_per_point": tested,
-            "units_per_launch": units_per_launch,
-            "avg_launch_ms": acc_ms_avg,
-            "launches": prof["accumulate_launches"],
-            "accumulate_ms_per_step": prof["accumulate_ms"] / args.steps,
-            "solve_ms_per_step": prof["solve_ms"] / args.steps,
-            # the SURVEY 8(d) model of the REFERENCE's 27-voxel walk (all C candidates): a speed-up-vs-model figure, not a utilisation
-            "algorithmic_ref_bytes_per_unit": bytes_ref,
-            "algorithmic_ref_gbs": ref_gbs,
-            "algorithmic_ref_over_peak": ref_gbs / HBM_PEAK_GBS,
-        },
+        "inputs_timed": "in `value`: every ICP iteration of every registration (correspondence search, accumulation, solve, slot refill) and the "
+                        "download of the results; NOT in `value`: the H2D upload and the device-side ordering of the scans (resident when the timed "
+                        "region starts).  `host_fed` times those too.",
+        "roofline": roofline,
     }
 
     # ---------------- extras outside the timed region ----------------
@@ -367,6 +411,43 @@ def main():
             "ms_per_call_median": 1e3 * float(np.median(tt)),
             "n_calls": k,
             "pose_equals_stream_to_1e-9": same,
+        }
+
+    if n_fed and rank == 0:
+        # The WHOLE registration inside the timed region: every scan starts in page-locked host memory, is uploaded (DMA, groups of
+        # ~32 MB on a copy stream), ordered on the device and registered -- elm_register_stream_host, RunRegister's per-call contract
+        # (reg.cpp:274-290) at stream rate.  Bit-identical to the resident stream.
+        ptrs = [pin.ptr + 12 * sum(fed_sizes[:i]) for i in range(n_fed)]
+        import ctypes as C
+        packed_f = ((C.c_void_p * n_fed)(*ptrs), (C.c_uint32 * n_fed)(*fed_sizes),
+                    np.ascontiguousarray(np.asarray(T0s[:n_fed], dtype=np.float64).reshape(-1, 4, 4).transpose(0, 2, 1)).reshape(-1), [pin])
+        fed = reg.RunRegisterStreamHost(packed_f, vm, slots=n_slots, raw=True)  # warm-up: staging sets, arena, side streams
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.hostfed_steps):
+            fed = reg.RunRegisterStreamHost(packed_f, vm, slots=n_slots, raw=True)
+        barrier()
+        tf_ = time.perf_counter() - t1
+        fed = results_from_raw(fed)
+        fed_bytes = 12.0 * float(sum(fed_sizes)) / n_fed
+        fed_rate = n_fed * args.hostfed_steps / tf_
+        h2d_gbs = ctx.measure_h2d(pin.ptr, int(12 * sum(fed_sizes[:min(n_fed, 64)])), reps=5)
+        result["host_fed"] = {
+            "what": "elm_register_stream_host: every scan in page-locked HOST memory when the timed region starts; H2D upload (packed float32 xyz, "
+                    "12 B/pt), device-side ordering (k_scan_order) and all ICP iterations inside the timed region, overlapped on three HIP streams",
+            "value": fed_rate,
+            "unit": "registrations/s",
+            "registrations_per_step": n_fed,
+            "steps": args.hostfed_steps,
+            "timed_region_s": tf_,
+            "bytes_per_registration": fed_bytes,
+            "pcie_achieved_gbs": fed_rate * fed_bytes / 1e9,
+            "pcie_h2d_probe_gbs": h2d_gbs,
+            "pcie_spec_gbs": 63.0,
+            "pcie_roof_registrations_per_s": h2d_gbs * 1e9 / fed_bytes,
+            "frac_of_pcie_probe": fed_rate * fed_bytes / 1e9 / h2d_gbs if h2d_gbs > 0 else None,
+            "bit_identical_to_resident": bool(all(np.array_equal(a["T"], b["T"]) and a["iterations"] == b["iterations"] for a, b in zip(fed, out))),
+            "max_abs_pose_diff_vs_resident": float(max(np.abs(a["T"] - b["T"]).max() for a, b in zip(fed, out))),
         }
 
     if extras and args.slots > 0 and args.guess == "easy":

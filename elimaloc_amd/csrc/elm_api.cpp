@@ -5,9 +5,12 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <map>
 #include <mutex>
+#include <new>
 #include <set>
 #include <string>
 #include <thread>
@@ -28,7 +31,8 @@ struct DevBuf {
 
 struct elm_scan {
     elm_ctx* ctx = nullptr;
-    float4* d_pts = nullptr;
+    uint64_t ctx_id = 0; // the owning context's unique id (a context allocated later at the same address is not the owner)
+    Pt3* d_pts = nullptr;
     size_t cap_bytes = 0;
     uint32_t n = 0, n_total = 0;
 };
@@ -79,7 +83,15 @@ static bool load_rccl(std::string* err) {
 
 struct elm_ctx {
     int device = 0;
+    uint64_t id = 0; // unique for the life of the process (children compare ids, not pointers)
     hipStream_t stream = nullptr;
+    // host-fed streams / ordered uploads: uploads (DMA) and the scan-ordering kernel run beside the iterations on the compute stream
+    hipStream_t copy_stream = nullptr, order_stream = nullptr, poll_stream = nullptr;
+    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_ordered[2] = {nullptr, nullptr}, ev_iter[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint16_t* d_hilbert = nullptr; // Hilbert index of every cell of the ordering grid (kOrderCells^2 entries)
+    DevBuf d_order_jobs, d_order_tmp, d_arena, d_raw;
+    void* h_jobs = nullptr; // pinned: ordering job descriptors
+    size_t h_jobs_cap = 0;
     std::string last_error;
     // scratch (grow-only; no allocation on the per-scan path after warm-up)
     DevBuf d_scans, d_state, d_partials, d_sums, d_T0, d_trace, d_stage_pts, d_active, d_queue, d_ds;
@@ -121,11 +133,15 @@ struct elm_ctx {
 
 // Contexts that are alive.  Maps and scans hold a pointer to their context; destroying the context first is legal (e.g. Python
 // object finalisation order): a child destroyed later finds its context gone and only releases its own device memory.
+// A child remembers the context's unique id: a NEW context that happens to be allocated at a destroyed context's address (possibly on
+// another device) is not its owner.
 static std::mutex g_live_mu;
-static std::set<const elm_ctx*> g_live_ctx;
-static bool ctx_alive(const elm_ctx* ctx) {
+static std::map<const elm_ctx*, uint64_t> g_live_ctx;
+static uint64_t g_next_ctx_id = 1;
+static bool ctx_alive(const elm_ctx* ctx, uint64_t id) {
     std::lock_guard<std::mutex> lk(g_live_mu);
-    return g_live_ctx.count(ctx) != 0;
+    auto it = g_live_ctx.find(ctx);
+    return it != g_live_ctx.end() && it->second == id;
 }
 
 #define HIPCHK(ctx, call)                                                                              \
@@ -212,7 +228,8 @@ extern "C" int elm_ctx_create(int device_id, elm_ctx** out) {
     if (const char* o = getenv("ELM_SCAN_ORDER")) ctx->scan_order = (strcmp(o, "none") == 0) ? 0 : 1;
     {
         std::lock_guard<std::mutex> lk(g_live_mu);
-        g_live_ctx.insert(ctx);
+        ctx->id = g_next_ctx_id++;
+        g_live_ctx[ctx] = ctx->id;
     }
     *out = ctx;
     return ELM_OK;
@@ -227,7 +244,14 @@ extern "C" void elm_ctx_destroy(elm_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm && g_rccl.comm_destroy) g_rccl.comm_destroy(ctx->comm);
-    DevBuf* bufs[] = {&ctx->d_scans, &ctx->d_state, &ctx->d_partials, &ctx->d_sums, &ctx->d_T0, &ctx->d_trace, &ctx->d_stage_pts, &ctx->d_active, &ctx->d_queue, &ctx->d_ds};
+    for (hipStream_t st : {ctx->copy_stream, ctx->order_stream, ctx->poll_stream})
+        if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (hipEvent_t e : {ctx->ev_copied[0], ctx->ev_copied[1], ctx->ev_ordered[0], ctx->ev_ordered[1], ctx->ev_iter[0], ctx->ev_iter[1], ctx->ev_iter[2], ctx->ev_iter[3]})
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->d_hilbert) (void)hipFree(ctx->d_hilbert);
+    if (ctx->h_jobs) (void)hipHostFree(ctx->h_jobs);
+    DevBuf* bufs[] = {&ctx->d_scans, &ctx->d_state, &ctx->d_partials, &ctx->d_sums, &ctx->d_T0, &ctx->d_trace, &ctx->d_stage_pts, &ctx->d_active, &ctx->d_queue, &ctx->d_ds,
+                      &ctx->d_order_jobs, &ctx->d_order_tmp, &ctx->d_arena, &ctx->d_raw};
     if (ctx->h_active) (void)hipHostFree(ctx->h_active);
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -277,6 +301,7 @@ extern "C" int elm_ctx_synchronize(elm_ctx* ctx) {
 // ------------------------------------------------------------------------------------------------------
 struct elm_map {
     elm_ctx* ctx = nullptr;
+    uint64_t ctx_id = 0;
     elm_map_info info{};
     DevMap dm{};
     HashSlot* d_slots = nullptr;
@@ -457,7 +482,7 @@ static void build_host(const float* xyz, size_t n, double voxel_size, int max_po
 
 static void map_free(elm_map* m) {
     if (!m) return;
-    if (ctx_alive(m->ctx)) (void)hipSetDevice(m->ctx->device); // a context destroyed first: just release the device memory
+    if (ctx_alive(m->ctx, m->ctx_id)) (void)hipSetDevice(m->ctx->device); // a context destroyed first: just release the device memory
     void* ptrs[] = {m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_vox_cinv, m->d_pt_gicp, m->d_pt_cov, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off, m->d_vqslots, m->d_vq_dense, m->d_vqf_dense, m->d_vface, m->d_vnbr, m->d_vnbr_blk,
                     m->d_grid_blk, m->d_grid_idx, m->d_grid_start, m->d_vox_stat, m->d_grid_gicp};
     for (void* p : ptrs)
@@ -474,6 +499,7 @@ extern "C" int elm_map_build(elm_ctx* ctx, const float* xyz, size_t n, double vo
     if (n) build_host(xyz, n, voxel_size, max_points_per_voxel, hb);
     elm_map* m = new elm_map();
     m->ctx = ctx;
+    m->ctx_id = ctx->id;
     const uint32_t n_vox = (uint32_t)hb.ranges.size();
     const uint32_t n_pts = (uint32_t)hb.pts.size();
     // load factor <= 0.25: a probe for an absent key (most of a workgroup's box cells are empty) ends after ~1.4 slots
@@ -781,10 +807,21 @@ static int refresh_grid_gicp(elm_map* m) {
 
 // Dense half-voxel cell grid (see DevMap::grid_*): the map points once, counting-sorted by cell on the host (init time), the
 // offsets of every cell of the bounding box (+ 2 cells of margin), and the dense voxel box of walk statistics.
-// ELM_ERR_UNSUPPORTED when the box needs more than max_cells cells (sparse or very large maps: the caller builds the
-// neighbourhood lists instead).
+// ELM_ERR_UNSUPPORTED (and grid_refused) when the grid is not affordable -- the box needs more than max_cells cells, its tables
+// do not fit the host / device memory that is free right now, or an allocation fails half-way -- the caller then builds the
+// neighbourhood lists instead; nothing is left allocated and the map is unchanged.
+static int build_cell_grid_impl(elm_map* m, uint64_t max_cells);
 static int build_cell_grid(elm_map* m, uint64_t max_cells) {
     if (m->has_grid) return ELM_OK;
+    try {
+        return build_cell_grid_impl(m, max_cells);
+    } catch (const std::bad_alloc&) { // a host table did not fit after all: same answer as the byte budget below
+        m->ctx->last_error = "cell grid: host allocation failed";
+        m->grid_refused = true;
+        return ELM_ERR_UNSUPPORTED;
+    }
+}
+static int build_cell_grid_impl(elm_map* m, uint64_t max_cells) {
     elm_ctx* ctx = m->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t n = m->dm.n_pts;
@@ -793,12 +830,10 @@ static int build_cell_grid(elm_map* m, uint64_t max_cells) {
     std::vector<float4> pts(n);
     HIPCHK(ctx, hipMemcpy(pts.data(), m->d_pts, n * sizeof(float4), hipMemcpyDeviceToHost));
     int32_t lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
-    std::vector<int32_t> cell(3 * n);
     for (size_t i = 0; i < n; ++i) {
         const float c3[3] = {pts[i].x, pts[i].y, pts[i].z};
         for (int a = 0; a < 3; ++a) {
             const int32_t c = grid_cell_of((double)c3[a], vs);
-            cell[3 * i + a] = c;
             lo[a] = std::min(lo[a], c);
             hi[a] = std::max(hi[a], c);
         }
@@ -813,37 +848,6 @@ static int build_cell_grid(elm_map* m, uint64_t max_cells) {
         m->grid_refused = true;
         return ELM_ERR_UNSUPPORTED;
     }
-    std::vector<uint32_t> start(cells + 4, 0u), lin(n);
-    for (size_t i = 0; i < n; ++i) {
-        const uint64_t l = ((uint64_t)(cell[3 * i] - lo[0]) * (uint64_t)dim[1] + (uint64_t)(cell[3 * i + 1] - lo[1])) * (uint64_t)dim[2] + (uint64_t)(cell[3 * i + 2] - lo[2]);
-        lin[i] = (uint32_t)l;
-        start[l + 1]++;
-    }
-    std::vector<int32_t>().swap(cell);
-    // points per cell -> blocks of four per cell -> exclusive scan: start[c] = first block of cell c, start[c + 1] = its end
-    std::vector<uint32_t> fill(cells); // points placed so far in each cell
-    uint64_t n_blk = 1; // block 0: four padding slots, read by masked-off loads
-    for (uint64_t c = 0; c < cells; ++c) {
-        const uint32_t cnt = start[c + 1];
-        fill[c] = 0;
-        start[c] = (uint32_t)n_blk;
-        n_blk += (cnt + 3) / 4;
-        if (n_blk * sizeof(GridBlk) > 0xFFFFFF00ull) { m->grid_refused = true; return ELM_ERR_UNSUPPORTED; } // the kernel addresses blocks by 32-bit byte offsets
-    }
-    for (uint64_t c = cells; c < cells + 4; ++c) start[c] = (uint32_t)n_blk;
-    std::vector<GridBlk> gb(std::max<uint64_t>(n_blk, 1));
-    std::vector<uint32_t> gi(std::max<uint64_t>(4 * n_blk, 4), 0xFFFFFFFFu);
-    for (auto& b : gb)
-        for (int u = 0; u < 4; ++u) b.x[u] = b.y[u] = b.z[u] = 1e18f; // padding: never the nearest, never within range
-    for (size_t i = 0; i < n; ++i) { // bucket order in, so a cell keeps its points in bucket (= insertion) order
-        const uint32_t c = lin[i];
-        const uint32_t pos = start[c] * 4 + fill[c]++;
-        gb[pos >> 2].x[pos & 3] = pts[i].x; gb[pos >> 2].y[pos & 3] = pts[i].y; gb[pos >> 2].z[pos & 3] = pts[i].z;
-        gi[pos] = (uint32_t)i;
-    }
-    std::vector<uint32_t>().swap(fill);
-    std::vector<float4>().swap(pts);
-    std::vector<uint32_t>().swap(lin);
     // dense voxel box of floor keys: a query with floor key f walks the stored keys f-1 .. f+1
     int32_t klo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, khi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
     for (uint32_t v = 0; v < m->dm.n_vox; ++v)
@@ -857,39 +861,118 @@ static int build_cell_grid(elm_map* m, uint64_t max_cells) {
         m->grid_refused = true;
         return ELM_ERR_UNSUPPORTED;
     }
+    // Byte budget (the cell count alone says nothing about a sparse or elongated map just under it): host transients = the
+    // offsets + the sorted copy (blocks of four: at most one block per point) + two index arrays; device = offsets + statistics +
+    // blocks + slot indices (+ the GICP records in slot order).  Not affordable right now -> the lists.
+    {
+        const uint64_t worst_blk = std::min<uint64_t>(n, cells) + n / 4 + 2;
+        const uint64_t host_need = (cells + 4) * 4 + worst_blk * (sizeof(GridBlk) + 16) + n * 8;
+        const uint64_t dev_need = (cells + 4) * 4 + vcells * 4 + worst_blk * (sizeof(GridBlk) + 16) + (m->info.has_point_cov ? worst_blk * 4 * 64 : 0);
+        size_t dev_free = 0, dev_total = 0;
+        HIPCHK(ctx, hipMemGetInfo(&dev_free, &dev_total));
+        const long pages = sysconf(_SC_AVPHYS_PAGES), psz = sysconf(_SC_PAGESIZE);
+        const uint64_t host_free = (pages > 0 && psz > 0) ? (uint64_t)pages * (uint64_t)psz : ~0ull;
+        if (host_need > host_free / 10 * 7 || dev_need > (uint64_t)dev_free / 10 * 8) {
+            ctx->last_error = "cell grid: tables exceed the memory that is free (host " + std::to_string(host_need >> 20) + " MB, device " +
+                              std::to_string(dev_need >> 20) + " MB needed)";
+            m->grid_refused = true;
+            return ELM_ERR_UNSUPPORTED;
+        }
+    }
+    // points per cell -> stable order of the points by cell (perm) -> blocks of four per cell.  ONE table of `cells` entries: it
+    // holds the counts, then the running cursors of the scatter, then -- rewritten cell by cell while the blocks are laid out --
+    // the first block of every cell (start[c + 1] = its end)
+    std::vector<uint32_t> start(cells + 4, 0u), lin(n);
+    for (size_t i = 0; i < n; ++i) {
+        const uint64_t l = ((uint64_t)(grid_cell_of((double)pts[i].x, vs) - lo[0]) * (uint64_t)dim[1] + (uint64_t)(grid_cell_of((double)pts[i].y, vs) - lo[1])) * (uint64_t)dim[2] +
+                           (uint64_t)(grid_cell_of((double)pts[i].z, vs) - lo[2]);
+        lin[i] = (uint32_t)l;
+        start[l + 1]++;
+    }
+    uint64_t n_blk = 1; // block 0: four padding slots, read by masked-off loads
+    for (uint64_t c = 0; c < cells; ++c) n_blk += (start[c + 1] + 3) / 4;
+    if (n_blk * sizeof(GridBlk) > 0xFFFFFF00ull) { m->grid_refused = true; return ELM_ERR_UNSUPPORTED; } // the kernel addresses blocks by 32-bit byte offsets
+    for (uint64_t c = 0; c < cells; ++c) start[c + 1] += start[c]; // start[c] = first position of cell c in the (unpadded) sorted order
+    std::vector<uint32_t> perm(n);
+    for (size_t i = 0; i < n; ++i) perm[start[lin[i]]++] = (uint32_t)i; // bucket order in, so a cell keeps its points in bucket (= insertion) order
+    std::vector<uint32_t>().swap(lin);
+    // the cursors now hold every cell's END: start[c] = end(c) = begin(c + 1)
+    std::vector<GridBlk> gb(std::max<uint64_t>(n_blk, 1));
+    std::vector<uint32_t> gi(std::max<uint64_t>(4 * n_blk, 4), 0xFFFFFFFFu);
+    for (auto& b : gb)
+        for (int u = 0; u < 4; ++u) b.x[u] = b.y[u] = b.z[u] = 1e18f; // padding: never the nearest, never within range
+    {
+        uint64_t blk = 1;
+        uint32_t begin = 0;
+        for (uint64_t c = 0; c < cells; ++c) {
+            const uint32_t end = start[c];
+            start[c] = (uint32_t)blk;
+            for (uint32_t k = begin; k < end; ++k) {
+                const uint32_t i = perm[k];
+                const uint64_t pos = blk * 4 + (k - begin);
+                gb[pos >> 2].x[pos & 3] = pts[i].x; gb[pos >> 2].y[pos & 3] = pts[i].y; gb[pos >> 2].z[pos & 3] = pts[i].z;
+                gi[pos] = i;
+            }
+            blk += (end - begin + 3) / 4;
+            begin = end;
+        }
+        for (uint64_t c = cells; c < cells + 4; ++c) start[c] = (uint32_t)blk;
+    }
+    std::vector<uint32_t>().swap(perm);
+    std::vector<float4>().swap(pts);
+    // device side: into locals, committed to the map only when every step has succeeded
+    GridBlk* d_blk = nullptr;
+    uint32_t *d_idx = nullptr, *d_start = nullptr, *d_stat = nullptr;
+    const DevMap dm_before = m->dm;
+    auto fail = [&](const std::string& what, hipError_t e) {
+        ctx->last_error = what + ": " + hipGetErrorString(e);
+        for (void* q : {(void*)d_blk, (void*)d_idx, (void*)d_start, (void*)d_stat})
+            if (q) (void)hipFree(q);
+        m->dm = dm_before;
+        (void)hipGetLastError();
+        m->grid_refused = true; // do not retry a multi-GB build at every registration
+        return e == hipErrorOutOfMemory ? ELM_ERR_UNSUPPORTED : ELM_ERR_DEVICE;
+    };
 #define GRID_CHK(call)                                                                        \
     do {                                                                                      \
         hipError_t e_ = (call);                                                               \
-        if (e_ != hipSuccess) {                                                               \
-            ctx->last_error = std::string(#call) + ": " + hipGetErrorString(e_);              \
-            return ELM_ERR_DEVICE;                                                            \
-        }                                                                                     \
+        if (e_ != hipSuccess) return fail(#call, e_);                                         \
     } while (0)
-    GRID_CHK(hipMalloc((void**)&m->d_grid_blk, gb.size() * sizeof(GridBlk)));
-    GRID_CHK(hipMalloc((void**)&m->d_grid_idx, gi.size() * sizeof(uint32_t)));
-    GRID_CHK(hipMalloc((void**)&m->d_grid_start, (cells + 4) * sizeof(uint32_t)));
-    GRID_CHK(hipMalloc((void**)&m->d_vox_stat, std::max<size_t>(vcells * sizeof(uint32_t), 256)));
-    GRID_CHK(hipMemcpy(m->d_grid_blk, gb.data(), gb.size() * sizeof(GridBlk), hipMemcpyHostToDevice));
-    GRID_CHK(hipMemcpy(m->d_grid_idx, gi.data(), gi.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    GRID_CHK(hipMemcpy(m->d_grid_start, start.data(), (cells + 4) * sizeof(uint32_t), hipMemcpyHostToDevice));
-    m->dm.grid_blk = m->d_grid_blk;
-    m->dm.grid_idx = m->d_grid_idx;
-    m->dm.grid_start = m->d_grid_start;
+    GRID_CHK(hipMalloc((void**)&d_blk, gb.size() * sizeof(GridBlk)));
+    GRID_CHK(hipMalloc((void**)&d_idx, gi.size() * sizeof(uint32_t)));
+    GRID_CHK(hipMalloc((void**)&d_start, (cells + 4) * sizeof(uint32_t)));
+    GRID_CHK(hipMalloc((void**)&d_stat, std::max<size_t>(vcells * sizeof(uint32_t), 256)));
+    GRID_CHK(hipMemcpy(d_blk, gb.data(), gb.size() * sizeof(GridBlk), hipMemcpyHostToDevice));
+    GRID_CHK(hipMemcpy(d_idx, gi.data(), gi.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    GRID_CHK(hipMemcpy(d_start, start.data(), (cells + 4) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    m->dm.grid_blk = d_blk;
+    m->dm.grid_idx = d_idx;
+    m->dm.grid_start = d_start;
     m->dm.gx0 = lo[0]; m->dm.gy0 = lo[1]; m->dm.gz0 = lo[2];
     m->dm.gnx = (int32_t)dim[0]; m->dm.gny = (int32_t)dim[1]; m->dm.gnz = (int32_t)dim[2];
-    m->dm.vox_stat = m->d_vox_stat;
+    m->dm.vox_stat = d_stat;
     m->dm.vx0 = klo[0] - 1; m->dm.vy0 = klo[1] - 1; m->dm.vz0 = klo[2] - 1;
     m->dm.vnx = (int32_t)vd[0]; m->dm.vny = (int32_t)vd[1]; m->dm.vnz = (int32_t)vd[2];
     (void)hipGetLastError();
-    launch_vox_stat(ctx->stream, m->dm, m->d_vox_stat);
+    launch_vox_stat(ctx->stream, m->dm, d_stat);
     GRID_CHK(hipGetLastError());
     GRID_CHK(hipStreamSynchronize(ctx->stream));
 #undef GRID_CHK
+    m->d_grid_blk = d_blk; m->d_grid_idx = d_idx; m->d_grid_start = d_start; m->d_vox_stat = d_stat;
     m->has_grid = true;
     m->grid_slots = gi.size();
     {
         const int rc2 = refresh_grid_gicp(m);
-        if (rc2 != ELM_OK) return rc2;
+        if (rc2 != ELM_OK) { // the payload copy did not fit: give the grid back, the lists read pt_gicp through their index
+            (void)hipFree(d_blk); (void)hipFree(d_idx); (void)hipFree(d_start); (void)hipFree(d_stat);
+            m->d_grid_blk = nullptr; m->d_grid_idx = nullptr; m->d_grid_start = nullptr; m->d_vox_stat = nullptr;
+            m->dm = dm_before;
+            m->has_grid = false;
+            m->grid_slots = 0;
+            m->grid_refused = true;
+            (void)hipGetLastError();
+            return ELM_ERR_UNSUPPORTED;
+        }
     }
     m->info.device_bytes += gb.size() * sizeof(GridBlk) + gi.size() * sizeof(uint32_t) + (cells + 4) * sizeof(uint32_t) + vcells * sizeof(uint32_t);
     m->info.n_query_voxels = vcells;
@@ -1138,76 +1221,100 @@ static inline uint32_t hilbert_xy2d(uint32_t order, uint32_t x, uint32_t y) {
     return d;
 }
 
-// Uploads one scan.  order = true: the points are ordered along a Hilbert curve over 2 m x 2 m sensor-frame cells (all heights of
-// a cell together) -- consecutive points, hence every 256-point workgroup and, through the XCD-aware block mapping, every XCD's
-// L2, touch a few adjacent map cells: +13 % registrations/s on resident scans (65.2k vs 57.7k).  The ordering costs ~1.3 ms of
-// host time for 131 072 points, far more than it saves on ONE registration, so elm_register keeps the caller's order.
-// No allocation after warm-up: ordering scratch, pinned staging, scan handles and device buffers are pooled in the context.
-static int scan_upload_impl(elm_ctx* ctx, const float* xyz, size_t n, size_t n_total, bool order, elm_scan** out) {
-    if (!ctx || !out || (!xyz && n) || n > 0x7FFFFFFFull || n_total > 0x7FFFFFFFull || n_total < n) return ELM_ERR_INVALID;
-    *out = nullptr;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    int rc = pinned_reserve(ctx, &ctx->h_stage, &ctx->h_stage_cap, std::max<size_t>(n * sizeof(float4), 4096));
-    if (rc != ELM_OK) return rc;
-    float4* hp = (float4*)ctx->h_stage;
-    if (!order || !ctx->scan_order) {
-        for (size_t i = 0; i < n; ++i) hp[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.f);
-    } else {
-        const double cs = 2.0;
-        // 20-bit keys: two stable 10-bit counting passes (LSD radix) over the index array, ~10x cheaper than a comparison sort
-        if (ctx->h_key.size() < n) { ctx->h_key.resize(n); ctx->h_ord.resize(n); ctx->h_tmp.resize(n); }
-        uint32_t *key = ctx->h_key.data(), *ord = ctx->h_ord.data(), *tmp = ctx->h_tmp.data();
-        for (size_t i = 0; i < n; ++i) {
-            const int cx = (int)floor((double)xyz[3 * i] / cs) + 512, cy = (int)floor((double)xyz[3 * i + 1] / cs) + 512;
-            const uint32_t ux = (uint32_t)std::min(std::max(cx, 0), 1023), uy = (uint32_t)std::min(std::max(cy, 0), 1023);
-            key[i] = hilbert_xy2d(10, ux, uy);
-        }
-        uint32_t cnt[1025];
-        memset(cnt, 0, sizeof cnt);
-        for (size_t i = 0; i < n; ++i) cnt[(key[i] & 1023u) + 1]++;
-        for (int b = 0; b < 1024; ++b) cnt[b + 1] += cnt[b];
-        for (size_t i = 0; i < n; ++i) tmp[cnt[key[i] & 1023u]++] = (uint32_t)i;
-        memset(cnt, 0, sizeof cnt);
-        for (size_t i = 0; i < n; ++i) cnt[(key[i] >> 10) + 1]++;
-        for (int b = 0; b < 1024; ++b) cnt[b + 1] += cnt[b];
-        for (size_t k = 0; k < n; ++k) ord[cnt[key[tmp[k]] >> 10]++] = tmp[k];
-        for (size_t k = 0; k < n; ++k) {
-            const size_t i = ord[k];
-            hp[k] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.f);
-        }
-    }
+// The ordering grid's Hilbert table (kOrderCells^2 16-bit entries), uploaded once per context.
+static int ensure_hilbert(elm_ctx* ctx) {
+    if (ctx->d_hilbert) return ELM_OK;
+    static_assert(kOrderCells == 64, "hilbert_xy2d order below");
+    std::vector<uint16_t> lut((size_t)kOrderCells * kOrderCells);
+    for (int y = 0; y < kOrderCells; ++y)
+        for (int x = 0; x < kOrderCells; ++x) lut[(size_t)y * kOrderCells + x] = (uint16_t)hilbert_xy2d(6, (uint32_t)x, (uint32_t)y);
+    HIPCHK(ctx, hipMalloc((void**)&ctx->d_hilbert, lut.size() * sizeof(uint16_t)));
+    HIPCHK(ctx, hipMemcpy(ctx->d_hilbert, lut.data(), lut.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return ELM_OK;
+}
+
+// A scan handle + a device buffer of at least n points, both from the context's pools when possible (a scan per LiDAR message: no
+// hipMalloc / hipFree on the per-scan path after warm-up).
+static int scan_alloc(elm_ctx* ctx, size_t n, elm_scan** out) {
     elm_scan* s;
     if (!ctx->scan_free.empty()) {
         s = ctx->scan_free.back();
         ctx->scan_free.pop_back();
         *s = elm_scan();
     } else {
-        s = new elm_scan();
+        s = new (std::nothrow) elm_scan();
+        if (!s) return ELM_ERR_ALLOC;
     }
     s->ctx = ctx;
-    s->n = (uint32_t)n;
-    s->n_total = (uint32_t)n_total;
-    const size_t need = std::max<size_t>(n * sizeof(float4), 256);
-    hipError_t e = hipSuccess;
-    {
-        int best = -1; // smallest pooled buffer that fits
-        for (int i = 0; i < (int)ctx->scan_pool.size(); ++i)
-            if (ctx->scan_pool[i].second >= need && (best < 0 || ctx->scan_pool[i].second < ctx->scan_pool[best].second)) best = i;
-        if (best >= 0) {
-            s->d_pts = (float4*)ctx->scan_pool[best].first;
-            s->cap_bytes = ctx->scan_pool[best].second;
-            ctx->scan_pool.erase(ctx->scan_pool.begin() + best);
-        } else {
-            s->cap_bytes = (need + 65535) & ~(size_t)65535;
-            e = hipMalloc((void**)&s->d_pts, s->cap_bytes);
+    s->ctx_id = ctx->id;
+    const size_t need = std::max<size_t>(n * sizeof(Pt3), 256);
+    int best = -1; // smallest pooled buffer that fits
+    for (int i = 0; i < (int)ctx->scan_pool.size(); ++i)
+        if (ctx->scan_pool[i].second >= need && (best < 0 || ctx->scan_pool[i].second < ctx->scan_pool[best].second)) best = i;
+    if (best >= 0) {
+        s->d_pts = (Pt3*)ctx->scan_pool[best].first;
+        s->cap_bytes = ctx->scan_pool[best].second;
+        ctx->scan_pool.erase(ctx->scan_pool.begin() + best);
+    } else {
+        s->cap_bytes = (need + 65535) & ~(size_t)65535;
+        const hipError_t e = hipMalloc((void**)&s->d_pts, s->cap_bytes);
+        if (e != hipSuccess) {
+            ctx->last_error = std::string("scan buffer allocation: ") + hipGetErrorString(e);
+            delete s;
+            return ELM_ERR_DEVICE;
         }
     }
-    if (e == hipSuccess && n) e = hipMemcpyAsync(s->d_pts, hp, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream); // the pinned staging buffer is reused by the next upload
+    *out = s;
+    return ELM_OK;
+}
+
+// Uploads one scan: the caller's packed float32 xyz (12 bytes per point) goes to HBM as it is -- no repack, no host-side sort.
+// order = true: the points are then ordered ON THE DEVICE along a Hilbert curve over 2 m x 2 m sensor-frame cells (k_scan_order,
+// ~0.1 ms per 131 072-point scan; the host radix sort of round 2 took 1.3 ms) -- consecutive points, hence every 256-point workgroup
+// and, through the XCD-aware block mapping, every XCD's L2, touch a few adjacent map cells: +11..13 % registrations/s on resident
+// scans.  order = false (elm_register): the caller's order; ordering one scan costs more than it saves on ONE registration.
+// No allocation after warm-up: pinned staging, scan handles and device buffers are pooled in the context.
+static int scan_upload_impl(elm_ctx* ctx, const float* xyz, size_t n, size_t n_total, bool order, bool sync, elm_scan** out) {
+    if (!ctx || !out || (!xyz && n) || n > 0x7FFFFFFFull || n_total > 0x7FFFFFFFull || n_total < n) return ELM_ERR_INVALID;
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = n * sizeof(Pt3);
+    int rc = pinned_reserve(ctx, &ctx->h_stage, &ctx->h_stage_cap, std::max<size_t>(bytes + sizeof(OrderJob), 4096));
+    if (rc != ELM_OK) return rc;
+    elm_scan* s = nullptr;
+    if ((rc = scan_alloc(ctx, n, &s)) != ELM_OK) return rc;
+    s->n = (uint32_t)n;
+    s->n_total = (uint32_t)n_total;
+    const bool do_order = order && ctx->scan_order && n > 1;
+    hipError_t e = hipSuccess;
+    if (n) memcpy(ctx->h_stage, xyz, bytes); // pinned staging: the DMA engine reads it directly (a pageable source is staged by the runtime in small pieces)
+    if (!do_order) {
+        if (n) e = hipMemcpyAsync(s->d_pts, ctx->h_stage, bytes, hipMemcpyHostToDevice, ctx->stream);
+    } else {
+        rc = ensure_hilbert(ctx);
+        if (rc == ELM_OK) rc = dev_reserve(ctx, ctx->d_raw, bytes);
+        if (rc == ELM_OK) rc = dev_reserve(ctx, ctx->d_order_tmp, n * sizeof(uint32_t));
+        if (rc == ELM_OK) rc = dev_reserve(ctx, ctx->d_order_jobs, sizeof(OrderJob));
+        if (rc != ELM_OK) { elm_scan_destroy(s); return rc; }
+        OrderJob* hj = (OrderJob*)((char*)ctx->h_stage + ((bytes + 15) & ~(size_t)15));
+        if ((char*)(hj + 1) > (char*)ctx->h_stage + ctx->h_stage_cap) { // keep the descriptor inside the staging buffer
+            rc = pinned_reserve(ctx, &ctx->h_jobs, &ctx->h_jobs_cap, 4096);
+            if (rc != ELM_OK) { elm_scan_destroy(s); return rc; }
+            hj = (OrderJob*)ctx->h_jobs;
+        }
+        hj->src = (const Pt3*)ctx->d_raw.p; hj->dst = s->d_pts; hj->tmp = (uint32_t*)ctx->d_order_tmp.p; hj->n = (uint32_t)n; hj->_pad = 0;
+        e = hipMemcpyAsync(ctx->d_raw.p, ctx->h_stage, bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_order_jobs.p, hj, sizeof(OrderJob), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            (void)hipGetLastError();
+            launch_scan_order(ctx->stream, (const OrderJob*)ctx->d_order_jobs.p, 1, ctx->d_hilbert);
+            e = hipGetLastError();
+        }
+    }
+    if (e == hipSuccess && sync) e = hipStreamSynchronize(ctx->stream); // the pinned staging buffer is reused by the next upload
     if (e != hipSuccess) {
         ctx->last_error = std::string("scan upload: ") + hipGetErrorString(e);
-        if (s->d_pts) (void)hipFree(s->d_pts);
-        delete s;
+        elm_scan_destroy(s);
         return ELM_ERR_DEVICE;
     }
     *out = s;
@@ -1215,12 +1322,12 @@ static int scan_upload_impl(elm_ctx* ctx, const float* xyz, size_t n, size_t n_t
 }
 
 extern "C" int elm_scan_upload(elm_ctx* ctx, const float* xyz, size_t n, size_t n_total, elm_scan** out) {
-    return scan_upload_impl(ctx, xyz, n, n_total, true, out);
+    return scan_upload_impl(ctx, xyz, n, n_total, true, true, out);
 }
 
 extern "C" void elm_scan_destroy(elm_scan* s) {
-    if (!s) return;
-    if (!ctx_alive(s->ctx)) { // the context went first: release the device buffer, nothing to pool
+    if (!s || !s->ctx) return; // a handle that is already back in the pool (double destroy)
+    if (!ctx_alive(s->ctx, s->ctx_id)) { // the context went first (or its address was reused): release the device buffer, nothing to pool
         if (s->d_pts) (void)hipFree(s->d_pts);
         delete s;
         return;
@@ -1235,20 +1342,20 @@ extern "C" void elm_scan_destroy(elm_scan* s) {
             (void)hipFree(s->d_pts);
         }
     }
+    s->d_pts = nullptr;
+    s->ctx = nullptr;
     if (ctx->scan_free.size() < 64) ctx->scan_free.push_back(s);
     else delete s;
 }
 extern "C" size_t elm_scan_size(const elm_scan* s) { return s ? s->n : 0; }
 extern "C" int elm_scan_download(const elm_scan* s, float* xyz, size_t cap) {
-    if (!s || (!xyz && cap)) return ELM_ERR_INVALID;
+    if (!s || !s->ctx || (!xyz && cap)) return ELM_ERR_INVALID;
     elm_ctx* ctx = s->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t n = std::min<size_t>(cap, s->n);
     if (!n) return ELM_OK;
-    std::vector<float4> tmp(n);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // the kernels that fill the scan run on the context stream
-    HIPCHK(ctx, hipMemcpy(tmp.data(), s->d_pts, n * sizeof(float4), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < n; ++i) { xyz[3 * i] = tmp[i].x; xyz[3 * i + 1] = tmp[i].y; xyz[3 * i + 2] = tmp[i].z; }
+    HIPCHK(ctx, hipMemcpy(xyz, s->d_pts, n * sizeof(Pt3), hipMemcpyDeviceToHost)); // packed xyz on both sides
     return ELM_OK;
 }
 
@@ -1522,7 +1629,7 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
         hd[s].pts = nullptr; hd[s].n = 0; hd[s].n_total = 0;
         hd[s].blk_begin = cap_blocks * (uint32_t)s; hd[s].blk_end = cap_blocks * (uint32_t)(s + 1);
     }
-    hc->next = 0; hc->completed = 0; hc->total = count; hc->_pad = 0;
+    hc->next = 0; hc->completed = 0; hc->total = count; hc->ready = count;
     if ((rc = dev_reserve(ctx, ctx->d_scans, d_bytes)) != ELM_OK) return rc;
     if ((rc = dev_reserve(ctx, ctx->d_state, (size_t)S * sizeof(ScanState))) != ELM_OK) return rc;
     if ((rc = dev_reserve(ctx, ctx->d_partials, (size_t)std::max<uint32_t>(blocks, 1) * kSums * sizeof(double))) != ELM_OK) return rc;
@@ -1593,7 +1700,7 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
             launch_stream_refill(ctx->stream, dsc, st, S, d_q, d_qT0, d_out, d_ctrl, 0); // slot assignment identical on every rank
         } else {
             // single rank: the solve hands finished slots their next registration itself (no refill launch)
-            const StreamArgs sa = {dsc, d_q, d_qT0, d_out, d_ctrl};
+            const StreamArgs sa = {dsc, d_q, d_qT0, d_out, d_ctrl, 0, 0};
             launch_solve(ctx->stream, dsc, S, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 0, d_active, &sa);
         }
         const int done_iters = it + 1;
@@ -1621,15 +1728,286 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     return ELM_OK;
 }
 
+// ---- host-fed continuous batching ---------------------------------------------------------------------------------------------
+extern "C" void* elm_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, std::max<size_t>(bytes, 64), hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+extern "C" void elm_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
+// Diagnostic for the benches: what one plain hipMemcpyAsync of `bytes` from `host` achieves on this box (median of reps), i.e.
+// the PCIe rate a host-fed stream sits under.
+extern "C" int elm_ctx_measure_h2d(elm_ctx* ctx, const void* host, size_t bytes, int reps, double* gb_per_s) {
+    if (!ctx || !host || !bytes || reps <= 0 || !gb_per_s) return ELM_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = dev_reserve(ctx, ctx->d_arena, bytes);
+    if (rc != ELM_OK) return rc;
+    hipEvent_t a, b;
+    HIPCHK(ctx, hipEventCreate(&a));
+    HIPCHK(ctx, hipEventCreate(&b));
+    std::vector<float> ms;
+    hipError_t e = hipSuccess;
+    for (int r = 0; r < reps + 1 && e == hipSuccess; ++r) { // the first copy warms the path up
+        e = hipEventRecord(a, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_arena.p, host, bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipEventRecord(b, ctx->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(b);
+        float t = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, a, b);
+        if (r) ms.push_back(t);
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    if (e != hipSuccess) {
+        ctx->last_error = std::string("h2d probe: ") + hipGetErrorString(e);
+        return ELM_ERR_DEVICE;
+    }
+    std::sort(ms.begin(), ms.end());
+    *gb_per_s = (double)bytes / ((double)ms[ms.size() / 2] * 1e-3) / 1e9;
+    return ELM_OK;
+}
+
+static int ensure_side_streams(elm_ctx* ctx) {
+    if (!ctx->copy_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (!ctx->order_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->order_stream, hipStreamNonBlocking));
+    if (!ctx->poll_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->poll_stream, hipStreamNonBlocking));
+    for (hipEvent_t* e : {&ctx->ev_copied[0], &ctx->ev_copied[1], &ctx->ev_ordered[0], &ctx->ev_ordered[1], &ctx->ev_iter[0], &ctx->ev_iter[1], &ctx->ev_iter[2], &ctx->ev_iter[3]})
+        if (!*e) HIPCHK(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
+    return ELM_OK;
+}
+static void sync_all_streams(elm_ctx* ctx) {
+    for (hipStream_t st : {ctx->copy_stream, ctx->order_stream, ctx->poll_stream, ctx->stream})
+        if (st) (void)hipStreamSynchronize(st);
+}
+
+// elm_register_stream with the scans still in HOST memory when the call starts (the per-call contract of RunRegister, reg.cpp:274-290:
+// the caller hands over a point vector, not a device handle).  Three things overlap:
+//   copy stream    H2D of the packed xyz of the next group of scans into one of two staging sets (page-locked sources: one DMA per
+//                  group when the group is contiguous in host memory)
+//   order stream   k_scan_order over the group (staging -> the registration's own place in the arena, Hilbert order), then the
+//                  group's arrival is published in ctrl->ready
+//   compute stream the ICP iterations of the registrations that have arrived: a slot that finishes (or idles) claims the next
+//                  arrived registration in the solve kernel, exactly as in elm_register_stream
+// Results are bit-identical to elm_register_stream on the same scans uploaded with elm_scan_upload (same ordering kernel).
+extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const float* const* scan_xyz, const uint32_t* n_pts, int count,
+                                        const double* T0, const elm_reg_config* cfg, int slots, elm_reg_result* results, elm_iter_trace* trace) {
+    if (!ctx || !map || !scan_xyz || !n_pts || count <= 0 || !T0 || !cfg || slots <= 0) return ELM_ERR_INVALID;
+    if (map->ctx != ctx) return ELM_ERR_INVALID;
+    if (cfg->use_radar_cov) return ELM_ERR_UNSUPPORTED;
+    if (cfg->icp_method < ELM_P2P || cfg->icp_method > ELM_AVGICP) return ELM_ERR_INVALID;
+    if (ctx->in_flight) return ELM_ERR_INVALID;
+    if (ctx->comm || ctx->hook) {
+        ctx->last_error = "host-fed streams run on one rank (slot assignment follows scan arrival, which differs between ranks)";
+        return ELM_ERR_UNSUPPORTED;
+    }
+    uint32_t max_n = 0;
+    for (int b = 0; b < count; ++b) {
+        if ((!scan_xyz[b] && n_pts[b]) || n_pts[b] > 0x7FFFFFFFu) return ELM_ERR_INVALID;
+        max_n = std::max(max_n, n_pts[b]);
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (map->dm.n_vox == 0 || cfg->max_iteration <= 0 || max_n == 0) {
+        // nothing iterates: upload and let the lockstep path handle the degenerate cases
+        std::vector<elm_scan*> sc((size_t)count, nullptr);
+        int rc = ELM_OK;
+        for (int b = 0; b < count && rc == ELM_OK; ++b) rc = elm_scan_upload(ctx, scan_xyz[b], n_pts[b], n_pts[b], &sc[b]);
+        if (rc == ELM_OK) rc = elm_register_batch(ctx, map, sc.data(), count, T0, cfg, results, trace);
+        for (elm_scan* x : sc) elm_scan_destroy(x);
+        return rc;
+    }
+    const int method = cfg->icp_method;
+    if ((method == ELM_VGICP || method == ELM_AVGICP) && !map->info.has_voxel_cov) {
+        ctx->last_error = "VGICP/AVGICP need elm_map_cal_voxel_cov_all() (pcm.cpp:92-95)";
+        return ELM_ERR_INVALID;
+    }
+    if (method == ELM_GICP && !map->info.has_point_cov) {
+        ctx->last_error = "GICP needs elm_map_cal_point_cov_all() (pcm.cpp:97-100)";
+        return ELM_ERR_INVALID;
+    }
+    int rc;
+    if ((rc = ensure_side_streams(ctx)) != ELM_OK) return rc;
+    if ((rc = ensure_hilbert(ctx)) != ELM_OK) return rc;
+    const int S = std::min(std::min(slots, count), stream_max_slots());
+    const uint32_t cap_blocks = (max_n + kBlock - 1) / kBlock;
+    const uint32_t blocks = cap_blocks * (uint32_t)S;
+    // upload groups: ~32 MB of points each, at most 64 scans (one ordering workgroup per scan)
+    const size_t scan_stride = (((size_t)max_n * sizeof(Pt3)) + 255) & ~(size_t)255;
+    const int G = (int)std::min<size_t>(std::min<size_t>(64, (size_t)count), std::max<size_t>(1, ((size_t)32 << 20) / scan_stride));
+    const int n_groups = (count + G - 1) / G;
+    // the arena: every registration's ordered scan has its own place for the whole call
+    std::vector<size_t> off((size_t)count + 1, 0);
+    for (int b = 0; b < count; ++b) off[b + 1] = off[b] + ((((size_t)n_pts[b] * sizeof(Pt3)) + 255) & ~(size_t)255);
+    if ((rc = dev_reserve(ctx, ctx->d_arena, std::max<size_t>(off[count], 256))) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_raw, 2 * (size_t)G * scan_stride)) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_order_tmp, 2 * (size_t)G * max_n * sizeof(uint32_t))) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_order_jobs, (size_t)count * sizeof(OrderJob))) != ELM_OK) return rc;
+    if ((rc = pinned_reserve(ctx, &ctx->h_jobs, &ctx->h_jobs_cap, std::max<size_t>((size_t)count * sizeof(OrderJob), 4096))) != ELM_OK) return rc;
+    OrderJob* hj = (OrderJob*)ctx->h_jobs;
+    for (int b = 0; b < count; ++b) {
+        const int set = (b / G) & 1, j = b % G;
+        hj[b].src = (const Pt3*)((char*)ctx->d_raw.p + ((size_t)set * G + j) * scan_stride);
+        hj[b].dst = (Pt3*)((char*)ctx->d_arena.p + off[b]);
+        hj[b].tmp = (uint32_t*)ctx->d_order_tmp.p + ((size_t)set * G + j) * max_n;
+        hj[b].n = n_pts[b];
+        hj[b]._pad = 0;
+    }
+    // queue, guesses, control block, result states (the layout of elm_register_stream)
+    const size_t q_bytes = (size_t)count * sizeof(QueueItem), t_bytes = (size_t)count * 16 * sizeof(double), d_bytes = (size_t)S * sizeof(ScanDesc);
+    const size_t stage_bytes = q_bytes + t_bytes + sizeof(StreamCtrl);
+    if ((rc = pinned_reserve(ctx, &ctx->h_desc, &ctx->h_desc_cap, std::max<size_t>(stage_bytes, 4096))) != ELM_OK) return rc;
+    QueueItem* hq = (QueueItem*)ctx->h_desc;
+    double* hT = (double*)((char*)ctx->h_desc + q_bytes);
+    StreamCtrl* hc = (StreamCtrl*)((char*)ctx->h_desc + q_bytes + t_bytes);
+    for (int b = 0; b < count; ++b) { hq[b].pts = hj[b].dst; hq[b].n = n_pts[b]; hq[b].n_total = n_pts[b]; }
+    memcpy(hT, T0, t_bytes);
+    hc->next = 0; hc->completed = 0; hc->total = count; hc->ready = 0;
+    if ((rc = dev_reserve(ctx, ctx->d_scans, d_bytes)) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_state, (size_t)S * sizeof(ScanState))) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_partials, (size_t)std::max<uint32_t>(blocks, 1) * kSums * sizeof(double))) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_sums, (size_t)S * kSums * sizeof(double))) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_queue, q_bytes + t_bytes + sizeof(StreamCtrl) + (size_t)count * sizeof(ScanState) + 64)) != ELM_OK) return rc;
+    if ((rc = pinned_reserve(ctx, &ctx->h_state, &ctx->h_state_cap, (size_t)count * sizeof(ScanState))) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_active, 256)) != ELM_OK) return rc;
+    if (!ctx->h_active) HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_active, 64, hipHostMallocDefault));
+    char* qb = (char*)ctx->d_queue.p;
+    QueueItem* d_q = (QueueItem*)qb;
+    double* d_qT0 = (double*)(qb + q_bytes);
+    StreamCtrl* d_ctrl = (StreamCtrl*)(qb + q_bytes + t_bytes);
+    ScanState* d_out = (ScanState*)(qb + q_bytes + t_bytes + ((sizeof(StreamCtrl) + 63) / 64) * 64);
+    elm_iter_trace* d_trace = nullptr;
+    if (trace) {
+        const size_t tb = (size_t)count * ELM_MAX_ITER_TRACE * sizeof(elm_iter_trace);
+        if ((rc = dev_reserve(ctx, ctx->d_trace, tb)) != ELM_OK) return rc;
+        if ((rc = pinned_reserve(ctx, &ctx->h_trace, &ctx->h_trace_cap, tb)) != ELM_OK) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_trace.p, 0, tb, ctx->stream));
+        d_trace = (elm_iter_trace*)ctx->d_trace.p;
+    }
+    RegParams rp;
+    rp.th = cfg->max_search_dist;
+    rp.th2 = cfg->max_search_dist * cfg->max_search_dist;
+    rp.lm_lambda = cfg->lm_lambda;
+    rp.term_thr = cfg->icp_termination_threshold_m;
+    rp.min_overlap = cfg->min_overlap_ratio;
+    rp.max_fitness = cfg->max_fitness_score;
+    rp.method = method;
+    rp.max_iter = cfg->max_iteration;
+    rp.uniform_blocks = cap_blocks;
+    rp._pad = 0;
+    ctx->rp = rp;
+    const bool use_nbr = ctx->kernel_mode != 2 && (method == ELM_P2P || method == ELM_GICP);
+    bool use_grid = use_nbr && ctx->kernel_mode == 4 && map->has_grid;
+    if (use_nbr && !use_grid && !map->has_nbr)
+        if ((rc = build_search_index(const_cast<elm_map*>(map), &use_grid)) != ELM_OK) return rc;
+    const bool use_cells = use_nbr && !use_grid && map->has_cells;
+    const bool use_vnbr = ctx->kernel_mode != 2 && (method == ELM_VGICP || method == ELM_AVGICP);
+    if (use_vnbr && !map->has_vnbr)
+        if ((rc = build_voxel_neighbourhoods(const_cast<elm_map*>(map))) != ELM_OK) return rc;
+
+#define HF_CHK(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            ctx->last_error = std::string(#call) + ": " + hipGetErrorString(e_);                       \
+            sync_all_streams(ctx);                                                                     \
+            return ELM_ERR_DEVICE;                                                                     \
+        }                                                                                              \
+    } while (0)
+    HF_CHK(hipMemcpyAsync(d_q, hq, q_bytes + t_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HF_CHK(hipMemcpyAsync(d_ctrl, hc, sizeof(StreamCtrl), hipMemcpyHostToDevice, ctx->stream));
+    HF_CHK(hipMemcpyAsync(ctx->d_order_jobs.p, hj, (size_t)count * sizeof(OrderJob), hipMemcpyHostToDevice, ctx->stream));
+    HF_CHK(hipMemsetAsync(ctx->d_active.p, 0, sizeof(int), ctx->stream));
+    ScanState* st = (ScanState*)ctx->d_state.p;
+    ScanDesc* dsc = (ScanDesc*)ctx->d_scans.p;
+    int* d_active = (int*)ctx->d_active.p;
+    (void)hipGetLastError();
+    launch_slots_idle(ctx->stream, dsc, st, S);
+    // the side streams start behind the control block's initialisation (and behind whatever the compute stream still reads from
+    // the arena / staging of an earlier call)
+    HF_CHK(hipEventRecord(ctx->ev_iter[0], ctx->stream));
+    HF_CHK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_iter[0], 0));
+    HF_CHK(hipStreamWaitEvent(ctx->order_stream, ctx->ev_iter[0], 0));
+    ctx->events_used = 0;
+    const OrderJob* d_jobs = (const OrderJob*)ctx->d_order_jobs.p;
+    int g_enq = 0;
+    auto enqueue_group = [&](int g) -> hipError_t {
+        const int set = g & 1, r0 = g * G, r1 = std::min(count, r0 + G);
+        hipError_t e = hipSuccess;
+        if (g >= 2) e = hipStreamWaitEvent(ctx->copy_stream, ctx->ev_ordered[set], 0); // the set's previous ordering kernel has read it
+        char* base = (char*)ctx->d_raw.p + (size_t)set * G * scan_stride;
+        // one DMA for the whole group when it is contiguous in host memory and in the staging set
+        bool contiguous = (size_t)max_n * sizeof(Pt3) == scan_stride;
+        for (int r = r0; r < r1 && contiguous; ++r)
+            contiguous = n_pts[r] == max_n && (r == r0 || scan_xyz[r] == scan_xyz[r - 1] + 3 * (size_t)max_n);
+        if (contiguous) {
+            if (e == hipSuccess) e = hipMemcpyAsync(base, scan_xyz[r0], (size_t)(r1 - r0) * scan_stride, hipMemcpyHostToDevice, ctx->copy_stream);
+        } else {
+            for (int r = r0; r < r1 && e == hipSuccess; ++r)
+                if (n_pts[r]) e = hipMemcpyAsync(base + (size_t)(r - r0) * scan_stride, scan_xyz[r], (size_t)n_pts[r] * sizeof(Pt3), hipMemcpyHostToDevice, ctx->copy_stream);
+        }
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev_copied[set], ctx->copy_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->order_stream, ctx->ev_copied[set], 0);
+        if (e == hipSuccess) {
+            launch_scan_order(ctx->order_stream, d_jobs + r0, r1 - r0, ctx->d_hilbert);
+            launch_publish_ready(ctx->order_stream, d_ctrl, r1);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev_ordered[set], ctx->order_stream);
+        return e;
+    };
+    // Iterations are enqueued a few ahead of the device (an event per iteration throttles the host); the number of finished
+    // registrations is read on a stream of its own, so that looking never waits for the iterations in flight.
+    const StreamArgs sa = {dsc, d_q, d_qT0, d_out, d_ctrl, 1, 0};
+    int it = 0, done_seen = 0, idle_turns = 0;
+    const int idle_limit = 4000000; // ~ minutes of polling without a single registration finishing: a lost upload, give up
+    for (;;) {
+        for (int k = 0; k < 2 && g_enq < n_groups; ++k, ++g_enq) HF_CHK(enqueue_group(g_enq));
+        if (it >= 4) HF_CHK(hipEventSynchronize(ctx->ev_iter[it & 3]));
+        if ((rc = enqueue_accumulate(ctx, map, dsc, S, blocks, st, rp, use_grid, use_cells, use_vnbr)) != ELM_OK) { sync_all_streams(ctx); return rc; }
+        launch_solve(ctx->stream, dsc, S, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 0, d_active, &sa);
+        HF_CHK(hipEventRecord(ctx->ev_iter[it & 3], ctx->stream));
+        ++it;
+        HF_CHK(hipMemcpyAsync(ctx->h_active, &d_ctrl->completed, sizeof(int), hipMemcpyDeviceToHost, ctx->poll_stream));
+        HF_CHK(hipStreamSynchronize(ctx->poll_stream));
+        const int c = *ctx->h_active;
+        if (c >= count) break;
+        idle_turns = (c == done_seen) ? idle_turns + 1 : 0;
+        done_seen = c;
+        if (idle_turns > idle_limit) {
+            ctx->last_error = "host-fed stream made no progress";
+            sync_all_streams(ctx);
+            return ELM_ERR_DEVICE;
+        }
+    }
+    if ((rc = prof_mark(ctx)) != ELM_OK) { sync_all_streams(ctx); return rc; }
+    HF_CHK(hipGetLastError());
+    HF_CHK(hipMemcpyAsync(ctx->h_state, d_out, (size_t)count * sizeof(ScanState), hipMemcpyDeviceToHost, ctx->stream));
+    if (trace)
+        HF_CHK(hipMemcpyAsync(ctx->h_trace, ctx->d_trace.p, (size_t)count * ELM_MAX_ITER_TRACE * sizeof(elm_iter_trace),
+                              hipMemcpyDeviceToHost, ctx->stream));
+    HF_CHK(hipStreamSynchronize(ctx->stream));
+#undef HF_CHK
+    if ((rc = prof_collect(ctx)) != ELM_OK) return rc;
+    const ScanState* hs = (const ScanState*)ctx->h_state;
+    for (int b = 0; results && b < count; ++b) state_to_result(hs[b], rp, results[b]);
+    if (trace) memcpy(trace, ctx->h_trace, (size_t)count * ELM_MAX_ITER_TRACE * sizeof(elm_iter_trace));
+    return ELM_OK;
+}
+
 extern "C" int elm_register(elm_ctx* ctx, const elm_map* map, const float* scan_xyz, size_t n, const double T0[16],
                             const elm_reg_config* cfg, double T_out[16], int* is_success, double* fitness_score,
                             double local_cov[36], elm_reg_result* result, elm_iter_trace* trace) {
     if (!ctx || !map || !T0 || !cfg) return ELM_ERR_INVALID;
     elm_scan* s = nullptr;
-    int rc = scan_upload_impl(ctx, scan_xyz, n, n, false, &s); // the caller's point order (see scan_upload_impl)
+    // the caller's point order (see scan_upload_impl); no wait between the upload and the iterations: the pinned staging buffer is
+    // not touched again before elm_register_batch has synchronised the stream
+    int rc = scan_upload_impl(ctx, scan_xyz, n, n, false, false, &s);
     if (rc != ELM_OK) return rc;
     elm_reg_result res;
     rc = elm_register_batch(ctx, map, &s, 1, T0, cfg, &res, trace);
+    if (rc != ELM_OK) (void)hipStreamSynchronize(ctx->stream); // the upload may still be reading the pinned staging buffer
     elm_scan_destroy(s);
     if (rc != ELM_OK) return rc;
     if (T_out) memcpy(T_out, res.T, sizeof(res.T));
@@ -1729,24 +2107,9 @@ extern "C" int elm_deskew_downsample(elm_ctx* ctx, const float* xyz, const float
     unsigned* d_slot = d_first + cap;
     unsigned* d_bcount = d_slot + std::max<size_t>(n, 1);
     unsigned* d_total = d_bcount + nb + 1; // [0] kept points, [1] overflow flag
-    elm_scan* sc = new elm_scan();
-    sc->ctx = ctx;
-    const size_t need = std::max<size_t>(n * sizeof(float4), 256);
+    elm_scan* sc = nullptr;
+    if ((rc = scan_alloc(ctx, n, &sc)) != ELM_OK) return rc;
     hipError_t e = hipSuccess;
-    {
-        int best = -1;
-        for (int i = 0; i < (int)ctx->scan_pool.size(); ++i)
-            if (ctx->scan_pool[i].second >= need && (best < 0 || ctx->scan_pool[i].second < ctx->scan_pool[best].second)) best = i;
-        if (best >= 0) {
-            sc->d_pts = (float4*)ctx->scan_pool[best].first;
-            sc->cap_bytes = ctx->scan_pool[best].second;
-            ctx->scan_pool.erase(ctx->scan_pool.begin() + best);
-        } else {
-            sc->cap_bytes = (need + 65535) & ~(size_t)65535;
-            e = hipMalloc((void**)&sc->d_pts, sc->cap_bytes);
-        }
-    }
-    if (e != hipSuccess) { delete sc; ctx->last_error = "scan buffer allocation failed"; return ELM_ERR_DEVICE; }
     unsigned h_total[2] = {0, 0};
     if (n) {
         e = hipMemsetAsync(d_table, 0xFF, cap * 12, ctx->stream); // keys and first indices: all ones

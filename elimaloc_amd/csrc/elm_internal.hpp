@@ -18,7 +18,7 @@ struct __attribute__((aligned(32))) HashSlot {
     uint32_t pad0, pad1;
 };
 
-struct Pt3 { // 12-byte candidate of the neighbourhood lists
+struct __attribute__((packed, aligned(4))) Pt3 { // 12-byte point: scan points (one global_load_dwordx3), candidates of the neighbourhood lists
     float x, y, z;
 };
 
@@ -106,7 +106,7 @@ __host__ __device__ __forceinline__ uint32_t hash3(int32_t x, int32_t y, int32_t
 
 // ---- scans / per-registration state -----------------------------------------------------------------
 struct ScanDesc {
-    const float4* pts; // sensor-frame points (xyz, w unused), coarse-cell ordered
+    const Pt3* pts;    // sensor-frame points, packed xyz (12 bytes: what the LiDAR driver / the caller holds, no repack on upload)
     uint32_t n;        // points resident on this GPU
     uint32_t n_total;  // points of the whole scan (== n on one GPU)
     uint32_t blk_begin; // first logical block of this scan in the batch launch
@@ -132,14 +132,14 @@ struct ScanState {
 
 // continuous batching (elm_register_stream): pending registrations and the device-side bookkeeping
 struct QueueItem {
-    const float4* pts;
+    const Pt3* pts;
     uint32_t n, n_total;
 };
 struct StreamCtrl {
     int32_t next;      // first registration not yet assigned to a slot
     int32_t completed; // registrations whose final state has been saved
     int32_t total;
-    int32_t _pad;
+    int32_t ready;     // host-fed streams: registrations whose scan has arrived in HBM (uploaded + ordered); a slot only takes r < ready
 };
 
 // in-solve refill of finished slots (single-rank streams, see finish_slot in elm_kernels.hip)
@@ -149,6 +149,8 @@ struct StreamArgs {
     const double* qT0;
     ScanState* out_state;
     StreamCtrl* ctrl; // nullptr: no refill in the solve
+    int32_t hostfed;  // 1: the queue fills while the stream runs (ctrl->ready grows): idle slots look for work at every solve
+    int32_t _pad;
 };
 
 struct RegParams {
@@ -221,7 +223,20 @@ struct DeskewDev {
 // ordered device-side VoxelDownsample: table / first sized 2^cap_log2 (table = all ones, first = all ones before the call),
 // slot n entries, block_count ceil(n / 1024) entries; *total = kept points, *overflow = 1 when a key does not pack
 void launch_voxel_downsample(hipStream_t s, const float* xyz, uint32_t n, double vs, unsigned long long* table, unsigned* first,
-                             unsigned cap_log2, unsigned* slot, unsigned* block_count, unsigned* total, int* overflow, float4* out);
+                             unsigned cap_log2, unsigned* slot, unsigned* block_count, unsigned* total, int* overflow, Pt3* out);
+// Scan ordering on the device (k_scan_order): one workgroup per scan sorts its points along a Hilbert curve over 2 m sensor-frame
+// cells (deterministic counting sort, no atomics on the data path).  jobs[j] = {src, dst, n, tmp}; src == dst is not allowed.
+struct OrderJob {
+    const Pt3* src; // caller's order
+    Pt3* dst;       // Hilbert order
+    uint32_t* tmp;  // n words of scratch
+    uint32_t n;
+    uint32_t _pad;
+};
+void launch_scan_order(hipStream_t s, const OrderJob* jobs, int n_jobs, const uint16_t* hilbert_lut);
+void launch_publish_ready(hipStream_t s, StreamCtrl* ctrl, int ready);
+void launch_slots_idle(hipStream_t s, ScanDesc* scans, ScanState* st, int slots);
+constexpr int kOrderCells = 64; // cells per axis of the ordering grid (2 m cells: +-64 m around the sensor, clamped beyond)
 void launch_deskew(hipStream_t s, const float* xyz, const float* rel_time, uint32_t n, const DeskewDev& d,
                    float* xyz_out);
 

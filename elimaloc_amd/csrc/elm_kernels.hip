@@ -420,7 +420,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_direct(const DevMap m, co
 #pragma unroll
     for (int k = 0; k < 32; ++k) acc[k] = 0.0;
     if (valid) {
-        const float4 pf = sd.pts[i];
+        const Pt3 pf = sd.pts[i];
         const double px = pf.x, py = pf.y, pz = pf.z;
         // g = T * [p,1]  (reg.hpp:141-146), same association as the reference's scalar product
         const double gx = ((S.T[0] * px + S.T[4] * py) + S.T[8] * pz) + S.T[12];
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_CELL_WAVES : ELM_C
     float hr2 = __builtin_inff();
     bool hard = false;
     if (valid) {
-        const float4 pf = sd.pts[i];
+        const Pt3 pf = sd.pts[i];
         px = pf.x; py = pf.y; pz = pf.z;
         gx = ((S.T[0] * px + S.T[4] * py) + S.T[8] * pz) + S.T[12];
         gy = ((S.T[1] * px + S.T[5] * py) + S.T[9] * pz) + S.T[13];
@@ -1223,7 +1223,8 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
     };
     if (valid) {
         double px, py, pz, gx, gy, gz;
-        float4 pf = sd.pts[i];
+        const Pt3 p3 = sd.pts[i]; // 12 bytes per point: one global_load_dwordx3
+        float4 pf = make_float4(p3.x, p3.y, p3.z, 0.f);
         transform(pf, px, py, pz, gx, gy, gz);
         const GridAxis ax = grid_axis(gx, m), ay = grid_axis(gy, m), az = grid_axis(gz, m);
         // statistics of the reference's walk for this query voxel: candidates and occupied buckets among the 27
@@ -1677,7 +1678,7 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
     PairSum P;
     pair_sum_zero(P);
     if (valid) {
-        const float4 pf = sd.pts[i];
+        const Pt3 pf = sd.pts[i];
         const double px = pf.x, py = pf.y, pz = pf.z;
         const double gx = ((S.T[0] * px + S.T[4] * py) + S.T[8] * pz) + S.T[12];
         const double gy = ((S.T[1] * px + S.T[5] * py) + S.T[9] * pz) + S.T[13];
@@ -2087,31 +2088,31 @@ __device__ __forceinline__ void wave_ldlt6(double a, const double* b, double x[6
     }
 }
 
-// Continuous batching inside the solve (single-rank streams): the lane that has just finished a registration saves its final
-// state and takes the next pending registration for the slot -- what k_stream_refill does, without the extra launch.  The
-// queue position comes from an atomic counter, so WHICH slot serves a registration depends on the order the workgroups get
-// here; a registration's arithmetic does not depend on its slot (uniform slot sizes, partial sums in block order), so every
-// result is unchanged.  Multi-rank streams keep k_stream_refill: there the slot assignment must be identical on every rank.
-// All 64 lanes of the solve's first wavefront call it (uniform); the lead lane's stores to S are complete and re-read with
-// agent-scope loads (they bypass this CU's vector cache).
-__device__ __forceinline__ void finish_slot(const StreamArgs& sa, ScanState& S, int s) {
-    constexpr int W = (int)(sizeof(ScanState) / sizeof(double));
-    const int lane = threadIdx.x & 63;
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
-    const int reg_old = __hip_atomic_load(&S.reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const double* src = reinterpret_cast<const double*>(&S);
-    double* dst = reinterpret_cast<double*>(&sa.out_state[reg_old]);
-    for (int k = lane; k < W; k += 64) dst[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int r = 0;
-    if (lane == 0) {
-        atomicAdd(&sa.ctrl->completed, 1);
-        r = atomicAdd(&sa.ctrl->next, 1);
+// queue position for a free slot, or -1 when nothing is pending.  Plain streams: every registration is there from the start, one
+// atomicAdd hands them out.  Host-fed streams: only registrations whose scan has landed in HBM (ctrl->ready, published by the upload
+// stream after the scan's ordering kernel) may start, so the counter advances by compare-and-swap and never overshoots.
+__device__ __forceinline__ int claim_registration(const StreamArgs& sa) {
+    if (!sa.hostfed) {
+        const int r = atomicAdd(&sa.ctrl->next, 1);
+        return (r < sa.ctrl->total) ? r : -1;
     }
+    int old = __hip_atomic_load(&sa.ctrl->next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        const int ready = __hip_atomic_load(&sa.ctrl->ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (old >= ready) return -1;
+        const int seen = atomicCAS(&sa.ctrl->next, old, old + 1);
+        if (seen == old) return old;
+        old = seen;
+    }
+}
+// The slot takes the next pending registration (descriptor + initial state: init_scan_state's arithmetic) or goes idle.
+// All 64 lanes of the solve's first wavefront call it (uniform).
+__device__ __forceinline__ void start_slot(const StreamArgs& sa, ScanState& S, int s) {
+    const int lane = threadIdx.x & 63;
+    int r = 0;
+    if (lane == 0) r = claim_registration(sa);
     r = __shfl(r, 0, 64);
-    __builtin_amdgcn_s_waitcnt(0); // the copy's loads are done before the state is overwritten
-    __builtin_amdgcn_wave_barrier();
-    if (r < sa.ctrl->total) {
+    if (r >= 0) {
         const double* T0 = sa.qT0 + (size_t)r * 16;
         if (lane >= 1 && lane < 37) S.local_cov[lane - 1] = ((lane - 1) % 7 == 0) ? 1.0 : 0.0; // reg.cpp:280
         if (lane == 0) { // the scalar part of init_scan_state, same arithmetic
@@ -2135,6 +2136,33 @@ __device__ __forceinline__ void finish_slot(const StreamArgs& sa, ScanState& S, 
         S.done = 1; // idle slot
         S.reg = -1;
     }
+}
+// Continuous batching inside the solve (single-rank streams): the wavefront that has just finished a registration saves its final
+// state and takes the next pending registration for the slot -- what k_stream_refill does, without the extra launch.  The
+// queue position comes from an atomic counter, so WHICH slot serves a registration depends on the order the workgroups get
+// here; a registration's arithmetic does not depend on its slot (uniform slot sizes, partial sums in block order), so every
+// result is unchanged.  Multi-rank streams keep k_stream_refill: there the slot assignment must be identical on every rank.
+// The lead lane's plain stores to S are ordered against the other lanes' loads by a workgroup-scope release / acquire fence pair
+// (the wavefront is the only writer and the only reader of S inside this launch) and re-read with agent-scope loads.
+__device__ __forceinline__ void finish_slot(const StreamArgs& sa, ScanState& S, int s) {
+#if !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__) && defined(__HIP_DEVICE_COMPILE__)
+#error "finish_slot relies on gfx9 memory ordering (one vmcnt for loads and stores, write-through vector L1)"
+#endif
+    constexpr int W = (int)(sizeof(ScanState) / sizeof(double));
+    const int lane = threadIdx.x & 63;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int reg_old = __hip_atomic_load(&S.reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double* src = reinterpret_cast<const double*>(&S);
+    double* dst = reinterpret_cast<double*>(&sa.out_state[reg_old]);
+    for (int k = lane; k < W; k += 64) dst[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) atomicAdd(&sa.ctrl->completed, 1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0); // the copy's loads are done before the state is overwritten
+    __builtin_amdgcn_wave_barrier();
+    start_slot(sa, S, s);
 }
 
 constexpr int kSolveThreads = 1024;
@@ -2191,7 +2219,12 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* scans, 
         if (t < 32) tot[t] = sums[(size_t)s * kSums + t];
     }
     __syncthreads();
-    if (done || t >= 64) return; // the first wave does the rest with uniform control flow; lane 0 owns the state
+    if (t >= 64) return; // the first wave does the rest with uniform control flow; lane 0 owns the state
+    if (done) {
+        // host-fed stream: an idle slot (nothing was pending when it last looked) takes a registration whose scan has arrived since
+        if (sa.ctrl && sa.hostfed && __hip_atomic_load(&S.reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) start_slot(sa, S, s);
+        return;
+    }
     const bool lead = (t == 0);
 
     if (rp.method != ELM_P2P) {
@@ -2563,7 +2596,7 @@ void launch_nbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint3
 
 void launch_solve(hipStream_t s, const ScanDesc* scans, int batch, ScanState* st, const double* partials,
                   double* sums, const RegParams& rp, elm_iter_trace* trace, int mode, int* active, const StreamArgs* refill) {
-    StreamArgs sa = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    StreamArgs sa = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
     if (refill) sa = *refill;
     hipLaunchKernelGGL(k_solve, dim3(batch), dim3(kSolveThreads), 0, s, scans, st, partials, sums, rp, trace, mode, active, sa);
 }
@@ -2644,7 +2677,7 @@ __global__ __launch_bounds__(1024) void k_ds_offsets(unsigned* block_count, unsi
 }
 __global__ __launch_bounds__(kDsBlock) void k_ds_scatter(const float* __restrict__ xyz, const unsigned* __restrict__ first,
                                                          const unsigned* __restrict__ slot, unsigned n,
-                                                         const unsigned* __restrict__ block_offset, float4* __restrict__ out) {
+                                                         const unsigned* __restrict__ block_offset, Pt3* __restrict__ out) {
     __shared__ unsigned s_cnt[kDsBlock / 64];
     const unsigned i = blockIdx.x * kDsBlock + threadIdx.x;
     const bool keep = i < n && first[slot[i]] == i;
@@ -2655,16 +2688,155 @@ __global__ __launch_bounds__(kDsBlock) void k_ds_scatter(const float* __restrict
     unsigned pos = block_offset[blockIdx.x];
     for (unsigned w = 0; w < wave; ++w) pos += s_cnt[w];
     pos += (unsigned)__popcll(b & ((1ull << lane) - 1ull));
-    if (keep) out[pos] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.f);
+    if (keep) {
+        Pt3 q;
+        q.x = xyz[3 * i]; q.y = xyz[3 * i + 1]; q.z = xyz[3 * i + 2];
+        out[pos] = q;
+    }
 }
 
 void launch_voxel_downsample(hipStream_t s, const float* xyz, uint32_t n, double vs, unsigned long long* table, unsigned* first,
-                             unsigned cap_log2, unsigned* slot, unsigned* block_count, unsigned* total, int* overflow, float4* out) {
+                             unsigned cap_log2, unsigned* slot, unsigned* block_count, unsigned* total, int* overflow, Pt3* out) {
     const unsigned nb = (n + kDsBlock - 1) / kDsBlock;
     hipLaunchKernelGGL(k_ds_insert, dim3((n + 255) / 256), dim3(256), 0, s, xyz, n, vs, table, first, cap_log2, slot, overflow);
     hipLaunchKernelGGL(k_ds_count, dim3(nb), dim3(kDsBlock), 0, s, first, slot, n, block_count);
     hipLaunchKernelGGL(k_ds_offsets, dim3(1), dim3(1024), 0, s, block_count, nb, total);
     hipLaunchKernelGGL(k_ds_scatter, dim3(nb), dim3(kDsBlock), 0, s, xyz, first, slot, n, block_count, out);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Scan ordering on the device: the points of a scan along a Hilbert curve over 2 m x 2 m sensor-frame cells (all heights of a cell
+// together), so that every 256-point workgroup of the accumulate kernels -- and, through the XCD-aware block mapping, every XCD's
+// L2 -- touches a few adjacent map cells.  Source order is not contractual (the reference's own VoxelDownsample emits
+// unordered_map order, vhm.hpp:278-280); the result must only be DETERMINISTIC (the summation tree follows the point order).
+// One 1024-thread workgroup per scan, a counting sort without atomics:
+//   A  wave w owns the contiguous points [w C, (w + 1) C); 64 consecutive points per step (coalesced 12-byte loads).  Lanes with the
+//      same 12-bit key find each other with 12 ballots; a point's rank inside its (wave, key) run = the wave's counter for that key
+//      (16-bit, LDS) + the number of lower lanes of its group; the group's last lane writes the counter back.  The 32-bit word
+//      key | rank << 12 goes to scratch.
+//   -  exclusive prefix of the counters over (key, wave): start of every (key, wave) run
+//   B  every point moves to start[key] + offset[wave][key] + rank.
+// Within a key the order is (wave, step, lane) = the caller's order: the sort is stable.  A (degenerate) scan with more than 65535
+// points in one cell or per wave keeps the caller's order.
+constexpr int kOrderWaves = 16;
+constexpr int kOrderThreads = kOrderWaves * 64;
+constexpr int kOrderBins = kOrderCells * kOrderCells; // 4096 keys: 128 KB of 16-bit counters + 16 KB of run starts
+__device__ __forceinline__ unsigned order_key(const Pt3 p, const unsigned short* lut) {
+    const int cx = (int)floorf(p.x * 0.5f) + kOrderCells / 2, cy = (int)floorf(p.y * 0.5f) + kOrderCells / 2;
+    const int ux = min(max(cx, 0), kOrderCells - 1), uy = min(max(cy, 0), kOrderCells - 1);
+    return lut[uy * kOrderCells + ux];
+}
+__global__ __launch_bounds__(kOrderThreads) void k_scan_order(const OrderJob* __restrict__ jobs, const uint16_t* __restrict__ hilbert_lut) {
+    __shared__ unsigned short s_cnt[kOrderWaves][kOrderBins];
+    __shared__ unsigned s_start[kOrderBins]; // phase A: the Hilbert table (16-bit entries) lives here
+    __shared__ unsigned s_wsum[kOrderWaves];
+    __shared__ int s_over;
+    const OrderJob job = jobs[blockIdx.x];
+    const unsigned n = job.n;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    unsigned short* s_lut = reinterpret_cast<unsigned short*>(s_start);
+    for (unsigned k = tid; k < (unsigned)kOrderBins; k += kOrderThreads) {
+        s_lut[k] = hilbert_lut[k];
+#pragma unroll
+        for (int w = 0; w < kOrderWaves; ++w) s_cnt[w][k] = 0;
+    }
+    if (tid == 0) s_over = 0;
+    __syncthreads();
+    const unsigned chunk = ((n + kOrderThreads - 1) / kOrderThreads) * 64u; // points per wave, a multiple of 64
+    const unsigned w0 = min(n, wave * chunk), w1 = min(n, w0 + chunk);
+    const bool too_long = chunk > 65535u; // uniform: the 16-bit counters cannot hold a wave's run
+    if (!too_long) {
+        Pt3 nxt;
+        nxt.x = nxt.y = nxt.z = 0.f;
+        if (w0 + lane < w1) nxt = job.src[w0 + lane];
+        for (unsigned base = w0; base < w1; base += 64u) {
+            const unsigned i = base + lane;
+            const bool valid = i < w1;
+            const Pt3 p = nxt;
+            if (i + 64u < w1) nxt = job.src[i + 64u]; // next step's point is in flight while this one is ranked
+            const unsigned key = valid ? order_key(p, s_lut) : 0u;
+            unsigned long long grp = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 12; ++b) {
+                const bool bit = (key >> b) & 1u;
+                const unsigned long long bal = __ballot(bit);
+                grp &= bit ? bal : ~bal;
+            }
+            const unsigned below = (unsigned)__popcll(grp & ((1ull << lane) - 1ull)), size = (unsigned)__popcll(grp);
+            const unsigned c = s_cnt[wave][key]; // every lane of the group reads the counter before its last lane writes it back
+            if (valid && below + 1u == size) s_cnt[wave][key] = (unsigned short)(c + size);
+            if (valid) job.tmp[i] = key | ((c + below) << 12);
+        }
+    }
+    __syncthreads();
+    // exclusive prefix over (key, wave): every thread takes four consecutive keys
+    unsigned tot = 0;
+    int over = too_long ? 1 : 0;
+    unsigned t4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned key = tid * 4u + (unsigned)q;
+        unsigned run = 0;
+#pragma unroll
+        for (int w = 0; w < kOrderWaves; ++w) {
+            const unsigned c = s_cnt[w][key];
+            s_cnt[w][key] = (unsigned short)run;
+            if (run > 65535u) over = 1;
+            run += c;
+        }
+        t4[q] = tot;
+        tot += run;
+    }
+    unsigned inc = tot; // inclusive scan over the wavefront
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = (unsigned)__shfl_up((int)inc, off, 64);
+        if (lane >= (unsigned)off) inc += o;
+    }
+    if (lane == 63u) s_wsum[wave] = inc;
+    if (over) s_over = 1;
+    __syncthreads(); // also: the last read of the Hilbert table is behind us
+    unsigned wbase = 0;
+#pragma unroll
+    for (int w = 0; w < kOrderWaves; ++w) wbase += ((unsigned)w < wave) ? s_wsum[w] : 0u;
+    const unsigned ex = wbase + inc - tot;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s_start[tid * 4u + (unsigned)q] = ex + t4[q];
+    __syncthreads();
+    const bool identity = s_over != 0; // uniform
+    if (identity) {
+        for (unsigned i = tid; i < n; i += kOrderThreads) job.dst[i] = job.src[i];
+        return;
+    }
+    for (unsigned base = w0; base < w1; base += 128u) { // two steps per trip: four loads in flight per lane
+        const unsigned i0 = base + lane, i1 = base + 64u + lane;
+        const bool v0 = i0 < w1, v1 = i1 < w1;
+        Pt3 p0, p1;
+        unsigned d0 = 0, d1 = 0;
+        if (v0) { p0 = job.src[i0]; d0 = job.tmp[i0]; }
+        if (v1) { p1 = job.src[i1]; d1 = job.tmp[i1]; }
+        if (v0) job.dst[s_start[d0 & 4095u] + s_cnt[wave][d0 & 4095u] + (d0 >> 12)] = p0;
+        if (v1) job.dst[s_start[d1 & 4095u] + s_cnt[wave][d1 & 4095u] + (d1 >> 12)] = p1;
+    }
+}
+void launch_scan_order(hipStream_t s, const OrderJob* jobs, int n_jobs, const uint16_t* hilbert_lut) {
+    if (n_jobs > 0) hipLaunchKernelGGL(k_scan_order, dim3(n_jobs), dim3(kOrderThreads), 0, s, jobs, hilbert_lut);
+}
+// host-fed streams: the upload stream publishes how many scans have landed (after their ordering kernel, same stream)
+__global__ void k_publish_ready(StreamCtrl* ctrl, int ready) {
+    __hip_atomic_store(&ctrl->ready, ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void launch_publish_ready(hipStream_t s, StreamCtrl* ctrl, int ready) { hipLaunchKernelGGL(k_publish_ready, dim3(1), dim3(1), 0, s, ctrl, ready); }
+// host-fed streams start with every slot idle: the solve hands out registrations as their scans arrive
+__global__ void k_slots_idle(ScanDesc* scans, ScanState* st, int slots) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= slots) return;
+    scans[s].pts = nullptr; scans[s].n = 0; scans[s].n_total = 0;
+    st[s].done = 1;
+    st[s].reg = -1;
+}
+void launch_slots_idle(hipStream_t s, ScanDesc* scans, ScanState* st, int slots) {
+    hipLaunchKernelGGL(k_slots_idle, dim3((slots + 255) / 256), dim3(256), 0, s, scans, st, slots);
 }
 
 void launch_deskew(hipStream_t s, const float* xyz, const float* rel_time, uint32_t n, const DeskewDev& d, float* xyz_out) {

@@ -81,6 +81,12 @@ class Context:
         return dict(accumulate_launches=int(p.accumulate_launches), solve_steps=int(p.solve_steps),
                     accumulate_ms=float(p.accumulate_ms), solve_ms=float(p.solve_ms))
 
+    def measure_h2d(self, host_ptr, nbytes, reps=5):
+        """GB/s of a plain host-to-device copy from host_ptr on this box (the PCIe rate a host-fed stream sits under)."""
+        g = C.c_double(0.0)
+        check(_lib.lib().elm_ctx_measure_h2d(self._h, C.c_void_p(host_ptr), int(nbytes), int(reps), C.byref(g)), self._h, "elm_ctx_measure_h2d")
+        return g.value
+
     # ---- multi-GPU (RCCL over xGMI): one small all-reduce of the packed normal equations per iteration
     @staticmethod
     def comm_unique_id():
@@ -268,6 +274,28 @@ class Scan:
             pass
 
 
+class PinnedBuffer:
+    """Page-locked host memory (elm_host_alloc) viewed as a float32 numpy array."""
+
+    def __init__(self, n_floats):
+        self.ptr = _lib.lib().elm_host_alloc(4 * int(n_floats))
+        if not self.ptr:
+            raise ElmError("elm_host_alloc failed")
+        self.array = np.ctypeslib.as_array((C.c_float * int(n_floats)).from_address(self.ptr))
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            _lib.lib().elm_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def _result_dict(r, trace=None):
     d = dict(T=np.array(r.T).reshape(4, 4).T.copy(), is_success=bool(r.is_success), iterations=int(r.iterations),
              gate=int(r.gate), fitness_score=float(r.fitness_score), d_fitness=float(r.d_fitness),
@@ -345,6 +373,42 @@ class Registration:
         check(_lib.lib().elm_register_stream(self.ctx._h, voxel_map._handle(), arr, B, _dp(T0), C.byref(cfg), int(slots), res, tr),
               self.ctx._h, "elm_register_stream")
         if raw:  # the elm_reg_result array as the library filled it; results_from_raw() turns it into dicts later
+            return res
+        return [_result_dict(res[b], tr[b * _lib.MAX_ITER_TRACE:(b + 1) * _lib.MAX_ITER_TRACE] if trace else None) for b in range(B)]
+
+    @staticmethod
+    def pack_host_inputs(scans_host, initial_guesses, pinned=None):
+        """Marshal HOST scans for RunRegisterStreamHost once: (pointer array, point counts, column-major guesses, keep-alive).
+
+        pinned: optional PinnedBuffer holding all scans back to back (page-locked: the DMA engines read it directly)."""
+        B = len(scans_host)
+        keep = [np.ascontiguousarray(s, dtype=np.float32).reshape(-1, 3) for s in scans_host]
+        npts = (C.c_uint32 * B)(*[k.shape[0] for k in keep])
+        if pinned is not None:
+            o = 0
+            ptrs = []
+            for k in keep:
+                pinned.array[o:o + k.size] = k.ravel()
+                ptrs.append(pinned.ptr + 4 * o)
+                o += k.size
+            keep = [pinned]
+        else:
+            ptrs = [k.ctypes.data for k in keep]
+        arr = (C.c_void_p * B)(*ptrs)
+        T0 = np.ascontiguousarray(np.asarray(initial_guesses, dtype=np.float64).reshape(-1, 4, 4).transpose(0, 2, 1)).reshape(-1)
+        return arr, npts, T0, keep
+
+    def RunRegisterStreamHost(self, packed, voxel_map, slots=32, m_config=None, trace=False, raw=False):
+        """elm_register_stream_host: the scans are in host memory when the call starts; uploads, device-side ordering and the
+        iterations of earlier registrations overlap.  packed = pack_host_inputs(...)."""
+        cfg = m_config if m_config is not None else self.config_
+        arr, npts, T0, _keep = packed
+        B = len(arr)
+        res = (RegResult * B)()
+        tr = (IterTrace * (_lib.MAX_ITER_TRACE * B))() if trace else None
+        check(_lib.lib().elm_register_stream_host(self.ctx._h, voxel_map._handle(), arr, npts, B, _dp(T0), C.byref(cfg), int(slots), res, tr),
+              self.ctx._h, "elm_register_stream_host")
+        if raw:
             return res
         return [_result_dict(res[b], tr[b * _lib.MAX_ITER_TRACE:(b + 1) * _lib.MAX_ITER_TRACE] if trace else None) for b in range(B)]
 

@@ -165,11 +165,11 @@ int elm_map_download_voxels(const elm_map* map, int32_t* key3, int32_t* npts, do
 int elm_map_find_ground_height(const elm_map* map, double x, double y, double* ground_z, int* found);
 
 /* ---------------------------------------------------------------- scans --------------------------- */
-/* Upload one source scan (sensor frame, float32 xyz; PointStruct.local == .pose, pcm.hpp:205-220).
+/* Upload one source scan (sensor frame, packed float32 xyz, 12 bytes per point; PointStruct.local == .pose, pcm.hpp:205-220).
  * n_total is the size of the whole scan when this context holds only a shard of it (multi-GPU; the overlap
- * ratio of reg.cpp:351 is taken against n_total); pass n_total = n on one GPU.  The points are re-ordered along a
- * Hilbert curve over coarse sensor-frame cells for locality (source order is not contractual: the reference's own
- * VoxelDownsample emits unordered_map order, vhm.hpp:278-280). */
+ * ratio of reg.cpp:351 is taken against n_total); pass n_total = n on one GPU.  The points go to HBM as they are and are
+ * re-ordered ON THE DEVICE along a Hilbert curve over 2 m sensor-frame cells for locality (source order is not contractual:
+ * the reference's own VoxelDownsample emits unordered_map order, vhm.hpp:278-280; ELM_SCAN_ORDER=none keeps the caller's). */
 int elm_scan_upload(elm_ctx* ctx, const float* xyz, size_t n, size_t n_total, elm_scan** out);
 void elm_scan_destroy(elm_scan* scan);
 size_t elm_scan_size(const elm_scan* scan);
@@ -193,13 +193,29 @@ int elm_register_batch(elm_ctx* ctx, const elm_map* map, elm_scan* const* scans,
 /* Continuous batching: `count` registrations through `slots` device slots.  Finished slots are refilled on the device with
  * the next pending registration after every ICP iteration, so every launch stays full until the queue is empty (throughput
  * mode for many more registrations than can usefully iterate in lockstep).  Results are bit-identical to
- * elm_register_batch / elm_register on the same inputs (which slot serves a registration may vary from call to call on one
+ * elm_register_batch on the same resident scans (which slot serves a registration may vary from call to call on one
  * rank -- the solve kernel hands out the queue positions -- but a registration's arithmetic does not depend on its slot; with a
- * communicator attached the assignment is in slot order, identical on every rank).  trace: NULL or count*ELM_MAX_ITER_TRACE
- * entries. */
+ * communicator attached the assignment is in slot order, identical on every rank).  elm_register keeps the caller's point order
+ * while elm_scan_upload orders the points: the two agree up to the order of the summation (1e-9 on every sum), not bit for bit.
+ * trace: NULL or count*ELM_MAX_ITER_TRACE entries. */
 int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* const* scans, int count, const double* T0,
                         const elm_reg_config* cfg, int slots, elm_reg_result* results, elm_iter_trace* trace);
-/* Asynchronous halves of the above: enqueue everything on the context stream / wait and fetch results.  enqueue returns
+/* The same with the scans still in HOST memory when the call starts -- RunRegister's per-call contract (reg.cpp:274-290: the
+ * caller hands over a point vector): scan_xyz[i] = packed float32 xyz of registration i, n_pts[i] points.  Uploads (DMA on a copy
+ * stream, in groups of ~32 MB), the device-side ordering kernel and the ICP iterations of the registrations that have already
+ * arrived overlap; a slot starts a registration as soon as its scan has landed.  Page-locked sources (elm_host_alloc or
+ * hipHostRegister) are read by the DMA engines directly and reach the PCIe rate; pageable ones are staged by the runtime.  HBM
+ * needed: every scan of the call (12 bytes per point) + two staging sets.  Results are bit-identical to elm_register_stream on
+ * the same scans uploaded with elm_scan_upload.  One rank only: ELM_ERR_UNSUPPORTED with a communicator or hook attached. */
+int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const float* const* scan_xyz, const uint32_t* n_pts, int count,
+                             const double* T0, const elm_reg_config* cfg, int slots, elm_reg_result* results, elm_iter_trace* trace);
+/* page-locked host memory for the sources of elm_register_stream_host / elm_scan_upload (NULL on failure) */
+void* elm_host_alloc(size_t bytes);
+void elm_host_free(void* p);
+/* diagnostic: GB/s of one plain host-to-device copy of `bytes` from `host` on this box (median of reps) -- the PCIe rate a
+ * host-fed stream sits under */
+int elm_ctx_measure_h2d(elm_ctx* ctx, const void* host, size_t bytes, int reps, double* gb_per_s);
+/* Asynchronous halves of elm_register_batch: enqueue everything on the context stream / wait and fetch results.  enqueue returns
  * without waiting for the device on the first batch of a context; afterwards it polls the device-side count of still-iterating
  * scans (one 4-byte read-back where the previous batch finished, then every second iteration) so that it can stop enqueueing
  * iterations early -- i.e. it may block for the iterations enqueued so far.  Exactly one batch may be in flight per context. */

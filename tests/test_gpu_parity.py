@@ -363,6 +363,16 @@ def test_full_size_properties(ctx, oracle):
     refp = oracle.register(om, scan_n, T0, oracle.default_config(0))
     dt, dr = synth.pose_error(refp["T"], out[0]["T"])
     assert refp["iterations"] == out[0]["iterations"] and dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
+    # the host-fed stream (uploads + device-side ordering overlapped with the iterations): bit-identical to the resident one,
+    # from page-locked and from pageable sources
+    from elimaloc_amd.registration import PinnedBuffer
+    hosts = [scan_n if i == 0 else synth.make_scan(world, 131072, seed=2100 + i)[0] for i in range(40)]
+    pin = PinnedBuffer(sum(h.size for h in hosts))
+    for packed in (regp.pack_host_inputs(hosts, T0s, pinned=pin), regp.pack_host_inputs(hosts, T0s)):
+        fed = regp.RunRegisterStreamHost(packed, vm, slots=8)
+        for a_, b_ in zip(fed, out):
+            assert np.array_equal(a_["T"], b_["T"]) and a_["iterations"] == b_["iterations"] and a_["is_success"] == b_["is_success"]
+    pin.close()
 
 
 def test_rccl_single_rank_allreduce_path(ctx, oracle, world100k):
