@@ -87,7 +87,8 @@ struct elm_ctx {
     hipStream_t stream = nullptr;
     // host-fed streams / ordered uploads: uploads (DMA) and the scan-ordering kernel run beside the iterations on the compute stream
     hipStream_t copy_stream = nullptr, order_stream = nullptr, poll_stream = nullptr;
-    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_ordered[2] = {nullptr, nullptr}, ev_iter[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_iter[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> ev_groups; // host-fed streams: per upload group its "copied" and "ordered" events
     uint16_t* d_hilbert = nullptr; // Hilbert index of every cell of the ordering grid (kOrderCells^2 entries)
     DevBuf d_order_jobs, d_order_tmp, d_arena, d_raw;
     void* h_jobs = nullptr; // pinned: ordering job descriptors
@@ -246,8 +247,9 @@ extern "C" void elm_ctx_destroy(elm_ctx* ctx) {
     if (ctx->comm && g_rccl.comm_destroy) g_rccl.comm_destroy(ctx->comm);
     for (hipStream_t st : {ctx->copy_stream, ctx->order_stream, ctx->poll_stream})
         if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-    for (hipEvent_t e : {ctx->ev_copied[0], ctx->ev_copied[1], ctx->ev_ordered[0], ctx->ev_ordered[1], ctx->ev_iter[0], ctx->ev_iter[1], ctx->ev_iter[2], ctx->ev_iter[3]})
+    for (hipEvent_t e : {ctx->ev_iter[0], ctx->ev_iter[1], ctx->ev_iter[2], ctx->ev_iter[3]})
         if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->ev_groups) (void)hipEventDestroy(e);
     if (ctx->d_hilbert) (void)hipFree(ctx->d_hilbert);
     if (ctx->h_jobs) (void)hipHostFree(ctx->h_jobs);
     DevBuf* bufs[] = {&ctx->d_scans, &ctx->d_state, &ctx->d_partials, &ctx->d_sums, &ctx->d_T0, &ctx->d_trace, &ctx->d_stage_pts, &ctx->d_active, &ctx->d_queue, &ctx->d_ds,
@@ -1774,7 +1776,7 @@ static int ensure_side_streams(elm_ctx* ctx) {
     if (!ctx->copy_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     if (!ctx->order_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->order_stream, hipStreamNonBlocking));
     if (!ctx->poll_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->poll_stream, hipStreamNonBlocking));
-    for (hipEvent_t* e : {&ctx->ev_copied[0], &ctx->ev_copied[1], &ctx->ev_ordered[0], &ctx->ev_ordered[1], &ctx->ev_iter[0], &ctx->ev_iter[1], &ctx->ev_iter[2], &ctx->ev_iter[3]})
+    for (hipEvent_t* e : {&ctx->ev_iter[0], &ctx->ev_iter[1], &ctx->ev_iter[2], &ctx->ev_iter[3]})
         if (!*e) HIPCHK(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
     return ELM_OK;
 }
@@ -1923,7 +1925,7 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
     ScanDesc* dsc = (ScanDesc*)ctx->d_scans.p;
     int* d_active = (int*)ctx->d_active.p;
     (void)hipGetLastError();
-    launch_slots_idle(ctx->stream, dsc, st, S);
+    launch_slots_idle(ctx->stream, dsc, st, S, cap_blocks);
     // the side streams start behind the control block's initialisation (and behind whatever the compute stream still reads from
     // the arena / staging of an earlier call)
     HF_CHK(hipEventRecord(ctx->ev_iter[0], ctx->stream));
@@ -1932,29 +1934,38 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
     ctx->events_used = 0;
     const OrderJob* d_jobs = (const OrderJob*)ctx->d_order_jobs.p;
     int g_enq = 0;
+    // one pair of events per upload group (a pool that only grows): group g's "copied" and "ordered"
+    while ((int)ctx->ev_groups.size() < 2 * n_groups) {
+        hipEvent_t e;
+        HF_CHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->ev_groups.push_back(e);
+    }
+    const bool serial = getenv("ELM_HOSTFED_SERIAL") != nullptr; // developer switch: uploads and ordering on the compute stream itself
+    hipStream_t copy_stream = serial ? ctx->stream : ctx->copy_stream, order_stream = serial ? ctx->stream : ctx->order_stream;
     auto enqueue_group = [&](int g) -> hipError_t {
         const int set = g & 1, r0 = g * G, r1 = std::min(count, r0 + G);
+        hipEvent_t ev_copied = ctx->ev_groups[2 * g], ev_ordered = ctx->ev_groups[2 * g + 1];
         hipError_t e = hipSuccess;
-        if (g >= 2) e = hipStreamWaitEvent(ctx->copy_stream, ctx->ev_ordered[set], 0); // the set's previous ordering kernel has read it
+        if (g >= 2) e = hipStreamWaitEvent(copy_stream, ctx->ev_groups[2 * (g - 2) + 1], 0); // the set's previous ordering kernel has read it
         char* base = (char*)ctx->d_raw.p + (size_t)set * G * scan_stride;
         // one DMA for the whole group when it is contiguous in host memory and in the staging set
         bool contiguous = (size_t)max_n * sizeof(Pt3) == scan_stride;
         for (int r = r0; r < r1 && contiguous; ++r)
             contiguous = n_pts[r] == max_n && (r == r0 || scan_xyz[r] == scan_xyz[r - 1] + 3 * (size_t)max_n);
         if (contiguous) {
-            if (e == hipSuccess) e = hipMemcpyAsync(base, scan_xyz[r0], (size_t)(r1 - r0) * scan_stride, hipMemcpyHostToDevice, ctx->copy_stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(base, scan_xyz[r0], (size_t)(r1 - r0) * scan_stride, hipMemcpyHostToDevice, copy_stream);
         } else {
             for (int r = r0; r < r1 && e == hipSuccess; ++r)
-                if (n_pts[r]) e = hipMemcpyAsync(base + (size_t)(r - r0) * scan_stride, scan_xyz[r], (size_t)n_pts[r] * sizeof(Pt3), hipMemcpyHostToDevice, ctx->copy_stream);
+                if (n_pts[r]) e = hipMemcpyAsync(base + (size_t)(r - r0) * scan_stride, scan_xyz[r], (size_t)n_pts[r] * sizeof(Pt3), hipMemcpyHostToDevice, copy_stream);
         }
-        if (e == hipSuccess) e = hipEventRecord(ctx->ev_copied[set], ctx->copy_stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->order_stream, ctx->ev_copied[set], 0);
+        if (e == hipSuccess) e = hipEventRecord(ev_copied, copy_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(order_stream, ev_copied, 0);
         if (e == hipSuccess) {
-            launch_scan_order(ctx->order_stream, d_jobs + r0, r1 - r0, ctx->d_hilbert);
-            launch_publish_ready(ctx->order_stream, d_ctrl, r1);
+            launch_scan_order(order_stream, d_jobs + r0, r1 - r0, ctx->d_hilbert);
+            launch_publish_ready(order_stream, d_ctrl, r1);
             e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipEventRecord(ctx->ev_ordered[set], ctx->order_stream);
+        if (e == hipSuccess) e = hipEventRecord(ev_ordered, order_stream);
         return e;
     };
     // Iterations are enqueued a few ahead of the device (an event per iteration throttles the host); the number of finished

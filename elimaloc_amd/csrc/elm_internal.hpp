@@ -235,7 +235,7 @@ struct OrderJob {
 };
 void launch_scan_order(hipStream_t s, const OrderJob* jobs, int n_jobs, const uint16_t* hilbert_lut);
 void launch_publish_ready(hipStream_t s, StreamCtrl* ctrl, int ready);
-void launch_slots_idle(hipStream_t s, ScanDesc* scans, ScanState* st, int slots);
+void launch_slots_idle(hipStream_t s, ScanDesc* scans, ScanState* st, int slots, unsigned cap_blocks);
 constexpr int kOrderCells = 64; // cells per axis of the ordering grid (2 m cells: +-64 m around the sensor, clamped beyond)
 void launch_deskew(hipStream_t s, const float* xyz, const float* rel_time, uint32_t n, const DeskewDev& d,
                    float* xyz_out);

@@ -2828,15 +2828,16 @@ __global__ void k_publish_ready(StreamCtrl* ctrl, int ready) {
 }
 void launch_publish_ready(hipStream_t s, StreamCtrl* ctrl, int ready) { hipLaunchKernelGGL(k_publish_ready, dim3(1), dim3(1), 0, s, ctrl, ready); }
 // host-fed streams start with every slot idle: the solve hands out registrations as their scans arrive
-__global__ void k_slots_idle(ScanDesc* scans, ScanState* st, int slots) {
+__global__ void k_slots_idle(ScanDesc* scans, ScanState* st, int slots, unsigned cap_blocks) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= slots) return;
     scans[s].pts = nullptr; scans[s].n = 0; scans[s].n_total = 0;
+    scans[s].blk_begin = cap_blocks * (unsigned)s; scans[s].blk_end = cap_blocks * (unsigned)(s + 1); // every slot owns cap_blocks workgroups
     st[s].done = 1;
     st[s].reg = -1;
 }
-void launch_slots_idle(hipStream_t s, ScanDesc* scans, ScanState* st, int slots) {
-    hipLaunchKernelGGL(k_slots_idle, dim3((slots + 255) / 256), dim3(256), 0, s, scans, st, slots);
+void launch_slots_idle(hipStream_t s, ScanDesc* scans, ScanState* st, int slots, unsigned cap_blocks) {
+    hipLaunchKernelGGL(k_slots_idle, dim3((slots + 255) / 256), dim3(256), 0, s, scans, st, slots, cap_blocks);
 }
 
 void launch_deskew(hipStream_t s, const float* xyz, const float* rel_time, uint32_t n, const DeskewDev& d, float* xyz_out) {
