@@ -16,6 +16,7 @@
 #include <thread>
 #include <vector>
 
+#include "elm_hostapi.hpp"
 #include "elm_internal.hpp"
 #include "elm_la.hpp"
 
@@ -115,6 +116,9 @@ struct elm_ctx {
     int batch = 0;
     bool want_trace = false;
     bool in_flight = false;
+    void* ds_clean_ptr = nullptr;     // the downsample hash table at this address ...
+    unsigned ds_clean_cap_log2 = 0;   // ... of this size is all ones (every pass cleans up the slots it touched)
+    bool results_ready = false; // the last early-stop check of the in-flight batch found every scan finished: h_state holds the final states
     RegParams rp{};
     int scan_order = 1;  // 1: order uploaded scans along a Hilbert curve (elm_scan_upload), 0: keep the caller's order (ELM_SCAN_ORDER=none)
     int kernel_mode = 4; // accumulate kernels: 4 = dense cell grid, or cell-indexed neighbourhood lists when the grid does not fit
@@ -1289,9 +1293,29 @@ static int scan_upload_impl(elm_ctx* ctx, const float* xyz, size_t n, size_t n_t
     s->n_total = (uint32_t)n_total;
     const bool do_order = order && ctx->scan_order && n > 1;
     hipError_t e = hipSuccess;
-    if (n) memcpy(ctx->h_stage, xyz, bytes); // pinned staging: the DMA engine reads it directly (a pageable source is staged by the runtime in small pieces)
+    // A page-locked source (elm_host_alloc, hipHostMalloc, hipHostRegister) is read by the DMA engine where it lies.  A pageable one
+    // goes through the context's pinned staging buffer in pieces, so that the copy of piece k + 1 overlaps the DMA of piece k
+    // (the runtime's own staging of pageable memory is several times slower).
+    bool pinned_src = false;
+    if (n) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, xyz) == hipSuccess && attr.type == hipMemoryTypeHost) pinned_src = true;
+        else (void)hipGetLastError();
+    }
+    auto upload = [&](void* dst) -> hipError_t {
+        if (!n) return hipSuccess;
+        if (pinned_src) return hipMemcpyAsync(dst, xyz, bytes, hipMemcpyHostToDevice, ctx->stream);
+        const size_t piece = (size_t)384 << 10;
+        hipError_t ee = hipSuccess;
+        for (size_t o = 0; o < bytes && ee == hipSuccess; o += piece) {
+            const size_t len = std::min(piece, bytes - o);
+            memcpy((char*)ctx->h_stage + o, (const char*)xyz + o, len);
+            ee = hipMemcpyAsync((char*)dst + o, (const char*)ctx->h_stage + o, len, hipMemcpyHostToDevice, ctx->stream);
+        }
+        return ee;
+    };
     if (!do_order) {
-        if (n) e = hipMemcpyAsync(s->d_pts, ctx->h_stage, bytes, hipMemcpyHostToDevice, ctx->stream);
+        e = upload(s->d_pts);
     } else {
         rc = ensure_hilbert(ctx);
         if (rc == ELM_OK) rc = dev_reserve(ctx, ctx->d_raw, bytes);
@@ -1305,7 +1329,7 @@ static int scan_upload_impl(elm_ctx* ctx, const float* xyz, size_t n, size_t n_t
             hj = (OrderJob*)ctx->h_jobs;
         }
         hj->src = (const Pt3*)ctx->d_raw.p; hj->dst = s->d_pts; hj->tmp = (uint32_t*)ctx->d_order_tmp.p; hj->n = (uint32_t)n; hj->_pad = 0;
-        e = hipMemcpyAsync(ctx->d_raw.p, ctx->h_stage, bytes, hipMemcpyHostToDevice, ctx->stream);
+        e = upload(ctx->d_raw.p);
         if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_order_jobs.p, hj, sizeof(OrderJob), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) {
             (void)hipGetLastError();
@@ -1413,8 +1437,10 @@ static int prof_collect(elm_ctx* ctx) {
     return ELM_OK;
 }
 
-extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_scan* const* scans, int batch,
-                                          const double* T0, const elm_reg_config* cfg, int want_trace) {
+// n_dev != nullptr (batch == 1): the scan's size lives in device memory (produced by the downsample kernels on this stream);
+// scans[0]->n is its upper bound (grid size).  The result's point counts then come from the device state.
+static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const* scans, int batch, const double* T0, const elm_reg_config* cfg,
+                              int want_trace, const unsigned* n_dev) {
     if (!ctx || !map || !scans || batch <= 0 || !T0 || !cfg) return ELM_ERR_INVALID;
     if (map->ctx != ctx) return ELM_ERR_INVALID;
     if (cfg->use_radar_cov) return ELM_ERR_UNSUPPORTED;
@@ -1453,12 +1479,16 @@ extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_
         hd[b].blk_end = blocks;
     }
     memcpy(hT, T0, (size_t)batch * 16 * sizeof(double));
+    // the counter of still-iterating scans sits right behind the states: an early-stop check reads both with ONE copy, and when the
+    // counter is zero the final states are already on the host
+    const size_t st_bytes = (size_t)batch * sizeof(ScanState);
     if ((rc = dev_reserve(ctx, ctx->d_scans, (size_t)batch * sizeof(ScanDesc))) != ELM_OK) return rc;
     if ((rc = dev_reserve(ctx, ctx->d_T0, (size_t)batch * 16 * sizeof(double))) != ELM_OK) return rc;
-    if ((rc = dev_reserve(ctx, ctx->d_state, (size_t)batch * sizeof(ScanState))) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_state, st_bytes + 64)) != ELM_OK) return rc;
     if ((rc = dev_reserve(ctx, ctx->d_partials, (size_t)std::max<uint32_t>(blocks, 1) * kSums * sizeof(double))) != ELM_OK) return rc;
     if ((rc = dev_reserve(ctx, ctx->d_sums, (size_t)batch * kSums * sizeof(double))) != ELM_OK) return rc;
-    if ((rc = pinned_reserve(ctx, &ctx->h_state, &ctx->h_state_cap, (size_t)batch * sizeof(ScanState))) != ELM_OK) return rc;
+    if ((rc = pinned_reserve(ctx, &ctx->h_state, &ctx->h_state_cap, st_bytes + 64)) != ELM_OK) return rc;
+    ctx->results_ready = false;
     elm_iter_trace* d_trace = nullptr;
     if (want_trace) {
         const size_t tb = (size_t)batch * ELM_MAX_ITER_TRACE * sizeof(elm_iter_trace);
@@ -1467,8 +1497,11 @@ extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_
         HIPCHK(ctx, hipMemsetAsync(ctx->d_trace.p, 0, tb, ctx->stream));
         d_trace = (elm_iter_trace*)ctx->d_trace.p;
     }
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_scans.p, hd, (size_t)batch * sizeof(ScanDesc), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_T0.p, hT, (size_t)batch * 16 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    const bool packed_init = batch <= kInitPack;
+    if (!packed_init) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_scans.p, hd, (size_t)batch * sizeof(ScanDesc), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_T0.p, hT, (size_t)batch * 16 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
 
     RegParams rp;
     rp.th = cfg->max_search_dist;
@@ -1497,12 +1530,20 @@ extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_
     }
     ScanState* st = (ScanState*)ctx->d_state.p;
     const ScanDesc* dsc = (const ScanDesc*)ctx->d_scans.p;
-    if ((rc = dev_reserve(ctx, ctx->d_active, 256)) != ELM_OK) return rc;
-    if (!ctx->h_active) HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_active, 64, hipHostMallocDefault));
-    int* d_active = (int*)ctx->d_active.p;
-    HIPCHK(ctx, hipMemsetAsync(d_active, 0, sizeof(int), ctx->stream));
+    int* d_active = (int*)((char*)ctx->d_state.p + st_bytes);
     (void)hipGetLastError();
-    launch_init_state(ctx->stream, st, (const double*)ctx->d_T0.p, batch, map_empty ? 1 : 0, d_active);
+    if (packed_init) { // descriptors and guesses as kernel arguments: no H2D copies, no memset
+        InitPack pack;
+        memset(&pack, 0, sizeof(pack));
+        for (int b = 0; b < batch; ++b) {
+            pack.d[b] = hd[b];
+            memcpy(pack.T0[b], T0 + (size_t)b * 16, 16 * sizeof(double));
+        }
+        launch_init_pack(ctx->stream, (ScanDesc*)ctx->d_scans.p, st, pack, batch, map_empty ? 1 : 0, d_active, n_dev);
+    } else {
+        HIPCHK(ctx, hipMemsetAsync(d_active, 0, sizeof(int), ctx->stream));
+        launch_init_state(ctx->stream, st, (const double*)ctx->d_T0.p, batch, map_empty ? 1 : 0, d_active);
+    }
     const bool distributed = (ctx->comm != nullptr) || (ctx->hook != nullptr);
     ctx->events_used = 0;
     if (!map_empty) {
@@ -1521,15 +1562,18 @@ extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_
             const int done_iters = it + 1;
             if (ctx->iter_hint > 0 && done_iters >= ctx->iter_hint && done_iters < cfg->max_iteration &&
                 ((done_iters - ctx->iter_hint) % 2) == 0) {
-                HIPCHK(ctx, hipMemcpyAsync(ctx->h_active, d_active, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipMemcpyAsync(ctx->h_state, st, st_bytes + 64, hipMemcpyDeviceToHost, ctx->stream)); // states + counter (+ the downsample totals)
                 HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-                if (*ctx->h_active == 0) break;
+                if (*(const int*)((const char*)ctx->h_state + st_bytes) == 0) {
+                    ctx->results_ready = true; // every scan has finished: these ARE the final states
+                    break;
+                }
             }
         }
         if ((rc = prof_mark(ctx)) != ELM_OK) return rc;
     }
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_state, st, (size_t)batch * sizeof(ScanState), hipMemcpyDeviceToHost, ctx->stream));
+    if (!ctx->results_ready) HIPCHK(ctx, hipMemcpyAsync(ctx->h_state, st, st_bytes + 64, hipMemcpyDeviceToHost, ctx->stream));
     if (want_trace)
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_trace, ctx->d_trace.p, (size_t)batch * ELM_MAX_ITER_TRACE * sizeof(elm_iter_trace),
                                    hipMemcpyDeviceToHost, ctx->stream));
@@ -1537,6 +1581,10 @@ extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_
     ctx->want_trace = want_trace != 0;
     ctx->in_flight = true;
     return ELM_OK;
+}
+extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_scan* const* scans, int batch,
+                                          const double* T0, const elm_reg_config* cfg, int want_trace) {
+    return batch_enqueue_impl(ctx, map, scans, batch, T0, cfg, want_trace, nullptr);
 }
 
 static void state_to_result(const ScanState& h, const RegParams& rp, elm_reg_result& r) {
@@ -1561,7 +1609,7 @@ extern "C" int elm_register_batch_finish(elm_ctx* ctx, elm_reg_result* results, 
     if (!ctx || !ctx->in_flight) return ELM_ERR_INVALID;
     ctx->in_flight = false;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->results_ready || ctx->want_trace || ctx->profiling) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     {
         int prc = prof_collect(ctx);
         if (prc != ELM_OK) return prc;
@@ -2092,6 +2140,50 @@ extern "C" int elm_deskew(elm_ctx* ctx, const float* xyz, const float* rel_time,
     return ELM_OK;
 }
 
+// VoxelHashMap::VoxelDownsample (vhm.hpp:260-283) of `d_und` (n undistorted points in HBM) into a fresh scan, on the context
+// stream, no host wait.  {kept points, "a key does not pack" flag} land in device memory right behind the state of a one-scan
+// batch, so the registration's own read-back brings them to the host.  The hash table is left clean by the pass itself.
+static int downsample_enqueue(elm_ctx* ctx, const float* d_und, size_t n, double voxel_size, elm_scan** sc_out, unsigned** d_total_out) {
+    int rc;
+    unsigned cap_log2 = 6;
+    while (((size_t)1 << cap_log2) < 2 * std::max<size_t>(n, 1)) ++cap_log2;
+    const size_t cap = (size_t)1 << cap_log2, nb = (n + 1023) / 1024;
+    const size_t bytes = cap * 12 + std::max<size_t>(n, 1) * 4 + (nb + 1) * 4 + 64;
+    if ((rc = dev_reserve(ctx, ctx->d_ds, bytes)) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_state, sizeof(ScanState) + 64)) != ELM_OK) return rc;
+    char* base = (char*)ctx->d_ds.p;
+    unsigned long long* d_table = (unsigned long long*)base;
+    unsigned* d_first = (unsigned*)(base + cap * 8);
+    unsigned* d_slot = d_first + cap;
+    unsigned* d_bcount = d_slot + std::max<size_t>(n, 1);
+    unsigned* d_total = (unsigned*)((char*)ctx->d_state.p + sizeof(ScanState) + 16); // [0] kept points, [1] overflow flag
+    elm_scan* sc = nullptr;
+    if ((rc = scan_alloc(ctx, n, &sc)) != ELM_OK) return rc;
+    hipError_t e = hipSuccess;
+    const bool clean = ctx->ds_clean_ptr == ctx->d_ds.p && ctx->ds_clean_cap_log2 == cap_log2;
+    ctx->ds_clean_ptr = nullptr; // dirty until this pass has cleaned up after itself
+    if (!clean) e = hipMemsetAsync(d_table, 0xFF, cap * 12, ctx->stream); // keys and first indices: all ones
+    if (e == hipSuccess) e = hipMemsetAsync(d_total, 0, 8, ctx->stream);
+    if (e == hipSuccess && n) {
+        (void)hipGetLastError();
+        launch_voxel_downsample(ctx->stream, d_und, (uint32_t)n, voxel_size, d_table, d_first, cap_log2, d_slot, d_bcount, d_total,
+                                (int*)(d_total + 1), sc->d_pts);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) {
+        ctx->last_error = std::string("downsample: ") + hipGetErrorString(e);
+        elm_scan_destroy(sc);
+        return ELM_ERR_DEVICE;
+    }
+    ctx->ds_clean_ptr = ctx->d_ds.p;
+    ctx->ds_clean_cap_log2 = cap_log2;
+    sc->n = (uint32_t)n; // upper bound until the host has read the kept count
+    sc->n_total = (uint32_t)n;
+    *sc_out = sc;
+    *d_total_out = d_total;
+    return ELM_OK;
+}
+
 // DeskewPointCloud's per-point loop + VoxelHashMap::VoxelDownsample fused on the device: the undistorted cloud never leaves
 // HBM, what comes out is a resident scan (the kept points in input order) ready for elm_register_batch.
 extern "C" int elm_deskew_downsample(elm_ctx* ctx, const float* xyz, const float* rel_time, size_t n, const elm_deskew_tables* tab,
@@ -2106,34 +2198,12 @@ extern "C" int elm_deskew_downsample(elm_ctx* ctx, const float* xyz, const float
     if (n) {
         if ((rc = deskew_enqueue(ctx, xyz, rel_time, n, tab, &d_und)) != ELM_OK) return rc;
     }
-    // table of 2^cap_log2 >= 2 n slots: keys (8 B) + first index (4 B); per point: slot (4 B); block counts; total + overflow
-    unsigned cap_log2 = 6;
-    while (((size_t)1 << cap_log2) < 2 * std::max<size_t>(n, 1)) ++cap_log2;
-    const size_t cap = (size_t)1 << cap_log2, nb = (n + 1023) / 1024;
-    const size_t bytes = cap * 12 + std::max<size_t>(n, 1) * 4 + (nb + 1) * 4 + 64;
-    if ((rc = dev_reserve(ctx, ctx->d_ds, bytes)) != ELM_OK) return rc;
-    char* base = (char*)ctx->d_ds.p;
-    unsigned long long* d_table = (unsigned long long*)base;
-    unsigned* d_first = (unsigned*)(base + cap * 8);
-    unsigned* d_slot = d_first + cap;
-    unsigned* d_bcount = d_slot + std::max<size_t>(n, 1);
-    unsigned* d_total = d_bcount + nb + 1; // [0] kept points, [1] overflow flag
     elm_scan* sc = nullptr;
-    if ((rc = scan_alloc(ctx, n, &sc)) != ELM_OK) return rc;
-    hipError_t e = hipSuccess;
+    unsigned* d_total = nullptr;
+    if ((rc = downsample_enqueue(ctx, d_und, n, voxel_size, &sc, &d_total)) != ELM_OK) return rc;
     unsigned h_total[2] = {0, 0};
-    if (n) {
-        e = hipMemsetAsync(d_table, 0xFF, cap * 12, ctx->stream); // keys and first indices: all ones
-        if (e == hipSuccess) e = hipMemsetAsync(d_total, 0, 8, ctx->stream);
-        if (e == hipSuccess) {
-            (void)hipGetLastError();
-            launch_voxel_downsample(ctx->stream, d_und, (uint32_t)n, voxel_size, d_table, d_first, cap_log2, d_slot, d_bcount, d_total,
-                                    (int*)(d_total + 1), sc->d_pts);
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = hipMemcpyAsync(h_total, d_total, 8, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    }
+    hipError_t e = hipMemcpyAsync(h_total, d_total, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess || h_total[1]) {
         ctx->last_error = e != hipSuccess ? std::string("deskew + downsample: ") + hipGetErrorString(e)
                                           : "a voxel key does not fit the packed device table (|coordinate / voxel size| >= 2^20)";
@@ -2145,6 +2215,67 @@ extern "C" int elm_deskew_downsample(elm_ctx* ctx, const float* xyz, const float
     *scan_out = sc;
     return ELM_OK;
 }
+
+// ---- the device pass of the node callback (elm_glue.cpp) ---------------------------------------------------------------------
+namespace elm_host {
+// page-locked scratch of the context: the callback filters the raw cloud straight into it, laid out as the device wants it
+// ([kCbTableBytes of deskew tables][xyz]), so that one DMA moves tables and points
+void* callback_staging(elm_ctx* ctx, size_t bytes) {
+    if (!ctx || hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+    if (pinned_reserve(ctx, &ctx->h_stage, &ctx->h_stage_cap, std::max<size_t>(bytes, 4096)) != ELM_OK) return nullptr;
+    return ctx->h_stage;
+}
+// DeskewPoint for every point -> VoxelDownsample -> RunRegister in ONE device pass: DMA of [tables | xyz] and of the per-point
+// times, k_deskew, the k_ds_* kernels, k_init_pack (the scan's size stays on the device) and the ICP iterations are enqueued
+// back to back; the host waits once, for the result.  stage = callback_staging(): tables at 0 (time, rot_x, rot_y, rot_z, 2000
+// doubles each), xyz at kCbTableBytes.  *unpackable = 1: a voxel key does not fit the device table -> the caller's host path.
+int callback_register(elm_ctx* ctx, const elm_map* map, const void* stage, const float* rel_time, size_t n, const elm_deskew_tables* tab,
+                      double voxel_size, const double T0[16], const elm_reg_config* cfg, elm_reg_result* result, uint64_t* n_source,
+                      int* unpackable) {
+    if (!ctx || !map || !stage || stage != ctx->h_stage || !rel_time || !tab || !T0 || !cfg || !result || !n_source || !unpackable || n == 0 ||
+        n > 0x7FFFFFFFull)
+        return ELM_ERR_INVALID;
+    *unpackable = 0;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    const size_t pts_bytes = n * 3 * sizeof(float);
+    if ((rc = dev_reserve(ctx, ctx->d_stage_pts, kCbTableBytes + n * 7 * sizeof(float) + 64)) != ELM_OK) return rc;
+    char* base = (char*)ctx->d_stage_pts.p;
+    double* d_tab = (double*)base;
+    float* d_xyz = (float*)(base + kCbTableBytes);
+    float* d_time = d_xyz + 3 * n;
+    float* d_out = d_time + n;
+    HIPCHK(ctx, hipMemcpyAsync(base, stage, kCbTableBytes + pts_bytes, hipMemcpyHostToDevice, ctx->stream));
+    const float* d_und = d_xyz; // run_deskew = 0: the cloud as it is (pcm.cpp:513-525)
+    if (tab->b_run_deskew) {
+        HIPCHK(ctx, hipMemcpyAsync(d_time, rel_time, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        DeskewDev d;
+        d.time_scan_cur = tab->d_time_scan_cur;
+        d.time_scan_end = tab->d_time_scan_end;
+        d.imu_pointer_cur = tab->i_imu_pointer_cur;
+        d.odom_available = tab->b_is_odom_available;
+        d.incre_x = tab->f_odom_incre_x; d.incre_y = tab->f_odom_incre_y; d.incre_z = tab->f_odom_incre_z;
+        d._pad = 0.f;
+        d.imu_time = d_tab; d.rot_x = d_tab + kCbTableRows; d.rot_y = d_tab + 2 * kCbTableRows; d.rot_z = d_tab + 3 * kCbTableRows;
+        (void)hipGetLastError();
+        launch_deskew(ctx->stream, d_xyz, d_time, (uint32_t)n, d, d_out);
+        HIPCHK(ctx, hipGetLastError());
+        d_und = d_out;
+    }
+    elm_scan* sc = nullptr;
+    unsigned* d_total = nullptr;
+    if ((rc = downsample_enqueue(ctx, d_und, n, voxel_size, &sc, &d_total)) != ELM_OK) return rc;
+    rc = batch_enqueue_impl(ctx, map, &sc, 1, T0, cfg, 0, d_total);
+    if (rc == ELM_OK) rc = elm_register_batch_finish(ctx, result, nullptr);
+    else (void)hipStreamSynchronize(ctx->stream);
+    elm_scan_destroy(sc);
+    if (rc != ELM_OK) return rc;
+    const unsigned* ht = (const unsigned*)((const char*)ctx->h_state + sizeof(ScanState) + 16);
+    *n_source = ht[0];
+    *unpackable = ht[1] ? 1 : 0;
+    return ELM_OK;
+}
+} // namespace elm_host
 
 namespace {
 // pcl::getTransformation (float) -- rotation Rz(yaw) Ry(pitch) Rx(roll) and translation

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/elimaloc_hip.h"
+#include "elm_hostapi.hpp"
 
 namespace {
 
@@ -335,13 +336,17 @@ extern "C" int elm_pcm_callback_point_cloud(elm_ctx* ctx, const elm_map* map, co
     memset(out, 0, sizeof(*out));
     stamp -= node->lidar_time_delay; // pcm.cpp:216-217
     if (n == 0) return ELM_OK;       // "Input Empty!" (pcm.cpp:226-229)
-    // per-thread scratch that only grows: no host allocation on the per-scan path after warm-up
-    static thread_local std::vector<float> fx, ft;
-    static thread_local std::vector<double> tab;
-    if (fx.size() < 3 * n) { fx.resize(3 * n); ft.resize(n); }
-    if (tab.size() < 4 * 2000) tab.resize(4 * 2000);
+    // The filtered cloud and the deskew tables are written straight into the context's page-locked staging buffer, laid out as
+    // the device wants them ([tables | xyz] then the per-point times): two DMAs per scan, no pageable copies.  Scratch only grows:
+    // no allocation on the per-scan path after warm-up.
+    char* stage = (char*)elm_host::callback_staging(ctx, elm_host::kCbTableBytes + n * 4 * sizeof(float) + 64);
+    if (!stage) return ELM_ERR_ALLOC;
+    double* tab = (double*)stage;
+    float* fx = (float*)(stage + elm_host::kCbTableBytes);
+    float* ft = fx + 3 * n;
+    const size_t TR = elm_host::kCbTableRows;
     size_t nf = 0;
-    int rc = elm_filter_points_by_distance(xyz, point_time, n, node->input_max_dist, fx.data(), ft.data(), &nf); // :235
+    int rc = elm_filter_points_by_distance(xyz, point_time, n, node->input_max_dist, fx, ft, &nf); // :235
     if (rc != ELM_OK) return rc;
     out->n_filtered = nf;
     if (nf == 0) return ELM_OK;
@@ -350,41 +355,40 @@ extern "C" int elm_pcm_callback_point_cloud(elm_ctx* ctx, const elm_map* map, co
     if (node->lidar_scan_time_end)
         for (size_t i = 0; i < nf; ++i) ft[i] -= front; // :483-485
     elm_deskew_tables tabs;
-    rc = elm_deskew_prepare(imu4, n_imu, odom14, n_odom, stamp, front, back, node->lidar_scan_time_end, node->run_deskew, tab.data(),
-                            tab.data() + 2000, tab.data() + 4000, tab.data() + 6000, 2000, &tabs);
+    rc = elm_deskew_prepare(imu4, n_imu, odom14, n_odom, stamp, front, back, node->lidar_scan_time_end, node->run_deskew, tab,
+                            tab + TR, tab + 2 * TR, tab + 3 * TR, TR, &tabs);
     if (rc != ELM_OK) return rc;
-    // Deskew + VoxelDownsample on the device (the undistorted cloud stays in HBM and becomes the registration source);
-    // ELM_CALLBACK=host, or voxel keys that do not pack, take the stage-by-stage host path with identical results.
+    // Deskew + VoxelDownsample + RunRegister in one device pass (the undistorted cloud stays in HBM and becomes the registration
+    // source, the host waits once); ELM_CALLBACK=host, or voxel keys that do not pack, take the stage-by-stage host path with
+    // identical results.
     static const bool host_path = [] { const char* e = getenv("ELM_CALLBACK"); return e && strcmp(e, "host") == 0; }();
     int ok = 0, success = 0;
     double fit = 0.0, cov6[36], syncd[16], T0[16];
     float sync[16];
-    elm_scan* dev_scan = nullptr;
-    rc = host_path ? ELM_ERR_UNSUPPORTED : elm_deskew_downsample(ctx, fx.data(), ft.data(), nf, &tabs, node->input_voxel_ds_m, &dev_scan, &ok);
+    if (!tabs.b_is_imu_available || !tabs.b_is_odom_available) return ELM_OK; // "Deskew fail!" (pcm.cpp:494-496, 238-241)
+    out->time_scan_end = tabs.d_time_scan_end;
+    rc = elm_get_interpolated_pose(odom14, n_odom, tabs.d_time_scan_end, sync, &ok); // :248-251 (a function of the odometry queue only)
+    if (rc != ELM_OK || !ok) return rc;
+    for (int i = 0; i < 16; ++i) syncd[i] = (double)sync[i];
+    mul4_cm(syncd, node->tf_ego_to_lidar, T0); // sync_lidar_pose (pcm.cpp:266)
+    int unpackable = 0;
+    rc = host_path ? ELM_ERR_UNSUPPORTED
+                   : elm_host::callback_register(ctx, map, stage, ft, nf, &tabs, node->input_voxel_ds_m, T0, reg, &out->result, &out->n_source, &unpackable);
+    if (rc == ELM_OK && unpackable) rc = ELM_ERR_UNSUPPORTED;
     if (rc == ELM_OK) {
-        if (!ok) return ELM_OK; // "Deskew fail!" (pcm.cpp:238-241)
-        out->time_scan_end = tabs.d_time_scan_end;
-        rc = elm_get_interpolated_pose(odom14, n_odom, tabs.d_time_scan_end, sync, &ok); // :248-251
-        if (rc != ELM_OK || !ok) { elm_scan_destroy(dev_scan); return rc; }
-        out->n_source = elm_scan_size(dev_scan);
-        for (int i = 0; i < 16; ++i) syncd[i] = (double)sync[i];
-        mul4_cm(syncd, node->tf_ego_to_lidar, T0); // sync_lidar_pose (pcm.cpp:266)
-        rc = elm_register_batch(ctx, map, &dev_scan, 1, T0, reg, &out->result, nullptr); // :280-282
-        elm_scan_destroy(dev_scan);
-        if (rc != ELM_OK) return rc;
         memcpy(out->pose_lidar, out->result.T, sizeof(out->pose_lidar));
         memcpy(cov6, out->result.local_cov, sizeof(cov6));
         success = out->result.is_success;
         fit = out->result.fitness_score;
     } else if (rc == ELM_ERR_UNSUPPORTED) {
+        // the staging buffer is about to be reused by elm_deskew / elm_register: take the inputs out of it first
+        std::vector<float> hx(fx, fx + 3 * nf), ht(ft, ft + nf);
+        std::vector<double> htab(tab, tab + 4 * TR);
+        tabs.vec_d_imu_time = htab.data(); tabs.vec_d_imu_rot_x = htab.data() + TR; tabs.vec_d_imu_rot_y = htab.data() + 2 * TR; tabs.vec_d_imu_rot_z = htab.data() + 3 * TR;
         std::vector<float> und(3 * nf);
-        rc = elm_deskew(ctx, fx.data(), ft.data(), nf, &tabs, und.data(), &ok);
+        rc = elm_deskew(ctx, hx.data(), ht.data(), nf, &tabs, und.data(), &ok);
         if (rc != ELM_OK) return rc;
         if (!ok) return ELM_OK; // "Deskew fail!" (pcm.cpp:238-241)
-        out->time_scan_end = tabs.d_time_scan_end;
-        rc = elm_get_interpolated_pose(odom14, n_odom, tabs.d_time_scan_end, sync, &ok); // :248-251
-        if (rc != ELM_OK) return rc;
-        if (!ok) return ELM_OK;
         std::vector<int64_t> keep(nf);
         size_t nk = 0;
         rc = elm_voxel_downsample(und.data(), nf, node->input_voxel_ds_m, keep.data(), &nk); // :257-258
@@ -395,8 +399,6 @@ extern "C" int elm_pcm_callback_point_cloud(elm_ctx* ctx, const elm_map* map, co
             src[3 * k] = und[3 * i]; src[3 * k + 1] = und[3 * i + 1]; src[3 * k + 2] = und[3 * i + 2];
         }
         out->n_source = nk;
-        for (int i = 0; i < 16; ++i) syncd[i] = (double)sync[i];
-        mul4_cm(syncd, node->tf_ego_to_lidar, T0); // sync_lidar_pose (pcm.cpp:266)
         rc = elm_register(ctx, map, src.data(), nk, T0, reg, out->pose_lidar, &success, &fit, cov6, &out->result, nullptr); // :280-282
         if (rc != ELM_OK) return rc;
     } else {

@@ -167,10 +167,16 @@ struct RegParams {
 };
 
 constexpr int kBlock = 256;
+constexpr int kInitPack = 8; // batches up to this size are initialised from kernel arguments (k_init_pack)
+struct InitPack {
+    ScanDesc d[kInitPack];
+    double T0[kInitPack][16];
+};
 constexpr int kSums = ELM_PACKED_SUMS; // 21 + 6 + 1 + 1 (+ n_cand, n_occ, pad)
 
 // ---- launchers (elm_kernels.hip) ----------------------------------------------------------------------
 void launch_init_state(hipStream_t s, ScanState* st, const double* T0, int batch, int map_empty, int* active);
+void launch_init_pack(hipStream_t s, ScanDesc* scans, ScanState* st, const InitPack& pack, int batch, int map_empty, int* active, const unsigned* n_dev);
 void launch_stream_refill(hipStream_t s, ScanDesc* scans, ScanState* st, int slots, const QueueItem* queue, const double* qT0,
                           ScanState* out_state, StreamCtrl* ctrl, int first);
 void launch_accumulate_direct(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,

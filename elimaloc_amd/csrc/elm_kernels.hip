@@ -1942,6 +1942,27 @@ __global__ __launch_bounds__(64) void k_init_state(ScanState* st, const double* 
     init_scan_state(st[s], T0 + (size_t)s * 16, s, map_empty);
 }
 
+// Small batches (a single RunRegister above all): descriptors and initial guesses travel as kernel arguments -- no H2D copies, no
+// memset of the counter.  n_dev != nullptr: the scan's size is only known on the device (the deskew + downsample kernels have just
+// produced it): the descriptor takes n from there, so the host never waits for it.
+__global__ __launch_bounds__(64) void k_init_pack(ScanDesc* scans, ScanState* st, const InitPack pack, int batch, int map_empty, int* active,
+                                                  const unsigned* __restrict__ n_dev) {
+    const int s = threadIdx.x;
+    if (s == 0) *active = map_empty ? 0 : batch;
+    if (s >= batch) return;
+    ScanDesc d = pack.d[s];
+    if (n_dev) {
+        d.n = *n_dev;
+        d.n_total = d.n;
+        d.blk_end = d.blk_begin + (d.n + kBlock - 1) / kBlock;
+    }
+    scans[s] = d;
+    init_scan_state(st[s], pack.T0[s], s, map_empty);
+}
+void launch_init_pack(hipStream_t s, ScanDesc* scans, ScanState* st, const InitPack& pack, int batch, int map_empty, int* active, const unsigned* n_dev) {
+    hipLaunchKernelGGL(k_init_pack, dim3(1), dim3(64), 0, s, scans, st, pack, batch, map_empty, active, n_dev);
+}
+
 // Continuous batching: after the solve of an iteration, every slot whose registration has finished saves its final state
 // and takes the next pending registration (descriptor + initial guess), so every accumulate launch stays full until the
 // queue runs dry.  Slots are served in slot order by one thread: the assignment is deterministic (identical on every rank).
@@ -2695,6 +2716,15 @@ __global__ __launch_bounds__(kDsBlock) void k_ds_scatter(const float* __restrict
     }
 }
 
+// leaves the table as it was found (all ones): only the slots this scan touched are rewritten, instead of a memset of the whole
+// table (3 MB for a 131 072-point scan) before every scan
+__global__ __launch_bounds__(256) void k_ds_clear(const unsigned* __restrict__ slot, unsigned n, unsigned long long* table, unsigned* first) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned h = slot[i];
+    table[h] = ~0ull;
+    first[h] = ~0u;
+}
 void launch_voxel_downsample(hipStream_t s, const float* xyz, uint32_t n, double vs, unsigned long long* table, unsigned* first,
                              unsigned cap_log2, unsigned* slot, unsigned* block_count, unsigned* total, int* overflow, Pt3* out) {
     const unsigned nb = (n + kDsBlock - 1) / kDsBlock;
@@ -2702,6 +2732,7 @@ void launch_voxel_downsample(hipStream_t s, const float* xyz, uint32_t n, double
     hipLaunchKernelGGL(k_ds_count, dim3(nb), dim3(kDsBlock), 0, s, first, slot, n, block_count);
     hipLaunchKernelGGL(k_ds_offsets, dim3(1), dim3(1024), 0, s, block_count, nb, total);
     hipLaunchKernelGGL(k_ds_scatter, dim3(nb), dim3(kDsBlock), 0, s, xyz, first, slot, n, block_count, out);
+    hipLaunchKernelGGL(k_ds_clear, dim3((n + 255) / 256), dim3(256), 0, s, slot, n, table, first);
 }
 
 // ------------------------------------------------------------------------------------------------------
