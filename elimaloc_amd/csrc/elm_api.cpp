@@ -314,7 +314,9 @@ struct elm_map {
     float4* d_pts = nullptr;
     uint2* d_ranges = nullptr;
     int32_t* d_keys = nullptr; // [n_vox][3] stored keys (for downloads)
-    double *d_vox_mean = nullptr, *d_vox_cov = nullptr, *d_vox_cinv = nullptr;
+    double *d_vox_mean = nullptr, *d_vox_cov = nullptr, *d_vox_cinv = nullptr, *d_vox_nk = nullptr;
+    unsigned* d_bad = nullptr;     // covariances outside the compact form I + k n n^T (counted by the covariance kernels)
+    double* d_grid_gicp8 = nullptr; // the compact GICP records in grid slot order
     double* d_pt_gicp = nullptr; // [n_pts][16]: mean, inverse covariance, fitness normal (DevMap::pt_gicp)
     double* d_pt_cov = nullptr;  // [n_pts][9]: the covariances themselves (Pointcloud() read-back only)
     HashSlot* d_qslots = nullptr;
@@ -334,6 +336,7 @@ struct elm_map {
     double* d_grid_gicp = nullptr; // the GICP records in grid slot order (built with the grid / refreshed by CalPointCovAll)
     size_t grid_slots = 0;
     bool has_grid = false;
+    bool want_gicp_compact = false; // every point covariance has the compact form: the grid gets 64-byte records
     bool grid_refused = false; // the bounding box needs more cells than the budget: neighbourhood lists instead
     bool has_vnbr = false; // voxel-mean lists (VGICP)
     bool has_cells = false; // lists sorted by half-voxel cell + offset tables (every list <= 1024 entries)
@@ -489,7 +492,7 @@ static void build_host(const float* xyz, size_t n, double voxel_size, int max_po
 static void map_free(elm_map* m) {
     if (!m) return;
     if (ctx_alive(m->ctx, m->ctx_id)) (void)hipSetDevice(m->ctx->device); // a context destroyed first: just release the device memory
-    void* ptrs[] = {m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_vox_cinv, m->d_pt_gicp, m->d_pt_cov, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off, m->d_vqslots, m->d_vq_dense, m->d_vqf_dense, m->d_vface, m->d_vnbr, m->d_vnbr_blk,
+    void* ptrs[] = {m->d_vox_nk, m->d_bad, m->d_grid_gicp8, m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_vox_cinv, m->d_pt_gicp, m->d_pt_cov, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off, m->d_vqslots, m->d_vq_dense, m->d_vqf_dense, m->d_vface, m->d_vnbr, m->d_vnbr_blk,
                     m->d_grid_blk, m->d_grid_idx, m->d_grid_start, m->d_vox_stat, m->d_grid_gicp};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -574,6 +577,10 @@ extern "C" int elm_map_build(elm_ctx* ctx, const float* xyz, size_t n, double vo
 
 extern "C" void elm_map_destroy(elm_map* m) { map_free(m); }
 
+static bool full_records_forced() {
+    const char* e = getenv("ELM_COV_RECORDS");
+    return e && strcmp(e, "full") == 0;
+}
 extern "C" int elm_map_cal_voxel_cov_all(elm_map* m) {
     if (!m) return ELM_ERR_INVALID;
     elm_ctx* ctx = m->ctx;
@@ -582,18 +589,28 @@ extern "C" int elm_map_cal_voxel_cov_all(elm_map* m) {
         HIPCHK(ctx, hipMalloc((void**)&m->d_vox_mean, std::max<size_t>((size_t)m->dm.n_vox * 3 * sizeof(double), 256)));
         HIPCHK(ctx, hipMalloc((void**)&m->d_vox_cov, std::max<size_t>((size_t)m->dm.n_vox * 9 * sizeof(double), 256)));
         HIPCHK(ctx, hipMalloc((void**)&m->d_vox_cinv, std::max<size_t>((size_t)m->dm.n_vox * 9 * sizeof(double), 256)));
-        m->info.device_bytes += (size_t)m->dm.n_vox * 21 * sizeof(double);
+        HIPCHK(ctx, hipMalloc((void**)&m->d_vox_nk, std::max<size_t>((size_t)m->dm.n_vox * 4 * sizeof(double), 256)));
+        m->info.device_bytes += (size_t)m->dm.n_vox * 25 * sizeof(double);
     }
+    if (!m->d_bad) HIPCHK(ctx, hipMalloc((void**)&m->d_bad, 256));
+    unsigned bad = 0;
     if (m->dm.n_vox) {
         (void)hipGetLastError(); // drop stale errors of other libraries (RCCL probes peer devices)
-        launch_voxel_cov(ctx->stream, m->dm, m->d_ranges, m->d_vox_mean, m->d_vox_cov, m->d_vox_cinv);
+        HIPCHK(ctx, hipMemsetAsync(m->d_bad, 0, sizeof(unsigned), ctx->stream));
+        launch_voxel_cov(ctx->stream, m->dm, m->d_ranges, m->d_vox_mean, m->d_vox_cov, m->d_vox_cinv, m->d_vox_nk, m->d_bad);
         HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(&bad, m->d_bad, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     m->dm.vox_mean = m->d_vox_mean;
     m->dm.vox_cov = m->d_vox_cov;
     m->dm.vox_cinv = m->d_vox_cinv;
+    m->dm.vox_nk = m->d_vox_nk;
+    // every inverse covariance is I + k n n^T (to 1e-10): the pairs rebuild it from the 64-byte list records.  One voxel outside
+    // that form (rank-deficient neighbourhood, U != V in its SVD) or ELM_COV_RECORDS=full: the stored 3x3 inverses stay in use.
+    m->dm.vox_compact = (bad == 0 && !full_records_forced()) ? 1 : 0;
     m->info.has_voxel_cov = 1;
+    m->info.compact_records = (m->info.compact_records & ~2) | (m->dm.vox_compact ? 2 : 0);
     return ELM_OK;
 }
 
@@ -607,13 +624,18 @@ extern "C" int elm_map_cal_point_cov_all(elm_map* m, double d_search_dist) {
         HIPCHK(ctx, hipMalloc((void**)&m->d_pt_cov, std::max<size_t>((size_t)m->dm.n_pts * 9 * sizeof(double), 256)));
         m->info.device_bytes += (size_t)m->dm.n_pts * 25 * sizeof(double);
     }
+    if (!m->d_bad) HIPCHK(ctx, hipMalloc((void**)&m->d_bad, 256));
+    unsigned bad = 0;
     if (m->dm.n_pts) {
         (void)hipGetLastError();
-        launch_point_cov(ctx->stream, m->dm, d_search_dist * d_search_dist, m->d_pt_gicp, m->d_pt_cov);
+        HIPCHK(ctx, hipMemsetAsync(m->d_bad, 0, sizeof(unsigned), ctx->stream));
+        launch_point_cov(ctx->stream, m->dm, d_search_dist * d_search_dist, m->d_pt_gicp, m->d_pt_cov, m->d_bad);
         HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(&bad, m->d_bad, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     m->dm.pt_gicp = m->d_pt_gicp;
+    m->want_gicp_compact = bad == 0 && !full_records_forced(); // see elm_map_cal_voxel_cov_all
     m->info.has_point_cov = 1;
     return refresh_grid_gicp(m); // a grid built before the covariances (or a new search radius): regather
 }
@@ -799,15 +821,21 @@ static int build_voxel_neighbourhoods(elm_map* m) {
 static int refresh_grid_gicp(elm_map* m) {
     if (!m->has_grid || !m->info.has_point_cov || !m->grid_slots) return ELM_OK;
     elm_ctx* ctx = m->ctx;
-    if (!m->d_grid_gicp) {
-        HIPCHK(ctx, hipMalloc((void**)&m->d_grid_gicp, m->grid_slots * 16 * sizeof(double)));
-        m->info.device_bytes += m->grid_slots * 16 * sizeof(double);
+    const bool compact = m->want_gicp_compact;
+    double** dst = compact ? &m->d_grid_gicp8 : &m->d_grid_gicp;
+    const size_t rec_bytes = (compact ? 8 : 16) * sizeof(double);
+    if (!*dst) {
+        HIPCHK(ctx, hipMalloc((void**)dst, m->grid_slots * rec_bytes));
+        m->info.device_bytes += m->grid_slots * rec_bytes;
     }
     (void)hipGetLastError();
-    launch_gather_gicp(ctx->stream, m->dm, m->grid_slots, m->d_grid_gicp);
+    launch_gather_gicp(ctx->stream, m->dm, m->grid_slots, *dst, compact ? 1 : 0);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     m->dm.grid_gicp = m->d_grid_gicp;
+    m->dm.grid_gicp8 = m->d_grid_gicp8;
+    m->dm.gicp_compact = compact ? 1 : 0;
+    m->info.compact_records = (m->info.compact_records & ~1) | (compact ? 1 : 0);
     return ELM_OK;
 }
 
@@ -873,7 +901,7 @@ static int build_cell_grid_impl(elm_map* m, uint64_t max_cells) {
     {
         const uint64_t worst_blk = std::min<uint64_t>(n, cells) + n / 4 + 2;
         const uint64_t host_need = (cells + 4) * 4 + worst_blk * (sizeof(GridBlk) + 16) + n * 8;
-        const uint64_t dev_need = (cells + 4) * 4 + vcells * 4 + worst_blk * (sizeof(GridBlk) + 16) + (m->info.has_point_cov ? worst_blk * 4 * 64 : 0);
+        const uint64_t dev_need = (cells + 4) * 4 + vcells * 4 + worst_blk * (sizeof(GridBlk) + 16) + (m->info.has_point_cov ? worst_blk * 4 * (m->want_gicp_compact ? 64 : 128) : 0);
         size_t dev_free = 0, dev_total = 0;
         HIPCHK(ctx, hipMemGetInfo(&dev_free, &dev_total));
         const long pages = sysconf(_SC_AVPHYS_PAGES), psz = sysconf(_SC_PAGESIZE);

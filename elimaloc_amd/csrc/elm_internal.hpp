@@ -26,10 +26,17 @@ struct __attribute__((aligned(16))) GridBlk { // four candidates of the cell gri
     float x[4], y[4], z[4];
 };
 
-struct VoxRec { // one occupied neighbour voxel of a query voxel (VGICP lists): its mean (float64, vhm.hpp:114-148) and id
+// One occupied neighbour voxel of a query voxel (VGICP / AVGICP lists), ONE 64-byte record = one memory sector per pair: the mean
+// (float64, vhm.hpp:114-148), the plane normal and k of its regularised covariance U diag(1, 1, 1e-3) V^T = I - 0.999 n n^T, whose
+// inverse is I + k n n^T with k = 999 (k = 0: the identity of voxels with fewer than two points) -- the 72-byte inverse covariance is
+// rebuilt in registers instead of being fetched.  Maps with a covariance that is NOT of that form (rank-deficient neighbourhoods:
+// round-off decides the signs of U against V, vhm.hpp:141) are found at map build and keep reading vox_cinv[vid].
+struct __attribute__((aligned(64))) VoxRec {
     double mx, my, mz;
+    double nx, ny, nz;
+    double k;
     int32_t vid;
-    int32_t pad;
+    int32_t pad; // position code of the neighbour (dx + 1) * 9 + (dy + 1) * 3 + (dz + 1)
 };
 
 struct DevMap {
@@ -42,6 +49,7 @@ struct DevMap {
     const double* vox_mean; // [n_vox][3]            CalVoxelCov (vhm.hpp:114-148)
     const double* vox_cov;  // [n_vox][9] row-major (read-backs: Covariances())
     const double* vox_cinv; // [n_vox][9] its inverse: what the VGICP / AVGICP pairs use (add_pair_world)
+    const double* vox_nk;   // [n_vox][4] unit plane normal + k of the inverse's compact form I + k n n^T (see VoxRec)
     // GICP payload of a map point, ONE 128-byte record (a matched point costs one cache line instead of three scattered
     // ones): [0..2] neighbourhood mean, [3..11] INVERSE of the covariance of ProcessVoxelBlock (vhm.hpp:195-250), row-major,
     // [12..14] eigenvector of the covariance's smallest eigenvalue (reg.cpp:89-91, precomputed once), [15] pad
@@ -85,6 +93,12 @@ struct DevMap {
                                 // ties); 0xFFFFFFFF in padding slots
     const uint32_t* grid_start; // [gnx * gny * gnz + 4]
     const double* grid_gicp;    // [4 * n_blk][16]: pt_gicp gathered into slot order -- a GICP match reads its record without the index hop
+                                // (only for maps with a covariance outside the compact form)
+    const double* grid_gicp8;   // [4 * n_blk][8]: the compact record {mean[3], unit normal[3], k, -}: 64 bytes = one memory sector per match;
+                                // the inverse covariance I + k n n^T is rebuilt in registers (k = 999: U diag(1, 1, 1e-3) V^T of
+                                // vhm.hpp:238-246 with U = V up to rounding, checked per point at map build; k = 0: identity)
+    int32_t gicp_compact;       // 1: every point covariance has the compact form and grid_gicp8 is what the grid kernel reads
+    int32_t vox_compact;        // 1: every voxel covariance has it: the VoxRec's own normal / k are used, vox_cinv is not read
     int32_t gx0, gy0, gz0;      // cell coordinates of grid entry (0, 0, 0)
     int32_t gnx, gny, gnz;
     // dense voxel box of the floor keys a query can have near the map: cnt27 | nocc27 << 16 of the reference's 27-voxel walk
@@ -197,7 +211,7 @@ int stream_max_slots(); // slots one elm_register_stream call can iterate concur
 void launch_accumulate_grid(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                             ScanState* st, double* partials, const RegParams& rp);
 void launch_vox_stat(hipStream_t s, const DevMap& m, uint32_t* out); // fills DevMap::vox_stat's box (m.vx0.., m.vnx..)
-void launch_gather_gicp(hipStream_t s, const DevMap& m, size_t n_slots, double* out); // pt_gicp[grid_idx[slot]] -> out[slot]
+void launch_gather_gicp(hipStream_t s, const DevMap& m, size_t n_slots, double* out, int compact); // pt_gicp[grid_idx[slot]] -> out[slot] (16 or 8 doubles)
 // half-voxel cell of a stored coordinate (host + device; the binning of DevMap::grid_pts)
 __host__ __device__ inline int grid_cell_of(double a, double voxel_size) {
     const double t = a / voxel_size; // the reference's own key arithmetic (vhm.cpp:275), truncated below
@@ -212,8 +226,9 @@ void launch_nbr_cellsort(hipStream_t s, const DevMap& m, const int32_t* qkeys, u
 size_t nbr_cell_stride();
 void launch_nbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets, Pt3* out,
                      uint32_t* out_idx);
-void launch_voxel_cov(hipStream_t s, const DevMap& m, const uint2* ranges, double* vox_mean, double* vox_cov, double* vox_cinv);
-void launch_point_cov(hipStream_t s, const DevMap& m, double d2max, double* pt_gicp, double* pt_cov); // pt_cov [n_pts][9]: read-backs
+// *bad counts the covariances whose inverse is not I + k n n^T to 1e-10 relative (the compact records are then not used)
+void launch_voxel_cov(hipStream_t s, const DevMap& m, const uint2* ranges, double* vox_mean, double* vox_cov, double* vox_cinv, double* vox_nk, unsigned* bad);
+void launch_point_cov(hipStream_t s, const DevMap& m, double d2max, double* pt_gicp, double* pt_cov, unsigned* bad); // pt_cov [n_pts][9]: read-backs
 
 struct DeskewDev {
     double time_scan_cur, time_scan_end;

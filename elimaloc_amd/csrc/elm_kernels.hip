@@ -71,6 +71,14 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// inverse covariance I + k n n^T from the compact records (DevMap::grid_gicp8, VoxRec)
+__device__ __forceinline__ void compact_cinv(double nx, double ny, double nz, double k, double* Ci) {
+    const double kx = k * nx, ky = k * ny, kz = k * nz;
+    Ci[0] = 1.0 + kx * nx; Ci[1] = kx * ny; Ci[2] = kx * nz;
+    Ci[3] = Ci[1]; Ci[4] = 1.0 + ky * ny; Ci[5] = ky * nz;
+    Ci[6] = Ci[2]; Ci[7] = Ci[5]; Ci[8] = 1.0 + kz * nz;
+}
+
 // upper-triangle packing of the symmetric 6x6: idx(i,j), i <= j
 __host__ __device__ constexpr int tri(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
 
@@ -1177,7 +1185,7 @@ __device__ __forceinline__ void two_smallest(float d, unsigned u, unsigned& m1, 
 #ifndef ELM_GICP_WAVES
 #define ELM_GICP_WAVES 5
 #endif
-template <int METHOD>
+template <int METHOD, int COMPACT>
 __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_GICP_WAVES)) void k_accumulate_grid(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
                                                                             unsigned total_blocks, const ScanState* __restrict__ st,
                                                                             double* __restrict__ partials, const RegParams rp) {
@@ -1532,7 +1540,12 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
             const double dfin = (bidx >= 0) ? bd2 : (gx * gx + gy * gy) + gz * gz;
             if (dfin < rp.th2) {
                 double Ci[9], mean[3], nf[3];
-                if (bidx >= 0) {
+                if (bidx >= 0 && COMPACT) { // one 64-byte record: mean, unit normal, k -- the inverse covariance is I + k n n^T
+                    const double* __restrict__ rec = m.grid_gicp8 + (size_t)bidx * 8;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { mean[k] = rec[k]; nf[k] = rec[3 + k]; }
+                    compact_cinv(nf[0], nf[1], nf[2], rec[6], Ci);
+                } else if (bidx >= 0) {
                     const double* __restrict__ rec = m.grid_gicp + (size_t)bidx * 16;
 #pragma unroll
                     for (int k = 0; k < 9; ++k) Ci[k] = rec[3 + k];
@@ -1554,13 +1567,18 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
     if (threadIdx.x < kSums) partials[(size_t)L * kSums + threadIdx.x] = (METHOD == ELM_P2P) ? p2p_expand(s_red, (int)threadIdx.x) : s_red[threadIdx.x];
 }
 
-// map build: the GICP payload records in grid slot order (16 lanes per record, one 8-byte word each)
+// map build: the GICP payload records in grid slot order (16 lanes per record, one 8-byte word each); COMPACT: the 64-byte form
+// {mean[3], unit normal[3], k, 0} (8 lanes per record)
+template <int COMPACT>
 __global__ __launch_bounds__(256) void k_gather_gicp(const DevMap m, size_t n_slots, double* __restrict__ out) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t slot = t >> 4;
+    constexpr unsigned W = COMPACT ? 8u : 16u;
+    const size_t slot = t / W;
     if (slot >= n_slots) return;
     const unsigned src = m.grid_idx[slot];
-    out[t] = (src == 0xFFFFFFFFu) ? 0.0 : m.pt_gicp[(size_t)src * 16 + (t & 15)];
+    const unsigned w = (unsigned)(t % W);
+    const unsigned from = COMPACT ? (w < 3u ? w : (w < 7u ? w + 9u : 15u)) : w; // mean 0..2, normal 12..14, k 15
+    out[t] = (src == 0xFFFFFFFFu || (COMPACT && w == 7u)) ? 0.0 : m.pt_gicp[(size_t)src * 16 + from];
 }
 
 // map build: cnt27 | nocc27 << 16 for every voxel of the dense floor-key box (see DevMap::vox_stat)
@@ -1662,7 +1680,7 @@ __global__ __launch_bounds__(64) void k_nbr_cellsort(const DevMap m, const int32
 #ifndef ELM_VNBR_WAVES
 #define ELM_VNBR_WAVES 1
 #endif
-template <int METHOD>
+template <int METHOD, int COMPACT>
 __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
                                                             unsigned total_blocks, const ScanState* __restrict__ st,
                                                             double* __restrict__ partials, const RegParams rp) {
@@ -1715,6 +1733,7 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
         const VoxRec* __restrict__ lp = ((METHOD == ELM_AVGICP && m.vq_dense && m.vqf_dense) ? m.vface : m.vnbr) + start;
         if (METHOD == ELM_VGICP) {
             double bd2 = DBL_MAX, bmx = 0.0, bmy = 0.0, bmz = 0.0;
+            double bn[4] = {1.0, 0.0, 0.0, 0.0}; // the winner's plane normal and k (compact records)
             int bvid = -1;
             unsigned bj = 0;
             // float32 filter over the means (blocks of four, three 16-byte loads each instead of eight for the float64 records):
@@ -1771,6 +1790,7 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
             if (cnt) { // the winner's float64 record (after the float64 walk: an L1 hit instead of five registers carried through it)
                 const VoxRec w = lp[min(bj, cnt - 1)];
                 bvid = w.vid; bmx = w.mx; bmy = w.my; bmz = w.mz;
+                if (COMPACT) { bn[0] = w.nx; bn[1] = w.ny; bn[2] = w.nz; bn[3] = w.k; }
                 const double ex = w.mx - gx, ey = w.my - gy, ez = w.mz - gz;
                 bd2 = (ex * ex + ey * ey) + ez * ez; // the walk's own arithmetic for this record
             }
@@ -1779,7 +1799,9 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
             if (dfin < rp.th2) {
                 if (bvid < 0) bmx = bmy = bmz = 0.0;
                 double Ci[9];
-                if (bvid >= 0) {
+                if (bvid >= 0 && COMPACT) { // the record carried the normal and k: no second fetch
+                    compact_cinv(bn[0], bn[1], bn[2], bn[3], Ci);
+                } else if (bvid >= 0) {
 #pragma unroll
                     for (int k = 0; k < 9; ++k) Ci[k] = m.vox_cinv[(size_t)bvid * 9 + k];
                 } else {
@@ -1811,9 +1833,13 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
                 for (int u = 0; u < ELM_AVG_RECS; ++u) {
                     const int code = r[u].pad;
                     use[u] = j + u < cnt && (code == 13 || code == 22 || code == 4 || code == 16 || code == 10 || code == 14 || code == 12);
-                    const double* __restrict__ cp = m.vox_cinv + (size_t)(use[u] ? r[u].vid : 0) * 9;
+                    if (COMPACT) {
+                        compact_cinv(r[u].nx, r[u].ny, r[u].nz, r[u].k, Ci[u]);
+                    } else {
+                        const double* __restrict__ cp = m.vox_cinv + (size_t)(use[u] ? r[u].vid : 0) * 9;
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) Ci[u][k] = cp[k];
+                        for (int k = 0; k < 9; ++k) Ci[u][k] = cp[k];
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < ELM_AVG_RECS; ++u) {
@@ -1853,6 +1879,8 @@ __global__ __launch_bounds__(256) void k_vnbr_fill(const DevMap m, const int32_t
                 if (pr.vid < 0 || pr.cnt == 0) continue;
                 VoxRec r;
                 r.mx = m.vox_mean[(size_t)pr.vid * 3]; r.my = m.vox_mean[(size_t)pr.vid * 3 + 1]; r.mz = m.vox_mean[(size_t)pr.vid * 3 + 2];
+                r.nx = m.vox_nk[(size_t)pr.vid * 4]; r.ny = m.vox_nk[(size_t)pr.vid * 4 + 1]; r.nz = m.vox_nk[(size_t)pr.vid * 4 + 2];
+                r.k = m.vox_nk[(size_t)pr.vid * 4 + 3];
                 r.vid = pr.vid;
                 r.pad = ((dx + 1) * 3 + (dy + 1)) * 3 + (dz + 1); // position code of this neighbour (AVGICP picks the face ones)
                 if (out_blk) { // the float32 filter copy: slot o % 4 of block o / 4
@@ -2362,13 +2390,27 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* scans, 
 // ------------------------------------------------------------------------------------------------------
 // K3 / K4: map covariances
 // ------------------------------------------------------------------------------------------------------
+// k of the compact form I + k n n^T of an inverse covariance (n = unit plane normal): k = trace - 3; *ok = false when the matrix is
+// not of that form to 1e-10 relative (a rank-deficient neighbourhood whose SVD returned U != V: the full matrix is then kept in use)
+__device__ __forceinline__ double compact_k(const double Ci[9], const double n[3], bool* ok) {
+    const double k = ((Ci[0] + Ci[4]) + Ci[8]) - 3.0;
+    double err = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) err = fmax(err, fabs(Ci[i * 3 + j] - (((i == j) ? 1.0 : 0.0) + k * n[i] * n[j])));
+    *ok = err <= 1e-10 * (1.0 + fabs(k)); // (NaN compares false)
+    return k;
+}
+
 __global__ __launch_bounds__(256) void k_voxel_cov(const DevMap m, const uint2* __restrict__ ranges, double* vox_mean,
-                                                   double* vox_cov, double* vox_cinv) {
+                                                   double* vox_cov, double* vox_cinv, double* vox_nk, unsigned* bad) {
     const unsigned v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= m.n_vox) return;
     const uint2 rg = ranges[v];
     const unsigned n = rg.y;
     double mean[3] = {0, 0, 0};
+    double nrm[3] = {1, 0, 0};
     double C[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     if (n == 1) {
         const float4 q = m.pts[rg.x];
@@ -2388,17 +2430,23 @@ __global__ __launch_bounds__(256) void k_voxel_cov(const DevMap m, const uint2* 
                 for (int bq = 0; bq < 3; ++bq) c[a * 3 + bq] += d[a] * d[bq];
         }
         for (int k = 0; k < 9; ++k) c[k] /= (double)(n - 1);
-        double nrm[3];
         plane_regularize(c, C, nrm);
+        const double nn = sqrt((nrm[0] * nrm[0] + nrm[1] * nrm[1]) + nrm[2] * nrm[2]);
+        if (nn > 0.0) { nrm[0] /= nn; nrm[1] /= nn; nrm[2] /= nn; }
     }
     for (int k = 0; k < 3; ++k) vox_mean[(size_t)v * 3 + k] = mean[k];
     for (int k = 0; k < 9; ++k) vox_cov[(size_t)v * 9 + k] = C[k];
     double Ci[9];
     inv3(C, Ci); // the inverse the registration needs (add_pair_world), by the cofactor form Eigen uses for Matrix3d::inverse()
     for (int k = 0; k < 9; ++k) vox_cinv[(size_t)v * 9 + k] = Ci[k];
+    bool ok;
+    const double kk = compact_k(Ci, nrm, &ok);
+    if (!ok) atomicAdd(bad, 1u);
+    for (int k = 0; k < 3; ++k) vox_nk[(size_t)v * 4 + k] = nrm[k];
+    vox_nk[(size_t)v * 4 + 3] = kk;
 }
 
-__global__ __launch_bounds__(256) void k_point_cov(const DevMap m, double d2max, double* pt_gicp, double* pt_cov) {
+__global__ __launch_bounds__(256) void k_point_cov(const DevMap m, double d2max, double* pt_gicp, double* pt_cov, unsigned* bad) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m.n_pts) return;
     const float4 pf = m.pts[i];
@@ -2461,7 +2509,9 @@ __global__ __launch_bounds__(256) void k_point_cov(const DevMap m, double d2max,
     double* rec = pt_gicp + (size_t)i * 16;
     for (int k = 0; k < 3; ++k) { rec[k] = mean[k]; rec[12 + k] = nf[k]; }
     for (int k = 0; k < 9; ++k) rec[3 + k] = Ci[k];
-    rec[15] = 0.0;
+    bool ok;
+    rec[15] = compact_k(Ci, nf, &ok); // k of Cinv = I + k n n^T (the compact 64-byte records, DevMap::grid_gicp8)
+    if (!ok) atomicAdd(bad, 1u);
     for (int k = 0; k < 9; ++k) pt_cov[(size_t)i * 9 + k] = C[k];
 }
 
@@ -2554,13 +2604,16 @@ void launch_accumulate_grid(hipStream_t s, const DevMap& m, const ScanDesc* scan
                             ScanState* st, double* partials, const RegParams& rp) {
     dim3 g(total_blocks), b(kBlock);
     if (rp.method == ELM_P2P)
-        hipLaunchKernelGGL((k_accumulate_grid<ELM_P2P>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
+        hipLaunchKernelGGL((k_accumulate_grid<ELM_P2P, 0>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
+    else if (m.gicp_compact)
+        hipLaunchKernelGGL((k_accumulate_grid<ELM_GICP, 1>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
     else
-        hipLaunchKernelGGL((k_accumulate_grid<ELM_GICP>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
+        hipLaunchKernelGGL((k_accumulate_grid<ELM_GICP, 0>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
 }
-void launch_gather_gicp(hipStream_t s, const DevMap& m, size_t n_slots, double* out) {
-    const size_t threads = n_slots * 16;
-    hipLaunchKernelGGL(k_gather_gicp, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, m, n_slots, out);
+void launch_gather_gicp(hipStream_t s, const DevMap& m, size_t n_slots, double* out, int compact) {
+    const size_t threads = n_slots * (compact ? 8 : 16);
+    if (compact) hipLaunchKernelGGL(k_gather_gicp<1>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, m, n_slots, out);
+    else hipLaunchKernelGGL(k_gather_gicp<0>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, m, n_slots, out);
 }
 void launch_vox_stat(hipStream_t s, const DevMap& m, uint32_t* out) {
     const size_t n = (size_t)m.vnx * m.vny * m.vnz;
@@ -2569,10 +2622,10 @@ void launch_vox_stat(hipStream_t s, const DevMap& m, uint32_t* out) {
 int stream_max_slots() { return kMaxSlots; }
 void launch_accumulate_vnbr(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                             ScanState* st, double* partials, const RegParams& rp) {
-    if (rp.method == ELM_VGICP)
-        hipLaunchKernelGGL((k_accumulate_vnbr<ELM_VGICP>), dim3(total_blocks), dim3(kBlock), 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
-    else
-        hipLaunchKernelGGL((k_accumulate_vnbr<ELM_AVGICP>), dim3(total_blocks), dim3(kBlock), 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
+#define ELM_LAUNCH_V(M, C) hipLaunchKernelGGL((k_accumulate_vnbr<M, C>), dim3(total_blocks), dim3(kBlock), 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp)
+    if (rp.method == ELM_VGICP) { if (m.vox_compact) ELM_LAUNCH_V(ELM_VGICP, 1); else ELM_LAUNCH_V(ELM_VGICP, 0); }
+    else { if (m.vox_compact) ELM_LAUNCH_V(ELM_AVGICP, 1); else ELM_LAUNCH_V(ELM_AVGICP, 0); }
+#undef ELM_LAUNCH_V
 }
 // map build: the face neighbours (and the voxel itself) of every voxel-mean list, in list order (AVGICP's pairs)
 __device__ __forceinline__ bool is_face_code(int code) {
@@ -2622,12 +2675,12 @@ void launch_solve(hipStream_t s, const ScanDesc* scans, int batch, ScanState* st
     hipLaunchKernelGGL(k_solve, dim3(batch), dim3(kSolveThreads), 0, s, scans, st, partials, sums, rp, trace, mode, active, sa);
 }
 
-void launch_voxel_cov(hipStream_t s, const DevMap& m, const uint2* ranges, double* vox_mean, double* vox_cov, double* vox_cinv) {
-    hipLaunchKernelGGL(k_voxel_cov, dim3((m.n_vox + 255) / 256), dim3(256), 0, s, m, ranges, vox_mean, vox_cov, vox_cinv);
+void launch_voxel_cov(hipStream_t s, const DevMap& m, const uint2* ranges, double* vox_mean, double* vox_cov, double* vox_cinv, double* vox_nk, unsigned* bad) {
+    hipLaunchKernelGGL(k_voxel_cov, dim3((m.n_vox + 255) / 256), dim3(256), 0, s, m, ranges, vox_mean, vox_cov, vox_cinv, vox_nk, bad);
 }
 
-void launch_point_cov(hipStream_t s, const DevMap& m, double d2max, double* pt_gicp, double* pt_cov) {
-    hipLaunchKernelGGL(k_point_cov, dim3((m.n_pts + 255) / 256), dim3(256), 0, s, m, d2max, pt_gicp, pt_cov);
+void launch_point_cov(hipStream_t s, const DevMap& m, double d2max, double* pt_gicp, double* pt_cov, unsigned* bad) {
+    hipLaunchKernelGGL(k_point_cov, dim3((m.n_pts + 255) / 256), dim3(256), 0, s, m, d2max, pt_gicp, pt_cov, bad);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -836,3 +836,76 @@ def test_api_misuse_fails_loudly(ctx, oracle, world100k):
     # and the context is still usable afterwards
     out = Registration(RegistrationConfig(icp_method=0), ctx).RunRegisterStream([sc], vm, [Tt], slots=2)
     assert out[0]["is_success"]
+
+
+@pytest.mark.parametrize("method", [1, 2, 3])
+def test_compact_covariance_records_equal_the_stored_inverses(oracle, world100k, method, monkeypatch):
+    """GICP / VGICP / AVGICP read 64-byte {mean, normal, k} records and rebuild the inverse covariance I + k n n^T in registers when
+    every covariance of the map has that form (checked per point / voxel at map build); ELM_COV_RECORDS=full keeps the stored 3x3
+    inverses.  Both agree with each other to the sum tolerance on every iteration, and with the oracle."""
+    from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, VoxelHashMap
+    m = IcpMethod(method)
+    scan, Tt = synth.make_scan(world100k, 8000, seed=4242)
+    T0 = synth.perturb(Tt, seed=4243, max_trans=0.3, max_rot_deg=1.0)
+    runs = {}
+    for mode in ("compact", "full"):
+        if mode == "full":
+            monkeypatch.setenv("ELM_COV_RECORDS", "full")
+        c = Context(0)
+        try:
+            vm = VoxelHashMap(1.0, 30, c)
+            vm.AddPoints(world100k)
+            if m == IcpMethod.GICP:
+                vm.CalPointCovAll(0.4)
+            else:
+                vm.CalVoxelCovAll()
+            runs[mode] = Registration(RegistrationConfig(icp_method=m), c).RunRegister(scan, vm, T0, trace=True)[-1]
+            bits = int(vm.info().compact_records)
+            want_bit = 1 if m == IcpMethod.GICP else 2
+            assert bool(bits & want_bit) == (mode == "compact"), (mode, bits)  # the jittered world has no rank-deficient neighbourhood
+        finally:
+            c.close()
+    a, b = runs["compact"], runs["full"]
+    assert a["iterations"] == b["iterations"] and a["is_success"] == b["is_success"]
+    for ia, ib in zip(a["iters"], b["iters"]):
+        assert ia["n_corr"] == ib["n_corr"]
+        assert np.abs(ia["JTJ"] - ib["JTJ"]).max() <= SUM_RTOL * np.abs(ib["JTJ"]).max()
+        assert np.abs(ia["JTr"] - ib["JTr"]).max() <= SUM_RTOL * max(np.abs(ib["JTr"]).max(), 1e-12 * np.abs(ib["JTJ"]).max())
+    om = oracle.Map(1.0, 30)
+    om.add_points(world100k)
+    if m == IcpMethod.GICP:
+        om.cal_point_cov_all(0.4)
+    else:
+        om.cal_voxel_cov_all()
+    ref = oracle.register(om, scan, T0, oracle.default_config(method))
+    for r in (a, b):
+        dt, dr = synth.pose_error(ref["T"], r["T"])
+        assert ref["iterations"] == r["iterations"] and dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
+
+
+def test_rank_deficient_covariances_keep_the_full_records(oracle):
+    """A map of exactly coplanar points: the sample covariances are rank deficient, the SVD's U and V may differ by signs and
+    U diag(1,1,1e-3) V^T need not be I - 0.999 n n^T.  Whatever the map build decides (compact form or stored inverses), the
+    registration follows the oracle's restatement of the same arithmetic."""
+    from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, VoxelHashMap
+    g = np.arange(-12, 12, 0.25, dtype=np.float32)
+    xx, yy = np.meshgrid(g, g, indexing="ij")
+    plane = np.stack([xx.ravel(), yy.ravel(), np.full(xx.size, 0.5, np.float32)], axis=1)
+    wall = np.stack([np.full(xx.size, 3.0, np.float32), yy.ravel(), (xx.ravel() + 12) / 4], axis=1).astype(np.float32)
+    world = np.ascontiguousarray(np.concatenate([plane, wall]))
+    rng = np.random.default_rng(5)
+    scan = world[rng.choice(len(world), 3000, replace=False)] + rng.normal(0, 0.01, (3000, 3)).astype(np.float32)
+    T0 = synth.perturb(np.eye(4), seed=9, max_trans=0.1, max_rot_deg=0.5)
+    scan = np.ascontiguousarray(scan.astype(np.float32))
+    c = Context(0)
+    try:
+        for method in (1, 2, 3):
+            m = IcpMethod(method)
+            vm, om = _maps(c, oracle, world, m)
+            got = Registration(RegistrationConfig(icp_method=m), c).RunRegister(scan, vm, T0, trace=True)[-1]
+            ref = oracle.register(om, scan, T0, oracle.default_config(method))
+            dt, dr = synth.pose_error(ref["T"], got["T"])
+            assert ref["iterations"] == got["iterations"] and ref["is_success"] == got["is_success"], (method, int(vm.info().compact_records))
+            assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (method, dt, dr, int(vm.info().compact_records))
+    finally:
+        c.close()
