@@ -94,7 +94,7 @@ class MapInfo(C.Structure):
         ("max_points_per_voxel", C.c_int32),
         ("has_voxel_cov", C.c_int32),
         ("has_point_cov", C.c_int32),
-        ("compact_records", C.c_int32),
+        ("layout_flags", C.c_int32),
         ("device_bytes", C.c_uint64),
         ("n_query_voxels", C.c_uint64),
         ("nbr_entries", C.c_uint64),

@@ -3,6 +3,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
@@ -332,6 +333,7 @@ struct elm_map {
     GridBlk* d_grid_blk = nullptr;    // dense cell grid (DevMap::grid_*), the default P2P / GICP search index
     uint32_t* d_grid_idx = nullptr;
     uint32_t* d_grid_start = nullptr;
+    uint2* d_grid_tiles = nullptr; // two-level grid only
     uint32_t* d_vox_stat = nullptr;
     double* d_grid_gicp = nullptr; // the GICP records in grid slot order (built with the grid / refreshed by CalPointCovAll)
     size_t grid_slots = 0;
@@ -492,7 +494,7 @@ static void build_host(const float* xyz, size_t n, double voxel_size, int max_po
 static void map_free(elm_map* m) {
     if (!m) return;
     if (ctx_alive(m->ctx, m->ctx_id)) (void)hipSetDevice(m->ctx->device); // a context destroyed first: just release the device memory
-    void* ptrs[] = {m->d_vox_nk, m->d_bad, m->d_grid_gicp8, m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_vox_cinv, m->d_pt_gicp, m->d_pt_cov, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off, m->d_vqslots, m->d_vq_dense, m->d_vqf_dense, m->d_vface, m->d_vnbr, m->d_vnbr_blk,
+    void* ptrs[] = {m->d_grid_tiles, m->d_vox_nk, m->d_bad, m->d_grid_gicp8, m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_vox_cinv, m->d_pt_gicp, m->d_pt_cov, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off, m->d_vqslots, m->d_vq_dense, m->d_vqf_dense, m->d_vface, m->d_vnbr, m->d_vnbr_blk,
                     m->d_grid_blk, m->d_grid_idx, m->d_grid_start, m->d_vox_stat, m->d_grid_gicp};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -610,7 +612,7 @@ extern "C" int elm_map_cal_voxel_cov_all(elm_map* m) {
     // that form (rank-deficient neighbourhood, U != V in its SVD) or ELM_COV_RECORDS=full: the stored 3x3 inverses stay in use.
     m->dm.vox_compact = (bad == 0 && !full_records_forced()) ? 1 : 0;
     m->info.has_voxel_cov = 1;
-    m->info.compact_records = (m->info.compact_records & ~2) | (m->dm.vox_compact ? 2 : 0);
+    m->info.layout_flags = (m->info.layout_flags & ~2) | (m->dm.vox_compact ? 2 : 0);
     return ELM_OK;
 }
 
@@ -835,7 +837,7 @@ static int refresh_grid_gicp(elm_map* m) {
     m->dm.grid_gicp = m->d_grid_gicp;
     m->dm.grid_gicp8 = m->d_grid_gicp8;
     m->dm.gicp_compact = compact ? 1 : 0;
-    m->info.compact_records = (m->info.compact_records & ~1) | (compact ? 1 : 0);
+    m->info.layout_flags = (m->info.layout_flags & ~1) | (compact ? 1 : 0);
     return ELM_OK;
 }
 
@@ -1015,6 +1017,175 @@ static int build_cell_grid_impl(elm_map* m, uint64_t max_cells) {
     return ELM_OK;
 }
 
+// The two-level form of the cell grid (DevMap::grid_tiles): for maps whose bounding box is too large or too sparse for one dense
+// offset table (a city-scale map at half-metre cells: billions of cells, a few hundred thousand of them occupied).  The same
+// blocks, sorted (tile, column, z); offsets only inside occupied tiles and only over each tile's own z range.  Host-side build
+// like the dense one; nothing is left allocated on failure.
+static int build_tiled_grid_impl(elm_map* m);
+static int build_tiled_grid(elm_map* m) {
+    if (m->has_grid) return ELM_OK;
+    try {
+        return build_tiled_grid_impl(m);
+    } catch (const std::bad_alloc&) {
+        m->ctx->last_error = "tiled cell grid: host allocation failed";
+        return ELM_ERR_UNSUPPORTED;
+    }
+}
+static int build_tiled_grid_impl(elm_map* m) {
+    elm_ctx* ctx = m->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t n = m->dm.n_pts;
+    const double vs = m->dm.voxel_size;
+    if (n == 0 || m->dm.n_vox == 0) return ELM_ERR_UNSUPPORTED;
+    std::vector<float4> pts(n);
+    HIPCHK(ctx, hipMemcpy(pts.data(), m->d_pts, n * sizeof(float4), hipMemcpyDeviceToHost));
+    int32_t lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    for (size_t i = 0; i < n; ++i) {
+        const float c3[3] = {pts[i].x, pts[i].y, pts[i].z};
+        for (int a = 0; a < 3; ++a) {
+            const int32_t c = grid_cell_of((double)c3[a], vs);
+            lo[a] = std::min(lo[a], c);
+            hi[a] = std::max(hi[a], c);
+        }
+    }
+    int64_t dim[3];
+    for (int a = 0; a < 3; ++a) {
+        lo[a] -= 2; hi[a] += 2;
+        dim[a] = (int64_t)hi[a] - lo[a] + 1;
+    }
+    const int64_t tnx = (dim[0] + kTile - 1) / kTile, tny = (dim[1] + kTile - 1) / kTile;
+    // 64 M tiles = 512 MB of tile table (a 32 km x 32 km box at half-metre cells); the z range of a tile is a 16-bit pair
+    if (tnx * tny > ((int64_t)64 << 20) || dim[2] > 65000 || tnx * kTile > 0x7FFFFFF0ll || tny * kTile > 0x7FFFFFF0ll) return ELM_ERR_UNSUPPORTED;
+    const size_t n_tiles = (size_t)(tnx * tny);
+    auto cell3 = [&](size_t i, int32_t& cx, int32_t& cy, int32_t& cz) {
+        cx = grid_cell_of((double)pts[i].x, vs) - lo[0];
+        cy = grid_cell_of((double)pts[i].y, vs) - lo[1];
+        cz = grid_cell_of((double)pts[i].z, vs) - lo[2];
+    };
+    std::vector<uint16_t> zmin(n_tiles, 0xFFFFu), zmax(n_tiles, 0u);
+    for (size_t i = 0; i < n; ++i) {
+        int32_t cx, cy, cz;
+        cell3(i, cx, cy, cz);
+        const size_t t = (size_t)(cx >> kTileShift) * (size_t)tny + (size_t)(cy >> kTileShift);
+        zmin[t] = std::min<uint16_t>(zmin[t], (uint16_t)cz);
+        zmax[t] = std::max<uint16_t>(zmax[t], (uint16_t)cz);
+    }
+    std::vector<uint2> tiles(n_tiles);
+    uint64_t entries = (uint64_t)kTile * kTile; // entries 0 .. 63: the shared zero run of every empty tile (nz = 0: one entry per column)
+    for (size_t t = 0; t < n_tiles; ++t) {
+        if (zmin[t] == 0xFFFFu) { tiles[t] = make_uint2(0u, 0u); continue; }
+        const uint32_t nz = (uint32_t)zmax[t] - zmin[t] + 1;
+        tiles[t] = make_uint2((uint32_t)entries, (uint32_t)zmin[t] | (nz << 16));
+        entries += (uint64_t)kTile * kTile * (nz + 1);
+        if (entries > 0xFFFFFFF0ull) return ELM_ERR_UNSUPPORTED;
+    }
+    auto entry_of = [&](int32_t cx, int32_t cy, int32_t cz) -> uint32_t {
+        const uint2 te = tiles[(size_t)(cx >> kTileShift) * (size_t)tny + (size_t)(cy >> kTileShift)];
+        const uint32_t z0 = te.y & 0xFFFFu, nz = te.y >> 16;
+        return te.x + (uint32_t)(((cx & (kTile - 1)) << kTileShift) | (cy & (kTile - 1))) * (nz + 1) + ((uint32_t)cz - z0);
+    };
+    // byte budget, as for the dense grid
+    {
+        const uint64_t worst_blk = n + 2;
+        const uint64_t host_need = (entries + 4) * 8 + worst_blk * (sizeof(GridBlk) + 16) + n * 8 + n_tiles * 12;
+        const uint64_t dev_need = (entries + 4) * 4 + n_tiles * 8 + worst_blk * (sizeof(GridBlk) + 16) + (m->info.has_point_cov ? worst_blk * 4 * (m->want_gicp_compact ? 64 : 128) : 0);
+        size_t dev_free = 0, dev_total = 0;
+        HIPCHK(ctx, hipMemGetInfo(&dev_free, &dev_total));
+        const long pages = sysconf(_SC_AVPHYS_PAGES), psz = sysconf(_SC_PAGESIZE);
+        const uint64_t host_free = (pages > 0 && psz > 0) ? (uint64_t)pages * (uint64_t)psz : ~0ull;
+        if (host_need > host_free / 10 * 7 || dev_need > (uint64_t)dev_free / 10 * 8) {
+            ctx->last_error = "tiled cell grid: tables exceed the memory that is free";
+            return ELM_ERR_UNSUPPORTED;
+        }
+    }
+    std::vector<uint32_t> start(entries + 4, 0u), cursor(entries + 4, 0u), ent(n);
+    for (size_t i = 0; i < n; ++i) {
+        int32_t cx, cy, cz;
+        cell3(i, cx, cy, cz);
+        ent[i] = entry_of(cx, cy, cz);
+        start[ent[i]]++; // counts first
+    }
+    // entry order = (tile, column, z): block starts; the extra entry of every column (index nz) = the column's end
+    uint64_t n_blk = 1, pos = 0;
+    for (uint64_t e = 0; e < entries; ++e) {
+        const uint32_t cnt = start[e];
+        start[e] = (uint32_t)n_blk;
+        cursor[e] = (uint32_t)pos; // position in the (unpadded) sorted order
+        n_blk += (cnt + 3) / 4;
+        pos += cnt;
+    }
+    for (uint64_t e = 0; e < (uint64_t)kTile * kTile; ++e) start[e] = 0; // empty tiles: block 0 .. block 0 (nothing)
+    for (uint64_t e = entries; e < entries + 4; ++e) start[e] = (uint32_t)n_blk;
+    if (n_blk * sizeof(GridBlk) > 0xFFFFFF00ull) return ELM_ERR_UNSUPPORTED;
+    std::vector<GridBlk> gb(std::max<uint64_t>(n_blk, 1));
+    std::vector<uint32_t> gi(std::max<uint64_t>(4 * n_blk, 4), 0xFFFFFFFFu);
+    for (auto& b : gb)
+        for (int u = 0; u < 4; ++u) b.x[u] = b.y[u] = b.z[u] = 1e18f;
+    {
+        std::vector<uint32_t> first(cursor); // where each entry's run begins in the sorted order
+        for (size_t i = 0; i < n; ++i) { // bucket order in: a cell keeps its points in bucket (= insertion) order
+            const uint32_t e = ent[i];
+            const uint64_t slot = (uint64_t)start[e] * 4 + (cursor[e] - first[e]);
+            cursor[e]++;
+            gb[slot >> 2].x[slot & 3] = pts[i].x; gb[slot >> 2].y[slot & 3] = pts[i].y; gb[slot >> 2].z[slot & 3] = pts[i].z;
+            gi[slot] = (uint32_t)i;
+        }
+    }
+    std::vector<uint32_t>().swap(cursor);
+    std::vector<uint32_t>().swap(ent);
+    std::vector<float4>().swap(pts);
+    GridBlk* d_blk = nullptr;
+    uint32_t *d_idx = nullptr, *d_start = nullptr;
+    uint2* d_tiles = nullptr;
+    auto fail = [&](const std::string& what, hipError_t e) {
+        ctx->last_error = what + ": " + hipGetErrorString(e);
+        for (void* q : {(void*)d_blk, (void*)d_idx, (void*)d_start, (void*)d_tiles})
+            if (q) (void)hipFree(q);
+        (void)hipGetLastError();
+        return e == hipErrorOutOfMemory ? ELM_ERR_UNSUPPORTED : ELM_ERR_DEVICE;
+    };
+#define TG_CHK(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) return fail(#call, e_);                                         \
+    } while (0)
+    TG_CHK(hipMalloc((void**)&d_blk, gb.size() * sizeof(GridBlk)));
+    TG_CHK(hipMalloc((void**)&d_idx, gi.size() * sizeof(uint32_t)));
+    TG_CHK(hipMalloc((void**)&d_start, (entries + 4) * sizeof(uint32_t)));
+    TG_CHK(hipMalloc((void**)&d_tiles, n_tiles * sizeof(uint2)));
+    TG_CHK(hipMemcpy(d_blk, gb.data(), gb.size() * sizeof(GridBlk), hipMemcpyHostToDevice));
+    TG_CHK(hipMemcpy(d_idx, gi.data(), gi.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    TG_CHK(hipMemcpy(d_start, start.data(), (entries + 4) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    TG_CHK(hipMemcpy(d_tiles, tiles.data(), n_tiles * sizeof(uint2), hipMemcpyHostToDevice));
+#undef TG_CHK
+    const DevMap dm_before = m->dm;
+    m->dm.grid_blk = d_blk; m->dm.grid_idx = d_idx; m->dm.grid_start = d_start; m->dm.grid_tiles = d_tiles;
+    m->dm.grid_tiled = 1;
+    m->dm.gtny = (int32_t)tny;
+    m->dm.gx0 = lo[0]; m->dm.gy0 = lo[1]; m->dm.gz0 = lo[2];
+    m->dm.gnx = (int32_t)(tnx * kTile); m->dm.gny = (int32_t)(tny * kTile); m->dm.gnz = (int32_t)dim[2];
+    m->dm.vox_stat = nullptr;
+    m->d_grid_blk = d_blk; m->d_grid_idx = d_idx; m->d_grid_start = d_start; m->d_grid_tiles = d_tiles;
+    m->has_grid = true;
+    m->grid_slots = gi.size();
+    if (refresh_grid_gicp(m) != ELM_OK) {
+        (void)hipFree(d_blk); (void)hipFree(d_idx); (void)hipFree(d_start); (void)hipFree(d_tiles);
+        m->d_grid_blk = nullptr; m->d_grid_idx = nullptr; m->d_grid_start = nullptr; m->d_grid_tiles = nullptr;
+        m->dm = dm_before;
+        m->has_grid = false;
+        m->grid_slots = 0;
+        (void)hipGetLastError();
+        return ELM_ERR_UNSUPPORTED;
+    }
+    const size_t idx_bytes = gb.size() * sizeof(GridBlk) + (entries + 4) * sizeof(uint32_t) + n_tiles * sizeof(uint2);
+    m->info.device_bytes += idx_bytes + gi.size() * sizeof(uint32_t);
+    m->info.n_query_voxels = n_tiles;
+    m->info.layout_flags |= 4;
+    m->info.nbr_entries = n;
+    m->info.index_bytes += idx_bytes;
+    return ELM_OK;
+}
+
 // Neighbourhood lists (see DevMap): query voxels = every floor key within +-1 of a stored (trunc) key.
 static int build_neighbourhood_lists(elm_map* m) {
     if (!m) return ELM_ERR_INVALID;
@@ -1124,11 +1295,23 @@ static uint64_t grid_max_cells() {
     if (const char* e = getenv("ELM_GRID_MAX_CELLS")) return strtoull(e, nullptr, 10);
     return 1500000000ull;
 }
+// The P2P / GICP search index of a map: the dense cell grid when its bounding box fits the cell and byte budgets, the two-level
+// (tiled) grid when it does not -- large or sparse maps keep the grid kernel -- and the per-query-voxel neighbourhood lists only
+// when neither can be built (or with ELM_KERNEL=lists; ELM_GRID=tiled forces the two-level form, ELM_GRID=dense forbids it).
 static int build_search_index(elm_map* m, bool* use_grid) {
     *use_grid = false;
     elm_ctx* ctx = m->ctx;
     if (ctx->kernel_mode == 4 && !m->grid_refused && m->dm.n_pts) {
-        const int rc = build_cell_grid(m, grid_max_cells());
+        const char* g = getenv("ELM_GRID");
+        const bool force_tiled = g && strcmp(g, "tiled") == 0, no_tiled = g && strcmp(g, "dense") == 0;
+        int rc = force_tiled ? ELM_ERR_UNSUPPORTED : build_cell_grid(m, grid_max_cells());
+        if (getenv("ELM_DEBUG")) fprintf(stderr, "[elm] dense grid: rc %d (%s)\n", rc, ctx->last_error.c_str());
+        if (rc == ELM_ERR_UNSUPPORTED && !no_tiled) {
+            rc = build_tiled_grid(m);
+            if (getenv("ELM_DEBUG")) fprintf(stderr, "[elm] tiled grid: rc %d (%s)\n", rc, ctx->last_error.c_str());
+            if (rc == ELM_ERR_UNSUPPORTED) m->grid_refused = true; // neither form: do not retry at every registration
+            else if (rc == ELM_OK) m->grid_refused = false;
+        }
         if (rc == ELM_OK) {
             *use_grid = true;
             return ELM_OK;

@@ -92,6 +92,13 @@ struct DevMap {
     const uint32_t* grid_idx;   // [4 * n_blk] bucket-order index of every candidate slot (GICP payload, insertion order for exact
                                 // ties); 0xFFFFFFFF in padding slots
     const uint32_t* grid_start; // [gnx * gny * gnz + 4]
+    // two-level form of the same grid (maps whose bounding box is too large or too sparse for one dense offset table): the box is cut
+    // into tiles of kTile x kTile (x, y) cells; grid_tiles[tile] = {first offset entry, z0 | nz << 16}: the tile stores offsets only for
+    // the cells z0 .. z0 + nz - 1 that hold points, (nz + 1) entries per column (its cell starts + the column end), columns (x, y)-major.
+    // Blocks are sorted (tile, column, z), so the cells of a column are still one contiguous run.  Empty tiles share 64 zero entries.
+    const uint2* grid_tiles;    // [gnx / kTile][gny / kTile] (gnx, gny are multiples of kTile)
+    int32_t grid_tiled;         // 1: grid_start is addressed through grid_tiles
+    int32_t gtny;               // tiles along y
     const double* grid_gicp;    // [4 * n_blk][16]: pt_gicp gathered into slot order -- a GICP match reads its record without the index hop
                                 // (only for maps with a covariance outside the compact form)
     const double* grid_gicp8;   // [4 * n_blk][8]: the compact record {mean[3], unit normal[3], k, -}: 64 bytes = one memory sector per match;
@@ -180,6 +187,7 @@ struct RegParams {
     uint32_t _pad;
 };
 
+constexpr int kTileShift = 3, kTile = 1 << kTileShift; // two-level grid: tiles of 8 x 8 columns
 constexpr int kBlock = 256;
 constexpr int kInitPack = 8; // batches up to this size are initialised from kernel arguments (k_init_pack)
 struct InitPack {

@@ -1178,6 +1178,24 @@ __device__ __forceinline__ void two_smallest(float d, unsigned u, unsigned& m1, 
     m1 = min(m1, key);
 }
 
+// The offsets of column (cx, cy) (grid-relative cell coordinates inside the grid) for the cells zlo .. zhi that the grid stores:
+// e[i] .. e[i + 1] = the blocks of cell zc0 + i, i < nzc (nzc = 0: nothing stored there), e[0] .. e[nzc] = the whole run.
+// Dense grid: one table over the bounding box.  Two-level grid: the column's tile first (DevMap::grid_tiles), then its own offsets.
+template <int TILED>
+__device__ __forceinline__ const uint32_t* col_cells(const DevMap& m, int cx, int cy, int zlo, int zhi, int& zc0, int& nzc) {
+    if (!TILED) {
+        zc0 = zlo;
+        nzc = zhi - zlo + 1;
+        return m.grid_start + (((unsigned)cx * (unsigned)m.gny + (unsigned)cy) * (unsigned)m.gnz + (unsigned)zlo);
+    }
+    const uint2 te = m.grid_tiles[(unsigned)(cx >> kTileShift) * (unsigned)m.gtny + (unsigned)(cy >> kTileShift)];
+    const int z0 = (int)(te.y & 0xFFFFu), nz = (int)(te.y >> 16);
+    const int lo = min(max(zlo - z0, 0), nz), hi = min(max(zhi + 1 - z0, lo), nz);
+    zc0 = z0 + lo;
+    nzc = hi - lo;
+    return m.grid_start + te.x + (unsigned)(((cx & (kTile - 1)) << kTileShift) | (cy & (kTile - 1))) * (unsigned)(nz + 1) + (unsigned)lo;
+}
+
 #ifndef ELM_GRID_WAVES
 #define ELM_GRID_WAVES 7 // minimum waves per SIMD = a 72-VGPR cap (2 spilled registers).  Measured registrations/s: 5 -> 59.8k, 6 -> 63.9k, 7 -> 65.6k,
                          // 8 (35 spills) -> 54.2k: the kernel is bound by memory latency, not by VALU issue (67 % busy) or HBM bandwidth
@@ -1185,7 +1203,7 @@ __device__ __forceinline__ void two_smallest(float d, unsigned u, unsigned& m1, 
 #ifndef ELM_GICP_WAVES
 #define ELM_GICP_WAVES 5
 #endif
-template <int METHOD, int COMPACT>
+template <int METHOD, int COMPACT, int TILED>
 __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_GICP_WAVES)) void k_accumulate_grid(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
                                                                             unsigned total_blocks, const ScanState* __restrict__ st,
                                                                             double* __restrict__ partials, const RegParams rp) {
@@ -1237,7 +1255,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
         const GridAxis ax = grid_axis(gx, m), ay = grid_axis(gy, m), az = grid_axis(gz, m);
         // statistics of the reference's walk for this query voxel: candidates and occupied buckets among the 27
         unsigned stat = 0;
-        {
+        if (!TILED) { // (the two-level grid keeps no dense statistics box: its work counters read 0)
             const int ux = ax.f - m.vx0, uy = ay.f - m.vy0, uz = az.f - m.vz0;
             const bool in_box = (unsigned)ux < (unsigned)m.vnx && (unsigned)uy < (unsigned)m.vny && (unsigned)uz < (unsigned)m.vnz;
             const unsigned sidx = in_box ? ((unsigned)ux * (unsigned)m.vny + (unsigned)uy) * (unsigned)m.vnz + (unsigned)uz : 0u;
@@ -1268,9 +1286,15 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
             const int cx = (k >> 1) ? rx1 : rx0, cy = (k & 1) ? ry1 : ry0;
             const bool dup = ((k >> 1) && rx1 == rx0) || ((k & 1) && ry1 == ry0); // a span clipped to one cell
             ok[k] = inside && !dup;
-            const unsigned cell = ok[k] ? ((unsigned)cx * (unsigned)m.gny + (unsigned)cy) * (unsigned)m.gnz + (unsigned)rz0 : 0u;
-            const uint32_t* e = m.grid_start + cell;
-            s0[k] = e[0]; s1[k] = e[1]; s2[k] = e[2];
+            if (!TILED) {
+                const unsigned cell = ok[k] ? ((unsigned)cx * (unsigned)m.gny + (unsigned)cy) * (unsigned)m.gnz + (unsigned)rz0 : 0u;
+                const uint32_t* e = m.grid_start + cell;
+                s0[k] = e[0]; s1[k] = e[1]; s2[k] = e[2];
+            } else { // the column's tile, then the two ends of its run (a masked column reads tile 0 / entry 0)
+                int zc0, nzc;
+                const uint32_t* e = col_cells<1>(m, ok[k] ? cx : 0, ok[k] ? cy : 0, rz0, rz1, zc0, nzc);
+                s0[k] = e[0]; s1[k] = e[nzc]; s2[k] = s1[k];
+            }
         }
         // everything that does not need the loads goes HERE, in their shadow (the asm is a scheduling barrier: left alone the
         // compiler waits for the offsets first and does this arithmetic on the critical path -- 7 % of the kernel)
@@ -1298,7 +1322,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 b0a[k] = ok[k] ? (int)s0[k] : 0;
-                b1a[k] = ok[k] ? (int)((rz1 > rz0) ? s2[k] : s1[k]) : 0;
+                b1a[k] = ok[k] ? (int)((rz1 > rz0 || TILED) ? s2[k] : s1[k]) : 0;
             }
             // column k = (ix << 1) | iy; own column o, y neighbour o ^ 1, x neighbour o ^ 2, diagonal o ^ 3
             const bool o0 = oy != 0, o1 = ox != 0, xfirst = Bx <= By;
@@ -1430,8 +1454,9 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
                 for (int c = (int)rl; c < ncol; c += (int)LPI) {
                     const int qx = (int)(((float)c + 0.5f) * rny);
                     const int cx = lox + qx, cy = loy + (c - qx * ny);
-                    const uint32_t* e = m.grid_start + (((unsigned)cx * (unsigned)m.gny + (unsigned)cy) * (unsigned)m.gnz + (unsigned)loz);
-                    const int b0 = (int)e[0], b1 = (int)e[nz];
+                    int zc0, nzc;
+                    const uint32_t* e = col_cells<TILED>(m, cx, cy, loz, hiz, zc0, nzc);
+                    const int b0 = (int)e[0], b1 = (int)e[nzc];
                     walked += 4 * (b1 - b0);
                     for (int b = b0; b < b1; ++b) {
                         const GridBlk B = lp[b];
@@ -1465,9 +1490,10 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
 #pragma unroll 1
                 for (int c = (int)rl; c < ncol64; c += (int)LPI) {
                     const int cx = lox + c / ny, cy = loy + c % ny;
-                    const uint32_t* e = m.grid_start + (((size_t)cx * m.gny + cy) * m.gnz + loz);
+                    int zc0, nzc;
+                    const uint32_t* e = col_cells<TILED>(m, cx, cy, loz, hiz, zc0, nzc);
 #pragma unroll 1
-                    for (int k = 4 * (int)e[0]; k < 4 * (int)e[nz]; ++k) {
+                    for (int k = 4 * (int)e[0]; k < 4 * (int)e[nzc]; ++k) {
                         const Pt3 q = blk_point(lp, k);
                         const double ex = (double)q.x - R.gx, ey = (double)q.y - R.gy, ez = (double)q.z - R.gz;
                         bd = fmin((ex * ex + ey * ey) + ez * ez, bd);
@@ -1481,10 +1507,11 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
                     const int cx = lox + c / ny, cy = loy + c % ny;
                     const int ccx = cx + m.gx0, ccy = cy + m.gy0;
                     const int kx = ccx >= 2 ? ccx >> 1 : (ccx >= -2 ? 0 : (ccx + 2) >> 1), ky = ccy >= 2 ? ccy >> 1 : (ccy >= -2 ? 0 : (ccy + 2) >> 1);
-                    const uint32_t* e = m.grid_start + (((size_t)cx * m.gny + cy) * m.gnz + loz);
+                    int zc0, nzc;
+                    const uint32_t* e = col_cells<TILED>(m, cx, cy, loz, hiz, zc0, nzc);
 #pragma unroll 1
-                    for (int z = 0; z < nz; ++z) {
-                        const int ccz = loz + z + m.gz0;
+                    for (int z = 0; z < nzc; ++z) {
+                        const int ccz = zc0 + z + m.gz0;
                         const int kz = ccz >= 2 ? ccz >> 1 : (ccz >= -2 ? 0 : (ccz + 2) >> 1);
                         const unsigned rank = (unsigned)(((kx - ax.f + 1) * 3 + (ky - ay.f + 1)) * 3 + (kz - az.f + 1));
 #pragma unroll 1
@@ -2603,12 +2630,11 @@ void launch_accumulate_cell(hipStream_t s, const DevMap& m, const ScanDesc* scan
 void launch_accumulate_grid(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                             ScanState* st, double* partials, const RegParams& rp) {
     dim3 g(total_blocks), b(kBlock);
-    if (rp.method == ELM_P2P)
-        hipLaunchKernelGGL((k_accumulate_grid<ELM_P2P, 0>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
-    else if (m.gicp_compact)
-        hipLaunchKernelGGL((k_accumulate_grid<ELM_GICP, 1>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
-    else
-        hipLaunchKernelGGL((k_accumulate_grid<ELM_GICP, 0>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);
+#define ELM_LAUNCH_G(M, C, T) hipLaunchKernelGGL((k_accumulate_grid<M, C, T>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp)
+    if (rp.method == ELM_P2P) { if (m.grid_tiled) ELM_LAUNCH_G(ELM_P2P, 0, 1); else ELM_LAUNCH_G(ELM_P2P, 0, 0); }
+    else if (m.gicp_compact) { if (m.grid_tiled) ELM_LAUNCH_G(ELM_GICP, 1, 1); else ELM_LAUNCH_G(ELM_GICP, 1, 0); }
+    else { if (m.grid_tiled) ELM_LAUNCH_G(ELM_GICP, 0, 1); else ELM_LAUNCH_G(ELM_GICP, 0, 0); }
+#undef ELM_LAUNCH_G
 }
 void launch_gather_gicp(hipStream_t s, const DevMap& m, size_t n_slots, double* out, int compact) {
     const size_t threads = n_slots * (compact ? 8 : 16);

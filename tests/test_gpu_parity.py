@@ -471,7 +471,16 @@ def test_full_size_c4_vgicp_shape(ctx, oracle):
     _compare_run(det, ref)
 
 
-@pytest.mark.parametrize("kernel_env", ["grid", "lists", "direct"])
+def _set_kernel_env(monkeypatch, kernel_env):
+    """grid: dense cell grid (default); tiled: its two-level form forced; lists / direct: the older kernel generations"""
+    if kernel_env == "tiled":
+        monkeypatch.setenv("ELM_KERNEL", "grid")
+        monkeypatch.setenv("ELM_GRID", "tiled")
+    else:
+        monkeypatch.setenv("ELM_KERNEL", kernel_env)
+
+
+@pytest.mark.parametrize("kernel_env", ["grid", "tiled", "lists", "direct"])
 @pytest.mark.parametrize("voxel_size,max_pts,th,method", [
     (0.5, 30, 5.0, 0),    # finer voxels
     (1.5, 50, 5.0, 1),    # README-recommended 50 points per voxel (buckets > 32 points), GICP
@@ -483,7 +492,7 @@ def test_full_size_c4_vgicp_shape(ctx, oracle):
 def test_config_variants(oracle, world100k, voxel_size, max_pts, th, method, kernel_env, monkeypatch):
     """Non-default map / registration parameters, on every accumulate kernel generation (ELM_KERNEL)."""
     from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod
-    monkeypatch.setenv("ELM_KERNEL", kernel_env)
+    _set_kernel_env(monkeypatch, kernel_env)
     c = Context(0)  # the kernel mode is read at context creation
     try:
         m = IcpMethod(method)
@@ -517,14 +526,14 @@ def _tie_world():
     return lattice, scan
 
 
-@pytest.mark.parametrize("kernel_env", ["grid", "lists", "direct"])
+@pytest.mark.parametrize("kernel_env", ["grid", "tiled", "lists", "direct"])
 @pytest.mark.parametrize("method", [0, 1, 2])
 def test_exact_ties_follow_the_reference_visiting_order(oracle, method, kernel_env, monkeypatch):
     """Equal float64 distances: the reference keeps the FIRST strict minimum of its walk (27 voxels x-major..z-minor,
     insertion order inside a bucket, vhm.cpp:31-88 / 208-243).  GICP's target is the matched point's neighbourhood mean
     and VGICP's the matched voxel's mean, so a different pick among tied candidates changes the sums."""
     from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod
-    monkeypatch.setenv("ELM_KERNEL", kernel_env)
+    _set_kernel_env(monkeypatch, kernel_env)
     c = Context(0)
     try:
         lattice, scan = _tie_world()
@@ -536,7 +545,7 @@ def test_exact_ties_follow_the_reference_visiting_order(oracle, method, kernel_e
         ref = oracle.register(om, scan, T0, oracle.default_config(method, max_iteration=3, icp_termination_threshold_m=0.0,
                                                                   min_overlap_ratio=0.0, max_fitness_score=10.0))
         _compare_run(det, ref)
-        if kernel_env in ("grid", "lists") and method in (0, 1):
+        if kernel_env in ("grid", "tiled", "lists") and method in (0, 1):
             assert det["fallback_blocks"] > 0  # the tied points really went through the exact float64 stage
     finally:
         c.close()
@@ -667,6 +676,51 @@ def test_randomized_configs_list_kernels(oracle, seed, monkeypatch):
         c.close()
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_randomized_configs_two_level_grid(oracle, seed, monkeypatch):
+    """The same sweep with the two-level (tiled) form of the cell grid forced: tile lookups, per-tile z ranges, empty tiles."""
+    from elimaloc_amd.registration import Context
+    monkeypatch.setenv("ELM_GRID", "tiled")
+    c = Context(0)
+    try:
+        _randomized_case(c, oracle, 100 + seed)
+    finally:
+        c.close()
+
+
+def test_city_scale_sparse_map_runs_the_grid_kernel(oracle):
+    """Districts of a map scattered over a 2 km x 2 km x 100 m box (3.2 G half-metre cells: beyond the dense grid's budget) get the
+    two-level grid -- the grid kernel, not the 27x neighbourhood lists -- with an index no larger than the dense one of a compact
+    map of the same size; P2P and GICP follow the oracle, also for a scan that straddles empty tiles."""
+    from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod
+    base = synth.make_world(60000, seed=77)
+    rng = np.random.default_rng(5)
+    offs = np.array([[-990.0, -985.0, 0.0], [975.0, 990.0, 92.0], [-400.0, 812.0, 37.0], [640.0, -930.0, 11.0], [3.0, -7.0, 55.0]])
+    world = np.ascontiguousarray(np.concatenate([base + o.astype(np.float32) for o in offs]).astype(np.float32))
+    c = Context(0)
+    try:
+        for method in (IcpMethod.P2P, IcpMethod.GICP):
+            vm, om = _maps(c, oracle, world, method)
+            k = 1 + int(method)
+            scan, T_true = synth.make_scan(base, 6000, seed=31 + k)  # cut from the district before it was moved
+            T_true = T_true.copy()
+            T_true[:3, 3] += offs[k]
+            T0 = synth.perturb(T_true, seed=41 + k, max_trans=0.3, max_rot_deg=1.0)
+            *_, det = Registration(RegistrationConfig(icp_method=method), c).RunRegister(scan, vm, T0, trace=True)
+            info = vm.info()
+            assert int(info.layout_flags) & 4, "expected the two-level grid"
+            assert info.nbr_entries == info.n_points  # every map point once: not the 27x lists
+            assert info.index_bytes < 60 * info.n_points  # blocks + offsets of occupied tiles + tile table
+            _compare_run(det, oracle.register(om, scan, T0, oracle.default_config(int(method))))
+            # a pose far from every district: no correspondences -> the overlap gate, exactly like the reference
+            far = np.eye(4); far[:3, 3] = [300.0, 300.0, 70.0]
+            pose, ok, *_ = Registration(RegistrationConfig(icp_method=method), c).RunRegister(scan, vm, far)
+            ref = oracle.register(om, scan, far, oracle.default_config(int(method)))
+            assert ok == ref["is_success"] and np.abs(pose - ref["T"]).max() < 1e-9
+    finally:
+        c.close()
+
+
 def test_grid_budget_voxel_lists_use_the_hash(oracle, world100k, monkeypatch):
     """VGICP / AVGICP on a map whose floor-key box exceeds the cell budget: the voxel-mean lists are found through the query hash
     instead of the dense table: same results."""
@@ -685,9 +739,11 @@ def test_grid_budget_voxel_lists_use_the_hash(oracle, world100k, monkeypatch):
 
 
 def test_grid_budget_falls_back_to_lists(oracle, world100k, monkeypatch):
-    """A map whose bounding box exceeds the cell budget gets the neighbourhood lists instead: same results."""
+    """A map whose bounding box exceeds the cell budget, with the two-level grid forbidden (ELM_GRID=dense), gets the
+    neighbourhood lists: same results."""
     from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod
     monkeypatch.setenv("ELM_GRID_MAX_CELLS", "1000")
+    monkeypatch.setenv("ELM_GRID", "dense")
     c = Context(0)
     try:
         vm, om = _maps(c, oracle, world100k, IcpMethod.P2P)
@@ -860,7 +916,7 @@ def test_compact_covariance_records_equal_the_stored_inverses(oracle, world100k,
             else:
                 vm.CalVoxelCovAll()
             runs[mode] = Registration(RegistrationConfig(icp_method=m), c).RunRegister(scan, vm, T0, trace=True)[-1]
-            bits = int(vm.info().compact_records)
+            bits = int(vm.info().layout_flags)
             want_bit = 1 if m == IcpMethod.GICP else 2
             assert bool(bits & want_bit) == (mode == "compact"), (mode, bits)  # the jittered world has no rank-deficient neighbourhood
         finally:
@@ -905,7 +961,7 @@ def test_rank_deficient_covariances_keep_the_full_records(oracle):
             got = Registration(RegistrationConfig(icp_method=m), c).RunRegister(scan, vm, T0, trace=True)[-1]
             ref = oracle.register(om, scan, T0, oracle.default_config(method))
             dt, dr = synth.pose_error(ref["T"], got["T"])
-            assert ref["iterations"] == got["iterations"] and ref["is_success"] == got["is_success"], (method, int(vm.info().compact_records))
-            assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (method, dt, dr, int(vm.info().compact_records))
+            assert ref["iterations"] == got["iterations"] and ref["is_success"] == got["is_success"], (method, int(vm.info().layout_flags))
+            assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (method, dt, dr, int(vm.info().layout_flags))
     finally:
         c.close()
