@@ -1957,8 +1957,10 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
         if (distributed) {
             launch_solve(ctx->stream, dsc, S, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 1, d_active);
             if ((rc = exchange(ctx, (double*)ctx->d_sums.p, (size_t)S * kSums)) != ELM_OK) return rc;
-            launch_solve(ctx->stream, dsc, S, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 2, d_active);
-            launch_stream_refill(ctx->stream, dsc, st, S, d_q, d_qT0, d_out, d_ctrl, 0); // slot assignment identical on every rank
+            // the solve also refills: slot s serves the registrations s, s + S, s + 2 S, ... -- a function of the slot alone, so every
+            // rank hands out the same registrations without a refill launch (3 launches + 1 collective per iteration)
+            const StreamArgs sr = {dsc, d_q, d_qT0, d_out, d_ctrl, 0, S};
+            launch_solve(ctx->stream, dsc, S, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 2, d_active, &sr);
         } else {
             // single rank: the solve hands finished slots their next registration itself (no refill launch)
             const StreamArgs sa = {dsc, d_q, d_qT0, d_out, d_ctrl, 0, 0};

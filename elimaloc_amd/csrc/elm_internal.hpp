@@ -171,7 +171,8 @@ struct StreamArgs {
     ScanState* out_state;
     StreamCtrl* ctrl; // nullptr: no refill in the solve
     int32_t hostfed;  // 1: the queue fills while the stream runs (ctrl->ready grows): idle slots look for work at every solve
-    int32_t _pad;
+    int32_t stride;   // > 0 (multi-rank streams): slot s serves the registrations s, s + stride, s + 2 stride, ... -- an assignment that
+                      // is a function of the slot alone, hence identical on every rank without any exchange; 0: first come, first served
 };
 
 struct RegParams {

@@ -2066,8 +2066,11 @@ __global__ __launch_bounds__(1024) void k_stream_refill(ScanDesc* scans, ScanSta
     }
 }
 
-// Wave-parallel 6x6 LDL^T with diagonal pivoting (the pivot rule of Eigen's LDLT: largest |diagonal| of the trailing
-// Schur complement, symmetric exchange), right-looking, on a matrix spread over lanes: lane l < 36 holds A[l/6][l%6].
+// Wave-parallel 6x6 LDL^T with Eigen's diagonal pivoting (Eigen/src/Cholesky/LDLT.h, ldlt_inplace<Lower>::unblocked): that routine
+// is left-looking -- at step k only column k has been updated -- so its pivot search `mat.diagonal().tail(size - k).cwiseAbs()
+// .maxCoeff()` sees the ORIGINAL diagonal entries of the rows not yet eliminated, in their current positions (every symmetric
+// exchange k <-> p moves row k to position p), and keeps the first of equal maxima.  The elimination itself runs right-looking here
+// (same L and D up to rounding), on a matrix spread over lanes: lane l < 36 holds A[l/6][l%6].
 // All 64 lanes execute it with uniform control flow.  Returns x = A^-1 b (uniform in every lane) and, when want_inv,
 // leaves A^-1[l/6][l%6] in `inv_elem` of lane l < 36.  ~3 us instead of ~25 us for the single-lane version.
 __device__ __forceinline__ void wave_ldlt6(double a, const double* b, double x[6], bool want_inv, double& inv_elem) {
@@ -2077,15 +2080,25 @@ __device__ __forceinline__ void wave_ldlt6(double a, const double* b, double x[6
     int order[6];
     double piv[6];
     int rank_i = 6, rank_j = 6, rank_l = 6; // elimination step of row li / column lj / index `lane` (lane < 6)
+    double d0[6]; // |original diagonal|
+    int pos[6];   // pos[j] = the row that Eigen's exchanges have moved to position j
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { d0[i] = fabs(__shfl(a, i * 7, 64)); pos[i] = i; }
+    auto d0_of = [&](int r) { return r == 0 ? d0[0] : r == 1 ? d0[1] : r == 2 ? d0[2] : r == 3 ? d0[3] : r == 4 ? d0[4] : d0[5]; };
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-        int p = 0;
-        double best = -1.0;
+        int jb = k;
+        double best = d0_of(pos[k]);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const double di = __shfl(a, i * 7, 64);
-            if (((active >> i) & 1u) && fabs(di) > best) { best = fabs(di); p = i; }
+        for (int j = k + 1; j < 6; ++j) {
+            const double v = d0_of(pos[j]);
+            if (v > best) { best = v; jb = j; } // strict: the first maximum stays
         }
+        int p = pos[k];
+#pragma unroll
+        for (int j = k + 1; j < 6; ++j)
+            if (j == jb) { p = pos[j]; pos[j] = pos[k]; }
+        pos[k] = p;
         const double dp = __shfl(a, p * 7, 64);
         const double aip = __shfl(a, li * 6 + p, 64), apj = __shfl(a, p * 6 + lj, 64);
         const bool ai = ((active >> li) & 1u) && li != p, aj = ((active >> lj) & 1u) && lj != p;
@@ -2167,7 +2180,11 @@ __device__ __forceinline__ void wave_ldlt6(double a, const double* b, double x[6
 // queue position for a free slot, or -1 when nothing is pending.  Plain streams: every registration is there from the start, one
 // atomicAdd hands them out.  Host-fed streams: only registrations whose scan has landed in HBM (ctrl->ready, published by the upload
 // stream after the scan's ordering kernel) may start, so the counter advances by compare-and-swap and never overshoots.
-__device__ __forceinline__ int claim_registration(const StreamArgs& sa) {
+__device__ __forceinline__ int claim_registration(const StreamArgs& sa, int prev) {
+    if (sa.stride > 0) { // static queue per slot (every rank takes the same decision)
+        const int r = prev + sa.stride;
+        return (r < sa.ctrl->total) ? r : -1;
+    }
     if (!sa.hostfed) {
         const int r = atomicAdd(&sa.ctrl->next, 1);
         return (r < sa.ctrl->total) ? r : -1;
@@ -2183,10 +2200,10 @@ __device__ __forceinline__ int claim_registration(const StreamArgs& sa) {
 }
 // The slot takes the next pending registration (descriptor + initial state: init_scan_state's arithmetic) or goes idle.
 // All 64 lanes of the solve's first wavefront call it (uniform).
-__device__ __forceinline__ void start_slot(const StreamArgs& sa, ScanState& S, int s) {
+__device__ __forceinline__ void start_slot(const StreamArgs& sa, ScanState& S, int s, int prev) {
     const int lane = threadIdx.x & 63;
     int r = 0;
-    if (lane == 0) r = claim_registration(sa);
+    if (lane == 0) r = claim_registration(sa, prev);
     r = __shfl(r, 0, 64);
     if (r >= 0) {
         const double* T0 = sa.qT0 + (size_t)r * 16;
@@ -2217,7 +2234,8 @@ __device__ __forceinline__ void start_slot(const StreamArgs& sa, ScanState& S, i
 // state and takes the next pending registration for the slot -- what k_stream_refill does, without the extra launch.  The
 // queue position comes from an atomic counter, so WHICH slot serves a registration depends on the order the workgroups get
 // here; a registration's arithmetic does not depend on its slot (uniform slot sizes, partial sums in block order), so every
-// result is unchanged.  Multi-rank streams keep k_stream_refill: there the slot assignment must be identical on every rank.
+// result is unchanged.  Multi-rank streams must assign identically on every rank: there slot s serves the registrations s, s + S,
+// s + 2 S, ... (StreamArgs::stride), also from inside the solve; k_stream_refill only does the initial fill.
 // The lead lane's plain stores to S are ordered against the other lanes' loads by a workgroup-scope release / acquire fence pair
 // (the wavefront is the only writer and the only reader of S inside this launch) and re-read with agent-scope loads.
 __device__ __forceinline__ void finish_slot(const StreamArgs& sa, ScanState& S, int s) {
@@ -2238,7 +2256,7 @@ __device__ __forceinline__ void finish_slot(const StreamArgs& sa, ScanState& S, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0); // the copy's loads are done before the state is overwritten
     __builtin_amdgcn_wave_barrier();
-    start_slot(sa, S, s);
+    start_slot(sa, S, s, reg_old);
 }
 
 constexpr int kSolveThreads = 1024;
@@ -2298,7 +2316,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* scans, 
     if (t >= 64) return; // the first wave does the rest with uniform control flow; lane 0 owns the state
     if (done) {
         // host-fed stream: an idle slot (nothing was pending when it last looked) takes a registration whose scan has arrived since
-        if (sa.ctrl && sa.hostfed && __hip_atomic_load(&S.reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) start_slot(sa, S, s);
+        if (sa.ctrl && sa.hostfed && __hip_atomic_load(&S.reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) start_slot(sa, S, s, -1);
         return;
     }
     const bool lead = (t == 0);

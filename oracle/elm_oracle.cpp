@@ -1806,6 +1806,12 @@ void orc_jacobi_svd3(const double A[9], double U[9], double S[3], double V[9]) {
     std::memcpy(U, u.m, sizeof(u.m));
     std::memcpy(V, v.m, sizeof(v.m));
 }
+void orc_smallest_eigenvector(const double C[9], double n[3]) {
+    M3 c;
+    std::memcpy(c.m, C, sizeof(c.m));
+    const V3 v = smallest_eigenvector(c);
+    n[0] = v.x; n[1] = v.y; n[2] = v.z;
+}
 void orc_angle_axis_to_matrix(const double rotvec[3], double R[9]) {
     M3 r = rotvec_to_matrix(V3{rotvec[0], rotvec[1], rotvec[2]});
     std::memcpy(R, r.m, sizeof(r.m));

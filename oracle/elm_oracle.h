@@ -142,6 +142,8 @@ void orc_shape_odom_covariance(const double local_cov[36], const double pose[16]
 void orc_ldlt_solve6(const double A[36], const double b[6], double x[6]);
 void orc_inverse6(const double A[36], double Ainv[36]);
 void orc_jacobi_svd3(const double A[9], double U[9], double S[3], double V[9]);
+/* eigenvector of the smallest eigenvalue as reg.cpp:89-91 takes it from SelfAdjointEigenSolver (col(0)); C col-major */
+void orc_smallest_eigenvector(const double C[9], double n[3]);
 void orc_angle_axis_to_matrix(const double rotvec[3], double R[9]);
 double orc_matrix_to_angle(const double R[9]);
 

@@ -129,6 +129,7 @@ def lib():
         L.orc_ldlt_solve6.argtypes = [dp, dp, dp]
         L.orc_inverse6.argtypes = [dp, dp]
         L.orc_jacobi_svd3.argtypes = [dp, dp, dp, dp]
+        L.orc_smallest_eigenvector.argtypes = [dp, dp]
         L.orc_angle_axis_to_matrix.argtypes = [dp, dp]
         L.orc_matrix_to_angle.restype = C.c_double
         L.orc_matrix_to_angle.argtypes = [dp]
@@ -309,6 +310,13 @@ def jacobi_svd3(A):
     U = np.empty(9); S = np.empty(3); V = np.empty(9)
     lib().orc_jacobi_svd3(_dp(A), _dp(U), _dp(S), _dp(V))
     return U.reshape(3, 3, order="F"), S, V.reshape(3, 3, order="F")
+
+
+def smallest_eigenvector(C):
+    C = np.asarray(C, dtype=np.float64).ravel(order="F").copy()
+    n = np.empty(3)
+    lib().orc_smallest_eigenvector(_dp(C), _dp(n))
+    return n
 
 
 def angle_axis_to_matrix(v):

@@ -203,3 +203,48 @@ def register(vox, scan, T0, method, voxel_size=1.0, max_iteration=10, th=5.0, la
     ok = not (fitness > max_fitness)
     return dict(T=T, is_success=ok, iterations=iters, gate=0 if ok else 3, iters=trace, fitness=fitness,
                 local_cov=local_cov)
+
+
+def eigen_ldlt_solve(A, b):
+    """Independent numpy statement of Eigen 3.3.7's LDLT<MatrixXd, Lower>::compute + solve, written from the published routine
+    (Eigen/src/Cholesky/LDLT.h: ldlt_inplace<Lower>::unblocked and LDLT::_solve_impl).  The factorisation is LEFT-looking: at step
+    k only column k is updated (A[k,k] -= A10 (D A10^T), A21 -= A20 (D A10^T)), so the pivot search
+    `mat.diagonal().tail(size-k).cwiseAbs().maxCoeff()` sees the not-yet-updated (original, permuted) diagonal entries of the
+    rows below k; the FIRST of equal maxima wins; the symmetric exchange touches the lower triangle only; the column is divided by
+    the pivot unless the pivot is exactly zero; the solve divides by D only where |d| > 1 / max_double (else the component is 0)."""
+    M = np.array(A, dtype=np.float64)
+    M = np.tril(M)  # only the lower triangle is read and written
+    n = M.shape[0]
+    trans = np.zeros(n, dtype=int)
+    for k in range(n):
+        p = k + int(np.argmax(np.abs(np.diag(M)[k:])))
+        trans[k] = p
+        if p != k:
+            s_ = n - p - 1
+            M[[k, p], :k] = M[[p, k], :k]                      # row(k).head(k) <-> row(p).head(k)
+            if s_ > 0:
+                M[p + 1:, [k, p]] = M[p + 1:, [p, k]]          # col(k).tail(s) <-> col(p).tail(s)
+            M[k, k], M[p, p] = M[p, p], M[k, k]
+            for i in range(k + 1, p):                          # the part between, transposed
+                M[i, k], M[p, i] = M[p, i], M[i, k]
+        rs = n - k - 1
+        if k > 0:
+            temp = np.diag(M)[:k] * M[k, :k]
+            M[k, k] -= M[k, :k] @ temp
+            if rs > 0:
+                M[k + 1:, k] -= M[k + 1:, :k] @ temp
+        if rs > 0 and abs(M[k, k]) > 0.0:
+            M[k + 1:, k] /= M[k, k]
+    y = np.asarray(b, dtype=np.float64).copy()
+    for k in range(n):
+        y[k], y[trans[k]] = y[trans[k]], y[k]
+    for i in range(n):
+        y[i] -= M[i, :i] @ y[:i]
+    tol = 1.0 / np.finfo(np.float64).max
+    d = np.diag(M)
+    y = np.where(np.abs(d) > tol, y / np.where(d == 0.0, 1.0, d), 0.0)
+    for i in range(n - 1, -1, -1):
+        y[i] -= M[i + 1:, i] @ y[i + 1:]
+    for k in range(n - 1, -1, -1):
+        y[k], y[trans[k]] = y[trans[k]], y[k]
+    return y

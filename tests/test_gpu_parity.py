@@ -965,3 +965,26 @@ def test_rank_deficient_covariances_keep_the_full_records(oracle):
             assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (method, dt, dr, int(vm.info().layout_flags))
     finally:
         c.close()
+
+
+def test_exactly_singular_normal_equations_zero_pivot(ctx, oracle, world100k):
+    """A scan whose points all lie on the sensor's x axis leaves the rotation about x unobservable: row / column 3 of the P2P
+    JTJ (and of JTJ + lambda diag) is exactly zero.  Eigen's LDLT (reg.cpp:56) then meets an exactly-zero pivot and its solve
+    zeroes that component (D^-1 with the 1 / max_double cut-off): the device solve must do the same, every iteration."""
+    from elimaloc_amd.registration import Registration, RegistrationConfig, IcpMethod
+    vm, om = _maps(ctx, oracle, world100k, IcpMethod.P2P)
+    scan = np.zeros((96, 3), np.float32)
+    scan[:, 0] = np.linspace(1.0, 24.0, 96, dtype=np.float32)
+    T0 = np.eye(4)
+    T0[:3, :3] = synth.rot_zyx(0.0, 0.0, 0.3)
+    T0[:3, 3] = [-9.0, -4.0, 0.36]
+    cfg = dict(max_iteration=6, icp_termination_threshold_m=0.0, min_overlap_ratio=0.0, max_fitness_score=10.0)
+    *_, det = Registration(RegistrationConfig(icp_method=IcpMethod.P2P, **cfg), ctx).RunRegister(scan, vm, T0, trace=True)
+    ref = oracle.register(om, scan, T0, oracle.default_config(0, **cfg))
+    assert det["iterations"] == ref["iterations"] == 6
+    for g, r in zip(det["iters"], ref["iters"]):
+        assert g["n_corr"] == r["n_corr"]
+        assert np.all(g["JTJ"][3, :] == 0.0) and np.all(g["JTJ"][:, 3] == 0.0) and np.all(r["JTJ"][3, :] == 0.0)
+        assert g["x"][3] == 0.0 and r["x"][3] == 0.0
+        np.testing.assert_allclose(g["x"], r["x"], rtol=0, atol=1e-9 * max(1.0, np.abs(r["x"]).max()))
+        np.testing.assert_allclose(g["T"], r["T"], rtol=0, atol=1e-9)

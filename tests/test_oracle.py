@@ -24,6 +24,68 @@ def test_ldlt_and_inverse_against_numpy(oracle):
     assert np.array_equal(oracle.ldlt_solve6(np.zeros((6, 6)), np.ones(6)), np.zeros(6))
 
 
+def test_ldlt_discrete_cases_follow_eigens_published_algorithm(oracle):
+    """The cases where Eigen's LDLT (registration.cpp:56,138,214) takes discrete decisions -- pivot order, exactly-zero pivots,
+    negative pivots -- against an independent numpy statement of the published algorithm (np_ref.eigen_ldlt_solve)."""
+    rng = np.random.default_rng(7)
+    cases = []
+    for _ in range(20):  # indefinite, well conditioned: negative pivots, pivot order matters for nothing but must not break anything
+        Q, _ = np.linalg.qr(rng.normal(size=(6, 6)))
+        cases.append((Q @ np.diag([5.0, -3.0, 2.0, -1.5, 1.0, 0.7]) @ Q.T, rng.normal(size=6), True))
+    # equal diagonal entries: the FIRST of the maxima is the pivot
+    H = np.full((6, 6), 0.25) + np.diag([2.0, 2.0, 2.0, 1.0, 2.0, 1.0])
+    cases.append((H, np.arange(1.0, 7.0), True))
+    # exact zero pivots (integers: no rounding): rank 3, the system of a scan whose points lie on the sensor's x axis has this shape
+    J = np.array([[1, 0, 0, 0, 2, -1], [0, 1, 0, -2, 0, 3], [0, 0, 1, 1, -3, 0]], dtype=np.float64)
+    cases.append((J.T @ J, J.T @ np.array([1.0, -2.0, 0.5]), False))
+    Z = np.zeros((6, 6)); Z[0, 0] = 4.0; Z[2, 2] = 1.0; Z[0, 2] = Z[2, 0] = 1.0  # zero rows / columns: components of zero pivots are zeroed
+    cases.append((Z, np.array([1.0, 5.0, 2.0, 7.0, 0.0, 3.0]), False))
+    for A, b, nonsingular in cases:
+        x = oracle.ldlt_solve6(A, b)
+        np.testing.assert_allclose(x, np_ref.eigen_ldlt_solve(A, b), rtol=1e-11, atol=1e-13)
+        if nonsingular:
+            np.testing.assert_allclose(x, np.linalg.solve(A, b), rtol=1e-9, atol=1e-12)
+    x = oracle.ldlt_solve6(Z, np.array([1.0, 5.0, 2.0, 7.0, 0.0, 3.0]))
+    assert x[1] == 0.0 and x[3] == 0.0 and x[4] == 0.0 and x[5] == 0.0  # D^-1 with Eigen's 1 / max_double cut-off
+    np.testing.assert_allclose(Z[np.ix_([0, 2], [0, 2])] @ x[[0, 2]], [1.0, 2.0], rtol=1e-14)
+
+
+def test_jacobi_svd_on_rank_deficient_and_signed_input(oracle):
+    """JacobiSVD<Matrix3d> (voxel_hash_map.hpp:141,241) where its conventions show: rows / columns that are exactly zero are never
+    rotated (two-sided Jacobi only touches index pairs with a non-zero off-diagonal), so an exactly planar neighbourhood gets the
+    SAME third column in U and V and its regularisation U diag(1,1,1e-3) V^T is symmetric; the sign of a negative diagonal entry
+    goes into U, not V (JacobiSVD.h step 3), so U != V for indefinite symmetric input."""
+    rng = np.random.default_rng(11)
+    P = rng.normal(size=(2, 30))
+    C = np.zeros((3, 3)); C[:2, :2] = np.cov(P)  # points with z exactly constant
+    U, S, V = oracle.jacobi_svd3(C)
+    assert S[2] == 0.0 and np.array_equal(np.abs(U[:, 2]), [0.0, 0.0, 1.0]) and np.array_equal(U[:, 2], V[:, 2])
+    reg = U @ np.diag([1.0, 1.0, 1e-3]) @ V.T
+    np.testing.assert_allclose(reg, np.eye(3) - 0.999 * np.outer([0, 0, 1.0], [0, 0, 1.0]), atol=1e-15)
+    np.testing.assert_allclose(U @ np.diag(S) @ V.T, C, atol=1e-14)
+    U, S, V = oracle.jacobi_svd3(np.diag([0.7, 0.0, 0.0]))  # collinear points along x: already diagonal, nothing to do
+    assert np.array_equal(U, np.eye(3)) and np.array_equal(V, np.eye(3)) and np.array_equal(S, [0.7, 0.0, 0.0])
+    U, S, V = oracle.jacobi_svd3(np.diag([0.0, 2.0, 3.0]))  # sorted by decreasing singular value: columns of U and V move together
+    assert np.array_equal(S, [3.0, 2.0, 0.0]) and np.array_equal(U, V) and np.array_equal(np.abs(U), np.eye(3)[:, [2, 1, 0]])
+    U, S, V = oracle.jacobi_svd3(np.diag([2.0, -1.0, 0.5]))  # a negative "singular value" is made positive by negating U's column
+    assert np.array_equal(S, [2.0, 1.0, 0.5]) and np.array_equal(V, np.eye(3)) and np.array_equal(U, np.diag([1.0, -1.0, 1.0]))
+
+
+def test_smallest_eigenvector_conventions(oracle):
+    """SelfAdjointEigenSolver<Matrix3d>::eigenvectors().col(0) (registration.cpp:89-91) on already-diagonal input: the 3x3
+    tridiagonalisation leaves the identity as eigenvector basis, the ascending sort is a selection sort that only swaps for a
+    strictly smaller value -- so the first of equal eigenvalues stays in place: C = I -> e_x."""
+    assert np.array_equal(oracle.smallest_eigenvector(np.eye(3)), [1.0, 0.0, 0.0])
+    assert np.array_equal(np.abs(oracle.smallest_eigenvector(np.diag([1.0, 1.0, 1e-3]))), [0.0, 0.0, 1.0])
+    assert np.array_equal(np.abs(oracle.smallest_eigenvector(np.diag([1.0, 1e-3, 1.0]))), [0.0, 1.0, 0.0])
+    assert np.array_equal(np.abs(oracle.smallest_eigenvector(np.diag([1e-3, 1e-3, 1.0]))), [1.0, 0.0, 0.0])  # two equal smallest: the first
+    rng = np.random.default_rng(12)
+    for _ in range(10):
+        Q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        n = oracle.smallest_eigenvector(Q @ np.diag([1.0, 1.0, 1e-3]) @ Q.T)
+        assert abs(abs(n @ Q[:, 2]) - 1.0) < 1e-12 and abs(np.linalg.norm(n) - 1.0) < 1e-12
+
+
 def test_jacobi_svd_reconstructs_and_orders(oracle):
     rng = np.random.default_rng(1)
     for _ in range(20):
