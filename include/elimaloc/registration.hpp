@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstring>
 #include <utility>
+#include <stdexcept>
 #include <vector>
 
 #include "voxel_hash_map.hpp"
@@ -66,8 +67,19 @@ struct Registration {
                                    const elimaloc::Matrix4d& initial_guess, RegistrationConfig m_config, bool& is_success,
                                    double& fitness_score, elimaloc::Matrix6d& local_cov) {
         scratch_xyz_.resize(3 * source_local.size()); // grows once; no allocation per scan after warm-up
+        // The reference transforms .pose (reg.hpp:142) but builds J and the residual from .local (reg.cpp:34,41); its only producer
+        // sets both to the same float32 point (pcm_matching.hpp:205-220).  The C ABI carries ONE float32 triple per point, so a
+        // caller whose .local differs from .pose is refused instead of being answered with other sums than the reference's
+        // (coordinates that are not float32 values are rounded to float32: INTEGRATION.md, interface differences).
+        bool same = true;
         for (size_t i = 0; i < source_local.size(); ++i)
-            for (int k = 0; k < 3; ++k) scratch_xyz_[3 * i + k] = (float)source_local[i].pose(k); // TransformPoints reads .pose (reg.hpp:142)
+            for (int k = 0; k < 3; ++k) {
+                scratch_xyz_[3 * i + k] = (float)source_local[i].pose(k);
+                same = same && source_local[i].local(k) == source_local[i].pose(k);
+            }
+        if (!same)
+            throw std::invalid_argument("RunRegister: PointStruct.local must equal PointStruct.pose (pcm_matching.hpp:205-220); "
+                                        "see INTEGRATION.md, interface differences");
         const elm_reg_config c = m_config.c_struct();
         elimaloc::Matrix4d T;
         int ok = 0;
