@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libelimaloc_hip.so")
+LIB_PATH = os.environ.get("ELM_LIB") or os.path.join(_HERE, "libelimaloc_hip.so")  # ELM_LIB: developer A/B of prebuilt variants
 
 ELM_OK = 0
 P2P, GICP, VGICP, AVGICP = 0, 1, 2, 3

@@ -2033,9 +2033,16 @@ extern "C" int elm_ctx_measure_h2d(elm_ctx* ctx, const void* host, size_t bytes,
     return ELM_OK;
 }
 
+constexpr int kStageSets = 3; // staging sets of a host-fed stream: the DMA of group g + 2 may run while group g is still being ordered
 static int ensure_side_streams(elm_ctx* ctx) {
     if (!ctx->copy_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-    if (!ctx->order_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->order_stream, hipStreamNonBlocking));
+    if (!ctx->order_stream) {
+        // the ordering kernel runs beside the accumulate launches of the compute stream: highest priority, so that its few workgroups
+        // are dispatched as soon as a CU has room instead of behind the tail of a 65 536-workgroup launch
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; (void)hipGetLastError(); }
+        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->order_stream, hipStreamNonBlocking, hi));
+    }
     if (!ctx->poll_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->poll_stream, hipStreamNonBlocking));
     for (hipEvent_t* e : {&ctx->ev_iter[0], &ctx->ev_iter[1], &ctx->ev_iter[2], &ctx->ev_iter[3]})
         if (!*e) HIPCHK(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -2104,13 +2111,13 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
     std::vector<size_t> off((size_t)count + 1, 0);
     for (int b = 0; b < count; ++b) off[b + 1] = off[b] + ((((size_t)n_pts[b] * sizeof(Pt3)) + 255) & ~(size_t)255);
     if ((rc = dev_reserve(ctx, ctx->d_arena, std::max<size_t>(off[count], 256))) != ELM_OK) return rc;
-    if ((rc = dev_reserve(ctx, ctx->d_raw, 2 * (size_t)G * scan_stride)) != ELM_OK) return rc;
-    if ((rc = dev_reserve(ctx, ctx->d_order_tmp, 2 * (size_t)G * max_n * sizeof(uint32_t))) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_raw, (size_t)kStageSets * G * scan_stride)) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_order_tmp, (size_t)kStageSets * G * max_n * sizeof(uint32_t))) != ELM_OK) return rc;
     if ((rc = dev_reserve(ctx, ctx->d_order_jobs, (size_t)count * sizeof(OrderJob))) != ELM_OK) return rc;
     if ((rc = pinned_reserve(ctx, &ctx->h_jobs, &ctx->h_jobs_cap, std::max<size_t>((size_t)count * sizeof(OrderJob), 4096))) != ELM_OK) return rc;
     OrderJob* hj = (OrderJob*)ctx->h_jobs;
     for (int b = 0; b < count; ++b) {
-        const int set = (b / G) & 1, j = b % G;
+        const int set = (b / G) % kStageSets, j = b % G;
         hj[b].src = (const Pt3*)((char*)ctx->d_raw.p + ((size_t)set * G + j) * scan_stride);
         hj[b].dst = (Pt3*)((char*)ctx->d_arena.p + off[b]);
         hj[b].tmp = (uint32_t*)ctx->d_order_tmp.p + ((size_t)set * G + j) * max_n;
@@ -2204,10 +2211,10 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
     const bool serial = getenv("ELM_HOSTFED_SERIAL") != nullptr; // developer switch: uploads and ordering on the compute stream itself
     hipStream_t copy_stream = serial ? ctx->stream : ctx->copy_stream, order_stream = serial ? ctx->stream : ctx->order_stream;
     auto enqueue_group = [&](int g) -> hipError_t {
-        const int set = g & 1, r0 = g * G, r1 = std::min(count, r0 + G);
+        const int set = g % kStageSets, r0 = g * G, r1 = std::min(count, r0 + G);
         hipEvent_t ev_copied = ctx->ev_groups[2 * g], ev_ordered = ctx->ev_groups[2 * g + 1];
         hipError_t e = hipSuccess;
-        if (g >= 2) e = hipStreamWaitEvent(copy_stream, ctx->ev_groups[2 * (g - 2) + 1], 0); // the set's previous ordering kernel has read it
+        if (g >= kStageSets) e = hipStreamWaitEvent(copy_stream, ctx->ev_groups[2 * (g - kStageSets) + 1], 0); // the set's previous ordering kernel has read it
         char* base = (char*)ctx->d_raw.p + (size_t)set * G * scan_stride;
         // one DMA for the whole group when it is contiguous in host memory and in the staging set
         bool contiguous = (size_t)max_n * sizeof(Pt3) == scan_stride;

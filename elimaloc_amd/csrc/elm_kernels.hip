@@ -2837,7 +2837,7 @@ void launch_voxel_downsample(hipStream_t s, const float* xyz, uint32_t n, double
 // together), so that every 256-point workgroup of the accumulate kernels -- and, through the XCD-aware block mapping, every XCD's
 // L2 -- touches a few adjacent map cells.  Source order is not contractual (the reference's own VoxelDownsample emits
 // unordered_map order, vhm.hpp:278-280); the result must only be DETERMINISTIC (the summation tree follows the point order).
-// One 1024-thread workgroup per scan, a counting sort without atomics:
+// One workgroup per scan (kOrderWaves wavefronts), a counting sort without atomics:
 //   A  wave w owns the contiguous points [w C, (w + 1) C); 64 consecutive points per step (coalesced 12-byte loads).  Lanes with the
 //      same 12-bit key find each other with 12 ballots; a point's rank inside its (wave, key) run = the wave's counter for that key
 //      (16-bit, LDS) + the number of lower lanes of its group; the group's last lane writes the counter back.  The 32-bit word
@@ -2846,9 +2846,13 @@ void launch_voxel_downsample(hipStream_t s, const float* xyz, uint32_t n, double
 //   B  every point moves to start[key] + offset[wave][key] + rank.
 // Within a key the order is (wave, step, lane) = the caller's order: the sort is stable.  A (degenerate) scan with more than 65535
 // points in one cell or per wave keeps the caller's order.
-constexpr int kOrderWaves = 16;
+#ifndef ELM_ORDER_WAVES
+#define ELM_ORDER_WAVES 8 // 512 threads, 80 KB of LDS (64 KB of counters + run starts): co-resides with the accumulate workgroups of the compute stream;
+                           // host-fed stream: 8 -> 32.4k, 16 (144 KB: waits for an empty CU) -> 31.0k registrations/s
+#endif
+constexpr int kOrderWaves = ELM_ORDER_WAVES;
 constexpr int kOrderThreads = kOrderWaves * 64;
-constexpr int kOrderBins = kOrderCells * kOrderCells; // 4096 keys: 128 KB of 16-bit counters + 16 KB of run starts
+constexpr int kOrderBins = kOrderCells * kOrderCells; // 4096 keys: kOrderWaves x 8 KB of 16-bit counters + 16 KB of run starts
 __device__ __forceinline__ unsigned order_key(const Pt3 p, const unsigned short* lut) {
     const int cx = (int)floorf(p.x * 0.5f) + kOrderCells / 2, cy = (int)floorf(p.y * 0.5f) + kOrderCells / 2;
     const int ux = min(max(cx, 0), kOrderCells - 1), uy = min(max(cy, 0), kOrderCells - 1);
@@ -2897,13 +2901,15 @@ __global__ __launch_bounds__(kOrderThreads) void k_scan_order(const OrderJob* __
         }
     }
     __syncthreads();
-    // exclusive prefix over (key, wave): every thread takes four consecutive keys
+    // exclusive prefix over (key, wave): every thread takes KPT consecutive keys
+    constexpr int KPT = kOrderBins / kOrderThreads;
+    static_assert(KPT * kOrderThreads == kOrderBins, "keys per thread");
     unsigned tot = 0;
     int over = too_long ? 1 : 0;
-    unsigned t4[4];
+    unsigned t4[KPT];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const unsigned key = tid * 4u + (unsigned)q;
+    for (int q = 0; q < KPT; ++q) {
+        const unsigned key = tid * (unsigned)KPT + (unsigned)q;
         unsigned run = 0;
 #pragma unroll
         for (int w = 0; w < kOrderWaves; ++w) {
@@ -2929,7 +2935,7 @@ __global__ __launch_bounds__(kOrderThreads) void k_scan_order(const OrderJob* __
     for (int w = 0; w < kOrderWaves; ++w) wbase += ((unsigned)w < wave) ? s_wsum[w] : 0u;
     const unsigned ex = wbase + inc - tot;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) s_start[tid * 4u + (unsigned)q] = ex + t4[q];
+    for (int q = 0; q < KPT; ++q) s_start[tid * (unsigned)KPT + (unsigned)q] = ex + t4[q];
     __syncthreads();
     const bool identity = s_over != 0; // uniform
     if (identity) {
