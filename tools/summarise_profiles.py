@@ -34,25 +34,36 @@ try:
     kname = b["roofline"]["kernel"].split("<")[0]
     kidx = {"P2P": "0", "GICP": "1", "VGICP": "2", "AVGICP": "3"}[b["roofline"]["kernel"].split("<")[1].rstrip(">")]
     for k, v in pmc.items():
-        if kname + "<" + kidx + ">" in k.replace("(elm::IcpMethod)", "") and "FETCH_SIZE" in v:
+        kk = k.replace("(elm::IcpMethod)", "")
+        if (kname + "<" + kidx + ">" in kk or kname + "<" + kidx + "," in kk) and "FETCH_SIZE" in v:
             fetch_kb = v["FETCH_SIZE"]["avg"]
             write_kb = v.get("WRITE_SIZE", {}).get("avg", 0.0)
-            # MI355X_MICROARCH.md (HBM): FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports exactly half of
-            # the bytes of a wide (16 B/lane) coalesced read stream -> doubled here; WRITE_SIZE is uncalibrated (tiny here)
+            units = max(b["roofline"]["units_per_launch"], 1.0)
+            hbm_view = b["roofline"].get("hbm", b["roofline"])
+            # MI355X_MICROARCH.md (HBM): FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports exactly half of the bytes
+            # of a wide coalesced read stream -- but, calibrated with tools/probes/gather_probe (profiles/r03_gather_probe.txt), the
+            # FULL bytes of this kernel's gathers (64-byte sectors of random 48-byte blocks / payload records: FETCH_SIZE = 1.008 x
+            # the unique sectors touched).  So: x1 for the gathered bytes + the uncounted half of the coalesced scan-point stream
+            # (12 B per unit, half of it missing = 6 B); the x2 figure of round 2 is kept as an upper bound.  WRITE_SIZE is
+            # uncalibrated (tiny here).  FETCH_SIZE counts Infinity-Cache hits: fabric-side traffic, an upper bound on DRAM bytes.
             summary.update({"kernel": b["roofline"]["kernel"], "method": {"P2P": 0, "GICP": 1, "VGICP": 2, "AVGICP": 3}[b["roofline"]["kernel"].split("<")[1].rstrip(">")],
                             "batch": b["config"]["batch_per_gpu"], "scan_points": 131072,
                             "fetch_size_kb_avg_raw": fetch_kb, "write_size_kb_avg": write_kb,
-                            "hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
+                            "hbm_bytes_per_launch": (fetch_kb + write_kb) * 1024.0 + 6.0 * units,
+                            "hbm_bytes_per_launch_x2_upper": (2.0 * fetch_kb + write_kb) * 1024.0,
                             "launches": v["FETCH_SIZE"]["launches"],
                             # traffic per unit of work (scan point x iteration): launch mixes differ between runs (early-exit
                             # launches move no data), so bench.py scales this by ITS units per launch
                             "units_per_launch_profiled": b["roofline"]["units_per_launch"],
-                            "hbm_bytes_per_unit": (2.0 * fetch_kb + write_kb) * 1024.0 / max(b["roofline"]["units_per_launch"], 1.0),
-                            "requested_bytes_per_unit": b["roofline"].get("requested_bytes_per_unit")})
+                            "hbm_bytes_per_unit": (fetch_kb + write_kb) * 1024.0 / units + 6.0,
+                            "hbm_bytes_per_unit_x2_upper": (2.0 * fetch_kb + write_kb) * 1024.0 / units,
+                            "calibration": "profiles/r03_gather_probe.txt: FETCH_SIZE x1 for 64-byte gather sectors, x2 only for the coalesced scan stream",
+                            "requested_bytes_per_unit": hbm_view.get("requested_bytes_per_unit")})
             if "SQ_ACTIVE_INST_VALU" in v and "GRBM_GUI_ACTIVE" in v:
                 cyc = v["GRBM_GUI_ACTIVE"]["avg"] / 8.0  # summed over the 8 XCDs
                 summary["valu_busy"] = 4.0 * v["SQ_ACTIVE_INST_VALU"]["avg"] / (1024.0 * cyc)  # 4 cycles per wave64 instruction, 1024 SIMDs
                 summary["valu_insts_per_wave"] = v["SQ_INSTS_VALU"]["avg"] / v["SQ_WAVES"]["avg"]
+                summary["waves_per_launch"] = v["SQ_WAVES"]["avg"]
             if "TA_TA_BUSY_sum" in v and "GRBM_GUI_ACTIVE" in v:
                 cyc = v["GRBM_GUI_ACTIVE"]["avg"] / 8.0
                 summary["ta_busy"] = v["TA_TA_BUSY_sum"]["avg"] / 256.0 / cyc  # 256 CUs
