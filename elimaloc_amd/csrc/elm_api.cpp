@@ -92,7 +92,10 @@ struct elm_ctx {
     hipEvent_t ev_iter[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ev_groups; // host-fed streams: per upload group its "copied" and "ordered" events
     uint16_t* d_hilbert = nullptr; // Hilbert index of every cell of the ordering grid (kOrderCells^2 entries)
-    DevBuf d_order_jobs, d_order_tmp, d_arena, d_raw;
+    DevBuf d_order_jobs, d_order_tmp, d_arena, d_raw, d_tickets;
+    bool fused_reduce = false; // ELM_FUSED_REDUCE=1: the accumulate kernels' last workgroups reduce the partial records (no reduce launch:
+                               // accumulate -> [all-reduce] -> solve).  Off by default: measured on one GPU the write-through publish + ticket
+                               // cost every workgroup more (accumulate +4 %) than the lighter solve saves: 83.7 k vs 86.5 k registrations/s
     void* h_jobs = nullptr; // pinned: ordering job descriptors
     size_t h_jobs_cap = 0;
     std::string last_error;
@@ -232,6 +235,7 @@ extern "C" int elm_ctx_create(int device_id, elm_ctx** out) {
     }
     if (const char* k = getenv("ELM_KERNEL")) ctx->kernel_mode = (strcmp(k, "direct") == 0) ? 2 : (strcmp(k, "lists") == 0) ? 3 : 4;
     if (const char* o = getenv("ELM_SCAN_ORDER")) ctx->scan_order = (strcmp(o, "none") == 0) ? 0 : 1;
+    if (const char* f = getenv("ELM_FUSED_REDUCE")) ctx->fused_reduce = strcmp(f, "0") != 0;
     {
         std::lock_guard<std::mutex> lk(g_live_mu);
         ctx->id = g_next_ctx_id++;
@@ -258,7 +262,7 @@ extern "C" void elm_ctx_destroy(elm_ctx* ctx) {
     if (ctx->d_hilbert) (void)hipFree(ctx->d_hilbert);
     if (ctx->h_jobs) (void)hipHostFree(ctx->h_jobs);
     DevBuf* bufs[] = {&ctx->d_scans, &ctx->d_state, &ctx->d_partials, &ctx->d_sums, &ctx->d_T0, &ctx->d_trace, &ctx->d_stage_pts, &ctx->d_active, &ctx->d_queue, &ctx->d_ds,
-                      &ctx->d_order_jobs, &ctx->d_order_tmp, &ctx->d_arena, &ctx->d_raw};
+                      &ctx->d_order_jobs, &ctx->d_order_tmp, &ctx->d_arena, &ctx->d_raw, &ctx->d_tickets};
     if (ctx->h_active) (void)hipHostFree(ctx->h_active);
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -1725,6 +1729,13 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
     rp.max_iter = cfg->max_iteration;
     rp.uniform_blocks = uniform_blocks;
     rp._pad = 0;
+    rp.sums = nullptr;
+    rp.tickets = nullptr;
+    if (ctx->fused_reduce) {
+        if ((rc = dev_reserve(ctx, ctx->d_tickets, (size_t)batch * sizeof(int32_t))) != ELM_OK) return rc;
+        rp.sums = (double*)ctx->d_sums.p;
+        rp.tickets = (int32_t*)ctx->d_tickets.p;
+    }
     ctx->rp = rp;
 
     // P2P / GICP default to the cell-indexed neighbourhood lists; the lists are built on first use (init-time cost).  Maps whose
@@ -1750,10 +1761,10 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
             pack.d[b] = hd[b];
             memcpy(pack.T0[b], T0 + (size_t)b * 16, 16 * sizeof(double));
         }
-        launch_init_pack(ctx->stream, (ScanDesc*)ctx->d_scans.p, st, pack, batch, map_empty ? 1 : 0, d_active, n_dev);
+        launch_init_pack(ctx->stream, (ScanDesc*)ctx->d_scans.p, st, pack, batch, map_empty ? 1 : 0, d_active, n_dev, rp.tickets);
     } else {
         HIPCHK(ctx, hipMemsetAsync(d_active, 0, sizeof(int), ctx->stream));
-        launch_init_state(ctx->stream, st, (const double*)ctx->d_T0.p, batch, map_empty ? 1 : 0, d_active);
+        launch_init_state(ctx->stream, st, (const double*)ctx->d_T0.p, batch, map_empty ? 1 : 0, d_active, rp.tickets);
     }
     const bool distributed = (ctx->comm != nullptr) || (ctx->hook != nullptr);
     ctx->events_used = 0;
@@ -1761,7 +1772,8 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
         for (int it = 0; it < cfg->max_iteration; ++it) {
             if ((rc = enqueue_accumulate(ctx, map, dsc, batch, blocks, st, rp, use_grid, use_cells, use_vnbr)) != ELM_OK) return rc;
             if (distributed) {
-                launch_solve(ctx->stream, dsc, batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 1, d_active);
+                // fused reduction: the sums are already in d_sums -- accumulate -> all-reduce -> solve (two launches + one collective)
+                if (!rp.tickets) launch_solve(ctx->stream, dsc, batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 1, d_active);
                 if ((rc = exchange(ctx, (double*)ctx->d_sums.p, (size_t)batch * kSums)) != ELM_OK) return rc;
                 launch_solve(ctx->stream, dsc, batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 2, d_active);
             } else {
@@ -1928,6 +1940,14 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     rp.max_iter = cfg->max_iteration;
     rp.uniform_blocks = cap_blocks; // every slot owns cap_blocks workgroups
     rp._pad = 0;
+    rp.sums = nullptr;
+    rp.tickets = nullptr;
+    if (ctx->fused_reduce) {
+        if ((rc = dev_reserve(ctx, ctx->d_tickets, (size_t)S * sizeof(int32_t))) != ELM_OK) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_tickets.p, 0, (size_t)S * sizeof(int32_t), ctx->stream));
+        rp.sums = (double*)ctx->d_sums.p;
+        rp.tickets = (int32_t*)ctx->d_tickets.p;
+    }
     ctx->rp = rp;
     const bool use_nbr = ctx->kernel_mode != 2 && (method == ELM_P2P || method == ELM_GICP);
     bool use_grid = use_nbr && ctx->kernel_mode == 4 && map->has_grid;
@@ -1955,7 +1975,7 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     for (; it < hard_limit; ++it) {
         if ((rc = enqueue_accumulate(ctx, map, dsc, S, blocks, st, rp, use_grid, use_cells, use_vnbr)) != ELM_OK) return rc;
         if (distributed) {
-            launch_solve(ctx->stream, dsc, S, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 1, d_active);
+            if (!rp.tickets) launch_solve(ctx->stream, dsc, S, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 1, d_active);
             if ((rc = exchange(ctx, (double*)ctx->d_sums.p, (size_t)S * kSums)) != ELM_OK) return rc;
             // the solve also refills: slot s serves the registrations s, s + S, s + 2 S, ... -- a function of the slot alone, so every
             // rank hands out the same registrations without a refill launch (3 launches + 1 collective per iteration)
@@ -2166,6 +2186,13 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
     rp.max_iter = cfg->max_iteration;
     rp.uniform_blocks = cap_blocks;
     rp._pad = 0;
+    rp.sums = nullptr;
+    rp.tickets = nullptr;
+    if (ctx->fused_reduce) {
+        if ((rc = dev_reserve(ctx, ctx->d_tickets, (size_t)S * sizeof(int32_t))) != ELM_OK) return rc;
+        rp.sums = (double*)ctx->d_sums.p;
+        rp.tickets = (int32_t*)ctx->d_tickets.p;
+    }
     ctx->rp = rp;
     const bool use_nbr = ctx->kernel_mode != 2 && (method == ELM_P2P || method == ELM_GICP);
     bool use_grid = use_nbr && ctx->kernel_mode == 4 && map->has_grid;
@@ -2193,7 +2220,7 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
     ScanDesc* dsc = (ScanDesc*)ctx->d_scans.p;
     int* d_active = (int*)ctx->d_active.p;
     (void)hipGetLastError();
-    launch_slots_idle(ctx->stream, dsc, st, S, cap_blocks);
+    launch_slots_idle(ctx->stream, dsc, st, S, cap_blocks, rp.tickets);
     // the side streams start behind the control block's initialisation (and behind whatever the compute stream still reads from
     // the arena / staging of an earlier call)
     HF_CHK(hipEventRecord(ctx->ev_iter[0], ctx->stream));

@@ -186,6 +186,10 @@ struct RegParams {
     int32_t max_iter;
     uint32_t uniform_blocks; // > 0: every scan / slot owns exactly that many consecutive workgroups (scan = block / uniform_blocks)
     uint32_t _pad;
+    // fused reduction: the LAST workgroup of a scan to arrive (ticket counter per scan) adds up the scan's partial records into
+    // sums[scan][32] -- no reduce launch; nullptr: the accumulate kernels only write partials, k_solve reduces (developer A/B)
+    double* sums;
+    int32_t* tickets;
 };
 
 constexpr int kTileShift = 3, kTile = 1 << kTileShift; // two-level grid: tiles of 8 x 8 columns
@@ -198,8 +202,9 @@ struct InitPack {
 constexpr int kSums = ELM_PACKED_SUMS; // 21 + 6 + 1 + 1 (+ n_cand, n_occ, pad)
 
 // ---- launchers (elm_kernels.hip) ----------------------------------------------------------------------
-void launch_init_state(hipStream_t s, ScanState* st, const double* T0, int batch, int map_empty, int* active);
-void launch_init_pack(hipStream_t s, ScanDesc* scans, ScanState* st, const InitPack& pack, int batch, int map_empty, int* active, const unsigned* n_dev);
+void launch_init_state(hipStream_t s, ScanState* st, const double* T0, int batch, int map_empty, int* active, int* tickets);
+void launch_init_pack(hipStream_t s, ScanDesc* scans, ScanState* st, const InitPack& pack, int batch, int map_empty, int* active, const unsigned* n_dev,
+                      int* tickets);
 void launch_stream_refill(hipStream_t s, ScanDesc* scans, ScanState* st, int slots, const QueueItem* queue, const double* qT0,
                           ScanState* out_state, StreamCtrl* ctrl, int first);
 void launch_accumulate_direct(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
@@ -265,7 +270,7 @@ struct OrderJob {
 };
 void launch_scan_order(hipStream_t s, const OrderJob* jobs, int n_jobs, const uint16_t* hilbert_lut);
 void launch_publish_ready(hipStream_t s, StreamCtrl* ctrl, int ready);
-void launch_slots_idle(hipStream_t s, ScanDesc* scans, ScanState* st, int slots, unsigned cap_blocks);
+void launch_slots_idle(hipStream_t s, ScanDesc* scans, ScanState* st, int slots, unsigned cap_blocks, int* tickets);
 constexpr int kOrderCells = 64; // cells per axis of the ordering grid (2 m cells: +-64 m around the sensor, clamped beyond)
 void launch_deskew(hipStream_t s, const float* xyz, const float* rel_time, uint32_t n, const DeskewDev& d,
                    float* xyz_out);

@@ -404,6 +404,65 @@ __device__ __forceinline__ void block_reduce_store(double* acc, double (*red)[32
         out[threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
+
+// ---- fused reduction of the partial records ----------------------------------------------------------------------------------
+// Every workgroup publishes its 32 block sums with 8-byte agent-scope stores (write-through: they leave the XCD's L2), drains
+// them (s_waitcnt vmcnt(0)) and takes a ticket on the scan's counter; the workgroup that draws the last ticket reads all records of
+// the scan back with agent-scope loads -- the "8-byte agent atomics on both sides" hand-off of MI355X_MICROARCH.md, no L2 write-back,
+// no acquire fence -- and adds them up in a FIXED order (eight interleaved groups, four rotating accumulators per group: trailing
+// all-zero records of a slot sized for a larger scan leave every sum bit-identical), so the result does not depend on which
+// workgroup came last.  sums[scan][32] is what the solve kernel (and, on several GPUs, the all-reduce) reads: an ICP iteration
+// is accumulate (+ reduce) -> [all-reduce] -> solve, no reduce launch.  s_scratch: >= 2 KB + 16 bytes of LDS that is dead by now.
+__device__ __forceinline__ void publish_and_reduce(double value, unsigned L, int s, unsigned blk_begin, unsigned blk_end, double* __restrict__ partials,
+                                                   const RegParams& rp, double* s_scratch) {
+    const unsigned t = threadIdx.x;
+    if (rp.tickets == nullptr) { // unfused: k_solve reduces
+        if (t < (unsigned)kSums) partials[(size_t)L * kSums + t] = value;
+        return;
+    }
+    int* s_flag = reinterpret_cast<int*>(s_scratch + 8 * kSums);
+    if (t < (unsigned)kSums) __hip_atomic_store(&partials[(size_t)L * kSums + t], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t < 64u) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the record has left this CU before the ticket is drawn
+        if (t == 0u) {
+            const int nblk = (int)(blk_end - blk_begin);
+            const int tk = __hip_atomic_fetch_add(&rp.tickets[s], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (tk == nblk - 1) ? 1 : 0;
+            if (last) __hip_atomic_store(&rp.tickets[s], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next iteration
+            *s_flag = last;
+        }
+    }
+    __syncthreads();
+    if (*s_flag == 0) return;
+    constexpr unsigned G = kBlock / 32; // 8 groups of 32 lanes, one lane per sum
+    const unsigned k = t & 31u, g = t >> 5;
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+    unsigned b = blk_begin + g;
+    auto rec = [&](unsigned bb) { return __hip_atomic_load(&partials[(size_t)bb * kSums + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    for (; b + 7 * G < blk_end; b += 8 * G) { // eight loads in flight, summed in the order of the loop below
+        double a[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] = rec(b + q * G);
+#pragma unroll
+        for (int q = 0; q < 8; q += 4) { v0 += a[q]; v1 += a[q + 1]; v2 += a[q + 2]; v3 += a[q + 3]; }
+    }
+    for (; b + 3 * G < blk_end; b += 4 * G) {
+        const double a0 = rec(b), a1 = rec(b + G), a2 = rec(b + 2 * G), a3 = rec(b + 3 * G);
+        v0 += a0; v1 += a1; v2 += a2; v3 += a3;
+    }
+    if (b < blk_end) { v0 += rec(b); b += G; }
+    if (b < blk_end) { v1 += rec(b); b += G; }
+    if (b < blk_end) { v2 += rec(b); b += G; }
+    s_scratch[g * kSums + k] = (v0 + v1) + (v2 + v3);
+    __syncthreads();
+    if (t < (unsigned)kSums) {
+        double a = s_scratch[t];
+#pragma unroll
+        for (unsigned q = 1; q < G; ++q) a += s_scratch[q * kSums + t];
+        rp.sums[(size_t)s * kSums + t] = a;
+    }
+}
+
 // DPP row operations (quad permutes, row rotations / mirrors) instead of ds_bpermute (__shfl), which goes through the LDS pipeline
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v) {
@@ -422,6 +481,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_direct(const DevMap m, co
     const ScanState& S = st[s];
     if (S.done) return; // uniform: the whole block leaves; k_solve skips this scan too
     const ScanDesc sd = scans[s];
+    if (L >= sd.blk_end) return; // a scan whose size was only known on the device owns fewer workgroups than were launched for it
     const unsigned i = (L - sd.blk_begin) * kBlock + threadIdx.x;
     const bool valid = i < sd.n;
     double acc[32];
@@ -468,7 +528,19 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_direct(const DevMap m, co
         acc[31] = n_cand; // every candidate is distance-tested on this path
     }
     __shared__ double red[kBlock / 64][32];
-    block_reduce_store(acc, red, partials + (size_t)L * kSums);
+    __shared__ double s_scr[8 * kSums + 2];
+    double sum = 0.0;
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const double v = wave_sum(acc[k]);
+            if (lane == 0) red[wave][k] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 32) sum = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    }
+    publish_and_reduce(sum, L, s, sd.blk_begin, sd.blk_end, partials, rp, s_scr);
 }
 
 // ---- K1 on the neighbourhood lists (fall-back search index) ---------------------------------------------------------
@@ -842,6 +914,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_CELL_WAVES : ELM_C
     const ScanState& S = st[s];
     if (S.done) return;
     const ScanDesc sd = scans[s];
+    if (L >= sd.blk_end) return; // a scan whose size was only known on the device owns fewer workgroups than were launched for it
     const unsigned i = (L - sd.blk_begin) * kBlock + threadIdx.x;
     const bool valid = i < sd.n;
     double v[NV];
@@ -1077,7 +1150,8 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_CELL_WAVES : ELM_C
         v[NV - 1] = (double)n_tested + (hard ? kFallbackUnit : 0.0); // high part: points served by stage 2
     }
     block_reduce_to_lds<NV, kRedPass>(v, s_buf, s_red);
-    if (threadIdx.x < kSums) partials[(size_t)L * kSums + threadIdx.x] = (METHOD == ELM_P2P) ? p2p_expand(s_red, (int)threadIdx.x) : s_red[threadIdx.x];
+    publish_and_reduce((threadIdx.x < kSums) ? ((METHOD == ELM_P2P) ? p2p_expand(s_red, (int)threadIdx.x) : s_red[threadIdx.x]) : 0.0, L, s, sd.blk_begin,
+                       sd.blk_end, partials, rp, s_buf);
 }
 
 // ---- K1g: dense cell grid (default search index for P2P / GICP) ---------------------------------------------------------
@@ -1218,6 +1292,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
     const ScanState& S = st[s];
     if (S.done) return;
     const ScanDesc sd = scans[s];
+    if (L >= sd.blk_end) return; // a scan whose size was only known on the device owns fewer workgroups than were launched for it
     const unsigned i = (L - sd.blk_begin) * kBlock + threadIdx.x;
     const bool valid = i < sd.n;
     double v[(METHOD == ELM_P2P) ? NV : 1]; // P2P: its 18 sums + 3 counters; GICP: the factored form P below
@@ -1591,7 +1666,8 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
     }
     if (METHOD == ELM_P2P) block_reduce_to_lds<NV, kRedPass>(v, s_buf, s_red);
     else block_reduce_pair_sum<kRedPass>(P, s_buf, s_red);
-    if (threadIdx.x < kSums) partials[(size_t)L * kSums + threadIdx.x] = (METHOD == ELM_P2P) ? p2p_expand(s_red, (int)threadIdx.x) : s_red[threadIdx.x];
+    publish_and_reduce((threadIdx.x < kSums) ? ((METHOD == ELM_P2P) ? p2p_expand(s_red, (int)threadIdx.x) : s_red[threadIdx.x]) : 0.0, L, s, sd.blk_begin,
+                       sd.blk_end, partials, rp, s_buf);
 }
 
 // map build: the GICP payload records in grid slot order (16 lanes per record, one 8-byte word each); COMPACT: the 64-byte form
@@ -1718,6 +1794,7 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
     const ScanState& S = st[s];
     if (S.done) return;
     const ScanDesc sd = scans[s];
+    if (L >= sd.blk_end) return; // a scan whose size was only known on the device owns fewer workgroups than were launched for it
     const unsigned i = (L - sd.blk_begin) * kBlock + threadIdx.x;
     const bool valid = i < sd.n;
     PairSum P;
@@ -1888,7 +1965,7 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
         }
     }
     block_reduce_pair_sum<kRedPass>(P, s_buf, s_red);
-    if (threadIdx.x < kSums) partials[(size_t)L * kSums + threadIdx.x] = s_red[threadIdx.x];
+    publish_and_reduce((threadIdx.x < kSums) ? s_red[threadIdx.x] : 0.0, L, s, sd.blk_begin, sd.blk_end, partials, rp, s_buf);
 }
 
 __global__ __launch_bounds__(256) void k_vnbr_fill(const DevMap m, const int32_t* __restrict__ qkeys, unsigned n_q,
@@ -1990,9 +2067,10 @@ __device__ void init_scan_state(ScanState& S, const double* __restrict__ T0, int
 }
 
 __global__ __launch_bounds__(64) void k_init_state(ScanState* st, const double* __restrict__ T0, int batch, int map_empty,
-                                                   int* active) {
+                                                   int* active, int* tickets) {
     const int s = blockIdx.x * 64 + threadIdx.x;
     if (s >= batch) return;
+    if (tickets) tickets[s] = 0;
     if (!map_empty) atomicAdd(active, 1); // scans still iterating (the host zeroed the counter)
     init_scan_state(st[s], T0 + (size_t)s * 16, s, map_empty);
 }
@@ -2001,10 +2079,11 @@ __global__ __launch_bounds__(64) void k_init_state(ScanState* st, const double* 
 // memset of the counter.  n_dev != nullptr: the scan's size is only known on the device (the deskew + downsample kernels have just
 // produced it): the descriptor takes n from there, so the host never waits for it.
 __global__ __launch_bounds__(64) void k_init_pack(ScanDesc* scans, ScanState* st, const InitPack pack, int batch, int map_empty, int* active,
-                                                  const unsigned* __restrict__ n_dev) {
+                                                  const unsigned* __restrict__ n_dev, int* tickets) {
     const int s = threadIdx.x;
     if (s == 0) *active = map_empty ? 0 : batch;
     if (s >= batch) return;
+    if (tickets) tickets[s] = 0;
     ScanDesc d = pack.d[s];
     if (n_dev) {
         d.n = *n_dev;
@@ -2014,8 +2093,9 @@ __global__ __launch_bounds__(64) void k_init_pack(ScanDesc* scans, ScanState* st
     scans[s] = d;
     init_scan_state(st[s], pack.T0[s], s, map_empty);
 }
-void launch_init_pack(hipStream_t s, ScanDesc* scans, ScanState* st, const InitPack& pack, int batch, int map_empty, int* active, const unsigned* n_dev) {
-    hipLaunchKernelGGL(k_init_pack, dim3(1), dim3(64), 0, s, scans, st, pack, batch, map_empty, active, n_dev);
+void launch_init_pack(hipStream_t s, ScanDesc* scans, ScanState* st, const InitPack& pack, int batch, int map_empty, int* active, const unsigned* n_dev,
+                      int* tickets) {
+    hipLaunchKernelGGL(k_init_pack, dim3(1), dim3(64), 0, s, scans, st, pack, batch, map_empty, active, n_dev, tickets);
 }
 
 // Continuous batching: after the solve of an iteration, every slot whose registration has finished saves its final state
@@ -2270,7 +2350,8 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* scans, 
     __shared__ double tot[kSums];
     __shared__ double part[kSolveThreads / 32][kSums];
     const bool done = S.done != 0;
-    if (mode != 2) {
+    const bool fused = rp.tickets != nullptr; // the accumulate kernels' last workgroups have left the scan's sums in `sums`
+    if (mode != 2 && !fused) {
         // deterministic reduction of this scan's per-workgroup partial sums: 32 strided groups of 32 lanes read whole
         // 256-byte records (four independent loads in flight per lane), then the group sums are added in a fixed order
         const int k = t & 31, g = t >> 5;
@@ -2310,7 +2391,8 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* scans, 
         }
         if (mode == 1) return;
     } else {
-        if (t < 32) tot[t] = sums[(size_t)s * kSums + t];
+        // (a scan without a single workgroup -- no points on this rank -- has no record and no sums: zeros)
+        if (t < 32) tot[t] = (scans[s].blk_end > scans[s].blk_begin) ? sums[(size_t)s * kSums + t] : 0.0;
     }
     __syncthreads();
     if (t >= 64) return; // the first wave does the rest with uniform control flow; lane 0 owns the state
@@ -2620,8 +2702,8 @@ void launch_stream_refill(hipStream_t s, ScanDesc* scans, ScanState* st, int slo
                           ScanState* out_state, StreamCtrl* ctrl, int first) {
     hipLaunchKernelGGL(k_stream_refill, dim3(1), dim3(1024), 0, s, scans, st, slots, queue, qT0, out_state, ctrl, first);
 }
-void launch_init_state(hipStream_t s, ScanState* st, const double* T0, int batch, int map_empty, int* active) {
-    hipLaunchKernelGGL(k_init_state, dim3((batch + 63) / 64), dim3(64), 0, s, st, T0, batch, map_empty, active);
+void launch_init_state(hipStream_t s, ScanState* st, const double* T0, int batch, int map_empty, int* active, int* tickets) {
+    hipLaunchKernelGGL(k_init_state, dim3((batch + 63) / 64), dim3(64), 0, s, st, T0, batch, map_empty, active, tickets);
 }
 
 void launch_accumulate_direct(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
@@ -2716,7 +2798,9 @@ void launch_solve(hipStream_t s, const ScanDesc* scans, int batch, ScanState* st
                   double* sums, const RegParams& rp, elm_iter_trace* trace, int mode, int* active, const StreamArgs* refill) {
     StreamArgs sa = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
     if (refill) sa = *refill;
-    hipLaunchKernelGGL(k_solve, dim3(batch), dim3(kSolveThreads), 0, s, scans, st, partials, sums, rp, trace, mode, active, sa);
+    // one wavefront per scan when the sums are already reduced (fused reduction, or the second half of a multi-rank iteration)
+    const int threads = (mode == 2 || rp.tickets != nullptr) ? 64 : kSolveThreads;
+    hipLaunchKernelGGL(k_solve, dim3(batch), dim3(threads), 0, s, scans, st, partials, sums, rp, trace, mode, active, sa);
 }
 
 void launch_voxel_cov(hipStream_t s, const DevMap& m, const uint2* ranges, double* vox_mean, double* vox_cov, double* vox_cinv, double* vox_nk, unsigned* bad) {
@@ -2962,16 +3046,17 @@ __global__ void k_publish_ready(StreamCtrl* ctrl, int ready) {
 }
 void launch_publish_ready(hipStream_t s, StreamCtrl* ctrl, int ready) { hipLaunchKernelGGL(k_publish_ready, dim3(1), dim3(1), 0, s, ctrl, ready); }
 // host-fed streams start with every slot idle: the solve hands out registrations as their scans arrive
-__global__ void k_slots_idle(ScanDesc* scans, ScanState* st, int slots, unsigned cap_blocks) {
+__global__ void k_slots_idle(ScanDesc* scans, ScanState* st, int slots, unsigned cap_blocks, int* tickets) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= slots) return;
+    if (tickets) tickets[s] = 0;
     scans[s].pts = nullptr; scans[s].n = 0; scans[s].n_total = 0;
     scans[s].blk_begin = cap_blocks * (unsigned)s; scans[s].blk_end = cap_blocks * (unsigned)(s + 1); // every slot owns cap_blocks workgroups
     st[s].done = 1;
     st[s].reg = -1;
 }
-void launch_slots_idle(hipStream_t s, ScanDesc* scans, ScanState* st, int slots, unsigned cap_blocks) {
-    hipLaunchKernelGGL(k_slots_idle, dim3((slots + 255) / 256), dim3(256), 0, s, scans, st, slots, cap_blocks);
+void launch_slots_idle(hipStream_t s, ScanDesc* scans, ScanState* st, int slots, unsigned cap_blocks, int* tickets) {
+    hipLaunchKernelGGL(k_slots_idle, dim3((slots + 255) / 256), dim3(256), 0, s, scans, st, slots, cap_blocks, tickets);
 }
 
 void launch_deskew(hipStream_t s, const float* xyz, const float* rel_time, uint32_t n, const DeskewDev& d, float* xyz_out) {

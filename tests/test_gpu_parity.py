@@ -988,3 +988,42 @@ def test_exactly_singular_normal_equations_zero_pivot(ctx, oracle, world100k):
         assert g["x"][3] == 0.0 and r["x"][3] == 0.0
         np.testing.assert_allclose(g["x"], r["x"], rtol=0, atol=1e-9 * max(1.0, np.abs(r["x"]).max()))
         np.testing.assert_allclose(g["T"], r["T"], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("method", [0, 2])
+def test_fused_reduction_path(oracle, world100k, method, monkeypatch):
+    """ELM_FUSED_REDUCE=1: the last workgroup of every scan (ticket counter, 8-byte agent-scope stores / loads) adds up the scan's
+    partial records inside the accumulate launch and the solve reads the sums -- accumulate -> [exchange] -> solve.  Same
+    trajectory as the default path to the sum tolerance, bit-identical between a stream and one-at-a-time calls, oracle parity."""
+    from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, Scan
+    m = IcpMethod(method)
+    monkeypatch.setenv("ELM_FUSED_REDUCE", "1")
+    c = Context(0)
+    try:
+        vm, om = _maps(c, oracle, world100k, m)
+        reg = Registration(RegistrationConfig(icp_method=m), c)
+        scans, T0s, singles, hosts = [], [], [], []
+        for i, n in enumerate([6000, 1000, 0, 257, 5000, 70000, 256, 4097, 1]):
+            sc, Tt = synth.make_scan(world100k, max(n, 1), seed=500 + i)
+            sc = sc[:n]
+            hosts.append(sc)
+            T0s.append(synth.perturb(Tt, seed=600 + i, max_trans=0.05 + 0.04 * i, max_rot_deg=0.2 * (i + 1)))
+            scans.append(Scan(c, sc))
+            singles.append(reg.RunRegisterBatch([scans[-1]], vm, [T0s[-1]], trace=True)[0])
+        for slots in (3, 64):
+            out = reg.RunRegisterStream(scans, vm, T0s, slots=slots, trace=True)
+            for k, (b, s_) in enumerate(zip(out, singles)):
+                assert (b["iterations"], b["is_success"], b["gate"]) == (s_["iterations"], s_["is_success"], s_["gate"]), k
+                assert np.array_equal(b["T"], s_["T"]) and np.array_equal(b["local_cov"], s_["local_cov"]), k
+        calls = []
+        c.set_allreduce_hook(lambda p, n, s: (calls.append(n), 0)[1])  # the multi-rank control flow: no reduce launch before the exchange
+        try:
+            hooked = reg.RunRegisterStream(scans, vm, T0s, slots=3)
+        finally:
+            c.set_allreduce_hook(None)
+        assert calls and all(np.array_equal(a["T"], b["T"]) for a, b in zip(hooked, singles))
+        for k in (0, 5):
+            ref = oracle.register(om, hosts[k], T0s[k], oracle.default_config(method))
+            _compare_run(singles[k], ref)
+    finally:
+        c.close()
