@@ -342,7 +342,8 @@ struct elm_map {
     double* d_grid_gicp = nullptr; // the GICP records in grid slot order (built with the grid / refreshed by CalPointCovAll)
     size_t grid_slots = 0;
     bool has_grid = false;
-    bool want_gicp_compact = false; // every point covariance has the compact form: the grid gets 64-byte records
+    bool want_gicp_compact = false; // the grid gets 64-byte GICP records (points outside the compact form are flagged and read pt_gicp)
+    unsigned n_bad_pts = 0, n_bad_vox = 0; // covariances outside the compact form (diagnostics)
     bool grid_refused = false; // the bounding box needs more cells than the budget: neighbourhood lists instead
     bool has_vnbr = false; // voxel-mean lists (VGICP)
     bool has_cells = false; // lists sorted by half-voxel cell + offset tables (every list <= 1024 entries)
@@ -612,9 +613,11 @@ extern "C" int elm_map_cal_voxel_cov_all(elm_map* m) {
     m->dm.vox_cov = m->d_vox_cov;
     m->dm.vox_cinv = m->d_vox_cinv;
     m->dm.vox_nk = m->d_vox_nk;
-    // every inverse covariance is I + k n n^T (to 1e-10): the pairs rebuild it from the 64-byte list records.  One voxel outside
-    // that form (rank-deficient neighbourhood, U != V in its SVD) or ELM_COV_RECORDS=full: the stored 3x3 inverses stay in use.
-    m->dm.vox_compact = (bad == 0 && !full_records_forced()) ? 1 : 0;
+    // an inverse covariance of the form I + k n n^T (to 1e-10) is rebuilt by the pairs from the 64-byte list record; the `bad` voxels
+    // outside that form (rank-deficient neighbourhood, U != V in its SVD) carry k = NaN and their pairs read the stored 3x3 inverse.
+    // ELM_COV_RECORDS=full: every pair reads the stored inverses.
+    m->n_bad_vox = bad;
+    m->dm.vox_compact = full_records_forced() ? 0 : 1;
     m->info.has_voxel_cov = 1;
     m->info.layout_flags = (m->info.layout_flags & ~2) | (m->dm.vox_compact ? 2 : 0);
     return ELM_OK;
@@ -641,7 +644,8 @@ extern "C" int elm_map_cal_point_cov_all(elm_map* m, double d_search_dist) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     m->dm.pt_gicp = m->d_pt_gicp;
-    m->want_gicp_compact = bad == 0 && !full_records_forced(); // see elm_map_cal_voxel_cov_all
+    m->n_bad_pts = bad;
+    m->want_gicp_compact = !full_records_forced(); // see elm_map_cal_voxel_cov_all: non-conforming points (k = NaN) read their full record
     m->info.has_point_cov = 1;
     return refresh_grid_gicp(m); // a grid built before the covariances (or a new search radius): regather
 }

@@ -104,8 +104,9 @@ struct DevMap {
     const double* grid_gicp8;   // [4 * n_blk][8]: the compact record {mean[3], unit normal[3], k, -}: 64 bytes = one memory sector per match;
                                 // the inverse covariance I + k n n^T is rebuilt in registers (k = 999: U diag(1, 1, 1e-3) V^T of
                                 // vhm.hpp:238-246 with U = V up to rounding, checked per point at map build; k = 0: identity)
-    int32_t gicp_compact;       // 1: every point covariance has the compact form and grid_gicp8 is what the grid kernel reads
-    int32_t vox_compact;        // 1: every voxel covariance has it: the VoxRec's own normal / k are used, vox_cinv is not read
+    int32_t gicp_compact;       // 1: grid_gicp8 is what the grid kernel reads (k = NaN flags a point outside the compact form: its full
+                                // record is read from pt_gicp by the index in word 7)
+    int32_t vox_compact;        // 1: the VoxRec's own normal / k are used (k = NaN: vox_cinv[vid] is read for that voxel)
     int32_t gx0, gy0, gz0;      // cell coordinates of grid entry (0, 0, 0)
     int32_t gnx, gny, gnz;
     // dense voxel box of the floor keys a query can have near the map: cnt27 | nocc27 << 16 of the reference's 27-voxel walk

@@ -1646,7 +1646,14 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
                     const double* __restrict__ rec = m.grid_gicp8 + (size_t)bidx * 8;
 #pragma unroll
                     for (int k = 0; k < 3; ++k) { mean[k] = rec[k]; nf[k] = rec[3 + k]; }
-                    compact_cinv(nf[0], nf[1], nf[2], rec[6], Ci);
+                    const double kk = rec[6];
+                    if (kk == kk) {
+                        compact_cinv(nf[0], nf[1], nf[2], kk, Ci);
+                    } else { // a rank-deficient neighbourhood (U != V in its SVD): the stored inverse, by the record's bucket-order index
+                        const double* __restrict__ full = m.pt_gicp + (size_t)(unsigned)rec[7] * 16;
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) Ci[k] = full[3 + k];
+                    }
                 } else if (bidx >= 0) {
                     const double* __restrict__ rec = m.grid_gicp + (size_t)bidx * 16;
 #pragma unroll
@@ -1680,8 +1687,9 @@ __global__ __launch_bounds__(256) void k_gather_gicp(const DevMap m, size_t n_sl
     if (slot >= n_slots) return;
     const unsigned src = m.grid_idx[slot];
     const unsigned w = (unsigned)(t % W);
-    const unsigned from = COMPACT ? (w < 3u ? w : (w < 7u ? w + 9u : 15u)) : w; // mean 0..2, normal 12..14, k 15
-    out[t] = (src == 0xFFFFFFFFu || (COMPACT && w == 7u)) ? 0.0 : m.pt_gicp[(size_t)src * 16 + from];
+    const unsigned from = COMPACT ? (w < 3u ? w : (w < 7u ? w + 9u : 15u)) : w; // mean 0..2, normal 12..14, k 15 (NaN: not of the compact form)
+    // word 7 of a compact record: the record's bucket-order index, where the full 128-byte record of a non-conforming point is found
+    out[t] = (src == 0xFFFFFFFFu) ? 0.0 : (COMPACT && w == 7u) ? (double)src : m.pt_gicp[(size_t)src * 16 + from];
 }
 
 // map build: cnt27 | nocc27 << 16 for every voxel of the dense floor-key box (see DevMap::vox_stat)
@@ -1903,9 +1911,9 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
             if (dfin < rp.th2) {
                 if (bvid < 0) bmx = bmy = bmz = 0.0;
                 double Ci[9];
-                if (bvid >= 0 && COMPACT) { // the record carried the normal and k: no second fetch
+                if (bvid >= 0 && COMPACT && bn[3] == bn[3]) { // the record carried the normal and k: no second fetch
                     compact_cinv(bn[0], bn[1], bn[2], bn[3], Ci);
-                } else if (bvid >= 0) {
+                } else if (bvid >= 0) { // (k = NaN: a voxel whose inverse is not of the compact form)
 #pragma unroll
                     for (int k = 0; k < 9; ++k) Ci[k] = m.vox_cinv[(size_t)bvid * 9 + k];
                 } else {
@@ -1937,7 +1945,7 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
                 for (int u = 0; u < ELM_AVG_RECS; ++u) {
                     const int code = r[u].pad;
                     use[u] = j + u < cnt && (code == 13 || code == 22 || code == 4 || code == 16 || code == 10 || code == 14 || code == 12);
-                    if (COMPACT) {
+                    if (COMPACT && r[u].k == r[u].k) {
                         compact_cinv(r[u].nx, r[u].ny, r[u].nz, r[u].k, Ci[u]);
                     } else {
                         const double* __restrict__ cp = m.vox_cinv + (size_t)(use[u] ? r[u].vid : 0) * 9;
@@ -2570,7 +2578,7 @@ __global__ __launch_bounds__(256) void k_voxel_cov(const DevMap m, const uint2* 
     const double kk = compact_k(Ci, nrm, &ok);
     if (!ok) atomicAdd(bad, 1u);
     for (int k = 0; k < 3; ++k) vox_nk[(size_t)v * 4 + k] = nrm[k];
-    vox_nk[(size_t)v * 4 + 3] = kk;
+    vox_nk[(size_t)v * 4 + 3] = ok ? kk : __builtin_nan(""); // NaN: the pairs of this voxel read vox_cinv[vid]
 }
 
 __global__ __launch_bounds__(256) void k_point_cov(const DevMap m, double d2max, double* pt_gicp, double* pt_cov, unsigned* bad) {
@@ -2637,7 +2645,8 @@ __global__ __launch_bounds__(256) void k_point_cov(const DevMap m, double d2max,
     for (int k = 0; k < 3; ++k) { rec[k] = mean[k]; rec[12 + k] = nf[k]; }
     for (int k = 0; k < 9; ++k) rec[3 + k] = Ci[k];
     bool ok;
-    rec[15] = compact_k(Ci, nf, &ok); // k of Cinv = I + k n n^T (the compact 64-byte records, DevMap::grid_gicp8)
+    const double kk = compact_k(Ci, nf, &ok); // k of Cinv = I + k n n^T (the compact 64-byte records, DevMap::grid_gicp8)
+    rec[15] = ok ? kk : __builtin_nan(""); // NaN: this point's inverse is not of that form -- its pairs read the full record
     if (!ok) atomicAdd(bad, 1u);
     for (int k = 0; k < 9; ++k) pt_cov[(size_t)i * 9 + k] = C[k];
 }

@@ -108,8 +108,9 @@ typedef struct elm_map_info {
     int32_t max_points_per_voxel;
     int32_t has_voxel_cov;
     int32_t has_point_cov;
-    int32_t layout_flags; /* bit 0: GICP payload as 64-byte {mean, normal, k} records (every point covariance is I - 0.999 n n^T),
-                           * bit 1: the same for the voxel covariances of VGICP / AVGICP (clear: the stored 3x3 inverses are read),
+    int32_t layout_flags; /* bit 0: GICP payload as 64-byte {mean, normal, k} records (a point covariance of the form I - 0.999 n n^T
+                           * has its inverse rebuilt as I + k n n^T; a point outside that form is flagged and reads its stored inverse),
+                           * bit 1: the same for the voxel covariances of VGICP / AVGICP (clear: ELM_COV_RECORDS=full, all stored inverses),
                            * bit 2: the P2P / GICP cell grid is the two-level (tiled) form (box too large / sparse for one dense table) */
     uint64_t device_bytes;
     uint64_t n_query_voxels; /* cell grid: voxels of the dense statistics box; neighbourhood lists: query voxels (0 until built) */

@@ -941,8 +941,9 @@ def test_compact_covariance_records_equal_the_stored_inverses(oracle, world100k,
 
 def test_rank_deficient_covariances_keep_the_full_records(oracle):
     """A map of exactly coplanar points: the sample covariances are rank deficient, the SVD's U and V may differ by signs and
-    U diag(1,1,1e-3) V^T need not be I - 0.999 n n^T.  Whatever the map build decides (compact form or stored inverses), the
-    registration follows the oracle's restatement of the same arithmetic."""
+    U diag(1,1,1e-3) V^T need not be I - 0.999 n n^T.  Such points / voxels are flagged (k = NaN) at map build and their pairs
+    read the stored inverse while the rest of the map keeps the compact records: the registration follows the oracle's
+    restatement of the same arithmetic either way."""
     from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, VoxelHashMap
     g = np.arange(-12, 12, 0.25, dtype=np.float32)
     xx, yy = np.meshgrid(g, g, indexing="ij")
