@@ -87,9 +87,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0, help="registrations per GPU per step (0 = 4096 on one GPU -- a timed region of ~1 s at 20 steps, "
                     "five draining launches per ~110 -- and 1024 per GPU on several)")
-    ap.add_argument("--hostfed-batch", type=int, default=1024, help="registrations per step of the host-fed leg (N = 1; 0 = skip)")
-    ap.add_argument("--hostfed-steps", type=int, default=5)
-    ap.add_argument("--slots", type=int, default=128, help="registrations iterating concurrently per GPU (continuous batching: "
+    ap.add_argument("--hostfed-batch", type=int, default=2048, help="registrations per step of the host-fed leg (N = 1; 0 = skip)")
+    ap.add_argument("--hostfed-steps", type=int, default=8)
+    ap.add_argument("--hostfed-slots", type=int, default=128, help="device slots of the host-fed leg (PCIe-bound: a third of them is busy)")
+    ap.add_argument("--slots", type=int, default=256, help="registrations iterating concurrently per GPU (measured 128 / 256 / 512: 87.6 / 90.7 / 90.3 k/s; continuous batching: "
                     "finished slots take the next pending registration on the device); 0 = lockstep batch of --batch")
     ap.add_argument("--scan-points", type=int, default=131072)
     ap.add_argument("--map-points", type=int, default=10_000_000)
@@ -434,28 +435,31 @@ def main():
         import ctypes as C
         packed_f = ((C.c_void_p * n_fed)(*ptrs), (C.c_uint32 * n_fed)(*fed_sizes),
                     np.ascontiguousarray(np.asarray(T0s[:n_fed], dtype=np.float64).reshape(-1, 4, 4).transpose(0, 2, 1)).reshape(-1), [pin])
-        fed = reg.RunRegisterStreamHost(packed_f, vm, slots=n_slots, raw=True)  # warm-up: staging sets, arena, side streams
+        fed = reg.RunRegisterStreamHost(packed_f, vm, slots=args.hostfed_slots, raw=True)  # warm-up: staging sets, arena, side streams
         barrier()
         t1 = time.perf_counter()
         for _ in range(args.hostfed_steps):
-            fed = reg.RunRegisterStreamHost(packed_f, vm, slots=n_slots, raw=True)
+            fed = reg.RunRegisterStreamHost(packed_f, vm, slots=args.hostfed_slots, raw=True)
         barrier()
         tf_ = time.perf_counter() - t1
         fed = results_from_raw(fed)
         fed_bytes = 12.0 * float(sum(fed_sizes)) / n_fed
         fed_rate = n_fed * args.hostfed_steps / tf_
-        h2d_gbs = ctx.measure_h2d(pin.ptr, int(12 * sum(fed_sizes[:min(n_fed, 64)])), reps=5)
+        h2d_gbs = ctx.measure_h2d(pin.ptr, int(12 * sum(fed_sizes)), reps=3)  # the WHOLE buffer the stream reads (its placement on the host's NUMA nodes matters)
+        h2d_head_gbs = ctx.measure_h2d(pin.ptr, int(12 * sum(fed_sizes[:min(n_fed, 64)])), reps=5)
         result["host_fed"] = {
             "what": "elm_register_stream_host: every scan in page-locked HOST memory when the timed region starts; H2D upload (packed float32 xyz, "
                     "12 B/pt), device-side ordering (k_scan_order) and all ICP iterations inside the timed region, overlapped on three HIP streams",
             "value": fed_rate,
             "unit": "registrations/s",
             "registrations_per_step": n_fed,
+            "slots": args.hostfed_slots,
             "steps": args.hostfed_steps,
             "timed_region_s": tf_,
             "bytes_per_registration": fed_bytes,
             "pcie_achieved_gbs": fed_rate * fed_bytes / 1e9,
             "pcie_h2d_probe_gbs": h2d_gbs,
+            "pcie_h2d_probe_first_100MB_gbs": h2d_head_gbs,
             "pcie_spec_gbs": 63.0,
             "pcie_roof_registrations_per_s": h2d_gbs * 1e9 / fed_bytes,
             "frac_of_pcie_probe": fed_rate * fed_bytes / 1e9 / h2d_gbs if h2d_gbs > 0 else None,

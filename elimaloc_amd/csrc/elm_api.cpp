@@ -2270,10 +2270,14 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
     // Iterations are enqueued a few ahead of the device (an event per iteration throttles the host); the number of finished
     // registrations is read on a stream of its own, so that looking never waits for the iterations in flight.
     const StreamArgs sa = {dsc, d_q, d_qT0, d_out, d_ctrl, 1, 0};
-    int it = 0, done_seen = 0, idle_turns = 0;
+    int it = 0, done_seen = 0, idle_turns = 0, g_done = 0;
     const int idle_limit = 4000000; // ~ minutes of polling without a single registration finishing: a lost upload, give up
+    const int groups_ahead = 2 * kStageSets; // uploads enqueued but not yet ordered: enough to keep the DMA engine fed; a long backlog
+                                             // of queued copies and cross-stream waits slows the runtime's submission path down
     for (;;) {
-        for (int k = 0; k < 2 && g_enq < n_groups; ++k, ++g_enq) HF_CHK(enqueue_group(g_enq));
+        while (g_done < g_enq && hipEventQuery(ctx->ev_groups[2 * g_done + 1]) == hipSuccess) ++g_done;
+        (void)hipGetLastError(); // hipErrorNotReady of the query
+        for (int k = 0; k < 2 && g_enq < n_groups && g_enq - g_done < groups_ahead; ++k, ++g_enq) HF_CHK(enqueue_group(g_enq));
         if (it >= 4) HF_CHK(hipEventSynchronize(ctx->ev_iter[it & 3]));
         if ((rc = enqueue_accumulate(ctx, map, dsc, S, blocks, st, rp, use_grid, use_cells, use_vnbr)) != ELM_OK) { sync_all_streams(ctx); return rc; }
         launch_solve(ctx->stream, dsc, S, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 0, d_active, &sa);
