@@ -2,10 +2,13 @@
 // PcmMatching::CallbackPointCloud either side of RunRegister, kept in the float32 / float64 arithmetic the reference uses.
 // Plain C++ (no device code); exported through the same C ABI.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
+#include <chrono>
 #include <unordered_map>
 #include <vector>
 
@@ -156,11 +159,27 @@ void normalize_covariance(const double in[9], double out[9]) {
 extern "C" int elm_filter_points_by_distance(const float* xyz, const float* time, size_t n, double max_dist, float* xyz_out,
                                              float* time_out, size_t* n_out) {
     if (!n_out || (n && (!xyz || !xyz_out))) return ELM_ERR_INVALID;
+    // pcm.cpp:456 drops a point when (double)sqrtf(x*x + y*y + z*z) > max_dist (float arithmetic, float sqrt, widened).  sqrtf is
+    // monotone, so that is s > s_max with s_max = the largest float whose float root does not exceed max_dist: the same decisions
+    // without a root per point.
+    float s_max;
+    if (!(max_dist >= 0.0)) {
+        s_max = -1.0f; // every point is dropped (NaN: every comparison of the reference is false -> handled below)
+    } else if (std::isinf(max_dist)) { // `distance > inf` is false for every point
+        s_max = __builtin_inff();
+    } else {
+        s_max = (float)(max_dist * max_dist);
+        while (s_max > 0.0f && (double)sqrtf(s_max) > max_dist) s_max = nextafterf(s_max, 0.0f);
+        while ((double)sqrtf(nextafterf(s_max, __builtin_inff())) <= max_dist) s_max = nextafterf(s_max, __builtin_inff());
+    }
     size_t k = 0;
+    if (max_dist != max_dist) { // NaN threshold: `distance > NaN` is false, nothing is dropped
+        s_max = __builtin_inff();
+    }
     for (size_t i = 0; i < n; ++i) {
         const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-        const double distance = sqrtf(x * x + y * y + z * z); // float arithmetic, float sqrt, widened (pcm.cpp:456)
-        if (distance > max_dist) continue;
+        const float s2 = x * x + y * y + z * z;
+        if (s2 > s_max) continue; // (a NaN coordinate compares false, as in the reference: the point is kept)
         xyz_out[3 * k] = x; xyz_out[3 * k + 1] = y; xyz_out[3 * k + 2] = z;
         if (time && time_out) time_out[k] = time[i];
         ++k;
@@ -339,6 +358,9 @@ extern "C" int elm_pcm_callback_point_cloud(elm_ctx* ctx, const elm_map* map, co
     // The filtered cloud and the deskew tables are written straight into the context's page-locked staging buffer, laid out as
     // the device wants them ([tables | xyz] then the per-point times): two DMAs per scan, no pageable copies.  Scratch only grows:
     // no allocation on the per-scan path after warm-up.
+    static const bool dbg_time = getenv("ELM_DEBUG_TIMING") != nullptr; // developer: host-side phase times of the callback on stderr
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
     char* stage = (char*)elm_host::callback_staging(ctx, elm_host::kCbTableBytes + n * 4 * sizeof(float) + 64);
     if (!stage) return ELM_ERR_ALLOC;
     double* tab = (double*)stage;
@@ -372,9 +394,13 @@ extern "C" int elm_pcm_callback_point_cloud(elm_ctx* ctx, const elm_map* map, co
     for (int i = 0; i < 16; ++i) syncd[i] = (double)sync[i];
     mul4_cm(syncd, node->tf_ego_to_lidar, T0); // sync_lidar_pose (pcm.cpp:266)
     int unpackable = 0;
+    const double us_host = since(t_begin);
+    const auto t_dev = std::chrono::steady_clock::now();
     rc = host_path ? ELM_ERR_UNSUPPORTED
                    : elm_host::callback_register(ctx, map, stage, ft, nf, &tabs, node->input_voxel_ds_m, T0, reg, &out->result, &out->n_source, &unpackable);
     if (rc == ELM_OK && unpackable) rc = ELM_ERR_UNSUPPORTED;
+    if (dbg_time) fprintf(stderr, "[elm] callback: host filter + tables + pose %.1f us, device pass %.1f us (%d iterations, %zu -> %llu points)\n", us_host,
+                          since(t_dev), (int)out->result.iterations, nf, (unsigned long long)out->n_source);
     if (rc == ELM_OK) {
         memcpy(out->pose_lidar, out->result.T, sizeof(out->pose_lidar));
         memcpy(cov6, out->result.local_cov, sizeof(cov6));

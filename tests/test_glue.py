@@ -24,6 +24,33 @@ def test_filter_and_downsample_match_oracle(oracle):
     assert e.shape == (0, 3) and ei.size == 0
 
 
+def test_filter_threshold_is_exact_at_the_boundary(oracle):
+    """The root-free form of FilterPointsByDistance (s > s_max instead of sqrtf(s) > max_dist) takes the reference's decision for
+    every float around the threshold, for thresholds that are and are not float squares, zero, negative, huge and NaN."""
+    from elimaloc_amd.pcm_matching import filter_points_by_distance
+    rng = np.random.default_rng(3)
+    for max_dist in (100.0, 60.0, 0.1, 1e-3, 37.123456789, 1.0, 0.0, -1.0, 3e19, 1.8446743e19, 1e300, float("inf"), float("nan")):
+        pts = []
+        if max_dist == max_dist and 0 < max_dist < 1e18:
+            s0 = np.float32(max_dist * max_dist)
+            s_list = [s0]
+            for _ in range(40):
+                s_list.append(np.nextafter(s_list[-1], np.float32(np.inf), dtype=np.float32))
+            lo = s0
+            for _ in range(40):
+                lo = np.nextafter(lo, np.float32(0), dtype=np.float32)
+                s_list.append(lo)
+            for s_ in s_list:  # points on one axis: x*x must reproduce the wanted float exactly often enough; add random directions too
+                pts.append([np.sqrt(np.float64(s_)), 0.0, 0.0])
+                d = rng.normal(size=3); d /= np.linalg.norm(d)
+                pts.append(list(d * np.sqrt(np.float64(s_))))
+        pts += [[0, 0, 0], [1e-20, 0, 0], [1e10, 1e10, 1e10], [np.nan, 0, 0], [3e19, 0, 0]]
+        xyz = np.asarray(pts, dtype=np.float32)
+        out, _ = filter_points_by_distance(xyz, np.zeros(len(xyz), np.float32), max_dist)
+        keep = oracle.filter_points_by_distance(xyz, max_dist)
+        assert np.array_equal(out, xyz[keep], equal_nan=True), max_dist
+
+
 def test_interpolated_pose_matches_oracle(oracle):
     from elimaloc_amd.pcm_matching import get_interpolated_pose
     st = synth.make_deskew_stream(10, seed=3)
