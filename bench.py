@@ -169,7 +169,7 @@ def main():
     synth.make_scan(world, 16, seed=1)  # builds the (cached) tile index of the world before the threads start
     scans_host, T_true, T0s, scans, digests, rmaxs = [], [], [], [], [], []
     # host-fed leg (N = 1): the first `n_fed` scans once more in ONE page-locked buffer, back to back (what a driver's DMA ring holds)
-    n_fed = min(args.hostfed_batch, n_batch) if (world_size == 1 and extras and args.slots > 0) else 0
+    n_fed = min(args.hostfed_batch, n_batch) if (world_size == 1 and not distributed and extras and args.slots > 0) else 0  # (a host-fed stream runs on one rank without a communicator)
     pin = PinnedBuffer(max(1, n_fed * args.scan_points * 3)) if n_fed else None
     fed_sizes = []
     from concurrent.futures import ThreadPoolExecutor

@@ -1270,6 +1270,9 @@ __device__ __forceinline__ const uint32_t* col_cells(const DevMap& m, int cx, in
     return m.grid_start + te.x + (unsigned)(((cx & (kTile - 1)) << kTileShift) | (cy & (kTile - 1))) * (unsigned)(nz + 1) + (unsigned)lo;
 }
 
+#ifndef ELM_S2_PIPE
+#define ELM_S2_PIPE 1
+#endif
 #ifndef ELM_GRID_WAVES
 #define ELM_GRID_WAVES 7 // minimum waves per SIMD = a 72-VGPR cap (2 spilled registers).  Measured registrations/s: 5 -> 59.8k, 6 -> 63.9k, 7 -> 65.6k,
                          // 8 (35 spills) -> 54.2k: the kernel is bound by memory latency, not by VALU issue (67 % busy) or HBM bandwidth
@@ -1526,6 +1529,39 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
                 unsigned m1 = 0x7F800000u, m2 = 0x7F800000u;
                 int jb = 0;
                 const float rny = __builtin_amdgcn_rcpf((float)ny); // c / ny for the few dozen columns of a ball: exact via float32
+#if ELM_S2_PIPE
+                // software-pipelined walk: the offsets of this lane's NEXT column are requested before the current column's blocks
+                // are walked, and block b + 1 before block b is evaluated -- the walk is a chain of dependent round trips (offsets ->
+                // blocks, column after column) that the other wavefronts only partly hide when many points are undecided
+                auto col_run = [&](int c, int& r0, int& r1) {
+                    const int qx = (int)(((float)c + 0.5f) * rny);
+                    const int cx = lox + qx, cy = loy + (c - qx * ny);
+                    int zc0, nzc;
+                    const uint32_t* e = col_cells<TILED>(m, cx, cy, loz, hiz, zc0, nzc);
+                    r0 = (int)e[0]; r1 = (int)e[nzc];
+                };
+                int c = (int)rl, nb0 = 0, nb1 = 0;
+                if (c < ncol) col_run(c, nb0, nb1);
+                while (c < ncol) {
+                    const int b0 = nb0, b1 = nb1;
+                    c += (int)LPI;
+                    if (c < ncol) col_run(c, nb0, nb1);
+                    walked += 4 * (b1 - b0);
+                    GridBlk Bn = lp[(b0 < b1) ? b0 : 0];
+                    for (int b = b0; b < b1; ++b) {
+                        const GridBlk B = Bn;
+                        Bn = lp[(b + 1 < b1) ? b + 1 : 0]; // (block 0: the padding block, always resident)
+                        f32x2 da, db;
+                        blk_dist(B, gxy, gzl, gl2, da, db);
+                        const unsigned was = m1;
+                        two_smallest(da.x, 0u, m1, m2);
+                        two_smallest(da.y, 1u, m1, m2);
+                        two_smallest(db.x, 2u, m1, m2);
+                        two_smallest(db.y, 3u, m1, m2);
+                        jb = (m1 != was) ? b : jb;
+                    }
+                }
+#else
                 for (int c = (int)rl; c < ncol; c += (int)LPI) {
                     const int qx = (int)(((float)c + 0.5f) * rny);
                     const int cx = lox + qx, cy = loy + (c - qx * ny);
@@ -1545,6 +1581,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
                         jb = (m1 != was) ? b : jb;
                     }
                 }
+#endif
                 const unsigned m1g = group_min_u32<LPI>(m1);
                 const unsigned long long holders = __ballot(m1 == m1g) & gmask;
                 const unsigned hl = (unsigned)__ffsll((long long)holders) - 1u; // first lane of the group that holds the minimum
