@@ -110,7 +110,24 @@ def test_point_cov_matches_oracle(ctx, oracle):
     np.testing.assert_allclose(gc[gi], oc[oi], rtol=0, atol=1e-9)
 
 
-def _compare_run(gpu, ref):
+def _tie_sensitive_points(om, scan, T, method, th, eps=2e-9):
+    """Scan points whose correspondence flips under a 2e-9 m nudge of the transformed point, i.e. that sit (numerically) on the
+    bisector of two candidates: there the last bits of the pose -- which differ between two correct solvers -- pick the winner."""
+    g = scan.astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+    pick = (lambda q: om.nearest_voxel(q, th)[1]) if method in (2, 3) else (lambda q: om.nearest_points(q, th)[1])
+    base = pick(g)
+    flips = np.zeros(len(g), bool)
+    for ax in range(3):
+        for sgn in (-1.0, 1.0):
+            d = np.zeros(3); d[ax] = sgn * eps
+            flips |= np.any(pick(g + d) != base, axis=1)
+    return int(flips.sum())
+
+
+def _compare_run(gpu, ref, om=None, scan=None, method=None, th=5.0):
+    """Per-iteration comparison of a device trajectory with the oracle's.  With the oracle map and the scan at hand the check is
+    tie-aware: a difference of the sums at an iteration k >= 1 is accepted only if the scan really has points on a bisector of two
+    candidates at that iteration's pose (the documented sensitivity: DESIGN.md section 5) -- and the poses still agree."""
     assert gpu["iterations"] == ref["iterations"]
     assert gpu["is_success"] == ref["is_success"]
     assert gpu["gate"] == ref["gate"]
@@ -119,11 +136,19 @@ def _compare_run(gpu, ref):
         if ref["gate"] == 2 and k == ref["iterations"] - 1:
             break
         scale = np.abs(r["JTJ"]).max()
-        np.testing.assert_allclose(g["JTJ"], r["JTJ"], rtol=0, atol=SUM_RTOL * scale, err_msg=f"JTJ iter {k}")
-        np.testing.assert_allclose(g["JTr"], r["JTr"], rtol=0, atol=SUM_RTOL * max(np.abs(r["JTr"]).max(), scale * 1e-3),
-                                   err_msg=f"JTr iter {k}")
-        np.testing.assert_allclose(g["residual_sum"], r["residual_sum"], rtol=SUM_RTOL)
-        np.testing.assert_allclose(g["T"], r["T"], rtol=0, atol=1e-9)
+        try:
+            np.testing.assert_allclose(g["JTJ"], r["JTJ"], rtol=0, atol=SUM_RTOL * scale, err_msg=f"JTJ iter {k}")
+            np.testing.assert_allclose(g["JTr"], r["JTr"], rtol=0, atol=SUM_RTOL * max(np.abs(r["JTr"]).max(), scale * 1e-3),
+                                       err_msg=f"JTr iter {k}")
+            np.testing.assert_allclose(g["residual_sum"], r["residual_sum"], rtol=SUM_RTOL)
+            np.testing.assert_allclose(g["T"], r["T"], rtol=0, atol=1e-9)
+        except AssertionError:
+            if k == 0 or om is None or scan is None:
+                raise
+            T_prev = ref["iters"][k - 1]["T"]
+            if _tie_sensitive_points(om, scan, T_prev, int(method), th) == 0:
+                raise
+            break  # tie-sensitive from here on: only the final pose is comparable
     dt, dr = synth.pose_error(ref["T"], gpu["T"])
     assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
     if ref["is_success"]:
@@ -656,7 +681,7 @@ def _randomized_case(ctx, oracle, seed):
     cfg = RegistrationConfig(icp_method=method, max_search_dist=th, max_iteration=8)
     *_, det = Registration(cfg, ctx).RunRegister(scan, vm, T0, trace=True)
     ref = oracle.register(om, scan, T0, oracle.default_config(int(method), max_search_dist=th, max_iteration=8))
-    _compare_run(det, ref)
+    _compare_run(det, ref, om=om, scan=scan, method=method, th=th)
 
 
 @pytest.mark.parametrize("seed", range(32))
