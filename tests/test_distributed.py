@@ -126,3 +126,64 @@ def test_pack_unpack_round_trip():
     v = pack_sums(H, g, 3.5, 17.0)
     H2, g2, rs, n = unpack_sums(v)
     assert np.array_equal(H, H2) and np.array_equal(g, g2) and rs == 3.5 and n == 17.0
+
+
+def _stream_worker(rank, world_size, port, out_q):
+    """The multi-rank STREAM protocol of elm_register_stream (elm_kernels.hip: claim_registration with StreamArgs::stride): S slots,
+    slot s serves the registrations s, s + S, s + 2S, ...; whether a registration finishes at an iteration is decided on sums that
+    every rank holds after the all-reduce of the slots' records -- so every rank takes the same refill decisions without any
+    exchange about them, issues the same number of collectives, and stops at the same iteration."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    count, S, max_iter = 23, 5, 10
+    rng = np.random.default_rng(1000 + rank)  # every rank contributes DIFFERENT partial sums (its shard of the points)
+    slot_reg = [s if s < count else -1 for s in range(S)]  # initial fill (k_stream_refill, first = 1)
+    slot_iter = [0] * S
+    log, completed, n_collectives = [], 0, 0
+    finished_at = {}
+    while completed < count:
+        buf = np.zeros(S * 32)
+        for s in range(S):
+            if slot_reg[s] >= 0:
+                buf[s * 32] = rng.uniform(0.0, 1.0)  # this rank's part of a "step size" that only the sum defines
+        t = torch.from_numpy(buf)
+        dist.all_reduce(t)
+        n_collectives += 1
+        for s in range(S):
+            r = slot_reg[s]
+            if r < 0:
+                continue
+            slot_iter[s] += 1
+            if buf[s * 32] < 0.45 * world_size or slot_iter[s] >= max_iter:  # termination on the all-reduced value
+                finished_at[r] = slot_iter[s]
+                completed += 1
+                nxt = r + S  # static queue of the slot: a function of the slot alone
+                slot_reg[s] = nxt if nxt < count else -1
+                slot_iter[s] = 0
+                log.append((n_collectives, s, r, slot_reg[s]))
+    gathered = [None] * world_size
+    dist.all_gather_object(gathered, (log, n_collectives, sorted(finished_at.items())))
+    if rank == 0:
+        out_q.put(dict(same=all(g == gathered[0] for g in gathered), served=sorted(finished_at), n_collectives=n_collectives,
+                       iters=[finished_at[r] for r in sorted(finished_at)]))
+    dist.destroy_process_group()
+
+
+def test_stream_static_slot_queue_world_size_2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29950 + (os.getpid() % 40)
+    procs = [ctx.Process(target=_stream_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res["same"]                       # identical refill decisions, collective counts and iteration counts on both ranks
+    assert res["served"] == list(range(23))  # every registration was served exactly once
+    assert len(set(res["iters"])) > 1        # and they finished at different iterations (the refills really interleave)
