@@ -71,6 +71,7 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+constexpr double kCompactK = 999.0; // 1 / 1e-3 - 1: the k of U diag(1, 1, 1e-3) U^T (vhm.hpp:143, 243)
 // inverse covariance I + k n n^T from the compact records (DevMap::grid_gicp8, VoxRec)
 __device__ __forceinline__ void compact_cinv(double nx, double ny, double nz, double k, double* Ci) {
     const double kx = k * nx, ky = k * ny, kz = k * nz;
@@ -1660,13 +1661,20 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
         // back empty): the reference's default PointStruct at the origin (vhm.cpp:37, QUIRK)
         float bx = 0.f, by = 0.f, bz = 0.f;
         int bidx = -1;
+        // GICP never uses the matched point itself (its target is the neighbourhood mean, reg.cpp:97) except in the range test
+        // d^2 < max_search_dist^2: a winner that stage 1 decided is a candidate of the point's own 2 x 2 x 2 block of cells, hence
+        // within 3.5 cell edges of it, so with a search radius beyond that the test is known to pass and the three loads of the
+        // winner's coordinates are skipped
+        const bool range_known = METHOD != ELM_P2P && !hard && bj >= 0 && (12.25 * h * h) * 1.0001 < rp.th2;
         if (bj >= 0) {
-            const Pt3 q = blk_point(lp, bj);
-            bx = q.x; by = q.y; bz = q.z;
+            if (!range_known) {
+                const Pt3 q = blk_point(lp, bj);
+                bx = q.x; by = q.y; bz = q.z;
+            }
             bidx = bj; // GICP: the payload records are stored in slot order (DevMap::grid_gicp)
         }
         const double ex = (double)bx - gx, ey = (double)by - gy, ez = (double)bz - gz;
-        const double bd2 = (ex * ex + ey * ey) + ez * ez;
+        const double bd2 = range_known ? 0.0 : (ex * ex + ey * ey) + ez * ez;
         const double c_cand = (double)(stat & 0xFFFFu); // candidates of the reference's walk
         const double c_occ = (double)(stat >> 16);     // occupied neighbour voxels
         const double c_tested = (double)n_tested + (hard ? kFallbackUnit : 0.0); // high part: points served by stage 2
@@ -1679,17 +1687,21 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
             const double dfin = (bidx >= 0) ? bd2 : (gx * gx + gy * gy) + gz * gz;
             if (dfin < rp.th2) {
                 double Ci[9], mean[3], nf[3];
-                if (bidx >= 0 && COMPACT) { // one 64-byte record: mean, unit normal, k -- the inverse covariance is I + k n n^T
+                if (bidx >= 0 && COMPACT) { // 48 of the record's 64 bytes: mean + unit normal -- the inverse covariance is I + 999 n n^T
                     const double* __restrict__ rec = m.grid_gicp8 + (size_t)bidx * 8;
 #pragma unroll
                     for (int k = 0; k < 3; ++k) { mean[k] = rec[k]; nf[k] = rec[3 + k]; }
-                    const double kk = rec[6];
-                    if (kk == kk) {
-                        compact_cinv(nf[0], nf[1], nf[2], kk, Ci);
-                    } else { // a rank-deficient neighbourhood (U != V in its SVD): the stored inverse, by the record's bucket-order index
+                    if (nf[0] == 2.0) { // identity covariance (a neighbourhood of the point alone): eigenvector e_x (reg.cpp:89-91)
+                        nf[0] = 1.0;
+                        compact_cinv(1.0, 0.0, 0.0, 0.0, Ci);
+                    } else if (nf[0] == nf[0]) {
+                        compact_cinv(nf[0], nf[1], nf[2], kCompactK, Ci);
+                    } else { // outside the compact form (rank-deficient neighbourhood, U != V in its SVD): the stored record, by its index
                         const double* __restrict__ full = m.pt_gicp + (size_t)(unsigned)rec[7] * 16;
 #pragma unroll
                         for (int k = 0; k < 9; ++k) Ci[k] = full[3 + k];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) nf[k] = full[12 + k];
                     }
                 } else if (bidx >= 0) {
                     const double* __restrict__ rec = m.grid_gicp + (size_t)bidx * 16;
@@ -1726,7 +1738,16 @@ __global__ __launch_bounds__(256) void k_gather_gicp(const DevMap m, size_t n_sl
     const unsigned w = (unsigned)(t % W);
     const unsigned from = COMPACT ? (w < 3u ? w : (w < 7u ? w + 9u : 15u)) : w; // mean 0..2, normal 12..14, k 15 (NaN: not of the compact form)
     // word 7 of a compact record: the record's bucket-order index, where the full 128-byte record of a non-conforming point is found
-    out[t] = (src == 0xFFFFFFFFu) ? 0.0 : (COMPACT && w == 7u) ? (double)src : m.pt_gicp[(size_t)src * 16 + from];
+    double v = (src == 0xFFFFFFFFu) ? 0.0 : (COMPACT && w == 7u) ? (double)src : m.pt_gicp[(size_t)src * 16 + from];
+    if (COMPACT && w == 3u && src != 0xFFFFFFFFu) {
+        // the first 48 bytes must tell the three kinds of record apart (the kernel loads only those in the common case):
+        //   k = kCompactK (regularised covariance): the unit normal as it is;  k = 0 (identity): n.x = 2 (not a unit vector);
+        //   anything else (k = NaN: outside the compact form, or another k): n.x = NaN -> the full record is read
+        const double k = m.pt_gicp[(size_t)src * 16 + 15];
+        if (k == 0.0) v = 2.0;
+        else if (!(fabs(k - kCompactK) <= 1e-7)) v = __builtin_nan("");
+    }
+    out[t] = v;
 }
 
 // map build: cnt27 | nocc27 << 16 for every voxel of the dense floor-key box (see DevMap::vox_stat)
