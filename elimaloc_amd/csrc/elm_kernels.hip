@@ -1841,7 +1841,9 @@ __global__ __launch_bounds__(64) void k_nbr_cellsort(const DevMap m, const int32
 #define ELM_VNBR_RECS 3 // VGICP: list records per round trip (measured 2 / 3 / 4 / 6 / 8: 105.9 / 110.5 / 102.3 / 99.3 / 92.3 k registrations/s)
 #endif
 #ifndef ELM_AVG_RECS
-#define ELM_AVG_RECS 1 // AVGICP: records per round trip (each brings a 72-byte inverse covariance along): 1 -> 78 VGPRs, 50.5k registrations/s; 2 -> 106, 43.2k; 3 -> 130, 42.0k
+#define ELM_AVG_RECS 1 // AVGICP: records per round trip: 1 -> 68 VGPRs, 7 waves, 89-91k registrations/s; 2 -> 99 VGPRs, 4 waves, 77.9k; 3 -> 76.9k;
+                       // 4 -> 56.1k (round 3, 64-byte self-contained records; accumulating the pairs' w (I + k n n^T) in symmetric form
+                       // without forming the 3x3 per pair: the same 88-89k -- the walk is a chain of dependent record loads, not arithmetic)
 #endif
 #ifndef ELM_VNBR_BLKS
 #define ELM_VNBR_BLKS 1 // VGICP filter: float32 blocks of four means per round trip (1 / 2 / 3: 123.4 / 121.0 / 120.5 k registrations/s)
