@@ -644,6 +644,7 @@ extern "C" int elm_map_cal_point_cov_all(elm_map* m, double d_search_dist) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     m->dm.pt_gicp = m->d_pt_gicp;
+    m->dm.pt_cov = m->d_pt_cov;
     m->n_bad_pts = bad;
     m->want_gicp_compact = !full_records_forced(); // see elm_map_cal_voxel_cov_all: non-conforming points (k = NaN) read their full record
     m->info.has_point_cov = 1;
@@ -1627,6 +1628,9 @@ static int exchange(elm_ctx* ctx, double* d_sums, size_t count) {
     return ELM_OK;
 }
 
+// use_radar_cov (reg.hpp:186-217) changes the arithmetic of the covariance methods only: AlignCloudsLocal (P2P) never reads a covariance.
+static bool radar_path(const elm_reg_config* cfg) { return cfg->use_radar_cov != 0 && cfg->icp_method != ELM_P2P; }
+
 // One ICP iteration's correspondence + accumulation launch for `n_scans` scans / slots, bracketed by two profiling marks (the
 // solve span starts at the second).
 static int enqueue_accumulate(elm_ctx* ctx, const elm_map* map, const ScanDesc* dsc, int n_scans, uint32_t blocks, ScanState* st,
@@ -1635,7 +1639,8 @@ static int enqueue_accumulate(elm_ctx* ctx, const elm_map* map, const ScanDesc* 
     if ((rc = prof_mark(ctx)) != ELM_OK) return rc;
     double* partials = (double*)ctx->d_partials.p;
     if (blocks) {
-        if (use_grid) launch_accumulate_grid(ctx->stream, map->dm, dsc, n_scans, (int)blocks, st, partials, rp);
+        if (rp.radar) launch_accumulate_radar(ctx->stream, map->dm, dsc, n_scans, (int)blocks, st, partials, rp);
+        else if (use_grid) launch_accumulate_grid(ctx->stream, map->dm, dsc, n_scans, (int)blocks, st, partials, rp);
         else if (use_cells) launch_accumulate_cell(ctx->stream, map->dm, dsc, n_scans, (int)blocks, st, partials, rp);
         else if (use_vnbr) launch_accumulate_vnbr(ctx->stream, map->dm, dsc, n_scans, (int)blocks, st, partials, rp);
         else launch_accumulate_direct(ctx->stream, map->dm, dsc, n_scans, (int)blocks, st, partials, rp);
@@ -1662,12 +1667,16 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
                               int want_trace, const unsigned* n_dev) {
     if (!ctx || !map || !scans || batch <= 0 || !T0 || !cfg) return ELM_ERR_INVALID;
     if (map->ctx != ctx) return ELM_ERR_INVALID;
-    if (cfg->use_radar_cov) return ELM_ERR_UNSUPPORTED;
     if (cfg->icp_method < ELM_P2P || cfg->icp_method > ELM_AVGICP) return ELM_ERR_INVALID;
     if (ctx->in_flight) return ELM_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int method = cfg->icp_method;
     const bool map_empty = map->dm.n_vox == 0;
+    const bool radar = radar_path(cfg) && !map_empty;
+    if (radar && (ctx->comm || ctx->hook)) {
+        ctx->last_error = "use_radar_cov runs on one rank (its 64-double partial records are not part of the all-reduce layout)";
+        return ELM_ERR_UNSUPPORTED;
+    }
     if (!map_empty) {
         if ((method == ELM_VGICP || method == ELM_AVGICP) && !map->info.has_voxel_cov) {
             ctx->last_error = "VGICP/AVGICP need elm_map_cal_voxel_cov_all() (pcm.cpp:92-95)";
@@ -1704,7 +1713,7 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
     if ((rc = dev_reserve(ctx, ctx->d_scans, (size_t)batch * sizeof(ScanDesc))) != ELM_OK) return rc;
     if ((rc = dev_reserve(ctx, ctx->d_T0, (size_t)batch * 16 * sizeof(double))) != ELM_OK) return rc;
     if ((rc = dev_reserve(ctx, ctx->d_state, st_bytes + 64)) != ELM_OK) return rc;
-    if ((rc = dev_reserve(ctx, ctx->d_partials, (size_t)std::max<uint32_t>(blocks, 1) * kSums * sizeof(double))) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_partials, (size_t)std::max<uint32_t>(blocks, 1) * (radar ? kRadarRecord : kSums) * sizeof(double))) != ELM_OK) return rc;
     if ((rc = dev_reserve(ctx, ctx->d_sums, (size_t)batch * kSums * sizeof(double))) != ELM_OK) return rc;
     if ((rc = pinned_reserve(ctx, &ctx->h_state, &ctx->h_state_cap, st_bytes + 64)) != ELM_OK) return rc;
     ctx->results_ready = false;
@@ -1732,10 +1741,13 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
     rp.method = method;
     rp.max_iter = cfg->max_iteration;
     rp.uniform_blocks = uniform_blocks;
-    rp._pad = 0;
+    rp.radar = radar ? 1 : 0;
+    rp.radar_var[0] = cfg->range_variance_m;
+    rp.radar_var[1] = cfg->azimuth_variance_deg;
+    rp.radar_var[2] = cfg->elevation_variance_deg;
     rp.sums = nullptr;
     rp.tickets = nullptr;
-    if (ctx->fused_reduce) {
+    if (ctx->fused_reduce && !radar) {
         if ((rc = dev_reserve(ctx, ctx->d_tickets, (size_t)batch * sizeof(int32_t))) != ELM_OK) return rc;
         rp.sums = (double*)ctx->d_sums.p;
         rp.tickets = (int32_t*)ctx->d_tickets.p;
@@ -1744,13 +1756,14 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
 
     // P2P / GICP default to the cell-indexed neighbourhood lists; the lists are built on first use (init-time cost).  Maps whose
     // lists cannot be cell-sorted (a list beyond 1024 candidates: voxel caps above ~37 points) take the plain walk.
-    const bool use_nbr = !map_empty && ctx->kernel_mode != 2 && (method == ELM_P2P || method == ELM_GICP);
+    // (use_radar_cov: k_accumulate_radar walks the hash map itself, no search index is needed)
+    const bool use_nbr = !map_empty && !radar && ctx->kernel_mode != 2 && (method == ELM_P2P || method == ELM_GICP);
     bool use_grid = use_nbr && ctx->kernel_mode == 4 && map->has_grid;
     if (use_nbr && !use_grid && !map->has_nbr) {
         if ((rc = build_search_index(const_cast<elm_map*>(map), &use_grid)) != ELM_OK) return rc;
     }
     const bool use_cells = use_nbr && !use_grid && map->has_cells;
-    const bool use_vnbr = !map_empty && ctx->kernel_mode != 2 && (method == ELM_VGICP || method == ELM_AVGICP);
+    const bool use_vnbr = !map_empty && !radar && ctx->kernel_mode != 2 && (method == ELM_VGICP || method == ELM_AVGICP);
     if (use_vnbr && !map->has_vnbr) {
         if ((rc = build_voxel_neighbourhoods(const_cast<elm_map*>(map))) != ELM_OK) return rc;
     }
@@ -1870,9 +1883,19 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     if (map->dm.n_vox == 0 || cfg->max_iteration <= 0) // nothing iterates: the lockstep path handles the degenerate cases
         return elm_register_batch(ctx, map, scans, count, T0, cfg, results, trace);
     if (map->ctx != ctx) return ELM_ERR_INVALID;
-    if (cfg->use_radar_cov) return ELM_ERR_UNSUPPORTED;
     if (cfg->icp_method < ELM_P2P || cfg->icp_method > ELM_AVGICP) return ELM_ERR_INVALID;
     if (ctx->in_flight) return ELM_ERR_INVALID;
+    if (radar_path(cfg)) {
+        // use_radar_cov: lockstep batches of `slots` registrations (k_accumulate_radar is not a slot kernel; a radar scan is a few hundred
+        // returns).  Per-registration arithmetic is that of elm_register_batch.
+        for (int b0 = 0; b0 < count; b0 += slots) {
+            const int n = std::min(slots, count - b0);
+            const int rc = elm_register_batch(ctx, map, scans + b0, n, T0 + (size_t)b0 * 16, cfg, results ? results + b0 : nullptr,
+                                              trace ? trace + (size_t)b0 * ELM_MAX_ITER_TRACE : nullptr);
+            if (rc != ELM_OK) return rc;
+        }
+        return ELM_OK;
+    }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int method = cfg->icp_method;
     if ((method == ELM_VGICP || method == ELM_AVGICP) && !map->info.has_voxel_cov) {
@@ -1943,7 +1966,8 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     rp.method = method;
     rp.max_iter = cfg->max_iteration;
     rp.uniform_blocks = cap_blocks; // every slot owns cap_blocks workgroups
-    rp._pad = 0;
+    rp.radar = 0;
+    rp.radar_var[0] = rp.radar_var[1] = rp.radar_var[2] = 0.0;
     rp.sums = nullptr;
     rp.tickets = nullptr;
     if (ctx->fused_reduce) {
@@ -2090,7 +2114,6 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
                                         const double* T0, const elm_reg_config* cfg, int slots, elm_reg_result* results, elm_iter_trace* trace) {
     if (!ctx || !map || !scan_xyz || !n_pts || count <= 0 || !T0 || !cfg || slots <= 0) return ELM_ERR_INVALID;
     if (map->ctx != ctx) return ELM_ERR_INVALID;
-    if (cfg->use_radar_cov) return ELM_ERR_UNSUPPORTED;
     if (cfg->icp_method < ELM_P2P || cfg->icp_method > ELM_AVGICP) return ELM_ERR_INVALID;
     if (ctx->in_flight) return ELM_ERR_INVALID;
     if (ctx->comm || ctx->hook) {
@@ -2103,8 +2126,8 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
         max_n = std::max(max_n, n_pts[b]);
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (map->dm.n_vox == 0 || cfg->max_iteration <= 0 || max_n == 0) {
-        // nothing iterates: upload and let the lockstep path handle the degenerate cases
+    if (map->dm.n_vox == 0 || cfg->max_iteration <= 0 || max_n == 0 || radar_path(cfg)) {
+        // nothing iterates (or use_radar_cov: see elm_register_stream): upload and let the lockstep path handle the degenerate cases
         std::vector<elm_scan*> sc((size_t)count, nullptr);
         int rc = ELM_OK;
         for (int b = 0; b < count && rc == ELM_OK; ++b) rc = elm_scan_upload(ctx, scan_xyz[b], n_pts[b], n_pts[b], &sc[b]);
@@ -2189,7 +2212,8 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
     rp.method = method;
     rp.max_iter = cfg->max_iteration;
     rp.uniform_blocks = cap_blocks;
-    rp._pad = 0;
+    rp.radar = 0;
+    rp.radar_var[0] = rp.radar_var[1] = rp.radar_var[2] = 0.0;
     rp.sums = nullptr;
     rp.tickets = nullptr;
     if (ctx->fused_reduce) {

@@ -54,6 +54,7 @@ struct DevMap {
     // ones): [0..2] neighbourhood mean, [3..11] INVERSE of the covariance of ProcessVoxelBlock (vhm.hpp:195-250), row-major,
     // [12..14] eigenvector of the covariance's smallest eigenvalue (reg.cpp:89-91, precomputed once), [15] pad
     const double* pt_gicp;  // [n_pts][16]
+    const double* pt_cov;   // [n_pts][9] the covariance itself, row-major (read-backs; the use_radar_cov kernel inverts R^-1 C R^-T + C_source)
     double voxel_size;
     double inv_vs_exact; // 1 / voxel_size when voxel_size is a power of two (g * inv == g / voxel_size bit for bit), else 0
     // neighbourhood lists (optional): for every FLOOR-keyed query voxel that has at least one stored neighbour, the
@@ -186,12 +187,14 @@ struct RegParams {
     int32_t method;
     int32_t max_iter;
     uint32_t uniform_blocks; // > 0: every scan / slot owns exactly that many consecutive workgroups (scan = block / uniform_blocks)
-    uint32_t _pad;
+    int32_t radar;           // use_radar_cov with a covariance method: k_accumulate_radar's 64-double partial records, full JTJ
     // fused reduction: the LAST workgroup of a scan to arrive (ticket counter per scan) adds up the scan's partial records into
     // sums[scan][32] -- no reduce launch; nullptr: the accumulate kernels only write partials, k_solve reduces (developer A/B)
     double* sums;
     int32_t* tickets;
+    double radar_var[3]; // range_variance_m, azimuth_variance_deg, elevation_variance_deg (reg.hpp:77-79)
 };
+constexpr int kRadarRecord = 64; // doubles per partial record of k_accumulate_radar
 
 constexpr int kTileShift = 3, kTile = 1 << kTileShift; // two-level grid: tiles of 8 x 8 columns
 constexpr int kBlock = 256;
@@ -208,6 +211,8 @@ void launch_init_pack(hipStream_t s, ScanDesc* scans, ScanState* st, const InitP
                       int* tickets);
 void launch_stream_refill(hipStream_t s, ScanDesc* scans, ScanState* st, int slots, const QueueItem* queue, const double* qT0,
                           ScanState* out_state, StreamCtrl* ctrl, int first);
+void launch_accumulate_radar(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks, ScanState* st, double* partials,
+                             const RegParams& rp); // use_radar_cov = 1, methods GICP / VGICP / AVGICP
 void launch_accumulate_direct(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                               ScanState* st, double* partials, const RegParams& rp);
 // mode 0: reduce + solve (single GPU); 1: reduce only -> sums; 2: solve only from sums

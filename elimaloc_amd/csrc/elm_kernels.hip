@@ -193,6 +193,111 @@ __device__ __forceinline__ void add_pair(double* acc, const double* Rinv, const 
     }
 }
 
+// ---- use_radar_cov = 1 (reg.hpp:186-217, reg.cpp:109-111 / 188-190 / 302-305) ----------------------------------------------------
+// The reference attaches a "covariance" R S to every source point -- R = Rz(azimuth) Ry(elevation) of the point's MAP-frame position
+// under the initial guess, S = diag(range spread, max(0.1, d sin(azimuth spread)), max(0.1, d sin(elevation spread))), d the
+// horizontal range; a product, not R S R^T: the matrix is not symmetric -- and adds it to R^-1 C R^-T before the inversion.  The
+// re-transform at the end of an iteration replaces it by the identity (see oracle/elm_oracle.cpp, orc_register), so the first
+// iteration sees R S and every later one I.  With a non-symmetric metric J^T M J is not symmetric either: JTJ.ldlt() reads its lower
+// triangle, GICP's covariance output is the inverse of the full matrix, so all 36 entries are accumulated -- in the sensor frame, with
+// the reference's own sequence of 3x3 products (the world-frame form of add_pair_world needs a symmetric C^-1 computed in advance).
+//   acc[0..35] J^T M J row-major, acc[36..41] J^T M r, acc[42] residual sum, acc[43] pair count, acc[44..46] search statistics
+constexpr int kRadarAcc = 47;
+constexpr int kRadarSums = 64; // doubles per partial record of the radar kernel
+__device__ __forceinline__ void radar_source_cov(double gx, double gy, double gz, const RegParams& rp, double* Cs) {
+    const double kPi = 3.14159265358979323846;
+    const double dist = sqrt(gx * gx + gy * gy);
+    const double s_x = rp.radar_var[0];
+    const double s_y = fmax(0.1, dist * sin(rp.radar_var[1] / 180 * kPi));
+    const double s_z = fmax(0.1, dist * sin(rp.radar_var[2] / 180 * kPi));
+    const double ele = atan2(gz, dist), azi = atan2(gy, gx);
+    // AngleAxisd(azi, UnitZ) * AngleAxisd(ele, UnitY) -> Matrix3d: quaternion product, then Quaternion::toRotationMatrix
+    const double yw = cos(azi / 2.0), yz = sin(azi / 2.0), pw = cos(ele / 2.0), py = sin(ele / 2.0);
+    const double w = yw * pw, x = -(yz * py), y = yw * py, z = yz * pw;
+    const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    const double R[9] = {1.0 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1.0 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1.0 - (txx + tyy)};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        Cs[r * 3 + 0] = R[r * 3 + 0] * s_x;
+        Cs[r * 3 + 1] = R[r * 3 + 1] * s_y;
+        Cs[r * 3 + 2] = R[r * 3 + 2] * s_z;
+    }
+}
+// p = source point in the sensor frame, (mx, my, mz) = target position and C = target covariance (row-major) in the map frame,
+// Cs = the source point's covariance term, nfit = GICP's plane normal in the map frame
+template <int METHOD>
+__device__ __forceinline__ void add_pair_radar(double* acc, const double* Rinv, const double* tinv, double px, double py, double pz,
+                                               double mx, double my, double mz, const double* C, const double* Cs, const double* nfit,
+                                               const RegParams& rp) {
+    const double lx = ((Rinv[0] * mx + Rinv[1] * my) + Rinv[2] * mz) + tinv[0];
+    const double ly = ((Rinv[3] * mx + Rinv[4] * my) + Rinv[5] * mz) + tinv[1];
+    const double lz = ((Rinv[6] * mx + Rinv[7] * my) + Rinv[8] * mz) + tinv[2];
+    const double rx = lx - px, ry = ly - py, rz = lz - pz; // residual_local
+    const double r2 = (rx * rx + ry * ry) + rz * rz;
+    const double den = rp.th + r2;
+    double w = rp.th2 / (den * den);
+    if (METHOD == ELM_GICP) w = w * 0.8 + 0.2;
+    acc[43] += 1.0;
+    if (METHOD == ELM_VGICP || METHOD == ELM_AVGICP) {
+        if (w < 0.01) return; // reg.cpp:201
+    }
+    double RC[9], RCR[9], M[9], A[9];
+    mul3(Rinv, C, RC);
+    mul3_bt(RC, Rinv, RCR);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) RCR[i] += Cs[i]; // reg.cpp:109-111 / 188-190
+    inv3(RCR, M);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) A[i] = w * M[i];
+    // J = [I | B], B = -[p]x = rows (0, pz, -py) (-pz, 0, px) (py, -px, 0); B^T = rows (0, -pz, py) (pz, 0, -px) (-py, px, 0)
+    double AB[9], BtA[9], BtAB[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        AB[i * 3 + 0] = A[i * 3 + 2] * py - A[i * 3 + 1] * pz;
+        AB[i * 3 + 1] = A[i * 3 + 0] * pz - A[i * 3 + 2] * px;
+        AB[i * 3 + 2] = A[i * 3 + 1] * px - A[i * 3 + 0] * py;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        BtA[0 * 3 + j] = py * A[6 + j] - pz * A[3 + j];
+        BtA[1 * 3 + j] = pz * A[0 + j] - px * A[6 + j];
+        BtA[2 * 3 + j] = px * A[3 + j] - py * A[0 + j];
+        BtAB[0 * 3 + j] = py * AB[6 + j] - pz * AB[3 + j];
+        BtAB[1 * 3 + j] = pz * AB[0 + j] - px * AB[6 + j];
+        BtAB[2 * 3 + j] = px * AB[3 + j] - py * AB[0 + j];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            acc[i * 6 + j] += A[i * 3 + j];
+            acc[i * 6 + 3 + j] += AB[i * 3 + j];
+            acc[(3 + i) * 6 + j] += BtA[i * 3 + j];
+            acc[(3 + i) * 6 + 3 + j] += BtAB[i * 3 + j];
+        }
+    const double ax = (A[0] * rx + A[1] * ry) + A[2] * rz;
+    const double ay = (A[3] * rx + A[4] * ry) + A[5] * rz;
+    const double az = (A[6] * rx + A[7] * ry) + A[8] * rz;
+    acc[36] += ax; acc[37] += ay; acc[38] += az;
+    acc[39] += py * az - pz * ay;
+    acc[40] += pz * ax - px * az;
+    acc[41] += px * ay - py * ax;
+    if (METHOD == ELM_GICP) {
+        double nx = (Rinv[0] * nfit[0] + Rinv[1] * nfit[1]) + Rinv[2] * nfit[2];
+        double ny = (Rinv[3] * nfit[0] + Rinv[4] * nfit[1]) + Rinv[5] * nfit[2];
+        double nz = (Rinv[6] * nfit[0] + Rinv[7] * nfit[1]) + Rinv[8] * nfit[2];
+        const double nn2 = (nx * nx + ny * ny) + nz * nz;
+        if (nn2 > 0.0) {
+            const double nn = sqrt(nn2);
+            nx /= nn; ny /= nn; nz /= nn;
+        }
+        acc[42] += fabs((rx * nx + ry * ny) + rz * nz);
+    } else {
+        acc[42] += sqrt(r2);
+    }
+}
+
 // The covariance-weighted methods in the WORLD frame.  With a = R p = g - t and the world residual e = m - g:
 //   r_l = R^-1 e,   M_l = (R^-1 C R^-T)^-1 = R^T C^-1 R,   R [p]x R^T = [a]x
 //   =>  J_l^T M_l J_l = P^T (J_w^T C^-1 J_w) P,   J_l^T M_l r_l = P^T (J_w^T C^-1 e),   J_w = [I | -[a]x],  P = diag(R, R)
@@ -542,6 +647,99 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_direct(const DevMap m, co
         if (threadIdx.x < 32) sum = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
     }
     publish_and_reduce(sum, L, s, sd.blk_begin, sd.blk_end, partials, rp, s_scr);
+}
+
+// ---- K1r: the radar-covariance variant of the direct kernel (use_radar_cov = 1, methods with covariances) ----------------------------
+// One thread per scan point, the plain 27-probe (7-probe) walk, 64-double partial records (see add_pair_radar).  A configuration for
+// radar sensors with a few hundred returns per scan: not a throughput path.
+template <int METHOD>
+__global__ __launch_bounds__(kBlock) void k_accumulate_radar(const DevMap m, const ScanDesc* __restrict__ scans, int batch, unsigned total_blocks,
+                                                             const ScanState* __restrict__ st, double* __restrict__ partials, const RegParams rp) {
+    const unsigned L = xcd_remap(blockIdx.x, total_blocks);
+    const int s = find_scan(scans, batch, L, rp);
+    const ScanState& S = st[s];
+    if (S.done) return;
+    const ScanDesc sd = scans[s];
+    if (L >= sd.blk_end) return;
+    const unsigned i = (L - sd.blk_begin) * kBlock + threadIdx.x;
+    double acc[kRadarAcc];
+#pragma unroll
+    for (int k = 0; k < kRadarAcc; ++k) acc[k] = 0.0;
+    if (i < sd.n) {
+        const Pt3 pf = sd.pts[i];
+        const double px = pf.x, py = pf.y, pz = pf.z;
+        const double gx = ((S.T[0] * px + S.T[4] * py) + S.T[8] * pz) + S.T[12];
+        const double gy = ((S.T[1] * px + S.T[5] * py) + S.T[9] * pz) + S.T[13];
+        const double gz = ((S.T[2] * px + S.T[6] * py) + S.T[10] * pz) + S.T[14];
+        double Cs[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        if (S.iters == 0) radar_source_cov(gx, gy, gz, rp, Cs); // S.T is still the initial guess: g is the pose CalFramePointCov reads
+        const int vx = floor_key(gx, m.voxel_size), vy = floor_key(gy, m.voxel_size), vz = floor_key(gz, m.voxel_size);
+        const double ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        double n_cand = 0.0, n_occ = 0.0;
+        if (METHOD == ELM_GICP) {
+            double bd2 = DBL_MAX;
+            float bx = 0.f, by = 0.f, bz = 0.f;
+            int bidx = -1;
+            nearest_point_direct(m, vx, vy, vz, gx, gy, gz, bd2, bx, by, bz, bidx, n_cand, n_occ);
+            const double dfin = (bidx >= 0) ? bd2 : (gx * gx + gy * gy) + gz * gz; // no bucket: the default PointStruct at the origin (vhm.cpp:37)
+            if (dfin < rp.th2) {
+                double C[9], mean[3] = {0.0, 0.0, 0.0}, nf[3] = {1.0, 0.0, 0.0};
+#pragma unroll
+                for (int k = 0; k < 9; ++k) C[k] = ident[k];
+                if (bidx >= 0) {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) C[k] = m.pt_cov[(size_t)bidx * 9 + k];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { mean[k] = m.pt_gicp[(size_t)bidx * 16 + k]; nf[k] = m.pt_gicp[(size_t)bidx * 16 + 12 + k]; }
+                }
+                add_pair_radar<ELM_GICP>(acc, S.Rinv, S.tinv, px, py, pz, mean[0], mean[1], mean[2], C, Cs, nf, rp);
+            }
+        } else if (METHOD == ELM_VGICP) {
+            double bd2 = DBL_MAX, bmx = 0.0, bmy = 0.0, bmz = 0.0;
+            int bvid = -1;
+            nearest_voxel_direct(m, vx, vy, vz, gx, gy, gz, bd2, bvid, bmx, bmy, bmz, n_cand, n_occ);
+            const double dfin = (bvid >= 0) ? bd2 : (gx * gx + gy * gy) + gz * gz;
+            if (dfin < rp.th2) {
+                double C[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) C[k] = (bvid >= 0) ? m.vox_cov[(size_t)bvid * 9 + k] : ident[k];
+                if (bvid < 0) bmx = bmy = bmz = 0.0;
+                add_pair_radar<ELM_VGICP>(acc, S.Rinv, S.tinv, px, py, pz, bmx, bmy, bmz, C, Cs, nullptr, rp);
+            }
+        } else {
+            const int ox[7] = {0, 1, -1, 0, 0, 0, 0}, oy[7] = {0, 0, 0, 1, -1, 0, 0}, oz[7] = {0, 0, 0, 0, 0, 1, -1};
+            for (int k7 = 0; k7 < 7; ++k7) {
+                const Probe pr = probe_voxel(m, vx + ox[k7], vy + oy[k7], vz + oz[k7]);
+                if (pr.vid < 0 || pr.cnt == 0) continue;
+                n_occ += 1.0;
+                n_cand += 1.0;
+                const double cx = m.vox_mean[(size_t)pr.vid * 3], cy = m.vox_mean[(size_t)pr.vid * 3 + 1], cz = m.vox_mean[(size_t)pr.vid * 3 + 2];
+                const double ex = cx - gx, ey = cy - gy, ez = cz - gz;
+                const double d2 = (ex * ex + ey * ey) + ez * ez;
+                if (d2 < rp.th2) {
+                    double C[9];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) C[k] = m.vox_cov[(size_t)pr.vid * 9 + k];
+                    add_pair_radar<ELM_AVGICP>(acc, S.Rinv, S.tinv, px, py, pz, cx, cy, cz, C, Cs, nullptr, rp);
+                }
+            }
+        }
+        acc[44] = n_cand;
+        acc[45] = n_occ;
+        acc[46] = n_cand;
+    }
+    __shared__ double red[kBlock / 64][kRadarSums];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kRadarAcc; ++k) {
+        const double v = wave_sum(acc[k]);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < (unsigned)kRadarSums) {
+        const int k = threadIdx.x;
+        partials[(size_t)L * kRadarSums + k] = (k < kRadarAcc) ? ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k] : 0.0;
+    }
 }
 
 // ---- K1 on the neighbourhood lists (fall-back search index) ---------------------------------------------------------
@@ -2325,6 +2523,41 @@ __device__ __forceinline__ void wave_ldlt6(double a, const double* b, double x[6
     }
 }
 
+// Matrix<double, 6, 6>::inverse() as Eigen computes it (PartialPivLU: row exchanges on the first largest |entry| of the column, then
+// the solve against the identity).  One lane, LDS operands (row-major in `lu`, overwritten; row-major out): only GICP with
+// use_radar_cov needs the inverse of a non-symmetric matrix.
+__device__ __noinline__ void inverse6_partial_piv(double* lu, double* inv) {
+    int perm[6];
+    for (int i = 0; i < 6; ++i) perm[i] = i;
+    for (int k = 0; k < 6; ++k) {
+        int piv = k;
+        double best = fabs(lu[k * 6 + k]);
+        for (int i = k + 1; i < 6; ++i) {
+            const double v = fabs(lu[i * 6 + k]);
+            if (v > best) { best = v; piv = i; }
+        }
+        if (piv != k) {
+            for (int c = 0; c < 6; ++c) { const double tmp = lu[k * 6 + c]; lu[k * 6 + c] = lu[piv * 6 + c]; lu[piv * 6 + c] = tmp; }
+            const int tp = perm[k]; perm[k] = perm[piv]; perm[piv] = tp;
+        }
+        if (lu[k * 6 + k] != 0.0)
+            for (int i = k + 1; i < 6; ++i) lu[i * 6 + k] /= lu[k * 6 + k];
+        for (int c = k + 1; c < 6; ++c)
+            for (int i = k + 1; i < 6; ++i) lu[i * 6 + c] -= lu[i * 6 + k] * lu[k * 6 + c];
+    }
+    for (int c = 0; c < 6; ++c) {
+        double y[6];
+        for (int i = 0; i < 6; ++i) y[i] = (perm[i] == c) ? 1.0 : 0.0;
+        for (int i = 0; i < 6; ++i)
+            for (int j = 0; j < i; ++j) y[i] -= lu[i * 6 + j] * y[j];
+        for (int i = 5; i >= 0; --i) {
+            for (int j = i + 1; j < 6; ++j) y[i] -= lu[i * 6 + j] * y[j];
+            y[i] /= lu[i * 6 + i];
+        }
+        for (int i = 0; i < 6; ++i) inv[i * 6 + c] = y[i];
+    }
+}
+
 // queue position for a free slot, or -1 when nothing is pending.  Plain streams: every registration is there from the start, one
 // atomicAdd hands them out.  Host-fed streams: only registrations whose scan has landed in HBM (ctrl->ready, published by the upload
 // stream after the scan's ordering kernel) may start, so the counter advances by compare-and-swap and never overshoots.
@@ -2419,7 +2652,26 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* scans, 
     __shared__ double part[kSolveThreads / 32][kSums];
     const bool done = S.done != 0;
     const bool fused = rp.tickets != nullptr; // the accumulate kernels' last workgroups have left the scan's sums in `sums`
-    if (mode != 2 && !fused) {
+    const bool radar = rp.radar != 0;         // k_accumulate_radar's records: 64 doubles, all 36 entries of J^T M J (single GPU, unfused)
+    __shared__ double full[36];               // radar: J^T M J row-major
+    if (radar) {
+        const int k = t & 63, g = t >> 6; // sixteen groups of 64 lanes, one lane per sum, fixed order
+        double* part64 = &part[0][0];
+        double v = 0.0;
+        if (!done) {
+            const ScanDesc sd = scans[s];
+            for (unsigned b = sd.blk_begin + g; b < sd.blk_end; b += kSolveThreads / 64) v += partials[(size_t)b * kRadarSums + k];
+        }
+        part64[g * 64 + k] = v;
+        __syncthreads();
+        if (t < 64) {
+            double a = part64[t];
+#pragma unroll
+            for (int q = 1; q < kSolveThreads / 64; ++q) a += part64[q * 64 + t];
+            if (t < 36) full[t] = a;
+            else if (t < kRadarAcc) tot[21 + (t - 36)] = a; // J^T M r, residual sum, pair count, statistics: the slots of the 32-sum layout
+        }
+    } else if (mode != 2 && !fused) {
         // deterministic reduction of this scan's per-workgroup partial sums: 32 strided groups of 32 lanes read whole
         // 256-byte records (four independent loads in flight per lane), then the group sums are added in a fixed order
         const int k = t & 31, g = t >> 5;
@@ -2471,7 +2723,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* scans, 
     }
     const bool lead = (t == 0);
 
-    if (rp.method != ELM_P2P) {
+    if (rp.method != ELM_P2P && !radar) {
         // the covariance-weighted kernels accumulate in the world frame (add_pair_world): H_l = P^T H_w P, b_l = P^T b_w with
         // P = diag(R, R), R the rotation the pairs were formed with (S.T is updated further down)
         __shared__ double hw[36], bw[6];
@@ -2540,11 +2792,23 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* scans, 
 
     // JTJ + lambda * diag(JTJ), one element per lane (reg.cpp:55-56 / 136-138 / 213-214)
     const int li = (t < 36) ? t / 6 : 0, lj = (t < 36) ? t % 6 : 0;
-    const double hij = tot[tri(li < lj ? li : lj, li < lj ? lj : li)];
+    // (radar: JTJ is not symmetric and JTJ.ldlt() reads its lower triangle -- the factorisation of the symmetric matrix with that triangle)
+    const double hij = radar ? full[(li < lj ? lj : li) * 6 + (li < lj ? li : lj)] : tot[tri(li < lj ? li : lj, li < lj ? lj : li)];
     const double a = (li == lj) ? hij + rp.lm_lambda * hij : hij;
     double x[6], inv_elem;
-    wave_ldlt6(a, &tot[21], x, rp.method == ELM_GICP, inv_elem);
-    if (rp.method == ELM_GICP && t < 36) S.local_cov[t] = inv_elem; // reg.cpp:141-142 (symmetric: layout-free)
+    wave_ldlt6(a, &tot[21], x, rp.method == ELM_GICP && !radar, inv_elem);
+    if (rp.method == ELM_GICP && !radar && t < 36) S.local_cov[t] = inv_elem; // reg.cpp:141-142 (symmetric: layout-free)
+    if (rp.method == ELM_GICP && radar) {
+        // JTJ_regularized.inverse() of the FULL matrix (reg.cpp:141-142): Eigen's PartialPivLU + solve against the identity; column-major out
+        __shared__ double lu[36], invm[36];
+        if (t < 36) lu[t] = (li == lj) ? full[t] + rp.lm_lambda * full[t] : full[t];
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        if (lead) inverse6_partial_piv(lu, invm);
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        if (t < 36) S.local_cov[t] = invm[lj * 6 + li];
+    }
 
     double dR[9];
     rotvec_to_matrix(&x[3], dR);
@@ -2557,7 +2821,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* scans, 
     }
     Tn[3] = 0.0; Tn[7] = 0.0; Tn[11] = 0.0; Tn[15] = 1.0;
     const double step = matrix_to_angle(dR) + sqrt((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2]); // reg.cpp:381-384
-    if (tr && t < 36) tr->JTJ[t] = hij; // symmetric
+    if (tr && t < 36) tr->JTJ[t] = radar ? full[lj * 6 + li] : hij; // column-major (symmetric unless radar)
     bool fin = false;
     if (lead) {
         S.fitness = fitness;
@@ -2775,6 +3039,16 @@ void launch_init_state(hipStream_t s, ScanState* st, const double* T0, int batch
     hipLaunchKernelGGL(k_init_state, dim3((batch + 63) / 64), dim3(64), 0, s, st, T0, batch, map_empty, active, tickets);
 }
 
+void launch_accumulate_radar(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks, ScanState* st, double* partials,
+                             const RegParams& rp) {
+    if (total_blocks <= 0) return;
+    const dim3 grid((unsigned)total_blocks), block(kBlock);
+    switch (rp.method) {
+    case ELM_GICP: hipLaunchKernelGGL(k_accumulate_radar<ELM_GICP>, grid, block, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp); break;
+    case ELM_VGICP: hipLaunchKernelGGL(k_accumulate_radar<ELM_VGICP>, grid, block, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp); break;
+    default: hipLaunchKernelGGL(k_accumulate_radar<ELM_AVGICP>, grid, block, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp); break;
+    }
+}
 void launch_accumulate_direct(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                               ScanState* st, double* partials, const RegParams& rp) {
     dim3 g(total_blocks), b(kBlock);

@@ -905,6 +905,50 @@ inline V3 to_local(const M4& Tinv, const V3& g) { // last_icp_pose_inv * [g,1], 
             ((Tinv(2, 0) * g.x + Tinv(2, 1) * g.y) + Tinv(2, 2) * g.z) + Tinv(2, 3) * 1.0};
 }
 
+// Eigen::AngleAxisd * Eigen::AngleAxisd assigned to a Matrix3d (reg.hpp:197-200): each AngleAxis becomes a quaternion (w = cos(a/2),
+// vec = sin(a/2) axis), the quaternions are multiplied (Eigen/src/Geometry/Quaternion.h, quat_product) and the product is converted
+// with QuaternionBase::toRotationMatrix.
+M3 yaw_pitch_matrix(double azi_angle, double ele_angle) {
+    const double yw = std::cos(azi_angle / 2.0), yz = std::sin(azi_angle / 2.0); // about UnitZ: (w, 0, 0, z)
+    const double pw = std::cos(ele_angle / 2.0), py = std::sin(ele_angle / 2.0); // about UnitY: (w, 0, y, 0)
+    // a * b with a = (yw; 0, 0, yz), b = (pw; 0, py, 0)
+    const double w = yw * pw - 0.0 * 0.0 - 0.0 * py - yz * 0.0;
+    const double x = yw * 0.0 + 0.0 * pw + 0.0 * 0.0 - yz * py;
+    const double y = yw * py + 0.0 * pw + yz * 0.0 - 0.0 * 0.0;
+    const double z = yw * 0.0 + yz * pw + 0.0 * py - 0.0 * 0.0;
+    const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w;
+    const double txx = tx * x, txy = ty * x, txz = tz * x;
+    const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    M3 R;
+    R(0, 0) = 1.0 - (tyy + tzz); R(0, 1) = txy - twz; R(0, 2) = txz + twy;
+    R(1, 0) = txy + twz; R(1, 1) = 1.0 - (txx + tzz); R(1, 2) = tyz - twx;
+    R(2, 0) = txz - twy; R(2, 1) = tyz + twx; R(2, 2) = 1.0 - (txx + tyy);
+    return R;
+}
+
+// Registration::CalPointCov / CalFramePointCov (reg.hpp:186-217): "covariance" of a radar return from its range / azimuth /
+// elevation spreads -- R * S with S = diag(s_x, s_y, s_z), NOT R S R^T: the matrix is not symmetric, and it is built from
+// point.pose, which at the call site (reg.cpp:302-305) is the point in the MAP frame under the initial guess.
+void CalFramePointCov(std::vector<PointStruct>& points, double range_var_m, double azim_var_deg, double ele_var_deg) {
+    for (auto& point : points) {
+        const double dist = std::sqrt(point.pose.x * point.pose.x + point.pose.y * point.pose.y);
+        const double s_x = range_var_m;
+        const double s_y = std::max(0.1, dist * std::sin(azim_var_deg / 180 * M_PI));
+        const double s_z = std::max(0.1, dist * std::sin(ele_var_deg / 180 * M_PI));
+        const double ele_angle = std::atan2(point.pose.z, dist);
+        const double azi_angle = std::atan2(point.pose.y, point.pose.x);
+        const M3 R = yaw_pitch_matrix(azi_angle, ele_angle);
+        M3 cov;
+        for (int r = 0; r < 3; ++r) {
+            cov(r, 0) = R(r, 0) * s_x;
+            cov(r, 1) = R(r, 1) * s_y;
+            cov(r, 2) = R(r, 2) * s_z;
+        }
+        point.covariance.cov = cov;
+    }
+}
+
 // AlignCloudsLocal -- P2P (reg.cpp:15-66)
 AlignOut AlignCloudsLocal(const std::vector<PointStruct>& source_global, const std::vector<PointStruct>& target_global,
                           const M4& last_icp_pose, double trans_th, const orc_config& cfg, double* fitness) {
@@ -946,6 +990,8 @@ AlignOut AlignCloudsLocalPointCov(const std::vector<PointStruct>& source_global,
         V3 target_local = to_local(inv, target_cov.mean); // the neighbourhood MEAN, not the matched point (reg.cpp:97)
         V3 residual_local = sub(target_local, source_global[i].local);
         M3 RCR = m3_mul(m3_mul(sensor_rot_inv, target_cov.cov), m3_transpose(sensor_rot_inv));
+        if (cfg.use_radar_cov) // reg.cpp:109-111
+            for (int k = 0; k < 9; ++k) RCR.m[k] += source_global[i].covariance.cov.m[k];
         M3 mahalanobis_local = m3_inverse(RCR);
         double J[3][6];
         make_Jg(source_global[i].local, J);
@@ -979,6 +1025,8 @@ AlignOut AlignCloudsLocalVoxelCov(const std::vector<PointStruct>& source_global,
         V3 target_local = to_local(inv, target_cov.mean);
         V3 residual_local = sub(target_local, source_global[i].local);
         M3 RCR = m3_mul(m3_mul(sensor_rot_inv, target_cov.cov), m3_transpose(sensor_rot_inv));
+        if (cfg.use_radar_cov) // reg.cpp:188-190
+            for (int k = 0; k < 9; ++k) RCR.m[k] += source_global[i].covariance.cov.m[k];
         M3 mahalanobis_local = m3_inverse(RCR);
         double J[3][6];
         make_Jg(source_global[i].local, J);
@@ -1217,6 +1265,11 @@ void orc_register(const orc_map* mp, const float* scan_xyz, size_t n, const doub
     }
 
     M4 last_icp_pose = initial_guess;
+    // reg.cpp:302-305: the radar covariances are attached to source_global ONCE, from the poses under the initial guess.  The
+    // re-transform at the end of every iteration (reg.cpp:390) rebuilds source_global from source_local and copies ITS covariance
+    // (the default identity of Pcl2PointStruct's points, pcm.hpp:205-220), so only the first iteration sees them.
+    if (cfg.use_radar_cov)
+        CalFramePointCov(source_global, cfg.range_variance_m, cfg.azimuth_variance_deg, cfg.elevation_variance_deg);
     auto start = Clock::now();
     int i_iteration = 0;
     double total_correspondence_time_ms = 0.0;

@@ -34,13 +34,16 @@ typedef struct orc_config {
     int32_t icp_method;
     int32_t max_iteration;
     int32_t max_thread; /* threads for the correspondence search (TBB arena size in the reference) */
-    int32_t use_radar_cov; /* must be 0: dead under every BASELINE config, not restated */
+    int32_t use_radar_cov; /* reg.hpp:186-217, reg.cpp:109-111, 188-190, 302-305 (off in the shipped localization.ini:105) */
     double max_search_dist;
     double lm_lambda;
     double icp_termination_threshold_m;
     double min_overlap_ratio;
     double max_fitness_score;
     double gicp_cov_search_dist;
+    double range_variance_m;       /* reg.hpp:80-82: only read with use_radar_cov */
+    double azimuth_variance_deg;
+    double elevation_variance_deg;
 } orc_config;
 
 #define ORC_MAX_ITER_TRACE 64

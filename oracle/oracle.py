@@ -29,6 +29,9 @@ class Config(C.Structure):
         ("min_overlap_ratio", C.c_double),
         ("max_fitness_score", C.c_double),
         ("gicp_cov_search_dist", C.c_double),
+        ("range_variance_m", C.c_double),
+        ("azimuth_variance_deg", C.c_double),
+        ("elevation_variance_deg", C.c_double),
     ]
 
 
@@ -149,7 +152,7 @@ def default_config(method=GICP, **kw):
     """Defaults = config/localization.ini:83-105 of the reference."""
     c = Config(icp_method=method, max_iteration=10, max_thread=10, use_radar_cov=0, max_search_dist=5.0,
                lm_lambda=0.5, icp_termination_threshold_m=0.02, min_overlap_ratio=0.4, max_fitness_score=0.5,
-               gicp_cov_search_dist=0.4)
+               gicp_cov_search_dist=0.4, range_variance_m=1.0, azimuth_variance_deg=0.4, elevation_variance_deg=0.4)
     for k, v in kw.items():
         setattr(c, k, v)
     return c

@@ -101,11 +101,26 @@ def rot_angle(R):
     return math.atan2(s, c)
 
 
+def radar_point_cov(g, range_var, az_var_deg, el_var_deg):
+    """Registration::CalPointCov (reg.hpp:186-208) from its definition: R S with R = Rz(azimuth) Ry(elevation) written as plain
+    rotation matrices and S = diag(range spread, cross-range spreads floored at 0.1) -- not symmetric, built from the MAP-frame point."""
+    dist = math.hypot(g[0], g[1])
+    S = np.diag([range_var, max(0.1, dist * math.sin(math.radians(az_var_deg))), max(0.1, dist * math.sin(math.radians(el_var_deg)))])
+    el, az = math.atan2(g[2], dist), math.atan2(g[1], g[0])
+    Rz = np.array([[math.cos(az), -math.sin(az), 0.0], [math.sin(az), math.cos(az), 0.0], [0.0, 0.0, 1.0]])
+    Ry = np.array([[math.cos(el), 0.0, math.sin(el)], [0.0, 1.0, 0.0], [-math.sin(el), 0.0, math.cos(el)]])
+    return Rz @ Ry @ S
+
+
 def register(vox, scan, T0, method, voxel_size=1.0, max_iteration=10, th=5.0, lam=0.5, term=0.02, min_overlap=0.4,
-             max_fitness=0.5, vcov=None, pcov=None):
-    """method: 0 P2P, 1 GICP, 2 VGICP, 3 AVGICP."""
+             max_fitness=0.5, vcov=None, pcov=None, radar=None):
+    """method: 0 P2P, 1 GICP, 2 VGICP, 3 AVGICP.  radar = (range_variance_m, azimuth_variance_deg, elevation_variance_deg) switches
+    use_radar_cov on: the source covariance added to R^T C R is CalPointCov of the point under the INITIAL guess in the first
+    iteration and the identity afterwards (reg.cpp:302-305 attaches it to source_global once, reg.cpp:390 rebuilds source_global
+    from source_local, whose points carry the default identity)."""
     scan = np.asarray(scan, dtype=np.float64)
     T = np.array(T0, dtype=np.float64)
+    T_init = T.copy()
     N = len(scan)
     trace = []
     fitness = 0.0
@@ -175,7 +190,13 @@ def register(vox, scan, T0, method, voxel_size=1.0, max_iteration=10, th=5.0, la
             w = th * th / (th + r @ r) ** 2
             if method == 1:
                 w = w * 0.8 + 0.2
-            M = np.eye(3) if C is None else np.linalg.inv(Rt @ C @ R)
+            if C is None:
+                M = np.eye(3)
+            else:
+                RCR = Rt @ C @ R
+                if radar is not None:
+                    RCR = RCR + (radar_point_cov(T_init[:3, :3] @ p + T_init[:3, 3], *radar) if iters == 1 else np.eye(3))
+                M = np.linalg.inv(RCR)
             if method >= 2 and w < 0.01:
                 continue
             H += w * J.T @ M @ J
@@ -188,7 +209,8 @@ def register(vox, scan, T0, method, voxel_size=1.0, max_iteration=10, th=5.0, la
                 rs += np.linalg.norm(r)
         fitness = rs / n_corr
         Hd = H + lam * np.diag(np.diag(H))
-        x = np.linalg.solve(Hd, b)
+        # with the radar covariances the metric (and so H) is not symmetric; JTJ.ldlt() reads the lower triangle only
+        x = eigen_ldlt_solve(Hd, b) if radar is not None else np.linalg.solve(Hd, b)
         if method == 1:
             local_cov = np.linalg.inv(Hd)
         dT = np.eye(4)

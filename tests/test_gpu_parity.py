@@ -892,16 +892,14 @@ def test_full_size_c4_two_shards(oracle):
 
 
 def test_api_misuse_fails_loudly(ctx, oracle, world100k):
-    """Status codes instead of silent fall-backs: bad method, radar covariance, missing covariances, zero slots, a scan of
-    another context."""
+    """Status codes instead of silent fall-backs: bad method, missing covariances, zero slots, a scan of another context."""
     from elimaloc_amd import _lib
     from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, Scan, VoxelHashMap
     vm = VoxelHashMap(1.0, 30, ctx)
     vm.AddPoints(world100k)
     scan, Tt = synth.make_scan(world100k, 2000, seed=5)
     sc = Scan(ctx, scan)
-    for cfg in (RegistrationConfig(icp_method=7), RegistrationConfig(use_radar_cov=1),
-                RegistrationConfig(icp_method=IcpMethod.VGICP), RegistrationConfig(icp_method=IcpMethod.GICP)):
+    for cfg in (RegistrationConfig(icp_method=7), RegistrationConfig(icp_method=IcpMethod.VGICP), RegistrationConfig(icp_method=IcpMethod.GICP)):
         with pytest.raises(_lib.ElmError):  # VGICP / GICP: the covariances were never computed (pcm.cpp:92-100)
             Registration(cfg, ctx).RunRegisterBatch([sc], vm, [Tt])
         with pytest.raises(_lib.ElmError):
@@ -1053,3 +1051,95 @@ def test_fused_reduction_path(oracle, world100k, method, monkeypatch):
             _compare_run(singles[k], ref)
     finally:
         c.close()
+
+
+RADAR = dict(use_radar_cov=1, range_variance_m=0.7, azimuth_variance_deg=1.5, elevation_variance_deg=0.9)
+
+
+def _compare_radar(gpu, ref):
+    """use_radar_cov: the first iteration's metric is not symmetric (R S, reg.hpp:186-217), J^T M J neither -- all 36 entries are compared;
+    the solve reads the lower triangle.  Poses to 1e-7 (the normal equations of that iteration are indefinite)."""
+    assert (gpu["iterations"], gpu["is_success"], gpu["gate"]) == (ref["iterations"], ref["is_success"], ref["gate"])
+    for k, (g, r) in enumerate(zip(gpu["iters"], ref["iters"])):
+        assert g["n_corr"] == r["n_corr"], k
+        if ref["gate"] == 2 and k == ref["iterations"] - 1:
+            break
+        scale = np.abs(r["JTJ"]).max()
+        np.testing.assert_allclose(g["JTJ"], r["JTJ"], rtol=0, atol=SUM_RTOL * scale, err_msg=f"JTJ iter {k}")
+        np.testing.assert_allclose(g["JTr"], r["JTr"], rtol=0, atol=SUM_RTOL * max(np.abs(r["JTr"]).max(), scale * 1e-3))
+        np.testing.assert_allclose(g["residual_sum"], r["residual_sum"], rtol=SUM_RTOL)
+        np.testing.assert_allclose(g["T"], r["T"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(gpu["T"], ref["T"], rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("method", [1, 2, 3])
+def test_radar_covariance_matches_oracle(ctx, oracle, world100k, method):
+    """use_radar_cov = 1 (reg.hpp:186-217, reg.cpp:109-111 / 188-190 / 302-305): R S of the point under the initial guess is added to
+    R^-1 C R^-T in the first iteration, the identity in the later ones."""
+    from elimaloc_amd.registration import Registration, RegistrationConfig, IcpMethod
+    m = IcpMethod(method)
+    vm, om = _maps(ctx, oracle, world100k, m)
+    scan, T_true = synth.make_scan(world100k, 1500, seed=4100 + method)
+    T0 = synth.perturb(T_true, seed=4200 + method, max_trans=0.3, max_rot_deg=1.0)
+    reg = Registration(RegistrationConfig(icp_method=m, **RADAR), ctx)
+    pose, ok, fit, cov, det = reg.RunRegister(scan, vm, T0, trace=True)
+    ref = oracle.register(om, scan, T0, oracle.default_config(method, **RADAR))
+    plain = oracle.register(om, scan, T0, oracle.default_config(method))
+    J0 = ref["iters"][0]["JTJ"]
+    assert np.abs(J0 - J0.T).max() > 1e-3 * np.abs(J0).max()  # the quirk is live: not symmetric
+    assert np.abs(J0 - plain["iters"][0]["JTJ"]).max() > 1e-3 * np.abs(J0).max()
+    _compare_radar(det, ref)
+    np.testing.assert_allclose(cov, ref["local_cov"], rtol=1e-6, atol=1e-12)
+    assert ok == ref["is_success"]
+
+
+def test_radar_covariance_one_iteration_gicp_covariance(ctx, oracle, world100k):
+    """max_iteration = 1: GICP's covariance output is the inverse of the FULL non-symmetric damped matrix (reg.cpp:141-142)."""
+    from elimaloc_amd.registration import Registration, RegistrationConfig, IcpMethod
+    vm, om = _maps(ctx, oracle, world100k, IcpMethod.GICP)
+    scan, T_true = synth.make_scan(world100k, 900, seed=4301)
+    T0 = synth.perturb(T_true, seed=4302, max_trans=0.2, max_rot_deg=0.5)
+    reg = Registration(RegistrationConfig(icp_method=IcpMethod.GICP, max_iteration=1, **RADAR), ctx)
+    pose, ok, fit, cov, det = reg.RunRegister(scan, vm, T0, trace=True)
+    ref = oracle.register(om, scan, T0, oracle.default_config(1, max_iteration=1, **RADAR))
+    _compare_radar(det, ref)
+    assert np.abs(ref["local_cov"] - ref["local_cov"].T).max() > 1e-3 * np.abs(ref["local_cov"]).max()
+    np.testing.assert_allclose(cov, ref["local_cov"], rtol=1e-6, atol=1e-9 * np.abs(ref["local_cov"]).max())
+
+
+def test_radar_covariance_entry_points(ctx, oracle, world100k):
+    """Batch, stream and host-fed stream give the same results under use_radar_cov (ragged sizes, an empty scan, a scan off the map);
+    P2P ignores the switch bit for bit (AlignCloudsLocal reads no covariance)."""
+    from elimaloc_amd.registration import Registration, RegistrationConfig, IcpMethod, Scan
+    vm, om = _maps(ctx, oracle, world100k, IcpMethod.VGICP)
+    sizes = [700, 0, 257, 1200, 1, 300]
+    scans_h, scans, T0s = [], [], []
+    for i, n in enumerate(sizes):
+        sc, Tt = synth.make_scan(world100k, max(n, 1), seed=4400 + i)
+        sc = sc[:n]
+        T0 = synth.perturb(Tt, seed=4500 + i, max_trans=0.1 + 0.05 * i, max_rot_deg=0.3 * (i + 1))
+        if i == 3:
+            T0 = T0.copy(); T0[:3, 3] += 500.0  # no correspondences: gate 2
+        scans_h.append(sc); scans.append(Scan(ctx, sc)); T0s.append(T0)
+    reg = Registration(RegistrationConfig(icp_method=IcpMethod.VGICP, **RADAR), ctx)
+    singles = [reg.RunRegisterBatch([s_], vm, [T])[0] for s_, T in zip(scans, T0s)]
+    batch = reg.RunRegisterBatch(scans, vm, T0s)
+    stream = reg.RunRegisterStream(scans, vm, T0s, slots=4)
+    fed = reg.RunRegisterStreamHost(reg.pack_host_inputs(scans_h, T0s), vm, slots=4)
+    for k, s_ in enumerate(singles):
+        ref = oracle.register(om, scans_h[k], T0s[k], oracle.default_config(2, **RADAR))
+        assert (s_["iterations"], s_["is_success"], s_["gate"]) == (ref["iterations"], ref["is_success"], ref["gate"]), k
+        np.testing.assert_allclose(s_["T"], ref["T"], rtol=0, atol=1e-7)
+        for other in (batch, stream):
+            o = other[k]
+            assert (o["iterations"], o["is_success"], o["gate"]) == (s_["iterations"], s_["is_success"], s_["gate"]), k
+            assert np.array_equal(o["T"], s_["T"]), k
+        # (the host-fed path reorders the scan's points on the device: same registration, another summation order)
+        f = fed[k]
+        assert (f["iterations"], f["is_success"], f["gate"]) == (s_["iterations"], s_["is_success"], s_["gate"]), k
+        np.testing.assert_allclose(f["T"], s_["T"], rtol=0, atol=1e-7)
+    assert singles[3]["gate"] == 2
+    p_on = Registration(RegistrationConfig(icp_method=IcpMethod.P2P, **RADAR), ctx).RunRegisterStream(scans, vm, T0s, slots=3)
+    p_off = Registration(RegistrationConfig(icp_method=IcpMethod.P2P), ctx).RunRegisterStream(scans, vm, T0s, slots=3)
+    for a, b in zip(p_on, p_off):
+        assert np.array_equal(a["T"], b["T"]) and a["iterations"] == b["iterations"]

@@ -292,8 +292,8 @@ def test_vgicp_small_weight_skip(oracle):
 
 
 # ------------------------------------------------------------------------------------------------ numpy cross-check
-@pytest.mark.parametrize("method", [0, 1, 2, 3])
-def test_oracle_matches_numpy_rederivation(oracle, method):
+@pytest.mark.parametrize("method,radar", [(0, False), (1, False), (2, False), (3, False), (1, True), (2, True), (3, True), (0, True)])
+def test_oracle_matches_numpy_rederivation(oracle, method, radar):
     if method == 0:
         world = synth.make_world(9000, seed=31)
         scan, T_true = synth.make_scan(world, 700, seed=32)
@@ -325,8 +325,11 @@ def test_oracle_matches_numpy_rederivation(oracle, method):
                 np.testing.assert_allclose(vcov[k][0], omap[k][0], atol=1e-9)
                 np.testing.assert_allclose(vcov[k][1], omap[k][1], atol=1e-12)
     if method == 1:
-        m.cal_point_cov_all(0.4)
-        pcov = np_ref.point_covs(vox, 1.0, 0.4)
+        # (radar variant: 0.8 m neighbourhoods, so that no covariance is rank deficient -- with sign-flipped regularisations
+        # R^T C R + I can be singular, and what Matrix3d::inverse() returns then is not worth pinning)
+        cov_dist = 0.8 if radar else 0.4
+        m.cal_point_cov_all(cov_dist)
+        pcov = np_ref.point_covs(vox, 1.0, cov_dist)
         oxyz, ocov, omean = m.pointcloud()
         omap = {tuple(p): (c, mu) for p, c, mu in zip(oxyz, ocov, omean)}
         for (k, idx) in pcov:
@@ -337,8 +340,17 @@ def test_oracle_matches_numpy_rederivation(oracle, method):
                 np.testing.assert_allclose(pcov[(k, idx)][0], o[0], atol=1e-9)
                 np.testing.assert_allclose(pcov[(k, idx)][1], o[1], atol=1e-12)
     assert len(np_ref.DEGENERATE) < 0.2 * m.num_points
-    ref = np_ref.register(vox, scan.astype(np.float64), T0, method, vcov=vcov, pcov=pcov)
-    out = oracle.register(m, scan, T0, oracle.default_config(method, max_thread=4))
+    if radar and method == 1:
+        assert not np_ref.DEGENERATE
+    # radar: use_radar_cov = 1 with non-default spreads (reg.hpp:186-217): the first iteration adds R S of the point under the
+    # initial guess to R^T C R, the later ones the identity; P2P ignores the switch (AlignCloudsLocal never reads a covariance)
+    rv = (0.7, 1.5, 0.9)
+    ref = np_ref.register(vox, scan.astype(np.float64), T0, method, vcov=vcov, pcov=pcov, radar=rv if radar else None)
+    out = oracle.register(m, scan, T0, oracle.default_config(method, max_thread=4, use_radar_cov=int(radar), range_variance_m=rv[0],
+                                                             azimuth_variance_deg=rv[1], elevation_variance_deg=rv[2]))
+    if radar and method != 0:
+        plain = oracle.register(m, scan, T0, oracle.default_config(method, max_thread=4))
+        assert np.abs(plain["iters"][0]["JTJ"] - out["iters"][0]["JTJ"]).max() > 1e-3 * np.abs(plain["iters"][0]["JTJ"]).max()  # the switch matters
     assert out["iterations"] == ref["iterations"] and out["is_success"] == ref["is_success"] and out["gate"] == ref["gate"]
     for a, b in zip(out["iters"], ref["iters"]):
         assert a["n_corr"] == b["n_corr"]
