@@ -30,7 +30,7 @@ extern "C" {
 #define ELM_ERR_DEVICE -2      /* HIP runtime error (elm_last_error has the text) */
 #define ELM_ERR_NO_DEVICE -3   /* no usable gfx950 device */
 #define ELM_ERR_COMM -4        /* RCCL error / not initialised */
-#define ELM_ERR_UNSUPPORTED -5 /* e.g. use_radar_cov = 1 */
+#define ELM_ERR_UNSUPPORTED -5 /* e.g. use_radar_cov = 1 together with a communicator */
 #define ELM_ERR_IO -6          /* file missing / unreadable */
 #define ELM_ERR_ALLOC -7       /* host allocation failed */
 
@@ -48,7 +48,7 @@ typedef struct elm_reg_config {
     int32_t i_max_thread;        /* unused on the GPU; kept for API parity */
     int32_t icp_method;          /* ELM_P2P .. ELM_AVGICP */
     int32_t voxel_search_method; /* parsed but unused by the reference (pcm.cpp:175) */
-    int32_t use_radar_cov;       /* must be 0 (reg.hpp:210-217 not built) */
+    int32_t use_radar_cov;       /* reg.hpp:186-217: first iteration adds CalPointCov of the point under the initial guess, later ones I (single rank) */
     int32_t max_iteration;
     int32_t b_debug_print;
     double gicp_cov_search_dist;
