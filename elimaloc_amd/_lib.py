@@ -133,8 +133,8 @@ EXPORTS = [
     "elm_register_batch_finish", "elm_deskew", "elm_deskew_downsample", "elm_deskew_prepare", "elm_comm_get_unique_id", "elm_comm_init",
     "elm_comm_destroy", "elm_comm_set_hook", "elm_filter_points_by_distance", "elm_voxel_downsample",
     "elm_get_interpolated_pose", "elm_shape_odom_covariance",
-    "elm_ekf_config_default", "elm_ekf_create", "elm_ekf_destroy", "elm_ekf_predict_imu", "elm_ekf_update_pose",
-    "elm_ekf_update_pcm_odom", "elm_ekf_get_state", "elm_ekf_publish",
+    "elm_ekf_config_default", "elm_ekf_create", "elm_ekf_destroy", "elm_ekf_predict_imu", "elm_ekf_predict", "elm_ekf_update_can",
+    "elm_ekf_update_pose", "elm_ekf_update_pcm_odom", "elm_ekf_get_state", "elm_ekf_publish",
     "elm_ini_load", "elm_ini_destroy", "elm_ini_get_string", "elm_ini_get_int", "elm_ini_get_bool", "elm_ini_get_double",
     "elm_ini_get_array", "elm_pcm_node_config_default", "elm_load_pcm_config", "elm_load_ekf_config", "elm_pcd_load_xyz",
     "elm_free", "elm_scan_from_cloud", "elm_pcm_callback_point_cloud",
@@ -172,7 +172,8 @@ class EkfConfig(C.Structure):
             "state_std_pos_m", "state_std_rot_deg", "state_std_vel_mps", "state_std_gyro_dps", "state_std_acc_mps",
             "imu_std_gyro_dps", "imu_std_acc_mps", "ekf_imu_bias_cov_gyro", "ekf_imu_bias_cov_acc",
             "gnss_min_cov_x_m", "gnss_min_cov_y_m", "gnss_min_cov_z_m", "gnss_min_cov_roll_deg", "gnss_min_cov_pitch_deg",
-            "gnss_min_cov_yaw_deg")]
+            "gnss_min_cov_yaw_deg", "can_vel_scale_factor", "ekf_can_meas_uncertainty_vel_mps",
+            "ekf_can_meas_uncertainty_yaw_rate_deg")]
 
 
 class EkfStateC(C.Structure):
@@ -261,6 +262,8 @@ def lib():
     L.elm_ekf_destroy.argtypes = [vp]
     L.elm_ekf_destroy.restype = None
     L.elm_ekf_predict_imu.argtypes = [vp, C.c_double, dp, dp, ip]
+    L.elm_ekf_predict.argtypes = [vp, C.c_double, ip]
+    L.elm_ekf_update_can.argtypes = [vp, C.c_double, dp, dp, ip]
     L.elm_ekf_update_pose.argtypes = [vp, C.c_double, dp, dp, dp, dp, C.c_int, ip]
     L.elm_ekf_update_pcm_odom.argtypes = [vp, C.c_double, dp, dp, dp, C.c_int, ip]
     L.elm_ekf_get_state.argtypes = [vp, C.POINTER(EkfStateC)]

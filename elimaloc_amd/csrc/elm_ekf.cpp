@@ -5,8 +5,9 @@
 // ComplementaryKalmanFilter :597-700, GetCurrentState :778-833), ekf_algorithm.hpp (UpdateEkfState :116-145, Check*
 // :148-213), ekf_localization.cpp (CallbackPcmOdom :147-179, GnssTimeCompensation :323-394, PublishInThread :397-410) and
 // localization_functions.hpp (RotToVec :312-333, CalEulerResidualFromQuat :354-370, Exp :412-419, ExpGyroToQuat :439-443,
-// PartialDerivativeRotWrtGyro :466-483, ConvertGlobalToLocalVelocity :491-513).  Not built: ZUPT, CAN update, IMU-mount
-// calibration (all off in the shipped localization.ini) -> ELM_ERR_UNSUPPORTED.
+// PartialDerivativeRotWrtGyro :466-483, ConvertGlobalToLocalVelocity :491-513).  The side modes that the shipped localization.ini
+// leaves off are here too: RunPrediction (the constant-velocity model of use_imu = 0, ekfa.cpp:81-165), RunCanUpdate + ZuptCan
+// (:434-506, :567-587), ZuptImu (:508-565) and CalibrateVehicleToImu (:703-776).
 #include <math.h>
 #include <string.h>
 
@@ -86,6 +87,16 @@ V3 q_inv_rotate(Q q, V3 v) { // S_.rot.inverse() * v
     V3 uv = cross(qv, v);
     uv = uv + uv;
     return v + uv * c.w + cross(qv, uv);
+}
+V3 q_rotate(Q q, V3 v) { // Quaterniond * Vector3d (Eigen's _transformVector: v + 2 w (u x v) + 2 u x (u x v))
+    const V3 qv{q.x, q.y, q.z};
+    V3 uv = cross(qv, v);
+    uv = uv + uv;
+    return v + uv * q.w + cross(qv, uv);
+}
+Q q_inverse(Q q) { // Quaterniond::inverse(): conjugate / squaredNorm
+    const double n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+    return {q.w / n2, -q.x / n2, -q.y / n2, -q.z / n2};
 }
 V3 R_mul(const double R[9], V3 v) { return {R[0] * v.x + R[1] * v.y + R[2] * v.z, R[3] * v.x + R[4] * v.y + R[5] * v.z, R[6] * v.x + R[7] * v.y + R[8] * v.z}; }
 
@@ -189,6 +200,9 @@ struct elm_ekf {
     double ckf_prev_vel_local_x = 0.0, ckf_prev_time = 0.0;
     elm_ego_state prev_ego{};
     std::deque<elm_ego_state> deq_ekf_state; // ekfl.hpp:136
+    double prev_can_timestamp = 0.0;    // prev_can_ (memset to zero in the constructor, ekfa.cpp:17)
+    double can_yaw_rate_bias_rad = 0.0; // d_can_yaw_rate_bias_rad_ (ekfa.hpp:279)
+    bool vehicle_imu_calib_started = false;
 };
 
 static void ekf_init(elm_ekf* e) { // EkfAlgorithm::Init (ekfa.cpp:23-69)
@@ -207,6 +221,47 @@ static void ekf_init(elm_ekf* e) { // EkfAlgorithm::Init (ekfa.cpp:23-69)
     for (int i = S_IMU_ROLL; i <= S_IMU_YAW; ++i) e->P[i * N + i] = c.ekf_imu_bias_cov_gyro;
     e->reset_for_init_prediction = true;
     e->yaw_initialized = e->state_initialized = e->rotation_stabilized = e->state_stabilized = e->pcm_init_on_going = false;
+}
+
+// ZuptImu (ekfa.cpp:508-565): near standstill the velocity is pulled to zero and the IMU biases (and gravity) follow the raw readings
+static void zupt_imu(elm_ekf* e, V3 imu_gyro, V3 imu_acc) {
+    const double alpha = 0.01, gamma = 0.01, vel_thre = 0.1, gyro_thre = 0.1, acc_thre = 0.1;
+    const V3 vel_local = q_inv_rotate(e->rot, e->vel);
+    if (fabs(vel_local.x) > vel_thre) return;
+    const double vel_coeff = (vel_thre - fabs(vel_local.x)) / vel_thre * 0.1; // head<1>().norm()
+    const V3 vel_error = e->vel * -1.0;
+    e->vel = e->vel + vel_error * vel_coeff;
+    const double acc_xy = sqrt(e->acc.x * e->acc.x + e->acc.y * e->acc.y);
+    if (norm(e->gyro) > gyro_thre || acc_xy > acc_thre) return;
+    const V3 gyro_error = imu_gyro - e->bg;
+    e->bg = e->bg + gyro_error * gamma;
+    const V3 grav_local = q_inv_rotate(e->rot, e->grav);
+    const V3 acc_error_loc = imu_acc - (grav_local + e->ba);
+    const V3 acc_error_global = q_rotate(e->rot, imu_acc - e->ba) - e->grav; // with the bias BEFORE its correction
+    e->ba = e->ba + acc_error_loc * alpha;
+    if (e->cfg.imu_estimate_gravity) e->grav.z += alpha * acc_error_global.z;
+}
+
+static void kalman_update(elm_ekf* e, const int* idx, int m, const double* Rm, const double* Y);
+
+// CalibrateVehicleToImu (ekfa.cpp:703-776): above 3 m/s and with a stabilised attitude the direction of travel seen from the IMU
+// frame is an observation of the IMU mounting angles (pitch, yaw; roll is not observable and gets a zero innovation)
+static void calibrate_vehicle_to_imu(elm_ekf* e) {
+    const V3 vel = e->vel;
+    if (norm(vel) < 3.0) return;
+    if (!e->rotation_stabilized) return;
+    e->vehicle_imu_calib_started = true;
+    const Q rel = q_mul(e->rot, q_inverse(e->imu_rot));
+    const V3 vl = q_rotate(q_inverse(rel), vel);
+    const double n = norm(vl);
+    V3 dir = vl;
+    if (n * n > 0.0) dir = vl * (1.0 / n);
+    const double d_yaw = atan2(dir.y, dir.x), d_pitch = -asin(dir.z), d_roll = 0.0;
+    const double innovation[3] = {-d_roll, -d_pitch, -d_yaw};
+    const double r1 = pow(1.0 * M_PI / 180.0, 2); // the dynamic uncertainty the reference computes is overwritten by these
+    const double R3[9] = {r1, 0, 0, 0, r1, 0, 0, 0, r1};
+    const int idx[3] = {S_IMU_ROLL, S_IMU_PITCH, S_IMU_YAW};
+    kalman_update(e, idx, 3, R3, innovation);
 }
 
 static inline double Pd(const elm_ekf* e, int i) { return e->P[i * N + i]; }
@@ -303,11 +358,11 @@ extern "C" void elm_ekf_config_default(elm_ekf_config* c) { // config/localizati
     c->state_std_pos_m = 0.02; c->state_std_rot_deg = 0.2; c->state_std_vel_mps = 2.0; c->state_std_gyro_dps = 5.0; c->state_std_acc_mps = 100.0;
     c->imu_std_gyro_dps = 0.01; c->imu_std_acc_mps = 0.001; c->ekf_imu_bias_cov_gyro = 0.0001; c->ekf_imu_bias_cov_acc = 0.0001;
     c->gnss_min_cov_x_m = 0.2; c->gnss_min_cov_y_m = 0.2; c->gnss_min_cov_z_m = 0.7;
+    c->can_vel_scale_factor = 1.0; c->ekf_can_meas_uncertainty_vel_mps = 2.0; c->ekf_can_meas_uncertainty_yaw_rate_deg = 10.0;
 }
 
 extern "C" int elm_ekf_create(const elm_ekf_config* cfg, elm_ekf** out) {
     if (!cfg || !out) return ELM_ERR_INVALID;
-    if (cfg->use_zupt || cfg->imu_estimate_calibration) return ELM_ERR_UNSUPPORTED;
     elm_ekf* e = new elm_ekf();
     e->cfg = *cfg;
     ekf_init(e);
@@ -384,8 +439,94 @@ extern "C" int elm_ekf_predict_imu(elm_ekf* e, double t, const double gyro_in[3]
     for (int b = 0; b < 9; ++b)
         for (int r = 0; r < 3; ++r) e->P[(b * 3 + r) * N + (b * 3 + r)] += qd[b];
     e->prev_timestamp = t;
+    if (c.use_zupt) zupt_imu(e, ig, ia); // ekfa.cpp:311-313: ZUPT, complementary filter, mount calibration -- in this order
     if (use_ckf) complementary_filter(e, t, ia);
+    if (c.imu_estimate_calibration) calibrate_vehicle_to_imu(e);
     *predicted = 1;
+    return ELM_OK;
+}
+
+// RunPrediction (ekfa.cpp:81-165): the constant-velocity / constant-acceleration model the node runs from its timer when use_imu = 0
+extern "C" int elm_ekf_predict(elm_ekf* e, double t, int* predicted) {
+    if (!e || !predicted) return ELM_ERR_INVALID;
+    *predicted = 0;
+    const elm_ekf_config& c = e->cfg;
+    if (e->reset_for_init_prediction) { e->prev_timestamp = t; e->reset_for_init_prediction = false; return ELM_OK; }
+    if (e->pcm_init_on_going) { e->prev_timestamp = t; return ELM_OK; }
+    if (fabs(t - e->prev_timestamp) < 1e-6) return ELM_OK;
+    const double dt = t - e->prev_timestamp;
+    const V3 pvel = e->vel, pacc = e->acc, pgyro = e->gyro;
+    e->pos = e->pos + (pvel * dt + pacc * (0.5 * dt * dt));
+    e->rot = q_normalized(q_mul(e->rot, exp_gyro_to_quat(pgyro, dt)));
+    e->vel = e->vel + pacc * dt;
+    // P = F P F^T + Q, F = I + dt [pos|vel] + dt [rot|rate] + dt^2 / 2 [pos|acc] + dt [vel|acc]
+    static thread_local double F[N * N], FP[N * N];
+    for (int i = 0; i < N * N; ++i) F[i] = 0.0;
+    for (int i = 0; i < N; ++i) F[i * N + i] = 1.0;
+    for (int r = 0; r < 3; ++r) {
+        F[(S_X + r) * N + (S_VX + r)] = dt;
+        F[(S_ROLL + r) * N + (S_ROLL_RATE + r)] = dt;
+        F[(S_X + r) * N + (S_AX + r)] = 0.5 * dt * dt;
+        F[(S_VX + r) * N + (S_AX + r)] = dt;
+    }
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < N; ++k) s += F[i * N + k] * e->P[k * N + j];
+            FP[i * N + j] = s;
+        }
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < N; ++k) s += FP[i * N + k] * F[j * N + k];
+            e->P[i * N + j] = s;
+        }
+    const double d2 = dt * dt, rad = M_PI / 180.0;
+    // (the gyro term is the square of the deg/s figure as it stands: ekfa.cpp:137-138 does not convert it)
+    const double qd[5] = {pow(c.state_std_pos_m, 2) * d2, pow(c.state_std_rot_deg * rad, 2) * d2, pow(c.state_std_vel_mps, 2) * d2,
+                          pow(c.state_std_gyro_dps, 2) * d2, pow(c.state_std_acc_mps, 2) * d2};
+    for (int b = 0; b < 5; ++b)
+        for (int r = 0; r < 3; ++r) e->P[(b * 3 + r) * N + (b * 3 + r)] += qd[b];
+    e->prev_timestamp = t;
+    *predicted = 1;
+    return ELM_OK;
+}
+
+// RunCanUpdate + ZuptCan (ekfa.cpp:434-506, 567-587): wheel speed (vehicle frame) and yaw rate as a 4-row measurement of the global
+// velocity and the yaw rate; the node fills vel.x and gyro.z only (ekfl.cpp:127-137)
+extern "C" int elm_ekf_update_can(elm_ekf* e, double t, const double vel_in[3], const double gyro_in[3], int* updated) {
+    if (!e || !vel_in || !gyro_in || !updated) return ELM_ERR_INVALID;
+    *updated = 0;
+    const elm_ekf_config& c = e->cfg;
+    const double can_dt = t - e->prev_can_timestamp;
+    if (fabs(can_dt) < 0.01) return ELM_OK;
+    V3 uvel{vel_in[0], vel_in[1], vel_in[2]};
+    const double ugyro_z = gyro_in[2] - e->can_yaw_rate_bias_rad;
+    uvel.x *= c.can_vel_scale_factor;
+    const V3 vg = q_rotate(e->rot, uvel);
+    const double Y[4] = {vg.x - e->vel.x, vg.y - e->vel.y, vg.z - e->vel.z, ugyro_z - e->gyro.z};
+    double Rl[3] = {pow(c.ekf_can_meas_uncertainty_vel_mps, 2), pow(c.ekf_can_meas_uncertainty_vel_mps * 2, 2), pow(c.ekf_can_meas_uncertainty_vel_mps * 2, 2)};
+    double G[9], R4[16];
+    q_to_R(e->rot, G);
+    for (int i = 0; i < 16; ++i) R4[i] = 0.0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < 3; ++k) s += G[i * 3 + k] * Rl[k] * G[j * 3 + k]; // rot R_local rot^T
+            R4[i * 4 + j] = s;
+        }
+    R4[15] = pow(c.ekf_can_meas_uncertainty_yaw_rate_deg * M_PI / 180.0, 2);
+    const int idx[4] = {S_VX, S_VY, S_VZ, S_YAW_RATE};
+    kalman_update(e, idx, 4, R4, Y);
+    e->prev_can_timestamp = t;
+    // ZuptCan with the RAW input
+    const double vn = sqrt(vel_in[0] * vel_in[0] + vel_in[1] * vel_in[1] + vel_in[2] * vel_in[2]);
+    if (!(vn > 0.05)) {
+        const double a = 0.05;
+        e->can_yaw_rate_bias_rad = a * gyro_in[2] + (1.0 - a) * e->can_yaw_rate_bias_rad;
+        e->vel = e->vel * (1.0 - a);
+    }
+    *updated = 1;
     return ELM_OK;
 }
 

@@ -242,7 +242,9 @@ extern "C" int elm_load_ekf_config(const char* localization_ini, elm_ekf_config*
         {"ekf_imu_bias_cov_acc", &c->ekf_imu_bias_cov_acc}, {"ekf_gnss_min_cov_x_m", &c->gnss_min_cov_x_m},
         {"ekf_gnss_min_cov_y_m", &c->gnss_min_cov_y_m}, {"ekf_gnss_min_cov_z_m", &c->gnss_min_cov_z_m},
         {"ekf_gnss_min_cov_roll_deg", &c->gnss_min_cov_roll_deg}, {"ekf_gnss_min_cov_pitch_deg", &c->gnss_min_cov_pitch_deg},
-        {"ekf_gnss_min_cov_yaw_deg", &c->gnss_min_cov_yaw_deg}};
+        {"ekf_gnss_min_cov_yaw_deg", &c->gnss_min_cov_yaw_deg}, {"can_vel_scale_factor", &c->can_vel_scale_factor},
+        {"ekf_can_meas_uncertainty_vel_mps", &c->ekf_can_meas_uncertainty_vel_mps},
+        {"ekf_can_meas_uncertainty_yaw_rate_deg", &c->ekf_can_meas_uncertainty_yaw_rate_deg}};
     for (const auto& k : keys) elm_ini_get_double(ini, S, k.first, k.second);
     elm_ini_destroy(ini);
     return ELM_OK;

@@ -1,7 +1,8 @@
 """Host-side mirror of the reference's EkfAlgorithm / EkfLocalization pose-update interface.
 
 The filter itself is plain CPU C++ in libelimaloc_hip.so (csrc/elm_ekf.cpp) -- north_star keeps the EKF on the CPU.
-Names follow ekf_localization/include/ekf_algorithm.hpp:72-104 (RunPredictionImu, RunGnssUpdate, GetCurrentState) and
+Names follow ekf_localization/include/ekf_algorithm.hpp:72-104 (RunPredictionImu, RunPrediction, RunCanUpdate, RunGnssUpdate,
+GetCurrentState) and
 ekf_localization.cpp:147-220 (CallbackPcmOdom, CallbackPcmInitOdom).
 """
 import ctypes as C
@@ -55,6 +56,20 @@ class EkfAlgorithm:
         a = np.ascontiguousarray(acc, np.float64)
         out = C.c_int(0)
         _lib.check(_lib.lib().elm_ekf_predict_imu(self._h, float(timestamp), _dp(g), _dp(a), C.byref(out)))
+        return bool(out.value)
+
+    def RunPrediction(self, timestamp):
+        """ekfa.cpp:81-165: the constant-velocity model (the node's timer path when use_imu = 0)."""
+        out = C.c_int(0)
+        _lib.check(_lib.lib().elm_ekf_predict(self._h, float(timestamp), C.byref(out)))
+        return bool(out.value)
+
+    def RunCanUpdate(self, timestamp, vel, gyro):
+        """ekfa.cpp:434-506 (+ ZuptCan): vehicle-frame velocity and angular rate of the CAN message."""
+        v = np.ascontiguousarray(vel, np.float64)
+        g = np.ascontiguousarray(gyro, np.float64)
+        out = C.c_int(0)
+        _lib.check(_lib.lib().elm_ekf_update_can(self._h, float(timestamp), _dp(v), _dp(g), C.byref(out)))
         return bool(out.value)
 
     def RunGnssUpdate(self, timestamp, pos, quat_xyzw, pos_cov, rot_cov, source=GnssSource.PCM):

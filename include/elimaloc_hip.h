@@ -296,6 +296,7 @@ typedef struct elm_ekf_config { /* [ekf_localization] keys of config/localizatio
     double state_std_pos_m, state_std_rot_deg, state_std_vel_mps, state_std_gyro_dps, state_std_acc_mps;
     double imu_std_gyro_dps, imu_std_acc_mps, ekf_imu_bias_cov_gyro, ekf_imu_bias_cov_acc;
     double gnss_min_cov_x_m, gnss_min_cov_y_m, gnss_min_cov_z_m, gnss_min_cov_roll_deg, gnss_min_cov_pitch_deg, gnss_min_cov_yaw_deg;
+    double can_vel_scale_factor, ekf_can_meas_uncertainty_vel_mps, ekf_can_meas_uncertainty_yaw_rate_deg; /* RunCanUpdate */
 } elm_ekf_config;
 typedef struct elm_ekf_state { /* EkfState (ls.hpp) + covariance, state order of ekf_algorithm.hpp:41-69 */
     double x[27];            /* rotation slots (3..5, 24..26) are 0: the attitude lives in the quaternions */
@@ -313,6 +314,10 @@ int elm_ekf_create(const elm_ekf_config* cfg, elm_ekf** out);
 void elm_ekf_destroy(elm_ekf* ekf);
 /* RunPredictionImu (ekfa.cpp:167-316): gyro / acc already rotated into the ego frame (ImuStructConverter) */
 int elm_ekf_predict_imu(elm_ekf* ekf, double timestamp, const double gyro[3], const double acc[3], int* predicted);
+/* RunPrediction (ekfa.cpp:81-165): the constant-velocity model of use_imu = 0 (ekfl.cpp:204-216) */
+int elm_ekf_predict(elm_ekf* ekf, double timestamp, int* predicted);
+/* RunCanUpdate + ZuptCan (ekfa.cpp:434-506, 567-587): vehicle-frame velocity and angular rate (the node fills vel[0], gyro[2]) */
+int elm_ekf_update_can(elm_ekf* ekf, double timestamp, const double vel[3], const double gyro[3], int* updated);
 /* RunGnssUpdate (ekfa.cpp:318-432): pos_cov / rot_cov row-major 3x3 */
 int elm_ekf_update_pose(elm_ekf* ekf, double timestamp, const double pos[3], const double quat_xyzw[4], const double pos_cov[9],
                         const double rot_cov[9], int source, int* updated);

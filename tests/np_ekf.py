@@ -130,6 +130,8 @@ class NpEkf:
         self.ckf = None
         self.prev_ego = dict(timestamp=0.0)
         self.deq = []
+        self.prev_can_t = 0.0
+        self.can_bias = 0.0
 
     # -- flags
     def _sd(self, i):
@@ -227,8 +229,90 @@ class NpEkf:
             F[S_AX + 2, S_G + 2] = -1.0
         self.P = F @ self.P @ F.T + Q
         self.prev_t = t
+        if c["use_zupt"]:
+            self._zupt_imu(gyro_in, acc_in)
         if use_ckf:
             self._ckf(t, acc_in)
+        if c["imu_estimate_calibration"]:
+            self._calibrate()
+        return True
+
+    # -- side modes (off in the shipped localization.ini)
+    def _zupt_imu(self, gyro_in, acc_in):  # ekf_algorithm.cpp:508-565
+        Rw = quat_R(self.rot / np.linalg.norm(self.rot))
+        vl = Rw.T @ self.vel
+        if abs(vl[0]) > 0.1:
+            return
+        self.vel = self.vel + (0.1 - abs(vl[0])) / 0.1 * 0.1 * (-self.vel)
+        if np.linalg.norm(self.gyro) > 0.1 or np.linalg.norm(self.acc[:2]) > 0.1:
+            return
+        ba0 = self.ba.copy()
+        self.bg = self.bg + 0.01 * (gyro_in - self.bg)
+        self.ba = ba0 + 0.01 * (acc_in - (Rw.T @ self.grav + ba0))
+        if self.c["imu_estimate_gravity"]:
+            self.grav = self.grav + np.array([0, 0, 0.01 * (Rw @ (acc_in - ba0) - self.grav)[2]])
+
+    def _calibrate(self):  # ekf_algorithm.cpp:703-776
+        if np.linalg.norm(self.vel) < 3.0 or not self.rot_stab:
+            return
+        Rrel = quat_R(self.rot / np.linalg.norm(self.rot)) @ quat_R(self.imu_rot / np.linalg.norm(self.imu_rot)).T
+        d = Rrel.T @ self.vel
+        d = d / np.linalg.norm(d)
+        inn = np.array([0.0, math.asin(d[2]), -math.atan2(d[1], d[0])])
+        H = np.zeros((3, N))
+        H[0, S_IMU] = H[1, S_IMU + 1] = H[2, S_IMU + 2] = 1.0
+        self._update(H, np.eye(3) * DEG**2, inn)
+
+    def predict(self, t):  # RunPrediction, ekf_algorithm.cpp:81-165
+        c = self.c
+        if self.reset:
+            self.prev_t, self.reset = t, False
+            return False
+        if self.pcm_init:
+            self.prev_t = t
+            return False
+        if abs(t - self.prev_t) < 1e-6:
+            return False
+        dt = t - self.prev_t
+        v0, a0, g0 = self.vel.copy(), self.acc.copy(), self.gyro.copy()
+        self.pos = self.pos + v0 * dt + 0.5 * a0 * dt * dt
+        q = quat_mul(self.rot, R_quat(so3_exp(g0 * dt)))
+        self.rot = q / np.linalg.norm(q)
+        self.vel = v0 + a0 * dt
+        Q = np.zeros((N, N))
+        for s0, sd in ((S_X, c["state_std_pos_m"]), (S_ROLL, c["state_std_rot_deg"] * DEG), (S_VX, c["state_std_vel_mps"]),
+                       (S_RR, c["state_std_gyro_dps"]), (S_AX, c["state_std_acc_mps"])):
+            Q[s0:s0 + 3, s0:s0 + 3] = np.eye(3) * sd**2 * dt * dt
+        F = np.eye(N)
+        F[S_X:S_X + 3, S_VX:S_VX + 3] = np.eye(3) * dt
+        F[S_ROLL:S_ROLL + 3, S_RR:S_RR + 3] = np.eye(3) * dt
+        F[S_X:S_X + 3, S_AX:S_AX + 3] = np.eye(3) * 0.5 * dt * dt
+        F[S_VX:S_VX + 3, S_AX:S_AX + 3] = np.eye(3) * dt
+        self.P = F @ self.P @ F.T + Q
+        self.prev_t = t
+        return True
+
+    def update_can(self, t, vel, gyro):  # RunCanUpdate + ZuptCan, ekf_algorithm.cpp:434-506, 567-587
+        c = self.c
+        vel, gyro = np.asarray(vel, float), np.asarray(gyro, float)
+        if abs(t - self.prev_can_t) < 0.01:
+            return False
+        v = vel.copy()
+        v[0] *= c["can_vel_scale_factor"]
+        Rw = quat_R(self.rot)
+        H = np.zeros((4, N))
+        H[0, S_VX] = H[1, S_VX + 1] = H[2, S_VX + 2] = H[3, S_RR + 2] = 1.0
+        z = np.concatenate([Rw @ v, [gyro[2] - self.can_bias]])
+        zs = np.concatenate([self.vel, [self.gyro[2]]])
+        s = c["ekf_can_meas_uncertainty_vel_mps"]
+        R = np.zeros((4, 4))
+        R[:3, :3] = Rw @ np.diag([s**2, (2 * s) ** 2, (2 * s) ** 2]) @ Rw.T
+        R[3, 3] = (c["ekf_can_meas_uncertainty_yaw_rate_deg"] * DEG) ** 2
+        self._update(H, R, z - zs)
+        self.prev_can_t = t
+        if not np.linalg.norm(vel) > 0.05:
+            self.can_bias = 0.05 * gyro[2] + 0.95 * self.can_bias
+            self.vel = 0.95 * self.vel
         return True
 
     def update_pose(self, t, pos, quat_xyzw, pos_cov, rot_cov, source):

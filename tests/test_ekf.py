@@ -167,8 +167,81 @@ def test_time_compensation_rejects_old_and_empty():
     assert e.CallbackPcmOdom(9.0, [0, 0, 0], [0, 0, 0, 1], cov) is False  # older than the whole history
 
 
-def test_unsupported_modes_fail_loudly():
-    with pytest.raises(_lib.ElmError):
-        EkfAlgorithm(EkfConfig(use_zupt=1))
-    with pytest.raises(_lib.ElmError):
-        EkfAlgorithm(EkfConfig(imu_estimate_calibration=1))
+def test_constant_velocity_prediction_and_can_updates():
+    """use_imu = 0 / use_can = 1 (ekf_algorithm.cpp:81-165, 434-506, 567-587): timer-driven CV prediction, CAN speed + yaw rate updates
+    (scale factor, rotated measurement covariance, yaw-rate bias learnt at standstill by ZuptCan), PCM pose updates in between."""
+    rng = np.random.default_rng(11)
+    cfg = EkfConfig(can_vel_scale_factor=1.02, ekf_can_meas_uncertainty_vel_mps=0.5, ekf_can_meas_uncertainty_yaw_rate_deg=2.0)
+    e, r = EkfAlgorithm(cfg), np_ekf.NpEkf(cfg_dict(cfg))
+    t0, n_can_zupt = 50.0, 0
+    q0 = euler_quat_xyzw(0.01, -0.02, 0.7)
+    assert e.RunPrediction(t0) is False and r.predict(t0) is False  # the first call only latches the time
+    assert e.CallbackPcmInitOdom(t0, [5, 6, 0.3], q0) and r.update_pcm_odom(t0, [5, 6, 0.3], q0, np.eye(6) * 1e-9, np_ekf.PCM_INIT)
+    assert e.RunPrediction(t0 + 0.01) is False and r.predict(t0 + 0.01) is False  # PCM initialisation on going
+    pos = np.array([5.0, 6.0, 0.3])
+    for k in range(1, 1500):
+        t = t0 + 0.01 * k
+        speed = 0.0 if k > 1100 else 6.0  # the vehicle stops at the end: ZuptCan
+        yaw = 0.7 + 0.1 * math.sin(0.01 * k)
+        pos = pos + 0.01 * speed * np.array([math.cos(yaw), math.sin(yaw), 0.0])
+        if k % 10 == 0:
+            q = euler_quat_xyzw(0.01, -0.02, yaw)
+            cov = np.diag([4e-4, 4e-4, 4e-4, 1e-6, 1e-6, 1e-6])
+            mp = pos + rng.normal(0, 0.01, 3)
+            assert e.RunGnssUpdate(t, mp, q, cov[:3, :3], cov[3:, 3:], GnssSource.PCM) == r.update_pose(t, mp, q, cov[:3, :3], cov[3:, 3:], np_ekf.PCM)
+        a, b = e.RunPrediction(t), r.predict(t)
+        assert a == b
+        if k % 2 == 0:
+            vel = [speed + rng.normal(0, 0.02) if speed else 0.0, 0.0, 0.0]
+            gyro = [0.0, 0.0, 0.1 * 0.01 * math.cos(0.01 * k) / 0.01 + 0.004]  # a constant yaw-rate bias of 4 mrad/s
+            a, b = e.RunCanUpdate(t, vel, gyro), r.update_can(t, vel, gyro)
+            assert a == b and a
+            t_can = t
+            n_can_zupt += speed == 0.0
+        if k % 5 == 0 or k < 40:
+            compare(e, r)
+        ego, ego_r = e.GetCurrentState(), r.publish()
+        for key, v in ego_r.items():
+            assert abs(ego[key] - v) <= 1e-9 * max(1.0, abs(v)), (key, ego[key], v)
+    compare(e, r)
+    assert n_can_zupt > 100 and abs(r.can_bias) > 1e-4  # the bias estimator ran
+    assert e.RunCanUpdate(t_can + 0.005, [0, 0, 0], [0, 0, 0]) is False and r.update_can(t_can + 0.005, [0, 0, 0], [0, 0, 0]) is False  # closer than 10 ms to the previous message: ignored
+    s = e.State()
+    assert np.linalg.norm(s["x"][6:9]) < 0.2  # standstill (6 m/s before)
+
+
+def test_zupt_and_mount_calibration_modes():
+    """use_zupt = 1 and imu_estimate_calibration = 1 (ekf_algorithm.cpp:508-565, 703-776) on the simulated drive, then parked."""
+    rng = np.random.default_rng(5)
+    cfg = EkfConfig(use_zupt=1, imu_estimate_calibration=1)
+    e, r = EkfAlgorithm(cfg), np_ekf.NpEkf(cfg_dict(cfg))
+    dt, t0 = 0.005, 10.0
+    pos = np.array([0.0, 0.0, 0.2])
+    imu_bias_g, imu_bias_a = np.array([2e-3, -1e-3, 3e-3]), np.array([0.02, -0.03, 0.01])
+    calibrated = zupted = 0
+    for k in range(6000):
+        t = t0 + k * dt
+        speed = 8.0 if k < 3600 else 0.0
+        yaw = 0.2 * math.sin(0.002 * k) if k < 3600 else 0.2 * math.sin(7.2)
+        q = euler_quat_xyzw(0.0, 0.0, yaw)
+        Rw = np_ekf.quat_R(np.array([q[3], q[0], q[1], q[2]]))
+        pos = pos + Rw @ np.array([speed, 0, 0]) * dt
+        yaw_rate = 0.2 * 0.002 * math.cos(0.002 * k) / dt if k < 3600 else 0.0
+        gyro = np.array([0, 0, yaw_rate]) + imu_bias_g + rng.normal(0, 1e-4, 3)
+        acc = Rw.T @ np.array([0, 0, 9.81]) + np.array([0, speed * yaw_rate, 0]) + imu_bias_a + rng.normal(0, 1e-3, 3)
+        if k == 2:
+            assert e.CallbackPcmInitOdom(t, pos, q) and r.update_pcm_odom(t, pos, q, np.eye(6) * 1e-9, np_ekf.PCM_INIT)
+        imu_rot_before, bg_before = r.imu_rot.copy(), r.bg.copy()
+        a, b = e.RunPredictionImu(t, gyro, acc), r.predict_imu(t, gyro, acc)
+        assert a == b
+        calibrated += bool(np.any(r.imu_rot != imu_rot_before))
+        zupted += bool(b and k >= 3600 and np.any(r.bg != bg_before))
+        e.GetCurrentState(); r.publish()
+        if k > 2 and k % 20 == 0:
+            cov = np.diag([1e-4, 1e-4, 1e-4, 1e-6, 1e-6, 1e-6])
+            mp = pos + rng.normal(0, 0.005, 3)
+            assert e.RunGnssUpdate(t, mp, q, cov[:3, :3], cov[3:, 3:], GnssSource.PCM) == r.update_pose(t, mp, q, cov[:3, :3], cov[3:, 3:], np_ekf.PCM)
+        if k % 11 == 0:
+            compare(e, r)
+    compare(e, r)
+    assert calibrated > 500 and zupted > 500  # both modes were live, not just enabled
