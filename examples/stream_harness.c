@@ -2,11 +2,16 @@
  * pcm_matching's CallbackPointCloud (one call: filter, deskew, pose sync, downsample, VGICP on the GPU) feeding the CPU EKF's
  * PCM update, whose IMU-rate odometry deskews and seeds the next scan.  A parked vehicle: 2 s of 200 Hz IMU, 10 Hz LiDAR.
  *   gcc -std=c11 -Iinclude examples/stream_harness.c -Lelimaloc_amd -lelimaloc_hip -lm -Wl,-rpath,$PWD/elimaloc_amd -o stream_harness
- * Optional arguments: localization.ini calibration.ini (the reference's own files).  Needs an MI355X to run. */
+ * Optional arguments: localization.ini calibration.ini (the reference's own files).  Needs an MI355X to run.
+ * Sizes from the environment (defaults: a 90 000-point map, 20 000-point scans, 19 scans): ELM_HARNESS_GRID (ground lattice edge:
+ * 3000 -> a 9 M-point map), ELM_HARNESS_SCAN (raw points per LiDAR message), ELM_HARNESS_SCANS.  Prints the wall time of the
+ * per-scan work (callback + EKF update) -- the config-5 latency as a C caller sees it. */
+#define _POSIX_C_SOURCE 199309L
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "elimaloc_hip.h"
 
@@ -18,6 +23,17 @@
             return 2;                                                                  \
         }                                                                              \
     } while (0)
+
+static double now_ms(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+static int env_int(const char* name, int def) {
+    const char* v = getenv(name);
+    return (v && atoi(v) > 0) ? atoi(v) : def;
+}
+static int cmp_double(const void* a, const void* b) { return (*(const double*)a > *(const double*)b) - (*(const double*)a < *(const double*)b); }
 
 static float frand(unsigned* s) { /* xorshift, uniform in [-1, 1) */
     *s ^= *s << 13; *s ^= *s >> 17; *s ^= *s << 5;
@@ -40,7 +56,7 @@ int main(int argc, char** argv) {
     }
     /* map: a jittered ground lattice + one wall (float32, file order) */
     unsigned seed = 12345u;
-    const int G = 300;
+    const int G = env_int("ELM_HARNESS_GRID", 300);
     size_t n_map = 0;
     float* map_xyz = (float*)malloc(sizeof(float) * 3 * ((size_t)G * G + (size_t)G * 30));
     for (int i = 0; i < G; ++i)
@@ -68,15 +84,17 @@ int main(int argc, char** argv) {
     const double yaw = 0.3, ego[3] = {1.5, -2.0, 0.3};
     const double q0[4] = {0.0, 0.0, sin(yaw / 2), cos(yaw / 2)};
     const double cr = cos(yaw), sr = sin(yaw);
-    enum { MAX_ODOM = 4096, N_SCAN = 20000 };
+    enum { MAX_ODOM = 4096 };
+    const int N_SCAN = env_int("ELM_HARNESS_SCAN", 20000), N_MSG = env_int("ELM_HARNESS_SCANS", 19);
     static double imu4[MAX_ODOM * 4], odom14[MAX_ODOM * 14];
+    double* scan_ms = (double*)malloc(sizeof(double) * (size_t)(N_MSG + 1));
     size_t n_imu = 0, n_odom = 0;
     float* scan = (float*)malloc(sizeof(float) * 3 * N_SCAN);
     float* ptime = (float*)malloc(sizeof(float) * N_SCAN);
     int updated = 0, predicted = 0, published = 0, n_pub = 0;
     const double t0 = 100.0, gyro[3] = {0, 0, 0}, acc[3] = {0, 0, 9.81};
     elm_pcm_scan_output out;
-    for (int k = 0; k <= 400; ++k) {
+    for (int k = 0; k <= 20 * (N_MSG + 1); ++k) {
         const double t = t0 + k / 200.0;
         if (k == 2) CHECK(elm_ekf_update_pcm_odom(ekf, t, ego, q0, (double[36]){0}, ELM_GNSS_PCM_INIT, &updated)); /* init pose */
         CHECK(elm_ekf_predict_imu(ekf, t, gyro, acc, &predicted));
@@ -103,6 +121,7 @@ int main(int argc, char** argv) {
                 ptime[i] = (float)(-0.1 + 0.1 * (i + 0.5) / N_SCAN);
             }
             ptime[N_SCAN - 1] = 0.f;
+            const double t_begin = now_ms();
             CHECK(elm_pcm_callback_point_cloud(ctx, map, &node, &reg, scan, ptime, N_SCAN, t - 0.005 + node.lidar_time_delay, imu4, n_imu,
                                                odom14, n_odom, &out, &published));
             if (published) {
@@ -111,16 +130,25 @@ int main(int argc, char** argv) {
                 const double pyaw = atan2(out.pose_ego[1], out.pose_ego[0]);
                 const double pos[3] = {out.pose_ego[12], out.pose_ego[13], out.pose_ego[14]}, q[4] = {0, 0, sin(pyaw / 2), cos(pyaw / 2)};
                 CHECK(elm_ekf_update_pcm_odom(ekf, out.time_scan_end, pos, q, out.covariance, ELM_GNSS_PCM, &updated));
+                if (n_pub <= N_MSG) scan_ms[n_pub - 1] = now_ms() - t_begin;
             }
         }
     }
     elm_ekf_state st;
     CHECK(elm_ekf_get_state(ekf, &st));
     const double err = sqrt((st.x[0] - ego[0]) * (st.x[0] - ego[0]) + (st.x[1] - ego[1]) * (st.x[1] - ego[1]));
-    printf("scans published %d/19  ekf xy error %.4f m  iterations(last) %d  fitness %.4f\n", n_pub, err, out.result.iterations, out.fitness_score);
+    printf("scans published %d/%d  ekf xy error %.4f m  iterations(last) %d  fitness %.4f\n", n_pub, N_MSG, err, out.result.iterations, out.fitness_score);
+    if (n_pub > 4) { /* the first scans carry one-time allocations: steady state = everything after the third */
+        const int n = n_pub - 3;
+        double sum = 0.0;
+        for (int i = 0; i < n; ++i) sum += scan_ms[3 + i];
+        qsort(scan_ms + 3, (size_t)n, sizeof(double), cmp_double);
+        printf("per scan (callback + EKF update, %zu-point map, %d raw points, %zu after the node's filters): mean %.3f ms  median %.3f ms  max %.3f ms  (n = %d)\n",
+               n_map, N_SCAN, (size_t)out.n_source, sum / n, scan_ms[3 + n / 2], scan_ms[3 + n - 1], n);
+    }
     elm_ekf_destroy(ekf);
     elm_map_destroy(map);
     elm_ctx_destroy(ctx);
-    free(map_xyz); free(scan); free(ptime);
-    return (n_pub >= 15 && err < 0.05) ? 0 : 1;
+    free(map_xyz); free(scan); free(ptime); free(scan_ms);
+    return (n_pub >= N_MSG - 4 && err < 0.05) ? 0 : 1;
 }
