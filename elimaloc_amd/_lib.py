@@ -133,7 +133,7 @@ EXPORTS = [
     "elm_register_batch_finish", "elm_deskew", "elm_deskew_downsample", "elm_deskew_prepare", "elm_comm_get_unique_id", "elm_comm_init",
     "elm_comm_destroy", "elm_comm_set_hook", "elm_filter_points_by_distance", "elm_voxel_downsample",
     "elm_get_interpolated_pose", "elm_shape_odom_covariance",
-    "elm_ekf_config_default", "elm_ekf_create", "elm_ekf_destroy", "elm_ekf_predict_imu", "elm_ekf_predict", "elm_ekf_update_can",
+    "elm_ekf_config_default", "elm_ekf_create", "elm_ekf_destroy", "elm_ekf_predict_imu", "elm_ekf_predict", "elm_ekf_update_can", "elm_gps_project", "elm_ekf_update_navsatfix",
     "elm_ekf_update_pose", "elm_ekf_update_pcm_odom", "elm_ekf_get_state", "elm_ekf_publish",
     "elm_ini_load", "elm_ini_destroy", "elm_ini_get_string", "elm_ini_get_int", "elm_ini_get_bool", "elm_ini_get_double",
     "elm_ini_get_array", "elm_pcm_node_config_default", "elm_load_pcm_config", "elm_load_ekf_config", "elm_pcd_load_xyz",
@@ -264,6 +264,8 @@ def lib():
     L.elm_ekf_predict_imu.argtypes = [vp, C.c_double, dp, dp, ip]
     L.elm_ekf_predict.argtypes = [vp, C.c_double, ip]
     L.elm_ekf_update_can.argtypes = [vp, C.c_double, dp, dp, ip]
+    L.elm_gps_project.argtypes = [C.c_double] * 6 + [dp]
+    L.elm_ekf_update_navsatfix.argtypes = [vp] + [C.c_double] * 4 + [dp] + [C.c_double] * 3 + [C.c_int, C.c_double, dp, ip]
     L.elm_ekf_update_pose.argtypes = [vp, C.c_double, dp, dp, dp, dp, C.c_int, ip]
     L.elm_ekf_update_pcm_odom.argtypes = [vp, C.c_double, dp, dp, dp, C.c_int, ip]
     L.elm_ekf_get_state.argtypes = [vp, C.POINTER(EkfStateC)]

@@ -7,7 +7,8 @@
 // localization_functions.hpp (RotToVec :312-333, CalEulerResidualFromQuat :354-370, Exp :412-419, ExpGyroToQuat :439-443,
 // PartialDerivativeRotWrtGyro :466-483, ConvertGlobalToLocalVelocity :491-513).  The side modes that the shipped localization.ini
 // leaves off are here too: RunPrediction (the constant-velocity model of use_imu = 0, ekfa.cpp:81-165), RunCanUpdate + ZuptCan
-// (:434-506, :567-587), ZuptImu (:508-565) and CalibrateVehicleToImu (:703-776).
+// (:434-506, :567-587), ZuptImu (:508-565) and CalibrateVehicleToImu (:703-776); and the node's NavSatFix front end (ekfl.cpp:92-125,
+// 643-648) with GeographicLib's LocalCartesian::Forward restated from its published formulas (WGS84 geodetic -> ECEF -> east-north-up).
 #include <math.h>
 #include <string.h>
 
@@ -580,6 +581,50 @@ extern "C" int elm_ekf_update_pose(elm_ekf* e, double t, const double pos[3], co
     e->prev_gnss_timestamp = t;
     *updated = 1;
     return ELM_OK;
+}
+
+// GeographicLib::LocalCartesian(lat0, lon0, h0).Forward(lat, lon, h) (GeographicLib 1.5x, LocalCartesian.cpp / Geocentric.cpp; the
+// library is an external dependency of the reference -- ekfl.cpp:643-648 -- and absent here): geodetic -> earth-centred (WGS84:
+// a = 6378137 m, f = 1 / 298.257223563), then the rotation to the east / north / up axes at the origin.
+static void geocentric(double lat_deg, double lon_deg, double h, double X[3], double M[9]) {
+    const double a = 6378137.0, f = 1.0 / 298.257223563, e2 = f * (2.0 - f), e2m = (1.0 - f) * (1.0 - f);
+    const double phi = lat_deg * M_PI / 180.0, lam = lon_deg * M_PI / 180.0;
+    const double sphi = sin(phi), cphi = cos(phi), slam = sin(lam), clam = cos(lam);
+    const double n = a / sqrt(1.0 - e2 * sphi * sphi);
+    const double Z = (e2m * n + h) * sphi, R = (n + h) * cphi;
+    X[0] = R * clam; X[1] = R * slam; X[2] = Z;
+    if (M) { // rows of M^T: east, north, up expressed in the earth-centred frame
+        M[0] = -slam;        M[1] = clam;         M[2] = 0.0;
+        M[3] = -clam * sphi; M[4] = -slam * sphi; M[5] = cphi;
+        M[6] = clam * cphi;  M[7] = slam * cphi;  M[8] = sphi;
+    }
+}
+extern "C" int elm_gps_project(double ref_lat_deg, double ref_lon_deg, double ref_alt_m, double lat_deg, double lon_deg, double alt_m, double xyz[3]) {
+    if (!xyz) return ELM_ERR_INVALID;
+    double X0[3], X[3], M[9];
+    geocentric(ref_lat_deg, ref_lon_deg, ref_alt_m, X0, M);
+    geocentric(lat_deg, lon_deg, alt_m, X, nullptr);
+    const double d[3] = {X[0] - X0[0], X[1] - X0[1], X[2] - X0[2]};
+    for (int i = 0; i < 3; ++i) xyz[i] = (M[i * 3] * d[0] + M[i * 3 + 1] * d[1]) + M[i * 3 + 2] * d[2];
+    return ELM_OK;
+}
+// EkfLocalization::CallbackNavsatFix (ekfl.cpp:92-125): projection, the squared standard deviations of the message's covariance
+// diagonal (the node squares them: :104-106), the use_gps switch and the uncertainty gate, then RunGnssUpdate with the NAVSATFIX source
+// (position rows only).  pos_out (optional) = the projected position (what the node's GPS marker / odometry shows).
+extern "C" int elm_ekf_update_navsatfix(elm_ekf* e, double stamp, double lat_deg, double lon_deg, double alt_m, const double position_covariance[9],
+                                        double ref_lat_deg, double ref_lon_deg, double ref_alt_m, int use_gps, double gnss_uncertainty_max_m,
+                                        double pos_out[3], int* updated) {
+    if (!e || !position_covariance || !updated) return ELM_ERR_INVALID;
+    *updated = 0;
+    double pos[3];
+    elm_gps_project(ref_lat_deg, ref_lon_deg, ref_alt_m, lat_deg, lon_deg, alt_m, pos);
+    if (pos_out) memcpy(pos_out, pos, sizeof(pos));
+    double pc[9] = {0}, rc[9] = {0};
+    pc[0] = pow(position_covariance[0], 2); pc[4] = pow(position_covariance[4], 2); pc[8] = pow(position_covariance[8], 2);
+    if (!use_gps) return ELM_OK;
+    if (pc[0] > gnss_uncertainty_max_m || pc[4] > gnss_uncertainty_max_m) return ELM_OK;
+    const double qi[4] = {0.0, 0.0, 0.0, 1.0}; // NavSatFix carries no attitude: identity, zero covariance
+    return elm_ekf_update_pose(e, stamp, pos, qi, pc, rc, ELM_GNSS_NAVSATFIX, updated);
 }
 
 extern "C" int elm_ekf_get_state(elm_ekf* e, elm_ekf_state* out) {

@@ -40,6 +40,13 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+def ProjectGpsPoint(ref_lla, lat, lon, alt):
+    """ekfl.cpp:643-648: east / north / up metres of (lat, lon, alt) at the reference (lat, lon, alt), WGS84."""
+    out = np.empty(3)
+    _lib.check(_lib.lib().elm_gps_project(float(ref_lla[0]), float(ref_lla[1]), float(ref_lla[2]), float(lat), float(lon), float(alt), _dp(out)))
+    return out
+
+
 class EkfAlgorithm:
     def __init__(self, cfg=None):
         self.cfg = cfg or EkfConfig()
@@ -71,6 +78,16 @@ class EkfAlgorithm:
         out = C.c_int(0)
         _lib.check(_lib.lib().elm_ekf_update_can(self._h, float(timestamp), _dp(v), _dp(g), C.byref(out)))
         return bool(out.value)
+
+    def CallbackNavsatFix(self, stamp, lat, lon, alt, position_covariance, ref_lla, use_gps=True, gnss_uncertainty_max_m=1.0):
+        """ekfl.cpp:92-125.  Returns (updated, projected position)."""
+        pc = np.ascontiguousarray(position_covariance, np.float64).reshape(9)
+        pos = np.empty(3)
+        out = C.c_int(0)
+        _lib.check(_lib.lib().elm_ekf_update_navsatfix(self._h, float(stamp), float(lat), float(lon), float(alt), _dp(pc), float(ref_lla[0]),
+                                                       float(ref_lla[1]), float(ref_lla[2]), int(bool(use_gps)), float(gnss_uncertainty_max_m),
+                                                       _dp(pos), C.byref(out)))
+        return bool(out.value), pos
 
     def RunGnssUpdate(self, timestamp, pos, quat_xyzw, pos_cov, rot_cov, source=GnssSource.PCM):
         p = np.ascontiguousarray(pos, np.float64)

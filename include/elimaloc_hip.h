@@ -325,6 +325,13 @@ int elm_ekf_update_pose(elm_ekf* ekf, double timestamp, const double pos[3], con
  * against the published state history (GnssTimeCompensation ekfl.cpp:323-394) */
 int elm_ekf_update_pcm_odom(elm_ekf* ekf, double stamp, const double pos[3], const double quat_xyzw[4],
                             const double covariance36[36], int source, int* updated);
+/* GeographicLib::LocalCartesian(ref).Forward (ekfl.cpp:643-648): WGS84 geodetic -> east / north / up metres at the reference point */
+int elm_gps_project(double ref_lat_deg, double ref_lon_deg, double ref_alt_m, double lat_deg, double lon_deg, double alt_m, double xyz[3]);
+/* CallbackNavsatFix (ekfl.cpp:92-125): position_covariance = the message's row-major 3x3 (its diagonal holds standard deviations, which
+ * the node squares); use_gps / gnss_uncertainty_max_m = the [ekf_localization] keys use_gps / gnss_uncertainy_max_m */
+int elm_ekf_update_navsatfix(elm_ekf* ekf, double stamp, double lat_deg, double lon_deg, double alt_m, const double position_covariance[9],
+                             double ref_lat_deg, double ref_lon_deg, double ref_alt_m, int use_gps, double gnss_uncertainty_max_m,
+                             double pos_out[3], int* updated);
 int elm_ekf_get_state(elm_ekf* ekf, elm_ekf_state* out);
 /* GetCurrentState + the state-history upkeep of PublishInThread (ekfl.cpp:397-410); call after every prediction */
 int elm_ekf_publish(elm_ekf* ekf, elm_ego_state* out);

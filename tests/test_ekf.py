@@ -245,3 +245,50 @@ def test_zupt_and_mount_calibration_modes():
             compare(e, r)
     compare(e, r)
     assert calibrated > 500 and zupted > 500  # both modes were live, not just enabled
+
+
+def _np_enu(ref, lat, lon, h):
+    """Independent statement of the geodetic -> local tangent plane conversion (textbook form with e^2 and the prime-vertical radius,
+    rotation written as R_x(90 deg - lat0) R_z(90 deg + lon0))."""
+    a, f = 6378137.0, 1.0 / 298.257223563
+    e2 = 2 * f - f * f
+
+    def ecef(la, lo, hh):
+        la, lo = math.radians(la), math.radians(lo)
+        N = a / math.sqrt(1 - e2 * math.sin(la) ** 2)
+        return np.array([(N + hh) * math.cos(la) * math.cos(lo), (N + hh) * math.cos(la) * math.sin(lo), (N * (1 - e2) + hh) * math.sin(la)])
+    la0, lo0 = math.radians(ref[0]), math.radians(ref[1])
+    Rz = np.array([[-math.sin(lo0), math.cos(lo0), 0], [-math.cos(lo0), -math.sin(lo0), 0], [0, 0, 1]])
+    Rx = np.array([[1, 0, 0], [0, math.sin(la0), math.cos(la0)], [0, -math.cos(la0), math.sin(la0)]])
+    return Rx @ Rz @ (ecef(lat, lon, h) - ecef(*ref))
+
+
+def test_gps_projection_and_navsatfix_front_end():
+    """ProjectGpsPoint = GeographicLib LocalCartesian.Forward (ekf_localization.cpp:643-648) and CallbackNavsatFix (:92-125)."""
+    from elimaloc_amd.ekf import ProjectGpsPoint
+    ref = (37.5407, 127.0793, 35.0)
+    np.testing.assert_allclose(ProjectGpsPoint(ref, *ref), 0.0, atol=1e-9)
+    np.testing.assert_allclose(ProjectGpsPoint(ref, ref[0], ref[1], ref[2] + 12.5), [0, 0, 12.5], atol=1e-9)
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        lat, lon, h = ref[0] + rng.uniform(-0.2, 0.2), ref[1] + rng.uniform(-0.2, 0.2), ref[2] + rng.uniform(-50, 200)
+        np.testing.assert_allclose(ProjectGpsPoint(ref, lat, lon, h), _np_enu(ref, lat, lon, h), rtol=0, atol=2e-8)
+    # one arc second to the north: the meridional radius of curvature at the reference latitude
+    a, f = 6378137.0, 1.0 / 298.257223563
+    e2 = 2 * f - f * f
+    Mr = a * (1 - e2) / (1 - e2 * math.sin(math.radians(ref[0])) ** 2) ** 1.5
+    n1 = ProjectGpsPoint(ref, ref[0] + 1.0 / 3600.0, ref[1], ref[2])
+    assert abs(n1[1] - (Mr + ref[2]) * math.radians(1.0 / 3600.0)) < 1e-3 and abs(n1[0]) < 1e-9
+    # the front end: squared standard deviations, the use_gps switch, the uncertainty gate, position rows only
+    cfg = EkfConfig()
+    e, r = EkfAlgorithm(cfg), np_ekf.NpEkf(cfg_dict(cfg))
+    lat, lon, h = ref[0] + 1e-4, ref[1] - 2e-4, ref[2] + 1.0
+    cov = np.diag([0.3, 0.4, 0.8])
+    ok, pos = e.CallbackNavsatFix(5.0, lat, lon, h, cov, ref, use_gps=False)
+    assert not ok and np.allclose(pos, _np_enu(ref, lat, lon, h), atol=2e-8)
+    ok, _ = e.CallbackNavsatFix(5.0, lat, lon, h, np.diag([1.5, 0.4, 0.8]), ref)  # 1.5^2 > gnss_uncertainy_max_m
+    assert not ok
+    np.testing.assert_array_equal(e.State()["P"], r.P)
+    ok, pos = e.CallbackNavsatFix(5.0, lat, lon, h, cov, ref)
+    assert ok and r.update_pose(5.0, pos, [0, 0, 0, 1], np.diag([0.09, 0.16, 0.64]), np.zeros((3, 3)), np_ekf.NAVSATFIX)
+    compare(e, r)
