@@ -2524,36 +2524,59 @@ __device__ __forceinline__ void wave_ldlt6(double a, const double* b, double x[6
 }
 
 // Matrix<double, 6, 6>::inverse() as Eigen computes it (PartialPivLU: row exchanges on the first largest |entry| of the column, then
-// the solve against the identity).  One lane, LDS operands (row-major in `lu`, overwritten; row-major out): only GICP with
-// use_radar_cov needs the inverse of a non-symmetric matrix.
-__device__ __noinline__ void inverse6_partial_piv(double* lu, double* inv) {
-    int perm[6];
-    for (int i = 0; i < 6; ++i) perm[i] = i;
+// the solve against the identity).  One lane, LDS operands throughout (row-major in `lu`, overwritten; row-major out; work = 12 doubles:
+// the permutation and one column) -- no private arrays, so the solve kernel stays free of scratch memory: only GICP with use_radar_cov
+// needs the inverse of a non-symmetric matrix.
+__device__ __forceinline__ void inverse6_partial_piv(double* lu, double* inv, double* work) {
+    double* perm = work;     // (exact small integers)
+    double* y = work + 6;
+#pragma unroll 1
+    for (int i = 0; i < 6; ++i) perm[i] = (double)i;
+#pragma unroll 1
     for (int k = 0; k < 6; ++k) {
         int piv = k;
         double best = fabs(lu[k * 6 + k]);
+#pragma unroll 1
         for (int i = k + 1; i < 6; ++i) {
             const double v = fabs(lu[i * 6 + k]);
             if (v > best) { best = v; piv = i; }
         }
         if (piv != k) {
+#pragma unroll 1
             for (int c = 0; c < 6; ++c) { const double tmp = lu[k * 6 + c]; lu[k * 6 + c] = lu[piv * 6 + c]; lu[piv * 6 + c] = tmp; }
-            const int tp = perm[k]; perm[k] = perm[piv]; perm[piv] = tp;
+            const double tp = perm[k]; perm[k] = perm[piv]; perm[piv] = tp;
         }
-        if (lu[k * 6 + k] != 0.0)
-            for (int i = k + 1; i < 6; ++i) lu[i * 6 + k] /= lu[k * 6 + k];
-        for (int c = k + 1; c < 6; ++c)
-            for (int i = k + 1; i < 6; ++i) lu[i * 6 + c] -= lu[i * 6 + k] * lu[k * 6 + c];
+        const double d = lu[k * 6 + k];
+        if (d != 0.0) {
+#pragma unroll 1
+            for (int i = k + 1; i < 6; ++i) lu[i * 6 + k] /= d;
+        }
+#pragma unroll 1
+        for (int c = k + 1; c < 6; ++c) {
+            const double ukc = lu[k * 6 + c];
+#pragma unroll 1
+            for (int i = k + 1; i < 6; ++i) lu[i * 6 + c] -= lu[i * 6 + k] * ukc;
+        }
     }
+#pragma unroll 1
     for (int c = 0; c < 6; ++c) {
-        double y[6];
-        for (int i = 0; i < 6; ++i) y[i] = (perm[i] == c) ? 1.0 : 0.0;
-        for (int i = 0; i < 6; ++i)
-            for (int j = 0; j < i; ++j) y[i] -= lu[i * 6 + j] * y[j];
-        for (int i = 5; i >= 0; --i) {
-            for (int j = i + 1; j < 6; ++j) y[i] -= lu[i * 6 + j] * y[j];
-            y[i] /= lu[i * 6 + i];
+#pragma unroll 1
+        for (int i = 0; i < 6; ++i) y[i] = (perm[i] == (double)c) ? 1.0 : 0.0;
+#pragma unroll 1
+        for (int i = 0; i < 6; ++i) {
+            double a = y[i];
+#pragma unroll 1
+            for (int j = 0; j < i; ++j) a -= lu[i * 6 + j] * y[j];
+            y[i] = a;
         }
+#pragma unroll 1
+        for (int i = 5; i >= 0; --i) {
+            double a = y[i];
+#pragma unroll 1
+            for (int j = i + 1; j < 6; ++j) a -= lu[i * 6 + j] * y[j];
+            y[i] = a / lu[i * 6 + i];
+        }
+#pragma unroll 1
         for (int i = 0; i < 6; ++i) inv[i * 6 + c] = y[i];
     }
 }
@@ -2800,11 +2823,11 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* scans, 
     if (rp.method == ELM_GICP && !radar && t < 36) S.local_cov[t] = inv_elem; // reg.cpp:141-142 (symmetric: layout-free)
     if (rp.method == ELM_GICP && radar) {
         // JTJ_regularized.inverse() of the FULL matrix (reg.cpp:141-142): Eigen's PartialPivLU + solve against the identity; column-major out
-        __shared__ double lu[36], invm[36];
+        __shared__ double lu[36], invm[36], lu_work[12];
         if (t < 36) lu[t] = (li == lj) ? full[t] + rp.lm_lambda * full[t] : full[t];
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
-        if (lead) inverse6_partial_piv(lu, invm);
+        if (lead) inverse6_partial_piv(lu, invm, lu_work);
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
         if (t < 36) S.local_cov[t] = invm[lj * 6 + li];
