@@ -370,6 +370,13 @@ extern "C" int elm_pcd_load_xyz(const char* path, float** xyz_out, size_t* n_out
         return ELM_ERR_INVALID; // (every ascii / binary record takes at least one byte of the file; a compressed body is checked below)
     for (int a = 0; a < 3; ++a)
         if ((size_t)fx[a]->offset + 4 > h.point_step) return ELM_ERR_INVALID;
+    uint32_t comp = 0, uncomp = 0;
+    if (h.data == 2) { // the compressed body states its own sizes: checked against the header BEFORE anything of n points is allocated
+        if (buf.size() < h.data_pos + 8) return ELM_ERR_INVALID;
+        memcpy(&comp, buf.data() + h.data_pos, 4);
+        memcpy(&uncomp, buf.data() + h.data_pos + 4, 4);
+        if (buf.size() - h.data_pos - 8 < (size_t)comp || (size_t)uncomp != n * h.point_step) return ELM_ERR_INVALID;
+    }
     float* xyz = (float*)malloc(sizeof(float) * 3 * (n ? n : 1));
     if (!xyz) return ELM_ERR_ALLOC;
     if (h.data == 0) {
@@ -391,11 +398,6 @@ extern "C" int elm_pcd_load_xyz(const char* path, float** xyz_out, size_t* n_out
         for (size_t i = 0; i < n; ++i)
             for (int a = 0; a < 3; ++a) memcpy(&xyz[i * 3 + a], d + i * h.point_step + fx[a]->offset, 4);
     } else {
-        if (buf.size() < h.data_pos + 8) { free(xyz); return ELM_ERR_INVALID; }
-        uint32_t comp = 0, uncomp = 0;
-        memcpy(&comp, buf.data() + h.data_pos, 4);
-        memcpy(&uncomp, buf.data() + h.data_pos + 4, 4);
-        if (buf.size() - h.data_pos - 8 < (size_t)comp || (size_t)uncomp != n * h.point_step) { free(xyz); return ELM_ERR_INVALID; }
         std::vector<unsigned char> raw(uncomp ? uncomp : 1);
         if (!lzf_decompress((const unsigned char*)buf.data() + h.data_pos + 8, comp, raw.data(), uncomp)) { free(xyz); return ELM_ERR_INVALID; }
         // structure-of-arrays inside: field f occupies bytes [offset_f * n, (offset_f + size_f*count_f) * n)

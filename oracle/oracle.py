@@ -92,7 +92,7 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "libelm_oracle.so")
+        so = os.environ.get("ELM_ORACLE_LIB") or os.path.join(_HERE, "libelm_oracle.so")  # (override: the sanitizer flavour, tools/sanitize.sh)
         if not os.path.exists(so):
             so = build()
         L = C.CDLL(so)
