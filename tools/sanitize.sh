@@ -9,4 +9,4 @@ SAN="-O1 -g -std=c++17 -ffp-contract=off -fPIC -pthread -fsanitize=address,undef
 g++ $SAN -shared -o build_ab/libelm_oracle_san.so oracle/elm_oracle.cpp
 g++ $SAN -shared -o build_ab/libelm_host_san.so elimaloc_amd/csrc/elm_ekf.cpp elimaloc_amd/csrc/elm_io.cpp elimaloc_amd/csrc/elm_glue.cpp tools/san/host_stubs.cpp
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
-  ELM_ORACLE_LIB=$PWD/build_ab/libelm_oracle_san.so ELM_LIB=$PWD/build_ab/libelm_host_san.so python tools/sanitize_run.py "$@"; rc=$?; rm -f build_ab/libelm_oracle_san.so build_ab/libelm_host_san.so; exit $rc
+  ELM_ORACLE_LIB=$PWD/build_ab/libelm_oracle_san.so ELM_LIB=$PWD/build_ab/libelm_host_san.so python tools/sanitize_run.py "$@" && rc=0 || rc=$?; rm -f build_ab/libelm_oracle_san.so build_ab/libelm_host_san.so; exit $rc
