@@ -3002,42 +3002,6 @@ __global__ __launch_bounds__(256) void k_point_cov(const DevMap m, double d2max,
 // K0: deskew (float32 semantics of pcm.cpp:780-824; sin/cos evaluated in fp64 and rounded once to float32,
 // which reproduces glibc's correctly-rounded sinf/cosf results)
 // ------------------------------------------------------------------------------------------------------
-// sinf / cosf as glibc >= 2.28 computes them on x86-64 (sysdeps/ieee754/flt-32/s_sincosf.h, the ARM optimized-routines algorithm, in its
-// FMA-contracted multiarch variant that every FMA-capable CPU selects): float64 polynomial on the reduced argument, one rounding to
-// float32.  pcl::getTransformation calls std::cos / std::sin on floats (pcm.cpp:806), so the deskewed points depend on these exact results.
-// Restated from the published routine and checked here against the container's glibc over 320 M arguments in (-120, 120): bit for bit.
-// (|x| >= 120 takes the correctly rounded float64 function: a deskew rotation never gets there.)
-struct GlibcSincosTab { double c0, c1, c2, c3, c4; };
-__device__ __forceinline__ float glibc_sincos_poly(double x, double x2, bool flip, int n) {
-    const double s1c = -0x1.555545995a603p-3, s2c = 0x1.1107605230bc4p-7, s3c = -0x1.994eb3774cf24p-13;
-    const double sg = flip ? -1.0 : 1.0; // the second table negates the cosine coefficients
-    const double c0 = sg * 0x1p0, c1c = sg * -0x1.ffffffd0c621cp-2, c2c = sg * 0x1.55553e1068f19p-5, c3c = sg * -0x1.6c087e89a359dp-10,
-                 c4c = sg * 0x1.99343027bf8c3p-16;
-    if ((n & 1) == 0) {
-        const double x3 = x * x2, s1 = __builtin_fma(x2, s3c, s2c), x7 = x3 * x2, s = __builtin_fma(x3, s1c, x);
-        return (float)__builtin_fma(x7, s1, s);
-    }
-    const double x4 = x2 * x2, c2 = __builtin_fma(x2, c4c, c3c), c1 = __builtin_fma(x2, c1c, c0), x6 = x4 * x2, c = __builtin_fma(x4, c2c, c1);
-    return (float)__builtin_fma(x6, c2, c);
-}
-template <bool COS>
-__device__ __forceinline__ float glibc_sincosf(float y) {
-    const unsigned top = (__float_as_uint(y) >> 20) & 0x7ffu; // abstop12
-    double x = (double)y;
-    if (top < ((__float_as_uint(0x1.921FB6p-1f) >> 20) & 0x7ffu)) { // |y| < pi / 4
-        if (top < ((__float_as_uint(0x1p-12f) >> 20) & 0x7ffu)) return COS ? 1.0f : y;
-        return glibc_sincos_poly(x, x * x, false, COS ? 1 : 0);
-    }
-    if (top < ((__float_as_uint(120.0f) >> 20) & 0x7ffu)) {
-        const double r = x * 0x1.45F306DC9C883p+23;
-        const int n = ((int)r + 0x800000) >> 24;
-        x = __builtin_fma(-(double)n, 0x1.921FB54442D18p0, x);
-        const int q = COS ? n + 1 : n;
-        const double sgn = ((q & 3) == 1 || (q & 3) == 2) ? -1.0 : 1.0; // sign[q & 3] = {1, -1, -1, 1}
-        return glibc_sincos_poly(x * sgn, x * x, (q & 2) != 0, COS ? (n ^ 1) : n);
-    }
-    return COS ? (float)cos(x) : (float)sin(x);
-}
 __global__ __launch_bounds__(256) void k_deskew(const float* __restrict__ xyz, const float* __restrict__ rel_time,
                                                 unsigned n, const DeskewDev d, float* __restrict__ out) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
