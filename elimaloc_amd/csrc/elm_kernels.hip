@@ -1472,6 +1472,9 @@ __device__ __forceinline__ const uint32_t* col_cells(const DevMap& m, int cx, in
 #ifndef ELM_S2_PIPE
 #define ELM_S2_PIPE 1
 #endif
+#ifndef ELM_S2_SEED
+#define ELM_S2_SEED 1 // stage 2 seeds the ball of a point whose stage-1 block was empty (0: full walk of its 27 voxels, developer A/B)
+#endif
 #ifndef ELM_GRID_WAVES
 #define ELM_GRID_WAVES 7 // minimum waves per SIMD = a 72-VGPR cap (2 spilled registers).  Measured registrations/s: 5 -> 59.8k, 6 -> 63.9k, 7 -> 65.6k,
                          // 8 (35 spills) -> 54.2k: the kernel is bound by memory latency, not by VALU issue (67 % busy) or HBM bandwidth
@@ -1700,11 +1703,46 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
             const GridHardRec R = s_rec[live ? it : 0];
             const GridAxis ax = grid_axis(R.gx, m), ay = grid_axis(R.gy, m), az = grid_axis(R.gz, m);
             int lox = ax.alo, hix = ax.ahi, loy = ay.alo, hiy = ay.ahi, loz = az.alo, hiz = az.ahi;
-            if (R.r2 < __builtin_inff()) {
+            int seeded = 0;
+            float r2s = R.r2;
+#if ELM_S2_SEED
+            // A point whose stage-1 block came back EMPTY (a third of the undecided points under a poor initial guess: the surface is
+            // two cells below the point) has no ball: it would walk all 36 columns of its 27 voxels, ~240 candidates.  Seed it first:
+            // the group's lanes probe the 2 x 2 columns nearest to the point over the whole allowed z-range; the nearest candidate found
+            // there bounds the nearest neighbour, and the walk below is confined to that ball like any other undecided point's.
+            if (__any(live && !(r2s < __builtin_inff()))) { // wave-uniform
+                float best = __builtin_inff();
+                if (live && !(r2s < __builtin_inff())) {
+                    const double inv_h = 2.0 / m.voxel_size;
+                    const int cx0 = (int)floor(R.gx * inv_h - 0.5), cy0 = (int)floor(R.gy * inv_h - 0.5);
+                    const float shx = (float)R.gx, shy = (float)R.gy, shz = (float)R.gz;
+                    const f32x2 sxy = {shx, shy}, szl = {shz, (float)(R.gx - (double)shx)}, sl2 = {(float)(R.gy - (double)shy), (float)(R.gz - (double)shz)};
+                    const int zlo = max(az.alo - m.gz0, 0), zhi = min(az.ahi - m.gz0, m.gnz - 1);
+                    for (unsigned q = rl; q < 4u; q += LPI) {
+                        const int cxa = cx0 + (int)(q & 1u), cya = cy0 + (int)(q >> 1);
+                        const int cx = cxa - m.gx0, cy = cya - m.gy0;
+                        if (cxa < ax.alo || cxa > ax.ahi || cya < ay.alo || cya > ay.ahi || cx < 0 || cx >= m.gnx || cy < 0 || cy >= m.gny || zlo > zhi) continue;
+                        int zc0, nzc;
+                        const uint32_t* e = col_cells<TILED>(m, cx, cy, zlo, zhi, zc0, nzc);
+                        const int b0 = (int)e[0], b1 = (int)e[nzc];
+                        seeded += 4 * (b1 - b0);
+                        for (int b = b0; b < b1; ++b) {
+                            f32x2 da, db;
+                            blk_dist(lp[b], sxy, szl, sl2, da, db);
+                            best = fminf(best, fminf(fminf(da.x, da.y), fminf(db.x, db.y)));
+                        }
+                    }
+                }
+                best = __uint_as_float(group_min_u32<LPI>(__float_as_uint(best))); // non-negative floats order like their bit patterns
+                if (!(r2s < __builtin_inff()) && best < 1e30f) // (padding slots sit at 1e18: their squares are not candidates)
+                    r2s = best + best * 4e-6f + 4e-11f * (fabsf((float)R.gx) + fabsf((float)R.gy) + fabsf((float)R.gz) + 1.0f);
+            }
+#endif
+            if (r2s < __builtin_inff()) {
                 // every candidate within sqrt(r2) of g -- the nearest one and whatever ties with it -- has its cell inside the
                 // per-axis cell range of [g - r, g + r] (1e-6 of margin: a stored coordinate exactly on a cell face counts to the
                 // cell further from zero, grid_cell_of)
-                const double r = (double)(__builtin_sqrtf(R.r2) * 1.000001f) + 1e-6; // float32 root (1 ulp) inside the margin
+                const double r = (double)(__builtin_sqrtf(r2s) * 1.000001f) + 1e-6; // float32 root (1 ulp) inside the margin
                 const double inv_h = 2.0 / m.voxel_size;
                 lox = max(lox, (int)floor((R.gx - r) * inv_h)); hix = min(hix, (int)floor((R.gx + r) * inv_h));
                 loy = max(loy, (int)floor((R.gy - r) * inv_h)); hiy = min(hiy, (int)floor((R.gy + r) * inv_h));
@@ -1719,7 +1757,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
             // whole ball by the margin is the float64 winner as well
             const unsigned gsh = threadIdx.x & 63u & ~(LPI - 1u);
             const unsigned long long gmask = ((1ull << LPI) - 1ull) << gsh;
-            int win = -1, walked = 0;
+            int win = -1, walked = seeded;
             bool need64 = false;
             {
                 const float ghx = (float)R.gx, ghy = (float)R.gy, ghz = (float)R.gz;
