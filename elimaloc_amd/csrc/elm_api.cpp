@@ -1500,6 +1500,30 @@ static int scan_alloc(elm_ctx* ctx, size_t n, elm_scan** out) {
 // and, through the XCD-aware block mapping, every XCD's L2, touch a few adjacent map cells: +11..13 % registrations/s on resident
 // scans.  order = false (elm_register): the caller's order; ordering one scan costs more than it saves on ONE registration.
 // No allocation after warm-up: pinned staging, scan handles and device buffers are pooled in the context.
+// Copy into page-locked staging memory that the CPU will not read again: non-temporal 32-byte stores (no read-for-ownership of the
+// destination lines, no cache pollution) where the CPU has AVX2, memcpy otherwise.  dst must be 32-byte aligned (staging buffers are).
+#include <immintrin.h>
+__attribute__((target("avx2"))) static void stage_copy_avx2(void* dst, const void* src, size_t len) {
+    char* d = (char*)dst;
+    const char* s = (const char*)src;
+    size_t i = 0;
+    for (; i + 128 <= len; i += 128) {
+        const __m256i a = _mm256_loadu_si256((const __m256i*)(s + i)), b = _mm256_loadu_si256((const __m256i*)(s + i + 32));
+        const __m256i c = _mm256_loadu_si256((const __m256i*)(s + i + 64)), e = _mm256_loadu_si256((const __m256i*)(s + i + 96));
+        _mm256_stream_si256((__m256i*)(d + i), a);
+        _mm256_stream_si256((__m256i*)(d + i + 32), b);
+        _mm256_stream_si256((__m256i*)(d + i + 64), c);
+        _mm256_stream_si256((__m256i*)(d + i + 96), e);
+    }
+    _mm_sfence();
+    if (i < len) memcpy(d + i, s + i, len - i);
+}
+static void stage_copy(void* dst, const void* src, size_t len) {
+    static const bool avx2 = __builtin_cpu_supports("avx2") && !getenv("ELM_STAGE_MEMCPY");
+    if (avx2 && (((uintptr_t)dst) & 31u) == 0) stage_copy_avx2(dst, src, len);
+    else memcpy(dst, src, len);
+}
+
 static int scan_upload_impl(elm_ctx* ctx, const float* xyz, size_t n, size_t n_total, bool order, bool sync, elm_scan** out) {
     if (!ctx || !out || (!xyz && n) || n > 0x7FFFFFFFull || n_total > 0x7FFFFFFFull || n_total < n) return ELM_ERR_INVALID;
     *out = nullptr;
@@ -1529,7 +1553,7 @@ static int scan_upload_impl(elm_ctx* ctx, const float* xyz, size_t n, size_t n_t
         hipError_t ee = hipSuccess;
         for (size_t o = 0; o < bytes && ee == hipSuccess; o += piece) {
             const size_t len = std::min(piece, bytes - o);
-            memcpy((char*)ctx->h_stage + o, (const char*)xyz + o, len);
+            stage_copy((char*)ctx->h_stage + o, (const char*)xyz + o, len); // (pieces are multiples of 32 bytes)
             ee = hipMemcpyAsync((char*)dst + o, (const char*)ctx->h_stage + o, len, hipMemcpyHostToDevice, ctx->stream);
         }
         return ee;
