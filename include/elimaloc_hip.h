@@ -200,7 +200,8 @@ int elm_register_batch(elm_ctx* ctx, const elm_map* map, elm_scan* const* scans,
  * rank -- the solve kernel hands out the queue positions -- but a registration's arithmetic does not depend on its slot; with a
  * communicator attached the assignment is in slot order, identical on every rank).  elm_register keeps the caller's point order
  * while elm_scan_upload orders the points: the two agree up to the order of the summation (1e-9 on every sum), not bit for bit.
- * trace: NULL or count*ELM_MAX_ITER_TRACE entries. */
+ * trace: NULL or count*ELM_MAX_ITER_TRACE entries.  use_radar_cov = 1 with a covariance method: the registrations run as lockstep
+ * batches of `slots` (same results as elm_register_batch); with a communicator attached that configuration is ELM_ERR_UNSUPPORTED. */
 int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* const* scans, int count, const double* T0,
                         const elm_reg_config* cfg, int slots, elm_reg_result* results, elm_iter_trace* trace);
 /* The same with the scans still in HOST memory when the call starts -- RunRegister's per-call contract (reg.cpp:274-290: the
