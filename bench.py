@@ -80,6 +80,123 @@ def percentile(v, q):
     return float(np.percentile(np.asarray(v, dtype=np.float64), q))
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed.run environment: become the launcher -- one rank per GPU of this
+    node, rendezvous on 127.0.0.1 (the form the driver itself uses for N > 1).  A box with fewer than N GPUs is refused HERE, loudly:
+    a run labelled N GPUs never silently measures one."""
+    if not args.dry_launch:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: this box has {have} GPU(s); one rank per GPU is the only mode "
+                             f"(no oversubscription, no CPU fallback) -- refusing to run")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execvpe(cmd[0], cmd, dict(os.environ))
+
+
+def generate_inputs(world, args, rank, world_size, dist, guess, n_keep, keep_own, consume):
+    """The step's registrations: n_batch = batch x world_size seeded scans + initial guesses; `consume(i, shard, n)` receives, in order
+    of i, THIS rank's contiguous shard [n rank / W, n (rank + 1) / W) of scan i (packed float32 xyz, the caller's point order).
+
+    One rank: every scan is generated here.  W ranks: rank r generates only the scans i = r (mod W) -- the host work per rank does not
+    grow with W -- and one all-to-all per round of 32 scans (host tensors over gloo, outside every timed region) hands every rank its
+    shard of every scan; the per-scan metadata (true pose, initial guess, SHA-1, extent) is all-gathered.  Bit-identical to the
+    one-rank generation (same seeds; `inputs.sha1` covers all of it).
+    Returns dict(T_true, T0s, digests, rmaxs, kept = {i: full scan} for i < n_keep on rank 0 (+ this rank's own scans if keep_own))."""
+    from concurrent.futures import ThreadPoolExecutor
+    from elimaloc_amd import synth
+    n_batch = args.batch * world_size
+    npts = args.scan_points
+
+    def gen(i):
+        sc, Tt = synth.make_scan(world, npts, seed=2002 + i, max_range=SCAN_RANGE_M, noise=SCAN_NOISE_M)
+        T0 = synth.perturb(Tt, seed=3003 + i, **guess)
+        h = hashlib.sha1(sc.tobytes())
+        h.update(np.ascontiguousarray(T0).tobytes())
+        rmax = float(np.sqrt((sc.astype(np.float64) ** 2).sum(axis=1).max())) if sc.shape[0] else 0.0
+        return sc, Tt, T0, h.digest(), rmax
+
+    synth.make_scan(world, 16, seed=1)  # builds the (cached) tile index of the world before the threads start
+    meta = [None] * n_batch  # (T_true, T0, digest, rmax)
+    kept = {}
+    workers = max(2, min(16, (os.cpu_count() or 16) // max(world_size, 1)))
+    with ThreadPoolExecutor(max_workers=workers) as pool:  # numpy releases the GIL in the heavy parts; make_scan calls no BLAS
+        if world_size == 1:
+            for i, (sc, Tt, T0, dg, rmax) in enumerate(pool.map(gen, range(n_batch))):
+                meta[i] = (Tt, T0, dg, rmax)
+                if i < n_keep or keep_own:
+                    kept[i] = sc
+                consume(i, sc, sc.shape[0])
+        else:
+            import torch
+            bounds = [npts * d // world_size for d in range(world_size + 1)]
+            mine = bounds[rank + 1] - bounds[rank]
+            ROUND = 32
+            for m0 in range(0, args.batch, ROUND):
+                ms = list(range(m0, min(m0 + ROUND, args.batch)))
+                cnt = len(ms)
+                own = list(pool.map(gen, [rank + world_size * m for m in ms]))
+                if any(o[0].shape[0] != npts for o in own):
+                    raise SystemExit("make_scan returned a scan of another size")
+                # send buffer: destination-major, then scan; receive buffer: source-major, then scan
+                inp = torch.from_numpy(np.concatenate([o[0][bounds[d]:bounds[d + 1]].reshape(-1) for d in range(world_size) for o in own]))
+                out = torch.empty(world_size * cnt * mine * 3, dtype=torch.float32)
+                dist.all_to_all_single(out, inp, [cnt * mine * 3] * world_size, [cnt * (bounds[d + 1] - bounds[d]) * 3 for d in range(world_size)])
+                metas = [None] * world_size
+                dist.all_gather_object(metas, [(o[1], o[2], o[3], o[4]) for o in own])
+                got = out.numpy().reshape(world_size, cnt, mine, 3)
+                for j, m in enumerate(ms):
+                    for src in range(world_size):
+                        i = src + world_size * m
+                        meta[i] = metas[src][j]
+                        consume(i, np.ascontiguousarray(got[src, j]), npts)
+                    if keep_own:
+                        kept[rank + world_size * m] = own[j][0]
+                    elif rank == 0 and world_size * m < n_keep:
+                        kept[world_size * m] = own[j][0]
+        # the pooled generation must equal a sequential one (round 1's pool corrupted rows through concurrent OpenBLAS calls)
+        mine_idx = list(range(n_batch)) if world_size == 1 else list(range(rank, n_batch, world_size))
+        for i in sorted(set([mine_idx[0], mine_idx[len(mine_idx) // 3], mine_idx[-1]])):
+            if gen(i)[3] != meta[i][2]:
+                raise SystemExit(f"input generation is not deterministic (scan {i})")
+    return dict(T_true=[m[0] for m in meta], T0s=[m[1] for m in meta], digests=[m[2] for m in meta], rmaxs=[m[3] for m in meta], kept=kept)
+
+
+def dry_launch(args, rank, world_size, local_rank, dist):
+    """--dry-launch: the launcher, the rendezvous and the sharded input generation + exchange WITHOUT a GPU (gloo only) -- what the CPU
+    test suite runs at N = 2.  Prints one JSON line (no `value`: nothing is measured)."""
+    from elimaloc_amd import synth
+    world = synth.make_world(args.map_points, seed=1001)
+    guess = dict(max_trans=0.15, max_rot_deg=0.5) if args.guess == "easy" else dict(max_trans=0.5, max_rot_deg=2.0)
+    shard_sha = hashlib.sha1()
+    shard_points = [0]
+
+    def consume(i, shard, n):
+        shard_sha.update(shard.tobytes())
+        shard_points[0] += shard.shape[0]
+
+    g = generate_inputs(world, args, rank, world_size, dist, guess, 0, False, consume)
+    who = [None] * world_size
+    mine = dict(rank=rank, local_rank=local_rank, pid=os.getpid(), shard_points=shard_points[0], shard_sha1=shard_sha.hexdigest())
+    if world_size > 1:
+        dist.all_gather_object(who, mine)
+    else:
+        who = [mine]
+    return {"dry_launch": True, "metric": "ICP registrations/sec, 128k-pt scan vs 10M-pt map; pose err vs CPU ref", "value": None,
+            "n_gpus": world_size, "rccl_ranks": None, "ranks": who,
+            "inputs": {"sha1": hashlib.sha1(b"".join(g["digests"])).hexdigest(), "registrations": len(g["digests"])}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,8 +219,13 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip latency / reference-API / hard-guess / replica legs (profiling passes)")
     ap.add_argument("--no-latency", action="store_true", help="alias of --no-extras")
+    ap.add_argument("--dry-launch", action="store_true", help="launcher + rendezvous + sharded input generation only, gloo, no GPU (CPU test of the N > 1 path)")
     args = ap.parse_args()
     extras = not (args.no_extras or args.no_latency)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        launch_ranks(args, sys.argv[1:])  # does not return
 
     # stdout carries exactly ONE JSON line: everything libraries print (RCCL banners, gloo notices) goes to stderr
     sys.stdout.flush()
@@ -114,6 +236,10 @@ def main():
     import torch.distributed as dist
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    # --gpus IS the number of ranks, whoever launched them (the driver's torch.distributed.run for N > 1, launch_ranks above, plain
+    # python for N = 1): a mismatch is an error, never a silently smaller run
+    if args.gpus != world_size:
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world_size}: launch one rank per GPU (python bench.py --gpus N does it itself)")
     if args.batch <= 0:
         args.batch = 4096 if world_size == 1 else 1024
     rank = int(os.environ.get("RANK", "0"))
@@ -121,10 +247,22 @@ def main():
     # launched by torch.distributed.run (RANK set): take the collective path even for one rank, so that a 1-GPU box
     # exercises exactly the code the 8-GPU node runs
     distributed = world_size > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
-    if args.gpus != world_size and distributed:
-        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world_size}")
+    if args.dry_launch:
+        if distributed:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world_size)
+        line = dry_launch(args, rank, world_size, local_rank, dist)
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if distributed:
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback")
+    if torch.cuda.device_count() < world_size or local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py --gpus {args.gpus}: {torch.cuda.device_count()} GPU(s) visible to rank {rank} (local rank {local_rank}); one rank per GPU is the only mode")
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -136,12 +274,23 @@ def main():
 
     method = IcpMethod(args.method)
     ctx = Context(local_rank)
+    rccl_ranks, rank_table = None, None
     if distributed:
         ids = [Context.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         ctx.comm_init(rank, world_size, ids[0])
+        # what the RCCL communicator itself reports: the run is an N-GPU run only if N ranks joined it, each on a device of its own
+        crank, rccl_ranks = ctx.comm_info()
+        if rccl_ranks != world_size or crank != rank:
+            raise SystemExit(f"RCCL communicator reports rank {crank} of {rccl_ranks}, expected rank {rank} of {world_size}")
+        props = torch.cuda.get_device_properties(local_rank)
+        rank_table = [None] * world_size
+        dist.all_gather_object(rank_table, dict(rank=rank, local_rank=local_rank, pid=os.getpid(), device=props.name,
+                                                gpu_uuid=str(getattr(props, "uuid", "")), rccl_rank=crank))
+        if len({(r["local_rank"], r["gpu_uuid"]) for r in rank_table}) != world_size or len({r["pid"] for r in rank_table}) != world_size:
+            raise SystemExit(f"ranks do not sit on {world_size} distinct GPUs / processes: {rank_table}")
 
-    # ---------------- synthetic inputs (identical on every rank: seeded, BLAS-free arithmetic) ----------------
+    # ---------------- synthetic inputs (seeded, BLAS-free arithmetic: bit-identical whoever generates them) ----------------
     t0 = time.time()
     world = synth.make_world(args.map_points, seed=1001)
     vm = VoxelHashMap(1.0, 30, ctx)
@@ -153,43 +302,26 @@ def main():
     info = vm.info()
     t_map = time.time() - t0
     n_batch = args.batch * world_size  # weak scaling: per-GPU points per launch fixed
-    n_keep = max(args.cpu_sample, 8) if rank == 0 else 0  # full host copies kept for the CPU / reference-API legs
+    n_keep = max(args.cpu_sample, 8) if (rank == 0 and world_size == 1) else 0  # full host copies kept for the CPU / reference-API legs (N = 1)
     guess = dict(max_trans=0.15, max_rot_deg=0.5) if args.guess == "easy" else dict(max_trans=0.5, max_rot_deg=2.0)
+    want_replica = extras and distributed and args.slots > 0 and (world_size > 1 or bool(os.environ.get("ELM_BENCH_FORCE_REPLICA")))
 
-    def gen(i):
-        sc, Tt = synth.make_scan(world, args.scan_points, seed=2002 + i, max_range=SCAN_RANGE_M, noise=SCAN_NOISE_M)
-        T0 = synth.perturb(Tt, seed=3003 + i, **guess)
-        n = sc.shape[0]
-        h = hashlib.sha1(sc.tobytes())
-        h.update(np.ascontiguousarray(T0).tobytes())
-        rmax = float(np.sqrt((sc.astype(np.float64) ** 2).sum(axis=1).max())) if n else 0.0
-        lo, hi = n * rank // world_size, n * (rank + 1) // world_size  # contiguous shard of every scan
-        return (sc if i < n_keep else None), Tt, T0, np.ascontiguousarray(sc[lo:hi]), n, h.digest(), rmax
-
-    synth.make_scan(world, 16, seed=1)  # builds the (cached) tile index of the world before the threads start
-    scans_host, T_true, T0s, scans, digests, rmaxs = [], [], [], [], [], []
+    scans = []
     # host-fed leg (N = 1): the first `n_fed` scans once more in ONE page-locked buffer, back to back (what a driver's DMA ring holds)
     n_fed = min(args.hostfed_batch, n_batch) if (world_size == 1 and not distributed and extras and args.slots > 0) else 0  # (a host-fed stream runs on one rank without a communicator)
     pin = PinnedBuffer(max(1, n_fed * args.scan_points * 3)) if n_fed else None
     fed_sizes = []
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=16) as pool:  # numpy releases the GIL in the heavy parts; make_scan calls no BLAS
-        for i, (full, Tt, T0, shard, n, dg, rmax) in enumerate(pool.map(gen, range(n_batch))):
-            if full is not None:
-                scans_host.append(full)
-            if i < n_fed:
-                o = sum(fed_sizes) * 3
-                pin.array[o:o + shard.size] = shard.ravel()
-                fed_sizes.append(shard.shape[0])
-            T_true.append(Tt)
-            T0s.append(T0)
-            scans.append(Scan(ctx, shard, n_total=n))
-            digests.append(dg)
-            rmaxs.append(rmax)
-    # the pooled generation must equal a sequential one (round 1's pool corrupted rows through concurrent OpenBLAS calls)
-    for i in sorted(set([0, n_batch // 3, n_batch - 1])):
-        if gen(i)[5] != digests[i]:
-            raise SystemExit(f"input generation is not deterministic (scan {i})")
+
+    def consume(i, shard, n):
+        if i < n_fed:
+            o = sum(fed_sizes) * 3
+            pin.array[o:o + shard.size] = shard.ravel()
+            fed_sizes.append(shard.shape[0])
+        scans.append(Scan(ctx, shard, n_total=n))  # H2D upload + device-side ordering of THIS rank's shard
+
+    gin = generate_inputs(world, args, rank, world_size, dist, guess, n_keep, want_replica, consume)
+    T_true, T0s, digests, rmaxs = gin["T_true"], gin["T0s"], gin["digests"], gin["rmaxs"]
+    scans_host = [gin["kept"][i] for i in range(n_keep)] if n_keep else []
     # every scan point lies within the sensor range (+ 5 sigma of the noise on every axis)
     if max(rmaxs) > SCAN_RANGE_M + 5.0 * SCAN_NOISE_M * 3 ** 0.5:
         raise SystemExit(f"corrupted scan: max |p| = {max(rmaxs):.3f} m")
@@ -266,7 +398,11 @@ def main():
     if os.path.exists(pmc_path):
         try:
             pm = json.load(open(pmc_path)).get(kernel_name)
-            if pm and pm.get("scan_points") == args.scan_points and args.map_points == 10_000_000 and args.guess == "easy":
+            # a counter pass speaks for THIS run only if it was taken at this operating point: same scan / map size, guess set, registrations
+            # per step and slots (the launch mix -- live slots per launch, draining launches -- follows from those); otherwise the line falls
+            # back to the compulsory HBM stream and says so
+            if (pm and pm.get("scan_points") == args.scan_points and args.map_points == 10_000_000 and pm.get("guess", "easy") == args.guess
+                    and pm.get("batch") == args.batch and pm.get("slots") == args.slots and world_size == 1):
                 traffic = pm.get("hbm_bytes_per_unit") * units_per_launch
                 traffic_src = (f"profiles/pmc_latest.json[{kernel_name}]: HBM bytes/unit of separate rocprofv3 --pmc passes of this command "
                                f"({pm.get('source', 'see profiles/README.md')}) x this run's units per launch; counters cannot be read in the timed run")
@@ -341,6 +477,8 @@ def main():
         "value": value,
         "unit": "registrations/s",
         "n_gpus": world_size,
+        "rccl_ranks": rccl_ranks,  # ncclCommCount of the communicator the timed region all-reduced over (null: one process, no communicator)
+        "ranks": rank_table,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
@@ -370,6 +508,8 @@ def main():
             "occupied_voxels_per_point_V": V,
             "map_build_s": t_map,
             "input_gen_s": t_in,
+            "input_generation": ("every scan generated on this rank" if world_size == 1 else
+                                 f"rank r generates the scans i = r mod {world_size}; one all-to-all per 32 scans (gloo, host) hands out the shards"),
         },
         "inputs": {
             "sha1": inputs_sha1,
@@ -496,7 +636,7 @@ def main():
     else:
         T0h, outh = None, None
 
-    if extras and distributed and args.slots > 0 and (world_size > 1 or os.environ.get("ELM_BENCH_FORCE_REPLICA")):
+    if want_replica:
         # replica mode: whole registrations per GPU, no collective (the comparison SURVEY 8e asks for)
         rctx = Context(local_rank)
         rvm = VoxelHashMap(1.0, 30, rctx)
@@ -506,9 +646,7 @@ def main():
         if method == IcpMethod.GICP:
             rvm.CalPointCovAll(0.4)
         mine = list(range(rank, n_batch, world_size))
-        with ThreadPoolExecutor(max_workers=16) as pool:  # the same scans as above (seeded), whole instead of sharded
-            rscans = [Scan(rctx, sc) for sc in pool.map(lambda i: synth.make_scan(world, args.scan_points, seed=2002 + i, max_range=SCAN_RANGE_M,
-                                                                                   noise=SCAN_NOISE_M)[0], mine)]
+        rscans = [Scan(rctx, gin["kept"][i]) for i in mine]  # the scans this rank generated (whole), the same registrations as above
         rreg = Registration(cfg, rctx)
         rp = rreg.pack_inputs(rscans, [T0s[i] for i in mine])
         rreg.RunRegisterStream(rp[0], rvm, rp[1], slots=args.slots, raw=True)

@@ -131,7 +131,7 @@ EXPORTS = [
     "elm_map_download_voxels", "elm_map_find_ground_height", "elm_scan_upload", "elm_scan_destroy",
     "elm_scan_size", "elm_scan_download", "elm_register", "elm_register_batch", "elm_register_stream", "elm_register_stream_host", "elm_host_alloc", "elm_host_free", "elm_ctx_measure_h2d", "elm_register_batch_enqueue",
     "elm_register_batch_finish", "elm_deskew", "elm_deskew_downsample", "elm_deskew_prepare", "elm_comm_get_unique_id", "elm_comm_init",
-    "elm_comm_destroy", "elm_comm_set_hook", "elm_filter_points_by_distance", "elm_voxel_downsample",
+    "elm_comm_destroy", "elm_comm_info", "elm_comm_set_hook", "elm_filter_points_by_distance", "elm_voxel_downsample",
     "elm_get_interpolated_pose", "elm_shape_odom_covariance",
     "elm_ekf_config_default", "elm_ekf_create", "elm_ekf_destroy", "elm_ekf_predict_imu", "elm_ekf_predict", "elm_ekf_update_can", "elm_gps_project", "elm_ekf_update_navsatfix",
     "elm_ekf_update_pose", "elm_ekf_update_pcm_odom", "elm_ekf_get_state", "elm_ekf_publish",
@@ -293,6 +293,7 @@ def lib():
     L.elm_comm_get_unique_id.argtypes = [vp]
     L.elm_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.elm_comm_destroy.argtypes = [vp]
+    L.elm_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.elm_comm_set_hook.argtypes = [vp, ALLREDUCE_FN, vp]
     _LIB = L
     return L

@@ -44,6 +44,7 @@ typedef int (*nccl_comm_init_rank_t)(void**, int, struct elm_nccl_id, int);
 typedef int (*nccl_all_reduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef int (*nccl_comm_destroy_t)(void*);
 typedef const char* (*nccl_get_error_string_t)(int);
+typedef int (*nccl_comm_query_t)(const void*, int*);
 struct elm_nccl_id {
     char internal[ELM_COMM_ID_BYTES];
 };
@@ -55,6 +56,7 @@ struct RcclApi {
     nccl_all_reduce_t all_reduce = nullptr;
     nccl_comm_destroy_t comm_destroy = nullptr;
     nccl_get_error_string_t get_error_string = nullptr;
+    nccl_comm_query_t comm_count = nullptr, comm_user_rank = nullptr;
 };
 static RcclApi g_rccl;
 
@@ -75,6 +77,8 @@ static bool load_rccl(std::string* err) {
     g_rccl.all_reduce = (nccl_all_reduce_t)dlsym(h, "ncclAllReduce");
     g_rccl.comm_destroy = (nccl_comm_destroy_t)dlsym(h, "ncclCommDestroy");
     g_rccl.get_error_string = (nccl_get_error_string_t)dlsym(h, "ncclGetErrorString");
+    g_rccl.comm_count = (nccl_comm_query_t)dlsym(h, "ncclCommCount");
+    g_rccl.comm_user_rank = (nccl_comm_query_t)dlsym(h, "ncclCommUserRank");
     if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.all_reduce || !g_rccl.comm_destroy) {
         if (err) *err = "librccl lacks ncclGetUniqueId/ncclCommInitRank/ncclAllReduce/ncclCommDestroy";
         return false;
@@ -2770,6 +2774,26 @@ extern "C" int elm_comm_destroy(elm_ctx* ctx) {
     ctx->comm = nullptr;
     ctx->nranks = 1;
     ctx->rank = 0;
+    return ELM_OK;
+}
+
+// What the COMMUNICATOR says about itself (ncclCommCount / ncclCommUserRank), not what the caller passed to elm_comm_init: the benches
+// print it so that a run labelled N GPUs is known to have formed an N-rank RCCL communicator.  No communicator: 0 ranks.
+extern "C" int elm_comm_info(elm_ctx* ctx, int* rank, int* nranks) {
+    if (!ctx || !rank || !nranks) return ELM_ERR_INVALID;
+    *rank = 0;
+    *nranks = 0;
+    if (!ctx->comm) return ELM_OK;
+    if (!g_rccl.comm_count || !g_rccl.comm_user_rank) {
+        ctx->last_error = "librccl lacks ncclCommCount / ncclCommUserRank";
+        return ELM_ERR_COMM;
+    }
+    int rc = g_rccl.comm_count(ctx->comm, nranks);
+    if (rc == 0) rc = g_rccl.comm_user_rank(ctx->comm, rank);
+    if (rc != 0) {
+        ctx->last_error = std::string("ncclCommCount: ") + (g_rccl.get_error_string ? g_rccl.get_error_string(rc) : "error");
+        return ELM_ERR_COMM;
+    }
     return ELM_OK;
 }
 

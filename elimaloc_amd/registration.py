@@ -101,6 +101,12 @@ class Context:
     def comm_destroy(self):
         check(_lib.lib().elm_comm_destroy(self._h), self._h, "elm_comm_destroy")
 
+    def comm_info(self):
+        """(rank, nranks) as the RCCL communicator reports them (ncclCommUserRank / ncclCommCount); (0, 0) without one."""
+        r, n = C.c_int(0), C.c_int(0)
+        check(_lib.lib().elm_comm_info(self._h, C.byref(r), C.byref(n)), self._h, "elm_comm_info")
+        return r.value, n.value
+
     def set_allreduce_hook(self, fn):
         """fn(dev_ptr:int, n_doubles:int, hip_stream:int) -> 0 on success; None removes the hook."""
         if fn is None:

@@ -411,6 +411,8 @@ int elm_pcm_callback_point_cloud(elm_ctx* ctx, const elm_map* map, const elm_pcm
 int elm_comm_get_unique_id(void* id_bytes /* ELM_COMM_ID_BYTES */);
 int elm_comm_init(elm_ctx* ctx, int rank, int nranks, const void* id_bytes);
 int elm_comm_destroy(elm_ctx* ctx);
+/* rank / size as the RCCL communicator itself reports them (ncclCommUserRank / ncclCommCount); nranks = 0 without a communicator */
+int elm_comm_info(elm_ctx* ctx, int* rank, int* nranks);
 /* Alternative exchange hook (e.g. a torch.distributed all_reduce from Python): called between the accumulate
  * and the solve launches with the device pointer of the packed sums. Pass NULL to remove. */
 typedef int (*elm_allreduce_fn)(void* dev_ptr, size_t n_doubles, void* hip_stream, void* user);

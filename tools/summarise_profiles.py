@@ -21,14 +21,29 @@ if c:
         for r in rows:
             f.write(f"\"{r[0]}\",{r[1]},{r[2]},{r[3]:.1f},{r[4]},{r[5]},{100.0 * r[2] / tot:.2f}\n")
 pmc = {}
-for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_ta"):
+pass_ns = {}  # per counter pass: the accumulate kernel's own average duration in THAT pass (the pass's --kernel-trace)
+import glob
+for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
+    name = os.path.basename(d)
+    if not os.path.isdir(d):
+        continue
     c = db(name)
     if not c:
         continue
-    for k, cn, n, avg in c.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
-                                   "group by kernel_name, counter_name"):
-        pmc.setdefault(k, {})[cn] = {"launches": n, "avg": avg}
-summary = {"counters": pmc, "source": os.path.basename(out.rstrip("/"))}
+    # one row per (dispatch, counter, dimension instance): sum the instances of a dispatch first, then average over dispatches
+    per = {}
+    for k, did, cn, v in c.execute("select kernel_name, dispatch_id, counter_name, sum(value) from counters_collection "
+                                   "group by kernel_name, dispatch_id, counter_name"):
+        per.setdefault((k, cn), []).append(v)
+    for (k, cn), vs in per.items():
+        pmc.setdefault(k, {})[cn] = {"launches": len(vs), "avg": sum(vs) / len(vs)}
+    try:
+        for k, n, avg in c.execute("select name, count(*), avg(end - start) from kernels group by name"):
+            if "k_accumulate" in k:
+                pass_ns.setdefault(name, {})[k.split("(")[0]] = {"launches": n, "avg_ns": avg}
+    except Exception:  # noqa: BLE001
+        pass
+summary = {"counters": pmc, "source": os.path.basename(out.rstrip("/")), "pass_kernel_ns": pass_ns}
 try:
     b = json.load(open(os.path.join(out, "bench_trace.json")))
     kname = b["roofline"]["kernel"].split("<")[0]
@@ -47,7 +62,9 @@ try:
             # (12 B per unit, half of it missing = 6 B); the x2 figure of round 2 is kept as an upper bound.  WRITE_SIZE is
             # uncalibrated (tiny here).  FETCH_SIZE counts Infinity-Cache hits: fabric-side traffic, an upper bound on DRAM bytes.
             summary.update({"kernel": b["roofline"]["kernel"], "method": {"P2P": 0, "GICP": 1, "VGICP": 2, "AVGICP": 3}[b["roofline"]["kernel"].split("<")[1].rstrip(">")],
-                            "batch": b["config"]["batch_per_gpu"], "scan_points": 131072,
+                            "batch": b["config"]["batch_per_gpu"], "slots": b["config"]["slots_per_gpu"], "steps": b["steps"], "warmup": b["warmup"],
+                            "guess": "hard" if "(hard)" in b["config"]["workload"] else "easy", "scan_points": 131072,
+                            "avg_launch_ms_traced": b["roofline"]["avg_launch_ms"], "ps_per_unit_traced": 1e9 * b["roofline"]["avg_launch_ms"] / units,
                             "fetch_size_kb_avg_raw": fetch_kb, "write_size_kb_avg": write_kb,
                             "hbm_bytes_per_launch": (fetch_kb + write_kb) * 1024.0 + 6.0 * units,
                             "hbm_bytes_per_launch_x2_upper": (2.0 * fetch_kb + write_kb) * 1024.0,
@@ -71,6 +88,15 @@ try:
                 summary["l1_hit"] = 1.0 - v["TCP_TCC_READ_REQ_sum"]["avg"] / max(v["TCP_TOTAL_CACHE_ACCESSES_sum"]["avg"], 1.0)
             if "TCC_HIT_sum" in v:
                 summary["l2_hit"] = v["TCC_HIT_sum"]["avg"] / (v["TCC_HIT_sum"]["avg"] + v["TCC_MISS_sum"]["avg"])
+            cls = {n[len("SQ_INSTS_VALU_"):]: v[n]["avg"] for n in v if n.startswith("SQ_INSTS_VALU_")}
+            if cls and "SQ_INSTS_VALU" in v:
+                summary["valu_class_share"] = {n: c_ / v["SQ_INSTS_VALU"]["avg"] for n, c_ in sorted(cls.items())}
+            if "SQ_WAVE_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
+                # SQ_WAVE_CYCLES counts quad-cycles of resident waves: x4 / (1024 SIMDs x kernel cycles) = average resident waves per SIMD
+                summary["resident_waves_per_simd"] = 4.0 * v["SQ_WAVE_CYCLES"]["avg"] / (1024.0 * v["GRBM_GUI_ACTIVE"]["avg"] / 8.0)
+            for n in ("SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA", "SQ_WAIT_INST_LDS"):
+                if n in v and "SQ_WAVE_CYCLES" in v:
+                    summary.setdefault("wave_cycle_share", {})[n] = v[n]["avg"] / v["SQ_WAVE_CYCLES"]["avg"]
 except Exception as e:  # noqa: BLE001
     summary["error"] = repr(e)
 json.dump(summary, open(os.path.join(out, "pmc.json"), "w"), indent=1)
