@@ -367,9 +367,16 @@ def main():
     value = regs / elapsed
     iters = np.array([r["iterations"] for r in out])
     pt_iters = float(sum(r["point_iterations"] for r in out))          # whole batch, all ranks (all-reduced sums)
-    C = float(sum(r["n_cand_total"] for r in out)) / max(pt_iters, 1)  # candidates of the reference's walk per point-iteration
-    V = float(sum(r["n_occ_total"] for r in out)) / max(pt_iters, 1)   # occupied neighbour voxels per point-iteration
-    tested = float(sum(r["n_tested_total"] for r in out)) / max(pt_iters, 1)  # candidates this kernel distance-tests
+    # The timed launches carry no instrumentation.  The work counters (candidates C / occupied voxels V of the reference's walk, candidates
+    # this kernel distance-tests) come from ONE untimed pass of the same step with the counters compiled in: same poses, bit for bit.
+    ctx.set_work_counters(True)
+    out_c = results_from_raw(step()) if args.slots > 0 else step()
+    ctx.set_work_counters(False)
+    if not all(np.array_equal(a["T"], b["T"]) and a["iterations"] == b["iterations"] for a, b in zip(out_c, out)):
+        raise SystemExit("the instrumented pass does not reproduce the timed one")
+    C = float(sum(r["n_cand_total"] for r in out_c)) / max(pt_iters, 1)  # candidates of the reference's walk per point-iteration
+    V = float(sum(r["n_occ_total"] for r in out_c)) / max(pt_iters, 1)   # occupied neighbour voxels per point-iteration
+    tested = float(sum(r["n_tested_total"] for r in out_c)) / max(pt_iters, 1)  # candidates this kernel distance-tests
     bytes_ref = b_alg_reference(int(method), C, V)
     info = vm.info()
     grid = int(info.nbr_entries) == int(info.n_points)  # the dense cell grid holds every map point once (the lists: 27 times)

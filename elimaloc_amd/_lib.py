@@ -126,7 +126,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void
 # every symbol include/elimaloc_hip.h declares (checked by the CPU test-suite)
 EXPORTS = [
     "elm_reg_config_default", "elm_ctx_create", "elm_ctx_destroy", "elm_last_error", "elm_strerror",
-    "elm_ctx_synchronize", "elm_ctx_stream", "elm_ctx_set_profiling", "elm_ctx_get_profile", "elm_map_build", "elm_map_destroy", "elm_map_cal_voxel_cov_all",
+    "elm_ctx_synchronize", "elm_ctx_stream", "elm_ctx_set_profiling", "elm_ctx_set_work_counters", "elm_ctx_get_profile", "elm_map_build", "elm_map_destroy", "elm_map_cal_voxel_cov_all",
     "elm_map_cal_point_cov_all", "elm_map_build_neighbourhoods", "elm_map_get_info", "elm_map_empty", "elm_map_download_points",
     "elm_map_download_voxels", "elm_map_find_ground_height", "elm_scan_upload", "elm_scan_destroy",
     "elm_scan_size", "elm_scan_download", "elm_register", "elm_register_batch", "elm_register_stream", "elm_register_stream_host", "elm_host_alloc", "elm_host_free", "elm_ctx_measure_h2d", "elm_register_batch_enqueue",
@@ -215,6 +215,7 @@ def lib():
     L.elm_ctx_stream.argtypes = [vp]
     L.elm_ctx_stream.restype = vp
     L.elm_ctx_set_profiling.argtypes = [vp, C.c_int]
+    L.elm_ctx_set_work_counters.argtypes = [vp, C.c_int]
     L.elm_ctx_get_profile.argtypes = [vp, C.POINTER(Profile), C.c_int]
     L.elm_map_build.argtypes = [vp, fp, C.c_size_t, C.c_double, C.c_int, C.POINTER(vp)]
     L.elm_map_destroy.argtypes = [vp]

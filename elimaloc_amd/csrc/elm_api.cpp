@@ -97,6 +97,8 @@ struct elm_ctx {
     std::vector<hipEvent_t> ev_groups; // host-fed streams: per upload group its "copied" and "ordered" events
     uint16_t* d_hilbert = nullptr; // Hilbert index of every cell of the ordering grid (kOrderCells^2 entries)
     DevBuf d_order_jobs, d_order_tmp, d_arena, d_raw, d_tickets;
+    bool work_counters = false; // elm_ctx_set_work_counters / ELM_WORK_COUNTERS=1: the accumulate launches also sum the work counters of
+                                // elm_reg_result (n_cand_total, n_occ_total, n_tested_total, fallback_blocks); off: those fields read 0
     bool fused_reduce = false; // ELM_FUSED_REDUCE=1: the accumulate kernels' last workgroups reduce the partial records (no reduce launch:
                                // accumulate -> [all-reduce] -> solve).  Off by default: measured on one GPU the write-through publish + ticket
                                // cost every workgroup more (accumulate +4 %) than the lighter solve saves: 83.7 k vs 86.5 k registrations/s
@@ -176,6 +178,22 @@ static int dev_reserve(elm_ctx* ctx, DevBuf& b, size_t bytes) {
     b.cap = cap;
     return ELM_OK;
 }
+// Host memory a large temporary may take: MemAvailable of /proc/meminfo (free + reclaimable page cache -- after a big PCD has been read
+// most of the RAM is page cache, and MemFree alone would refuse the grid depending on the cache state); unknown: no limit (the
+// allocations themselves fail with bad_alloc, which the builders handle).
+static uint64_t host_available_bytes() {
+    FILE* f = fopen("/proc/meminfo", "r");
+    if (!f) return ~0ull;
+    char line[256];
+    uint64_t kb = 0;
+    bool found = false;
+    while (fgets(line, sizeof(line), f)) {
+        unsigned long long v = 0;
+        if (sscanf(line, "MemAvailable: %llu kB", &v) == 1) { kb = v; found = true; break; }
+    }
+    fclose(f);
+    return found ? kb * 1024ull : ~0ull;
+}
 static int pinned_reserve(elm_ctx* ctx, void** p, size_t* cap, size_t bytes) {
     if (bytes <= *cap) return ELM_OK;
     if (*p) HIPCHK(ctx, hipHostFree(*p));
@@ -240,6 +258,7 @@ extern "C" int elm_ctx_create(int device_id, elm_ctx** out) {
     if (const char* k = getenv("ELM_KERNEL")) ctx->kernel_mode = (strcmp(k, "direct") == 0) ? 2 : (strcmp(k, "lists") == 0) ? 3 : 4;
     if (const char* o = getenv("ELM_SCAN_ORDER")) ctx->scan_order = (strcmp(o, "none") == 0) ? 0 : 1;
     if (const char* f = getenv("ELM_FUSED_REDUCE")) ctx->fused_reduce = strcmp(f, "0") != 0;
+    if (const char* f = getenv("ELM_WORK_COUNTERS")) ctx->work_counters = strcmp(f, "0") != 0;
     {
         std::lock_guard<std::mutex> lk(g_live_mu);
         ctx->id = g_next_ctx_id++;
@@ -283,6 +302,13 @@ extern "C" void elm_ctx_destroy(elm_ctx* ctx) {
 
 extern "C" const char* elm_last_error(const elm_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 extern "C" void* elm_ctx_stream(elm_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+extern "C" int elm_ctx_set_work_counters(elm_ctx* ctx, int enable) {
+    if (!ctx) return ELM_ERR_INVALID;
+    if (ctx->in_flight) return ELM_ERR_INVALID;
+    ctx->work_counters = enable != 0;
+    return ELM_OK;
+}
+
 extern "C" int elm_ctx_set_profiling(elm_ctx* ctx, int enable) {
     if (!ctx) return ELM_ERR_INVALID;
     ctx->profiling = enable != 0;
@@ -919,8 +945,7 @@ static int build_cell_grid_impl(elm_map* m, uint64_t max_cells) {
         const uint64_t dev_need = (cells + 4) * 4 + vcells * 4 + worst_blk * (sizeof(GridBlk) + 16) + (m->info.has_point_cov ? worst_blk * 4 * (m->want_gicp_compact ? 64 : 128) : 0);
         size_t dev_free = 0, dev_total = 0;
         HIPCHK(ctx, hipMemGetInfo(&dev_free, &dev_total));
-        const long pages = sysconf(_SC_AVPHYS_PAGES), psz = sysconf(_SC_PAGESIZE);
-        const uint64_t host_free = (pages > 0 && psz > 0) ? (uint64_t)pages * (uint64_t)psz : ~0ull;
+        const uint64_t host_free = host_available_bytes();
         if (host_need > host_free / 10 * 7 || dev_need > (uint64_t)dev_free / 10 * 8) {
             ctx->last_error = "cell grid: tables exceed the memory that is free (host " + std::to_string(host_need >> 20) + " MB, device " +
                               std::to_string(dev_need >> 20) + " MB needed)";
@@ -1104,8 +1129,7 @@ static int build_tiled_grid_impl(elm_map* m) {
         const uint64_t dev_need = (entries + 4) * 4 + n_tiles * 8 + worst_blk * (sizeof(GridBlk) + 16) + (m->info.has_point_cov ? worst_blk * 4 * (m->want_gicp_compact ? 64 : 128) : 0);
         size_t dev_free = 0, dev_total = 0;
         HIPCHK(ctx, hipMemGetInfo(&dev_free, &dev_total));
-        const long pages = sysconf(_SC_AVPHYS_PAGES), psz = sysconf(_SC_PAGESIZE);
-        const uint64_t host_free = (pages > 0 && psz > 0) ? (uint64_t)pages * (uint64_t)psz : ~0ull;
+        const uint64_t host_free = host_available_bytes();
         if (host_need > host_free / 10 * 7 || dev_need > (uint64_t)dev_free / 10 * 8) {
             ctx->last_error = "tiled cell grid: tables exceed the memory that is free";
             return ELM_ERR_UNSUPPORTED;
@@ -1770,6 +1794,7 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
     rp.max_iter = cfg->max_iteration;
     rp.uniform_blocks = uniform_blocks;
     rp.radar = radar ? 1 : 0;
+    rp.stats = ctx->work_counters ? 1 : 0;
     rp.radar_var[0] = cfg->range_variance_m;
     rp.radar_var[1] = cfg->azimuth_variance_deg;
     rp.radar_var[2] = cfg->elevation_variance_deg;
@@ -1995,6 +2020,7 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     rp.max_iter = cfg->max_iteration;
     rp.uniform_blocks = cap_blocks; // every slot owns cap_blocks workgroups
     rp.radar = 0;
+    rp.stats = ctx->work_counters ? 1 : 0;
     rp.radar_var[0] = rp.radar_var[1] = rp.radar_var[2] = 0.0;
     rp.sums = nullptr;
     rp.tickets = nullptr;
@@ -2131,7 +2157,7 @@ static void sync_all_streams(elm_ctx* ctx) {
 
 // elm_register_stream with the scans still in HOST memory when the call starts (the per-call contract of RunRegister, reg.cpp:274-290:
 // the caller hands over a point vector, not a device handle).  Three things overlap:
-//   copy stream    H2D of the packed xyz of the next group of scans into one of two staging sets (page-locked sources: one DMA per
+//   copy stream    H2D of the packed xyz of the next group of scans into one of kStageSets (3) staging sets (page-locked sources: one DMA per
 //                  group when the group is contiguous in host memory)
 //   order stream   k_scan_order over the group (staging -> the registration's own place in the arena, Hilbert order), then the
 //                  group's arrival is published in ctrl->ready
@@ -2241,6 +2267,7 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
     rp.max_iter = cfg->max_iteration;
     rp.uniform_blocks = cap_blocks;
     rp.radar = 0;
+    rp.stats = ctx->work_counters ? 1 : 0;
     rp.radar_var[0] = rp.radar_var[1] = rp.radar_var[2] = 0.0;
     rp.sums = nullptr;
     rp.tickets = nullptr;
@@ -2456,6 +2483,7 @@ static int downsample_enqueue(elm_ctx* ctx, const float* d_und, size_t n, double
     while (((size_t)1 << cap_log2) < 2 * std::max<size_t>(n, 1)) ++cap_log2;
     const size_t cap = (size_t)1 << cap_log2, nb = (n + 1023) / 1024;
     const size_t bytes = cap * 12 + std::max<size_t>(n, 1) * 4 + (nb + 1) * 4 + 64;
+    if (bytes > ctx->d_ds.cap) ctx->ds_clean_ptr = nullptr; // dev_reserve reallocates: fresh memory (even at the same address) is not "all ones"
     if ((rc = dev_reserve(ctx, ctx->d_ds, bytes)) != ELM_OK) return rc;
     if ((rc = dev_reserve(ctx, ctx->d_state, sizeof(ScanState) + 64)) != ELM_OK) return rc;
     char* base = (char*)ctx->d_ds.p;

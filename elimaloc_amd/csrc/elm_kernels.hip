@@ -877,27 +877,27 @@ __device__ __forceinline__ double pair_sum_value(const PairSum& P) {
     if (K == 31) return P.c31;
     return 0.0;
 }
-template <int H, int PP, int Q>
+template <int H, int PP, int Q, int NVAL>
 struct PairPassWriter {
     static __device__ __forceinline__ void run(const PairSum& P, double* buf, int tid) {
-        if (H * PP + Q < kSums) buf[Q * kBlock + tid] = pair_sum_value<H * PP + Q>(P);
-        PairPassWriter<H, PP, Q + 1>::run(P, buf, tid);
+        if (H * PP + Q < NVAL) buf[Q * kBlock + tid] = pair_sum_value<H * PP + Q>(P);
+        PairPassWriter<H, PP, Q + 1, NVAL>::run(P, buf, tid);
     }
 };
-template <int H, int PP>
-struct PairPassWriter<H, PP, PP> {
+template <int H, int PP, int NVAL>
+struct PairPassWriter<H, PP, PP, NVAL> {
     static __device__ __forceinline__ void run(const PairSum&, double*, int) {}
 };
-template <int PP, int H>
+template <int PP, int H, int NVAL>
 struct PairReducePass {
     static __device__ __forceinline__ void run(const PairSum& P, double* buf, double* red) {
         constexpr int LPV = kBlock / PP;
         const int tid = threadIdx.x;
         const int k = tid / LPV, seg = tid % LPV;
         if (H) __syncthreads();
-        PairPassWriter<H, PP, 0>::run(P, buf, tid);
+        PairPassWriter<H, PP, 0, NVAL>::run(P, buf, tid);
         __syncthreads();
-        if (H * PP + k < kSums) {
+        if (H * PP + k < NVAL) {
             double a = 0.0;
 #pragma unroll
             for (int i = 0; i < PP; ++i) a += buf[k * kBlock + i * LPV + seg];
@@ -908,17 +908,18 @@ struct PairReducePass {
             if (LPV == 32) a += __shfl_xor(a, 16, 64);
             if (seg == 0) red[H * PP + k] = a;
         }
-        PairReducePass<PP, H + 1>::run(P, buf, red);
+        PairReducePass<PP, H + 1, NVAL>::run(P, buf, red);
     }
 };
-template <int PP>
-struct PairReducePass<PP, (kSums + PP - 1) / PP> {
+template <int PP, int NVAL>
+struct PairReducePass<PP, (kSums + PP - 1) / PP, NVAL> {
     static __device__ __forceinline__ void run(const PairSum&, double*, double*) {}
 };
-// block_reduce_to_lds<kSums, PP> on the factored sums: same passes, same tree, same values
-template <int PP>
+// block_reduce_to_lds<NVAL, PP> on the factored sums (NVAL = kSums, or kSums - 3 without the work counters): same passes, same tree,
+// same values; red[NVAL .. kSums) is left untouched
+template <int PP, int NVAL = kSums>
 __device__ __forceinline__ void block_reduce_pair_sum(const PairSum& P, double* buf, double* red) {
-    PairReducePass<PP, 0>::run(P, buf, red);
+    PairReducePass<PP, 0, NVAL>::run(P, buf, red);
     __syncthreads();
 }
 // one pair into the factored form (add_pair_world's weight, threshold and residual rules)
@@ -1482,15 +1483,18 @@ __device__ __forceinline__ const uint32_t* col_cells(const DevMap& m, int cx, in
 #ifndef ELM_GICP_WAVES
 #define ELM_GICP_WAVES 5
 #endif
-template <int METHOD, int COMPACT, int TILED>
+// STATS = 1 (elm_ctx_set_work_counters): the launch also sums the three work counters (candidates / occupied buckets of the reference's
+// walk from the dense statistics box, candidates this kernel tested + points served by stage 2).  The production launches run with
+// STATS = 0: no statistics load, 18 (P2P) / 29 reduced values, no per-point bookkeeping in stage 2.
+template <int METHOD, int COMPACT, int TILED, int STATS>
 __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_GICP_WAVES)) void k_accumulate_grid(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
                                                                             unsigned total_blocks, const ScanState* __restrict__ st,
                                                                             double* __restrict__ partials, const RegParams rp) {
-    constexpr int NV = (METHOD == ELM_P2P) ? kP2PVals : kSums;
+    constexpr int NV = (METHOD == ELM_P2P) ? (STATS ? kP2PVals : kP2PVals - 3) : kSums;
     __shared__ double s_buf[kRedPass * kBlock]; // stage 2: the queue of undecided points; afterwards the reduction's transpose buffer
     __shared__ double s_red[kSums];
     __shared__ int s_res[kBlock];
-    __shared__ int s_tst[kBlock];
+    __shared__ int s_tst[STATS ? kBlock : 1];
     __shared__ unsigned s_cnt[kBlock / 64];
     const unsigned L = xcd_remap(blockIdx.x, total_blocks);
     const int s = find_scan(scans, batch, L, rp);
@@ -1535,7 +1539,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
         const GridAxis ax = grid_axis(gx, m), ay = grid_axis(gy, m), az = grid_axis(gz, m);
         // statistics of the reference's walk for this query voxel: candidates and occupied buckets among the 27
         unsigned stat = 0;
-        if (!TILED) { // (the two-level grid keeps no dense statistics box: its work counters read 0)
+        if (STATS && !TILED) { // (the two-level grid keeps no dense statistics box: its work counters read 0)
             const int ux = ax.f - m.vx0, uy = ay.f - m.vy0, uz = az.f - m.vz0;
             const bool in_box = (unsigned)ux < (unsigned)m.vnx && (unsigned)uy < (unsigned)m.vny && (unsigned)uz < (unsigned)m.vnz;
             const unsigned sidx = in_box ? ((unsigned)ux * (unsigned)m.vny + (unsigned)uy) * (unsigned)m.vnz + (unsigned)uz : 0u;
@@ -1881,11 +1885,17 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
                 }
                 win = need64 ? bk : win;
             }
-            walked = group_sum_int<LPI>(walked);
-            if (rl == 0 && live) { s_res[it] = win; s_tst[it] = walked; }
+            if (STATS) walked = group_sum_int<LPI>(walked);
+            if (rl == 0 && live) {
+                s_res[it] = win;
+                if (STATS) s_tst[it] = walked;
+            }
         }
         __syncthreads();
-        if (hard) { bj = s_res[my_slot]; n_tested += s_tst[my_slot]; }
+        if (hard) {
+            bj = s_res[my_slot];
+            if (STATS) n_tested += s_tst[my_slot];
+        }
         __syncthreads(); // the queue is dead: the reduction may overwrite it
     }
     if (valid) {
@@ -1916,7 +1926,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
         const double c_tested = (double)n_tested + (hard ? kFallbackUnit : 0.0); // high part: points served by stage 2
         if (METHOD == ELM_P2P) {
             if (bd2 < rp.th2) pair_p2p(v, S.Rinv, px, py, pz, ex, ey, ez, bd2, rp);
-            v[NV - 3] = c_cand; v[NV - 2] = c_occ; v[NV - 1] = c_tested;
+            if (STATS) { v[NV - 3] = c_cand; v[NV - 2] = c_occ; v[NV - 1] = c_tested; }
         } else {
             // finish_point_pair: no bucket at all -> the reference's default PointStruct at the origin with covariance I (QUIRK);
             // GICP's target position is the neighbourhood MEAN of the matched point (reg.cpp:97)
@@ -1953,12 +1963,13 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
                 pair_sum_single<ELM_GICP>(P, mean[0] - gx, mean[1] - gy, mean[2] - gz, Ci, nf, rp);
                 P.ax = gx - S.T[12]; P.ay = gy - S.T[13]; P.az = gz - S.T[14];
             }
-            P.c29 = c_cand; P.c30 = c_occ; P.c31 = c_tested;
+            if (STATS) { P.c29 = c_cand; P.c30 = c_occ; P.c31 = c_tested; }
         }
     }
     if (METHOD == ELM_P2P) block_reduce_to_lds<NV, kRedPass>(v, s_buf, s_red);
-    else block_reduce_pair_sum<kRedPass>(P, s_buf, s_red);
-    publish_and_reduce((threadIdx.x < kSums) ? ((METHOD == ELM_P2P) ? p2p_expand(s_red, (int)threadIdx.x) : s_red[threadIdx.x]) : 0.0, L, s, sd.blk_begin,
+    else block_reduce_pair_sum<kRedPass, STATS ? kSums : kSums - 3>(P, s_buf, s_red);
+    const int tk = (int)threadIdx.x;
+    publish_and_reduce((tk < kSums && (STATS || tk < kSums - 3)) ? ((METHOD == ELM_P2P) ? p2p_expand(s_red, tk) : s_red[tk]) : 0.0, L, s, sd.blk_begin,
                        sd.blk_end, partials, rp, s_buf);
 }
 
@@ -2087,7 +2098,7 @@ __global__ __launch_bounds__(64) void k_nbr_cellsort(const DevMap m, const int32
 #ifndef ELM_VNBR_WAVES
 #define ELM_VNBR_WAVES 1
 #endif
-template <int METHOD, int COMPACT>
+template <int METHOD, int COMPACT, int STATS>
 __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
                                                             unsigned total_blocks, const ScanState* __restrict__ st,
                                                             double* __restrict__ partials, const RegParams rp) {
@@ -2219,9 +2230,7 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
                 P.ax = gx - S.T[12]; P.ay = gy - S.T[13]; P.az = gz - S.T[14];
             }
             (void)px; (void)py; (void)pz;
-            P.c29 = (double)cnt;
-            P.c30 = (double)cnt;
-            P.c31 = (double)cnt;
+            if (STATS) { P.c29 = (double)cnt; P.c30 = (double)cnt; P.c31 = (double)cnt; }
         } else {
             // AVGICP, GetCorrespondencesAllCov (vhm.cpp:153-206): every existing FACE neighbour (and the voxel itself) whose
             // mean is within range is a pair of its own.  The records carry the neighbour's position code (dx+1)*9+(dy+1)*3+
@@ -2263,13 +2272,11 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
             P.b[0] = Q.b[0]; P.b[1] = Q.b[1]; P.b[2] = Q.b[2];
             P.rsum = Q.rsum; P.n = Q.n;
             P.ax = gx - S.T[12]; P.ay = gy - S.T[13]; P.az = gz - S.T[14];
-            P.c29 = n_pairs;
-            P.c30 = n_pairs;
-            P.c31 = n_pairs;
+            if (STATS) { P.c29 = n_pairs; P.c30 = n_pairs; P.c31 = n_pairs; }
         }
     }
-    block_reduce_pair_sum<kRedPass>(P, s_buf, s_red);
-    publish_and_reduce((threadIdx.x < kSums) ? s_red[threadIdx.x] : 0.0, L, s, sd.blk_begin, sd.blk_end, partials, rp, s_buf);
+    block_reduce_pair_sum<kRedPass, STATS ? kSums : kSums - 3>(P, s_buf, s_red);
+    publish_and_reduce((threadIdx.x < (STATS ? kSums : kSums - 3)) ? s_red[threadIdx.x] : 0.0, L, s, sd.blk_begin, sd.blk_end, partials, rp, s_buf);
 }
 
 __global__ __launch_bounds__(256) void k_vnbr_fill(const DevMap m, const int32_t* __restrict__ qkeys, unsigned n_q,
@@ -3134,7 +3141,11 @@ void launch_accumulate_cell(hipStream_t s, const DevMap& m, const ScanDesc* scan
 void launch_accumulate_grid(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                             ScanState* st, double* partials, const RegParams& rp) {
     dim3 g(total_blocks), b(kBlock);
-#define ELM_LAUNCH_G(M, C, T) hipLaunchKernelGGL((k_accumulate_grid<M, C, T>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp)
+#define ELM_LAUNCH_G(M, C, T)                                                                                                                        \
+    do {                                                                                                                                          \
+        if (rp.stats) hipLaunchKernelGGL((k_accumulate_grid<M, C, T, 1>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp); \
+        else hipLaunchKernelGGL((k_accumulate_grid<M, C, T, 0>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);          \
+    } while (0)
     if (rp.method == ELM_P2P) { if (m.grid_tiled) ELM_LAUNCH_G(ELM_P2P, 0, 1); else ELM_LAUNCH_G(ELM_P2P, 0, 0); }
     else if (m.gicp_compact) { if (m.grid_tiled) ELM_LAUNCH_G(ELM_GICP, 1, 1); else ELM_LAUNCH_G(ELM_GICP, 1, 0); }
     else { if (m.grid_tiled) ELM_LAUNCH_G(ELM_GICP, 0, 1); else ELM_LAUNCH_G(ELM_GICP, 0, 0); }
@@ -3152,7 +3163,11 @@ void launch_vox_stat(hipStream_t s, const DevMap& m, uint32_t* out) {
 int stream_max_slots() { return kMaxSlots; }
 void launch_accumulate_vnbr(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                             ScanState* st, double* partials, const RegParams& rp) {
-#define ELM_LAUNCH_V(M, C) hipLaunchKernelGGL((k_accumulate_vnbr<M, C>), dim3(total_blocks), dim3(kBlock), 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp)
+#define ELM_LAUNCH_V(M, C)                                                                                                                                                \
+    do {                                                                                                                                                                  \
+        if (rp.stats) hipLaunchKernelGGL((k_accumulate_vnbr<M, C, 1>), dim3(total_blocks), dim3(kBlock), 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp); \
+        else hipLaunchKernelGGL((k_accumulate_vnbr<M, C, 0>), dim3(total_blocks), dim3(kBlock), 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);          \
+    } while (0)
     if (rp.method == ELM_VGICP) { if (m.vox_compact) ELM_LAUNCH_V(ELM_VGICP, 1); else ELM_LAUNCH_V(ELM_VGICP, 0); }
     else { if (m.vox_compact) ELM_LAUNCH_V(ELM_AVGICP, 1); else ELM_LAUNCH_V(ELM_AVGICP, 0); }
 #undef ELM_LAUNCH_V

@@ -72,6 +72,10 @@ class Context:
     def stream(self):
         return _lib.lib().elm_ctx_stream(self._h)
 
+    def set_work_counters(self, on=True):
+        """n_cand_total / n_occ_total / n_tested_total / fallback_blocks of the results: off by default (they read 0), on = instrumented kernels."""
+        check(_lib.lib().elm_ctx_set_work_counters(self._h, int(bool(on))), self._h, "elm_ctx_set_work_counters")
+
     def set_profiling(self, on=True):
         check(_lib.lib().elm_ctx_set_profiling(self._h, int(bool(on))), self._h, "elm_ctx_set_profiling")
 

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <utility>
 #include <stdexcept>
+#include <iostream>
 #include <vector>
 
 #include "voxel_hash_map.hpp"
@@ -74,12 +75,20 @@ struct Registration {
         bool same = true;
         for (size_t i = 0; i < source_local.size(); ++i)
             for (int k = 0; k < 3; ++k) {
-                scratch_xyz_[3 * i + k] = (float)source_local[i].pose(k);
-                same = same && source_local[i].local(k) == source_local[i].pose(k);
+                const double a = source_local[i].local(k), b = source_local[i].pose(k);
+                scratch_xyz_[3 * i + k] = (float)b;
+                // a NaN return (the node does not remove them: FilterPointsByDistance keeps a point whose range is NaN) is "the same"
+                // in both fields; the reference pairs such a point with nothing (every comparison with its distance is false)
+                same = same && (a == b || (a != a && b != b));
             }
-        if (!same)
-            throw std::invalid_argument("RunRegister: PointStruct.local must equal PointStruct.pose (pcm_matching.hpp:205-220); "
-                                        "see INTEGRATION.md, interface differences");
+        if (!same) {
+            // the reference reports nothing but is_success (no exceptions, no error codes): refuse the same way
+            std::cerr << "[elimaloc] RunRegister: PointStruct.local must equal PointStruct.pose (pcm_matching.hpp:205-220; INTEGRATION.md, "
+                         "interface differences) -- registration refused" << std::endl;
+            is_success = false;
+            local_cov = elimaloc::Matrix6d::Identity();
+            return initial_guess;
+        }
         const elm_reg_config c = m_config.c_struct();
         elimaloc::Matrix4d T;
         int ok = 0;

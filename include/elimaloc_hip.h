@@ -91,8 +91,9 @@ typedef struct elm_reg_result {
     int32_t gate;       /* 0 none, 1 empty map, 2 overlap ratio (reg.cpp:352), 3 fitness (reg.cpp:405) */
     int32_t _pad;
     double n_corr_last; /* correspondences of the last executed iteration */
-    /* work counters summed over the executed iterations (for the algorithmic-bytes model) */
     double point_iterations; /* scan points processed x iterations */
+    /* work counters summed over the executed iterations (for the algorithmic-bytes model): 0 unless
+     * elm_ctx_set_work_counters(ctx, 1) */
     double n_cand_total;     /* candidate map points (P2P/GICP) or voxel means (VGICP/AVGICP) distance-tested */
     double n_occ_total;      /* occupied neighbour voxels visited */
     double fallback_blocks;  /* workgroup launches that took the un-staged path */
@@ -136,6 +137,10 @@ typedef struct elm_profile {
     double solve_ms;      /* sum of the reduce/solve (+ all-reduce, + slot refill) spans */
 } elm_profile;
 int elm_ctx_set_profiling(elm_ctx* ctx, int enable);
+/* Work counters of elm_reg_result (n_cand_total, n_occ_total, n_tested_total, fallback_blocks): OFF by default -- the registration
+ * launches then carry no instrumentation and those fields read 0; on (or ELM_WORK_COUNTERS=1 in the environment): the same kernels with
+ * the counters compiled in (~1 % slower).  poses, flags, iteration counts and point_iterations do not depend on the switch. */
+int elm_ctx_set_work_counters(elm_ctx* ctx, int enable);
 int elm_ctx_get_profile(elm_ctx* ctx, elm_profile* out, int reset);
 
 /* ---------------------------------------------------------------- map ----------------------------- */
@@ -209,7 +214,8 @@ int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* const* scans
  * stream, in groups of ~32 MB), the device-side ordering kernel and the ICP iterations of the registrations that have already
  * arrived overlap; a slot starts a registration as soon as its scan has landed.  Page-locked sources (elm_host_alloc or
  * hipHostRegister) are read by the DMA engines directly and reach the PCIe rate; pageable ones are staged by the runtime.  HBM
- * needed: every scan of the call (12 bytes per point) + two staging sets.  Results are bit-identical to elm_register_stream on
+ * needed: every scan of the call (12 bytes per point) + THREE staging sets of one upload group (~32 MB of packed xyz) each + 4 bytes
+ * per staged point of ordering scratch.  Results are bit-identical to elm_register_stream on
  * the same scans uploaded with elm_scan_upload.  One rank only: ELM_ERR_UNSUPPORTED with a communicator or hook attached. */
 int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const float* const* scan_xyz, const uint32_t* n_pts, int count,
                              const double* T0, const elm_reg_config* cfg, int slots, elm_reg_result* results, elm_iter_trace* trace);

@@ -124,10 +124,25 @@ def _tie_sensitive_points(om, scan, T, method, th, eps=2e-9):
     return int(flips.sum())
 
 
-def _compare_run(gpu, ref, om=None, scan=None, method=None, th=5.0):
+FORGIVEN = []  # (iteration, tie-sensitive points, max |dJTJ| / scale) of every tie-sensitive iteration a comparison went through
+MAX_FORGIVEN = 6  # over the whole session: more than a handful means the rule is hiding something
+
+
+def _assert_iter_close(g, r, k):
+    scale = np.abs(r["JTJ"]).max()
+    np.testing.assert_allclose(g["JTJ"], r["JTJ"], rtol=0, atol=SUM_RTOL * scale, err_msg=f"JTJ iter {k}")
+    np.testing.assert_allclose(g["JTr"], r["JTr"], rtol=0, atol=SUM_RTOL * max(np.abs(r["JTr"]).max(), scale * 1e-3), err_msg=f"JTr iter {k}")
+    np.testing.assert_allclose(g["residual_sum"], r["residual_sum"], rtol=SUM_RTOL)
+    np.testing.assert_allclose(g["T"], r["T"], rtol=0, atol=1e-9)
+
+
+def _compare_run(gpu, ref, om=None, scan=None, method=None, th=5.0, ocfg=None, oracle_mod=None):
     """Per-iteration comparison of a device trajectory with the oracle's.  With the oracle map and the scan at hand the check is
-    tie-aware: a difference of the sums at an iteration k >= 1 is accepted only if the scan really has points on a bisector of two
-    candidates at that iteration's pose (the documented sensitivity: DESIGN.md section 5) -- and the poses still agree."""
+    tie-aware: a difference of the sums at an iteration k >= 1 is accepted only if (i) the scan really has points on a bisector of
+    two candidates at that iteration's pose (the documented sensitivity: DESIGN.md section 5), (ii) the difference is no larger than
+    those points swapping their pairs could make it, and (iii) -- with the oracle's configuration at hand -- the oracle RE-SEEDED
+    with the device's own pose before iteration k reproduces the device's remaining iterations to the usual 1e-9.  Every accepted
+    iteration is counted (FORGIVEN, printed in the terminal summary) and the session fails beyond MAX_FORGIVEN."""
     assert gpu["iterations"] == ref["iterations"]
     assert gpu["is_success"] == ref["is_success"]
     assert gpu["gate"] == ref["gate"]
@@ -135,20 +150,36 @@ def _compare_run(gpu, ref, om=None, scan=None, method=None, th=5.0):
         assert g["n_corr"] == r["n_corr"], f"iteration {k}: correspondence count"
         if ref["gate"] == 2 and k == ref["iterations"] - 1:
             break
-        scale = np.abs(r["JTJ"]).max()
         try:
-            np.testing.assert_allclose(g["JTJ"], r["JTJ"], rtol=0, atol=SUM_RTOL * scale, err_msg=f"JTJ iter {k}")
-            np.testing.assert_allclose(g["JTr"], r["JTr"], rtol=0, atol=SUM_RTOL * max(np.abs(r["JTr"]).max(), scale * 1e-3),
-                                       err_msg=f"JTr iter {k}")
-            np.testing.assert_allclose(g["residual_sum"], r["residual_sum"], rtol=SUM_RTOL)
-            np.testing.assert_allclose(g["T"], r["T"], rtol=0, atol=1e-9)
+            _assert_iter_close(g, r, k)
         except AssertionError:
             if k == 0 or om is None or scan is None:
                 raise
             T_prev = ref["iters"][k - 1]["T"]
-            if _tie_sensitive_points(om, scan, T_prev, int(method), th) == 0:
+            n_tie = _tie_sensitive_points(om, scan, T_prev, int(method), th)
+            if n_tie == 0:
                 raise
-            break  # tie-sensitive from here on: only the final pose is comparable
+            # (ii) a tie point swaps one pair for another: each side contributes at most w |M| (1 + |p|^2) to an entry of JTJ
+            # (w <= 1; |M| = 1 for P2P, <= 1000 for the regularised covariances)
+            pmax2 = float((scan.astype(np.float64) ** 2).sum(axis=1).max())
+            bound = 2.0 * n_tie * (1.0 if int(method) == 0 else 1000.0) * (1.0 + pmax2)
+            gap = float(np.abs(g["JTJ"] - r["JTJ"]).max())
+            assert gap <= bound, f"iteration {k}: |dJTJ| {gap:.3g} exceeds what {n_tie} tie points can explain ({bound:.3g})"
+            FORGIVEN.append((k, n_tie, gap / max(float(np.abs(r["JTJ"]).max()), 1e-300)))
+            assert len(FORGIVEN) <= MAX_FORGIVEN, f"too many tie-sensitive iterations forgiven: {FORGIVEN}"
+            if ocfg is not None and oracle_mod is not None:
+                # (iii) the oracle from the device's own pose: same tie picks, so the rest of the trajectory must match again
+                c2 = type(ocfg).from_buffer_copy(ocfg)
+                c2.max_iteration = int(ocfg.max_iteration) - k
+                ref2 = oracle_mod.register(om, scan, gpu["iters"][k - 1]["T"], c2)
+                assert ref2["iterations"] == gpu["iterations"] - k
+                for j, r2 in enumerate(ref2["iters"]):
+                    g2 = gpu["iters"][k + j]
+                    assert g2["n_corr"] == r2["n_corr"], f"re-seeded oracle, iteration {k + j}: correspondence count"
+                    if ref2["gate"] == 2 and j == ref2["iterations"] - 1:
+                        break
+                    _assert_iter_close(g2, r2, k + j)
+            break  # tie-sensitive from here on against the ORIGINAL oracle run: only the final pose is comparable
     dt, dr = synth.pose_error(ref["T"], gpu["T"])
     assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
     if ref["is_success"]:
@@ -561,6 +592,7 @@ def test_exact_ties_follow_the_reference_visiting_order(oracle, method, kernel_e
     from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod
     _set_kernel_env(monkeypatch, kernel_env)
     c = Context(0)
+    c.set_work_counters(True)  # fallback_blocks below
     try:
         lattice, scan = _tie_world()
         m = IcpMethod(method)
@@ -681,8 +713,9 @@ def _randomized_case(ctx, oracle, seed):
     T0 = synth.perturb(T_true, seed=1300 + seed, max_trans=float(rng.choice([0.01, 0.1, 0.3, 0.5])), max_rot_deg=float(rng.choice([0.1, 1.0, 2.0])))
     cfg = RegistrationConfig(icp_method=method, max_search_dist=th, max_iteration=8)
     *_, det = Registration(cfg, ctx).RunRegister(scan, vm, T0, trace=True)
-    ref = oracle.register(om, scan, T0, oracle.default_config(int(method), max_search_dist=th, max_iteration=8))
-    _compare_run(det, ref, om=om, scan=scan, method=method, th=th)
+    ocfg = oracle.default_config(int(method), max_search_dist=th, max_iteration=8)
+    ref = oracle.register(om, scan, T0, ocfg)
+    _compare_run(det, ref, om=om, scan=scan, method=method, th=th, ocfg=ocfg, oracle_mod=oracle)
 
 
 @pytest.mark.parametrize("seed", range(32))

@@ -6,6 +6,7 @@ import numpy as np
 from elimaloc_amd import synth
 from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, Scan, VoxelHashMap, results_from_raw
 ctx = Context(0)
+ctx.set_work_counters(True)
 world = synth.make_world(10_000_000, seed=1001)
 vm = VoxelHashMap(1.0, 30, ctx); vm.AddPoints(world)
 reg = Registration(RegistrationConfig(icp_method=IcpMethod.P2P), ctx)

@@ -18,6 +18,7 @@ ap.add_argument("--term", type=float, default=0.02)
 ap.add_argument("--slots", type=int, default=0, help=">0: continuous batching (elm_register_stream) with that many slots")
 a = ap.parse_args()
 ctx = Context(0)
+ctx.set_work_counters(True)
 world = synth.make_world(a.map_points, seed=1001)
 vm = VoxelHashMap(1.0, 30, ctx); vm.AddPoints(world)
 m = IcpMethod(a.method)
