@@ -404,7 +404,7 @@ def main():
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_path):
         try:
-            pm = json.load(open(pmc_path)).get(kernel_name)
+            pm = json.load(open(pmc_path)).get(kernel_name + ("@hard" if args.guess == "hard" else ""))
             # a counter pass speaks for THIS run only if it was taken at this operating point: same scan / map size, guess set, registrations
             # per step and slots (the launch mix -- live slots per launch, draining launches -- follows from those); otherwise the line falls
             # back to the compulsory HBM stream and says so

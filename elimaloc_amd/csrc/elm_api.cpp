@@ -93,6 +93,10 @@ struct elm_ctx {
     hipStream_t stream = nullptr;
     // host-fed streams / ordered uploads: uploads (DMA) and the scan-ordering kernel run beside the iterations on the compute stream
     hipStream_t copy_stream = nullptr, order_stream = nullptr, poll_stream = nullptr;
+    hipStream_t solve_stream = nullptr; // half-set streams: the solve side (reduce -> all-reduce -> solve + refill) of one half of the slots runs
+                                        // here, under the other half's accumulate launch on the compute stream
+    std::vector<hipEvent_t> ev_halves;  // its cross-stream events (never re-recorded while a wait on them may be pending: one pair per half-iteration)
+    int half_sets = 1;                  // ELM_HALF_SETS=0: one set of slots, everything on the compute stream (developer A/B)
     hipEvent_t ev_iter[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ev_groups; // host-fed streams: per upload group its "copied" and "ordered" events
     uint16_t* d_hilbert = nullptr; // Hilbert index of every cell of the ordering grid (kOrderCells^2 entries)
@@ -259,6 +263,7 @@ extern "C" int elm_ctx_create(int device_id, elm_ctx** out) {
     if (const char* o = getenv("ELM_SCAN_ORDER")) ctx->scan_order = (strcmp(o, "none") == 0) ? 0 : 1;
     if (const char* f = getenv("ELM_FUSED_REDUCE")) ctx->fused_reduce = strcmp(f, "0") != 0;
     if (const char* f = getenv("ELM_WORK_COUNTERS")) ctx->work_counters = strcmp(f, "0") != 0;
+    if (const char* f = getenv("ELM_HALF_SETS")) ctx->half_sets = strcmp(f, "0") != 0 ? 1 : 0;
     {
         std::lock_guard<std::mutex> lk(g_live_mu);
         ctx->id = g_next_ctx_id++;
@@ -277,7 +282,8 @@ extern "C" void elm_ctx_destroy(elm_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm && g_rccl.comm_destroy) g_rccl.comm_destroy(ctx->comm);
-    for (hipStream_t st : {ctx->copy_stream, ctx->order_stream, ctx->poll_stream})
+    for (hipEvent_t e : ctx->ev_halves) (void)hipEventDestroy(e);
+    for (hipStream_t st : {ctx->copy_stream, ctx->order_stream, ctx->poll_stream, ctx->solve_stream})
         if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (hipEvent_t e : {ctx->ev_iter[0], ctx->ev_iter[1], ctx->ev_iter[2], ctx->ev_iter[3]})
         if (e) (void)hipEventDestroy(e);
@@ -1660,9 +1666,10 @@ extern "C" int elm_scan_download(const elm_scan* s, float* xyz, size_t cap) {
 // ------------------------------------------------------------------------------------------------------
 // registration
 // ------------------------------------------------------------------------------------------------------
-static int exchange(elm_ctx* ctx, double* d_sums, size_t count) {
+static int exchange(elm_ctx* ctx, double* d_sums, size_t count, hipStream_t stream = nullptr) {
+    if (!stream) stream = ctx->stream;
     if (ctx->hook) {
-        int rc = ctx->hook(d_sums, count, (void*)ctx->stream, ctx->hook_user);
+        int rc = ctx->hook(d_sums, count, (void*)stream, ctx->hook_user);
         if (rc != 0) {
             ctx->last_error = "allreduce hook failed";
             return ELM_ERR_COMM;
@@ -1671,7 +1678,7 @@ static int exchange(elm_ctx* ctx, double* d_sums, size_t count) {
     }
     if (ctx->comm) {
         // ONE sum all-reduce of the packed normal equations of the whole batch per ICP iteration
-        int rc = g_rccl.all_reduce(d_sums, d_sums, count, /*ncclDouble*/ 8, /*ncclSum*/ 0, ctx->comm, ctx->stream);
+        int rc = g_rccl.all_reduce(d_sums, d_sums, count, /*ncclDouble*/ 8, /*ncclSum*/ 0, ctx->comm, stream);
         if (rc != 0) {
             ctx->last_error = std::string("ncclAllReduce: ") + (g_rccl.get_error_string ? g_rccl.get_error_string(rc) : "error");
             return ELM_ERR_COMM;
@@ -1686,10 +1693,10 @@ static bool radar_path(const elm_reg_config* cfg) { return cfg->use_radar_cov !=
 // One ICP iteration's correspondence + accumulation launch for `n_scans` scans / slots, bracketed by two profiling marks (the
 // solve span starts at the second).
 static int enqueue_accumulate(elm_ctx* ctx, const elm_map* map, const ScanDesc* dsc, int n_scans, uint32_t blocks, ScanState* st,
-                              const RegParams& rp, bool use_grid, bool use_cells, bool use_vnbr) {
+                              const RegParams& rp, bool use_grid, bool use_cells, bool use_vnbr, double* partials = nullptr) {
     int rc;
     if ((rc = prof_mark(ctx)) != ELM_OK) return rc;
-    double* partials = (double*)ctx->d_partials.p;
+    if (!partials) partials = (double*)ctx->d_partials.p;
     if (blocks) {
         if (rp.radar) launch_accumulate_radar(ctx->stream, map->dm, dsc, n_scans, (int)blocks, st, partials, rp);
         else if (use_grid) launch_accumulate_grid(ctx->stream, map->dm, dsc, n_scans, (int)blocks, st, partials, rp);
@@ -1978,9 +1985,17 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     StreamCtrl* hc = (StreamCtrl*)((char*)ctx->h_desc + q_bytes + t_bytes + d_bytes);
     for (int b = 0; b < count; ++b) { hq[b].pts = scans[b]->d_pts; hq[b].n = scans[b]->n; hq[b].n_total = scans[b]->n_total; }
     memcpy(hT, T0, t_bytes);
+    // Half-sets: the slots are split into two halves that alternate on the compute stream; the solve side of a half (reduce ->
+    // all-reduce -> solve + refill: three small launches and the collective) runs on a second, high-priority stream UNDER the other
+    // half's accumulate launch, so neither the collective's latency nor the solve is exposed.  The accumulate launches stay on ONE
+    // stream, back to back (their hipEvent brackets time one kernel at a time).  Each half is a stream of its own in everything but the
+    // queue: its descriptors' workgroup ranges and its partial records start at zero.
+    const int H = (ctx->half_sets && S >= 16) ? 2 : 1;
+    const int S0 = (H == 2) ? (S + 1) / 2 : S; // slots of half 0; half 1: S - S0
     for (int s = 0; s < S; ++s) {
+        const uint32_t rel = (uint32_t)(s < S0 ? s : s - S0);
         hd[s].pts = nullptr; hd[s].n = 0; hd[s].n_total = 0;
-        hd[s].blk_begin = cap_blocks * (uint32_t)s; hd[s].blk_end = cap_blocks * (uint32_t)(s + 1);
+        hd[s].blk_begin = cap_blocks * rel; hd[s].blk_end = cap_blocks * (rel + 1);
     }
     hc->next = 0; hc->completed = 0; hc->total = count; hc->ready = count;
     if ((rc = dev_reserve(ctx, ctx->d_scans, d_bytes)) != ELM_OK) return rc;
@@ -2053,28 +2068,74 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     const int hard_limit = ((count + S - 1) / S + 1) * cfg->max_iteration;
     const bool same_shape = ctx->stream_hint_count == count && ctx->stream_hint_slots == S;
     const int predicted = same_shape ? ctx->stream_hint_iters : 0;
+    if (H == 2 && !ctx->solve_stream) {
+        int lo = 0, hi = 0;
+        HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->solve_stream, hipStreamNonBlocking, hi)); // its few workgroups go ahead of the accumulate's
+    }
+    size_t ev_used = 0;
+    auto half_event = [&](hipEvent_t* out) -> int { // a fresh event per use: re-recording one that still has a pending wait loses stream order here
+        if (ev_used == ctx->ev_halves.size()) {
+            hipEvent_t e;
+            HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->ev_halves.push_back(e);
+        }
+        *out = ctx->ev_halves[ev_used++];
+        return ELM_OK;
+    };
+    hipEvent_t solved[2] = {nullptr, nullptr}; // the half's previous solve (its next accumulate waits for it)
     int it = 0;
     for (; it < hard_limit; ++it) {
-        if ((rc = enqueue_accumulate(ctx, map, dsc, S, blocks, st, rp, use_grid, use_cells, use_vnbr)) != ELM_OK) return rc;
-        if (distributed) {
-            if (!rp.tickets) launch_solve(ctx->stream, dsc, S, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 1, d_active);
-            if ((rc = exchange(ctx, (double*)ctx->d_sums.p, (size_t)S * kSums)) != ELM_OK) return rc;
-            // the solve also refills: slot s serves the registrations s, s + S, s + 2 S, ... -- a function of the slot alone, so every
-            // rank hands out the same registrations without a refill launch (3 launches + 1 collective per iteration)
-            const StreamArgs sr = {dsc, d_q, d_qT0, d_out, d_ctrl, 0, S};
-            launch_solve(ctx->stream, dsc, S, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 2, d_active, &sr);
-        } else {
-            // single rank: the solve hands finished slots their next registration itself (no refill launch)
-            const StreamArgs sa = {dsc, d_q, d_qT0, d_out, d_ctrl, 0, 0};
-            launch_solve(ctx->stream, dsc, S, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 0, d_active, &sa);
+        for (int h = 0; h < H; ++h) {
+            const int base = h ? S0 : 0, Sh = h ? S - S0 : S0;
+            const uint32_t blocks_h = cap_blocks * (uint32_t)Sh;
+            ScanDesc* dsc_h = dsc + base;
+            ScanState* st_h = st + base;
+            double* partials_h = (double*)ctx->d_partials.p + (size_t)cap_blocks * (size_t)base * kSums;
+            double* sums_h = (double*)ctx->d_sums.p + (size_t)base * kSums;
+            RegParams rph = rp;
+            if (rp.tickets) { rph.sums = sums_h; rph.tickets = rp.tickets + base; }
+            hipStream_t ss = ctx->stream;
+            if (H == 2) {
+                ss = ctx->solve_stream;
+                if (solved[h]) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, solved[h], 0));
+            }
+            if ((rc = enqueue_accumulate(ctx, map, dsc_h, Sh, blocks_h, st_h, rph, use_grid, use_cells, use_vnbr, partials_h)) != ELM_OK) return rc;
+            if (H == 2) {
+                hipEvent_t acc_done;
+                if ((rc = half_event(&acc_done)) != ELM_OK) return rc;
+                HIPCHK(ctx, hipEventRecord(acc_done, ctx->stream));
+                HIPCHK(ctx, hipStreamWaitEvent(ss, acc_done, 0));
+            }
+            if (distributed) {
+                if (!rp.tickets) launch_solve(ss, dsc_h, Sh, st_h, partials_h, sums_h, rph, d_trace, 1, d_active);
+                if ((rc = exchange(ctx, sums_h, (size_t)Sh * kSums, ss)) != ELM_OK) return rc;
+                // the solve also refills: slot s serves the registrations s, s + S, s + 2 S, ... -- a function of the slot alone, so every
+                // rank hands out the same registrations without a refill launch (3 launches + 1 collective per iteration)
+                const StreamArgs sr = {dsc_h, d_q, d_qT0, d_out, d_ctrl, 0, S};
+                launch_solve(ss, dsc_h, Sh, st_h, partials_h, sums_h, rph, d_trace, 2, d_active, &sr);
+            } else {
+                // single rank: the solve hands finished slots their next registration itself (no refill launch)
+                const StreamArgs sa = {dsc_h, d_q, d_qT0, d_out, d_ctrl, 0, 0};
+                launch_solve(ss, dsc_h, Sh, st_h, partials_h, sums_h, rph, d_trace, 0, d_active, &sa);
+            }
+            if (H == 2) {
+                if ((rc = half_event(&solved[h])) != ELM_OK) return rc;
+                HIPCHK(ctx, hipEventRecord(solved[h], ss));
+            }
         }
         const int done_iters = it + 1;
         const bool look = predicted > 0 ? done_iters >= predicted : (done_iters >= (count + S - 1) / S && (done_iters % 2) == 0);
         if (look) {
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_active, &d_ctrl->completed, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            hipStream_t ls = (H == 2) ? ctx->solve_stream : ctx->stream; // both halves' solves of this iteration are queued there
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_active, &d_ctrl->completed, sizeof(int), hipMemcpyDeviceToHost, ls));
+            HIPCHK(ctx, hipStreamSynchronize(ls));
             if (*ctx->h_active == count) { ++it; break; }
         }
+    }
+    if (H == 2) { // the result download below is queued behind the last solves
+        for (int h = 0; h < 2; ++h)
+            if (solved[h]) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, solved[h], 0));
     }
     if ((rc = prof_mark(ctx)) != ELM_OK) return rc;
     HIPCHK(ctx, hipGetLastError());

@@ -655,11 +655,21 @@ def test_stream_many_registrations_refilled_in_the_solve(ctx, oracle, world100k)
     batch = reg.RunRegisterBatch(scans, vm, T0s)
     assert any(not b["is_success"] for b in batch) and any(b["is_success"] for b in batch)
     assert len({b["iterations"] for b in batch}) > 3
-    for slots in (7, 7, 32):
-        out = reg.RunRegisterStream(scans, vm, T0s, slots=slots)
+    # 7 slots: one set on the compute stream; 32 and 17: two half-sets (16 + 16, 9 + 8) whose solve side runs on a second stream under
+    # the other half's accumulate launch; the last round with an identity exchange hook = the multi-rank control flow (reduce-only
+    # launch -> exchange -> solve-only launch with the static per-slot queue) on the half-set streams
+    calls = []
+    for slots, hooked in ((7, False), (7, False), (32, False), (17, False), (17, True), (32, True)):
+        if hooked:
+            ctx.set_allreduce_hook(lambda p, n, s: (calls.append(n), 0)[1])
+        try:
+            out = reg.RunRegisterStream(scans, vm, T0s, slots=slots)
+        finally:
+            ctx.set_allreduce_hook(None)
         for k, (a, b) in enumerate(zip(out, batch)):
-            assert (a["iterations"], a["is_success"], a["gate"]) == (b["iterations"], b["is_success"], b["gate"]), k
-            assert np.array_equal(a["T"], b["T"]) and a["n_corr_last"] == b["n_corr_last"], k
+            assert (a["iterations"], a["is_success"], a["gate"]) == (b["iterations"], b["is_success"], b["gate"]), (slots, hooked, k)
+            assert np.array_equal(a["T"], b["T"]) and a["n_corr_last"] == b["n_corr_last"], (slots, hooked, k)
+    assert set(calls) == {9 * 32, 8 * 32, 16 * 32}  # one exchange per half per iteration, slots x 32 doubles each
 
 
 def test_stream_through_exchange_hook(ctx, oracle, world100k):
@@ -825,6 +835,7 @@ def _run_two_ranks(world, full, T0s, m, stream, slots=3, cov_dist=0.4):
     from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, Scan, VoxelHashMap
     hip = C.CDLL("libamdhip64.so")
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
     barrier = threading.Barrier(2)
     bufs, results, errors = [None, None], [None, None], []
 
@@ -843,7 +854,7 @@ def _run_two_ranks(world, full, T0s, m, stream, slots=3, cov_dist=0.4):
                 scans.append(Scan(ctx, s[lo:hi], n_total=len(s)))
 
             def hook(ptr, n, hip_stream):
-                ctx.synchronize()
+                assert hip.hipStreamSynchronize(C.c_void_p(hip_stream)) == 0  # the stream the reduce launch was queued on (half-set streams: not the context's)
                 mine = np.empty(n, np.float64)
                 assert hip.hipMemcpy(mine.ctypes.data, ptr, n * 8, 2) == 0  # device -> host
                 bufs[r] = mine

@@ -2,10 +2,12 @@
 // roofline is quoted from (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, SQ_BUSY_CYCLES) read for a kernel whose issue rate is KNOWN?
 //
 // Every kernel is a loop over one block of 32 instructions of ONE class on 8 independent accumulators (no dependent pair closer than
-// 8 instructions), bracketed by s_memtime (shader cycles).  It is launched so that every SIMD of the chip holds exactly W waves
+// 8 instructions), bracketed by s_memtime.  (s_memtime is a CONSTANT-rate counter on this chip, not the shader clock: the first run read
+// 2.0 shader cycles -- GRBM_GUI_ACTIVE / 8 of the same launch -- per tick at the ~2.05 GHz the kernels ran at; the columns below are in
+// ticks, the counter table of run_valu_probe.sh is in shader cycles.)  It is launched so that every SIMD of the chip holds exactly W waves
 // (W = 1, 2, 4, 8: workgroups of 256 threads = one wave per SIMD, W workgroups per CU held apart by their LDS allocation) and prints
-//   cyc/inst/wave  = elapsed shader cycles of one wave / its instructions          (what a lone wave sees: issue + dependency)
-//   cyc/inst/SIMD  = elapsed / (W x instructions)                                  (the SIMD's issue cost per wave64 instruction
+//   cyc/inst/wave  = elapsed ticks of one wave / its instructions                  (what a lone wave sees: issue + dependency)
+//   cyc/inst/SIMD  = elapsed ticks / (W x instructions)                                  (the SIMD's issue cost per wave64 instruction
 //                                                                                    once enough waves hide the dependencies)
 // Under `rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE` the same launches calibrate
 // the counters (tools/probes/run_valu_probe.sh -> profiles/r04_valu_probe.txt).
@@ -44,12 +46,22 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define I_SQRT_F32(n) "v_sqrt_f32 %" #n ", %" #n "\n"
 #define I_CVT_F64_F32(n) "v_cvt_f32_f64 %" #n ", %8\n"
 #define I_MOV(n) "v_mov_b32 %" #n ", %8\n"
+#define I_ADD_F32(n) "v_add_f32 %" #n ", %" #n ", %8\n"
+#define I_MAX_F32(n) "v_max_f32 %" #n ", %" #n ", %8\n"
+#define I_AND_B32(n) "v_and_b32 %" #n ", %" #n ", %8\n"
+#define I_LSHLREV(n) "v_lshlrev_b32 %" #n ", 1, %" #n "\n"
+#define I_BFE(n) "v_bfe_u32 %" #n ", %" #n ", 1, 30\n"
+#define I_CMP(n) "v_cmp_lt_u32 vcc, %" #n ", %8\n"
+#define I_CNDMASK_S(n) "v_cndmask_b32 %" #n ", %" #n ", %8, s[10:11]\n"
+#define I_CMP_CND(n) "v_cmp_lt_u32 vcc, %" #n ", %9\n v_cndmask_b32 %" #n ", %" #n ", %8, vcc\n"
 
 enum Kind { FMA_F32, PK_FMA_F32, PK_ADD_F32, PK_MUL_F32, FMA_F64, ADD_F64, MUL_F64, AND_OR, MED3, MIN_U32, ADD_U32, LSHL_ADD, CNDMASK, MUL_LO, RCP_F32,
-            SQRT_F32, CVT_F32_F64, MOV, MIX_GRID, N_KIND };
+            SQRT_F32, CVT_F32_F64, MOV, MIX_GRID, ADD_F32, MAX_F32, AND_B32, LSHLREV, BFE, CMP, CNDMASK_S, CMP_CND, N_KIND };
 static const char* kKindName[N_KIND] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_add_f32", "v_pk_mul_f32", "v_fma_f64", "v_add_f64", "v_mul_f64", "v_and_or_b32",
                                         "v_med3_u32", "v_min_u32", "v_add_u32", "v_lshl_add_u32", "v_cndmask_b32", "v_mul_lo_u32", "v_rcp_f32", "v_sqrt_f32",
-                                        "v_cvt_f32_f64", "v_mov_b32", "mix: 12 pk_f32 + 12 int (and_or/med3/min) + 8 fma_f64"};
+                                        "v_cvt_f32_f64", "v_mov_b32", "mix: 12 pk_f32 + 12 int (and_or/med3/min) + 8 fma_f64", "v_add_f32", "v_max_f32", "v_and_b32",
+                                        "v_lshlrev_b32", "v_bfe_u32", "v_cmp_lt_u32 (vcc)", "v_cndmask_b32 (mask in s[10:11])",
+                                        "v_cmp_lt_u32 + v_cndmask_b32 (per PAIR)"};
 
 __device__ __forceinline__ uint64_t now() {
     uint64_t t;
@@ -62,7 +74,7 @@ __global__ __launch_bounds__(256) void k_valu(uint64_t* __restrict__ out, int it
     extern __shared__ char lds_pad[]; // sized by the host so that exactly W workgroups fit a CU
     if (seed == 12345.f) lds_pad[threadIdx.x] = 1;
     uint64_t t0, t1;
-    if (KIND == FMA_F32 || KIND == RCP_F32 || KIND == SQRT_F32 || KIND == MOV) {
+    if (KIND == FMA_F32 || KIND == RCP_F32 || KIND == SQRT_F32 || KIND == MOV || KIND == ADD_F32 || KIND == MAX_F32) {
         float a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3, a4 = seed + 4, a5 = seed + 5, a6 = seed + 6, a7 = seed + 7;
         const float b = 0.999f, c = 0.001f;
         t0 = now();
@@ -71,6 +83,8 @@ __global__ __launch_bounds__(256) void k_valu(uint64_t* __restrict__ out, int it
             if (KIND == RCP_F32) asm volatile(R32(I_RCP_F32) : ACC8 : "v"(b), "v"(c));
             if (KIND == SQRT_F32) asm volatile(R32(I_SQRT_F32) : ACC8 : "v"(b), "v"(c));
             if (KIND == MOV) asm volatile(R32(I_MOV) : ACC8 : "v"(b), "v"(c));
+            if (KIND == ADD_F32) asm volatile(R32(I_ADD_F32) : ACC8 : "v"(c), "v"(b));
+            if (KIND == MAX_F32) asm volatile(R32(I_MAX_F32) : ACC8 : "v"(c), "v"(b));
         }
         t1 = now();
         if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 1.2345f) out[0] = 1;
@@ -139,6 +153,12 @@ __global__ __launch_bounds__(256) void k_valu(uint64_t* __restrict__ out, int it
             if (KIND == LSHL_ADD) asm volatile(R32(I_LSHL_ADD) : ACC8 : "v"(c), "v"(b));
             if (KIND == CNDMASK) asm volatile(R32(I_CNDMASK) : ACC8 : "v"(c), "v"(b) : "vcc");
             if (KIND == MUL_LO) asm volatile(R32(I_MUL_LO) : ACC8 : "v"(c), "v"(b));
+            if (KIND == AND_B32) asm volatile(R32(I_AND_B32) : ACC8 : "v"(b), "v"(c));
+            if (KIND == LSHLREV) asm volatile(R32(I_LSHLREV) : ACC8 : "v"(b), "v"(c));
+            if (KIND == BFE) asm volatile(R32(I_BFE) : ACC8 : "v"(b), "v"(c));
+            if (KIND == CMP) asm volatile(R32(I_CMP) : ACC8 : "v"(b), "v"(c) : "vcc");
+            if (KIND == CNDMASK_S) asm volatile("s_mov_b64 s[10:11], 0x5555\n" R32(I_CNDMASK_S) : ACC8 : "v"(c), "v"(b) : "s10", "s11");
+            if (KIND == CMP_CND) asm volatile(R8(I_CMP_CND) R8(I_CMP_CND) : ACC8 : "v"(c), "v"(b) : "vcc"); // 16 pairs = 32 instructions
         }
         t1 = now();
         if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 12345u) out[0] = 1;
@@ -166,7 +186,7 @@ int main(int argc, char** argv) {
     CHK(hipMalloc(&d, n_out * 8));
     std::vector<uint64_t> h(n_out);
     printf("# %s, %d CUs, clock %d MHz; %d x 32 instructions per wave\n", prop.name, cus, prop.clockRate / 1000, iters);
-    printf("%-58s %3s %14s %14s %10s\n", "instruction", "W", "cyc/inst/wave", "cyc/inst/SIMD", "wall_us");
+    printf("%-58s %3s %14s %14s %10s\n", "instruction", "W", "tick/inst/wave", "tick/inst/SIMD", "wall_us");
     for (int k = 0; k < N_KIND; ++k) {
         for (int W : {1, 2, 4, 8}) {
             if (only_w && W != only_w) continue;
