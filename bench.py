@@ -413,7 +413,8 @@ def main():
                 traffic = pm.get("hbm_bytes_per_unit") * units_per_launch
                 traffic_src = (f"profiles/pmc_latest.json[{kernel_name}]: HBM bytes/unit of separate rocprofv3 --pmc passes of this command "
                                f"({pm.get('source', 'see profiles/README.md')}) x this run's units per launch; counters cannot be read in the timed run")
-                pmc_extra = {k: pm[k] for k in ("valu_busy", "ta_busy", "l1_line_accesses_per_cu_cycle", "l1_hit", "l2_hit", "valu_insts_per_wave", "waves_per_simd") if k in pm}
+                pmc_extra = {k: pm[k] for k in ("valu_busy", "valu_insts_per_simd_cycle", "ta_busy", "l1_line_accesses_per_cu_cycle", "l1_hit", "l2_hit", "valu_insts_per_wave",
+                                                "resident_waves_per_simd", "ps_per_unit_traced", "batch", "slots", "source") if k in pm}
         except Exception:  # noqa: BLE001
             traffic = None
     measured_gbs = (traffic / sec / 1e9) if (traffic and sec > 0) else None
@@ -445,25 +446,45 @@ def main():
         "algorithmic_ref_gbs": ref_gbs,
         "algorithmic_ref_over_peak": ref_gbs / HBM_PEAK_GBS,
     }
-    # The binding roof.  The committed SQ counter pass of this command says which unit the kernel keeps busiest: VALU issue
-    # (SQ_ACTIVE_INST_VALU x 4 cycles / SIMD cycles) for the grid and the VGICP kernels, the vector-memory front end (TA busy) for
-    # GICP / AVGICP; HBM carries a smaller share.  Without a matching pass the line falls back to the HBM stream.
+    # The binding roof.  The committed counter passes of THIS command (same batch / slots: checked above) say which unit the kernel keeps
+    # busiest.  VALU issue: wave64 VALU instructions per SIMD per shader cycle (SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)) x the
+    # kernel's mean issue cost in cycles.  The cost model is measured, not assumed: tools/probes/valu_probe (profiles/r04_valu_probe.txt)
+    # times every instruction class at 8 waves / SIMD -- ~2.4 cycles (v_fma_f32, v_add_f32, v_add_u32, v_and_b32, v_mov_b32), ~4.3 (packed
+    # float32, every float64 op, v_and_or / v_med3 / v_min / v_max / shifts / v_cmp / v_cndmask / conversions), ~8.2 (rcp, sqrt) -- and
+    # shows that SQ_ACTIVE_INST_VALU ticks ONCE per instruction whatever its class (twice for transcendentals), so round 3's
+    # "4 x SQ_ACTIVE_INST_VALU / SIMD cycles" over-counted the 2.4-cycle class; tools/valu_mix.py weighs the kernel's own opcode mix
+    # (profiles/r04_valu_mix.txt: 27 % fast, 72 % slow, 1 % transcendental for the P2P grid kernel -> 3.81 cycles).  TA busy is the
+    # vector-memory front end.  Without a matching pass the line falls back to the HBM stream.
     clock_ghz = 2.4  # MI355X_MICROARCH.md: max clock
     simd_cycles = 1024 * clock_ghz  # G SIMD-cycles/s over the chip (256 CUs x 4 SIMDs)
+    issue_cycles = {"k_accumulate_grid<P2P>": 3.81, "k_accumulate_grid<GICP>": 3.84, "k_accumulate_vnbr<VGICP>": 3.89, "k_accumulate_vnbr<AVGICP>": 3.90}
     roofline = dict(hbm)
     roofline["bound"] = "hbm"
-    if pmc_extra.get("valu_busy") is not None:
-        vb, tb = float(pmc_extra["valu_busy"]), float(pmc_extra.get("ta_busy", 0.0))
+    vb = None
+    if pmc_extra.get("valu_insts_per_simd_cycle") is not None and kernel_name in issue_cycles:
+        vb = float(pmc_extra["valu_insts_per_simd_cycle"]) * issue_cycles[kernel_name]
+    elif pmc_extra.get("valu_busy") is not None:  # a pass summarised before the probe: the x4 figure rescaled to the mix's mean cost
+        vb = float(pmc_extra["valu_busy"]) / 4.0 * issue_cycles.get(kernel_name, 4.0)
+    if vb is not None:
+        tb = float(pmc_extra.get("ta_busy", 0.0))
         if vb >= tb and vb > hbm["frac"]:
-            roofline = {"bound": "valu_issue", "achieved": vb * simd_cycles, "peak": simd_cycles, "unit": "G SIMD-cycles/s (VALU-busy)", "frac": vb,
-                        "achieved_is": "SQ_ACTIVE_INST_VALU x 4 cycles per wave64 instruction / (1024 SIMDs x kernel cycles), committed rocprofv3 --pmc "
-                                       "pass of this command (profiles/); the launch time it belongs to is measured live below",
+            roofline = {"bound": "valu_issue", "achieved": vb * simd_cycles, "peak": simd_cycles, "unit": "G SIMD-cycles/s (VALU issue)", "frac": vb,
+                        "achieved_is": f"SQ_INSTS_VALU per SIMD-cycle ({pmc_extra.get('valu_insts_per_simd_cycle')}) x {issue_cycles.get(kernel_name, 4.0)} cycles mean issue cost "
+                                       "of this kernel's opcode mix (profiles/r04_valu_mix.txt, per-class costs measured by tools/probes/valu_probe: "
+                                       "profiles/r04_valu_probe.txt); counters: committed rocprofv3 --pmc pass of this command at this batch / slots "
+                                       "(profiles/); the launch time it belongs to is measured live below",
+                        "frac_bounds": {"every_instruction_2.4_cycles": float(pmc_extra.get("valu_insts_per_simd_cycle", 0.0)) * 2.4,
+                                        "every_instruction_4.3_cycles": float(pmc_extra.get("valu_insts_per_simd_cycle", 0.0)) * 4.3},
                         "traffic": traffic}
         elif tb > hbm["frac"]:
             roofline = {"bound": "vector_memory_issue", "achieved": tb * 256 * clock_ghz, "peak": 256 * clock_ghz, "unit": "G CU-cycles/s (TA-busy)", "frac": tb,
                         "achieved_is": "TA_TA_BUSY / (256 CUs x kernel cycles), committed rocprofv3 --pmc pass of this command (profiles/)",
                         "traffic": traffic}
         roofline["hbm"] = hbm
+        roofline["valu_issue_frac"] = vb
+        if pmc_extra.get("ps_per_unit_traced") is not None and units_per_launch > 0:
+            roofline["counter_pass_ps_per_unit"] = pmc_extra["ps_per_unit_traced"]
+            roofline["this_run_ps_per_unit"] = 1e9 * acc_ms_avg / units_per_launch
     roofline.update({
         "kernel": kernel_name,
         "counters": pmc_extra,

@@ -185,6 +185,14 @@ static int dev_reserve(elm_ctx* ctx, DevBuf& b, size_t bytes) {
 // Host memory a large temporary may take: MemAvailable of /proc/meminfo (free + reclaimable page cache -- after a big PCD has been read
 // most of the RAM is page cache, and MemFree alone would refuse the grid depending on the cache state); unknown: no limit (the
 // allocations themselves fail with bad_alloc, which the builders handle).
+// The block array of the cell grid: 4 slots per block must number below 2^31 (the kernels carry slot numbers as ints); below
+// grid_narrow_limit() bytes stage 1 uses 32-bit byte offsets, beyond it 16-byte units (ELM_GRID_MAX_BLOCK_BYTES lowers the limit: tests
+// force the wide form onto small maps).
+constexpr uint64_t kGridMaxBlocks = 0x1FFFFFF0ull;
+static uint64_t grid_narrow_limit() {
+    if (const char* e = getenv("ELM_GRID_MAX_BLOCK_BYTES")) return std::min<uint64_t>(strtoull(e, nullptr, 10), 0xFFFFFF00ull);
+    return 0xFFFFFF00ull;
+}
 static uint64_t host_available_bytes() {
     FILE* f = fopen("/proc/meminfo", "r");
     if (!f) return ~0ull;
@@ -971,7 +979,10 @@ static int build_cell_grid_impl(elm_map* m, uint64_t max_cells) {
     }
     uint64_t n_blk = 1; // block 0: four padding slots, read by masked-off loads
     for (uint64_t c = 0; c < cells; ++c) n_blk += (start[c + 1] + 3) / 4;
-    if (n_blk * sizeof(GridBlk) > 0xFFFFFF00ull) { m->grid_refused = true; return ELM_ERR_UNSUPPORTED; } // the kernel addresses blocks by 32-bit byte offsets
+    // stage 1 addresses blocks by 32-bit BYTE offsets (one scalar base + a lane offset) while the array stays below 4 GB (~275 M map
+    // points), by 32-bit offsets in 16-byte units beyond (template flag WIDE: one 64-bit shift-add per block); slot numbers are ints
+    if (n_blk > kGridMaxBlocks) { m->grid_refused = true; return ELM_ERR_UNSUPPORTED; }
+    const bool wide_blocks = n_blk * sizeof(GridBlk) > grid_narrow_limit();
     for (uint64_t c = 0; c < cells; ++c) start[c + 1] += start[c]; // start[c] = first position of cell c in the (unpadded) sorted order
     std::vector<uint32_t> perm(n);
     for (size_t i = 0; i < n; ++i) perm[start[lin[i]]++] = (uint32_t)i; // bucket order in, so a cell keeps its points in bucket (= insertion) order
@@ -1028,6 +1039,7 @@ static int build_cell_grid_impl(elm_map* m, uint64_t max_cells) {
     m->dm.grid_blk = d_blk;
     m->dm.grid_idx = d_idx;
     m->dm.grid_start = d_start;
+    m->dm.grid_wide = wide_blocks ? 1 : 0;
     m->dm.gx0 = lo[0]; m->dm.gy0 = lo[1]; m->dm.gz0 = lo[2];
     m->dm.gnx = (int32_t)dim[0]; m->dm.gny = (int32_t)dim[1]; m->dm.gnz = (int32_t)dim[2];
     m->dm.vox_stat = d_stat;
@@ -1159,7 +1171,8 @@ static int build_tiled_grid_impl(elm_map* m) {
     }
     for (uint64_t e = 0; e < (uint64_t)kTile * kTile; ++e) start[e] = 0; // empty tiles: block 0 .. block 0 (nothing)
     for (uint64_t e = entries; e < entries + 4; ++e) start[e] = (uint32_t)n_blk;
-    if (n_blk * sizeof(GridBlk) > 0xFFFFFF00ull) return ELM_ERR_UNSUPPORTED;
+    if (n_blk > kGridMaxBlocks) return ELM_ERR_UNSUPPORTED;
+    const bool wide_blocks = n_blk * sizeof(GridBlk) > grid_narrow_limit();
     std::vector<GridBlk> gb(std::max<uint64_t>(n_blk, 1));
     std::vector<uint32_t> gi(std::max<uint64_t>(4 * n_blk, 4), 0xFFFFFFFFu);
     for (auto& b : gb)
@@ -1204,6 +1217,7 @@ static int build_tiled_grid_impl(elm_map* m) {
     const DevMap dm_before = m->dm;
     m->dm.grid_blk = d_blk; m->dm.grid_idx = d_idx; m->dm.grid_start = d_start; m->dm.grid_tiles = d_tiles;
     m->dm.grid_tiled = 1;
+    m->dm.grid_wide = wide_blocks ? 1 : 0;
     m->dm.gtny = (int32_t)tny;
     m->dm.gx0 = lo[0]; m->dm.gy0 = lo[1]; m->dm.gz0 = lo[2];
     m->dm.gnx = (int32_t)(tnx * kTile); m->dm.gny = (int32_t)(tny * kTile); m->dm.gnz = (int32_t)dim[2];
@@ -1597,7 +1611,9 @@ static int scan_upload_impl(elm_ctx* ctx, const float* xyz, size_t n, size_t n_t
     } else {
         rc = ensure_hilbert(ctx);
         if (rc == ELM_OK) rc = dev_reserve(ctx, ctx->d_raw, bytes);
-        if (rc == ELM_OK) rc = dev_reserve(ctx, ctx->d_order_tmp, n * sizeof(uint32_t));
+        const bool wide = n >= 16384 && !getenv("ELM_ORDER_NARROW"); // one scan on its own: many workgroups (same bytes, ~10x sooner)
+        const size_t tmp_bytes = ((n * sizeof(uint32_t) + 255) / 256) * 256;
+        if (rc == ELM_OK) rc = dev_reserve(ctx, ctx->d_order_tmp, tmp_bytes + (wide ? order_wide_scratch_bytes((unsigned)n) : 0));
         if (rc == ELM_OK) rc = dev_reserve(ctx, ctx->d_order_jobs, sizeof(OrderJob));
         if (rc != ELM_OK) { elm_scan_destroy(s); return rc; }
         OrderJob* hj = (OrderJob*)((char*)ctx->h_stage + ((bytes + 15) & ~(size_t)15));
@@ -1611,7 +1627,8 @@ static int scan_upload_impl(elm_ctx* ctx, const float* xyz, size_t n, size_t n_t
         if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_order_jobs.p, hj, sizeof(OrderJob), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) {
             (void)hipGetLastError();
-            launch_scan_order(ctx->stream, (const OrderJob*)ctx->d_order_jobs.p, 1, ctx->d_hilbert);
+            if (wide) launch_scan_order_wide(ctx->stream, (const OrderJob*)ctx->d_order_jobs.p, (unsigned)n, ctx->d_hilbert, (char*)ctx->d_order_tmp.p + tmp_bytes);
+            else launch_scan_order(ctx->stream, (const OrderJob*)ctx->d_order_jobs.p, 1, ctx->d_hilbert);
             e = hipGetLastError();
         }
     }

@@ -100,6 +100,8 @@ struct DevMap {
     const uint2* grid_tiles;    // [gnx / kTile][gny / kTile] (gnx, gny are multiples of kTile)
     int32_t grid_tiled;         // 1: grid_start is addressed through grid_tiles
     int32_t gtny;               // tiles along y
+    int32_t grid_wide;          // 1: the block array is 4 GB or more -- stage 1 addresses it in 16-byte units (template flag WIDE)
+    int32_t _grid_pad;
     const double* grid_gicp;    // [4 * n_blk][16]: pt_gicp gathered into slot order -- a GICP match reads its record without the index hop
                                 // (only for maps with a covariance outside the compact form)
     const double* grid_gicp8;   // [4 * n_blk][8]: the compact record {mean[3], unit normal[3], k, -}: 64 bytes = one memory sector per match;
@@ -276,6 +278,10 @@ struct OrderJob {
     uint32_t _pad;
 };
 void launch_scan_order(hipStream_t s, const OrderJob* jobs, int n_jobs, const uint16_t* hilbert_lut);
+// one scan ordered by many workgroups (three launches, the same bytes as k_scan_order); scratch = order_wide_scratch_bytes(n) bytes
+unsigned order_wide_groups(unsigned n);
+size_t order_wide_scratch_bytes(unsigned n);
+void launch_scan_order_wide(hipStream_t s, const OrderJob* job, unsigned n, const uint16_t* hilbert_lut, void* scratch);
 void launch_publish_ready(hipStream_t s, StreamCtrl* ctrl, int ready);
 void launch_slots_idle(hipStream_t s, ScanDesc* scans, ScanState* st, int slots, unsigned cap_blocks, int* tickets);
 constexpr int kOrderCells = 64; // cells per axis of the ordering grid (2 m cells: +-64 m around the sensor, clamped beyond)

@@ -1486,7 +1486,9 @@ __device__ __forceinline__ const uint32_t* col_cells(const DevMap& m, int cx, in
 // STATS = 1 (elm_ctx_set_work_counters): the launch also sums the three work counters (candidates / occupied buckets of the reference's
 // walk from the dense statistics box, candidates this kernel tested + points served by stage 2).  The production launches run with
 // STATS = 0: no statistics load, 18 (P2P) / 29 reduced values, no per-point bookkeeping in stage 2.
-template <int METHOD, int COMPACT, int TILED, int STATS>
+// WIDE = 1: the block array does not fit 32-bit byte offsets (4 GB = ~275 M map points): stage 1 carries offsets in 16-byte units
+// (three per block) and forms the 64-bit address per block with one shift-add; everything else addresses blocks by index already.
+template <int METHOD, int COMPACT, int TILED, int STATS, int WIDE>
 __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_GICP_WAVES)) void k_accumulate_grid(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
                                                                             unsigned total_blocks, const ScanState* __restrict__ st,
                                                                             double* __restrict__ partials, const RegParams rp) {
@@ -1515,6 +1517,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
     bool hard = false;
     const double h = 0.5 * m.voxel_size;
     const GridBlk* __restrict__ lp = m.grid_blk;
+    constexpr unsigned kBlkStep = WIDE ? (unsigned)(sizeof(GridBlk) / 16) : (unsigned)sizeof(GridBlk); // stage-1 offsets: 16-byte units / bytes
     // the point and its transform are cheap to redo (one 16-byte load that hits L1/L2 + 18 float64 operations): they are NOT kept
     // in registers across the candidate loop and the cooperative stage -- the kernel is bound by latency, i.e. by occupancy
     // the point and the walk statistics of its query voxel wait in LDS, in the upper half of the reduction buffer (the queue of
@@ -1620,7 +1623,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
             visit_order(b1a, b1v);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                sb[k] = (unsigned)(b0v[k] - cb[k]) * (unsigned)sizeof(GridBlk); // block t of the flattened sequence lives at byte sb[k] + 48 t for cb[k] <= t < cb[k + 1]
+                sb[k] = (unsigned)(b0v[k] - cb[k]) * kBlkStep; // block t of the flattened sequence lives at byte (unit) sb[k] + 48 (3) t for cb[k] <= t < cb[k + 1]
                 cb[k + 1] = cb[k] + (b1v[k] - b0v[k]);
             }
         }
@@ -1637,11 +1640,12 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
                     unsigned b_ = sb[3];
 #pragma unroll
                     for (int k = 2; k >= 0; --k) b_ = (t < cb[k + 1]) ? sb[k] : b_;
-                    pb[w] = (t < nblk) ? b_ + (unsigned)t * (unsigned)sizeof(GridBlk) : 0u; // past the end: block 0, four padding slots
+                    pb[w] = (t < nblk) ? b_ + (unsigned)t * kBlkStep : 0u; // past the end: block 0, four padding slots
                 }
                 GridBlk B[ELM_BLOCKS_PER_TRIP];
 #pragma unroll
-                for (int w = 0; w < ELM_BLOCKS_PER_TRIP; ++w) B[w] = *reinterpret_cast<const GridBlk*>(reinterpret_cast<const char*>(lp) + pb[w]);
+                for (int w = 0; w < ELM_BLOCKS_PER_TRIP; ++w)
+                    B[w] = *reinterpret_cast<const GridBlk*>(reinterpret_cast<const char*>(lp) + (WIDE ? ((size_t)pb[w] << 4) : (size_t)pb[w]));
                 __builtin_amdgcn_sched_barrier(0); // all six loads are in flight before the first is waited for (the scheduler otherwise
                                                    // sometimes starts on the first block between the two blocks' loads)
 #pragma unroll
@@ -1670,7 +1674,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
                 const float r2 = d1 + d1 * 3.814697265625e-06f + egrr; // >= the winner's exact squared distance when it lies below rr
                 hr2 = d1 + d1 * 3.814697265625e-06f + egblk;           // the same bound for any block candidate: stage 2's ball
                 if (d2 - d2 * 3.814697265625e-06f > r2 + egrr && r2 < rr2) {
-                    bj = (int)(jb / (unsigned)sizeof(GridBlk)) * 4 + (int)(m1 & 3u);
+                    bj = (int)(jb / kBlkStep) * 4 + (int)(m1 & 3u);
                     hard = false;
                 }
             }
@@ -3141,15 +3145,22 @@ void launch_accumulate_cell(hipStream_t s, const DevMap& m, const ScanDesc* scan
 void launch_accumulate_grid(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                             ScanState* st, double* partials, const RegParams& rp) {
     dim3 g(total_blocks), b(kBlock);
-#define ELM_LAUNCH_G(M, C, T)                                                                                                                        \
-    do {                                                                                                                                          \
-        if (rp.stats) hipLaunchKernelGGL((k_accumulate_grid<M, C, T, 1>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp); \
-        else hipLaunchKernelGGL((k_accumulate_grid<M, C, T, 0>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);          \
+#define ELM_LAUNCH_GW(M, C, T, S_, W_) hipLaunchKernelGGL((k_accumulate_grid<M, C, T, S_, W_>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp)
+#define ELM_LAUNCH_G(M, C, T)                                   \
+    do {                                                        \
+        if (m.grid_wide) {                                      \
+            if (rp.stats) ELM_LAUNCH_GW(M, C, T, 1, 1);         \
+            else ELM_LAUNCH_GW(M, C, T, 0, 1);                  \
+        } else {                                                \
+            if (rp.stats) ELM_LAUNCH_GW(M, C, T, 1, 0);         \
+            else ELM_LAUNCH_GW(M, C, T, 0, 0);                  \
+        }                                                       \
     } while (0)
     if (rp.method == ELM_P2P) { if (m.grid_tiled) ELM_LAUNCH_G(ELM_P2P, 0, 1); else ELM_LAUNCH_G(ELM_P2P, 0, 0); }
     else if (m.gicp_compact) { if (m.grid_tiled) ELM_LAUNCH_G(ELM_GICP, 1, 1); else ELM_LAUNCH_G(ELM_GICP, 1, 0); }
     else { if (m.grid_tiled) ELM_LAUNCH_G(ELM_GICP, 0, 1); else ELM_LAUNCH_G(ELM_GICP, 0, 0); }
 #undef ELM_LAUNCH_G
+#undef ELM_LAUNCH_GW
 }
 void launch_gather_gicp(hipStream_t s, const DevMap& m, size_t n_slots, double* out, int compact) {
     const size_t threads = n_slots * (compact ? 8 : 16);
@@ -3418,9 +3429,9 @@ __global__ __launch_bounds__(kOrderThreads) void k_scan_order(const OrderJob* __
         for (int w = 0; w < kOrderWaves; ++w) {
             const unsigned c = s_cnt[w][key];
             s_cnt[w][key] = (unsigned short)run;
-            if (run > 65535u) over = 1;
             run += c;
         }
+        if (run > 65535u) over = 1; // a cell with more than 65535 points: the scan keeps the caller's order (k_order_prefix: the same rule)
         t4[q] = tot;
         tot += run;
     }
@@ -3458,6 +3469,145 @@ __global__ __launch_bounds__(kOrderThreads) void k_scan_order(const OrderJob* __
 }
 void launch_scan_order(hipStream_t s, const OrderJob* jobs, int n_jobs, const uint16_t* hilbert_lut) {
     if (n_jobs > 0) hipLaunchKernelGGL(k_scan_order, dim3(n_jobs), dim3(kOrderThreads), 0, s, jobs, hilbert_lut);
+}
+
+// ---- the same ordering of ONE scan by many workgroups (a scan uploaded on its own: k_scan_order's single workgroup takes 0.29 ms for
+// 131 072 points on one CU).  Three launches, the same stable counting sort, hence the same bytes as k_scan_order:
+//   k_order_rank     workgroup g owns the contiguous points [g C, (g + 1) C) (4 wavefronts, contiguous quarters): rank of every point
+//                    inside its (workgroup, key) run -- per-wave ballot ranking as above, then the exclusive prefix over the four
+//                    waves -- into tmp[i] = key | rank << 12, the workgroup's per-key totals into hist[g][key]
+//   k_order_prefix   one workgroup: start[g][key] = points of smaller keys + points of this key in workgroups before g; flag = a key
+//                    with more than 65535 points or a scan beyond k_scan_order's size limit (the scan keeps the caller's order)
+//   k_order_scatter  dst[start[g][key] + rank] = src[i]
+constexpr int kWideWaves = 4, kWideThreads = kWideWaves * 64;
+__global__ __launch_bounds__(kWideThreads) void k_order_rank(const OrderJob* __restrict__ jobs, const uint16_t* __restrict__ hilbert_lut, unsigned chunk,
+                                                            uint16_t* __restrict__ hist) {
+    __shared__ unsigned short s_cnt[kWideWaves][kOrderBins];
+    __shared__ unsigned short s_lut[kOrderBins];
+    const OrderJob job = jobs[0];
+    const unsigned n = job.n;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, g = blockIdx.x;
+    for (unsigned k = tid; k < (unsigned)kOrderBins; k += kWideThreads) {
+        s_lut[k] = hilbert_lut[k];
+#pragma unroll
+        for (int w = 0; w < kWideWaves; ++w) s_cnt[w][k] = 0;
+    }
+    __syncthreads();
+    const unsigned sub = chunk / kWideWaves; // a multiple of 64
+    const unsigned w0 = min(n, g * chunk + wave * sub), w1 = min(n, w0 + sub);
+    for (unsigned base = w0; base < w1; base += 64u) {
+        const unsigned i = base + lane;
+        const bool valid = i < w1;
+        Pt3 p;
+        p.x = p.y = p.z = 0.f;
+        if (valid) p = job.src[i];
+        const unsigned key = valid ? order_key(p, s_lut) : 0u;
+        unsigned long long grp = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 12; ++b) {
+            const bool bit = (key >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            grp &= bit ? bal : ~bal;
+        }
+        const unsigned below = (unsigned)__popcll(grp & ((1ull << lane) - 1ull)), size = (unsigned)__popcll(grp);
+        const unsigned c = s_cnt[wave][key];
+        if (valid && below + 1u == size) s_cnt[wave][key] = (unsigned short)(c + size);
+        if (valid) job.tmp[i] = key | ((c + below) << 12);
+    }
+    __syncthreads();
+    for (unsigned key = tid; key < (unsigned)kOrderBins; key += kWideThreads) { // exclusive prefix over the waves; totals out
+        unsigned run = 0;
+#pragma unroll
+        for (int w = 0; w < kWideWaves; ++w) {
+            const unsigned c = s_cnt[w][key];
+            s_cnt[w][key] = (unsigned short)run;
+            run += c;
+        }
+        hist[(size_t)g * kOrderBins + key] = (uint16_t)run;
+    }
+    __syncthreads();
+    for (unsigned i = w0 + lane; i < w1; i += 64u) { // (the wave re-reads what it wrote itself)
+        const unsigned d = job.tmp[i];
+        job.tmp[i] = (d & 4095u) | (((d >> 12) + s_cnt[wave][d & 4095u]) << 12);
+    }
+}
+__global__ __launch_bounds__(1024) void k_order_prefix(const OrderJob* __restrict__ jobs, const uint16_t* __restrict__ hist, unsigned G, unsigned* __restrict__ start,
+                                                      int* __restrict__ flag) {
+    __shared__ unsigned s_tot[kOrderBins];
+    __shared__ unsigned s_wsum[16];
+    __shared__ int s_over;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) s_over = (((jobs[0].n + kOrderThreads - 1) / kOrderThreads) * 64u > 65535u) ? 1 : 0; // k_scan_order's own size limit (its `too_long`)
+    __syncthreads();
+    for (unsigned key = tid; key < (unsigned)kOrderBins; key += 1024u) { // coalesced over the keys
+        unsigned run = 0;
+        for (unsigned g = 0; g < G; ++g) {
+            const unsigned c = hist[(size_t)g * kOrderBins + key];
+            start[(size_t)g * kOrderBins + key] = run;
+            run += c;
+        }
+        s_tot[key] = run;
+        if (run > 65535u) s_over = 1;
+    }
+    __syncthreads();
+    unsigned t4[4], tot = 0; // exclusive scan over the keys: four consecutive keys per thread
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { t4[q] = tot; tot += s_tot[tid * 4u + (unsigned)q]; }
+    unsigned inc = tot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = (unsigned)__shfl_up((int)inc, off, 64);
+        if (lane >= (unsigned)off) inc += o;
+    }
+    if (lane == 63u) s_wsum[wave] = inc;
+    __syncthreads();
+    unsigned wbase = 0;
+#pragma unroll
+    for (unsigned w = 0; w < 16u; ++w) wbase += (w < wave) ? s_wsum[w] : 0u;
+    const unsigned ex = wbase + inc - tot;
+    __syncthreads(); // every thread has read its four totals
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s_tot[tid * 4u + (unsigned)q] = ex + t4[q];
+    __syncthreads();
+    for (unsigned key = tid; key < (unsigned)kOrderBins; key += 1024u) {
+        const unsigned b = s_tot[key];
+        for (unsigned g = 0; g < G; ++g) start[(size_t)g * kOrderBins + key] += b;
+    }
+    if (tid == 0) *flag = s_over;
+}
+__global__ __launch_bounds__(kWideThreads) void k_order_scatter(const OrderJob* __restrict__ jobs, unsigned chunk, const unsigned* __restrict__ start,
+                                                               const int* __restrict__ flag) {
+    __shared__ unsigned s_start[kOrderBins];
+    const OrderJob job = jobs[0];
+    const unsigned n = job.n, tid = threadIdx.x, g = blockIdx.x;
+    const unsigned i0 = min(n, g * chunk), i1 = min(n, i0 + chunk);
+    if (*flag) { // degenerate scan: the caller's order
+        for (unsigned i = i0 + tid; i < i1; i += kWideThreads) job.dst[i] = job.src[i];
+        return;
+    }
+    for (unsigned k = tid; k < (unsigned)kOrderBins; k += kWideThreads) s_start[k] = start[(size_t)g * kOrderBins + k];
+    __syncthreads();
+    for (unsigned i = i0 + tid; i < i1; i += kWideThreads) {
+        const unsigned d = job.tmp[i];
+        job.dst[s_start[d & 4095u] + (d >> 12)] = job.src[i];
+    }
+}
+// scratch: order_wide_scratch_bytes(n) behind the n words of job.tmp
+unsigned order_wide_groups(unsigned n) {
+    unsigned G = (n + 2047u) / 2048u;
+    return G < 2u ? 2u : (G > 64u ? 64u : G);
+}
+size_t order_wide_scratch_bytes(unsigned n) { return (size_t)order_wide_groups(n) * kOrderBins * 6 + 64; }
+void launch_scan_order_wide(hipStream_t s, const OrderJob* job, unsigned n, const uint16_t* hilbert_lut, void* scratch) {
+    const unsigned G = order_wide_groups(n);
+    unsigned chunk = (n + G - 1) / G;
+    chunk = ((chunk + kWideThreads - 1) / kWideThreads) * kWideThreads; // whole 64-point steps per wave
+    unsigned* start = (unsigned*)scratch;
+    uint16_t* hist = (uint16_t*)((char*)scratch + (size_t)G * kOrderBins * 4);
+    int* flag = (int*)((char*)scratch + (size_t)G * kOrderBins * 6);
+    hipLaunchKernelGGL(k_order_rank, dim3(G), dim3(kWideThreads), 0, s, job, hilbert_lut, chunk, hist);
+    hipLaunchKernelGGL(k_order_prefix, dim3(1), dim3(1024), 0, s, job, (const uint16_t*)hist, G, start, flag);
+    hipLaunchKernelGGL(k_order_scatter, dim3(G), dim3(kWideThreads), 0, s, job, chunk, (const unsigned*)start, (const int*)flag);
 }
 // host-fed streams: the upload stream publishes how many scans have landed (after their ordering kernel, same stream)
 __global__ void k_publish_ready(StreamCtrl* ctrl, int ready) {

@@ -78,7 +78,11 @@ try:
                             "requested_bytes_per_unit": hbm_view.get("requested_bytes_per_unit")})
             if "SQ_ACTIVE_INST_VALU" in v and "GRBM_GUI_ACTIVE" in v:
                 cyc = v["GRBM_GUI_ACTIVE"]["avg"] / 8.0  # summed over the 8 XCDs
-                summary["valu_busy"] = 4.0 * v["SQ_ACTIVE_INST_VALU"]["avg"] / (1024.0 * cyc)  # 4 cycles per wave64 instruction, 1024 SIMDs
+                summary["valu_busy"] = 4.0 * v["SQ_ACTIVE_INST_VALU"]["avg"] / (1024.0 * cyc)  # the round-3 figure: 4 cycles per counter tick, 1024 SIMDs
+                # wave64 VALU instructions issued per SIMD per shader cycle; x the kernel's mean issue cost (tools/valu_mix.py with the
+                # per-class costs of tools/probes/valu_probe: ~2.4 / ~4.3 / ~8.2 cycles) = share of the SIMDs' issue cycles in use
+                summary["valu_insts_per_simd_cycle"] = v["SQ_INSTS_VALU"]["avg"] / (1024.0 * cyc)
+                summary["kernel_cycles"] = cyc
                 summary["valu_insts_per_wave"] = v["SQ_INSTS_VALU"]["avg"] / v["SQ_WAVES"]["avg"]
                 summary["waves_per_launch"] = v["SQ_WAVES"]["avg"]
             if "TA_TA_BUSY_sum" in v and "GRBM_GUI_ACTIVE" in v:
