@@ -96,7 +96,10 @@ struct elm_ctx {
     hipStream_t solve_stream = nullptr; // half-set streams: the solve side (reduce -> all-reduce -> solve + refill) of one half of the slots runs
                                         // here, under the other half's accumulate launch on the compute stream
     std::vector<hipEvent_t> ev_halves;  // its cross-stream events (never re-recorded while a wait on them may be pending: one pair per half-iteration)
-    int half_sets = 1;                  // ELM_HALF_SETS=0: one set of slots, everything on the compute stream (developer A/B)
+    int half_sets = 0;                  // ELM_HALF_SETS=1: the two-half pipeline (off by default: measured on one MI355X it LOSES 4 % without a
+                                        // communicator and 40 % on the one-rank RCCL path -- the solve's 1024-thread, 84-VGPR workgroups are not
+                                        // placed while the other half's accumulate grid still has workgroups to issue, so nothing overlaps and the
+                                        // half-size launches pay their tails twice; profiles/r04_halfsets.txt)
     hipEvent_t ev_iter[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ev_groups; // host-fed streams: per upload group its "copied" and "ordered" events
     uint16_t* d_hilbert = nullptr; // Hilbert index of every cell of the ordering grid (kOrderCells^2 entries)

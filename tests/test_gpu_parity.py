@@ -655,21 +655,47 @@ def test_stream_many_registrations_refilled_in_the_solve(ctx, oracle, world100k)
     batch = reg.RunRegisterBatch(scans, vm, T0s)
     assert any(not b["is_success"] for b in batch) and any(b["is_success"] for b in batch)
     assert len({b["iterations"] for b in batch}) > 3
-    # 7 slots: one set on the compute stream; 32 and 17: two half-sets (16 + 16, 9 + 8) whose solve side runs on a second stream under
-    # the other half's accumulate launch; the last round with an identity exchange hook = the multi-rank control flow (reduce-only
-    # launch -> exchange -> solve-only launch with the static per-slot queue) on the half-set streams
-    calls = []
-    for slots, hooked in ((7, False), (7, False), (32, False), (17, False), (17, True), (32, True)):
-        if hooked:
-            ctx.set_allreduce_hook(lambda p, n, s: (calls.append(n), 0)[1])
-        try:
-            out = reg.RunRegisterStream(scans, vm, T0s, slots=slots)
-        finally:
-            ctx.set_allreduce_hook(None)
+    for slots in (7, 7, 32):
+        out = reg.RunRegisterStream(scans, vm, T0s, slots=slots)
         for k, (a, b) in enumerate(zip(out, batch)):
-            assert (a["iterations"], a["is_success"], a["gate"]) == (b["iterations"], b["is_success"], b["gate"]), (slots, hooked, k)
-            assert np.array_equal(a["T"], b["T"]) and a["n_corr_last"] == b["n_corr_last"], (slots, hooked, k)
-    assert set(calls) == {9 * 32, 8 * 32, 16 * 32}  # one exchange per half per iteration, slots x 32 doubles each
+            assert (a["iterations"], a["is_success"], a["gate"]) == (b["iterations"], b["is_success"], b["gate"]), k
+            assert np.array_equal(a["T"], b["T"]) and a["n_corr_last"] == b["n_corr_last"], k
+
+
+def test_half_set_streams(oracle, world100k, monkeypatch):
+    """ELM_HALF_SETS=1 (opt-in): the slots split into two halves (16 + 16, 9 + 8) whose solve side -- reduce, exchange, solve + refill --
+    is queued on a second stream behind the half's accumulate launch while the compute stream goes on with the other half.  Results
+    bit-identical to the lockstep batch, also through an identity exchange hook = the multi-rank control flow (reduce-only launch ->
+    exchange -> solve-only launch with the static per-slot queue), one exchange of slots x 32 doubles per half per iteration."""
+    from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, Scan
+    monkeypatch.setenv("ELM_HALF_SETS", "1")
+    c = Context(0)
+    try:
+        vm, om = _maps(c, oracle, world100k, IcpMethod.P2P)
+        reg = Registration(RegistrationConfig(icp_method=IcpMethod.P2P, min_overlap_ratio=0.5), c)
+        scans, T0s = [], []
+        for i in range(150):
+            sc, Tt = synth.make_scan(world100k, 300 + 37 * (i % 11), seed=2000 + i)
+            if i % 13 == 5:
+                sc = sc + np.float32(500.0)  # fails the overlap gate in its first iteration
+            scans.append(Scan(c, sc))
+            T0s.append(synth.perturb(Tt, seed=3000 + i, max_trans=0.02 + 0.01 * (i % 17), max_rot_deg=0.1 * (i % 9)))
+        batch = reg.RunRegisterBatch(scans, vm, T0s)
+        calls = []
+        for slots, hooked in ((7, False), (32, False), (17, False), (17, True), (32, True)):
+            if hooked:
+                c.set_allreduce_hook(lambda p, n, s: (calls.append(n), 0)[1])
+            try:
+                out = reg.RunRegisterStream(scans, vm, T0s, slots=slots)
+            finally:
+                c.set_allreduce_hook(None)
+            for k, (a, b) in enumerate(zip(out, batch)):
+                assert (a["iterations"], a["is_success"], a["gate"]) == (b["iterations"], b["is_success"], b["gate"]), (slots, hooked, k)
+                assert np.array_equal(a["T"], b["T"]) and a["n_corr_last"] == b["n_corr_last"], (slots, hooked, k)
+        assert set(calls) == {9 * 32, 8 * 32, 16 * 32}
+        del scans, vm
+    finally:
+        c.close()
 
 
 def test_stream_through_exchange_hook(ctx, oracle, world100k):
@@ -753,6 +779,22 @@ def test_randomized_configs_two_level_grid(oracle, seed, monkeypatch):
     c = Context(0)
     try:
         _randomized_case(c, oracle, 100 + seed)
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("seed,tiled", [(s, t) for s in range(8) for t in (False, True)])
+def test_randomized_configs_wide_block_addressing(oracle, seed, tiled, monkeypatch):
+    """The same sweep with the block array treated as 4 GB or more (ELM_GRID_MAX_BLOCK_BYTES forces the limit down): stage 1 of the
+    grid kernels then carries block offsets in 16-byte units and forms 64-bit addresses (template flag WIDE) -- the form maps beyond
+    ~275 M points take -- on the dense and on the two-level grid."""
+    from elimaloc_amd.registration import Context
+    monkeypatch.setenv("ELM_GRID_MAX_BLOCK_BYTES", "48")
+    if tiled:
+        monkeypatch.setenv("ELM_GRID", "tiled")
+    c = Context(0)
+    try:
+        _randomized_case(c, oracle, 200 + seed)
     finally:
         c.close()
 
