@@ -103,7 +103,8 @@ struct elm_ctx {
     hipEvent_t ev_iter[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ev_groups; // host-fed streams: per upload group its "copied" and "ordered" events
     uint16_t* d_hilbert = nullptr; // Hilbert index of every cell of the ordering grid (kOrderCells^2 entries)
-    DevBuf d_order_jobs, d_order_tmp, d_arena, d_raw, d_tickets;
+    DevBuf d_order_jobs, d_order_tmp, d_arena, d_raw, d_tickets, d_prev;
+    bool prev_winner = true; // ELM_PREV_WINNER=0: the grid kernels keep no previous winners (developer A/B)
     bool work_counters = false; // elm_ctx_set_work_counters / ELM_WORK_COUNTERS=1: the accumulate launches also sum the work counters of
                                 // elm_reg_result (n_cand_total, n_occ_total, n_tested_total, fallback_blocks); off: those fields read 0
     bool fused_reduce = false; // ELM_FUSED_REDUCE=1: the accumulate kernels' last workgroups reduce the partial records (no reduce launch:
@@ -275,6 +276,7 @@ extern "C" int elm_ctx_create(int device_id, elm_ctx** out) {
     if (const char* f = getenv("ELM_FUSED_REDUCE")) ctx->fused_reduce = strcmp(f, "0") != 0;
     if (const char* f = getenv("ELM_WORK_COUNTERS")) ctx->work_counters = strcmp(f, "0") != 0;
     if (const char* f = getenv("ELM_HALF_SETS")) ctx->half_sets = strcmp(f, "0") != 0 ? 1 : 0;
+    if (const char* f = getenv("ELM_PREV_WINNER")) ctx->prev_winner = strcmp(f, "0") != 0;
     {
         std::lock_guard<std::mutex> lk(g_live_mu);
         ctx->id = g_next_ctx_id++;
@@ -302,7 +304,7 @@ extern "C" void elm_ctx_destroy(elm_ctx* ctx) {
     if (ctx->d_hilbert) (void)hipFree(ctx->d_hilbert);
     if (ctx->h_jobs) (void)hipHostFree(ctx->h_jobs);
     DevBuf* bufs[] = {&ctx->d_scans, &ctx->d_state, &ctx->d_partials, &ctx->d_sums, &ctx->d_T0, &ctx->d_trace, &ctx->d_stage_pts, &ctx->d_active, &ctx->d_queue, &ctx->d_ds,
-                      &ctx->d_order_jobs, &ctx->d_order_tmp, &ctx->d_arena, &ctx->d_raw, &ctx->d_tickets};
+                      &ctx->d_order_jobs, &ctx->d_order_tmp, &ctx->d_arena, &ctx->d_raw, &ctx->d_tickets, &ctx->d_prev};
     if (ctx->h_active) (void)hipHostFree(ctx->h_active);
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -1827,6 +1829,11 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
     rp.radar_var[2] = cfg->elevation_variance_deg;
     rp.sums = nullptr;
     rp.tickets = nullptr;
+    rp.prev = nullptr;
+    if (ctx->prev_winner && !radar && blocks) { // one slot number per scan point: the next iteration's exact search starts from it
+        if ((rc = dev_reserve(ctx, ctx->d_prev, (size_t)blocks * kBlock * sizeof(uint32_t))) != ELM_OK) return rc;
+        rp.prev = (uint32_t*)ctx->d_prev.p;
+    }
     if (ctx->fused_reduce && !radar) {
         if ((rc = dev_reserve(ctx, ctx->d_tickets, (size_t)batch * sizeof(int32_t))) != ELM_OK) return rc;
         rp.sums = (double*)ctx->d_sums.p;
@@ -2059,6 +2066,11 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     rp.radar_var[0] = rp.radar_var[1] = rp.radar_var[2] = 0.0;
     rp.sums = nullptr;
     rp.tickets = nullptr;
+    rp.prev = nullptr;
+    if (ctx->prev_winner && blocks) {
+        if ((rc = dev_reserve(ctx, ctx->d_prev, (size_t)blocks * kBlock * sizeof(uint32_t))) != ELM_OK) return rc;
+        rp.prev = (uint32_t*)ctx->d_prev.p;
+    }
     if (ctx->fused_reduce) {
         if ((rc = dev_reserve(ctx, ctx->d_tickets, (size_t)S * sizeof(int32_t))) != ELM_OK) return rc;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_tickets.p, 0, (size_t)S * sizeof(int32_t), ctx->stream));
@@ -2115,6 +2127,7 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
             double* sums_h = (double*)ctx->d_sums.p + (size_t)base * kSums;
             RegParams rph = rp;
             if (rp.tickets) { rph.sums = sums_h; rph.tickets = rp.tickets + base; }
+            if (rp.prev) rph.prev = rp.prev + (size_t)cap_blocks * (size_t)base * kBlock;
             hipStream_t ss = ctx->stream;
             if (H == 2) {
                 ss = ctx->solve_stream;
@@ -2352,6 +2365,11 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
     rp.radar_var[0] = rp.radar_var[1] = rp.radar_var[2] = 0.0;
     rp.sums = nullptr;
     rp.tickets = nullptr;
+    rp.prev = nullptr;
+    if (ctx->prev_winner) {
+        if ((rc = dev_reserve(ctx, ctx->d_prev, (size_t)cap_blocks * (size_t)S * kBlock * sizeof(uint32_t))) != ELM_OK) return rc;
+        rp.prev = (uint32_t*)ctx->d_prev.p;
+    }
     if (ctx->fused_reduce) {
         if ((rc = dev_reserve(ctx, ctx->d_tickets, (size_t)S * sizeof(int32_t))) != ELM_OK) return rc;
         rp.sums = (double*)ctx->d_sums.p;

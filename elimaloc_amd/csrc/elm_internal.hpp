@@ -195,6 +195,8 @@ struct RegParams {
     // sums[scan][32] -- no reduce launch; nullptr: the accumulate kernels only write partials, k_solve reduces (developer A/B)
     double* sums;
     int32_t* tickets;
+    uint32_t* prev;      // [workgroups * kBlock] the winner (grid slot number, -1: none) of every scan point in the slot's previous iteration:
+                         // bounds the exact search of the next one (k_accumulate_grid); nullptr: not kept
     double radar_var[3]; // range_variance_m, azimuth_variance_deg, elevation_variance_deg (reg.hpp:77-79)
 };
 constexpr int kRadarRecord = 64; // doubles per partial record of k_accumulate_radar

@@ -1476,6 +1476,9 @@ __device__ __forceinline__ const uint32_t* col_cells(const DevMap& m, int cx, in
 #ifndef ELM_S2_SEED
 #define ELM_S2_SEED 1 // stage 2 seeds the ball of a point whose stage-1 block was empty (0: full walk of its 27 voxels, developer A/B)
 #endif
+#ifndef ELM_PREV_WINNER
+#define ELM_PREV_WINNER 1 // an undecided point's ball is also bounded by its previous iteration's winner (0: developer A/B)
+#endif
 #ifndef ELM_GRID_WAVES
 #define ELM_GRID_WAVES 7 // minimum waves per SIMD = a 72-VGPR cap (2 spilled registers).  Measured registrations/s: 5 -> 59.8k, 6 -> 63.9k, 7 -> 65.6k,
                          // 8 (35 spills) -> 54.2k: the kernel is bound by memory latency, not by VALU issue (67 % busy) or HBM bandwidth
@@ -1680,6 +1683,29 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
             }
         }
     }
+    // The previous iteration's winner of the same registration (rp.prev: one slot number per scan point, written at the end of every
+    // launch) is a candidate like any other: its distance to the NEW g bounds the nearest neighbour before anything is walked.  An
+    // undecided point takes the smaller of this bound and stage 1's -- a tighter ball and, for a point whose stage-1 block came back
+    // empty (a third of the undecided points under a poor initial guess), no seeding pass at all.  Exactness is untouched: the ball
+    // is still cleared completely, the bound only has to be an upper bound (float64 distance, rounded up).
+    const size_t pidx = (size_t)L * kBlock + threadIdx.x;
+    if (ELM_PREV_WINNER && rp.prev && S.iters > 0 && hard) {
+        const int pj = (int)rp.prev[pidx];
+        if (pj >= 0) {
+            double px, py, pz, gx, gy, gz;
+            transform(*stash(), px, py, pz, gx, gy, gz);
+            const Pt3 q = blk_point(lp, pj);
+            // only a point of one of the 27 buckets the reference visits for the NEW g is a candidate: stored (truncated) key within one of
+            // the query's floor key on every axis (vhm.cpp:275 / vhm.hpp:176-180, the arithmetic of grid_axis / visit_rank)
+            auto vk = [&](double v) { return (m.inv_vs_exact != 0.0) ? v * m.inv_vs_exact : v / m.voxel_size; };
+            const int dx = (int)vk((double)q.x) - (int)floor(vk(gx)), dy = (int)vk((double)q.y) - (int)floor(vk(gy)), dz = (int)vk((double)q.z) - (int)floor(vk(gz));
+            if (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1) {
+                const double ex = (double)q.x - gx, ey = (double)q.y - gy, ez = (double)q.z - gz;
+                const float d = (float)((ex * ex + ey * ey) + ez * ez);
+                hr2 = fminf(hr2, d + d * 2.4e-7f + 1e-30f); // (float) rounds to nearest: 2^-22 relative covers it upwards
+            }
+        }
+    }
     // ---- stage 2: queue the undecided points in thread order, ELM_HARD_LANES lanes per point
     const unsigned long long hm = __ballot(hard);
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1768,9 +1794,11 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
             int win = -1, walked = seeded;
             bool need64 = false;
             {
+                // distances to gh = float32(g) alone (six packed subtractions fewer per block, as in stage 1): an exact distance to g differs
+                // from the one to gh by at most eg = |g - gh|_1 in the ROOT, which the decision below pays for
                 const float ghx = (float)R.gx, ghy = (float)R.gy, ghz = (float)R.gz;
-                const float glx = (float)(R.gx - (double)ghx), gly = (float)(R.gy - (double)ghy), glz = (float)(R.gz - (double)ghz);
-                const f32x2 gxy = {ghx, ghy}, gzl = {ghz, glx}, gl2 = {gly, glz};
+                const float eg = (fabsf((float)(R.gx - (double)ghx)) + fabsf((float)(R.gy - (double)ghy)) + fabsf((float)(R.gz - (double)ghz))) * 1.000001f;
+                const f32x2 gxy = {ghx, ghy}, gzz = {ghz, 0.f};
                 unsigned m1 = 0x7F800000u, m2 = 0x7F800000u;
                 int jb = 0;
                 const float rny = __builtin_amdgcn_rcpf((float)ny); // c / ny for the few dozen columns of a ball: exact via float32
@@ -1797,7 +1825,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
                         const GridBlk B = Bn;
                         Bn = lp[(b + 1 < b1) ? b + 1 : 0]; // (block 0: the padding block, always resident)
                         f32x2 da, db;
-                        blk_dist(B, gxy, gzl, gl2, da, db);
+                        blk_dist_h(B, gxy, gzz, da, db);
                         const unsigned was = m1;
                         two_smallest(da.x, 0u, m1, m2);
                         two_smallest(da.y, 1u, m1, m2);
@@ -1817,7 +1845,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
                     for (int b = b0; b < b1; ++b) {
                         const GridBlk B = lp[b];
                         f32x2 da, db;
-                        blk_dist(B, gxy, gzl, gl2, da, db);
+                        blk_dist_h(B, gxy, gzz, da, db);
                         const unsigned was = m1;
                         two_smallest(da.x, 0u, m1, m2);
                         two_smallest(da.y, 1u, m1, m2);
@@ -1833,8 +1861,12 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
                 const unsigned m2g = group_min_u32<LPI>((lane == hl) ? m2 : m1); // a second holder of the same key counts as a tie
                 const int jw = __shfl(jb * 4 + (int)(m1 & 3u), (int)hl, 64);
                 const float d1 = __uint_as_float(m1g & ~3u), d2 = __uint_as_float(m2g & ~3u);
-                const float slack = 4e-11f * (fabsf(ghx) + fabsf(ghy) + fabsf(ghz) + 1.0f);
-                if (jw >= 4 && d2 > d1 + d1 * 3.814697265625e-06f + slack) win = jw; // clear float32 winner (2^-18, see stage 1)
+                // clear float32 winner: sqrt(d2) - sqrt(d1) > 2 eg holds for the distances to gh (2^-18: float32 arithmetic + key bits, see
+                // stage 1) <=> d2 > d1 + 4 eg sqrt(d1) + 4 eg^2, with sqrt(d2) >= sqrt(d1) in its place (one root per point, padding
+                // slots at 1e36 included: they never win)
+                const float s2 = __builtin_sqrtf(fminf(d2, 1e30f)) * 1.000001f;
+                const float slack = (4.0f * eg * s2 + 4.0f * eg * eg) * 1.000001f;
+                if (jw >= 4 && d2 > d1 + d1 * 3.814697265625e-06f + slack) win = jw; // (2^-18 on one side covers both, as in stage 1)
                 else need64 = live && jw >= 4;                                         // near tie: the float64 walk below decides
             }
             if (__any(need64)) { // wave-uniform; practically never taken
@@ -1902,6 +1934,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
         }
         __syncthreads(); // the queue is dead: the reduction may overwrite it
     }
+    if (ELM_PREV_WINNER && rp.prev && valid) rp.prev[pidx] = (unsigned)bj; // (-1: no candidate at all)
     if (valid) {
         double px, py, pz, gx, gy, gz;
         const float4 pf = *stash();
