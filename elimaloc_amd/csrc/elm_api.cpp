@@ -96,6 +96,23 @@ struct elm_ctx {
     hipStream_t solve_stream = nullptr; // half-set streams: the solve side (reduce -> all-reduce -> solve + refill) of one half of the slots runs
                                         // here, under the other half's accumulate launch on the compute stream
     std::vector<hipEvent_t> ev_halves;  // its cross-stream events (never re-recorded while a wait on them may be pending: one pair per half-iteration)
+    // hipGraph of ONE registration (batch = 1: RunRegister's own shape): descriptor + guess upload, init, K x (accumulate, solve), result
+    // download captured once and replayed -- no launch gaps between the 2 K + 1 kernels.  Rebuilt when anything baked into it changes
+    // (graph_key: the map's device view, the registration parameters, the grid size, K, the buffers).  ELM_GRAPH=0: plain launches.
+    bool use_graph = true;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    std::vector<unsigned char> graph_key;
+    int graph_K = 0;          // iterations inside the cached graph
+    int graph_K_want = 0;     // grows with the iteration counts seen
+    int graph_short_run = 0;  // consecutive registrations that needed fewer
+    struct {
+        bool active = false;  // the in-flight batch went through the graph: finish may have to continue it
+        const elm_map* map = nullptr;
+        bool use_grid = false, use_cells = false, use_vnbr = false;
+        uint32_t blocks = 0;
+        int iters = 0, max_iter = 0;
+    } grun;
     int half_sets = 0;                  // ELM_HALF_SETS=1: the two-half pipeline (off by default: measured on one MI355X it LOSES 4 % without a
                                         // communicator and 40 % on the one-rank RCCL path -- the solve's 1024-thread, 84-VGPR workgroups are not
                                         // placed while the other half's accumulate grid still has workgroups to issue, so nothing overlaps and the
@@ -277,6 +294,7 @@ extern "C" int elm_ctx_create(int device_id, elm_ctx** out) {
     if (const char* f = getenv("ELM_WORK_COUNTERS")) ctx->work_counters = strcmp(f, "0") != 0;
     if (const char* f = getenv("ELM_HALF_SETS")) ctx->half_sets = strcmp(f, "0") != 0 ? 1 : 0;
     if (const char* f = getenv("ELM_PREV_WINNER")) ctx->prev_winner = strcmp(f, "0") != 0;
+    if (const char* f = getenv("ELM_GRAPH")) ctx->use_graph = strcmp(f, "0") != 0;
     {
         std::lock_guard<std::mutex> lk(g_live_mu);
         ctx->id = g_next_ctx_id++;
@@ -295,6 +313,8 @@ extern "C" void elm_ctx_destroy(elm_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm && g_rccl.comm_destroy) g_rccl.comm_destroy(ctx->comm);
+    if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
+    if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
     for (hipEvent_t e : ctx->ev_halves) (void)hipEventDestroy(e);
     for (hipStream_t st : {ctx->copy_stream, ctx->order_stream, ctx->poll_stream, ctx->solve_stream})
         if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
@@ -1806,13 +1826,18 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
         HIPCHK(ctx, hipMemsetAsync(ctx->d_trace.p, 0, tb, ctx->stream));
         d_trace = (elm_iter_trace*)ctx->d_trace.p;
     }
-    const bool packed_init = batch <= kInitPack;
-    if (!packed_init) {
+    // one resident registration without trace / profiling / exchange: the replayed graph (descriptor and guess travel through the pinned
+    // staging buffer, so nothing call-specific is baked into it)
+    const bool graph_mode = ctx->use_graph && batch == 1 && !want_trace && !ctx->profiling && !n_dev && !map_empty && !radar && !ctx->comm && !ctx->hook &&
+                            cfg->max_iteration > 0 && blocks > 0 && ctx->iter_hint > 0; // (iter_hint: a first call has no history to size the graph with)
+    const bool packed_init = batch <= kInitPack && !graph_mode;
+    if (!packed_init && !graph_mode) {
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_scans.p, hd, (size_t)batch * sizeof(ScanDesc), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_T0.p, hT, (size_t)batch * 16 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     }
 
     RegParams rp;
+    memset(&rp, 0, sizeof(rp)); // (padding too: the registration graph compares it bytewise)
     rp.th = cfg->max_search_dist;
     rp.th2 = cfg->max_search_dist * cfg->max_search_dist;
     rp.lm_lambda = cfg->lm_lambda;
@@ -1858,6 +1883,66 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
     const ScanDesc* dsc = (const ScanDesc*)ctx->d_scans.p;
     int* d_active = (int*)((char*)ctx->d_state.p + st_bytes);
     (void)hipGetLastError();
+    ctx->grun.active = false;
+    if (graph_mode) {
+        // K iterations inside the graph: one more than the longest registration seen on this context (a finished scan's launches return
+        // at once); a registration that needs more is continued with plain launches by elm_register_batch_finish
+        // (never shrinks while longer registrations keep coming: one graph per shape; 32 short ones in a row let it shrink again)
+        ctx->graph_short_run = (ctx->iter_hint + 1 < ctx->graph_K_want) ? ctx->graph_short_run + 1 : 0;
+        if (ctx->graph_short_run >= 32) { ctx->graph_K_want = ctx->iter_hint + 1; ctx->graph_short_run = 0; }
+        const int K = std::min(cfg->max_iteration, std::max(ctx->graph_K_want, ctx->iter_hint + 1));
+        ctx->graph_K_want = K;
+        std::vector<unsigned char> key;
+        auto put = [&](const void* p, size_t n) { key.insert(key.end(), (const unsigned char*)p, (const unsigned char*)p + n); };
+        put(&map->dm, sizeof(DevMap));
+        put(&rp, sizeof(RegParams));
+        const void* ptrs[] = {ctx->d_scans.p, ctx->d_T0.p, ctx->d_state.p, ctx->d_partials.p, ctx->d_sums.p, ctx->h_desc, ctx->h_state};
+        put(ptrs, sizeof(ptrs));
+        const uint32_t shape[] = {blocks, (uint32_t)K, (uint32_t)use_grid, (uint32_t)use_cells, (uint32_t)use_vnbr, (uint32_t)st_bytes};
+        put(shape, sizeof(shape));
+        if (!ctx->graph_exec || key != ctx->graph_key) {
+            if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
+            if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
+            HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+            hipError_t ce = hipMemcpyAsync(ctx->d_scans.p, hd, sizeof(ScanDesc), hipMemcpyHostToDevice, ctx->stream);
+            if (ce == hipSuccess) ce = hipMemcpyAsync(ctx->d_T0.p, hT, 16 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+            if (ce == hipSuccess) ce = hipMemsetAsync(d_active, 0, sizeof(int), ctx->stream);
+            if (ce == hipSuccess) {
+                launch_init_state(ctx->stream, st, (const double*)ctx->d_T0.p, 1, 0, d_active, rp.tickets);
+                for (int it = 0; it < K; ++it) {
+                    if (enqueue_accumulate(ctx, map, dsc, 1, blocks, st, rp, use_grid, use_cells, use_vnbr) != ELM_OK) { ce = hipErrorUnknown; break; }
+                    launch_solve(ctx->stream, dsc, 1, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, nullptr, 0, d_active);
+                }
+            }
+            if (ce == hipSuccess) ce = hipMemcpyAsync(ctx->h_state, st, st_bytes + 64, hipMemcpyDeviceToHost, ctx->stream);
+            hipGraph_t g = nullptr;
+            const hipError_t ee = hipStreamEndCapture(ctx->stream, &g);
+            if (ce == hipSuccess) ce = ee;
+            if (ce == hipSuccess) ce = hipGraphInstantiate(&ctx->graph_exec, g, nullptr, nullptr, 0);
+            if (ce != hipSuccess) {
+                if (g) (void)hipGraphDestroy(g);
+                ctx->graph_exec = nullptr;
+                ctx->last_error = std::string("registration graph: ") + hipGetErrorString(ce);
+                (void)hipGetLastError();
+                return ELM_ERR_DEVICE;
+            }
+            ctx->graph = g;
+            ctx->graph_key = key;
+            ctx->graph_K = K;
+        }
+        HIPCHK(ctx, hipGraphLaunch(ctx->graph_exec, ctx->stream));
+        ctx->grun.active = true;
+        ctx->grun.map = map;
+        ctx->grun.use_grid = use_grid; ctx->grun.use_cells = use_cells; ctx->grun.use_vnbr = use_vnbr;
+        ctx->grun.blocks = blocks;
+        ctx->grun.iters = ctx->graph_K;
+        ctx->grun.max_iter = cfg->max_iteration;
+        ctx->events_used = 0;
+        ctx->batch = batch;
+        ctx->want_trace = false;
+        ctx->in_flight = true;
+        return ELM_OK;
+    }
     if (packed_init) { // descriptors and guesses as kernel arguments: no H2D copies, no memset
         InitPack pack;
         memset(&pack, 0, sizeof(pack));
@@ -1937,6 +2022,24 @@ extern "C" int elm_register_batch_finish(elm_ctx* ctx, elm_reg_result* results, 
     ctx->in_flight = false;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (!ctx->results_ready || ctx->want_trace || ctx->profiling) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->grun.active) {
+        // the graph ran its K iterations; a registration that is still iterating goes on with plain launches, two iterations per look
+        ctx->grun.active = false;
+        const size_t st_bytes = (size_t)ctx->batch * sizeof(ScanState);
+        ScanState* st = (ScanState*)ctx->d_state.p;
+        const ScanDesc* dsc = (const ScanDesc*)ctx->d_scans.p;
+        int* d_active = (int*)((char*)ctx->d_state.p + st_bytes);
+        int it = ctx->grun.iters;
+        while (*(const int*)((const char*)ctx->h_state + st_bytes) != 0 && it < ctx->grun.max_iter) {
+            for (int k = 0; k < 2 && it < ctx->grun.max_iter; ++k, ++it) {
+                int rc = enqueue_accumulate(ctx, ctx->grun.map, dsc, ctx->batch, ctx->grun.blocks, st, ctx->rp, ctx->grun.use_grid, ctx->grun.use_cells, ctx->grun.use_vnbr);
+                if (rc != ELM_OK) return rc;
+                launch_solve(ctx->stream, dsc, ctx->batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, ctx->rp, nullptr, 0, d_active);
+            }
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_state, st, st_bytes + 64, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
     {
         int prc = prof_collect(ctx);
         if (prc != ELM_OK) return prc;
@@ -2052,6 +2155,7 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     HIPCHK(ctx, hipMemsetAsync(ctx->d_active.p, 0, sizeof(int), ctx->stream));
 
     RegParams rp;
+    memset(&rp, 0, sizeof(rp)); // (padding too: the registration graph compares it bytewise)
     rp.th = cfg->max_search_dist;
     rp.th2 = cfg->max_search_dist * cfg->max_search_dist;
     rp.lm_lambda = cfg->lm_lambda;
@@ -2351,6 +2455,7 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
         d_trace = (elm_iter_trace*)ctx->d_trace.p;
     }
     RegParams rp;
+    memset(&rp, 0, sizeof(rp)); // (padding too: the registration graph compares it bytewise)
     rp.th = cfg->max_search_dist;
     rp.th2 = cfg->max_search_dist * cfg->max_search_dist;
     rp.lm_lambda = cfg->lm_lambda;

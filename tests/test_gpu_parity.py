@@ -662,6 +662,46 @@ def test_stream_many_registrations_refilled_in_the_solve(ctx, oracle, world100k)
             assert np.array_equal(a["T"], b["T"]) and a["n_corr_last"] == b["n_corr_last"], k
 
 
+def test_single_registration_graph_replay(oracle, world100k, monkeypatch):
+    """One registration at a time (RunRegister's own shape) is replayed from a captured hipGraph after the first call: descriptor and
+    guess travel through pinned memory, K = (longest registration seen) + 1 iterations inside the graph, a registration that needs more
+    continues with plain launches.  Bit-identical to the plain-launch path (ELM_GRAPH=0) call by call -- short ones, a long one behind
+    short ones (continuation), another scan size (new graph), another method -- and to the oracle."""
+    from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, Scan
+    seq = []
+    for i, (n, tr, rot, meth) in enumerate([(6000, 0.03, 0.1, 0), (6000, 0.03, 0.1, 0), (6000, 0.05, 0.2, 0), (6000, 0.6, 2.5, 0), (6000, 0.04, 0.1, 0),
+                                            (3500, 0.1, 0.5, 0), (6000, 0.1, 0.5, 2), (6000, 0.03, 0.1, 0)]):
+        sc, Tt = synth.make_scan(world100k, n, seed=4100 + i)
+        seq.append((sc, synth.perturb(Tt, seed=4200 + i, max_trans=tr, max_rot_deg=rot), meth))
+    runs = {}
+    for graph in ("1", "0"):
+        monkeypatch.setenv("ELM_GRAPH", graph)
+        c = Context(0)
+        try:
+            maps = {m: _maps(c, oracle, world100k, IcpMethod(m)) for m in (0, 2)}
+            out = []
+            for sc, T0, meth in seq:
+                reg = Registration(RegistrationConfig(icp_method=IcpMethod(meth)), c)
+                det = reg.RunRegisterBatch([Scan(c, sc)], maps[meth][0], [T0])[0]  # a batch of one: the shape elm_register itself enqueues
+                out.append((det["T"], det["is_success"], det["iterations"], det["gate"], det["n_corr_last"]))
+                pose, ok, fit, cov = reg.RunRegister(sc, maps[meth][0], T0)  # the reference API on host points (caller's order: other sums)
+                assert ok == det["is_success"] and float(np.abs(pose - det["T"]).max()) < 1e-9
+            runs[graph] = out
+            if graph == "1":
+                its = [o[2] for o in out]
+                assert max(its) >= min(its) + 3  # the long registration really outlasts the graph sized by the short ones
+                for (sc, T0, meth), o in zip(seq, out):
+                    ref = oracle.register(maps[meth][1], sc, T0, oracle.default_config(meth))
+                    assert ref["iterations"] == o[2] and ref["is_success"] == o[1]
+                    dt, dr = synth.pose_error(ref["T"], o[0])
+                    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
+            del maps
+        finally:
+            c.close()
+    for a, b in zip(runs["1"], runs["0"]):
+        assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
+
+
 def test_half_set_streams(oracle, world100k, monkeypatch):
     """ELM_HALF_SETS=1 (opt-in): the slots split into two halves (16 + 16, 9 + 8) whose solve side -- reduce, exchange, solve + refill --
     is queued on a second stream behind the half's accumulate launch while the compute stream goes on with the other half.  Results
