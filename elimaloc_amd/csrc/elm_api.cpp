@@ -227,6 +227,15 @@ static uint64_t host_available_bytes() {
     fclose(f);
     return found ? kb * 1024ull : ~0ull;
 }
+// the previous-winner buffer of the grid kernels: all -1 when it is (re)allocated (entries are only ever slot numbers or -1)
+static int prev_reserve(elm_ctx* ctx, size_t entries) {
+    const size_t bytes = entries * sizeof(uint32_t);
+    if (bytes <= ctx->d_prev.cap) return ELM_OK;
+    int rc = dev_reserve(ctx, ctx->d_prev, bytes);
+    if (rc != ELM_OK) return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_prev.p, 0xFF, ctx->d_prev.cap, ctx->stream));
+    return ELM_OK;
+}
 static int pinned_reserve(elm_ctx* ctx, void** p, size_t* cap, size_t bytes) {
     if (bytes <= *cap) return ELM_OK;
     if (*p) HIPCHK(ctx, hipHostFree(*p));
@@ -1856,7 +1865,7 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
     rp.tickets = nullptr;
     rp.prev = nullptr;
     if (ctx->prev_winner && !radar && blocks) { // one slot number per scan point: the next iteration's exact search starts from it
-        if ((rc = dev_reserve(ctx, ctx->d_prev, (size_t)blocks * kBlock * sizeof(uint32_t))) != ELM_OK) return rc;
+        if ((rc = prev_reserve(ctx, (size_t)blocks * kBlock)) != ELM_OK) return rc;
         rp.prev = (uint32_t*)ctx->d_prev.p;
     }
     if (ctx->fused_reduce && !radar) {
@@ -2172,7 +2181,7 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     rp.tickets = nullptr;
     rp.prev = nullptr;
     if (ctx->prev_winner && blocks) {
-        if ((rc = dev_reserve(ctx, ctx->d_prev, (size_t)blocks * kBlock * sizeof(uint32_t))) != ELM_OK) return rc;
+        if ((rc = prev_reserve(ctx, (size_t)blocks * kBlock)) != ELM_OK) return rc;
         rp.prev = (uint32_t*)ctx->d_prev.p;
     }
     if (ctx->fused_reduce) {
@@ -2472,7 +2481,7 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
     rp.tickets = nullptr;
     rp.prev = nullptr;
     if (ctx->prev_winner) {
-        if ((rc = dev_reserve(ctx, ctx->d_prev, (size_t)cap_blocks * (size_t)S * kBlock * sizeof(uint32_t))) != ELM_OK) return rc;
+        if ((rc = prev_reserve(ctx, (size_t)cap_blocks * (size_t)S * kBlock)) != ELM_OK) return rc;
         rp.prev = (uint32_t*)ctx->d_prev.p;
     }
     if (ctx->fused_reduce) {

@@ -1683,29 +1683,6 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
             }
         }
     }
-    // The previous iteration's winner of the same registration (rp.prev: one slot number per scan point, written at the end of every
-    // launch) is a candidate like any other: its distance to the NEW g bounds the nearest neighbour before anything is walked.  An
-    // undecided point takes the smaller of this bound and stage 1's -- a tighter ball and, for a point whose stage-1 block came back
-    // empty (a third of the undecided points under a poor initial guess), no seeding pass at all.  Exactness is untouched: the ball
-    // is still cleared completely, the bound only has to be an upper bound (float64 distance, rounded up).
-    const size_t pidx = (size_t)L * kBlock + threadIdx.x;
-    if (ELM_PREV_WINNER && rp.prev && S.iters > 0 && hard) {
-        const int pj = (int)rp.prev[pidx];
-        if (pj >= 0) {
-            double px, py, pz, gx, gy, gz;
-            transform(*stash(), px, py, pz, gx, gy, gz);
-            const Pt3 q = blk_point(lp, pj);
-            // only a point of one of the 27 buckets the reference visits for the NEW g is a candidate: stored (truncated) key within one of
-            // the query's floor key on every axis (vhm.cpp:275 / vhm.hpp:176-180, the arithmetic of grid_axis / visit_rank)
-            auto vk = [&](double v) { return (m.inv_vs_exact != 0.0) ? v * m.inv_vs_exact : v / m.voxel_size; };
-            const int dx = (int)vk((double)q.x) - (int)floor(vk(gx)), dy = (int)vk((double)q.y) - (int)floor(vk(gy)), dz = (int)vk((double)q.z) - (int)floor(vk(gz));
-            if (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1) {
-                const double ex = (double)q.x - gx, ey = (double)q.y - gy, ez = (double)q.z - gz;
-                const float d = (float)((ex * ex + ey * ey) + ez * ez);
-                hr2 = fminf(hr2, d + d * 2.4e-7f + 1e-30f); // (float) rounds to nearest: 2^-22 relative covers it upwards
-            }
-        }
-    }
     // ---- stage 2: queue the undecided points in thread order, ELM_HARD_LANES lanes per point
     const unsigned long long hm = __ballot(hard);
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1718,8 +1695,34 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
         n_hard += s_cnt[w];
     }
     my_slot += (unsigned)__popcll(hm & ((1ull << lane) - 1ull));
+    // A slot number per scan point (rp.prev) is kept -- read here, written at the end -- only by workgroups in which an eighth of the points
+    // or more are undecided (poor initial guesses; with a good one 2-3 % are, and the bookkeeping would cost more than it saves: -1.9 %
+    // on the easy set when unconditional).  An entry that is stale (an older iteration, an earlier registration of the slot) is still
+    // the slot of a real map point and is checked like any other before its distance is used; the buffer starts out as all -1.
+    const bool keep_prev = ELM_PREV_WINNER && rp.prev && n_hard >= (unsigned)kBlock / 8u; // uniform
+    const size_t pidx = (size_t)L * kBlock + threadIdx.x;
     if (n_hard) { // uniform
         GridHardRec* __restrict__ s_rec = reinterpret_cast<GridHardRec*>(s_buf);
+        if (keep_prev && hard) {
+            // its distance to the NEW g bounds the nearest neighbour before anything is walked: the point takes the smaller of this bound
+            // and stage 1's -- a tighter ball and, when the stage-1 block came back empty, no seeding pass.  Exactness is untouched: the
+            // ball is still cleared completely, the bound only has to be an upper bound (float64 distance, rounded up).
+            const int pj = (int)rp.prev[pidx];
+            if (pj >= 0) {
+                double px, py, pz, gx, gy, gz;
+                transform(*stash(), px, py, pz, gx, gy, gz);
+                const Pt3 q = blk_point(lp, pj);
+                // only a point of one of the 27 buckets the reference visits for the NEW g is a candidate: stored (truncated) key within one
+                // of the query's floor key on every axis (vhm.cpp:275 / vhm.hpp:176-180, the arithmetic of grid_axis / visit_rank)
+                auto vk = [&](double v) { return (m.inv_vs_exact != 0.0) ? v * m.inv_vs_exact : v / m.voxel_size; };
+                const int dx = (int)vk((double)q.x) - (int)floor(vk(gx)), dy = (int)vk((double)q.y) - (int)floor(vk(gy)), dz = (int)vk((double)q.z) - (int)floor(vk(gz));
+                if (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1) {
+                    const double ex = (double)q.x - gx, ey = (double)q.y - gy, ez = (double)q.z - gz;
+                    const float d = (float)((ex * ex + ey * ey) + ez * ez);
+                    hr2 = fminf(hr2, d + d * 2.4e-7f + 1e-30f); // (float) rounds to nearest: 2^-22 relative covers it upwards
+                }
+            }
+        }
         if (hard) {
             double px, py, pz;
             GridHardRec r;
@@ -1934,7 +1937,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
         }
         __syncthreads(); // the queue is dead: the reduction may overwrite it
     }
-    if (ELM_PREV_WINNER && rp.prev && valid) rp.prev[pidx] = (unsigned)bj; // (-1: no candidate at all)
+    if (keep_prev && valid) rp.prev[pidx] = (unsigned)bj; // (-1: no candidate at all)
     if (valid) {
         double px, py, pz, gx, gy, gz;
         const float4 pf = *stash();
