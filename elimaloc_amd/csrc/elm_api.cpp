@@ -99,7 +99,8 @@ struct elm_ctx {
     // hipGraph of ONE registration (batch = 1: RunRegister's own shape): descriptor + guess upload, init, K x (accumulate, solve), result
     // download captured once and replayed -- no launch gaps between the 2 K + 1 kernels.  Rebuilt when anything baked into it changes
     // (graph_key: the map's device view, the registration parameters, the grid size, K, the buffers).  ELM_GRAPH=0: plain launches.
-    bool use_graph = true;
+    bool use_graph = false; // ELM_GRAPH=1 (opt-in: measured on this runtime the replay is SLOWER than the plain launches -- 0.135 ms against 0.127 ms per
+                            // resident 131 072-point registration -- a graph launch costs more than the five launch gaps it removes)
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     std::vector<unsigned char> graph_key;
@@ -121,7 +122,7 @@ struct elm_ctx {
     std::vector<hipEvent_t> ev_groups; // host-fed streams: per upload group its "copied" and "ordered" events
     uint16_t* d_hilbert = nullptr; // Hilbert index of every cell of the ordering grid (kOrderCells^2 entries)
     DevBuf d_order_jobs, d_order_tmp, d_arena, d_raw, d_tickets, d_prev;
-    bool prev_winner = true; // ELM_PREV_WINNER=0: the grid kernels keep no previous winners (developer A/B)
+    bool prev_winner = false; // ELM_PREV_WINNER=1 (with a library built with -DELM_PREV_WINNER=1): the grid kernels keep every point's previous winner
     bool work_counters = false; // elm_ctx_set_work_counters / ELM_WORK_COUNTERS=1: the accumulate launches also sum the work counters of
                                 // elm_reg_result (n_cand_total, n_occ_total, n_tested_total, fallback_blocks); off: those fields read 0
     bool fused_reduce = false; // ELM_FUSED_REDUCE=1: the accumulate kernels' last workgroups reduce the partial records (no reduce launch:
@@ -1074,6 +1075,7 @@ static int build_cell_grid_impl(elm_map* m, uint64_t max_cells) {
     m->dm.grid_idx = d_idx;
     m->dm.grid_start = d_start;
     m->dm.grid_wide = wide_blocks ? 1 : 0;
+    m->dm.grid_nslots = (uint32_t)(4 * n_blk);
     m->dm.gx0 = lo[0]; m->dm.gy0 = lo[1]; m->dm.gz0 = lo[2];
     m->dm.gnx = (int32_t)dim[0]; m->dm.gny = (int32_t)dim[1]; m->dm.gnz = (int32_t)dim[2];
     m->dm.vox_stat = d_stat;
@@ -1252,6 +1254,7 @@ static int build_tiled_grid_impl(elm_map* m) {
     m->dm.grid_blk = d_blk; m->dm.grid_idx = d_idx; m->dm.grid_start = d_start; m->dm.grid_tiles = d_tiles;
     m->dm.grid_tiled = 1;
     m->dm.grid_wide = wide_blocks ? 1 : 0;
+    m->dm.grid_nslots = (uint32_t)(4 * n_blk);
     m->dm.gtny = (int32_t)tny;
     m->dm.gx0 = lo[0]; m->dm.gy0 = lo[1]; m->dm.gz0 = lo[2];
     m->dm.gnx = (int32_t)(tnx * kTile); m->dm.gny = (int32_t)(tny * kTile); m->dm.gnz = (int32_t)dim[2];

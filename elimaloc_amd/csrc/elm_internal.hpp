@@ -101,7 +101,8 @@ struct DevMap {
     int32_t grid_tiled;         // 1: grid_start is addressed through grid_tiles
     int32_t gtny;               // tiles along y
     int32_t grid_wide;          // 1: the block array is 4 GB or more -- stage 1 addresses it in 16-byte units (template flag WIDE)
-    int32_t _grid_pad;
+    uint32_t grid_nslots;       // 4 * n_blk: candidate slots of the block array (a slot number from elsewhere -- RegParams::prev may hold
+                                // entries written against another map -- is only dereferenced below this)
     const double* grid_gicp;    // [4 * n_blk][16]: pt_gicp gathered into slot order -- a GICP match reads its record without the index hop
                                 // (only for maps with a covariance outside the compact form)
     const double* grid_gicp8;   // [4 * n_blk][8]: the compact record {mean[3], unit normal[3], k, -}: 64 bytes = one memory sector per match;

@@ -1476,8 +1476,15 @@ __device__ __forceinline__ const uint32_t* col_cells(const DevMap& m, int cx, in
 #ifndef ELM_S2_SEED
 #define ELM_S2_SEED 1 // stage 2 seeds the ball of a point whose stage-1 block was empty (0: full walk of its 27 voxels, developer A/B)
 #endif
+#ifndef ELM_S2_GH
+#define ELM_S2_GH 0 // 1: stage 2's float32 pass on float32(g) alone (six packed subtractions fewer per block).  Measured (tools/r4_call5.sh, prebuilt
+                    // variants, two runs each): easy 94.46 k -> 93.78 k, hard 20.46 k -> 20.20 k registrations/s -- the root and the wider margin of the
+                    // decision cost more than the subtractions save.  Off.
+#endif
 #ifndef ELM_PREV_WINNER
-#define ELM_PREV_WINNER 1 // an undecided point's ball is also bounded by its previous iteration's winner (0: developer A/B)
+#define ELM_PREV_WINNER 0 // 1: an undecided point's ball is also bounded by its previous iteration's winner (RegParams::prev).  Measured (same A/B):
+                          // hard 20.20 k -> 20.71 k (+2.5 %), easy 93.78 k -> 93.08 k (-0.75 %, although only workgroups with >= 1/8 undecided points keep
+                          // the winners).  The headline workload pays for it: off; built with -DELM_PREV_WINNER=1 and run with ELM_PREV_WINNER=1
 #endif
 #ifndef ELM_GRID_WAVES
 #define ELM_GRID_WAVES 7 // minimum waves per SIMD = a 72-VGPR cap (2 spilled registers).  Measured registrations/s: 5 -> 59.8k, 6 -> 63.9k, 7 -> 65.6k,
@@ -1707,11 +1714,11 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
             // its distance to the NEW g bounds the nearest neighbour before anything is walked: the point takes the smaller of this bound
             // and stage 1's -- a tighter ball and, when the stage-1 block came back empty, no seeding pass.  Exactness is untouched: the
             // ball is still cleared completely, the bound only has to be an upper bound (float64 distance, rounded up).
-            const int pj = (int)rp.prev[pidx];
-            if (pj >= 0) {
+            const unsigned pj = rp.prev[pidx];
+            if (pj < m.grid_nslots) { // (-1 = none; an entry written against another map may lie beyond this one's slots)
                 double px, py, pz, gx, gy, gz;
                 transform(*stash(), px, py, pz, gx, gy, gz);
-                const Pt3 q = blk_point(lp, pj);
+                const Pt3 q = blk_point(lp, (int)pj);
                 // only a point of one of the 27 buckets the reference visits for the NEW g is a candidate: stored (truncated) key within one
                 // of the query's floor key on every axis (vhm.cpp:275 / vhm.hpp:176-180, the arithmetic of grid_axis / visit_rank)
                 auto vk = [&](double v) { return (m.inv_vs_exact != 0.0) ? v * m.inv_vs_exact : v / m.voxel_size; };
@@ -1800,8 +1807,10 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
                 // distances to gh = float32(g) alone (six packed subtractions fewer per block, as in stage 1): an exact distance to g differs
                 // from the one to gh by at most eg = |g - gh|_1 in the ROOT, which the decision below pays for
                 const float ghx = (float)R.gx, ghy = (float)R.gy, ghz = (float)R.gz;
-                const float eg = (fabsf((float)(R.gx - (double)ghx)) + fabsf((float)(R.gy - (double)ghy)) + fabsf((float)(R.gz - (double)ghz))) * 1.000001f;
-                const f32x2 gxy = {ghx, ghy}, gzz = {ghz, 0.f};
+                const float glx = (float)(R.gx - (double)ghx), gly = (float)(R.gy - (double)ghy), glz = (float)(R.gz - (double)ghz);
+                const float eg = ELM_S2_GH ? (fabsf(glx) + fabsf(gly) + fabsf(glz)) * 1.000001f : 0.f;
+                const f32x2 gxy = {ghx, ghy}, gzz = {ghz, 0.f}, gzl = {ghz, glx}, gl2 = {gly, glz};
+                (void)gzz; (void)gzl; (void)gl2;
                 unsigned m1 = 0x7F800000u, m2 = 0x7F800000u;
                 int jb = 0;
                 const float rny = __builtin_amdgcn_rcpf((float)ny); // c / ny for the few dozen columns of a ball: exact via float32
@@ -1828,7 +1837,8 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
                         const GridBlk B = Bn;
                         Bn = lp[(b + 1 < b1) ? b + 1 : 0]; // (block 0: the padding block, always resident)
                         f32x2 da, db;
-                        blk_dist_h(B, gxy, gzz, da, db);
+                        if (ELM_S2_GH) blk_dist_h(B, gxy, gzz, da, db);
+                        else blk_dist(B, gxy, gzl, gl2, da, db);
                         const unsigned was = m1;
                         two_smallest(da.x, 0u, m1, m2);
                         two_smallest(da.y, 1u, m1, m2);
@@ -1848,7 +1858,8 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
                     for (int b = b0; b < b1; ++b) {
                         const GridBlk B = lp[b];
                         f32x2 da, db;
-                        blk_dist_h(B, gxy, gzz, da, db);
+                        if (ELM_S2_GH) blk_dist_h(B, gxy, gzz, da, db);
+                        else blk_dist(B, gxy, gzl, gl2, da, db);
                         const unsigned was = m1;
                         two_smallest(da.x, 0u, m1, m2);
                         two_smallest(da.y, 1u, m1, m2);
@@ -1868,7 +1879,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
                 // stage 1) <=> d2 > d1 + 4 eg sqrt(d1) + 4 eg^2, with sqrt(d2) >= sqrt(d1) in its place (one root per point, padding
                 // slots at 1e36 included: they never win)
                 const float s2 = __builtin_sqrtf(fminf(d2, 1e30f)) * 1.000001f;
-                const float slack = (4.0f * eg * s2 + 4.0f * eg * eg) * 1.000001f;
+                const float slack = ELM_S2_GH ? (4.0f * eg * s2 + 4.0f * eg * eg) * 1.000001f : 4e-11f * (fabsf(ghx) + fabsf(ghy) + fabsf(ghz) + 1.0f);
                 if (jw >= 4 && d2 > d1 + d1 * 3.814697265625e-06f + slack) win = jw; // (2^-18 on one side covers both, as in stage 1)
                 else need64 = live && jw >= 4;                                         // near tie: the float64 walk below decides
             }
@@ -2279,6 +2290,7 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
             double n_pairs = 0.0;
             AvgPairSum Q;
             avg_pair_init(Q);
+            const bool faces_only = m.vq_dense && m.vqf_dense; // uniform: lp is a face sublist
             for (unsigned j = 0; j < cnt; j += ELM_AVG_RECS) { // ELM_AVG_RECS records (two 16-byte loads each) per round trip
                 VoxRec r[ELM_AVG_RECS];
 #pragma unroll
@@ -2288,8 +2300,11 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
                 double Ci[ELM_AVG_RECS][9];
 #pragma unroll
                 for (int u = 0; u < ELM_AVG_RECS; ++u) {
-                    const int code = r[u].pad;
-                    use[u] = j + u < cnt && (code == 13 || code == 22 || code == 4 || code == 16 || code == 10 || code == 14 || code == 12);
+                    // the face neighbours (and the voxel itself): position codes 4, 10, 12, 13, 14, 16, 22 -- one shift of a 27-bit mask; the
+                    // face sublists hold nothing else (uniform branch: no test at all)
+                    constexpr unsigned kFaceMask = (1u << 4) | (1u << 10) | (1u << 12) | (1u << 13) | (1u << 14) | (1u << 16) | (1u << 22);
+                    if (faces_only) use[u] = j + u < cnt;
+                    else use[u] = j + u < cnt && ((kFaceMask >> ((unsigned)r[u].pad & 31u)) & 1u) != 0u;
                     if (COMPACT && r[u].k == r[u].k) {
                         compact_cinv(r[u].nx, r[u].ny, r[u].nz, r[u].k, Ci[u]);
                     } else {
@@ -3508,13 +3523,14 @@ void launch_scan_order(hipStream_t s, const OrderJob* jobs, int n_jobs, const ui
 }
 
 // ---- the same ordering of ONE scan by many workgroups (a scan uploaded on its own: k_scan_order's single workgroup takes 0.29 ms for
-// 131 072 points on one CU).  Three launches, the same stable counting sort, hence the same bytes as k_scan_order:
+// 131 072 points on one CU).  Four launches, the same stable counting sort, hence the same bytes as k_scan_order:
 //   k_order_rank     workgroup g owns the contiguous points [g C, (g + 1) C) (4 wavefronts, contiguous quarters): rank of every point
 //                    inside its (workgroup, key) run -- per-wave ballot ranking as above, then the exclusive prefix over the four
 //                    waves -- into tmp[i] = key | rank << 12, the workgroup's per-key totals into hist[g][key]
-//   k_order_prefix   one workgroup: start[g][key] = points of smaller keys + points of this key in workgroups before g; flag = a key
-//                    with more than 65535 points or a scan beyond k_scan_order's size limit (the scan keeps the caller's order)
-//   k_order_scatter  dst[start[g][key] + rank] = src[i]
+//   k_order_prefix   start[g][key] = points of this key in workgroups before g (16 workgroups x 256 keys), tot[key]; flag = a key with more
+//                    than 65535 points (the scan keeps the caller's order)
+//   k_order_base     one workgroup: base[key] = points of smaller keys; flag also for a scan beyond k_scan_order's size limit
+//   k_order_scatter  dst[start[g][key] + base[key] + rank] = src[i]
 constexpr int kWideWaves = 4, kWideThreads = kWideWaves * 64;
 __global__ __launch_bounds__(kWideThreads) void k_order_rank(const OrderJob* __restrict__ jobs, const uint16_t* __restrict__ hilbert_lut, unsigned chunk,
                                                             uint16_t* __restrict__ hist) {
@@ -3567,29 +3583,33 @@ __global__ __launch_bounds__(kWideThreads) void k_order_rank(const OrderJob* __r
         job.tmp[i] = (d & 4095u) | (((d >> 12) + s_cnt[wave][d & 4095u]) << 12);
     }
 }
-__global__ __launch_bounds__(1024) void k_order_prefix(const OrderJob* __restrict__ jobs, const uint16_t* __restrict__ hist, unsigned G, unsigned* __restrict__ start,
-                                                      int* __restrict__ flag) {
-    __shared__ unsigned s_tot[kOrderBins];
-    __shared__ unsigned s_wsum[16];
-    __shared__ int s_over;
-    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    if (tid == 0) s_over = (((jobs[0].n + kOrderThreads - 1) / kOrderThreads) * 64u > 65535u) ? 1 : 0; // k_scan_order's own size limit (its `too_long`)
-    __syncthreads();
-    for (unsigned key = tid; key < (unsigned)kOrderBins; key += 1024u) { // coalesced over the keys
-        unsigned run = 0;
-        for (unsigned g = 0; g < G; ++g) {
-            const unsigned c = hist[(size_t)g * kOrderBins + key];
-            start[(size_t)g * kOrderBins + key] = run;
-            run += c;
-        }
-        s_tot[key] = run;
-        if (run > 65535u) s_over = 1;
-    }
-    __syncthreads();
-    unsigned t4[4], tot = 0; // exclusive scan over the keys: four consecutive keys per thread
+// (a) per key, over the workgroups: 16 workgroups x 256 keys, the G loads of a key sixteen at a time
+__global__ __launch_bounds__(256) void k_order_prefix(const uint16_t* __restrict__ hist, unsigned G, unsigned* __restrict__ start, unsigned* __restrict__ tot,
+                                                     int* __restrict__ flag) {
+    const unsigned key = blockIdx.x * 256u + threadIdx.x;
+    unsigned run = 0;
+    for (unsigned g0 = 0; g0 < G; g0 += 16u) { // sixteen independent loads in flight, then the running sum
+        unsigned c[16];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { t4[q] = tot; tot += s_tot[tid * 4u + (unsigned)q]; }
-    unsigned inc = tot;
+        for (unsigned u = 0; u < 16u; ++u) c[u] = (g0 + u < G) ? hist[(size_t)(g0 + u) * kOrderBins + key] : 0u;
+#pragma unroll
+        for (unsigned u = 0; u < 16u; ++u) {
+            if (g0 + u < G) start[(size_t)(g0 + u) * kOrderBins + key] = run;
+            run += c[u];
+        }
+    }
+    tot[key] = run;
+    if (run > 65535u) atomicOr(flag, 1); // a cell with more than 65535 points: the scan keeps the caller's order (k_scan_order's rule)
+}
+// (b) over the keys: base[key] = points of smaller keys (one workgroup, four consecutive keys per thread)
+__global__ __launch_bounds__(1024) void k_order_base(const OrderJob* __restrict__ jobs, const unsigned* __restrict__ tot, unsigned* __restrict__ base,
+                                                    int* __restrict__ flag) {
+    __shared__ unsigned s_wsum[16];
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint4 t = reinterpret_cast<const uint4*>(tot)[tid];
+    const unsigned t4[4] = {0u, t.x, t.x + t.y, t.x + t.y + t.z};
+    const unsigned sum = t.x + t.y + t.z + t.w;
+    unsigned inc = sum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const unsigned o = (unsigned)__shfl_up((int)inc, off, 64);
@@ -3600,19 +3620,12 @@ __global__ __launch_bounds__(1024) void k_order_prefix(const OrderJob* __restric
     unsigned wbase = 0;
 #pragma unroll
     for (unsigned w = 0; w < 16u; ++w) wbase += (w < wave) ? s_wsum[w] : 0u;
-    const unsigned ex = wbase + inc - tot;
-    __syncthreads(); // every thread has read its four totals
-#pragma unroll
-    for (int q = 0; q < 4; ++q) s_tot[tid * 4u + (unsigned)q] = ex + t4[q];
-    __syncthreads();
-    for (unsigned key = tid; key < (unsigned)kOrderBins; key += 1024u) {
-        const unsigned b = s_tot[key];
-        for (unsigned g = 0; g < G; ++g) start[(size_t)g * kOrderBins + key] += b;
-    }
-    if (tid == 0) *flag = s_over;
+    const unsigned ex = wbase + inc - sum;
+    reinterpret_cast<uint4*>(base)[tid] = make_uint4(ex + t4[0], ex + t4[1], ex + t4[2], ex + t4[3]);
+    if (tid == 0 && ((jobs[0].n + kOrderThreads - 1) / kOrderThreads) * 64u > 65535u) atomicOr(flag, 1); // k_scan_order's own size limit (its `too_long`)
 }
 __global__ __launch_bounds__(kWideThreads) void k_order_scatter(const OrderJob* __restrict__ jobs, unsigned chunk, const unsigned* __restrict__ start,
-                                                               const int* __restrict__ flag) {
+                                                               const unsigned* __restrict__ base, const int* __restrict__ flag) {
     __shared__ unsigned s_start[kOrderBins];
     const OrderJob job = jobs[0];
     const unsigned n = job.n, tid = threadIdx.x, g = blockIdx.x;
@@ -3621,7 +3634,7 @@ __global__ __launch_bounds__(kWideThreads) void k_order_scatter(const OrderJob* 
         for (unsigned i = i0 + tid; i < i1; i += kWideThreads) job.dst[i] = job.src[i];
         return;
     }
-    for (unsigned k = tid; k < (unsigned)kOrderBins; k += kWideThreads) s_start[k] = start[(size_t)g * kOrderBins + k];
+    for (unsigned k = tid; k < (unsigned)kOrderBins; k += kWideThreads) s_start[k] = start[(size_t)g * kOrderBins + k] + base[k];
     __syncthreads();
     for (unsigned i = i0 + tid; i < i1; i += kWideThreads) {
         const unsigned d = job.tmp[i];
@@ -3633,17 +3646,21 @@ unsigned order_wide_groups(unsigned n) {
     unsigned G = (n + 2047u) / 2048u;
     return G < 2u ? 2u : (G > 64u ? 64u : G);
 }
-size_t order_wide_scratch_bytes(unsigned n) { return (size_t)order_wide_groups(n) * kOrderBins * 6 + 64; }
+size_t order_wide_scratch_bytes(unsigned n) { return (size_t)order_wide_groups(n) * kOrderBins * 6 + (size_t)kOrderBins * 8 + 64; }
 void launch_scan_order_wide(hipStream_t s, const OrderJob* job, unsigned n, const uint16_t* hilbert_lut, void* scratch) {
     const unsigned G = order_wide_groups(n);
     unsigned chunk = (n + G - 1) / G;
     chunk = ((chunk + kWideThreads - 1) / kWideThreads) * kWideThreads; // whole 64-point steps per wave
     unsigned* start = (unsigned*)scratch;
-    uint16_t* hist = (uint16_t*)((char*)scratch + (size_t)G * kOrderBins * 4);
-    int* flag = (int*)((char*)scratch + (size_t)G * kOrderBins * 6);
+    unsigned* tot = start + (size_t)G * kOrderBins;
+    unsigned* base = tot + kOrderBins;
+    uint16_t* hist = (uint16_t*)(base + kOrderBins);
+    int* flag = (int*)((char*)scratch + (size_t)G * kOrderBins * 6 + (size_t)kOrderBins * 8);
+    (void)hipMemsetAsync(flag, 0, sizeof(int), s);
     hipLaunchKernelGGL(k_order_rank, dim3(G), dim3(kWideThreads), 0, s, job, hilbert_lut, chunk, hist);
-    hipLaunchKernelGGL(k_order_prefix, dim3(1), dim3(1024), 0, s, job, (const uint16_t*)hist, G, start, flag);
-    hipLaunchKernelGGL(k_order_scatter, dim3(G), dim3(kWideThreads), 0, s, job, chunk, (const unsigned*)start, (const int*)flag);
+    hipLaunchKernelGGL(k_order_prefix, dim3(kOrderBins / 256), dim3(256), 0, s, (const uint16_t*)hist, G, start, tot, flag);
+    hipLaunchKernelGGL(k_order_base, dim3(1), dim3(1024), 0, s, job, (const unsigned*)tot, base, flag);
+    hipLaunchKernelGGL(k_order_scatter, dim3(G), dim3(kWideThreads), 0, s, job, chunk, (const unsigned*)start, (const unsigned*)base, (const int*)flag);
 }
 // host-fed streams: the upload stream publishes how many scans have landed (after their ordering kernel, same stream)
 __global__ void k_publish_ready(StreamCtrl* ctrl, int ready) {

@@ -674,7 +674,7 @@ def test_single_registration_graph_replay(oracle, world100k, monkeypatch):
         sc, Tt = synth.make_scan(world100k, n, seed=4100 + i)
         seq.append((sc, synth.perturb(Tt, seed=4200 + i, max_trans=tr, max_rot_deg=rot), meth))
     runs = {}
-    for graph in ("1", "0"):
+    for graph in ("1", "0"):  # (opt-in: plain launches are the default)
         monkeypatch.setenv("ELM_GRAPH", graph)
         c = Context(0)
         try:
