@@ -99,6 +99,7 @@ struct elm_ctx {
     // hipGraph of ONE registration (batch = 1: RunRegister's own shape): descriptor + guess upload, init, K x (accumulate, solve), result
     // download captured once and replayed -- no launch gaps between the 2 K + 1 kernels.  Rebuilt when anything baked into it changes
     // (graph_key: the map's device view, the registration parameters, the grid size, K, the buffers).  ELM_GRAPH=0: plain launches.
+    int persist_wgs = 0;    // ELM_PERSIST_WGS=n: resident workgroups of the grid kernel (developer A/B; 0 = one workgroup per tile)
     bool use_graph = false; // ELM_GRAPH=1 (opt-in: measured on this runtime the replay is SLOWER than the plain launches -- 0.135 ms against 0.127 ms per
                             // resident 131 072-point registration -- a graph launch costs more than the five launch gaps it removes)
     hipGraph_t graph = nullptr;
@@ -305,6 +306,7 @@ extern "C" int elm_ctx_create(int device_id, elm_ctx** out) {
     if (const char* f = getenv("ELM_HALF_SETS")) ctx->half_sets = strcmp(f, "0") != 0 ? 1 : 0;
     if (const char* f = getenv("ELM_PREV_WINNER")) ctx->prev_winner = strcmp(f, "0") != 0;
     if (const char* f = getenv("ELM_GRAPH")) ctx->use_graph = strcmp(f, "0") != 0;
+    if (const char* f = getenv("ELM_PERSIST_WGS")) ctx->persist_wgs = atoi(f);
     {
         std::lock_guard<std::mutex> lk(g_live_mu);
         ctx->id = g_next_ctx_id++;
@@ -1861,6 +1863,7 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
     rp.uniform_blocks = uniform_blocks;
     rp.radar = radar ? 1 : 0;
     rp.stats = ctx->work_counters ? 1 : 0;
+    rp.persist_wgs = ctx->persist_wgs;
     rp.radar_var[0] = cfg->range_variance_m;
     rp.radar_var[1] = cfg->azimuth_variance_deg;
     rp.radar_var[2] = cfg->elevation_variance_deg;
@@ -2179,6 +2182,7 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     rp.uniform_blocks = cap_blocks; // every slot owns cap_blocks workgroups
     rp.radar = 0;
     rp.stats = ctx->work_counters ? 1 : 0;
+    rp.persist_wgs = ctx->persist_wgs;
     rp.radar_var[0] = rp.radar_var[1] = rp.radar_var[2] = 0.0;
     rp.sums = nullptr;
     rp.tickets = nullptr;
@@ -2479,6 +2483,7 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
     rp.uniform_blocks = cap_blocks;
     rp.radar = 0;
     rp.stats = ctx->work_counters ? 1 : 0;
+    rp.persist_wgs = ctx->persist_wgs;
     rp.radar_var[0] = rp.radar_var[1] = rp.radar_var[2] = 0.0;
     rp.sums = nullptr;
     rp.tickets = nullptr;
