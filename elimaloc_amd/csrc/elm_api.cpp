@@ -99,7 +99,6 @@ struct elm_ctx {
     // hipGraph of ONE registration (batch = 1: RunRegister's own shape): descriptor + guess upload, init, K x (accumulate, solve), result
     // download captured once and replayed -- no launch gaps between the 2 K + 1 kernels.  Rebuilt when anything baked into it changes
     // (graph_key: the map's device view, the registration parameters, the grid size, K, the buffers).  ELM_GRAPH=0: plain launches.
-    int persist_wgs = 0;    // ELM_PERSIST_WGS=n: resident workgroups of the grid kernel (developer A/B; 0 = one workgroup per tile)
     bool use_graph = false; // ELM_GRAPH=1 (opt-in: measured on this runtime the replay is SLOWER than the plain launches -- 0.135 ms against 0.127 ms per
                             // resident 131 072-point registration -- a graph launch costs more than the five launch gaps it removes)
     hipGraph_t graph = nullptr;
@@ -136,7 +135,9 @@ struct elm_ctx {
     DevBuf d_scans, d_state, d_partials, d_sums, d_T0, d_trace, d_stage_pts, d_active, d_queue, d_ds;
     int stream_hint_count = 0, stream_hint_slots = 0, stream_hint_iters = 0; // iterations the last elm_register_stream call of that shape needed
     int* h_active = nullptr; // pinned: number of scans still iterating, read back at the early-stop checks
-    int iter_hint = 0;       // iterations the previous batch needed (0 = unknown): first early-stop check happens there
+    int iter_hint = 0;       // iterations the longest of the last eight batches needed (0 = unknown): first early-stop check happens there
+    int iter_ring[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned iter_ring_pos = 0;
     void* h_state = nullptr; // pinned
     size_t h_state_cap = 0;
     void* h_trace = nullptr; // pinned
@@ -306,7 +307,6 @@ extern "C" int elm_ctx_create(int device_id, elm_ctx** out) {
     if (const char* f = getenv("ELM_HALF_SETS")) ctx->half_sets = strcmp(f, "0") != 0 ? 1 : 0;
     if (const char* f = getenv("ELM_PREV_WINNER")) ctx->prev_winner = strcmp(f, "0") != 0;
     if (const char* f = getenv("ELM_GRAPH")) ctx->use_graph = strcmp(f, "0") != 0;
-    if (const char* f = getenv("ELM_PERSIST_WGS")) ctx->persist_wgs = atoi(f);
     {
         std::lock_guard<std::mutex> lk(g_live_mu);
         ctx->id = g_next_ctx_id++;
@@ -1863,7 +1863,6 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
     rp.uniform_blocks = uniform_blocks;
     rp.radar = radar ? 1 : 0;
     rp.stats = ctx->work_counters ? 1 : 0;
-    rp.persist_wgs = ctx->persist_wgs;
     rp.radar_var[0] = cfg->range_variance_m;
     rp.radar_var[1] = cfg->azimuth_variance_deg;
     rp.radar_var[2] = cfg->elevation_variance_deg;
@@ -2064,7 +2063,14 @@ extern "C" int elm_register_batch_finish(elm_ctx* ctx, elm_reg_result* results, 
     {
         int mx = 0;
         for (int b = 0; b < ctx->batch; ++b) mx = std::max(mx, (int)hs[b].iters);
-        ctx->iter_hint = mx; // where the next batch's first early-stop check goes
+        // where the next batch's first early-stop check goes: the LONGEST of the last eight batches.  (The previous batch's own count
+        // mispredicts a stream whose registrations alternate between 2 and 3 iterations every other call: a check one iteration early
+        // costs a host round trip in the middle of the registration, ~25 us, a check one iteration late one pair of launches that
+        // return at once, ~10 us -- profiles/r04_single_timeline.txt.)
+        ctx->iter_ring[ctx->iter_ring_pos++ & 7] = mx;
+        int h = 0;
+        for (int k = 0; k < 8; ++k) h = std::max(h, ctx->iter_ring[k]);
+        ctx->iter_hint = h;
     }
     if (trace && ctx->want_trace)
         memcpy(trace, ctx->h_trace, (size_t)ctx->batch * ELM_MAX_ITER_TRACE * sizeof(elm_iter_trace));
@@ -2182,7 +2188,6 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     rp.uniform_blocks = cap_blocks; // every slot owns cap_blocks workgroups
     rp.radar = 0;
     rp.stats = ctx->work_counters ? 1 : 0;
-    rp.persist_wgs = ctx->persist_wgs;
     rp.radar_var[0] = rp.radar_var[1] = rp.radar_var[2] = 0.0;
     rp.sums = nullptr;
     rp.tickets = nullptr;
@@ -2483,7 +2488,6 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
     rp.uniform_blocks = cap_blocks;
     rp.radar = 0;
     rp.stats = ctx->work_counters ? 1 : 0;
-    rp.persist_wgs = ctx->persist_wgs;
     rp.radar_var[0] = rp.radar_var[1] = rp.radar_var[2] = 0.0;
     rp.sums = nullptr;
     rp.tickets = nullptr;

@@ -1498,8 +1498,7 @@ __device__ __forceinline__ const uint32_t* col_cells(const DevMap& m, int cx, in
 // STATS = 0: no statistics load, 18 (P2P) / 29 reduced values, no per-point bookkeeping in stage 2.
 // WIDE = 1: the block array does not fit 32-bit byte offsets (4 GB = ~275 M map points): stage 1 carries offsets in 16-byte units
 // (three per block) and forms the 64-bit address per block with one shift-add; everything else addresses blocks by index already.
-// PERSIST = 1 (RegParams::persist_wgs, developer A/B): fewer, resident workgroups that walk the tiles.
-template <int METHOD, int COMPACT, int TILED, int STATS, int WIDE, int PERSIST>
+template <int METHOD, int COMPACT, int TILED, int STATS, int WIDE>
 __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_GICP_WAVES)) void k_accumulate_grid(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
                                                                             unsigned total_blocks, const ScanState* __restrict__ st,
                                                                             double* __restrict__ partials, const RegParams rp) {
@@ -1509,17 +1508,12 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
     __shared__ int s_res[kBlock];
     __shared__ int s_tst[STATS ? kBlock : 1];
     __shared__ unsigned s_cnt[kBlock / 64];
-    // Launched with one workgroup per 256-point tile, or (RegParams::persist_wgs) with fewer, resident workgroups that walk the tiles
-    // tile = blockIdx.x, + gridDim.x, ... (gridDim.x a multiple of 8, so a workgroup's tiles share its XCD and xcd_remap's ranges hold)
-    unsigned tile = blockIdx.x;
-    do {
-    if (PERSIST && tile != blockIdx.x) __syncthreads(); // the previous tile's reduction has read its LDS
-    const unsigned L = xcd_remap(tile, total_blocks);
+    const unsigned L = xcd_remap(blockIdx.x, total_blocks);
     const int s = find_scan(scans, batch, L, rp);
     const ScanState& S = st[s];
-    if (S.done) continue;
+    if (S.done) return;
     const ScanDesc sd = scans[s];
-    if (L >= sd.blk_end) continue; // a scan whose size was only known on the device owns fewer workgroups than were launched for it
+    if (L >= sd.blk_end) return; // a scan whose size was only known on the device owns fewer workgroups than were launched for it
     const unsigned i = (L - sd.blk_begin) * kBlock + threadIdx.x;
     const bool valid = i < sd.n;
     double v[(METHOD == ELM_P2P) ? NV : 1]; // P2P: its 18 sums + 3 counters; GICP: the factored form P below
@@ -2028,7 +2022,6 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
     const int tk = (int)threadIdx.x;
     publish_and_reduce((tk < kSums && (STATS || tk < kSums - 3)) ? ((METHOD == ELM_P2P) ? p2p_expand(s_red, tk) : s_red[tk]) : 0.0, L, s, sd.blk_begin,
                        sd.blk_end, partials, rp, s_buf);
-    } while (PERSIST && (tile += gridDim.x) < total_blocks); // tiles
 }
 
 // map build: the GICP payload records in grid slot order (16 lanes per record, one 8-byte word each); COMPACT: the 64-byte form
@@ -3202,15 +3195,8 @@ void launch_accumulate_cell(hipStream_t s, const DevMap& m, const ScanDesc* scan
 }
 void launch_accumulate_grid(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                             ScanState* st, double* partials, const RegParams& rp) {
-    const int resident = rp.persist_wgs & ~7;
-    const bool persist = resident > 0 && resident < total_blocks;
     dim3 g(total_blocks), b(kBlock);
-#define ELM_LAUNCH_GW(M, C, T, S_, W_)                                                                                                                      \
-    do {                                                                                                                                                \
-        if (persist && !(T) && !(S_) && !(W_)) /* the resident form exists for the dense, uninstrumented, narrow kernels only */                          \
-            hipLaunchKernelGGL((k_accumulate_grid<M, C, 0, 0, 0, 1>), dim3(resident), b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp); \
-        else hipLaunchKernelGGL((k_accumulate_grid<M, C, T, S_, W_, 0>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);          \
-    } while (0)
+#define ELM_LAUNCH_GW(M, C, T, S_, W_) hipLaunchKernelGGL((k_accumulate_grid<M, C, T, S_, W_>), g, b, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp)
 #define ELM_LAUNCH_G(M, C, T)                                   \
     do {                                                        \
         if (m.grid_wide) {                                      \
