@@ -114,6 +114,8 @@ struct elm_ctx {
         uint32_t blocks = 0;
         int iters = 0, max_iter = 0;
     } grun;
+    bool dist_refill_kernel = false; // ELM_DIST_REFILL=kernel: multi-rank streams refill their slots with a launch of their own (dynamic, in slot order)
+                                     // instead of the static per-slot queue inside the solve
     int half_sets = 0;                  // ELM_HALF_SETS=1: the two-half pipeline (off by default: measured on one MI355X it LOSES 4 % without a
                                         // communicator and 40 % on the one-rank RCCL path -- the solve's 1024-thread, 84-VGPR workgroups are not
                                         // placed while the other half's accumulate grid still has workgroups to issue, so nothing overlaps and the
@@ -305,6 +307,7 @@ extern "C" int elm_ctx_create(int device_id, elm_ctx** out) {
     if (const char* f = getenv("ELM_FUSED_REDUCE")) ctx->fused_reduce = strcmp(f, "0") != 0;
     if (const char* f = getenv("ELM_WORK_COUNTERS")) ctx->work_counters = strcmp(f, "0") != 0;
     if (const char* f = getenv("ELM_HALF_SETS")) ctx->half_sets = strcmp(f, "0") != 0 ? 1 : 0;
+    if (const char* f = getenv("ELM_DIST_REFILL")) ctx->dist_refill_kernel = strcmp(f, "kernel") == 0;
     if (const char* f = getenv("ELM_PREV_WINNER")) ctx->prev_winner = strcmp(f, "0") != 0;
     if (const char* f = getenv("ELM_GRAPH")) ctx->use_graph = strcmp(f, "0") != 0;
     {
@@ -2270,8 +2273,16 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
                 if ((rc = exchange(ctx, sums_h, (size_t)Sh * kSums, ss)) != ELM_OK) return rc;
                 // the solve also refills: slot s serves the registrations s, s + S, s + 2 S, ... -- a function of the slot alone, so every
                 // rank hands out the same registrations without a refill launch (3 launches + 1 collective per iteration)
-                const StreamArgs sr = {dsc_h, d_q, d_qT0, d_out, d_ctrl, 0, S};
-                launch_solve(ss, dsc_h, Sh, st_h, partials_h, sums_h, rph, d_trace, 2, d_active, &sr);
+                if (ctx->dist_refill_kernel && H == 1) {
+                    // ... or a refill launch of its own (4 launches + 1 collective): ONE workgroup walks the slots in slot order and hands the
+                    // finished ones the next pending registrations -- first come, first served like the single-rank stream, yet identical on
+                    // every rank (the finished flags derive from the all-reduced sums), so no slot idles while the queue has work
+                    launch_solve(ss, dsc_h, Sh, st_h, partials_h, sums_h, rph, d_trace, 2, d_active);
+                    launch_stream_refill(ss, dsc, st, S, d_q, d_qT0, d_out, d_ctrl, 0);
+                } else {
+                    const StreamArgs sr = {dsc_h, d_q, d_qT0, d_out, d_ctrl, 0, S};
+                    launch_solve(ss, dsc_h, Sh, st_h, partials_h, sums_h, rph, d_trace, 2, d_active, &sr);
+                }
             } else {
                 // single rank: the solve hands finished slots their next registration itself (no refill launch)
                 const StreamArgs sa = {dsc_h, d_q, d_qT0, d_out, d_ctrl, 0, 0};

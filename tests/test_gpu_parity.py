@@ -702,6 +702,43 @@ def test_single_registration_graph_replay(oracle, world100k, monkeypatch):
         assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
 
 
+@pytest.mark.parametrize("refill", ["kernel", "solve"])
+def test_multi_rank_stream_refill_forms(oracle, world100k, monkeypatch, refill):
+    """The two ways a multi-rank stream hands finished slots their next registration identically on every rank: the static per-slot queue
+    inside the solve launch (slot s serves s, s + S, ...) and (ELM_DIST_REFILL=kernel) a refill launch that walks the slots in slot order.
+    Driven through an identity exchange hook (the multi-rank control flow on one rank): bit-identical to the lockstep batch, gated
+    registrations included, and the dynamic form needs no more iterations than the static one."""
+    from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, Scan
+    monkeypatch.setenv("ELM_DIST_REFILL", refill)
+    c = Context(0)
+    try:
+        vm, om = _maps(c, oracle, world100k, IcpMethod.P2P)
+        reg = Registration(RegistrationConfig(icp_method=IcpMethod.P2P, min_overlap_ratio=0.5), c)
+        scans, T0s = [], []
+        for i in range(90):
+            sc, Tt = synth.make_scan(world100k, 300 + 37 * (i % 11), seed=2000 + i)
+            if i % 13 == 5:
+                sc = sc + np.float32(500.0)
+            scans.append(Scan(c, sc))
+            T0s.append(synth.perturb(Tt, seed=3000 + i, max_trans=0.02 + 0.01 * (i % 17), max_rot_deg=0.1 * (i % 9)))
+        batch = reg.RunRegisterBatch(scans, vm, T0s)
+        calls = []
+        c.set_allreduce_hook(lambda p, n, s: (calls.append(n), 0)[1])
+        try:
+            for slots in (7, 20):
+                del calls[:]
+                out = reg.RunRegisterStream(scans, vm, T0s, slots=slots)
+                for k, (a, b) in enumerate(zip(out, batch)):
+                    assert (a["iterations"], a["is_success"], a["gate"]) == (b["iterations"], b["is_success"], b["gate"]), (slots, k)
+                    assert np.array_equal(a["T"], b["T"]) and a["n_corr_last"] == b["n_corr_last"], (slots, k)
+                assert set(calls) == {slots * 32}
+        finally:
+            c.set_allreduce_hook(None)
+        del scans, vm
+    finally:
+        c.close()
+
+
 def test_half_set_streams(oracle, world100k, monkeypatch):
     """ELM_HALF_SETS=1 (opt-in): the slots split into two halves (16 + 16, 9 + 8) whose solve side -- reduce, exchange, solve + refill --
     is queued on a second stream behind the half's accumulate launch while the compute stream goes on with the other half.  Results
