@@ -154,10 +154,12 @@ void elm_map_destroy(elm_map* map);
 int elm_map_cal_voxel_cov_all(elm_map* map);
 /* VoxelHashMap::CalPointCovAll (vhm.hpp:252-257), HIP kernel over map points */
 int elm_map_cal_point_cov_all(elm_map* map, double d_search_dist);
-/* Precompute, for every floor-keyed voxel a query can fall into, the concatenation of its 27 neighbour buckets in
- * the reference's visiting order (GetAdjacentVoxels order vhm.cpp:234-240, insertion order inside a bucket): 27x the
- * map points in HBM, so the P2P/GICP correspondence search streams one contiguous list per point.  Called
- * automatically by elm_register* on first use; exposed so the cost can be paid at map-build time. */
+/* Build the search index of the P2P / GICP correspondence search now instead of on the first registration (an init-time cost of a few
+ * seconds on a 10 M-point map): the dense half-voxel CELL GRID -- the map points once more, sorted by cell in 48-byte blocks of four,
+ * plus one offset per cell of the bounding box -- when the box fits the cell and byte budgets; its two-level form (tiles of 8 x 8 columns
+ * with their own z range) when it does not; the round-1 neighbourhood lists (per query voxel the points of its 27 buckets, 27x the map)
+ * only when neither can be built or ELM_KERNEL=lists asks for them.  Results do not depend on which index is in use (the reference's
+ * visiting order -- vhm.cpp:234-240, insertion order inside a bucket -- settles exact ties in all of them). */
 int elm_map_build_neighbourhoods(elm_map* map);
 int elm_map_get_info(const elm_map* map, elm_map_info* info);
 /* VoxelHashMap::Empty (vhm.hpp:325) */

@@ -669,7 +669,7 @@ def test_single_registration_graph_replay(oracle, world100k, monkeypatch):
     short ones (continuation), another scan size (new graph), another method -- and to the oracle."""
     from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, Scan
     seq = []
-    for i, (n, tr, rot, meth) in enumerate([(6000, 0.03, 0.1, 0), (6000, 0.03, 0.1, 0), (6000, 0.05, 0.2, 0), (6000, 0.6, 2.5, 0), (6000, 0.04, 0.1, 0),
+    for i, (n, tr, rot, meth) in enumerate([(6000, 0.03, 0.1, 0), (6000, 0.03, 0.1, 0), (6000, 0.03, 0.1, 0), (6000, 0.5, 2.0, 0), (6000, 0.04, 0.1, 0),
                                             (3500, 0.1, 0.5, 0), (6000, 0.1, 0.5, 2), (6000, 0.03, 0.1, 0)]):
         sc, Tt = synth.make_scan(world100k, n, seed=4100 + i)
         seq.append((sc, synth.perturb(Tt, seed=4200 + i, max_trans=tr, max_rot_deg=rot), meth))
@@ -689,7 +689,8 @@ def test_single_registration_graph_replay(oracle, world100k, monkeypatch):
             runs[graph] = out
             if graph == "1":
                 its = [o[2] for o in out]
-                assert max(its) >= min(its) + 3  # the long registration really outlasts the graph sized by the short ones
+                # a registration really outlasts the graph sized by the ones before it (K = longest of the last eight + 1)
+                assert any(its[k] > max(its[max(0, k - 8):k]) + 1 for k in range(1, 5)), its
                 for (sc, T0, meth), o in zip(seq, out):
                     ref = oracle.register(maps[meth][1], sc, T0, oracle.default_config(meth))
                     assert ref["iterations"] == o[2] and ref["is_success"] == o[1]
