@@ -673,6 +673,7 @@ def test_single_registration_graph_replay(oracle, world100k, monkeypatch):
                                             (3500, 0.1, 0.5, 0), (6000, 0.1, 0.5, 2), (6000, 0.03, 0.1, 0)]):
         sc, Tt = synth.make_scan(world100k, n, seed=4100 + i)
         seq.append((sc, synth.perturb(Tt, seed=4200 + i, max_trans=tr, max_rot_deg=rot), meth))
+    TERM = {0: 1e-4, 2: 0.02}  # a tight P2P termination threshold: iteration counts follow the initial error (a handful .. max_iteration)
     runs = {}
     for graph in ("1", "0"):  # (opt-in: plain launches are the default)
         monkeypatch.setenv("ELM_GRAPH", graph)
@@ -681,7 +682,7 @@ def test_single_registration_graph_replay(oracle, world100k, monkeypatch):
             maps = {m: _maps(c, oracle, world100k, IcpMethod(m)) for m in (0, 2)}
             out = []
             for sc, T0, meth in seq:
-                reg = Registration(RegistrationConfig(icp_method=IcpMethod(meth)), c)
+                reg = Registration(RegistrationConfig(icp_method=IcpMethod(meth), icp_termination_threshold_m=TERM[meth]), c)
                 det = reg.RunRegisterBatch([Scan(c, sc)], maps[meth][0], [T0])[0]  # a batch of one: the shape elm_register itself enqueues
                 out.append((det["T"], det["is_success"], det["iterations"], det["gate"], det["n_corr_last"]))
                 pose, ok, fit, cov = reg.RunRegister(sc, maps[meth][0], T0)  # the reference API on host points (caller's order: other sums)
@@ -692,7 +693,7 @@ def test_single_registration_graph_replay(oracle, world100k, monkeypatch):
                 # a registration really outlasts the graph sized by the ones before it (K = longest of the last eight + 1)
                 assert any(its[k] > max(its[max(0, k - 8):k]) + 1 for k in range(1, 5)), its
                 for (sc, T0, meth), o in zip(seq, out):
-                    ref = oracle.register(maps[meth][1], sc, T0, oracle.default_config(meth))
+                    ref = oracle.register(maps[meth][1], sc, T0, oracle.default_config(meth, icp_termination_threshold_m=TERM[meth]))
                     assert ref["iterations"] == o[2] and ref["is_success"] == o[1]
                     dt, dr = synth.pose_error(ref["T"], o[0])
                     assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
