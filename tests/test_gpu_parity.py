@@ -187,6 +187,30 @@ def _compare_run(gpu, ref, om=None, scan=None, method=None, th=5.0, ocfg=None, o
 
 
 @pytest.mark.parametrize("method", [0, 1, 2, 3])
+def test_nan_returns_pair_with_nothing(ctx, oracle, world100k, method):
+    """The node does not remove NaN returns before RunRegister (FilterPointsByDistance keeps a point whose range is NaN: pcm.cpp:451-465).
+    In the reference such a point finds no voxel, its distance to the default neighbour is NaN and every comparison with it is false: it
+    pairs with nothing but still counts in the overlap ratio's denominator.  Same trajectory as the oracle, resident and host-fed scans."""
+    from elimaloc_amd.registration import Registration, RegistrationConfig, IcpMethod, Scan
+    m = IcpMethod(method)
+    vm, om = _maps(ctx, oracle, world100k, m)
+    scan, T_true = synth.make_scan(world100k, 8000, seed=77 + method)
+    scan = scan.copy()
+    scan[5::17, 0] = np.nan          # one coordinate
+    scan[11::29] = np.nan            # all three
+    scan[700, 2] = np.inf            # and an infinite return
+    T0 = synth.perturb(T_true, seed=78 + method)
+    reg = Registration(RegistrationConfig(icp_method=m), ctx)
+    pose, ok, fit, cov, det = reg.RunRegister(scan, vm, T0, trace=True)
+    ref = oracle.register(om, scan, T0, oracle.default_config(method))
+    assert det["iters"][0]["n_corr"] < 8000 - 8000 // 17 and np.all(np.isfinite(pose))
+    _compare_run(det, ref)
+    assert ok == ref["is_success"]
+    res = reg.RunRegisterBatch([Scan(ctx, scan)], vm, [T0])[0]  # device-ordered copy of the same scan (NaN keys clamp into a border cell)
+    assert res["iterations"] == ref["iterations"] and float(np.abs(res["T"] - pose).max()) < 1e-9
+
+
+@pytest.mark.parametrize("method", [0, 1, 2, 3])
 @pytest.mark.parametrize("seed", [2002, 2003])
 def test_register_matches_oracle(ctx, oracle, world100k, method, seed):
     """All four methods, 16k-pt scan vs 100k-pt map, defaults of localization.ini; per-iteration trace + pose."""
