@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- ICP registrations/sec of the MI355X-native pcm_matching hot path.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (N>1: launched by torch.distributed.run, one rank per GPU).
+Contract: `python bench.py --gpus N --steps K --warmup W`.  N > 1: one rank per GPU -- either launched by the caller
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`, the driver's form) or, when no rank environment is set, by
+bench.py itself (it re-executes under torch.distributed.run on 127.0.0.1); `--gpus` must equal the number of ranks, a box with fewer GPUs is
+refused with a non-zero exit, and the line carries `rccl_ranks` (ncclCommCount of the communicator the timed region all-reduced over).
 One STEP = one pass of the hot path over one batch of synthetic input: `--batch` (per GPU) full RunRegister-equivalent
 registrations (initial transform -> iterate to the reference's own termination rule or max_iteration), all scans
 already resident in HBM -- uploaded as packed float32 xyz and ordered ON THE DEVICE (k_scan_order) -- when the timed region
@@ -12,16 +15,18 @@ region (elm_register_stream_host), reported beside the PCIe rate it sits under.
 Workload (BASELINE.json configs[1]): P2P ICP, 131072-pt synthetic scans vs a 10M-pt voxel-hashed map, defaults of
 config/localization.ini.  N>1: every scan is sharded point-wise over the N GPUs (map replicated), ONE RCCL all-reduce
 of the packed normal equations of the whole batch per ICP iteration; the batch grows with N (weak scaling: per-GPU
-points per launch fixed).  With N>1 the same registrations are also timed in replica mode (whole registrations per GPU,
-no collective) and reported under "replica" (SURVEY.md 8e asks for both).
+points per launch fixed); rank r generates only the scans i = r (mod N) and one all-to-all per 32 scans hands out the shards
+(bit-identical inputs to the one-rank generation).  With N>1 the same registrations are also timed in replica mode (whole
+registrations per GPU, no collective) and reported under "replica" (SURVEY.md 8e asks for both).
+The timed launches carry no instrumentation: the work counters (C, V, tested candidates) come from one untimed pass of the same step.
 
 Prints ONE JSON line on rank 0 with
   * `inputs`: SHA-1 of every uploaded scan + initial guess (the workload is bit-reproducible: seeded, BLAS-free),
-  * `roofline`: dominant kernel; `achieved` = its HBM stream (bytes/unit of the rocprofv3 --pmc passes of this command
-    committed under profiles/ x this run's units per launch -- counters cannot be read inside the timed run -- or, without a
-    matching pass, the compulsory bytes) / hipEvent-measured launch time, against 8 TB/s (a fraction <= 1); next to it the
-    compulsory stream, the bytes the points REQUEST from the kernel's own structures (model in DESIGN.md section 4; the
-    index is cache-resident, so this exceeds the HBM stream) and the SURVEY 8(d) figure of the REFERENCE's walk,
+  * `roofline`: dominant kernel and the unit that binds it -- VALU issue for the grid kernel: SQ_INSTS_VALU per SIMD-cycle of the
+    committed rocprofv3 --pmc pass of this command AT THIS batch / slots (refused otherwise) x the kernel's mean issue cost
+    (tools/probes/valu_probe + tools/valu_mix.py), with the hipEvent-measured launch time it belongs to; under
+    `hbm` the HBM stream (measured fabric bytes/unit x this run's units per launch / launch time against 8 TB/s), the compulsory
+    stream, the bytes the points REQUEST from the kernel's own structures and the SURVEY 8(d) figure of the REFERENCE's walk,
   * at N=1 `cpu_baseline`: the CPU oracle on the host cores, SURVEY 8(d) protocol (3 warm-ups, >= 20 timed
     registrations, median / p10 / p90, correspondence-vs-total split, 10 threads and all cores, a full-map sample),
     `pose_err_vs_cpu`, `reference_api` (RunRegister on host buffers, one call at a time) and `hard_guess` (the 0.5 m /
