@@ -203,7 +203,9 @@ def test_nan_returns_pair_with_nothing(ctx, oracle, world100k, method):
     reg = Registration(RegistrationConfig(icp_method=m), ctx)
     pose, ok, fit, cov, det = reg.RunRegister(scan, vm, T0, trace=True)
     ref = oracle.register(om, scan, T0, oracle.default_config(method))
-    assert det["iters"][0]["n_corr"] < 8000 - 8000 // 17 and np.all(np.isfinite(pose))
+    if method != 3:  # (AVGICP counts up to seven pairs per point)
+        assert det["iters"][0]["n_corr"] < 8000 - 8000 // 17
+    assert np.all(np.isfinite(pose))
     _compare_run(det, ref)
     assert ok == ref["is_success"]
     res = reg.RunRegisterBatch([Scan(ctx, scan)], vm, [T0])[0]  # device-ordered copy of the same scan (NaN keys clamp into a border cell)
@@ -693,8 +695,9 @@ def test_single_registration_graph_replay(oracle, world100k, monkeypatch):
     short ones (continuation), another scan size (new graph), another method -- and to the oracle."""
     from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, Scan
     seq = []
-    for i, (n, tr, rot, meth) in enumerate([(6000, 0.03, 0.1, 0), (6000, 0.03, 0.1, 0), (6000, 0.03, 0.1, 0), (6000, 0.5, 2.0, 0), (6000, 0.04, 0.1, 0),
-                                            (3500, 0.1, 0.5, 0), (6000, 0.1, 0.5, 2), (6000, 0.03, 0.1, 0)]):
+    # (seed id, points, initial error, method); on the GPU box ids 1, 2 take 6 iterations, 3, 4 take 9, 0 and 5 all 10: the short ones first
+    for i, n, tr, rot, meth in [(1, 6000, 0.03, 0.1, 0), (2, 6000, 0.03, 0.1, 0), (3, 6000, 0.5, 2.0, 0), (4, 6000, 0.04, 0.1, 0), (0, 6000, 0.03, 0.1, 0),
+                                (5, 3500, 0.1, 0.5, 0), (6, 6000, 0.1, 0.5, 2), (7, 6000, 0.03, 0.1, 0)]:
         sc, Tt = synth.make_scan(world100k, n, seed=4100 + i)
         seq.append((sc, synth.perturb(Tt, seed=4200 + i, max_trans=tr, max_rot_deg=rot), meth))
     TERM = {0: 1e-4, 2: 0.02}  # a tight P2P termination threshold: iteration counts follow the initial error (a handful .. max_iteration)
