@@ -2278,15 +2278,16 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
                     // ... or a refill launch of its own (4 launches + 1 collective): ONE workgroup walks the slots in slot order and hands the
                     // finished ones the next pending registrations -- first come, first served like the single-rank stream, yet identical on
                     // every rank (the finished flags derive from the all-reduced sums), so no slot idles while the queue has work
-                    launch_solve(ss, dsc_h, Sh, st_h, partials_h, sums_h, rph, d_trace, 2, d_active);
-                    launch_stream_refill(ss, dsc, st, S, d_q, d_qT0, d_out, d_ctrl, 0);
+                    const StreamArgs sv = {dsc_h, d_q, d_qT0, d_out, d_ctrl, 0, /*save_only*/ 1, 0}; // the solve saves + counts, the refill assigns
+                    launch_solve(ss, dsc_h, Sh, st_h, partials_h, sums_h, rph, d_trace, 2, d_active, &sv);
+                    launch_stream_refill(ss, dsc, st, S, d_q, d_qT0, d_out, d_ctrl, 0, /*save*/ 0);
                 } else {
-                    const StreamArgs sr = {dsc_h, d_q, d_qT0, d_out, d_ctrl, 0, S};
+                    const StreamArgs sr = {dsc_h, d_q, d_qT0, d_out, d_ctrl, 0, 0, S};
                     launch_solve(ss, dsc_h, Sh, st_h, partials_h, sums_h, rph, d_trace, 2, d_active, &sr);
                 }
             } else {
                 // single rank: the solve hands finished slots their next registration itself (no refill launch)
-                const StreamArgs sa = {dsc_h, d_q, d_qT0, d_out, d_ctrl, 0, 0};
+                const StreamArgs sa = {dsc_h, d_q, d_qT0, d_out, d_ctrl, 0, 0, 0};
                 launch_solve(ss, dsc_h, Sh, st_h, partials_h, sums_h, rph, d_trace, 0, d_active, &sa);
             }
             if (H == 2) {
@@ -2585,7 +2586,7 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
     };
     // Iterations are enqueued a few ahead of the device (an event per iteration throttles the host); the number of finished
     // registrations is read on a stream of its own, so that looking never waits for the iterations in flight.
-    const StreamArgs sa = {dsc, d_q, d_qT0, d_out, d_ctrl, 1, 0};
+    const StreamArgs sa = {dsc, d_q, d_qT0, d_out, d_ctrl, 1, 0, 0};
     int it = 0, done_seen = 0, idle_turns = 0, g_done = 0;
     const int idle_limit = 4000000; // ~ minutes of polling without a single registration finishing: a lost upload, give up
     const int groups_ahead = 2 * kStageSets; // uploads enqueued but not yet ordered: enough to keep the DMA engine fed; a long backlog

@@ -176,6 +176,8 @@ struct StreamArgs {
     ScanState* out_state;
     StreamCtrl* ctrl; // nullptr: no refill in the solve
     int32_t hostfed;  // 1: the queue fills while the stream runs (ctrl->ready grows): idle slots look for work at every solve
+    int32_t save_only; // 1 (multi-rank streams with the refill launch): the solve saves a finished registration's state and counts it, the slot
+                       // stays free for k_stream_refill to hand it the next registration in slot order
     int32_t stride;   // > 0 (multi-rank streams): slot s serves the registrations s, s + stride, s + 2 stride, ... -- an assignment that
                       // is a function of the slot alone, hence identical on every rank without any exchange; 0: first come, first served
 };
@@ -216,7 +218,8 @@ void launch_init_state(hipStream_t s, ScanState* st, const double* T0, int batch
 void launch_init_pack(hipStream_t s, ScanDesc* scans, ScanState* st, const InitPack& pack, int batch, int map_empty, int* active, const unsigned* n_dev,
                       int* tickets);
 void launch_stream_refill(hipStream_t s, ScanDesc* scans, ScanState* st, int slots, const QueueItem* queue, const double* qT0,
-                          ScanState* out_state, StreamCtrl* ctrl, int first);
+                          /* first: initial fill; save: copy finished states out + count them (0: the solve has done that) */
+                          ScanState* out_state, StreamCtrl* ctrl, int first, int save = 1);
 void launch_accumulate_radar(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks, ScanState* st, double* partials,
                              const RegParams& rp); // use_radar_cov = 1, methods GICP / VGICP / AVGICP
 void launch_accumulate_direct(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,

@@ -2326,7 +2326,9 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
             for (int k = 0; k < 9; ++k) P.A[k] = Q.A[k];
             P.b[0] = Q.b[0]; P.b[1] = Q.b[1]; P.b[2] = Q.b[2];
             P.rsum = Q.rsum; P.n = Q.n;
-            P.ax = gx - S.T[12]; P.ay = gy - S.T[13]; P.az = gz - S.T[14];
+            if (Q.n > 0.0) { // (a point without a pair -- a NaN / infinite return among them -- contributes zeros, not 0 x NaN)
+                P.ax = gx - S.T[12]; P.ay = gy - S.T[13]; P.az = gz - S.T[14];
+            }
             if (STATS) { P.c29 = n_pairs; P.c30 = n_pairs; P.c31 = n_pairs; }
         }
     }
@@ -2469,27 +2471,50 @@ void launch_init_pack(hipStream_t s, ScanDesc* scans, ScanState* st, const InitP
 // queue runs dry.  Slots are served in slot order by one thread: the assignment is deterministic (identical on every rank).
 constexpr int kMaxSlots = 4096; // 32 KB of LDS for the two slot tables
 __global__ __launch_bounds__(1024) void k_stream_refill(ScanDesc* scans, ScanState* st, int slots, const QueueItem* __restrict__ queue,
-                                                       const double* __restrict__ qT0, ScanState* out_state, StreamCtrl* ctrl, int first) {
+                                                       const double* __restrict__ qT0, ScanState* out_state, StreamCtrl* ctrl, int first, int save) {
     __shared__ int s_assign[kMaxSlots]; // registration to start in the slot, -1 = slot keeps going, -2 = slot goes idle
     __shared__ int s_save[kMaxSlots];   // registration whose final state is copied out, -1 = none
     // the slots' flags are fetched by all threads at once; the serial part below only touches LDS
     for (int s = threadIdx.x; s < slots; s += blockDim.x) s_save[s] = (!first && st[s].done && st[s].reg >= 0) ? st[s].reg : -1;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int next = first ? 0 : ctrl->next, completed = first ? 0 : ctrl->completed;
-        const int total = ctrl->total;
-        for (int s = 0; s < slots; ++s) {
-            s_assign[s] = -1;
-            if (!first && s_save[s] < 0) continue; // still iterating, or already idle
-            if (!first) ++completed;
-            s_assign[s] = (next < total) ? next++ : -2;
+    {
+        // free slots take the pending registrations in SLOT ORDER: an exclusive prefix count of the free flags (every thread owns a
+        // contiguous run of slots; wave scan + the 16 wave totals) instead of one thread walking the slots (that walk, a chain of
+        // dependent LDS accesses, took 12 us of this launch's 24 at 256 slots)
+        __shared__ int s_wtot[16];
+        const int per = (slots + (int)blockDim.x - 1) / (int)blockDim.x, s0 = (int)threadIdx.x * per, s1 = min(slots, s0 + per);
+        int mine = 0;
+        for (int s = s0; s < s1; ++s) mine += (first || s_save[s] >= 0) ? 1 : 0;
+        int inc = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(inc, off, 64);
+            if ((int)(threadIdx.x & 63u) >= off) inc += o;
         }
-        ctrl->next = next;
-        ctrl->completed = completed;
+        if ((threadIdx.x & 63u) == 63u) s_wtot[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        int before = inc - mine, all = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+            before += (w < (int)(threadIdx.x >> 6)) ? s_wtot[w] : 0;
+            all += s_wtot[w];
+        }
+        const int next0 = first ? 0 : ctrl->next, total = ctrl->total;
+        int r = next0 + before;
+        for (int s = s0; s < s1; ++s) {
+            const bool free_slot = first || s_save[s] >= 0; // (otherwise: still iterating, or already idle)
+            s_assign[s] = free_slot ? ((r < total) ? r : -2) : -1;
+            r += free_slot ? 1 : 0;
+        }
+        __syncthreads(); // every thread has read ctrl->next
+        if (threadIdx.x == 0) {
+            ctrl->next = min(total, next0 + all);
+            if (first) ctrl->completed = 0;
+            else if (save) ctrl->completed += all; // (save = 0: the solve has saved and counted them)
+        }
     }
     __syncthreads();
     constexpr int W = (int)(sizeof(ScanState) / sizeof(double));
-    for (int s = (int)(threadIdx.x >> 6); s < slots; s += (int)(blockDim.x >> 6)) { // one wavefront per slot
+    for (int s = (int)(threadIdx.x >> 6); save && s < slots; s += (int)(blockDim.x >> 6)) { // one wavefront per slot
         const int r = s_save[s];
         if (r < 0) continue;
         const double* src = reinterpret_cast<const double*>(&st[s]);
@@ -2760,6 +2785,7 @@ __device__ __forceinline__ void finish_slot(const StreamArgs& sa, ScanState& S, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0); // the copy's loads are done before the state is overwritten
     __builtin_amdgcn_wave_barrier();
+    if (sa.save_only) return; // the refill launch hands the slot its next registration (S.done = 1 and S.reg >= 0 mark it free)
     start_slot(sa, S, s, reg_old);
 }
 
@@ -3155,8 +3181,8 @@ __global__ __launch_bounds__(256) void k_deskew(const float* __restrict__ xyz, c
 // launchers
 // ------------------------------------------------------------------------------------------------------
 void launch_stream_refill(hipStream_t s, ScanDesc* scans, ScanState* st, int slots, const QueueItem* queue, const double* qT0,
-                          ScanState* out_state, StreamCtrl* ctrl, int first) {
-    hipLaunchKernelGGL(k_stream_refill, dim3(1), dim3(1024), 0, s, scans, st, slots, queue, qT0, out_state, ctrl, first);
+                          ScanState* out_state, StreamCtrl* ctrl, int first, int save) {
+    hipLaunchKernelGGL(k_stream_refill, dim3(1), dim3(1024), 0, s, scans, st, slots, queue, qT0, out_state, ctrl, first, save);
 }
 void launch_init_state(hipStream_t s, ScanState* st, const double* T0, int batch, int map_empty, int* active, int* tickets) {
     hipLaunchKernelGGL(k_init_state, dim3((batch + 63) / 64), dim3(64), 0, s, st, T0, batch, map_empty, active, tickets);
@@ -3277,7 +3303,7 @@ void launch_nbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint3
 
 void launch_solve(hipStream_t s, const ScanDesc* scans, int batch, ScanState* st, const double* partials,
                   double* sums, const RegParams& rp, elm_iter_trace* trace, int mode, int* active, const StreamArgs* refill) {
-    StreamArgs sa = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    StreamArgs sa = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
     if (refill) sa = *refill;
     // one wavefront per scan when the sums are already reduced (fused reduction, or the second half of a multi-rank iteration)
     const int threads = (mode == 2 || rp.tickets != nullptr) ? 64 : kSolveThreads;
