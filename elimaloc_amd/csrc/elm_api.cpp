@@ -116,7 +116,7 @@ struct elm_ctx {
     } grun;
     bool dist_refill_kernel = true; // multi-rank streams refill their slots with a launch of their own (dynamic, in slot order: 4 launches + 1 collective
                                     // per iteration); ELM_DIST_REFILL=solve: the static per-slot queue inside the solve (3 + 1).  One-rank RCCL path,
-                                    // two runs each: 91.7 k against 89.7 k registrations/s (48 instead of 56 accumulate launches per step)
+                                    // two runs each: 94.3 k against 89.7 k registrations/s (48 instead of 56 accumulate launches per step)
     int half_sets = 0;                  // ELM_HALF_SETS=1: the two-half pipeline (off by default: measured on one MI355X it LOSES 4 % without a
                                         // communicator and 40 % on the one-rank RCCL path -- the solve's 1024-thread, 84-VGPR workgroups are not
                                         // placed while the other half's accumulate grid still has workgroups to issue, so nothing overlaps and the
