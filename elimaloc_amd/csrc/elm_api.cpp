@@ -1867,6 +1867,7 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
     rp.uniform_blocks = uniform_blocks;
     rp.radar = radar ? 1 : 0;
     rp.stats = ctx->work_counters ? 1 : 0;
+    rp.solve_small = ctx->half_sets ? 1 : 0;
     rp.radar_var[0] = cfg->range_variance_m;
     rp.radar_var[1] = cfg->azimuth_variance_deg;
     rp.radar_var[2] = cfg->elevation_variance_deg;
@@ -2192,6 +2193,7 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     rp.uniform_blocks = cap_blocks; // every slot owns cap_blocks workgroups
     rp.radar = 0;
     rp.stats = ctx->work_counters ? 1 : 0;
+    rp.solve_small = ctx->half_sets ? 1 : 0;
     rp.radar_var[0] = rp.radar_var[1] = rp.radar_var[2] = 0.0;
     rp.sums = nullptr;
     rp.tickets = nullptr;
@@ -2501,6 +2503,7 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
     rp.uniform_blocks = cap_blocks;
     rp.radar = 0;
     rp.stats = ctx->work_counters ? 1 : 0;
+    rp.solve_small = ctx->half_sets ? 1 : 0;
     rp.radar_var[0] = rp.radar_var[1] = rp.radar_var[2] = 0.0;
     rp.sums = nullptr;
     rp.tickets = nullptr;

@@ -193,6 +193,7 @@ struct RegParams {
     int32_t max_iter;
     uint32_t uniform_blocks; // > 0: every scan / slot owns exactly that many consecutive workgroups (scan = block / uniform_blocks)
     int32_t radar;           // use_radar_cov with a covariance method: k_accumulate_radar's 64-double partial records, full JTJ
+    int32_t solve_small;     // 1 (half-set streams): k_solve<256> -- workgroups that fit beside a running accumulate launch
     int32_t stats;           // elm_ctx_set_work_counters: the grid / voxel-list kernels also sum the three work counters (STATS = 1)
     // fused reduction: the LAST workgroup of a scan to arrive (ticket counter per scan) adds up the scan's partial records into
     // sums[scan][32] -- no reduce launch; nullptr: the accumulate kernels only write partials, k_solve reduces (developer A/B)

@@ -2790,7 +2790,11 @@ __device__ __forceinline__ void finish_slot(const StreamArgs& sa, ScanState& S, 
 }
 
 constexpr int kSolveThreads = 1024;
-__global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* scans, ScanState* st,
+// NT = 1024 threads (default) or 256 (half-set streams: a workgroup of 4 waves and <= 80 VGPRs fits the slot a retiring accumulate
+// workgroup frees, so the solve can run beside the other half's accumulate launch).  The reduction always adds the partial records in
+// the order of 32 groups of 32 lanes -- 256 threads walk four of those groups each -- so the sums do not depend on NT.
+template <int NT>
+__global__ __launch_bounds__(NT, NT == 256 ? 6 : 1) void k_solve(const ScanDesc* scans, ScanState* st,
                                                          const double* __restrict__ partials, double* sums,
                                                          const RegParams rp, elm_iter_trace* trace, int mode, int* active,
                                                          const StreamArgs sa) {
@@ -2799,6 +2803,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* scans, 
     const int t = threadIdx.x;
     __shared__ double tot[kSums];
     __shared__ double part[kSolveThreads / 32][kSums];
+    static_assert(NT == kSolveThreads || NT == 256, "solve workgroup size");
     const bool done = S.done != 0;
     const bool fused = rp.tickets != nullptr; // the accumulate kernels' last workgroups have left the scan's sums in `sums`
     const bool radar = rp.radar != 0;         // k_accumulate_radar's records: 64 doubles, all 36 entries of J^T M J (single GPU, unfused)
@@ -2823,33 +2828,41 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(const ScanDesc* scans, 
     } else if (mode != 2 && !fused) {
         // deterministic reduction of this scan's per-workgroup partial sums: 32 strided groups of 32 lanes read whole
         // 256-byte records (four independent loads in flight per lane), then the group sums are added in a fixed order
-        const int k = t & 31, g = t >> 5;
+        const int k = t & 31;
         constexpr unsigned G = kSolveThreads / 32;
-        double v = 0.0;
-        if (!done) {
-            const ScanDesc sd = scans[s];
-            unsigned b = sd.blk_begin + g;
-            double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
-            for (; b + 15 * G < sd.blk_end; b += 16 * G) { // sixteen loads in flight, summed in the order of the loop below
-                double a[16];
+        auto group_sum = [&](int g) -> double {
+            double v = 0.0;
+            if (!done) {
+                const ScanDesc sd = scans[s];
+                unsigned b = sd.blk_begin + g;
+                double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+                for (; b + 15 * G < sd.blk_end; b += 16 * G) { // sixteen loads in flight, summed in the order of the loop below
+                    double a[16];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) a[q] = partials[(size_t)(b + q * G) * kSums + k];
+                    for (int q = 0; q < 16; ++q) a[q] = partials[(size_t)(b + q * G) * kSums + k];
 #pragma unroll
-                for (int q = 0; q < 16; q += 4) { v0 += a[q]; v1 += a[q + 1]; v2 += a[q + 2]; v3 += a[q + 3]; }
+                    for (int q = 0; q < 16; q += 4) { v0 += a[q]; v1 += a[q + 1]; v2 += a[q + 2]; v3 += a[q + 3]; }
+                }
+                for (; b + 3 * G < sd.blk_end; b += 4 * G) {
+                    const double a0 = partials[(size_t)b * kSums + k], a1 = partials[(size_t)(b + G) * kSums + k];
+                    const double a2 = partials[(size_t)(b + 2 * G) * kSums + k], a3 = partials[(size_t)(b + 3 * G) * kSums + k];
+                    v0 += a0; v1 += a1; v2 += a2; v3 += a3;
+                }
+                // the tail keeps the accumulator rotation of the unrolled loop, so trailing all-zero records (slots of a stream
+                // are sized for the largest scan) leave every sum bit-identical to the exact-size layout
+                if (b < sd.blk_end) { v0 += partials[(size_t)b * kSums + k]; b += G; }
+                if (b < sd.blk_end) { v1 += partials[(size_t)b * kSums + k]; b += G; }
+                if (b < sd.blk_end) { v2 += partials[(size_t)b * kSums + k]; b += G; }
+                v = (v0 + v1) + (v2 + v3);
             }
-            for (; b + 3 * G < sd.blk_end; b += 4 * G) {
-                const double a0 = partials[(size_t)b * kSums + k], a1 = partials[(size_t)(b + G) * kSums + k];
-                const double a2 = partials[(size_t)(b + 2 * G) * kSums + k], a3 = partials[(size_t)(b + 3 * G) * kSums + k];
-                v0 += a0; v1 += a1; v2 += a2; v3 += a3;
-            }
-            // the tail keeps the accumulator rotation of the unrolled loop, so trailing all-zero records (slots of a stream
-            // are sized for the largest scan) leave every sum bit-identical to the exact-size layout
-            if (b < sd.blk_end) { v0 += partials[(size_t)b * kSums + k]; b += G; }
-            if (b < sd.blk_end) { v1 += partials[(size_t)b * kSums + k]; b += G; }
-            if (b < sd.blk_end) { v2 += partials[(size_t)b * kSums + k]; b += G; }
-            v = (v0 + v1) + (v2 + v3);
+            return v;
+        };
+        if (NT == kSolveThreads) { // one group per 32 lanes
+            part[t >> 5][k] = group_sum(t >> 5);
+        } else { // 256 threads: four of the 32 groups each, the same sums
+#pragma unroll 1
+            for (int g = t >> 5; g < (int)G; g += NT / 32) part[g][k] = group_sum(g);
         }
-        part[g][k] = v;
         __syncthreads();
         if (t < 32) {
             double a = part[0][t];
@@ -3306,8 +3319,10 @@ void launch_solve(hipStream_t s, const ScanDesc* scans, int batch, ScanState* st
     StreamArgs sa = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
     if (refill) sa = *refill;
     // one wavefront per scan when the sums are already reduced (fused reduction, or the second half of a multi-rank iteration)
-    const int threads = (mode == 2 || rp.tickets != nullptr) ? 64 : kSolveThreads;
-    hipLaunchKernelGGL(k_solve, dim3(batch), dim3(threads), 0, s, scans, st, partials, sums, rp, trace, mode, active, sa);
+    const bool small = rp.solve_small != 0 && rp.radar == 0;
+    const int threads = (mode == 2 || rp.tickets != nullptr) ? 64 : (small ? 256 : kSolveThreads);
+    if (small) hipLaunchKernelGGL(k_solve<256>, dim3(batch), dim3(threads), 0, s, scans, st, partials, sums, rp, trace, mode, active, sa);
+    else hipLaunchKernelGGL(k_solve<kSolveThreads>, dim3(batch), dim3(threads), 0, s, scans, st, partials, sums, rp, trace, mode, active, sa);
 }
 
 void launch_voxel_cov(hipStream_t s, const DevMap& m, const uint2* ranges, double* vox_mean, double* vox_cov, double* vox_cinv, double* vox_nk, unsigned* bad) {
