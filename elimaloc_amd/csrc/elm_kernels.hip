@@ -1487,11 +1487,12 @@ __device__ __forceinline__ const uint32_t* col_cells(const DevMap& m, int cx, in
                           // the winners).  The headline workload pays for it: off; built with -DELM_PREV_WINNER=1 and run with ELM_PREV_WINNER=1
 #endif
 #ifndef ELM_GRID_WAVES
-#define ELM_GRID_WAVES 7 // minimum waves per SIMD = a 72-VGPR cap (2 spilled registers).  Measured registrations/s: 5 -> 59.8k, 6 -> 63.9k, 7 -> 65.6k,
-                         // 8 (35 spills) -> 54.2k: the kernel is bound by memory latency, not by VALU issue (67 % busy) or HBM bandwidth
+#define ELM_GRID_WAVES 8 // minimum waves per SIMD of the P2P kernel = a 64-VGPR cap.  Round 4, after the work counters left the production kernels (2 spilled
+                         // VGPRs, 26 spilled SGPRs at the cap): 6 -> 89.0 k, 7 -> 94.0-94.3 k, 8 -> 95.8-96.4 k registrations/s (hard guesses 20.5 -> 20.8 k);
+                         // round 2, with the counters: 5 -> 59.8k, 6 -> 63.9k, 7 -> 65.6k, 8 (35 spills) -> 54.2k.  profiles/r04_sweep.txt
 #endif
 #ifndef ELM_GICP_WAVES
-#define ELM_GICP_WAVES 5
+#define ELM_GICP_WAVES 7 // GICP: 5 (the old cap; the kernel used 72 VGPRs anyway) -> 71.2-71.6 k, 7 (one spill) -> 72.5-73.3 k, 8 (8 spills) -> 67.2 k
 #endif
 // STATS = 1 (elm_ctx_set_work_counters): the launch also sums the three work counters (candidates / occupied buckets of the reference's
 // walk from the dense statistics box, candidates this kernel tested + points served by stage 2).  The production launches run with
