@@ -1792,10 +1792,7 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
     const int method = cfg->icp_method;
     const bool map_empty = map->dm.n_vox == 0;
     const bool radar = radar_path(cfg) && !map_empty;
-    if (radar && (ctx->comm || ctx->hook)) {
-        ctx->last_error = "use_radar_cov runs on one rank (its 64-double partial records are not part of the all-reduce layout)";
-        return ELM_ERR_UNSUPPORTED;
-    }
+    // (use_radar_cov on several ranks: the all-reduce carries the radar kernel's 64 sums per scan instead of the 32 of the packed layout)
     if (!map_empty) {
         if ((method == ELM_VGICP || method == ELM_AVGICP) && !map->info.has_voxel_cov) {
             ctx->last_error = "VGICP/AVGICP need elm_map_cal_voxel_cov_all() (pcm.cpp:92-95)";
@@ -1833,7 +1830,7 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
     if ((rc = dev_reserve(ctx, ctx->d_T0, (size_t)batch * 16 * sizeof(double))) != ELM_OK) return rc;
     if ((rc = dev_reserve(ctx, ctx->d_state, st_bytes + 64)) != ELM_OK) return rc;
     if ((rc = dev_reserve(ctx, ctx->d_partials, (size_t)std::max<uint32_t>(blocks, 1) * (radar ? kRadarRecord : kSums) * sizeof(double))) != ELM_OK) return rc;
-    if ((rc = dev_reserve(ctx, ctx->d_sums, (size_t)batch * kSums * sizeof(double))) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_sums, (size_t)batch * (radar ? kRadarRecord : kSums) * sizeof(double))) != ELM_OK) return rc;
     if ((rc = pinned_reserve(ctx, &ctx->h_state, &ctx->h_state_cap, st_bytes + 64)) != ELM_OK) return rc;
     ctx->results_ready = false;
     elm_iter_trace* d_trace = nullptr;
@@ -1982,7 +1979,7 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
             if (distributed) {
                 // fused reduction: the sums are already in d_sums -- accumulate -> all-reduce -> solve (two launches + one collective)
                 if (!rp.tickets) launch_solve(ctx->stream, dsc, batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 1, d_active);
-                if ((rc = exchange(ctx, (double*)ctx->d_sums.p, (size_t)batch * kSums)) != ELM_OK) return rc;
+                if ((rc = exchange(ctx, (double*)ctx->d_sums.p, (size_t)batch * (radar ? kRadarRecord : kSums))) != ELM_OK) return rc;
                 launch_solve(ctx->stream, dsc, batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 2, d_active);
             } else {
                 launch_solve(ctx->stream, dsc, batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 0, d_active);

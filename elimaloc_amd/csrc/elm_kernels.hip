@@ -2810,19 +2810,29 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : 1) void k_solve(const ScanDesc*
     const bool radar = rp.radar != 0;         // k_accumulate_radar's records: 64 doubles, all 36 entries of J^T M J (single GPU, unfused)
     __shared__ double full[36];               // radar: J^T M J row-major
     if (radar) {
-        const int k = t & 63, g = t >> 6; // sixteen groups of 64 lanes, one lane per sum, fixed order
-        double* part64 = &part[0][0];
-        double v = 0.0;
-        if (!done) {
-            const ScanDesc sd = scans[s];
-            for (unsigned b = sd.blk_begin + g; b < sd.blk_end; b += kSolveThreads / 64) v += partials[(size_t)b * kRadarSums + k];
-        }
-        part64[g * 64 + k] = v;
-        __syncthreads();
-        if (t < 64) {
-            double a = part64[t];
+        // multi-rank: mode 1 leaves the 64 sums of the scan in sums[s][64] for the all-reduce, mode 2 (one wavefront) reads them back
+        double a = 0.0;
+        if (mode != 2) {
+            const int k = t & 63, g = t >> 6; // sixteen groups of 64 lanes, one lane per sum, fixed order
+            double* part64 = &part[0][0];
+            double v = 0.0;
+            if (!done) {
+                const ScanDesc sd = scans[s];
+                for (unsigned b = sd.blk_begin + g; b < sd.blk_end; b += kSolveThreads / 64) v += partials[(size_t)b * kRadarSums + k];
+            }
+            part64[g * 64 + k] = v;
+            __syncthreads();
+            if (t < 64) {
+                a = part64[t];
 #pragma unroll
-            for (int q = 1; q < kSolveThreads / 64; ++q) a += part64[q * 64 + t];
+                for (int q = 1; q < kSolveThreads / 64; ++q) a += part64[q * 64 + t];
+                if (mode == 1) sums[(size_t)s * kRadarSums + t] = (t < kRadarAcc) ? a : 0.0; // (zeros for finished scans keep the buffer defined)
+            }
+            if (mode == 1) return;
+        } else if (t < 64) {
+            a = (scans[s].blk_end > scans[s].blk_begin) ? sums[(size_t)s * kRadarSums + t] : 0.0;
+        }
+        if (t < 64) {
             if (t < 36) full[t] = a;
             else if (t < kRadarAcc) tot[21 + (t - 36)] = a; // J^T M r, residual sum, pair count, statistics: the slots of the 32-sum layout
         }

@@ -30,7 +30,7 @@ extern "C" {
 #define ELM_ERR_DEVICE -2      /* HIP runtime error (elm_last_error has the text) */
 #define ELM_ERR_NO_DEVICE -3   /* no usable gfx950 device */
 #define ELM_ERR_COMM -4        /* RCCL error / not initialised */
-#define ELM_ERR_UNSUPPORTED -5 /* e.g. use_radar_cov = 1 together with a communicator */
+#define ELM_ERR_UNSUPPORTED -5 /* e.g. a host-fed stream with a communicator attached; a search index that cannot be built */
 #define ELM_ERR_IO -6          /* file missing / unreadable */
 #define ELM_ERR_ALLOC -7       /* host allocation failed */
 
@@ -48,7 +48,7 @@ typedef struct elm_reg_config {
     int32_t i_max_thread;        /* unused on the GPU; kept for API parity */
     int32_t icp_method;          /* ELM_P2P .. ELM_AVGICP */
     int32_t voxel_search_method; /* parsed but unused by the reference (pcm.cpp:175) */
-    int32_t use_radar_cov;       /* reg.hpp:186-217: first iteration adds CalPointCov of the point under the initial guess, later ones I (single rank) */
+    int32_t use_radar_cov;       /* reg.hpp:186-217: first iteration adds CalPointCov of the point under the initial guess, later ones I */
     int32_t max_iteration;
     int32_t b_debug_print;
     double gicp_cov_search_dist;
@@ -208,7 +208,7 @@ int elm_register_batch(elm_ctx* ctx, const elm_map* map, elm_scan* const* scans,
  * communicator attached the assignment is in slot order, identical on every rank).  elm_register keeps the caller's point order
  * while elm_scan_upload orders the points: the two agree up to the order of the summation (1e-9 on every sum), not bit for bit.
  * trace: NULL or count*ELM_MAX_ITER_TRACE entries.  use_radar_cov = 1 with a covariance method: the registrations run as lockstep
- * batches of `slots` (same results as elm_register_batch); with a communicator attached that configuration is ELM_ERR_UNSUPPORTED. */
+ * batches of `slots` (same results as elm_register_batch; with a communicator attached the all-reduce then carries 64 sums per scan). */
 int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* const* scans, int count, const double* T0,
                         const elm_reg_config* cfg, int slots, elm_reg_result* results, elm_iter_trace* trace);
 /* The same with the scans still in HOST memory when the call starts -- RunRegister's per-call contract (reg.cpp:274-290: the

@@ -973,7 +973,7 @@ def test_grid_budget_falls_back_to_lists(oracle, world100k, monkeypatch):
         c.close()
 
 
-def _run_two_ranks(world, full, T0s, m, stream, slots=3, cov_dist=0.4):
+def _run_two_ranks(world, full, T0s, m, stream, slots=3, cov_dist=0.4, cfg_kw=None):
     """Two REAL ranks on this GPU: two contexts (two host threads, two streams), every scan's points sharded in two, the map
     replicated, and an exchange hook that adds the two ranks' packed sums -- what the RCCL all-reduce does between the
     reduce-only and the solve-only launch of every iteration.  Returns the two ranks' result lists."""
@@ -1013,7 +1013,7 @@ def _run_two_ranks(world, full, T0s, m, stream, slots=3, cov_dist=0.4):
                 return 0
 
             ctx.set_allreduce_hook(hook)
-            reg = Registration(RegistrationConfig(icp_method=m), ctx)
+            reg = Registration(RegistrationConfig(icp_method=m, **(cfg_kw or {})), ctx)
             results[r] = reg.RunRegisterStream(scans, vmr, T0s, slots=slots) if stream else reg.RunRegisterBatch(scans, vmr, T0s)
             ctx.set_allreduce_hook(None)
             del scans, vmr
@@ -1284,6 +1284,30 @@ def test_radar_covariance_matches_oracle(ctx, oracle, world100k, method):
     _compare_radar(det, ref)
     np.testing.assert_allclose(cov, ref["local_cov"], rtol=1e-6, atol=1e-12)
     assert ok == ref["is_success"]
+
+
+@pytest.mark.parametrize("method,stream", [(1, False), (2, True), (3, False)])
+def test_radar_covariance_two_ranks(ctx, oracle, world100k, method, stream):
+    """use_radar_cov on several ranks: the exchange carries the radar kernel's 64 sums per scan (all 36 entries of the non-symmetric
+    J^T M J).  Two real ranks on one GPU, every scan sharded in two: both ranks bit-identical, the same trajectory as the oracle."""
+    from elimaloc_amd.registration import IcpMethod
+    m = IcpMethod(method)
+    full, T0s = [], []
+    for i, n in enumerate([1500, 900, 1201]):
+        sc, Tt = synth.make_scan(world100k, n, seed=4600 + i)
+        full.append(sc); T0s.append(synth.perturb(Tt, seed=4700 + i, max_trans=0.2, max_rot_deg=0.8))
+    res = _run_two_ranks(world100k, full, T0s, m, stream=stream, slots=2, cfg_kw=RADAR)
+    om = oracle.Map(1.0, 30); om.add_points(world100k)
+    if m in (IcpMethod.VGICP, IcpMethod.AVGICP):
+        om.cal_voxel_cov_all()
+    if m == IcpMethod.GICP:
+        om.cal_point_cov_all(0.4)
+    for k in range(len(full)):
+        a, b = res[0][k], res[1][k]
+        assert np.array_equal(a["T"], b["T"]) and a["iterations"] == b["iterations"] and a["is_success"] == b["is_success"]
+        ref = oracle.register(om, full[k], T0s[k], oracle.default_config(method, **RADAR))
+        assert (a["iterations"], a["is_success"]) == (ref["iterations"], ref["is_success"]), k
+        np.testing.assert_allclose(a["T"], ref["T"], rtol=0, atol=1e-7)
 
 
 def test_radar_covariance_one_iteration_gicp_covariance(ctx, oracle, world100k):
