@@ -1577,20 +1577,43 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
         cb[0] = 0;
         // all four 12-byte loads are issued before the first is used (a column that is clipped away or outside reads cell 0 and is
         // masked afterwards); cell indices fit 32 bits (build_cell_grid)
+        // The columns are requested in VISITING order straight away -- own, the nearer of the x / y neighbour, the other, the diagonal one
+        // (lower bounds of the squared distance from the point's position in its cell: 1e-6 m off each face distance for the float32
+        // cell coordinate) -- so nothing has to be permuted once the offsets are back.  ox / oy: the own cell is the span's first (0) or
+        // second (1) cell; a span clipped to one cell has no neighbour on that axis.
+        const float ex_ = fmaxf(dxo * (float)h - 1e-6f, 0.f), ey_ = fmaxf(dyo * (float)h - 1e-6f, 0.f);
+        const float Bx = fminf(ex_ * ex_, 1e36f), By = fminf(ey_ * ey_, 1e36f);
+        const bool xfirst = Bx <= By, has_x = rx1 != rx0, has_y = ry1 != ry0;
         unsigned s0[4], s1[4], s2[4];
         bool ok[4];
+        ok[0] = inside;
+        ok[1] = inside && (xfirst ? has_x : has_y);
+        ok[2] = inside && (xfirst ? has_y : has_x);
+        ok[3] = inside && has_x && has_y;
+        if (!TILED) {
+            // cell index of the own column, the neighbours one column step away (x: gny * gnz cells, y: gnz), towards the other cell of the span
+            const int own_x = ox ? rx1 : rx0, own_y = oy ? ry1 : ry0;
+            const unsigned base = ((unsigned)own_x * (unsigned)m.gny + (unsigned)own_y) * (unsigned)m.gnz + (unsigned)rz0;
+            const unsigned xs = (unsigned)m.gny * (unsigned)m.gnz, ys = (unsigned)m.gnz; // (scalar)
+            const unsigned cx_n = ox ? base - xs : base + xs, cy_n = oy ? base - ys : base + ys, cd = ox ? cy_n - xs : cy_n + xs;
+            unsigned cellv[4];
+            cellv[0] = base; cellv[1] = xfirst ? cx_n : cy_n; cellv[2] = xfirst ? cy_n : cx_n; cellv[3] = cd;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int cx = (k >> 1) ? rx1 : rx0, cy = (k & 1) ? ry1 : ry0;
-            const bool dup = ((k >> 1) && rx1 == rx0) || ((k & 1) && ry1 == ry0); // a span clipped to one cell
-            ok[k] = inside && !dup;
-            if (!TILED) {
-                const unsigned cell = ok[k] ? ((unsigned)cx * (unsigned)m.gny + (unsigned)cy) * (unsigned)m.gnz + (unsigned)rz0 : 0u;
-                const uint32_t* e = m.grid_start + cell;
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t* e = m.grid_start + (ok[k] ? cellv[k] : 0u);
                 s0[k] = e[0]; s1[k] = e[1]; s2[k] = e[2];
-            } else { // the column's tile, then the two ends of its run (a masked column reads tile 0 / entry 0)
+            }
+        } else { // the column's tile, then the two ends of its run (a masked column reads tile 0 / entry 0)
+            const int own_x = ox ? rx1 : rx0, oth_x = ox ? rx0 : rx1, own_y = oy ? ry1 : ry0, oth_y = oy ? ry0 : ry1;
+            int cxv[4], cyv[4];
+            cxv[0] = own_x; cyv[0] = own_y;
+            cxv[1] = xfirst ? oth_x : own_x; cyv[1] = xfirst ? own_y : oth_y;
+            cxv[2] = xfirst ? own_x : oth_x; cyv[2] = xfirst ? oth_y : own_y;
+            cxv[3] = oth_x; cyv[3] = oth_y;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
                 int zc0, nzc;
-                const uint32_t* e = col_cells<1>(m, ok[k] ? cx : 0, ok[k] ? cy : 0, rz0, rz1, zc0, nzc);
+                const uint32_t* e = col_cells<1>(m, ok[k] ? cxv[k] : 0, ok[k] ? cyv[k] : 0, rz0, rz1, zc0, nzc);
                 s0[k] = e[0]; s1[k] = e[nzc]; s2[k] = s1[k];
             }
         }
@@ -1606,32 +1629,18 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
         float egrr = (2.0f * eg * fmaxf(rr, 0.f) + eg * eg) * 1.000001f;
         // for the ball of an undecided point: any block candidate is within 3.5 h of g
         float egblk = (7.0f * eg * (float)h + eg * eg) * 1.000001f;
-        // the columns are visited nearest first -- own, the nearer of the x / y neighbour, the other, the diagonal one -- and a lane
-        // stops at the first column that lies farther than its current winner: lower bounds of the squared distance to the three
-        // neighbour columns (1e-6 m off each face distance for the float32 cell coordinate)
-        const float ex_ = fmaxf(dxo * (float)h - 1e-6f, 0.f), ey_ = fmaxf(dyo * (float)h - 1e-6f, 0.f);
-        const float Bx = fminf(ex_ * ex_, 1e36f), By = fminf(ey_ * ey_, 1e36f);
+        // a lane stops at the first column (in visiting order) that lies farther than its current winner
         float L1 = fminf(Bx, By), L2 = fmaxf(Bx, By), L3 = (Bx + By) * 0.999999f;
         asm volatile("" : "+v"(rr2), "+v"(ghx), "+v"(ghy), "+v"(ghz), "+v"(egrr), "+v"(egblk), "+v"(L1), "+v"(L2), "+v"(L3));
         pf.w = __uint_as_float(stat);
         *stash() = pf;
         {
-            int b0a[4], b1a[4];
+            int b0v[4], b1v[4]; // (already in visiting order)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                b0a[k] = ok[k] ? (int)s0[k] : 0;
-                b1a[k] = ok[k] ? (int)((rz1 > rz0 || TILED) ? s2[k] : s1[k]) : 0;
+                b0v[k] = ok[k] ? (int)s0[k] : 0;
+                b1v[k] = ok[k] ? (int)((rz1 > rz0 || TILED) ? s2[k] : s1[k]) : 0;
             }
-            // column k = (ix << 1) | iy; own column o, y neighbour o ^ 1, x neighbour o ^ 2, diagonal o ^ 3
-            const bool o0 = oy != 0, o1 = ox != 0, xfirst = Bx <= By;
-            int b0v[4], b1v[4];
-            auto visit_order = [&](const int* A, int* V) {
-                const int lo0 = o0 ? A[1] : A[0], lo1 = o0 ? A[0] : A[1], hi0 = o0 ? A[3] : A[2], hi1 = o0 ? A[2] : A[3];
-                const int P = o1 ? hi0 : lo0, Q = o1 ? hi1 : lo1, R = o1 ? lo0 : hi0, S = o1 ? lo1 : hi1;
-                V[0] = P; V[1] = xfirst ? R : Q; V[2] = xfirst ? Q : R; V[3] = S;
-            };
-            visit_order(b0a, b0v);
-            visit_order(b1a, b1v);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 sb[k] = (unsigned)(b0v[k] - cb[k]) * kBlkStep; // block t of the flattened sequence lives at byte (unit) sb[k] + 48 (3) t for cb[k] <= t < cb[k + 1]
