@@ -1500,7 +1500,8 @@ __device__ __forceinline__ const uint32_t* col_cells(const DevMap& m, int cx, in
 // WIDE = 1: the block array does not fit 32-bit byte offsets (4 GB = ~275 M map points): stage 1 carries offsets in 16-byte units
 // (three per block) and forms the 64-bit address per block with one shift-add; everything else addresses blocks by index already.
 template <int METHOD, int COMPACT, int TILED, int STATS, int WIDE>
-__global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_GICP_WAVES)) void k_accumulate_grid(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
+__global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_WAVES) : ELM_GICP_WAVES)) void k_accumulate_grid( // (the instrumented P2P build holds 20.7 KB of LDS: 7 workgroups per CU)
+       const DevMap m, const ScanDesc* __restrict__ scans, int batch,
                                                                             unsigned total_blocks, const ScanState* __restrict__ st,
                                                                             double* __restrict__ partials, const RegParams rp) {
     constexpr int NV = (METHOD == ELM_P2P) ? (STATS ? kP2PVals : kP2PVals - 3) : kSums;
@@ -1508,6 +1509,8 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
     __shared__ double s_red[kSums];
     __shared__ int s_res[kBlock];
     __shared__ int s_tst[STATS ? kBlock : 1];
+    __shared__ float s_pz[METHOD == ELM_P2P ? kBlock : 1];  // P2P: the point's z (x and y ride in the stash's spare 8 bytes)
+    __shared__ unsigned s_st[STATS ? kBlock : 1];           // instrumented builds: the walk statistics of the query voxel
     __shared__ unsigned s_cnt[kBlock / 64];
     const unsigned L = xcd_remap(blockIdx.x, total_blocks);
     const int s = find_scan(scans, batch, L, rp);
@@ -1529,15 +1532,22 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
     const double h = 0.5 * m.voxel_size;
     const GridBlk* __restrict__ lp = m.grid_blk;
     constexpr unsigned kBlkStep = WIDE ? (unsigned)(sizeof(GridBlk) / 16) : (unsigned)sizeof(GridBlk); // stage-1 offsets: 16-byte units / bytes
-    // the point and its transform are cheap to redo (one 16-byte load that hits L1/L2 + 18 float64 operations): they are NOT kept
-    // in registers across the candidate loop and the cooperative stage -- the kernel is bound by latency, i.e. by occupancy
-    // the point and the walk statistics of its query voxel wait in LDS, in the upper half of the reduction buffer (the queue of
-    // stage 2 takes at most the lower half), at the 16 bytes this thread's own wavefront overwrites first in the reduction
-    // (values 4 and 5 of the first pass): no barrier is needed between the last read of the stash and the reduction
-    auto stash = [&]() -> float4* { // recomputed at each of its three uses (an address held across the kernel costs a register)
+    // The transformed point g (three doubles) and the walk statistics of its query voxel are NOT kept in registers across the candidate
+    // loop and the cooperative stage (the kernel lives on occupancy): they wait in LDS, in the upper half of the reduction buffer (the queue
+    // of stage 2 takes at most the lower half), in the 32 bytes this thread's own wavefront overwrites first in the reduction (values 4..7
+    // of the first pass): no barrier is needed between the last read of the stash and the reduction.  (Rounds 2-3 stashed the point and
+    // redid the 18-operation float64 transform at both later uses -- in the epilogue and, for a wavefront with an undecided point, before
+    // stage 2: 36 half-rate instructions per point.  The P2P pair also needs the point itself: x and y as floats in the stash's last 8
+    // bytes, z in a 1 KB array of its own -- re-reading it from global memory at the epilogue cost 4.7 %.)
+    auto stash = [&](unsigned half) -> double2* { // recomputed at each use (an address held across the kernel costs a register)
         unsigned t = threadIdx.x;
         asm volatile("" : "+v"(t));
-        return reinterpret_cast<float4*>(s_buf) + ((4u + ((t >> 5) & 1u)) * (kBlock / 2) + (t >> 6) * 32u + (t & 31u));
+        return reinterpret_cast<double2*>(s_buf) + ((4u + 2u * half + ((t >> 5) & 1u)) * (kBlock / 2) + (t >> 6) * 32u + (t & 31u));
+    };
+    auto load_g = [&](double& gx, double& gy, double& gz, float& pxf, float& pyf) {
+        const double2 a = *stash(0), b = *stash(1);
+        gx = a.x; gy = a.y; gz = b.x;
+        pxf = __int_as_float(__double2loint(b.y)); pyf = __int_as_float(__double2hiint(b.y));
     };
     auto transform = [&](const float4 pf, double& px, double& py, double& pz, double& gx, double& gy, double& gz) {
         px = pf.x; py = pf.y; pz = pf.z;
@@ -1632,8 +1642,10 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
         // a lane stops at the first column (in visiting order) that lies farther than its current winner
         float L1 = fminf(Bx, By), L2 = fmaxf(Bx, By), L3 = (Bx + By) * 0.999999f;
         asm volatile("" : "+v"(rr2), "+v"(ghx), "+v"(ghy), "+v"(ghz), "+v"(egrr), "+v"(egblk), "+v"(L1), "+v"(L2), "+v"(L3));
-        pf.w = __uint_as_float(stat);
-        *stash() = pf;
+        *stash(0) = make_double2(gx, gy);
+        *stash(1) = make_double2(gz, __hiloint2double(__float_as_int(pf.y), __float_as_int(pf.x)));
+        if (METHOD == ELM_P2P) s_pz[threadIdx.x] = pf.z;
+        if (STATS) s_st[threadIdx.x] = stat;
         {
             int b0v[4], b1v[4]; // (already in visiting order)
 #pragma unroll
@@ -1726,8 +1738,9 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
             // ball is still cleared completely, the bound only has to be an upper bound (float64 distance, rounded up).
             const unsigned pj = rp.prev[pidx];
             if (pj < m.grid_nslots) { // (-1 = none; an entry written against another map may lie beyond this one's slots)
-                double px, py, pz, gx, gy, gz;
-                transform(*stash(), px, py, pz, gx, gy, gz);
+                double gx, gy, gz;
+                float pxf_, pyf_;
+                load_g(gx, gy, gz, pxf_, pyf_);
                 const Pt3 q = blk_point(lp, (int)pj);
                 // only a point of one of the 27 buckets the reference visits for the NEW g is a candidate: stored (truncated) key within one
                 // of the query's floor key on every axis (vhm.cpp:275 / vhm.hpp:176-180, the arithmetic of grid_axis / visit_rank)
@@ -1741,9 +1754,9 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
             }
         }
         if (hard) {
-            double px, py, pz;
             GridHardRec r;
-            transform(*stash(), px, py, pz, r.gx, r.gy, r.gz);
+            float pxf_, pyf_;
+            load_g(r.gx, r.gy, r.gz, pxf_, pyf_);
             r.r2 = hr2; r._pad = 0.f;
             s_rec[my_slot] = r;
         }
@@ -1960,10 +1973,11 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_GRID_WAVES : ELM_G
     }
     if (keep_prev && valid) rp.prev[pidx] = (unsigned)bj; // (-1: no candidate at all)
     if (valid) {
-        double px, py, pz, gx, gy, gz;
-        const float4 pf = *stash();
-        transform(pf, px, py, pz, gx, gy, gz);
-        const unsigned stat = __float_as_uint(pf.w);
+        double gx, gy, gz;
+        float pxf, pyf;
+        load_g(gx, gy, gz, pxf, pyf);
+        const double px = pxf, py = pyf, pz = (METHOD == ELM_P2P) ? (double)s_pz[threadIdx.x] : 0.0; // (the pair of P2P: J = [I | -[p]x])
+        const unsigned stat = STATS ? s_st[threadIdx.x] : 0u;
         // the winner's float64 distance in the reference's arithmetic (range test, weight); no bucket at all (the search came
         // back empty): the reference's default PointStruct at the origin (vhm.cpp:37, QUIRK)
         float bx = 0.f, by = 0.f, bz = 0.f;
