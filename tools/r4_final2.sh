@@ -1,21 +1,26 @@
 #!/bin/bash
 # round-4 final call after the re-tune (P2P kernel at 8 waves / 64 VGPRs, GICP at 7): full gpu suite, default line with every leg, default trace,
 # counter passes of the re-tuned kernels at the operating point, per-method lines, the one-rank RCCL line
+TAG=${1:-h}; export TAG
+# PASSES_ONLY=1: only the counter passes (merged into profiles/pmc_latest.json before the bench lines are taken)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 mkdir -p gpurun_out
-python -m pytest tests -q -m gpu > gpurun_out/g.pytest 2>&1; tail -3 gpurun_out/g.pytest
-python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/g_smoke.log 2>&1; tail -1 gpurun_out/g_smoke.log
-python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/g_default.json 2> gpurun_out/g_default.err || tail -5 gpurun_out/g_default.err
-for m in 1 2 3; do python bench.py --method $m --no-cpu --no-extras > gpurun_out/g_m$m.json 2> gpurun_out/g_m$m.err; done
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 1 --no-cpu --no-extras > gpurun_out/g_dist1.json 2> gpurun_out/g_dist1.err
-tools/default_trace.sh > gpurun_out/g_trace.log 2>&1
-PROF_NO_FINAL=1 tools/collect_profiles.sh r04g_p2p 2>&1 | tail -1 | cut -c1-160
-BENCH_ARGS="--method 1" PROF_NO_FINAL=1 tools/collect_profiles.sh r04g_gicp 2>&1 | tail -1 | cut -c1-160
-BENCH_ARGS="--guess hard" PROF_NO_FINAL=1 PROF_STEPS=2 tools/collect_profiles.sh r04g_hard 2>&1 | tail -1 | cut -c1-160
+if [ -n "${PASSES_ONLY:-}" ]; then
+PROF_NO_FINAL=1 tools/collect_profiles.sh r04${TAG}_p2p 2>&1 | tail -1 | cut -c1-160
+BENCH_ARGS="--method 1" PROF_NO_FINAL=1 tools/collect_profiles.sh r04${TAG}_gicp 2>&1 | tail -1 | cut -c1-160
+BENCH_ARGS="--guess hard" PROF_NO_FINAL=1 PROF_STEPS=2 tools/collect_profiles.sh r04${TAG}_hard 2>&1 | tail -1 | cut -c1-160
+exit 0
+fi
+python -m pytest tests -q -m gpu > gpurun_out/${TAG}.pytest 2>&1; tail -3 gpurun_out/${TAG}.pytest
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.log 2>&1; tail -1 gpurun_out/${TAG}_smoke.log
+python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_default.json 2> gpurun_out/${TAG}_default.err || tail -5 gpurun_out/${TAG}_default.err
+for m in 1 2 3; do python bench.py --method $m --no-cpu --no-extras > gpurun_out/${TAG}_m$m.json 2> gpurun_out/${TAG}_m$m.err; done
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 1 --no-cpu --no-extras > gpurun_out/${TAG}_dist1.json 2> gpurun_out/${TAG}_dist1.err
+tools/default_trace.sh > gpurun_out/${TAG}_trace.log 2>&1
 python - <<'PY'
 import json, glob
-for f in sorted(glob.glob("gpurun_out/g_*.json")):
+for f in sorted(glob.glob("gpurun_out/%s_*.json" % __import__("os").environ.get("TAG", "h"))):
     try:
         r = json.load(open(f)); ro = r["roofline"]; ra = r.get("reference_api", {})
         print("%-26s value %8.0f ms/step %.2f launches %d avg %.4f ms | lat1 %s | refapi %s pinned %s | hard %s | hostfed %s | frac %.3f %s | rccl %s" % (

@@ -1,0 +1,15 @@
+#!/bin/bash
+# sweep of the kernel constants at the round's final kernel (8 waves, columns in visiting order, g stashed)
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R
+mkdir -p gpurun_out
+one() { local L=$1 T=$2; shift 2
+  ELM_LIB=$PWD/build_ab/lib_$L.so python bench.py --no-cpu --no-extras "$@" > gpurun_out/s3_${L}_$T.json 2> gpurun_out/s3_${L}_$T.err || tail -3 gpurun_out/s3_${L}_$T.err
+  python - $L $T gpurun_out/s3_${L}_$T.json <<'PY'
+import json, sys
+r = json.load(open(sys.argv[3])); f = r["roofline"]
+print("%-6s %-7s %8.0f reg/s  launch %.4f ms" % (sys.argv[1], sys.argv[2], r["value"], f["avg_launch_ms"]), flush=True)
+PY
+}
+for L in cur t1 t3 l2 l8 w7 cur; do one $L easy; done
+for L in cur t1 l2; do one $L hard --guess hard --steps 6; done
