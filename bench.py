@@ -458,11 +458,11 @@ def main():
     # float32, every float64 op, v_and_or / v_med3 / v_min / v_max / shifts / v_cmp / v_cndmask / conversions), ~8.2 (rcp, sqrt) -- and
     # shows that SQ_ACTIVE_INST_VALU ticks ONCE per instruction whatever its class (twice for transcendentals), so round 3's
     # "4 x SQ_ACTIVE_INST_VALU / SIMD cycles" over-counted the 2.4-cycle class; tools/valu_mix.py weighs the kernel's own opcode mix
-    # (profiles/r04_valu_mix.txt: 27 % fast, 72 % slow, 1 % transcendental for the P2P grid kernel -> 3.81 cycles).  TA busy is the
+    # (profiles/r04_valu_mix.txt: 29 % fast, 70 % slow, 1 % transcendental for the P2P grid kernel -> 3.78 cycles).  TA busy is the
     # vector-memory front end.  Without a matching pass the line falls back to the HBM stream.
     clock_ghz = 2.4  # MI355X_MICROARCH.md: max clock
     simd_cycles = 1024 * clock_ghz  # G SIMD-cycles/s over the chip (256 CUs x 4 SIMDs)
-    issue_cycles = {"k_accumulate_grid<P2P>": 3.81, "k_accumulate_grid<GICP>": 3.84, "k_accumulate_vnbr<VGICP>": 3.89, "k_accumulate_vnbr<AVGICP>": 3.90}
+    issue_cycles = {"k_accumulate_grid<P2P>": 3.78, "k_accumulate_grid<GICP>": 3.81, "k_accumulate_vnbr<VGICP>": 3.89, "k_accumulate_vnbr<AVGICP>": 3.90}  # profiles/r04_valu_mix.txt
     roofline = dict(hbm)
     roofline["bound"] = "hbm"
     vb = None
