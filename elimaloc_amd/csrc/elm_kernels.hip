@@ -2173,7 +2173,8 @@ __global__ __launch_bounds__(64) void k_nbr_cellsort(const DevMap m, const int32
 #ifndef ELM_VNBR_WAVES
 #define ELM_VNBR_WAVES 1
 #endif
-template <int METHOD, int COMPACT, int STATS>
+// FACES = 1 (AVGICP on maps with the dense face-sublist table): the walk reads the face sublists, 48 bytes per record
+template <int METHOD, int COMPACT, int STATS, int FACES>
 __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
                                                             unsigned total_blocks, const ScanState* __restrict__ st,
                                                             double* __restrict__ partials, const RegParams rp) {
@@ -2314,7 +2315,30 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
             double n_pairs = 0.0;
             AvgPairSum Q;
             avg_pair_init(Q);
-            const bool faces_only = m.vq_dense && m.vqf_dense; // uniform: lp is a face sublist
+            const bool faces_only = FACES != 0; // lp is a face sublist (the launcher checks m.vq_dense && m.vqf_dense)
+            if (COMPACT && FACES) {
+                // Face sublists, compact records: 48 of the record's 64 bytes -- mean and unit normal; k = kCompactK is implied, the other two
+                // kinds are flagged in the normal's first word by k_vface (2: identity covariance, NaN: outside the compact form -> the stored
+                // inverse by the record's voxel id).  Three 16-byte loads per pair instead of four: the walk is a chain of record loads.
+                for (unsigned j = 0; j < cnt; ++j) {
+                    const double2* __restrict__ rp16 = reinterpret_cast<const double2*>(lp + j);
+                    const double2 r0 = rp16[0], r1 = rp16[1], r2 = rp16[2]; // (mx, my), (mz, nx), (ny, nz)
+                    double Ci[9];
+                    if (r1.y == 2.0) {
+                        compact_cinv(1.0, 0.0, 0.0, 0.0, Ci);
+                    } else if (r1.y == r1.y) {
+                        compact_cinv(r1.y, r2.x, r2.y, kCompactK, Ci);
+                    } else {
+                        const double* __restrict__ cp = m.vox_cinv + (size_t)lp[j].vid * 9;
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) Ci[k] = cp[k];
+                    }
+                    n_pairs += 1.0;
+                    const double ex = r0.x - gx, ey = r0.y - gy, ez = r1.x - gz;
+                    const double d2 = (ex * ex + ey * ey) + ez * ez;
+                    if (d2 < rp.th2) avg_pair_add(Q, ex, ey, ez, Ci, rp);
+                }
+            } else
             for (unsigned j = 0; j < cnt; j += ELM_AVG_RECS) { // ELM_AVG_RECS records (two 16-byte loads each) per round trip
                 VoxRec r[ELM_AVG_RECS];
 #pragma unroll
@@ -3298,14 +3322,22 @@ void launch_vox_stat(hipStream_t s, const DevMap& m, uint32_t* out) {
 int stream_max_slots() { return kMaxSlots; }
 void launch_accumulate_vnbr(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                             ScanState* st, double* partials, const RegParams& rp) {
-#define ELM_LAUNCH_V(M, C)                                                                                                                                                \
-    do {                                                                                                                                                                  \
-        if (rp.stats) hipLaunchKernelGGL((k_accumulate_vnbr<M, C, 1>), dim3(total_blocks), dim3(kBlock), 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp); \
-        else hipLaunchKernelGGL((k_accumulate_vnbr<M, C, 0>), dim3(total_blocks), dim3(kBlock), 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp);          \
+#define ELM_LAUNCH_VF(M, C, S_, F_) hipLaunchKernelGGL((k_accumulate_vnbr<M, C, S_, F_>), dim3(total_blocks), dim3(kBlock), 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp)
+#define ELM_LAUNCH_V(M, C)                                                         \
+    do {                                                                           \
+        const bool faces_ = (M) == ELM_AVGICP && m.vq_dense && m.vqf_dense;        \
+        if (faces_) {                                                              \
+            if (rp.stats) ELM_LAUNCH_VF(M, C, 1, ((M) == ELM_AVGICP ? 1 : 0));     \
+            else ELM_LAUNCH_VF(M, C, 0, ((M) == ELM_AVGICP ? 1 : 0));              \
+        } else {                                                                   \
+            if (rp.stats) ELM_LAUNCH_VF(M, C, 1, 0);                               \
+            else ELM_LAUNCH_VF(M, C, 0, 0);                                        \
+        }                                                                          \
     } while (0)
     if (rp.method == ELM_VGICP) { if (m.vox_compact) ELM_LAUNCH_V(ELM_VGICP, 1); else ELM_LAUNCH_V(ELM_VGICP, 0); }
     else { if (m.vox_compact) ELM_LAUNCH_V(ELM_AVGICP, 1); else ELM_LAUNCH_V(ELM_AVGICP, 0); }
 #undef ELM_LAUNCH_V
+#undef ELM_LAUNCH_VF
 }
 // map build: the face neighbours (and the voxel itself) of every voxel-mean list, in list order (AVGICP's pairs)
 __device__ __forceinline__ bool is_face_code(int code) {
@@ -3320,8 +3352,13 @@ __global__ __launch_bounds__(256) void k_vface(const VoxRec* __restrict__ vnbr, 
     unsigned n = 0;
     const unsigned o = out ? face_off[q] : 0u;
     for (unsigned j = 0; j < counts[q]; ++j) {
-        const VoxRec r = lp[j];
+        VoxRec r = lp[j];
         if (!is_face_code(r.pad)) continue;
+        // the first 48 bytes tell the three kinds of record apart (k_accumulate_vnbr<AVGICP> loads only those in the common case):
+        //   k = kCompactK (regularised covariance): the unit normal as it is;  k = 0 (identity): n.x = 2 (not a unit vector);
+        //   anything else (k = NaN: outside the compact form, or another k): n.x = NaN -> the stored inverse is read
+        if (r.k == 0.0) r.nx = 2.0;
+        else if (!(fabs(r.k - kCompactK) <= 1e-7)) r.nx = __builtin_nan("");
         if (out) out[o + n] = r;
         ++n;
     }
