@@ -894,6 +894,7 @@ static int build_voxel_neighbourhoods(elm_map* m) {
                 VF_CHK(hipMemcpy(m->d_vqf_dense, dense.data(), vcells * sizeof(uint32_t), hipMemcpyHostToDevice));
                 m->dm.vface = m->d_vface;
                 m->dm.vqf_dense = m->d_vqf_dense;
+                m->dm.vface_plain = (m->dm.vox_compact && m->n_bad_vox == 0 && !std::getenv("ELM_AVG_NINE")) ? 1 : 0;
                 m->info.device_bytes += vcells * sizeof(uint32_t) + (size_t)ftotal * sizeof(VoxRec);
                 m->info.index_bytes += vcells * sizeof(uint32_t) + (size_t)ftotal * sizeof(VoxRec);
             }

@@ -111,6 +111,8 @@ struct DevMap {
     int32_t gicp_compact;       // 1: grid_gicp8 is what the grid kernel reads (k = NaN flags a point outside the compact form: its full
                                 // record is read from pt_gicp by the index in word 7)
     int32_t vox_compact;        // 1: the VoxRec's own normal / k are used (k = NaN: vox_cinv[vid] is read for that voxel)
+    int32_t vface_plain;        // 1: every face-sublist record is of the compact form or the identity (no voxel outside it in this map): the
+                                // AVGICP walk gathers sum w and sum (w k) n n^T instead of nine entries per pair
     int32_t gx0, gy0, gz0;      // cell coordinates of grid entry (0, 0, 0)
     int32_t gnx, gny, gnz;
     // dense voxel box of the floor keys a query can have near the map: cnt27 | nocc27 << 16 of the reference's 27-voxel walk

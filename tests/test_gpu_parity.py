@@ -1155,6 +1155,41 @@ def test_compact_covariance_records_equal_the_stored_inverses(oracle, world100k,
         assert ref["iterations"] == r["iterations"] and dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
 
 
+def test_avgicp_walk_forms_agree(oracle, world100k, monkeypatch):
+    """AVGICP on a map whose every voxel is of the compact form gathers sum w and sum (w k) n n^T per point (six entries, fused)
+    instead of nine entries of w C^-1 per pair; ELM_AVG_NINE=1 (read when the neighbourhoods are built) keeps the nine-entry walk.
+    Same pairs, the same sums to the sum tolerance on every iteration, and the oracle's pose."""
+    from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, VoxelHashMap
+    scan, Tt = synth.make_scan(world100k, 8000, seed=5151)
+    T0 = synth.perturb(Tt, seed=5152, max_trans=0.3, max_rot_deg=1.0)
+    runs = {}
+    for mode in ("six", "nine"):
+        if mode == "nine":
+            monkeypatch.setenv("ELM_AVG_NINE", "1")
+        c = Context(0)
+        try:
+            vm = VoxelHashMap(1.0, 30, c)
+            vm.AddPoints(world100k)
+            vm.CalVoxelCovAll()
+            runs[mode] = Registration(RegistrationConfig(icp_method=IcpMethod.AVGICP), c).RunRegister(scan, vm, T0, trace=True)[-1]
+        finally:
+            c.close()
+    a, b = runs["six"], runs["nine"]
+    assert a["iterations"] == b["iterations"] and a["is_success"] == b["is_success"]
+    for ia, ib in zip(a["iters"], b["iters"]):
+        assert ia["n_corr"] == ib["n_corr"]
+        assert np.abs(ia["JTJ"] - ib["JTJ"]).max() <= SUM_RTOL * np.abs(ib["JTJ"]).max()
+        assert np.abs(ia["JTr"] - ib["JTr"]).max() <= SUM_RTOL * max(np.abs(ib["JTr"]).max(), 1e-12 * np.abs(ib["JTJ"]).max())
+        np.testing.assert_allclose(ia["residual_sum"], ib["residual_sum"], rtol=SUM_RTOL)
+    om = oracle.Map(1.0, 30)
+    om.add_points(world100k)
+    om.cal_voxel_cov_all()
+    ref = oracle.register(om, scan, T0, oracle.default_config(3))
+    for r in (a, b):
+        dt, dr = synth.pose_error(ref["T"], r["T"])
+        assert ref["iterations"] == r["iterations"] and dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
+
+
 def test_rank_deficient_covariances_keep_the_full_records(oracle):
     """A map of exactly coplanar points: the sample covariances are rank deficient, the SVD's U and V may differ by signs and
     U diag(1,1,1e-3) V^T need not be I - 0.999 n n^T.  Such points / voxels are flagged (k = NaN) at map build and their pairs

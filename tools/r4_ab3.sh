@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B: AVGICP face sublists read 48 B per record (new) against 64 B (cur); then the full gpu suite on the new build
+# A/B: AVGICP gathering sum w + sum (w k) n n^T (six) against nine entries per pair (new = the 48-byte records); then the gpu suite
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 mkdir -p gpurun_out
@@ -11,6 +11,6 @@ r = json.load(open(sys.argv[3])); f = r["roofline"]
 print("%-6s %-7s %8.0f reg/s  launch %.4f ms" % (sys.argv[1], sys.argv[2], r["value"], f["avg_launch_ms"]), flush=True)
 PY
 }
-for L in cur new cur new cur new; do one $L avg --method 3; done
-for L in cur new; do one $L vg --method 2; done
+for L in new six new six new six; do one $L avg --method 3; done
+for L in new six; do one $L vg --method 2; done
 python -m pytest tests -q -m gpu > gpurun_out/z.pytest 2>&1; tail -3 gpurun_out/z.pytest; grep -n "^FAILED" gpurun_out/z.pytest | head
