@@ -702,7 +702,7 @@ extern "C" int elm_map_cal_voxel_cov_all(elm_map* m) {
     // outside that form (rank-deficient neighbourhood, U != V in its SVD) carry k = NaN and their pairs read the stored 3x3 inverse.
     // ELM_COV_RECORDS=full: every pair reads the stored inverses.
     m->n_bad_vox = bad;
-    m->dm.vox_compact = full_records_forced() ? 0 : 1;
+    m->dm.vox_compact = full_records_forced() ? 0 : ((bad == 0 && !std::getenv("ELM_PAIR_NINE")) ? 2 : 1); // 2: no flagged voxel at all
     m->info.has_voxel_cov = 1;
     m->info.layout_flags = (m->info.layout_flags & ~2) | (m->dm.vox_compact ? 2 : 0);
     return ELM_OK;
@@ -894,7 +894,7 @@ static int build_voxel_neighbourhoods(elm_map* m) {
                 VF_CHK(hipMemcpy(m->d_vqf_dense, dense.data(), vcells * sizeof(uint32_t), hipMemcpyHostToDevice));
                 m->dm.vface = m->d_vface;
                 m->dm.vqf_dense = m->d_vqf_dense;
-                m->dm.vface_plain = (m->dm.vox_compact && m->n_bad_vox == 0 && !std::getenv("ELM_AVG_NINE")) ? 1 : 0;
+                m->dm.vface_plain = (m->dm.vox_compact && m->n_bad_vox == 0 && !std::getenv("ELM_AVG_NINE") && !std::getenv("ELM_PAIR_NINE")) ? 1 : 0;
                 m->info.device_bytes += vcells * sizeof(uint32_t) + (size_t)ftotal * sizeof(VoxRec);
                 m->info.index_bytes += vcells * sizeof(uint32_t) + (size_t)ftotal * sizeof(VoxRec);
             }
@@ -931,7 +931,9 @@ static int refresh_grid_gicp(elm_map* m) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     m->dm.grid_gicp = m->d_grid_gicp;
     m->dm.grid_gicp8 = m->d_grid_gicp8;
-    m->dm.gicp_compact = compact ? 1 : 0;
+    // 2: no point outside the compact form -- the kernel has no full-record fallback and gathers the pair fused (ELM_PAIR_NINE=1: the
+    // nine-entry form with its fallback, as for maps with flagged points)
+    m->dm.gicp_compact = compact ? ((m->n_bad_pts == 0 && !std::getenv("ELM_PAIR_NINE")) ? 2 : 1) : 0;
     m->info.layout_flags = (m->info.layout_flags & ~1) | (compact ? 1 : 0);
     return ELM_OK;
 }

@@ -109,8 +109,9 @@ struct DevMap {
                                 // the inverse covariance I + k n n^T is rebuilt in registers (k = 999: U diag(1, 1, 1e-3) V^T of
                                 // vhm.hpp:238-246 with U = V up to rounding, checked per point at map build; k = 0: identity)
     int32_t gicp_compact;       // 1: grid_gicp8 is what the grid kernel reads (k = NaN flags a point outside the compact form: its full
-                                // record is read from pt_gicp by the index in word 7)
-    int32_t vox_compact;        // 1: the VoxRec's own normal / k are used (k = NaN: vox_cinv[vid] is read for that voxel)
+                                // record is read from pt_gicp by the index in word 7); 2: the same and no point is flagged -- the kernel
+                                // instantiation without the fallback, its pair gathered fused (pair_sum_compact)
+    int32_t vox_compact;        // 1: the VoxRec's own normal / k are used (k = NaN: vox_cinv[vid] is read for that voxel); 2: no voxel flagged
     int32_t vface_plain;        // 1: every face-sublist record is of the compact form or the identity (no voxel outside it in this map): the
                                 // AVGICP walk gathers sum w and sum (w k) n n^T instead of nine entries per pair
     int32_t gx0, gy0, gz0;      // cell coordinates of grid entry (0, 0, 0)

@@ -942,6 +942,33 @@ __device__ __forceinline__ void pair_sum_single(PairSum& P, double ex, double ey
     else P.rsum = sqrt_dist2(r2);
 }
 
+// pair_sum_single on a compact record: C^-1 = I + k n n^T is never formed -- A = w I + (w k) n n^T and b = w e + (w k)(n . e) n,
+// fused (the same values up to the rounding of the last bit; 20 float64 operations less).  Maps whose every covariance is of the
+// compact form only (DevMap::gicp_compact / vox_compact == 2): there is no full-record fallback in the kernels that use it.
+template <int METHOD>
+__device__ __forceinline__ void pair_sum_compact(PairSum& P, double ex, double ey, double ez, double nx, double ny, double nz, double k, const RegParams& rp) {
+    const double r2 = (ex * ex + ey * ey) + ez * ez;
+    const double den = rp.th + r2;
+    double w = div_normal(rp.th2, den * den); // square(th) / square(th + |r|^2)
+    if (METHOD == ELM_GICP) w = w * 0.8 + 0.2;
+    P.n = 1.0;
+    if (METHOD == ELM_VGICP || METHOD == ELM_AVGICP) {
+        if (w < 0.01) return; // reg.cpp:201 -- skipped pairs stay in the fitness denominator
+    }
+    const double wk = w * k;
+    const double ne = __builtin_fma(nz, ez, __builtin_fma(ny, ey, nx * ex));
+    const double sn = wk * ne;
+    const double ux = wk * nx, uy = wk * ny, uz = wk * nz;
+    P.A[0] = __builtin_fma(ux, nx, w); P.A[1] = ux * ny; P.A[2] = ux * nz;
+    P.A[3] = P.A[1]; P.A[4] = __builtin_fma(uy, ny, w); P.A[5] = uy * nz;
+    P.A[6] = P.A[2]; P.A[7] = P.A[5]; P.A[8] = __builtin_fma(uz, nz, w);
+    P.b[0] = __builtin_fma(sn, nx, w * ex);
+    P.b[1] = __builtin_fma(sn, ny, w * ey);
+    P.b[2] = __builtin_fma(sn, nz, w * ez);
+    if (METHOD == ELM_GICP) P.rsum = fabs((ex * nx + ey * ny) + ez * nz); // |r_l . n_l| (reg.cpp:91-95, 128), pair_sum_single's arithmetic
+    else P.rsum = sqrt_dist2(r2);
+}
+
 // ---- P2P pair in 18 sums ---------------------------------------------------------------------------------------------
 // AlignCloudsLocal (reg.cpp:28-51) has M = I and J = [I | -[p]x], so J^T w J and J^T w r are functions of
 //   w, w p (3), w p p^T (6 unique), w r (3), w (p x r) (3), |r|, pair count            (18 sums instead of 29)
@@ -2006,7 +2033,21 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
             // finish_point_pair: no bucket at all -> the reference's default PointStruct at the origin with covariance I (QUIRK);
             // GICP's target position is the neighbourhood MEAN of the matched point (reg.cpp:97)
             const double dfin = (bidx >= 0) ? bd2 : (gx * gx + gy * gy) + gz * gz;
-            if (dfin < rp.th2) {
+            if (COMPACT == 2) { // every record of this map is compact: mean + unit normal, k implied (0 with n.x = 2: identity)
+                if (dfin < rp.th2) {
+                    double mean[3] = {0.0, 0.0, 0.0}, nf[3] = {1.0, 0.0, 0.0}, k = 0.0;
+                    if (bidx >= 0) {
+                        const double* __restrict__ rec = m.grid_gicp8 + (size_t)bidx * 8;
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) { mean[q] = rec[q]; nf[q] = rec[3 + q]; }
+                        const bool ident = nf[0] == 2.0;
+                        nf[0] = ident ? 1.0 : nf[0];
+                        k = ident ? 0.0 : kCompactK;
+                    }
+                    pair_sum_compact<ELM_GICP>(P, mean[0] - gx, mean[1] - gy, mean[2] - gz, nf[0], nf[1], nf[2], k, rp);
+                    P.ax = gx - S.T[12]; P.ay = gy - S.T[13]; P.az = gz - S.T[14];
+                }
+            } else if (dfin < rp.th2) {
                 double Ci[9], mean[3], nf[3];
                 if (bidx >= 0 && COMPACT) { // 48 of the record's 64 bytes: mean + unit normal -- the inverse covariance is I + 999 n n^T
                     const double* __restrict__ rec = m.grid_gicp8 + (size_t)bidx * 8;
@@ -2291,7 +2332,13 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
             }
             // finish_voxel_pair: no voxel at all -> the reference's default VoxelStruct at the origin with covariance I (QUIRK)
             const double dfin = (bvid >= 0) ? bd2 : (gx * gx + gy * gy) + gz * gz;
-            if (dfin < rp.th2) {
+            if (COMPACT == 2) { // every voxel of this map is compact (no voxel at all: the default at the origin, covariance I: k = 0)
+                if (dfin < rp.th2) {
+                    if (bvid < 0) bmx = bmy = bmz = 0.0;
+                    pair_sum_compact<ELM_VGICP>(P, bmx - gx, bmy - gy, bmz - gz, bn[0], bn[1], bn[2], bn[3], rp);
+                    P.ax = gx - S.T[12]; P.ay = gy - S.T[13]; P.az = gz - S.T[14];
+                }
+            } else if (dfin < rp.th2) {
                 if (bvid < 0) bmx = bmy = bmz = 0.0;
                 double Ci[9];
                 if (bvid >= 0 && COMPACT && bn[3] == bn[3]) { // the record carried the normal and k: no second fetch
@@ -3226,7 +3273,8 @@ __global__ __launch_bounds__(256) void k_point_cov(const DevMap m, double d2max,
     for (int k = 0; k < 3; ++k) { rec[k] = mean[k]; rec[12 + k] = nf[k]; }
     for (int k = 0; k < 9; ++k) rec[3 + k] = Ci[k];
     bool ok;
-    const double kk = compact_k(Ci, nf, &ok); // k of Cinv = I + k n n^T (the compact 64-byte records, DevMap::grid_gicp8)
+    double kk = compact_k(Ci, nf, &ok); // k of Cinv = I + k n n^T (the compact 64-byte records, DevMap::grid_gicp8)
+    ok = ok && (kk == 0.0 || fabs(kk - kCompactK) <= 1e-7); // (the 48-byte reads imply k: 0 or 1 / 1e-3 - 1, nothing else is compact)
     rec[15] = ok ? kk : __builtin_nan(""); // NaN: this point's inverse is not of that form -- its pairs read the full record
     if (!ok) atomicAdd(bad, 1u);
     for (int k = 0; k < 9; ++k) pt_cov[(size_t)i * 9 + k] = C[k];
@@ -3342,6 +3390,7 @@ void launch_accumulate_grid(hipStream_t s, const DevMap& m, const ScanDesc* scan
         }                                                       \
     } while (0)
     if (rp.method == ELM_P2P) { if (m.grid_tiled) ELM_LAUNCH_G(ELM_P2P, 0, 1); else ELM_LAUNCH_G(ELM_P2P, 0, 0); }
+    else if (m.gicp_compact == 2) { if (m.grid_tiled) ELM_LAUNCH_G(ELM_GICP, 2, 1); else ELM_LAUNCH_G(ELM_GICP, 2, 0); }
     else if (m.gicp_compact) { if (m.grid_tiled) ELM_LAUNCH_G(ELM_GICP, 1, 1); else ELM_LAUNCH_G(ELM_GICP, 1, 0); }
     else { if (m.grid_tiled) ELM_LAUNCH_G(ELM_GICP, 0, 1); else ELM_LAUNCH_G(ELM_GICP, 0, 0); }
 #undef ELM_LAUNCH_G
@@ -3374,7 +3423,11 @@ void launch_accumulate_vnbr(hipStream_t s, const DevMap& m, const ScanDesc* scan
             else ELM_LAUNCH_VF(M, C, 0, 0);                                        \
         }                                                                          \
     } while (0)
-    if (rp.method == ELM_VGICP) { if (m.vox_compact) ELM_LAUNCH_V(ELM_VGICP, 1); else ELM_LAUNCH_V(ELM_VGICP, 0); }
+    if (rp.method == ELM_VGICP) {
+        if (m.vox_compact == 2) ELM_LAUNCH_V(ELM_VGICP, 2);
+        else if (m.vox_compact) ELM_LAUNCH_V(ELM_VGICP, 1);
+        else ELM_LAUNCH_V(ELM_VGICP, 0);
+    }
     else { if (m.vox_compact) ELM_LAUNCH_V(ELM_AVGICP, 1); else ELM_LAUNCH_V(ELM_AVGICP, 0); }
 #undef ELM_LAUNCH_V
 #undef ELM_LAUNCH_VF

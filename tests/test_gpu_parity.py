@@ -1155,26 +1155,32 @@ def test_compact_covariance_records_equal_the_stored_inverses(oracle, world100k,
         assert ref["iterations"] == r["iterations"] and dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
 
 
-def test_avgicp_walk_forms_agree(oracle, world100k, monkeypatch):
-    """AVGICP on a map whose every voxel is of the compact form gathers sum w and sum (w k) n n^T per point (six entries, fused)
-    instead of nine entries of w C^-1 per pair; ELM_AVG_NINE=1 (read when the neighbourhoods are built) keeps the nine-entry walk.
-    Same pairs, the same sums to the sum tolerance on every iteration, and the oracle's pose."""
+@pytest.mark.parametrize("method,env", [(1, "ELM_PAIR_NINE"), (2, "ELM_PAIR_NINE"), (3, "ELM_PAIR_NINE"), (3, "ELM_AVG_NINE")])
+def test_fused_compact_pairs_agree_with_the_nine_entry_form(oracle, world100k, method, env, monkeypatch):
+    """On a map whose every covariance is of the compact form the kernels never form C^-1 = I + k n n^T: GICP / VGICP gather
+    A = w I + (w k) n n^T and b = w e + (w k)(n . e) n fused, AVGICP gathers sum w and sum (w k) n n^T per point (six entries)
+    instead of nine entries of w C^-1 per pair.  ELM_PAIR_NINE=1 (read at map build; ELM_AVG_NINE=1: AVGICP's walk alone) keeps
+    the nine-entry forms.  Same pairs, the same sums to the sum tolerance on every iteration, and the oracle's pose."""
     from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, VoxelHashMap
+    m = IcpMethod(method)
     scan, Tt = synth.make_scan(world100k, 8000, seed=5151)
     T0 = synth.perturb(Tt, seed=5152, max_trans=0.3, max_rot_deg=1.0)
     runs = {}
-    for mode in ("six", "nine"):
+    for mode in ("fused", "nine"):
         if mode == "nine":
-            monkeypatch.setenv("ELM_AVG_NINE", "1")
+            monkeypatch.setenv(env, "1")
         c = Context(0)
         try:
             vm = VoxelHashMap(1.0, 30, c)
             vm.AddPoints(world100k)
-            vm.CalVoxelCovAll()
-            runs[mode] = Registration(RegistrationConfig(icp_method=IcpMethod.AVGICP), c).RunRegister(scan, vm, T0, trace=True)[-1]
+            if m == IcpMethod.GICP:
+                vm.CalPointCovAll(0.4)
+            else:
+                vm.CalVoxelCovAll()
+            runs[mode] = Registration(RegistrationConfig(icp_method=m), c).RunRegister(scan, vm, T0, trace=True)[-1]
         finally:
             c.close()
-    a, b = runs["six"], runs["nine"]
+    a, b = runs["fused"], runs["nine"]
     assert a["iterations"] == b["iterations"] and a["is_success"] == b["is_success"]
     for ia, ib in zip(a["iters"], b["iters"]):
         assert ia["n_corr"] == ib["n_corr"]
@@ -1183,8 +1189,11 @@ def test_avgicp_walk_forms_agree(oracle, world100k, monkeypatch):
         np.testing.assert_allclose(ia["residual_sum"], ib["residual_sum"], rtol=SUM_RTOL)
     om = oracle.Map(1.0, 30)
     om.add_points(world100k)
-    om.cal_voxel_cov_all()
-    ref = oracle.register(om, scan, T0, oracle.default_config(3))
+    if m == IcpMethod.GICP:
+        om.cal_point_cov_all(0.4)
+    else:
+        om.cal_voxel_cov_all()
+    ref = oracle.register(om, scan, T0, oracle.default_config(method))
     for r in (a, b):
         dt, dr = synth.pose_error(ref["T"], r["T"])
         assert ref["iterations"] == r["iterations"] and dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
