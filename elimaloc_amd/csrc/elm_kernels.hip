@@ -837,9 +837,10 @@ __device__ __forceinline__ void pair_sum_zero(PairSum& P) {
 // entry (i, j) of A * (-[a]x)
 template <int I, int J>
 __device__ __forceinline__ double pair_ab(const PairSum& P) {
-    if (J == 0) return P.A[I * 3 + 2] * P.ay - P.A[I * 3 + 1] * P.az;
-    if (J == 1) return P.A[I * 3 + 0] * P.az - P.A[I * 3 + 2] * P.ax;
-    return P.A[I * 3 + 1] * P.ax - P.A[I * 3 + 0] * P.ay;
+    // (x y - z w as fma(x, y, -(z w)): one rounding less than add_pair_world's two products and a difference, one instruction less)
+    if (J == 0) return __builtin_fma(P.A[I * 3 + 2], P.ay, -(P.A[I * 3 + 1] * P.az));
+    if (J == 1) return __builtin_fma(P.A[I * 3 + 0], P.az, -(P.A[I * 3 + 2] * P.ax));
+    return __builtin_fma(P.A[I * 3 + 1], P.ax, -(P.A[I * 3 + 0] * P.ay));
 }
 template <int K>
 __device__ __forceinline__ double pair_sum_value(const PairSum& P) {
@@ -858,18 +859,18 @@ __device__ __forceinline__ double pair_sum_value(const PairSum& P) {
     if (K == tri(2, 3)) return pair_ab<2, 0>(P);
     if (K == tri(2, 4)) return pair_ab<2, 1>(P);
     if (K == tri(2, 5)) return pair_ab<2, 2>(P);
-    if (K == tri(3, 3)) return P.ay * pair_ab<2, 0>(P) - P.az * pair_ab<1, 0>(P);
-    if (K == tri(3, 4)) return P.ay * pair_ab<2, 1>(P) - P.az * pair_ab<1, 1>(P);
-    if (K == tri(3, 5)) return P.ay * pair_ab<2, 2>(P) - P.az * pair_ab<1, 2>(P);
-    if (K == tri(4, 4)) return P.az * pair_ab<0, 1>(P) - P.ax * pair_ab<2, 1>(P);
-    if (K == tri(4, 5)) return P.az * pair_ab<0, 2>(P) - P.ax * pair_ab<2, 2>(P);
-    if (K == tri(5, 5)) return P.ax * pair_ab<1, 2>(P) - P.ay * pair_ab<0, 2>(P);
+    if (K == tri(3, 3)) return __builtin_fma(P.ay, pair_ab<2, 0>(P), -(P.az * pair_ab<1, 0>(P)));
+    if (K == tri(3, 4)) return __builtin_fma(P.ay, pair_ab<2, 1>(P), -(P.az * pair_ab<1, 1>(P)));
+    if (K == tri(3, 5)) return __builtin_fma(P.ay, pair_ab<2, 2>(P), -(P.az * pair_ab<1, 2>(P)));
+    if (K == tri(4, 4)) return __builtin_fma(P.az, pair_ab<0, 1>(P), -(P.ax * pair_ab<2, 1>(P)));
+    if (K == tri(4, 5)) return __builtin_fma(P.az, pair_ab<0, 2>(P), -(P.ax * pair_ab<2, 2>(P)));
+    if (K == tri(5, 5)) return __builtin_fma(P.ax, pair_ab<1, 2>(P), -(P.ay * pair_ab<0, 2>(P)));
     if (K == 21) return P.b[0];
     if (K == 22) return P.b[1];
     if (K == 23) return P.b[2];
-    if (K == 24) return P.ay * P.b[2] - P.az * P.b[1];
-    if (K == 25) return P.az * P.b[0] - P.ax * P.b[2];
-    if (K == 26) return P.ax * P.b[1] - P.ay * P.b[0];
+    if (K == 24) return __builtin_fma(P.ay, P.b[2], -(P.az * P.b[1]));
+    if (K == 25) return __builtin_fma(P.az, P.b[0], -(P.ax * P.b[2]));
+    if (K == 26) return __builtin_fma(P.ax, P.b[1], -(P.ay * P.b[0]));
     if (K == 27) return P.rsum;
     if (K == 28) return P.n;
     if (K == 29) return P.c29;

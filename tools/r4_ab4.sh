@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B: GICP / VGICP pairs gathered fused on all-compact maps (fused) against the nine-entry form (six = the build before); gpu suite
+# A/B: fused multiply-adds in the block reduction's expansion of the pair sums (fma) against products and differences (fused = the build before); gpu suite
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 mkdir -p gpurun_out
@@ -11,7 +11,7 @@ r = json.load(open(sys.argv[3])); f = r["roofline"]
 print("%-6s %-7s %8.0f reg/s  launch %.4f ms" % (sys.argv[1], sys.argv[2], r["value"], f["avg_launch_ms"]), flush=True)
 PY
 }
-for L in six fused six fused six fused; do one $L gicp --method 1; done
-for L in six fused six fused; do one $L vg --method 2; done
-for L in six fused; do one $L avg --method 3; done
+for L in fused fma fused fma; do one $L gicp --method 1; done
+for L in fused fma fused fma; do one $L vg --method 2; done
+for L in fused fma fused fma; do one $L avg --method 3; done
 python -m pytest tests -q -m gpu > gpurun_out/z.pytest 2>&1; tail -3 gpurun_out/z.pytest; grep -n "^FAILED" gpurun_out/z.pytest | head
