@@ -871,7 +871,8 @@ static int build_voxel_neighbourhoods(elm_map* m) {
         if (e2_ != hipSuccess) { face_cleanup(); VN_CHK(e2_); }                               \
     } while (0)
             (void)hipGetLastError();
-            launch_vface(ctx->stream, m->d_vnbr, d_off, d_nocc, n_q, d_fcnt, nullptr, nullptr);
+            const int plain = (m->dm.vox_compact && m->n_bad_vox == 0 && !std::getenv("ELM_AVG_NINE") && !std::getenv("ELM_PAIR_NINE")) ? 1 : 0;
+            launch_vface(ctx->stream, m->d_vnbr, d_off, d_nocc, n_q, d_fcnt, nullptr, nullptr, plain);
             VF_CHK(hipGetLastError());
             VF_CHK(hipStreamSynchronize(ctx->stream));
             std::vector<uint32_t> fcnt(n_q), foff(n_q);
@@ -881,7 +882,7 @@ static int build_voxel_neighbourhoods(elm_map* m) {
             if (ftotal < (1ull << 29)) {
                 VF_CHK(hipMemcpy(d_foff, foff.data(), (size_t)n_q * sizeof(uint32_t), hipMemcpyHostToDevice));
                 VF_CHK(hipMalloc((void**)&m->d_vface, std::max<size_t>((size_t)ftotal * sizeof(VoxRec), 256)));
-                launch_vface(ctx->stream, m->d_vnbr, d_off, d_nocc, n_q, d_fcnt, d_foff, m->d_vface);
+                launch_vface(ctx->stream, m->d_vnbr, d_off, d_nocc, n_q, d_fcnt, d_foff, m->d_vface, plain);
                 VF_CHK(hipGetLastError());
                 VF_CHK(hipStreamSynchronize(ctx->stream));
                 std::fill(dense.begin(), dense.end(), 0u);
@@ -894,7 +895,7 @@ static int build_voxel_neighbourhoods(elm_map* m) {
                 VF_CHK(hipMemcpy(m->d_vqf_dense, dense.data(), vcells * sizeof(uint32_t), hipMemcpyHostToDevice));
                 m->dm.vface = m->d_vface;
                 m->dm.vqf_dense = m->d_vqf_dense;
-                m->dm.vface_plain = (m->dm.vox_compact && m->n_bad_vox == 0 && !std::getenv("ELM_AVG_NINE") && !std::getenv("ELM_PAIR_NINE")) ? 1 : 0;
+                m->dm.vface_plain = plain;
                 m->info.device_bytes += vcells * sizeof(uint32_t) + (size_t)ftotal * sizeof(VoxRec);
                 m->info.index_bytes += vcells * sizeof(uint32_t) + (size_t)ftotal * sizeof(VoxRec);
             }

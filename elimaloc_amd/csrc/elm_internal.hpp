@@ -237,7 +237,7 @@ void launch_accumulate_vnbr(hipStream_t s, const DevMap& m, const ScanDesc* scan
 void launch_vnbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets, VoxRec* out, GridBlk* out_blk);
 // face-neighbour sublists of the voxel-mean lists: counts (out == nullptr) or the records at face_off
 void launch_vface(hipStream_t s, const VoxRec* vnbr, const uint32_t* offsets, const uint32_t* counts, uint32_t n_q, uint32_t* face_cnt,
-                  const uint32_t* face_off, VoxRec* out);
+                  const uint32_t* face_off, VoxRec* out, int plain);
 void launch_accumulate_cell(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                             ScanState* st, double* partials, const RegParams& rp);
 int stream_max_slots(); // slots one elm_register_stream call can iterate concurrently

@@ -109,6 +109,16 @@ __device__ __forceinline__ double div_normal(double a, double b) {
     const double r = __builtin_fma(-b, q, a);
     return __builtin_fma(r, y, q);
 }
+// the same without the final residual correction: within an ulp or two of a / b (the weights of the fused pair forms, which are
+// not bit-for-bit restatements of the reference's arithmetic anyway)
+__device__ __forceinline__ double div_close(double a, double b) {
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    return a * y;
+}
 
 // Adds one (source point, target) pair to the thread's packed sums.
 //   acc[0..20] upper JTJ, acc[21..26] JTr, acc[27] residual sum, acc[28] pair count
@@ -2378,12 +2388,11 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
                     const double d2 = (ex * ex + ey * ey) + ez * ez;
                     if (d2 < rp.th2) {
                         const double den = rp.th + d2;
-                        const double w = div_normal(rp.th2, den * den); // square(th) / square(th + |r|^2)
+                        const double w = div_close(rp.th2, den * den); // square(th) / square(th + |r|^2)
                         Q.n += 1.0;
                         if (!(w < 0.01)) { // reg.cpp:201 -- skipped pairs stay in the fitness denominator
-                            const bool ident = r1.y == 2.0; // identity covariance: k = 0 (its stored normal is (2, 0, 0))
-                            const double nx = ident ? 1.0 : r1.y, ny = r2.x, nz = r2.y;
-                            const double wk = ident ? 0.0 : w * kCompactK;
+                            const double nx = r1.y, ny = r2.x, nz = r2.y; // (identity covariance: the zero normal, k_vface)
+                            const double wk = w * kCompactK;
                             const double sn = wk * __builtin_fma(nz, ez, __builtin_fma(ny, ey, nx * ex));
                             Q.b[0] = __builtin_fma(sn, nx, __builtin_fma(w, ex, Q.b[0]));
                             Q.b[1] = __builtin_fma(sn, ny, __builtin_fma(w, ey, Q.b[1]));
@@ -3439,7 +3448,7 @@ __device__ __forceinline__ bool is_face_code(int code) {
 }
 __global__ __launch_bounds__(256) void k_vface(const VoxRec* __restrict__ vnbr, const uint32_t* __restrict__ offsets,
                                                const uint32_t* __restrict__ counts, unsigned n_q, uint32_t* __restrict__ face_cnt,
-                                               const uint32_t* __restrict__ face_off, VoxRec* __restrict__ out) {
+                                               const uint32_t* __restrict__ face_off, VoxRec* __restrict__ out, int plain) {
     const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n_q) return;
     const VoxRec* lp = vnbr + offsets[q];
@@ -3451,7 +3460,9 @@ __global__ __launch_bounds__(256) void k_vface(const VoxRec* __restrict__ vnbr, 
         // the first 48 bytes tell the three kinds of record apart (k_accumulate_vnbr<AVGICP> loads only those in the common case):
         //   k = kCompactK (regularised covariance): the unit normal as it is;  k = 0 (identity): n.x = 2 (not a unit vector);
         //   anything else (k = NaN: outside the compact form, or another k): n.x = NaN -> the stored inverse is read
-        if (r.k == 0.0) r.nx = 2.0;
+        // plain (DevMap::vface_plain: no voxel outside the compact form, the fused walk): an identity covariance is written as the ZERO
+        // normal -- I + 999 * 0 0^T -- so that walk treats every record alike
+        if (r.k == 0.0) { r.nx = plain ? 0.0 : 2.0; if (plain) r.ny = r.nz = 0.0; }
         else if (!(fabs(r.k - kCompactK) <= 1e-7)) r.nx = __builtin_nan("");
         if (out) out[o + n] = r;
         ++n;
@@ -3459,8 +3470,8 @@ __global__ __launch_bounds__(256) void k_vface(const VoxRec* __restrict__ vnbr, 
     if (!out) face_cnt[q] = n;
 }
 void launch_vface(hipStream_t s, const VoxRec* vnbr, const uint32_t* offsets, const uint32_t* counts, uint32_t n_q, uint32_t* face_cnt,
-                  const uint32_t* face_off, VoxRec* out) {
-    if (n_q) hipLaunchKernelGGL(k_vface, dim3((n_q + 255) / 256), dim3(256), 0, s, vnbr, offsets, counts, n_q, face_cnt, face_off, out);
+                  const uint32_t* face_off, VoxRec* out, int plain) {
+    if (n_q) hipLaunchKernelGGL(k_vface, dim3((n_q + 255) / 256), dim3(256), 0, s, vnbr, offsets, counts, n_q, face_cnt, face_off, out, plain);
 }
 void launch_vnbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets, VoxRec* out, GridBlk* out_blk) {
     hipLaunchKernelGGL(k_vnbr_fill, dim3((n_q + 255) / 256), dim3(256), 0, s, m, qkeys, n_q, offsets, out, out_blk);
