@@ -71,6 +71,9 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+#ifndef ELM_P2P_FUSED
+#define ELM_P2P_FUSED 1 // pair_p2p with fused multiply-adds (0: the reference's products and sums, one rounding each)
+#endif
 constexpr double kCompactK = 999.0; // 1 / 1e-3 - 1: the k of U diag(1, 1, 1e-3) U^T (vhm.hpp:143, 243)
 // inverse covariance I + k n n^T from the compact records (DevMap::grid_gicp8, VoxRec)
 __device__ __forceinline__ void compact_cinv(double nx, double ny, double nz, double k, double* Ci) {
@@ -988,18 +991,32 @@ __device__ __forceinline__ void pair_sum_compact(PairSum& P, double ex, double e
 constexpr int kP2PVals = 21; // 18 sums + the three work counters
 __device__ __forceinline__ void pair_p2p(double* v, const double* Rinv, double px, double py, double pz, double ex, double ey, double ez,
                                          double d2, const RegParams& rp) {
+#if ELM_P2P_FUSED
+    // (the rotation of e and the cross product with fused multiply-adds, the weight without the division's last correction: eleven
+    // float64 instructions less per pair, the sums the same to the last bit or two)
+    const double rx = __builtin_fma(Rinv[2], ez, __builtin_fma(Rinv[1], ey, Rinv[0] * ex));
+    const double ry = __builtin_fma(Rinv[5], ez, __builtin_fma(Rinv[4], ey, Rinv[3] * ex));
+    const double rz = __builtin_fma(Rinv[8], ez, __builtin_fma(Rinv[7], ey, Rinv[6] * ex));
+    const double den = rp.th + d2;
+    const double w = div_close(rp.th2, den * den); // square(th) / square(th + |r|^2)  (reg.cpp:38-39)
+#else
     const double rx = (Rinv[0] * ex + Rinv[1] * ey) + Rinv[2] * ez;
     const double ry = (Rinv[3] * ex + Rinv[4] * ey) + Rinv[5] * ez;
     const double rz = (Rinv[6] * ex + Rinv[7] * ey) + Rinv[8] * ez;
     const double den = rp.th + d2;
     const double w = div_normal(rp.th2, den * den); // square(th) / square(th + |r|^2)  (reg.cpp:38-39)
+#endif
     const double wx = w * px, wy = w * py, wz = w * pz;
     const double ax = w * rx, ay = w * ry, az = w * rz;
     v[0] = w;
     v[1] = wx; v[2] = wy; v[3] = wz;
     v[4] = wx * px; v[5] = wx * py; v[6] = wx * pz; v[7] = wy * py; v[8] = wy * pz; v[9] = wz * pz;
     v[10] = ax; v[11] = ay; v[12] = az;
+#if ELM_P2P_FUSED
+    v[13] = __builtin_fma(py, az, -(pz * ay)); v[14] = __builtin_fma(pz, ax, -(px * az)); v[15] = __builtin_fma(px, ay, -(py * ax));
+#else
     v[13] = py * az - pz * ay; v[14] = pz * ax - px * az; v[15] = px * ay - py * ax;
+#endif
     v[16] = sqrt_dist2(d2);
     v[17] = 1.0;
 }

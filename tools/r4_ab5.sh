@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B: AVGICP identity records as zero normals + weight without the division's last correction (zn) against the build before (fma); gpu suite
+# A/B: pair_p2p with fused multiply-adds (pf) against the build before (zn); gpu suite
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 mkdir -p gpurun_out
@@ -11,5 +11,6 @@ r = json.load(open(sys.argv[3])); f = r["roofline"]
 print("%-6s %-7s %8.0f reg/s  launch %.4f ms" % (sys.argv[1], sys.argv[2], r["value"], f["avg_launch_ms"]), flush=True)
 PY
 }
-for L in fma zn fma zn; do one $L avg --method 3; done
+for L in zn pf zn pf zn pf; do one $L easy; done
+for L in zn pf; do one $L hard --guess hard --steps 6; done
 python -m pytest tests -q -m gpu > gpurun_out/z.pytest 2>&1; tail -3 gpurun_out/z.pytest; grep -n "^FAILED" gpurun_out/z.pytest | head
