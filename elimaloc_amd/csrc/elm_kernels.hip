@@ -963,8 +963,8 @@ template <int METHOD>
 __device__ __forceinline__ void pair_sum_compact(PairSum& P, double ex, double ey, double ez, double nx, double ny, double nz, double k, const RegParams& rp) {
     const double r2 = (ex * ex + ey * ey) + ez * ez;
     const double den = rp.th + r2;
-    double w = div_normal(rp.th2, den * den); // square(th) / square(th + |r|^2)
-    if (METHOD == ELM_GICP) w = w * 0.8 + 0.2;
+    double w = div_close(rp.th2, den * den); // square(th) / square(th + |r|^2)
+    if (METHOD == ELM_GICP) w = __builtin_fma(w, 0.8, 0.2);
     P.n = 1.0;
     if (METHOD == ELM_VGICP || METHOD == ELM_AVGICP) {
         if (w < 0.01) return; // reg.cpp:201 -- skipped pairs stay in the fitness denominator
@@ -979,7 +979,7 @@ __device__ __forceinline__ void pair_sum_compact(PairSum& P, double ex, double e
     P.b[0] = __builtin_fma(sn, nx, w * ex);
     P.b[1] = __builtin_fma(sn, ny, w * ey);
     P.b[2] = __builtin_fma(sn, nz, w * ez);
-    if (METHOD == ELM_GICP) P.rsum = fabs((ex * nx + ey * ny) + ez * nz); // |r_l . n_l| (reg.cpp:91-95, 128), pair_sum_single's arithmetic
+    if (METHOD == ELM_GICP) P.rsum = fabs(ne); // |r_l . n_l| (reg.cpp:91-95, 128)
     else P.rsum = sqrt_dist2(r2);
 }
 
