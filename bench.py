@@ -462,7 +462,7 @@ def main():
     # vector-memory front end.  Without a matching pass the line falls back to the HBM stream.
     clock_ghz = 2.4  # MI355X_MICROARCH.md: max clock
     simd_cycles = 1024 * clock_ghz  # G SIMD-cycles/s over the chip (256 CUs x 4 SIMDs)
-    issue_cycles = {"k_accumulate_grid<P2P>": 3.78, "k_accumulate_grid<GICP>": 3.81, "k_accumulate_vnbr<VGICP>": 3.89, "k_accumulate_vnbr<AVGICP>": 3.90}  # profiles/r04_valu_mix.txt
+    issue_cycles = {"k_accumulate_grid<P2P>": 3.78, "k_accumulate_grid<GICP>": 3.78, "k_accumulate_vnbr<VGICP>": 3.85, "k_accumulate_vnbr<AVGICP>": 3.86}  # profiles/r04_valu_mix.txt
     roofline = dict(hbm)
     roofline["bound"] = "hbm"
     vb = None
