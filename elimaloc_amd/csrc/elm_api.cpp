@@ -704,7 +704,7 @@ extern "C" int elm_map_cal_voxel_cov_all(elm_map* m) {
     m->n_bad_vox = bad;
     m->dm.vox_compact = full_records_forced() ? 0 : ((bad == 0 && !std::getenv("ELM_PAIR_NINE")) ? 2 : 1); // 2: no flagged voxel at all
     m->info.has_voxel_cov = 1;
-    m->info.layout_flags = (m->info.layout_flags & ~2) | (m->dm.vox_compact ? 2 : 0);
+    m->info.layout_flags = (m->info.layout_flags & ~(2 | 16)) | (m->dm.vox_compact ? 2 : 0) | (m->dm.vox_compact == 2 ? 16 : 0);
     return ELM_OK;
 }
 
@@ -935,7 +935,7 @@ static int refresh_grid_gicp(elm_map* m) {
     // 2: no point outside the compact form -- the kernel has no full-record fallback and gathers the pair fused (ELM_PAIR_NINE=1: the
     // nine-entry form with its fallback, as for maps with flagged points)
     m->dm.gicp_compact = compact ? ((m->n_bad_pts == 0 && !std::getenv("ELM_PAIR_NINE")) ? 2 : 1) : 0;
-    m->info.layout_flags = (m->info.layout_flags & ~1) | (compact ? 1 : 0);
+    m->info.layout_flags = (m->info.layout_flags & ~(1 | 8)) | (compact ? 1 : 0) | (m->dm.gicp_compact == 2 ? 8 : 0);
     return ELM_OK;
 }
 

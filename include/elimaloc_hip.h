@@ -112,7 +112,10 @@ typedef struct elm_map_info {
     int32_t layout_flags; /* bit 0: GICP payload as 64-byte {mean, normal, k} records (a point covariance of the form I - 0.999 n n^T
                            * has its inverse rebuilt as I + k n n^T; a point outside that form is flagged and reads its stored inverse),
                            * bit 1: the same for the voxel covariances of VGICP / AVGICP (clear: ELM_COV_RECORDS=full, all stored inverses),
-                           * bit 2: the P2P / GICP cell grid is the two-level (tiled) form (box too large / sparse for one dense table) */
+                           * bit 2: the P2P / GICP cell grid is the two-level (tiled) form (box too large / sparse for one dense table),
+                           * bit 3: no point covariance is flagged: GICP runs the kernels without the stored-inverse fallback and gathers its
+                           *        pair fused, A = w I + (w k) n n^T (clear with ELM_PAIR_NINE=1 at map build: nine entries of w C^-1),
+                           * bit 4: the same for the voxel covariances (VGICP's pair; AVGICP gathers sum w and sum (w k) n n^T per point) */
     uint64_t device_bytes;
     uint64_t n_query_voxels; /* cell grid: voxels of the dense statistics box; neighbourhood lists: query voxels (0 until built) */
     uint64_t nbr_entries;    /* cell grid: == n_points (every map point once); neighbourhood lists: ~27 x n_points */

@@ -1178,6 +1178,8 @@ def test_fused_compact_pairs_agree_with_the_nine_entry_form(oracle, world100k, m
             else:
                 vm.CalVoxelCovAll()
             runs[mode] = Registration(RegistrationConfig(icp_method=m), c).RunRegister(scan, vm, T0, trace=True)[-1]
+            if env == "ELM_PAIR_NINE":  # layout bits 3 / 4: the fused kernels are what ran (the jittered world has no flagged covariance)
+                assert bool(int(vm.info().layout_flags) & (8 if m == IcpMethod.GICP else 16)) == (mode == "fused")
         finally:
             c.close()
     a, b = runs["fused"], runs["nine"]
