@@ -124,7 +124,7 @@ struct elm_ctx {
     hipEvent_t ev_iter[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ev_groups; // host-fed streams: per upload group its "copied" and "ordered" events
     uint16_t* d_hilbert = nullptr; // Hilbert index of every cell of the ordering grid (kOrderCells^2 entries)
-    DevBuf d_order_jobs, d_order_tmp, d_arena, d_raw, d_tickets, d_prev;
+    DevBuf d_order_jobs, d_order_tmp, d_arena, d_raw, d_tickets, d_prev, d_flagged;
     bool prev_winner = false; // ELM_PREV_WINNER=1 (with a library built with -DELM_PREV_WINNER=1): the grid kernels keep every point's previous winner
     bool work_counters = false; // elm_ctx_set_work_counters / ELM_WORK_COUNTERS=1: the accumulate launches also sum the work counters of
                                 // elm_reg_result (n_cand_total, n_occ_total, n_tested_total, fallback_blocks); off: those fields read 0
@@ -340,7 +340,7 @@ extern "C" void elm_ctx_destroy(elm_ctx* ctx) {
     if (ctx->d_hilbert) (void)hipFree(ctx->d_hilbert);
     if (ctx->h_jobs) (void)hipHostFree(ctx->h_jobs);
     DevBuf* bufs[] = {&ctx->d_scans, &ctx->d_state, &ctx->d_partials, &ctx->d_sums, &ctx->d_T0, &ctx->d_trace, &ctx->d_stage_pts, &ctx->d_active, &ctx->d_queue, &ctx->d_ds,
-                      &ctx->d_order_jobs, &ctx->d_order_tmp, &ctx->d_arena, &ctx->d_raw, &ctx->d_tickets, &ctx->d_prev};
+                      &ctx->d_order_jobs, &ctx->d_order_tmp, &ctx->d_arena, &ctx->d_raw, &ctx->d_tickets, &ctx->d_prev, &ctx->d_flagged};
     if (ctx->h_active) (void)hipHostFree(ctx->h_active);
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -871,7 +871,11 @@ static int build_voxel_neighbourhoods(elm_map* m) {
         if (e2_ != hipSuccess) { face_cleanup(); VN_CHK(e2_); }                               \
     } while (0)
             (void)hipGetLastError();
-            const int plain = (m->dm.vox_compact && m->n_bad_vox == 0 && !std::getenv("ELM_AVG_NINE") && !std::getenv("ELM_PAIR_NINE")) ? 1 : 0;
+            // the fused AVGICP walk's record format; flagged voxels (NaN normals) are left to its fix-up launch (ELM_AVG_FIXUP=0: such maps
+            // keep the nine-entry walk with its in-line fallback)
+            const char* fx = std::getenv("ELM_AVG_FIXUP");
+            const bool fixup_ok = !(fx && strcmp(fx, "0") == 0);
+            const int plain = (m->dm.vox_compact && (m->n_bad_vox == 0 || fixup_ok) && !std::getenv("ELM_AVG_NINE") && !std::getenv("ELM_PAIR_NINE")) ? 1 : 0;
             launch_vface(ctx->stream, m->d_vnbr, d_off, d_nocc, n_q, d_fcnt, nullptr, nullptr, plain);
             VF_CHK(hipGetLastError());
             VF_CHK(hipStreamSynchronize(ctx->stream));
@@ -896,6 +900,8 @@ static int build_voxel_neighbourhoods(elm_map* m) {
                 m->dm.vface = m->d_vface;
                 m->dm.vqf_dense = m->d_vqf_dense;
                 m->dm.vface_plain = plain;
+                m->dm.vface_flagged = (plain && m->n_bad_vox != 0) ? ((fx && strcmp(fx, "skip") == 0) ? 2 : 1) : 0; // (2: tests only -- no fix-up launch, the flagged pairs are dropped)
+                m->info.layout_flags = (m->info.layout_flags & ~(32 | 64)) | (plain ? 32 : 0) | (m->dm.vface_flagged ? 64 : 0);
                 m->info.device_bytes += vcells * sizeof(uint32_t) + (size_t)ftotal * sizeof(VoxRec);
                 m->info.index_bytes += vcells * sizeof(uint32_t) + (size_t)ftotal * sizeof(VoxRec);
             }
@@ -1765,6 +1771,20 @@ static int enqueue_accumulate(elm_ctx* ctx, const elm_map* map, const ScanDesc* 
         if (rp.radar) launch_accumulate_radar(ctx->stream, map->dm, dsc, n_scans, (int)blocks, st, partials, rp);
         else if (use_grid) launch_accumulate_grid(ctx->stream, map->dm, dsc, n_scans, (int)blocks, st, partials, rp);
         else if (use_cells) launch_accumulate_cell(ctx->stream, map->dm, dsc, n_scans, (int)blocks, st, partials, rp);
+        else if (use_vnbr && rp.method == ELM_AVGICP && map->dm.vface_flagged && !rp.tickets) {
+            // the fused walk on a map with flagged voxels: one flag per workgroup (all zero between launches: the fix-up launch clears what
+            // the walk sets).  Not while a graph is being captured (no allocation there): the launcher then takes the nine-entry walk.
+            RegParams rq = rp;
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(ctx->stream, &cs);
+            const size_t need = (size_t)blocks * sizeof(uint32_t);
+            if (cs == hipStreamCaptureStatusNone && need > ctx->d_flagged.cap) {
+                if ((rc = dev_reserve(ctx, ctx->d_flagged, need + need / 2)) != ELM_OK) return rc;
+                HIPCHK(ctx, hipMemsetAsync(ctx->d_flagged.p, 0, ctx->d_flagged.cap, ctx->stream));
+            }
+            rq.flagged = (need <= ctx->d_flagged.cap) ? (uint32_t*)ctx->d_flagged.p : nullptr;
+            launch_accumulate_vnbr(ctx->stream, map->dm, dsc, n_scans, (int)blocks, st, partials, rq);
+        }
         else if (use_vnbr) launch_accumulate_vnbr(ctx->stream, map->dm, dsc, n_scans, (int)blocks, st, partials, rp);
         else launch_accumulate_direct(ctx->stream, map->dm, dsc, n_scans, (int)blocks, st, partials, rp);
     }

@@ -112,8 +112,10 @@ struct DevMap {
                                 // record is read from pt_gicp by the index in word 7); 2: the same and no point is flagged -- the kernel
                                 // instantiation without the fallback, its pair gathered fused (pair_sum_compact)
     int32_t vox_compact;        // 1: the VoxRec's own normal / k are used (k = NaN: vox_cinv[vid] is read for that voxel); 2: no voxel flagged
-    int32_t vface_plain;        // 1: every face-sublist record is of the compact form or the identity (no voxel outside it in this map): the
-                                // AVGICP walk gathers sum w and sum (w k) n n^T instead of nine entries per pair
+    int32_t vface_plain;        // 1: the face sublists are written for the fused AVGICP walk (identity covariances as zero normals), which gathers
+                                // sum w and sum (w k) n n^T instead of nine entries per pair
+    int32_t vface_flagged;      // 1: some voxel of this map is outside the compact form (its records carry NaN in the normal): the fused walk
+                                // skips those pairs and a fix-up launch adds them (RegParams::flagged)
     int32_t gx0, gy0, gz0;      // cell coordinates of grid entry (0, 0, 0)
     int32_t gnx, gny, gnz;
     // dense voxel box of the floor keys a query can have near the map: cnt27 | nocc27 << 16 of the reference's 27-voxel walk
@@ -202,6 +204,9 @@ struct RegParams {
     // sums[scan][32] -- no reduce launch; nullptr: the accumulate kernels only write partials, k_solve reduces (developer A/B)
     double* sums;
     int32_t* tickets;
+    uint32_t* flagged;   // [workgroups] AVGICP on a map with flagged voxels: set by a workgroup of the fused walk that met (and skipped) a flagged
+                         // record, read and cleared by the fix-up launch that adds those pairs to the workgroup's partial record (nullptr: the
+                         // map runs the nine-entry walk with its fallback instead)
     uint32_t* prev;      // [workgroups * kBlock] the winner (grid slot number, -1: none) of every scan point in the slot's previous iteration:
                          // bounds the exact search of the next one (k_accumulate_grid); nullptr: not kept
     double radar_var[3]; // range_variance_m, azimuth_variance_deg, elevation_variance_deg (reg.hpp:77-79)

@@ -2257,6 +2257,11 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
     if (L >= sd.blk_end) return; // a scan whose size was only known on the device owns fewer workgroups than were launched for it
     const unsigned i = (L - sd.blk_begin) * kBlock + threadIdx.x;
     const bool valid = i < sd.n;
+    if (FACES == 3) { // the fix-up launch: only workgroups whose fused walk met a flagged record have anything to add
+        if (rp.flagged[L] == 0u) return; // (uniform)
+        __syncthreads();
+        if (threadIdx.x == 0) rp.flagged[L] = 0u; // ready for the next iteration
+    }
     PairSum P;
     pair_sum_zero(P);
     if (valid) {
@@ -2404,6 +2409,10 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
                     const double ex = r0.x - gx, ey = r0.y - gy, ez = r1.x - gz;
                     const double d2 = (ex * ex + ey * ey) + ez * ez;
                     if (d2 < rp.th2) {
+                        if (r1.y != r1.y) { // a flagged voxel (NaN normal): the fix-up launch adds this pair, with the stored inverse
+                            rp.flagged[L] = 1u; // (only maps with such voxels meet this; they always come with the array)
+                            continue;
+                        }
                         const double den = rp.th + d2;
                         const double w = div_close(rp.th2, den * den); // square(th) / square(th + |r|^2)
                         Q.n += 1.0;
@@ -2425,7 +2434,7 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
                 Q.A[0] = W + M00; Q.A[1] = M01; Q.A[2] = M02;
                 Q.A[3] = M01; Q.A[4] = W + M11; Q.A[5] = M12;
                 Q.A[6] = M02; Q.A[7] = M12; Q.A[8] = W + M22;
-            } else if (COMPACT && FACES) {
+            } else if (COMPACT && FACES) { // (FACES = 3, the fix-up launch: the flagged records alone)
                 // Face sublists, compact records: 48 of the record's 64 bytes -- mean and unit normal; k = kCompactK is implied, the other two
                 // kinds are flagged in the normal's first word by k_vface (2: identity covariance, NaN: outside the compact form -> the stored
                 // inverse by the record's voxel id).  Three 16-byte loads per pair instead of four: the walk is a chain of record loads.
@@ -2433,6 +2442,7 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
                     const double2* __restrict__ rp16 = reinterpret_cast<const double2*>(lp + j);
                     const double2 r0 = rp16[0], r1 = rp16[1], r2 = rp16[2]; // (mx, my), (mz, nx), (ny, nz)
                     double Ci[9];
+                    if (FACES == 3 && r1.y == r1.y) continue;
                     if (r1.y == 2.0) {
                         compact_cinv(1.0, 0.0, 0.0, 0.0, Ci);
                     } else if (r1.y == r1.y) {
@@ -2486,10 +2496,14 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
             if (Q.n > 0.0) { // (a point without a pair -- a NaN / infinite return among them -- contributes zeros, not 0 x NaN)
                 P.ax = gx - S.T[12]; P.ay = gy - S.T[13]; P.az = gz - S.T[14];
             }
-            if (STATS) { P.c29 = n_pairs; P.c30 = n_pairs; P.c31 = n_pairs; }
+            if (STATS && FACES != 3) { P.c29 = n_pairs; P.c30 = n_pairs; P.c31 = n_pairs; } // (the fused walk has counted every record)
         }
     }
     block_reduce_pair_sum<kRedPass, STATS ? kSums : kSums - 3>(P, s_buf, s_red);
+    if (FACES == 3) { // added to the record the fused walk of this workgroup wrote earlier on the stream (the solve's reduction comes after both)
+        if (threadIdx.x < (unsigned)kSums - 3u) partials[(size_t)L * kSums + threadIdx.x] += s_red[threadIdx.x];
+        return;
+    }
     publish_and_reduce((threadIdx.x < (STATS ? kSums : kSums - 3)) ? s_red[threadIdx.x] : 0.0, L, s, sd.blk_begin, sd.blk_end, partials, rp, s_buf);
 }
 
@@ -3439,9 +3453,11 @@ void launch_accumulate_vnbr(hipStream_t s, const DevMap& m, const ScanDesc* scan
 #define ELM_LAUNCH_V(M, C)                                                         \
     do {                                                                           \
         const bool faces_ = (M) == ELM_AVGICP && m.vq_dense && m.vqf_dense;        \
-        if (faces_ && (C) && m.vface_plain) {                                      \
+        /* the fused walk; on a map with flagged voxels it needs the workgroup flags and partial records it can add to (no fused reduction) */ \
+        if (faces_ && (C) && m.vface_plain && (!m.vface_flagged || (rp.flagged && !rp.tickets))) { \
             if (rp.stats) ELM_LAUNCH_VF(M, C, 1, ((M) == ELM_AVGICP && (C) ? 2 : 0)); \
             else ELM_LAUNCH_VF(M, C, 0, ((M) == ELM_AVGICP && (C) ? 2 : 0));       \
+            if (m.vface_flagged == 1) ELM_LAUNCH_VF(M, C, 0, ((M) == ELM_AVGICP && (C) ? 3 : 0)); \
         } else if (faces_) {                                                       \
             if (rp.stats) ELM_LAUNCH_VF(M, C, 1, ((M) == ELM_AVGICP ? 1 : 0));     \
             else ELM_LAUNCH_VF(M, C, 0, ((M) == ELM_AVGICP ? 1 : 0));              \

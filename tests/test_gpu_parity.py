@@ -1251,6 +1251,66 @@ def test_rank_deficient_covariances_keep_the_full_records(oracle):
         c.close()
 
 
+def test_avgicp_fused_walk_with_flagged_voxels_fix_up_launch(oracle, monkeypatch):
+    """A map with voxels outside the compact form still runs the fused AVGICP walk: it skips the pairs of flagged voxels (NaN normals in
+    the face sublists), marks its workgroup, and a fix-up launch over the marked workgroups adds those pairs -- with the stored 3x3
+    inverse -- to the workgroup's partial record before the solve reduces it (layout bit 6).  ELM_AVG_FIXUP=0 keeps such maps on the
+    nine-entry walk with its in-line fallback.  Same pairs, same sums to the sum tolerance on every iteration, bit-identical when
+    repeated, and the oracle's trajectory; the stream path (continuous batching) agrees with the single registrations."""
+    from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, VoxelHashMap, Scan
+    # the jittered world (no flagged voxel) + sixty two-point voxels one layer above the ground: rank-1 covariances, whose SVD in the
+    # reference's regularisation returns U != V -- flagged -- and which are the +z face neighbours of the ground points below them
+    rng = np.random.default_rng(5)
+    base = synth.make_world(100000, seed=1001)
+    xy = rng.uniform(-25, 25, (60, 2))
+    c0 = np.column_stack([np.floor(xy[:, 0]) + 0.3, np.floor(xy[:, 1]) + 0.4, np.full(60, 1.35)])
+    c1 = c0 + rng.uniform(0.1, 0.3, (60, 3))
+    world = np.ascontiguousarray(np.concatenate([base, c0.astype(np.float32), c1.astype(np.float32)]).astype(np.float32))
+    scans, T0s = [], []
+    for k in range(3):
+        sc, Tt = synth.make_scan(world, 6000 + 1000 * k, seed=6100 + k)
+        scans.append(sc)
+        T0s.append(synth.perturb(Tt, seed=6200 + k, max_trans=0.2, max_rot_deg=0.8))
+    runs = {}
+    for mode in ("fixup", "inline", "skip"):  # skip: the fused walk WITHOUT its fix-up launch (a test switch): the flagged pairs go missing
+        if mode != "fixup":
+            monkeypatch.setenv("ELM_AVG_FIXUP", "0" if mode == "inline" else "skip")
+        c = Context(0)
+        try:
+            vm = VoxelHashMap(1.0, 30, c)
+            vm.AddPoints(world)
+            vm.CalVoxelCovAll()
+            reg = Registration(RegistrationConfig(icp_method=IcpMethod.AVGICP), c)
+            one = [reg.RunRegister(sc, vm, T0, trace=True)[-1] for sc, T0 in zip(scans, T0s)]
+            again = [reg.RunRegister(sc, vm, T0, trace=True)[-1] for sc, T0 in zip(scans, T0s)]
+            stream = reg.RunRegisterStream([Scan(c, sc) for sc in scans], vm, T0s, slots=2)
+            bits = int(vm.info().layout_flags)
+            assert not bits & 16  # the map does have flagged voxels
+            assert bool(bits & 64) == (mode != "inline"), bits
+            for a, b, st in zip(one, again, stream):
+                assert np.array_equal(a["T"], b["T"]) and a["iterations"] == b["iterations"]  # deterministic
+                assert st["iterations"] == a["iterations"]
+                np.testing.assert_allclose(st["T"], a["T"], rtol=0, atol=1e-9)
+            runs[mode] = one
+        finally:
+            c.close()
+    # the scans do meet flagged voxels, and it is the fix-up launch that supplies their pairs: without it pairs are missing
+    assert any(a["iters"][0]["n_corr"] < b["iters"][0]["n_corr"] for a, b in zip(runs["skip"], runs["inline"]))
+    om = oracle.Map(1.0, 30)
+    om.add_points(world)
+    om.cal_voxel_cov_all()
+    for k, (a, b) in enumerate(zip(runs["fixup"], runs["inline"])):
+        assert a["iterations"] == b["iterations"] and a["is_success"] == b["is_success"]
+        for ia, ib in zip(a["iters"], b["iters"]):
+            assert ia["n_corr"] == ib["n_corr"]
+            assert np.abs(ia["JTJ"] - ib["JTJ"]).max() <= SUM_RTOL * np.abs(ib["JTJ"]).max()
+            assert np.abs(ia["JTr"] - ib["JTr"]).max() <= SUM_RTOL * max(np.abs(ib["JTr"]).max(), 1e-12 * np.abs(ib["JTJ"]).max())
+            np.testing.assert_allclose(ia["residual_sum"], ib["residual_sum"], rtol=SUM_RTOL)
+        ref = oracle.register(om, scans[k], T0s[k], oracle.default_config(3))
+        dt, dr = synth.pose_error(ref["T"], a["T"])
+        assert ref["iterations"] == a["iterations"] and dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
+
+
 def test_exactly_singular_normal_equations_zero_pivot(ctx, oracle, world100k):
     """A scan whose points all lie on the sensor's x axis leaves the rotation about x unobservable: row / column 3 of the P2P
     JTJ (and of JTJ + lambda diag) is exactly zero.  Eigen's LDLT (reg.cpp:56) then meets an exactly-zero pivot and its solve
