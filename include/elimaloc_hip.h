@@ -115,7 +115,10 @@ typedef struct elm_map_info {
                            * bit 2: the P2P / GICP cell grid is the two-level (tiled) form (box too large / sparse for one dense table),
                            * bit 3: no point covariance is flagged: GICP runs the kernels without the stored-inverse fallback and gathers its
                            *        pair fused, A = w I + (w k) n n^T (clear with ELM_PAIR_NINE=1 at map build: nine entries of w C^-1),
-                           * bit 4: the same for the voxel covariances (VGICP's pair; AVGICP gathers sum w and sum (w k) n n^T per point) */
+                           * bit 4: the same for the voxel covariances (VGICP's pair; AVGICP gathers sum w and sum (w k) n n^T per point),
+                           * bit 5: the face sublists are written for AVGICP's fused walk,
+                           * bit 6: ... and some voxel is flagged: the fused walk skips its pairs and a fix-up launch over the marked
+                           *        workgroups adds them (ELM_AVG_FIXUP=0 at map build: the nine-entry walk with its in-line fallback instead) */
     uint64_t device_bytes;
     uint64_t n_query_voxels; /* cell grid: voxels of the dense statistics box; neighbourhood lists: query voxels (0 until built) */
     uint64_t nbr_entries;    /* cell grid: == n_points (every map point once); neighbourhood lists: ~27 x n_points */
