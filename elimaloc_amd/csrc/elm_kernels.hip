@@ -2242,7 +2242,11 @@ __global__ __launch_bounds__(64) void k_nbr_cellsort(const DevMap m, const int32
 #ifndef ELM_VNBR_WAVES
 #define ELM_VNBR_WAVES 1
 #endif
-// FACES = 1 (AVGICP on maps with the dense face-sublist table): the walk reads the face sublists, 48 bytes per record
+// FACES (AVGICP on maps with the dense face-sublist table; the walk reads the face sublists, 48 bytes per record):
+//   1  nine entries of w C^-1 per pair, flagged voxels read their stored inverse in line
+//   2  the fused walk (sum w, sum (w k) n n^T, b) on a map without a flagged voxel
+//   4  the fused walk on a map WITH flagged voxels: their pairs are skipped, the workgroup is marked (RegParams::flagged)
+//   3  the fix-up launch after 4: marked workgroups only, flagged records only (form 1's arithmetic), ADDED to the partial record
 template <int METHOD, int COMPACT, int STATS, int FACES>
 __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
                                                             unsigned total_blocks, const ScanState* __restrict__ st,
@@ -2396,7 +2400,7 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
             AvgPairSum Q;
             avg_pair_init(Q);
             const bool faces_only = FACES != 0; // lp is a face sublist (the launcher checks m.vq_dense && m.vqf_dense)
-            if (COMPACT && FACES == 2) {
+            if (COMPACT && (FACES == 2 || FACES == 4)) { // (4: on a map with flagged voxels -- their pairs are left to the fix-up launch)
                 // Face sublists of a map whose every voxel is of the compact form (DevMap::vface_plain): 48 bytes per record as below, and
                 // A_v = w (I + k n n^T) is never formed -- the point gathers sum w, sum (w k) n n^T (six entries) and
                 // b = sum w e + (w k)(n . e) n, fused: 25 float64 operations per pair less than the nine-entry form, the same sums up
@@ -2409,7 +2413,7 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
                     const double ex = r0.x - gx, ey = r0.y - gy, ez = r1.x - gz;
                     const double d2 = (ex * ex + ey * ey) + ez * ez;
                     if (d2 < rp.th2) {
-                        if (r1.y != r1.y) { // a flagged voxel (NaN normal): the fix-up launch adds this pair, with the stored inverse
+                        if (FACES == 4 && r1.y != r1.y) { // a flagged voxel (NaN normal): the fix-up launch adds this pair, with the stored inverse
                             rp.flagged[L] = 1u; // (only maps with such voxels meet this; they always come with the array)
                             continue;
                         }
@@ -3455,9 +3459,14 @@ void launch_accumulate_vnbr(hipStream_t s, const DevMap& m, const ScanDesc* scan
         const bool faces_ = (M) == ELM_AVGICP && m.vq_dense && m.vqf_dense;        \
         /* the fused walk; on a map with flagged voxels it needs the workgroup flags and partial records it can add to (no fused reduction) */ \
         if (faces_ && (C) && m.vface_plain && (!m.vface_flagged || (rp.flagged && !rp.tickets))) { \
-            if (rp.stats) ELM_LAUNCH_VF(M, C, 1, ((M) == ELM_AVGICP && (C) ? 2 : 0)); \
-            else ELM_LAUNCH_VF(M, C, 0, ((M) == ELM_AVGICP && (C) ? 2 : 0));       \
-            if (m.vface_flagged == 1) ELM_LAUNCH_VF(M, C, 0, ((M) == ELM_AVGICP && (C) ? 3 : 0)); \
+            if (!m.vface_flagged) {                                                \
+                if (rp.stats) ELM_LAUNCH_VF(M, C, 1, ((M) == ELM_AVGICP && (C) ? 2 : 0)); \
+                else ELM_LAUNCH_VF(M, C, 0, ((M) == ELM_AVGICP && (C) ? 2 : 0));   \
+            } else {                                                               \
+                if (rp.stats) ELM_LAUNCH_VF(M, C, 1, ((M) == ELM_AVGICP && (C) ? 4 : 0)); \
+                else ELM_LAUNCH_VF(M, C, 0, ((M) == ELM_AVGICP && (C) ? 4 : 0));   \
+                if (m.vface_flagged == 1) ELM_LAUNCH_VF(M, C, 0, ((M) == ELM_AVGICP && (C) ? 3 : 0)); \
+            }                                                                      \
         } else if (faces_) {                                                       \
             if (rp.stats) ELM_LAUNCH_VF(M, C, 1, ((M) == ELM_AVGICP ? 1 : 0));     \
             else ELM_LAUNCH_VF(M, C, 0, ((M) == ELM_AVGICP ? 1 : 0));              \
