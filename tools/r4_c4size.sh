@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 mkdir -p gpurun_out
-for m in 2 0; do
+for m in ${C4_METHODS:-2 0}; do
   timeout 900 python bench.py --no-cpu --no-extras --method $m --scan-points 262144 --map-points 50000000 --batch 128 --slots 32 --steps 5 --warmup 1 > gpurun_out/c4size_m$m.json 2> gpurun_out/c4size_m$m.err || tail -3 gpurun_out/c4size_m$m.err
   python - gpurun_out/c4size_m$m.json <<'PY'
 import json, sys
