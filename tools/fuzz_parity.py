@@ -30,6 +30,7 @@ ctx = Context(0)
 bad = 0
 soft = 0
 singular = 0
+ill = 0
 for case in range(a.seed0, a.seed0 + a.cases):
     rng = np.random.default_rng(50_000 + case)
     method = int(rng.integers(0, 4))
@@ -115,7 +116,7 @@ for case in range(a.seed0, a.seed0 + a.cases):
         # U != V has an eigenvalue -1: adding the later iterations' identity cancels it) -- the sums are then 1e16 x round-off on both
         # sides and nothing is comparable from that iteration on.  Everything before it must still agree.
         try:
-            sing = [k for k, r in enumerate(ref["iters"]) if "JTJ" in r and not (np.abs(r["JTJ"]).max() <= 1e8 * max(1.0, r["n_corr"]))]
+            sing = [k for k, r in enumerate(ref["iters"]) if "JTJ" in r and not (np.abs(r["JTJ"]).max() <= 3e7 * max(1.0, r["n_corr"]))]  # (a regular pair adds at most ~4e6: 1e3 x |a|^2)
             if sing:
                 k0 = sing[0]
                 pre = all(g["n_corr"] == r["n_corr"] and np.abs(g["JTJ"] - r["JTJ"]).max() <= 1e-9 * 30.0 ** k * max(np.abs(r["JTJ"]).max(), 1e-300)
@@ -127,6 +128,31 @@ for case in range(a.seed0, a.seed0 + a.cases):
                     print(f"singular-metric case {case}: method {method} kind {kind} from iteration {k0} on (agreement up to there)")
         except Exception as e:  # noqa: BLE001
             print("   (singular check failed:", repr(e), ")")
+    if not ok:
+        # A singular or indefinite system: from the first iteration whose regularised normal matrix (the lower triangle LDLT reads, + lambda
+        # diag) is not safely positive definite -- a scan of a handful of points, two or three pairs, an asymmetric "covariance" of a flagged
+        # voxel -- the solve turns last-bit differences of the sums (summation order, fused multiply-adds, exact lattice cancellations that
+        # only one operation order preserves) into any step at all; Eigen's own result there depends on its build flags.  Everything up to
+        # and including that iteration's SUMS must still agree.  Reported separately, not counted as a kernel mismatch.
+        try:
+            def shaky(r):
+                if "JTJ" not in r or r["n_corr"] == 0:
+                    return False
+                L_ = np.tril(r["JTJ"]) + np.tril(r["JTJ"], -1).T
+                ev = np.linalg.eigvalsh(L_)
+                return bool(ev.min() <= 1e-10 * max(abs(ev.max()), 1e-300))
+            sing = [k for k, r in enumerate(ref["iters"]) if shaky(r)]
+            if sing:
+                k0 = sing[0]
+                upto = all(g["n_corr"] == r["n_corr"] and
+                           np.abs(g["JTJ"] - r["JTJ"]).max() <= min(1e-9 * 30.0 ** k, 1e-5) * max(np.abs(r["JTJ"]).max(), 1e-300)
+                           for k, (g, r) in enumerate(zip(det["iters"][:k0 + 1], ref["iters"][:k0 + 1])))
+                if upto and len(det["iters"]) > k0:
+                    ill += 1
+                    ok = True
+                    print(f"singular-system case {case}: method {method} kind {kind} n_scan {len(scan)} from iteration {k0} on (sums agree up to and including it)")
+        except Exception as e:  # noqa: BLE001
+            print("   (singular-system check failed:", repr(e), ")")
     if not ok:
         # first iteration identical (same inputs), every count / flag identical, final pose inside the tolerance: the later
         # iterations differ because the poses they start from differ in the last bits, which exact-lattice inputs turn into
@@ -155,6 +181,6 @@ for case in range(a.seed0, a.seed0 + a.cases):
             print("   (no detail:", repr(e), ")")
         print(f"MISMATCH case {case}: method {method} voxel {voxel} max_pts {max_pts} th {th} kind {kind} n_scan {len(scan)} "
               f"iters {det.get('iterations')} vs {ref.get('iterations')} gate {det.get('gate')} vs {ref.get('gate')}")
-print(f"singular-metric radar cases: {singular}")
+print(f"singular-metric radar cases: {singular}; singular-system cases: {ill}")
 print(f"{a.cases - bad - soft}/{a.cases} cases agree, {soft} tie-sensitive, {bad} mismatches (kernel {a.kernel})")
 sys.exit(1 if bad else 0)
