@@ -1758,7 +1758,15 @@ static int exchange(elm_ctx* ctx, double* d_sums, size_t count, hipStream_t stre
 }
 
 // use_radar_cov (reg.hpp:186-217) changes the arithmetic of the covariance methods only: AlignCloudsLocal (P2P) never reads a covariance.
-static bool radar_path(const elm_reg_config* cfg) { return cfg->use_radar_cov != 0 && cfg->icp_method != ELM_P2P; }
+// ELM_STRICT_PAIRS=1: the covariance-weighted methods run the reference's own per-pair arithmetic -- (R^-1 C R^-T)^-1 by 3x3 products and an
+// inverse per pair, all 36 entries of J^T M J, LDLT on the lower triangle: the radar kernels with a zero source term -- instead of the
+// world-frame / fused forms.  Exact also for the asymmetric "covariances" of flagged voxels; a plain walk, no
+// streams: an order of magnitude slower.
+static bool strict_pairs() {
+    static const bool on = [] { const char* e = getenv("ELM_STRICT_PAIRS"); return e && strcmp(e, "0") != 0; }();
+    return on;
+}
+static bool radar_path(const elm_reg_config* cfg) { return (cfg->use_radar_cov != 0 || strict_pairs()) && cfg->icp_method != ELM_P2P; }
 
 // One ICP iteration's correspondence + accumulation launch for `n_scans` scans / slots, bracketed by two profiling marks (the
 // solve span starts at the second).
@@ -1886,7 +1894,7 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
     rp.method = method;
     rp.max_iter = cfg->max_iteration;
     rp.uniform_blocks = uniform_blocks;
-    rp.radar = radar ? 1 : 0;
+    rp.radar = radar ? (cfg->use_radar_cov != 0 ? 1 : 2) : 0; // 2: the radar kernels without a source covariance (ELM_STRICT_PAIRS)
     rp.stats = ctx->work_counters ? 1 : 0;
     rp.solve_small = ctx->half_sets ? 1 : 0;
     rp.radar_var[0] = cfg->range_variance_m;

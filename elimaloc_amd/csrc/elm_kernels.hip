@@ -685,7 +685,10 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_radar(const DevMap m, con
         const double gy = ((S.T[1] * px + S.T[5] * py) + S.T[9] * pz) + S.T[13];
         const double gz = ((S.T[2] * px + S.T[6] * py) + S.T[10] * pz) + S.T[14];
         double Cs[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-        if (S.iters == 0) radar_source_cov(gx, gy, gz, rp, Cs); // S.T is still the initial guess: g is the pose CalFramePointCov reads
+        if (rp.radar == 2) { // ELM_STRICT_PAIRS: the reference's arithmetic of use_radar_cov = 0 -- no source term at all
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Cs[k] = 0.0;
+        } else if (S.iters == 0) radar_source_cov(gx, gy, gz, rp, Cs); // S.T is still the initial guess: g is the pose CalFramePointCov reads
         const int vx = floor_key(gx, m.voxel_size), vy = floor_key(gy, m.voxel_size), vz = floor_key(gz, m.voxel_size);
         const double ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
         double n_cand = 0.0, n_occ = 0.0;

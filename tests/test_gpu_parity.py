@@ -1311,6 +1311,28 @@ def test_avgicp_fused_walk_with_flagged_voxels_fix_up_launch(oracle, monkeypatch
         assert ref["iterations"] == a["iterations"] and dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
 
 
+def test_strict_pairs_switch_is_exact_on_asymmetric_flagged_covariances():
+    """a rank-deficient neighbourhood whose SVD returns U != V gives the reference an ASYMMETRIC regularised
+    covariance; the fast kernels pack the symmetric 21 sums and deviate there (fuzz case 813687: GICP, exact lattice, one point per
+    voxel -- J^T J off by the reference matrix's own asymmetry, pose still inside the tolerance).  ELM_STRICT_PAIRS=1 runs the reference's
+    per-pair arithmetic (all 36 entries, LDLT on the lower triangle) and agrees with the oracle to the 1e-9 bar on that case."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "--cases", "1", "--seed0", "813687"]
+    env = dict(os.environ)
+    env.pop("ELM_STRICT_PAIRS", None)
+    fast = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert "MISMATCH case 813687" in fast.stdout and "pose error" in fast.stdout, fast.stdout[-2000:] + fast.stderr[-2000:]  # the known deviation
+    pe = [ln for ln in fast.stdout.splitlines() if "pose error" in ln][-1]
+    dt, dr = [float(v) for v in pe.split("(")[1].split(")")[0].split(",")]
+    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD  # ... stays inside the north_star tolerance
+    env["ELM_STRICT_PAIRS"] = "1"
+    strict = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert strict.returncode == 0 and "1/1 cases agree" in strict.stdout, strict.stdout[-2000:] + strict.stderr[-2000:]
+
+
 def test_exactly_singular_normal_equations_zero_pivot(ctx, oracle, world100k):
     """A scan whose points all lie on the sensor's x axis leaves the rotation about x unobservable: row / column 3 of the P2P
     JTJ (and of JTJ + lambda diag) is exactly zero.  Eigen's LDLT (reg.cpp:56) then meets an exactly-zero pivot and its solve
