@@ -1,5 +1,6 @@
 #!/bin/bash
 # the five cases the first pass of tools/r4_soak3.sh reported, and their blocks again, with the singular-system classification
+# (build_ab/lib_r04h.so = the library of commit 176049f: git archive 176049f elimaloc_amd/csrc include | tar -x -C /tmp/old && make -C /tmp/old/elimaloc_amd/csrc)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 mkdir -p gpurun_out
