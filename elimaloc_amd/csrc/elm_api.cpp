@@ -429,6 +429,7 @@ struct elm_map {
     bool has_grid = false;
     bool want_gicp_compact = false; // the grid gets 64-byte GICP records (points outside the compact form are flagged and read pt_gicp)
     unsigned n_bad_pts = 0, n_bad_vox = 0; // covariances outside the compact form (diagnostics)
+    unsigned n_asym_pts = 0, n_asym_vox = 0; // ... of which the stored inverse is not symmetric: such a map runs the per-pair kernels (strict_for)
     bool grid_refused = false; // the bounding box needs more cells than the budget: neighbourhood lists instead
     bool has_vnbr = false; // voxel-mean lists (VGICP)
     bool has_cells = false; // lists sorted by half-voxel cell + offset tables (every list <= 1024 entries)
@@ -685,13 +686,14 @@ extern "C" int elm_map_cal_voxel_cov_all(elm_map* m) {
         m->info.device_bytes += (size_t)m->dm.n_vox * 25 * sizeof(double);
     }
     if (!m->d_bad) HIPCHK(ctx, hipMalloc((void**)&m->d_bad, 256));
-    unsigned bad = 0;
+    unsigned bad2[2] = {0, 0}; // [0] flagged, [1] flagged with an asymmetric stored inverse
+    unsigned& bad = bad2[0];
     if (m->dm.n_vox) {
         (void)hipGetLastError(); // drop stale errors of other libraries (RCCL probes peer devices)
-        HIPCHK(ctx, hipMemsetAsync(m->d_bad, 0, sizeof(unsigned), ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(m->d_bad, 0, 2 * sizeof(unsigned), ctx->stream));
         launch_voxel_cov(ctx->stream, m->dm, m->d_ranges, m->d_vox_mean, m->d_vox_cov, m->d_vox_cinv, m->d_vox_nk, m->d_bad);
         HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipMemcpyAsync(&bad, m->d_bad, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(bad2, m->d_bad, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     m->dm.vox_mean = m->d_vox_mean;
@@ -702,6 +704,8 @@ extern "C" int elm_map_cal_voxel_cov_all(elm_map* m) {
     // outside that form (rank-deficient neighbourhood, U != V in its SVD) carry k = NaN and their pairs read the stored 3x3 inverse.
     // ELM_COV_RECORDS=full: every pair reads the stored inverses.
     m->n_bad_vox = bad;
+    m->n_asym_vox = bad2[1];
+    m->info.layout_flags = (m->info.layout_flags & ~256) | (bad2[1] ? 256 : 0);
     m->dm.vox_compact = full_records_forced() ? 0 : ((bad == 0 && !std::getenv("ELM_PAIR_NINE")) ? 2 : 1); // 2: no flagged voxel at all
     m->info.has_voxel_cov = 1;
     m->info.layout_flags = (m->info.layout_flags & ~(2 | 16)) | (m->dm.vox_compact ? 2 : 0) | (m->dm.vox_compact == 2 ? 16 : 0);
@@ -719,18 +723,21 @@ extern "C" int elm_map_cal_point_cov_all(elm_map* m, double d_search_dist) {
         m->info.device_bytes += (size_t)m->dm.n_pts * 25 * sizeof(double);
     }
     if (!m->d_bad) HIPCHK(ctx, hipMalloc((void**)&m->d_bad, 256));
-    unsigned bad = 0;
+    unsigned bad2[2] = {0, 0}; // [0] flagged, [1] flagged with an asymmetric stored inverse
+    unsigned& bad = bad2[0];
     if (m->dm.n_pts) {
         (void)hipGetLastError();
-        HIPCHK(ctx, hipMemsetAsync(m->d_bad, 0, sizeof(unsigned), ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(m->d_bad, 0, 2 * sizeof(unsigned), ctx->stream));
         launch_point_cov(ctx->stream, m->dm, d_search_dist * d_search_dist, m->d_pt_gicp, m->d_pt_cov, m->d_bad);
         HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipMemcpyAsync(&bad, m->d_bad, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(bad2, m->d_bad, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     m->dm.pt_gicp = m->d_pt_gicp;
     m->dm.pt_cov = m->d_pt_cov;
     m->n_bad_pts = bad;
+    m->n_asym_pts = bad2[1];
+    m->info.layout_flags = (m->info.layout_flags & ~128) | (bad2[1] ? 128 : 0);
     m->want_gicp_compact = !full_records_forced(); // see elm_map_cal_voxel_cov_all: non-conforming points (k = NaN) read their full record
     m->info.has_point_cov = 1;
     return refresh_grid_gicp(m); // a grid built before the covariances (or a new search radius): regather
@@ -1762,11 +1769,21 @@ static int exchange(elm_ctx* ctx, double* d_sums, size_t count, hipStream_t stre
 // inverse per pair, all 36 entries of J^T M J, LDLT on the lower triangle: the radar kernels with a zero source term -- instead of the
 // world-frame / fused forms.  Exact also for the asymmetric "covariances" of flagged voxels; a plain walk, no
 // streams: an order of magnitude slower.
-static bool strict_pairs() {
-    static const bool on = [] { const char* e = getenv("ELM_STRICT_PAIRS"); return e && strcmp(e, "0") != 0; }();
-    return on;
+// Unset (the default): only the maps that need it -- a flagged covariance of the method's own kind with an asymmetric stored inverse
+// (layout_flags bits 7 / 8, counted by k_point_cov / k_voxel_cov) -- take that path; ELM_STRICT_PAIRS=0 keeps the fast kernels on those too.
+static int strict_pairs() { // 1: always, 0: never, -1: by map
+    const char* e = getenv("ELM_STRICT_PAIRS"); // (read per call: a registration call, not a launch)
+    return !e ? -1 : (strcmp(e, "0") != 0 ? 1 : 0);
 }
-static bool radar_path(const elm_reg_config* cfg) { return (cfg->use_radar_cov != 0 || strict_pairs()) && cfg->icp_method != ELM_P2P; }
+static bool strict_for(const elm_reg_config* cfg, const elm_map* map) {
+    const int mode = strict_pairs();
+    if (mode >= 0) return mode != 0;
+    if (!map) return false;
+    return cfg->icp_method == ELM_GICP ? map->n_asym_pts != 0 : map->n_asym_vox != 0;
+}
+static bool radar_path(const elm_reg_config* cfg, const elm_map* map) {
+    return cfg->icp_method != ELM_P2P && (cfg->use_radar_cov != 0 || strict_for(cfg, map));
+}
 
 // One ICP iteration's correspondence + accumulation launch for `n_scans` scans / slots, bracketed by two profiling marks (the
 // solve span starts at the second).
@@ -1823,7 +1840,7 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int method = cfg->icp_method;
     const bool map_empty = map->dm.n_vox == 0;
-    const bool radar = radar_path(cfg) && !map_empty;
+    const bool radar = radar_path(cfg, map) && !map_empty;
     // (use_radar_cov on several ranks: the all-reduce carries the radar kernel's 64 sums per scan instead of the 32 of the packed layout)
     if (!map_empty) {
         if ((method == ELM_VGICP || method == ELM_AVGICP) && !map->info.has_voxel_cov) {
@@ -2130,7 +2147,7 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     if (map->ctx != ctx) return ELM_ERR_INVALID;
     if (cfg->icp_method < ELM_P2P || cfg->icp_method > ELM_AVGICP) return ELM_ERR_INVALID;
     if (ctx->in_flight) return ELM_ERR_INVALID;
-    if (radar_path(cfg)) {
+    if (radar_path(cfg, map)) {
         // use_radar_cov: lockstep batches of `slots` registrations (k_accumulate_radar is not a slot kernel; a radar scan is a few hundred
         // returns).  Per-registration arithmetic is that of elm_register_batch.
         for (int b0 = 0; b0 < count; b0 += slots) {
@@ -2443,7 +2460,7 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
         max_n = std::max(max_n, n_pts[b]);
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (map->dm.n_vox == 0 || cfg->max_iteration <= 0 || max_n == 0 || radar_path(cfg)) {
+    if (map->dm.n_vox == 0 || cfg->max_iteration <= 0 || max_n == 0 || radar_path(cfg, map)) {
         // nothing iterates (or use_radar_cov: see elm_register_stream): upload and let the lockstep path handle the degenerate cases
         std::vector<elm_scan*> sc((size_t)count, nullptr);
         int rc = ELM_OK;

@@ -3212,6 +3212,15 @@ __device__ __forceinline__ double compact_k(const double Ci[9], const double n[3
     return k;
 }
 
+// A flagged covariance whose stored inverse is not symmetric (U != V in the SVD of a rank-deficient neighbourhood):
+// the packed 21-sum forms cannot carry its antisymmetric part, so the host routes such a map to the per-pair kernels (bad[1] counts them).
+__device__ inline bool inv_asymmetric(const double Ci[9]) {
+    double mx = 0.0;
+    for (int k = 0; k < 9; ++k) mx = fmax(mx, fabs(Ci[k]));
+    const double d = fmax(fmax(fabs(Ci[1] - Ci[3]), fabs(Ci[2] - Ci[6])), fabs(Ci[5] - Ci[7]));
+    return !(d <= 1e-12 * mx); // (NaN entries count as asymmetric: the per-pair kernels reproduce the reference's NaN propagation)
+}
+
 __global__ __launch_bounds__(256) void k_voxel_cov(const DevMap m, const uint2* __restrict__ ranges, double* vox_mean,
                                                    double* vox_cov, double* vox_cinv, double* vox_nk, unsigned* bad) {
     const unsigned v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3253,6 +3262,7 @@ __global__ __launch_bounds__(256) void k_voxel_cov(const DevMap m, const uint2* 
     // (k is 0 -- identity -- or 1 / 1e-3 - 1 for every regularised covariance; the face sublists imply it, so anything else is `bad`)
     ok = ok && (kk == 0.0 || fabs(kk - kCompactK) <= 1e-7);
     if (!ok) atomicAdd(bad, 1u);
+    if (!ok && inv_asymmetric(Ci)) atomicAdd(bad + 1, 1u);
     for (int k = 0; k < 3; ++k) vox_nk[(size_t)v * 4 + k] = nrm[k];
     vox_nk[(size_t)v * 4 + 3] = ok ? kk : __builtin_nan(""); // NaN: the pairs of this voxel read vox_cinv[vid]
 }
@@ -3325,6 +3335,7 @@ __global__ __launch_bounds__(256) void k_point_cov(const DevMap m, double d2max,
     ok = ok && (kk == 0.0 || fabs(kk - kCompactK) <= 1e-7); // (the 48-byte reads imply k: 0 or 1 / 1e-3 - 1, nothing else is compact)
     rec[15] = ok ? kk : __builtin_nan(""); // NaN: this point's inverse is not of that form -- its pairs read the full record
     if (!ok) atomicAdd(bad, 1u);
+    if (!ok && inv_asymmetric(Ci)) atomicAdd(bad + 1, 1u);
     for (int k = 0; k < 9; ++k) pt_cov[(size_t)i * 9 + k] = C[k];
 }
 

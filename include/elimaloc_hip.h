@@ -118,7 +118,12 @@ typedef struct elm_map_info {
                            * bit 4: the same for the voxel covariances (VGICP's pair; AVGICP gathers sum w and sum (w k) n n^T per point),
                            * bit 5: the face sublists are written for AVGICP's fused walk,
                            * bit 6: ... and some voxel is flagged: the fused walk skips its pairs and a fix-up launch over the marked
-                           *        workgroups adds them (ELM_AVG_FIXUP=0 at map build: the nine-entry walk with its in-line fallback instead) */
+                           *        workgroups adds them (ELM_AVG_FIXUP=0 at map build: the nine-entry walk with its in-line fallback instead),
+                           * bit 7: some flagged POINT covariance has an asymmetric stored inverse (rank-deficient neighbourhood, U != V in its
+                           *        SVD): GICP on this map runs the reference's per-pair arithmetic (all 36 entries of J^T M J, LDLT on the lower
+                           *        triangle; an order of magnitude slower) because the packed symmetric sums cannot carry it
+                           *        (ELM_STRICT_PAIRS=0: fast kernels anyway, =1: per-pair arithmetic on every map),
+                           * bit 8: the same for the voxel covariances (VGICP / AVGICP) */
     uint64_t device_bytes;
     uint64_t n_query_voxels; /* cell grid: voxels of the dense statistics box; neighbourhood lists: query voxels (0 until built) */
     uint64_t nbr_entries;    /* cell grid: == n_points (every map point once); neighbourhood lists: ~27 x n_points */

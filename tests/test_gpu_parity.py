@@ -1271,6 +1271,7 @@ def test_avgicp_fused_walk_with_flagged_voxels_fix_up_launch(oracle, monkeypatch
         sc, Tt = synth.make_scan(world, 6000 + 1000 * k, seed=6100 + k)
         scans.append(sc)
         T0s.append(synth.perturb(Tt, seed=6200 + k, max_trans=0.2, max_rot_deg=0.8))
+    monkeypatch.setenv("ELM_STRICT_PAIRS", "0")  # this test is about the fast kernels, whatever the symmetry of the crafted covariances
     runs = {}
     for mode in ("fixup", "inline", "skip"):  # skip: the fused walk WITHOUT its fix-up launch (a test switch): the flagged pairs go missing
         if mode != "fixup":
@@ -1313,9 +1314,11 @@ def test_avgicp_fused_walk_with_flagged_voxels_fix_up_launch(oracle, monkeypatch
 
 def test_strict_pairs_switch_is_exact_on_asymmetric_flagged_covariances():
     """a rank-deficient neighbourhood whose SVD returns U != V gives the reference an ASYMMETRIC regularised
-    covariance; the fast kernels pack the symmetric 21 sums and deviate there (fuzz case 813687: GICP, exact lattice, one point per
-    voxel -- J^T J off by the reference matrix's own asymmetry, pose still inside the tolerance).  ELM_STRICT_PAIRS=1 runs the reference's
-    per-pair arithmetic (all 36 entries, LDLT on the lower triangle) and agrees with the oracle to the 1e-9 bar on that case."""
+    covariance; the fast kernels pack the symmetric 21 sums and would deviate there (fuzz case 813687: GICP, exact lattice, one point per
+    voxel -- J^T J off by the reference matrix's own asymmetry, pose still inside the tolerance).  The covariance kernels count such
+    records (layout bits 7 / 8) and a map that holds one runs the reference's per-pair arithmetic (all 36 entries, LDLT on the lower
+    triangle): the DEFAULT agrees with the oracle to the 1e-9 bar on that case; ELM_STRICT_PAIRS=0 keeps the fast kernels and shows the
+    deviation the routing removes; ELM_STRICT_PAIRS=1 forces the per-pair arithmetic on every map."""
     import os
     import subprocess
     import sys
@@ -1323,6 +1326,9 @@ def test_strict_pairs_switch_is_exact_on_asymmetric_flagged_covariances():
     cmd = [sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "--cases", "1", "--seed0", "813687"]
     env = dict(os.environ)
     env.pop("ELM_STRICT_PAIRS", None)
+    auto = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert auto.returncode == 0 and "1/1 cases agree" in auto.stdout, auto.stdout[-2000:] + auto.stderr[-2000:]
+    env["ELM_STRICT_PAIRS"] = "0"
     fast = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert "MISMATCH case 813687" in fast.stdout and "pose error" in fast.stdout, fast.stdout[-2000:] + fast.stderr[-2000:]  # the known deviation
     pe = [ln for ln in fast.stdout.splitlines() if "pose error" in ln][-1]
@@ -1331,6 +1337,23 @@ def test_strict_pairs_switch_is_exact_on_asymmetric_flagged_covariances():
     env["ELM_STRICT_PAIRS"] = "1"
     strict = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert strict.returncode == 0 and "1/1 cases agree" in strict.stdout, strict.stdout[-2000:] + strict.stderr[-2000:]
+
+
+def test_ordinary_maps_carry_no_asymmetric_covariance_and_stay_on_the_fast_kernels(ctx, world100k):
+    """Layout bits 7 / 8 (a flagged covariance with an asymmetric stored inverse -> per-pair arithmetic) are clear on the jittered world and
+    on the crafted rank-1 voxels of the fix-up test: the routing of section 5 (ii) costs ordinary maps nothing."""
+    from elimaloc_amd.registration import VoxelHashMap
+    rng = np.random.default_rng(5)
+    xy = rng.uniform(-25, 25, (60, 2))
+    c0 = np.column_stack([np.floor(xy[:, 0]) + 0.3, np.floor(xy[:, 1]) + 0.4, np.full(60, 1.35)])
+    c1 = c0 + rng.uniform(0.1, 0.3, (60, 3))
+    crafted = np.ascontiguousarray(np.concatenate([world100k, c0.astype(np.float32), c1.astype(np.float32)]).astype(np.float32))
+    for w in (world100k, crafted):
+        vm = VoxelHashMap(1.0, 30, ctx)
+        vm.AddPoints(w)
+        vm.CalVoxelCovAll()
+        vm.CalPointCovAll(0.4)
+        assert not int(vm.info().layout_flags) & (128 | 256), int(vm.info().layout_flags)
 
 
 def test_exactly_singular_normal_equations_zero_pivot(ctx, oracle, world100k):
