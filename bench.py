@@ -537,6 +537,7 @@ def main():
             "success_rate": float(np.mean([r["is_success"] for r in out])),
             "map_points_retained": int(info.n_points),
             "map_voxels": int(info.n_voxels),
+            "map_layout_flags": int(info.layout_flags),  # include/elimaloc_hip.h; bits 7 / 8 set would mean the per-pair (strict) path ran
             "candidates_per_point_C": C,
             "occupied_voxels_per_point_V": V,
             "map_build_s": t_map,
