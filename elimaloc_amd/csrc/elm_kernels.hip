@@ -3218,7 +3218,7 @@ __device__ inline bool inv_asymmetric(const double Ci[9]) {
     double mx = 0.0;
     for (int k = 0; k < 9; ++k) mx = fmax(mx, fabs(Ci[k]));
     const double d = fmax(fmax(fabs(Ci[1] - Ci[3]), fabs(Ci[2] - Ci[6])), fabs(Ci[5] - Ci[7]));
-    return !(d <= 1e-12 * mx); // (NaN entries count as asymmetric: the per-pair kernels reproduce the reference's NaN propagation)
+    return d > 1e-12 * mx; // (false on NaN / inf entries: a map with non-finite points keeps the path it always had)
 }
 
 __global__ __launch_bounds__(256) void k_voxel_cov(const DevMap m, const uint2* __restrict__ ranges, double* vox_mean,
