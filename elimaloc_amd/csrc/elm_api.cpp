@@ -1768,7 +1768,7 @@ static int exchange(elm_ctx* ctx, double* d_sums, size_t count, hipStream_t stre
 // ELM_STRICT_PAIRS=1: the covariance-weighted methods run the reference's own per-pair arithmetic -- (R^-1 C R^-T)^-1 by 3x3 products and an
 // inverse per pair, all 36 entries of J^T M J, LDLT on the lower triangle: the radar kernels with a zero source term -- instead of the
 // world-frame / fused forms.  Exact also for the asymmetric "covariances" of flagged voxels; a plain walk, no
-// streams: an order of magnitude slower.
+// streams: 12-27 times slower at 131 072-point scans (profiles/r04k_strict_rate.txt).
 // Unset (the default): only the maps that need it -- a flagged covariance of the method's own kind with an asymmetric stored inverse
 // (layout_flags bits 7 / 8, counted by k_point_cov / k_voxel_cov) -- take that path; ELM_STRICT_PAIRS=0 keeps the fast kernels on those too.
 static int strict_pairs() { // 1: always, 0: never, -1: by map

@@ -121,7 +121,7 @@ typedef struct elm_map_info {
                            *        workgroups adds them (ELM_AVG_FIXUP=0 at map build: the nine-entry walk with its in-line fallback instead),
                            * bit 7: some flagged POINT covariance has an asymmetric stored inverse (rank-deficient neighbourhood, U != V in its
                            *        SVD): GICP on this map runs the reference's per-pair arithmetic (all 36 entries of J^T M J, LDLT on the lower
-                           *        triangle; an order of magnitude slower) because the packed symmetric sums cannot carry it
+                           *        triangle; 12-27 times slower at 131 072-point scans) because the packed symmetric sums cannot carry it
                            *        (ELM_STRICT_PAIRS=0: fast kernels anyway, =1: per-pair arithmetic on every map),
                            * bit 8: the same for the voxel covariances (VGICP / AVGICP) */
     uint64_t device_bytes;
