@@ -224,6 +224,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip latency / reference-API / hard-guess / replica legs (profiling passes)")
     ap.add_argument("--no-latency", action="store_true", help="alias of --no-extras")
+    ap.add_argument("--asym-triples", type=int, default=0, help="append this many isolated collinear point triples to the world (synth.collinear_triples): "
+                    "rank-1 neighbourhoods whose regularised covariance is not symmetric (layout bits 7 / 8) -- the covariance methods then "
+                    "carry the antisymmetric side records")
     ap.add_argument("--dry-launch", action="store_true", help="launcher + rendezvous + sharded input generation only, gloo, no GPU (CPU test of the N > 1 path)")
     args = ap.parse_args()
     extras = not (args.no_extras or args.no_latency)
@@ -298,6 +301,8 @@ def main():
     # ---------------- synthetic inputs (seeded, BLAS-free arithmetic: bit-identical whoever generates them) ----------------
     t0 = time.time()
     world = synth.make_world(args.map_points, seed=1001)
+    if args.asym_triples > 0:
+        world = np.ascontiguousarray(np.concatenate([world, synth.collinear_triples(world, args.asym_triples, seed=4004)]))
     vm = VoxelHashMap(1.0, 30, ctx)
     vm.AddPoints(world)
     if method in (IcpMethod.VGICP, IcpMethod.AVGICP):

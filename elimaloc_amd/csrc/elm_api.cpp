@@ -124,7 +124,7 @@ struct elm_ctx {
     hipEvent_t ev_iter[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ev_groups; // host-fed streams: per upload group its "copied" and "ordered" events
     uint16_t* d_hilbert = nullptr; // Hilbert index of every cell of the ordering grid (kOrderCells^2 entries)
-    DevBuf d_order_jobs, d_order_tmp, d_arena, d_raw, d_tickets, d_prev, d_flagged;
+    DevBuf d_order_jobs, d_order_tmp, d_arena, d_raw, d_tickets, d_prev, d_flagged, d_asym;
     bool prev_winner = false; // ELM_PREV_WINNER=1 (with a library built with -DELM_PREV_WINNER=1): the grid kernels keep every point's previous winner
     bool work_counters = false; // elm_ctx_set_work_counters / ELM_WORK_COUNTERS=1: the accumulate launches also sum the work counters of
                                 // elm_reg_result (n_cand_total, n_occ_total, n_tested_total, fallback_blocks); off: those fields read 0
@@ -340,7 +340,7 @@ extern "C" void elm_ctx_destroy(elm_ctx* ctx) {
     if (ctx->d_hilbert) (void)hipFree(ctx->d_hilbert);
     if (ctx->h_jobs) (void)hipHostFree(ctx->h_jobs);
     DevBuf* bufs[] = {&ctx->d_scans, &ctx->d_state, &ctx->d_partials, &ctx->d_sums, &ctx->d_T0, &ctx->d_trace, &ctx->d_stage_pts, &ctx->d_active, &ctx->d_queue, &ctx->d_ds,
-                      &ctx->d_order_jobs, &ctx->d_order_tmp, &ctx->d_arena, &ctx->d_raw, &ctx->d_tickets, &ctx->d_prev, &ctx->d_flagged};
+                      &ctx->d_order_jobs, &ctx->d_order_tmp, &ctx->d_arena, &ctx->d_raw, &ctx->d_tickets, &ctx->d_prev, &ctx->d_flagged, &ctx->d_asym};
     if (ctx->h_active) (void)hipHostFree(ctx->h_active);
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -429,7 +429,7 @@ struct elm_map {
     bool has_grid = false;
     bool want_gicp_compact = false; // the grid gets 64-byte GICP records (points outside the compact form are flagged and read pt_gicp)
     unsigned n_bad_pts = 0, n_bad_vox = 0; // covariances outside the compact form (diagnostics)
-    unsigned n_asym_pts = 0, n_asym_vox = 0; // ... of which the stored inverse is not symmetric: such a map runs the per-pair kernels (strict_for)
+    unsigned n_asym_pts = 0, n_asym_vox = 0; // ... of which the stored inverse is not symmetric: such a map carries side records (choose_path)
     bool grid_refused = false; // the bounding box needs more cells than the budget: neighbourhood lists instead
     bool has_vnbr = false; // voxel-mean lists (VGICP)
     bool has_cells = false; // lists sorted by half-voxel cell + offset tables (every list <= 1024 entries)
@@ -1767,22 +1767,56 @@ static int exchange(elm_ctx* ctx, double* d_sums, size_t count, hipStream_t stre
 // use_radar_cov (reg.hpp:186-217) changes the arithmetic of the covariance methods only: AlignCloudsLocal (P2P) never reads a covariance.
 // ELM_STRICT_PAIRS=1: the covariance-weighted methods run the reference's own per-pair arithmetic -- (R^-1 C R^-T)^-1 by 3x3 products and an
 // inverse per pair, all 36 entries of J^T M J, LDLT on the lower triangle: the radar kernels with a zero source term -- instead of the
-// world-frame / fused forms.  Exact also for the asymmetric "covariances" of flagged voxels; a plain walk, no
-// streams: 12-27 times slower at 131 072-point scans (profiles/r04k_strict_rate.txt).
-// Unset (the default): only the maps that need it -- a flagged covariance of the method's own kind with an asymmetric stored inverse
-// (layout_flags bits 7 / 8, counted by k_point_cov / k_voxel_cov) -- take that path; ELM_STRICT_PAIRS=0 keeps the fast kernels on those too.
-static int strict_pairs() { // 1: always, 0: never, -1: by map
+// world-frame / fused forms: the in-product checker of the fast forms (a plain walk, no streams: 12-27 times slower at 131 072-point
+// scans, profiles/r04k_strict_rate.txt).
+// Unset (the default): every map runs the fast kernels; a map with a flagged covariance of the method's own kind whose stored inverse is
+// not symmetric (layout_flags bits 7 / 8, counted by k_point_cov / k_voxel_cov) additionally carries the antisymmetric part of J^T M J in
+// side records (choose_path, asym_side_store) -- exact like the per-pair arithmetic.  ELM_STRICT_PAIRS=0: fast kernels WITHOUT the side
+// records (the behaviour before round 5: off by the antisymmetric part on such maps; kept for the test that shows the side records matter).
+static int strict_pairs() { // 1: per-pair kernels always, 0: fast kernels without side records, -1: fast kernels, side records by map
     const char* e = getenv("ELM_STRICT_PAIRS"); // (read per call: a registration call, not a launch)
     return !e ? -1 : (strcmp(e, "0") != 0 ? 1 : 0);
 }
-static bool strict_for(const elm_reg_config* cfg, const elm_map* map) {
+static int build_search_index(elm_map* m, bool* use_grid);
+static int build_voxel_neighbourhoods(elm_map* m);
+// Which kernels one registration call runs.  `radar`: the per-pair kernels (use_radar_cov, or ELM_STRICT_PAIRS=1).  Otherwise the search
+// index (built on first use) -- dense / two-level cell grid, neighbourhood lists, voxel-mean lists, or the plain walk -- and `asym`: the
+// map holds a flagged covariance of the method's kind whose stored inverse is not symmetric, and the fast kernels carry the antisymmetric
+// part of J^T M J in side records (RegParams::asym; grid and voxel-list kernels, unfused reduction).  Such a map on one of the fall-back
+// indices (lists / plain walk: maps the grid cannot hold, ELM_KERNEL=...) or under ELM_FUSED_REDUCE still takes the per-pair kernels.
+struct PathChoice {
+    bool radar = false, asym = false, use_grid = false, use_cells = false, use_vnbr = false;
+};
+static int choose_path(elm_ctx* ctx, const elm_map* map, const elm_reg_config* cfg, PathChoice* pc) {
+    *pc = PathChoice();
+    const int method = cfg->icp_method;
+    if (!map || map->dm.n_vox == 0) return ELM_OK;
     const int mode = strict_pairs();
-    if (mode >= 0) return mode != 0;
-    if (!map) return false;
-    return cfg->icp_method == ELM_GICP ? map->n_asym_pts != 0 : map->n_asym_vox != 0;
+    if (method != ELM_P2P && (cfg->use_radar_cov != 0 || mode == 1)) { pc->radar = true; return ELM_OK; }
+    int rc;
+    const bool use_nbr = ctx->kernel_mode != 2 && (method == ELM_P2P || method == ELM_GICP);
+    pc->use_grid = use_nbr && ctx->kernel_mode == 4 && map->has_grid;
+    if (use_nbr && !pc->use_grid && !map->has_nbr)
+        if ((rc = build_search_index(const_cast<elm_map*>(map), &pc->use_grid)) != ELM_OK) return rc;
+    pc->use_cells = use_nbr && !pc->use_grid && map->has_cells;
+    pc->use_vnbr = ctx->kernel_mode != 2 && (method == ELM_VGICP || method == ELM_AVGICP);
+    if (pc->use_vnbr && !map->has_vnbr)
+        if ((rc = build_voxel_neighbourhoods(const_cast<elm_map*>(map))) != ELM_OK) return rc;
+    const bool asym_map = mode < 0 && method != ELM_P2P && (method == ELM_GICP ? map->n_asym_pts != 0 : map->n_asym_vox != 0);
+    if (asym_map) {
+        if ((pc->use_grid || pc->use_vnbr) && !ctx->fused_reduce) pc->asym = true;
+        else { pc->radar = true; pc->use_grid = pc->use_cells = pc->use_vnbr = false; }
+    }
+    return ELM_OK;
 }
-static bool radar_path(const elm_reg_config* cfg, const elm_map* map) {
-    return cfg->icp_method != ELM_P2P && (cfg->use_radar_cov != 0 || strict_for(cfg, map));
+// the side records of a launch of `blocks` workgroups over `n_scans` scans / slots; the scans' reduced side sums sit right behind the
+// packed sums in d_sums (one exchange carries both)
+static int reserve_asym(elm_ctx* ctx, RegParams& rp, uint32_t blocks, int n_scans) {
+    int rc;
+    if ((rc = dev_reserve(ctx, ctx->d_asym, (size_t)std::max<uint32_t>(blocks, 1) * kAsymRecord * sizeof(double))) != ELM_OK) return rc;
+    rp.asym = (double*)ctx->d_asym.p;
+    rp.asym_sums = (double*)ctx->d_sums.p + (size_t)n_scans * kSums;
+    return ELM_OK;
 }
 
 // One ICP iteration's correspondence + accumulation launch for `n_scans` scans / slots, bracketed by two profiling marks (the
@@ -1840,7 +1874,6 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int method = cfg->icp_method;
     const bool map_empty = map->dm.n_vox == 0;
-    const bool radar = radar_path(cfg, map) && !map_empty;
     // (use_radar_cov on several ranks: the all-reduce carries the radar kernel's 64 sums per scan instead of the 32 of the packed layout)
     if (!map_empty) {
         if ((method == ELM_VGICP || method == ELM_AVGICP) && !map->info.has_voxel_cov) {
@@ -1852,8 +1885,11 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
             return ELM_ERR_INVALID;
         }
     }
-    // batch descriptors
     int rc;
+    PathChoice pc;
+    if ((rc = choose_path(ctx, map, cfg, &pc)) != ELM_OK) return rc;
+    const bool radar = pc.radar;
+    // batch descriptors
     const size_t stage_bytes = (size_t)batch * (sizeof(ScanDesc) + 16 * sizeof(double));
     if ((rc = pinned_reserve(ctx, &ctx->h_desc, &ctx->h_desc_cap, std::max<size_t>(stage_bytes, 4096))) != ELM_OK) return rc;
     ScanDesc* hd = (ScanDesc*)ctx->h_desc;
@@ -1879,7 +1915,7 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
     if ((rc = dev_reserve(ctx, ctx->d_T0, (size_t)batch * 16 * sizeof(double))) != ELM_OK) return rc;
     if ((rc = dev_reserve(ctx, ctx->d_state, st_bytes + 64)) != ELM_OK) return rc;
     if ((rc = dev_reserve(ctx, ctx->d_partials, (size_t)std::max<uint32_t>(blocks, 1) * (radar ? kRadarRecord : kSums) * sizeof(double))) != ELM_OK) return rc;
-    if ((rc = dev_reserve(ctx, ctx->d_sums, (size_t)batch * (radar ? kRadarRecord : kSums) * sizeof(double))) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_sums, (size_t)batch * (radar ? kRadarRecord : kSums + kAsymRecord) * sizeof(double))) != ELM_OK) return rc;
     if ((rc = pinned_reserve(ctx, &ctx->h_state, &ctx->h_state_cap, st_bytes + 64)) != ELM_OK) return rc;
     ctx->results_ready = false;
     elm_iter_trace* d_trace = nullptr;
@@ -1892,7 +1928,7 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
     }
     // one resident registration without trace / profiling / exchange: the replayed graph (descriptor and guess travel through the pinned
     // staging buffer, so nothing call-specific is baked into it)
-    const bool graph_mode = ctx->use_graph && batch == 1 && !want_trace && !ctx->profiling && !n_dev && !map_empty && !radar && !ctx->comm && !ctx->hook &&
+    const bool graph_mode = ctx->use_graph && batch == 1 && !want_trace && !ctx->profiling && !n_dev && !map_empty && !radar && !pc.asym && !ctx->comm && !ctx->hook &&
                             cfg->max_iteration > 0 && blocks > 0 && ctx->iter_hint > 0; // (iter_hint: a first call has no history to size the graph with)
     const bool packed_init = batch <= kInitPack && !graph_mode;
     if (!packed_init && !graph_mode) {
@@ -1929,21 +1965,12 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
         rp.sums = (double*)ctx->d_sums.p;
         rp.tickets = (int32_t*)ctx->d_tickets.p;
     }
+    if (pc.asym && (rc = reserve_asym(ctx, rp, blocks, batch)) != ELM_OK) return rc;
     ctx->rp = rp;
 
-    // P2P / GICP default to the cell-indexed neighbourhood lists; the lists are built on first use (init-time cost).  Maps whose
-    // lists cannot be cell-sorted (a list beyond 1024 candidates: voxel caps above ~37 points) take the plain walk.
-    // (use_radar_cov: k_accumulate_radar walks the hash map itself, no search index is needed)
-    const bool use_nbr = !map_empty && !radar && ctx->kernel_mode != 2 && (method == ELM_P2P || method == ELM_GICP);
-    bool use_grid = use_nbr && ctx->kernel_mode == 4 && map->has_grid;
-    if (use_nbr && !use_grid && !map->has_nbr) {
-        if ((rc = build_search_index(const_cast<elm_map*>(map), &use_grid)) != ELM_OK) return rc;
-    }
-    const bool use_cells = use_nbr && !use_grid && map->has_cells;
-    const bool use_vnbr = !map_empty && !radar && ctx->kernel_mode != 2 && (method == ELM_VGICP || method == ELM_AVGICP);
-    if (use_vnbr && !map->has_vnbr) {
-        if ((rc = build_voxel_neighbourhoods(const_cast<elm_map*>(map))) != ELM_OK) return rc;
-    }
+    // the search index (choose_path built it on first use): dense / two-level cell grid, else the cell-indexed neighbourhood lists, else
+    // the plain walk (maps whose lists cannot be cell-sorted); use_radar_cov: k_accumulate_radar walks the hash map itself
+    const bool use_grid = pc.use_grid, use_cells = pc.use_cells, use_vnbr = pc.use_vnbr;
     ScanState* st = (ScanState*)ctx->d_state.p;
     const ScanDesc* dsc = (const ScanDesc*)ctx->d_scans.p;
     int* d_active = (int*)((char*)ctx->d_state.p + st_bytes);
@@ -2028,7 +2055,7 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
             if (distributed) {
                 // fused reduction: the sums are already in d_sums -- accumulate -> all-reduce -> solve (two launches + one collective)
                 if (!rp.tickets) launch_solve(ctx->stream, dsc, batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 1, d_active);
-                if ((rc = exchange(ctx, (double*)ctx->d_sums.p, (size_t)batch * (radar ? kRadarRecord : kSums))) != ELM_OK) return rc;
+                if ((rc = exchange(ctx, (double*)ctx->d_sums.p, (size_t)batch * (radar ? kRadarRecord : (rp.asym ? kSums + kAsymRecord : kSums)))) != ELM_OK) return rc;
                 launch_solve(ctx->stream, dsc, batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 2, d_active);
             } else {
                 launch_solve(ctx->stream, dsc, batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 0, d_active);
@@ -2147,7 +2174,10 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     if (map->ctx != ctx) return ELM_ERR_INVALID;
     if (cfg->icp_method < ELM_P2P || cfg->icp_method > ELM_AVGICP) return ELM_ERR_INVALID;
     if (ctx->in_flight) return ELM_ERR_INVALID;
-    if (radar_path(cfg, map)) {
+    int rc;
+    PathChoice pc;
+    if ((rc = choose_path(ctx, map, cfg, &pc)) != ELM_OK) return rc;
+    if (pc.radar) {
         // use_radar_cov: lockstep batches of `slots` registrations (k_accumulate_radar is not a slot kernel; a radar scan is a few hundred
         // returns).  Per-registration arithmetic is that of elm_register_batch.
         for (int b0 = 0; b0 < count; b0 += slots) {
@@ -2169,7 +2199,6 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
         return ELM_ERR_INVALID;
     }
     const int S = std::min(std::min(slots, count), stream_max_slots());
-    int rc;
     // queue (host staging): items, initial guesses; slot descriptors with fixed block ranges sized for the largest scan
     uint32_t max_n = 0;
     for (int b = 0; b < count; ++b) {
@@ -2203,7 +2232,7 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     if ((rc = dev_reserve(ctx, ctx->d_scans, d_bytes)) != ELM_OK) return rc;
     if ((rc = dev_reserve(ctx, ctx->d_state, (size_t)S * sizeof(ScanState))) != ELM_OK) return rc;
     if ((rc = dev_reserve(ctx, ctx->d_partials, (size_t)std::max<uint32_t>(blocks, 1) * kSums * sizeof(double))) != ELM_OK) return rc;
-    if ((rc = dev_reserve(ctx, ctx->d_sums, (size_t)S * kSums * sizeof(double))) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_sums, (size_t)S * (kSums + kAsymRecord) * sizeof(double))) != ELM_OK) return rc;
     if ((rc = dev_reserve(ctx, ctx->d_queue, q_bytes + t_bytes + sizeof(StreamCtrl) + (size_t)count * sizeof(ScanState) + 64)) != ELM_OK) return rc;
     if ((rc = pinned_reserve(ctx, &ctx->h_state, &ctx->h_state_cap, (size_t)count * sizeof(ScanState))) != ELM_OK) return rc;
     if ((rc = dev_reserve(ctx, ctx->d_active, 256)) != ELM_OK) return rc;
@@ -2254,15 +2283,9 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
         rp.sums = (double*)ctx->d_sums.p;
         rp.tickets = (int32_t*)ctx->d_tickets.p;
     }
+    if (pc.asym && (rc = reserve_asym(ctx, rp, blocks, S)) != ELM_OK) return rc;
     ctx->rp = rp;
-    const bool use_nbr = ctx->kernel_mode != 2 && (method == ELM_P2P || method == ELM_GICP);
-    bool use_grid = use_nbr && ctx->kernel_mode == 4 && map->has_grid;
-    if (use_nbr && !use_grid && !map->has_nbr)
-        if ((rc = build_search_index(const_cast<elm_map*>(map), &use_grid)) != ELM_OK) return rc;
-    const bool use_cells = use_nbr && !use_grid && map->has_cells;
-    const bool use_vnbr = ctx->kernel_mode != 2 && (method == ELM_VGICP || method == ELM_AVGICP);
-    if (use_vnbr && !map->has_vnbr)
-        if ((rc = build_voxel_neighbourhoods(const_cast<elm_map*>(map))) != ELM_OK) return rc;
+    const bool use_grid = pc.use_grid, use_cells = pc.use_cells, use_vnbr = pc.use_vnbr;
 
     ScanState* st = (ScanState*)ctx->d_state.p;
     ScanDesc* dsc = (ScanDesc*)ctx->d_scans.p;
@@ -2305,6 +2328,7 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
             RegParams rph = rp;
             if (rp.tickets) { rph.sums = sums_h; rph.tickets = rp.tickets + base; }
             if (rp.prev) rph.prev = rp.prev + (size_t)cap_blocks * (size_t)base * kBlock;
+            if (rp.asym) { rph.asym = rp.asym + (size_t)cap_blocks * (size_t)base * kAsymRecord; rph.asym_sums = rp.asym_sums + (size_t)base * kAsymRecord; }
             hipStream_t ss = ctx->stream;
             if (H == 2) {
                 ss = ctx->solve_stream;
@@ -2319,7 +2343,9 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
             }
             if (distributed) {
                 if (!rp.tickets) launch_solve(ss, dsc_h, Sh, st_h, partials_h, sums_h, rph, d_trace, 1, d_active);
-                if ((rc = exchange(ctx, sums_h, (size_t)Sh * kSums, ss)) != ELM_OK) return rc;
+                // (side sums of a map with an asymmetric covariance: right behind the packed sums -- one exchange; half-sets: one more)
+                if ((rc = exchange(ctx, sums_h, (size_t)Sh * ((rp.asym && H == 1) ? kSums + kAsymRecord : kSums), ss)) != ELM_OK) return rc;
+                if (rp.asym && H == 2 && (rc = exchange(ctx, rph.asym_sums, (size_t)Sh * kAsymRecord, ss)) != ELM_OK) return rc;
                 // the solve also refills: slot s serves the registrations s, s + S, s + 2 S, ... -- a function of the slot alone, so every
                 // rank hands out the same registrations without a refill launch (3 launches + 1 collective per iteration)
                 if (ctx->dist_refill_kernel && H == 1) {
@@ -2460,10 +2486,13 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
         max_n = std::max(max_n, n_pts[b]);
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (map->dm.n_vox == 0 || cfg->max_iteration <= 0 || max_n == 0 || radar_path(cfg, map)) {
+    int rc;
+    PathChoice pc;
+    if ((rc = choose_path(ctx, map, cfg, &pc)) != ELM_OK) return rc;
+    if (map->dm.n_vox == 0 || cfg->max_iteration <= 0 || max_n == 0 || pc.radar) {
         // nothing iterates (or use_radar_cov: see elm_register_stream): upload and let the lockstep path handle the degenerate cases
         std::vector<elm_scan*> sc((size_t)count, nullptr);
-        int rc = ELM_OK;
+        rc = ELM_OK;
         for (int b = 0; b < count && rc == ELM_OK; ++b) rc = elm_scan_upload(ctx, scan_xyz[b], n_pts[b], n_pts[b], &sc[b]);
         if (rc == ELM_OK) rc = elm_register_batch(ctx, map, sc.data(), count, T0, cfg, results, trace);
         for (elm_scan* x : sc) elm_scan_destroy(x);
@@ -2478,7 +2507,6 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
         ctx->last_error = "GICP needs elm_map_cal_point_cov_all() (pcm.cpp:97-100)";
         return ELM_ERR_INVALID;
     }
-    int rc;
     if ((rc = ensure_side_streams(ctx)) != ELM_OK) return rc;
     if ((rc = ensure_hilbert(ctx)) != ELM_OK) return rc;
     const int S = std::min(std::min(slots, count), stream_max_slots());
@@ -2518,7 +2546,7 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
     if ((rc = dev_reserve(ctx, ctx->d_scans, d_bytes)) != ELM_OK) return rc;
     if ((rc = dev_reserve(ctx, ctx->d_state, (size_t)S * sizeof(ScanState))) != ELM_OK) return rc;
     if ((rc = dev_reserve(ctx, ctx->d_partials, (size_t)std::max<uint32_t>(blocks, 1) * kSums * sizeof(double))) != ELM_OK) return rc;
-    if ((rc = dev_reserve(ctx, ctx->d_sums, (size_t)S * kSums * sizeof(double))) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_sums, (size_t)S * (kSums + kAsymRecord) * sizeof(double))) != ELM_OK) return rc;
     if ((rc = dev_reserve(ctx, ctx->d_queue, q_bytes + t_bytes + sizeof(StreamCtrl) + (size_t)count * sizeof(ScanState) + 64)) != ELM_OK) return rc;
     if ((rc = pinned_reserve(ctx, &ctx->h_state, &ctx->h_state_cap, (size_t)count * sizeof(ScanState))) != ELM_OK) return rc;
     if ((rc = dev_reserve(ctx, ctx->d_active, 256)) != ELM_OK) return rc;
@@ -2563,15 +2591,9 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
         rp.sums = (double*)ctx->d_sums.p;
         rp.tickets = (int32_t*)ctx->d_tickets.p;
     }
+    if (pc.asym && (rc = reserve_asym(ctx, rp, blocks, S)) != ELM_OK) return rc;
     ctx->rp = rp;
-    const bool use_nbr = ctx->kernel_mode != 2 && (method == ELM_P2P || method == ELM_GICP);
-    bool use_grid = use_nbr && ctx->kernel_mode == 4 && map->has_grid;
-    if (use_nbr && !use_grid && !map->has_nbr)
-        if ((rc = build_search_index(const_cast<elm_map*>(map), &use_grid)) != ELM_OK) return rc;
-    const bool use_cells = use_nbr && !use_grid && map->has_cells;
-    const bool use_vnbr = ctx->kernel_mode != 2 && (method == ELM_VGICP || method == ELM_AVGICP);
-    if (use_vnbr && !map->has_vnbr)
-        if ((rc = build_voxel_neighbourhoods(const_cast<elm_map*>(map))) != ELM_OK) return rc;
+    const bool use_grid = pc.use_grid, use_cells = pc.use_cells, use_vnbr = pc.use_vnbr;
 
 #define HF_CHK(call)                                                                                   \
     do {                                                                                               \

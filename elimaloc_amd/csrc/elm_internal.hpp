@@ -209,8 +209,14 @@ struct RegParams {
                          // map runs the nine-entry walk with its fallback instead)
     uint32_t* prev;      // [workgroups * kBlock] the winner (grid slot number, -1: none) of every scan point in the slot's previous iteration:
                          // bounds the exact search of the next one (k_accumulate_grid); nullptr: not kept
+    double* asym;        // [workgroups][16] side records of a map with an asymmetric flagged covariance (the strict lower triangle of
+                         // H_w - H_w^T, see asym_side_store in elm_kernels.hip): written by every workgroup of such a launch, reduced by
+                         // k_solve, which restores all 36 entries of J^T M J before the congruence; nullptr on every other map
+    double* asym_sums;   // [scans][16] the scans' reduced side sums when the iteration is split around an exchange (modes 1 / 2 of k_solve;
+                         // laid out right behind the packed sums, so ONE all-reduce carries both)
     double radar_var[3]; // range_variance_m, azimuth_variance_deg, elevation_variance_deg (reg.hpp:77-79)
 };
+constexpr int kAsymRecord = 16; // doubles per side record (15 used)
 constexpr int kRadarRecord = 64; // doubles per partial record of k_accumulate_radar
 
 constexpr int kTileShift = 3, kTile = 1 << kTileShift; // two-level grid: tiles of 8 x 8 columns

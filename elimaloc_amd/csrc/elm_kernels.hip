@@ -939,6 +939,48 @@ __device__ __forceinline__ void block_reduce_pair_sum(const PairSum& P, double* 
     PairReducePass<PP, 0, NVAL>::run(P, buf, red);
     __syncthreads();
 }
+// ---- the antisymmetric side sums (maps with a flagged covariance whose stored inverse is NOT symmetric) -------------------------
+// A rank-deficient neighbourhood whose SVD returns U != V gives the reference a "covariance" U diag(1, 1, 1e-3) V^T that is not
+// symmetric; J^T M J is then not symmetric either, JTJ.ldlt() reads its LOWER triangle and GICP's covariance output inverts the full
+// matrix (reg.cpp:107-113, 136-142; vhm.hpp:141-146, 241-247).  The packed record holds the 21 entries of the UPPER triangle of the
+// world-frame sum H_w = sum J_w^T A J_w (exact for any A: every entry of A is used).  What is missing is D = strict lower triangle of
+// H_w - H_w^T = sum J_w^T (A - A^T) J_w.  With A - A^T = [nu]x (nu = the axial vector of A's antisymmetric part), J_w = [I | -[a]x]
+// and s = a . nu:
+//     J^T [nu]x J = [ [nu]x            .        ]          ([a]x [nu]x = nu a^T - s I,   [a]x [nu]x (-[a]x) = s [a]x)
+//                   [ nu a^T - s I     s [a]x   ]
+// -- fifteen numbers per pair, all zero for a symmetric A.  They travel in a SIDE record of 16 doubles per workgroup
+// (RegParams::asym, written by every workgroup of a launch on such a map: zeros unless one of its pairs is asymmetric) and k_solve
+// restores all 36 entries of H_w before the congruence with P.  Slot order: D(1,0) D(2,0) D(2,1) | D(3+i, j) row-major | D(4,3) D(5,3) D(5,4).
+constexpr int kAsymSums = kAsymRecord;
+// before the block reduction: does this wavefront hold a pair with an asymmetric A?  One flag per wavefront in LDS (every wavefront writes
+// its own, so nothing has to be cleared); the reduction's barriers publish them.
+__device__ __forceinline__ void asym_mark(const double* A, const RegParams& rp, unsigned* s_hitw) {
+    if (!rp.asym) return; // (uniform: the map holds no asymmetric record)
+    const bool hit = (A[7] != A[5]) || (A[2] != A[6]) || (A[3] != A[1]); // never for the compact and the symmetric stored inverses
+    const unsigned long long any = __ballot(hit);
+    if ((threadIdx.x & 63u) == 0u) s_hitw[threadIdx.x >> 6] = any ? 1u : 0u;
+}
+// after the block reduction (its last barrier has passed; `buf` is free again): the workgroup's side record
+__device__ __forceinline__ void asym_side_store(const double* A, double ax, double ay, double az, unsigned L, const RegParams& rp, double* buf, double* red16,
+                                                const unsigned* s_hitw) {
+    if (!rp.asym) return;
+    const unsigned t = threadIdx.x;
+    if (s_hitw[0] | s_hitw[1] | s_hitw[2] | s_hitw[3]) { // (uniform)
+        const double n1 = A[7] - A[5], n2 = A[2] - A[6], n3 = A[3] - A[1];
+        const double s = (ax * n1 + ay * n2) + az * n3;
+        double d[15];
+        d[0] = n3; d[1] = -n2; d[2] = n1;
+        d[3] = n1 * ax - s; d[4] = n1 * ay; d[5] = n1 * az;
+        d[6] = n2 * ax; d[7] = n2 * ay - s; d[8] = n2 * az;
+        d[9] = n3 * ax; d[10] = n3 * ay; d[11] = n3 * az - s;
+        d[12] = s * az; d[13] = -(s * ay); d[14] = s * ax;
+        block_reduce_to_lds<15, 8>(d, buf, red16); // two passes of eight values through the (by now free) reduction buffer
+        if (t < (unsigned)kAsymSums) rp.asym[(size_t)L * kAsymSums + t] = (t < 15u) ? red16[t] : 0.0;
+    } else if (t < (unsigned)kAsymSums) {
+        rp.asym[(size_t)L * kAsymSums + t] = 0.0;
+    }
+}
+
 // one pair into the factored form (add_pair_world's weight, threshold and residual rules)
 template <int METHOD>
 __device__ __forceinline__ void pair_sum_single(PairSum& P, double ex, double ey, double ez, const double* Cinv, const double* nfit, const RegParams& rp) {
@@ -2113,8 +2155,13 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
             if (STATS) { P.c29 = c_cand; P.c30 = c_occ; P.c31 = c_tested; }
         }
     }
+    // maps with an asymmetric flagged covariance (only the instantiations that read stored inverses can meet one): the side record
+    __shared__ double s_asym[(METHOD != ELM_P2P && COMPACT != 2) ? kAsymSums : 1];
+    __shared__ unsigned s_hitw[kBlock / 64];
+    if (METHOD != ELM_P2P && COMPACT != 2) asym_mark(P.A, rp, s_hitw);
     if (METHOD == ELM_P2P) block_reduce_to_lds<NV, kRedPass>(v, s_buf, s_red);
     else block_reduce_pair_sum<kRedPass, STATS ? kSums : kSums - 3>(P, s_buf, s_red);
+    if (METHOD != ELM_P2P && COMPACT != 2) asym_side_store(P.A, P.ax, P.ay, P.az, L, rp, s_buf, s_asym, s_hitw);
     const int tk = (int)threadIdx.x;
     publish_and_reduce((tk < kSums && (STATS || tk < kSums - 3)) ? ((METHOD == ELM_P2P) ? p2p_expand(s_red, tk) : s_red[tk]) : 0.0, L, s, sd.blk_begin,
                        sd.blk_end, partials, rp, s_buf);
@@ -2506,7 +2553,19 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
             if (STATS && FACES != 3) { P.c29 = n_pairs; P.c30 = n_pairs; P.c31 = n_pairs; } // (the fused walk has counted every record)
         }
     }
+    // The side record of maps with an asymmetric flagged covariance (asym_side_store): every instantiation that reads stored inverses
+    // computes it; the fused walk on a map with flagged voxels (FACES = 4) has skipped those pairs and writes zeros, which its fix-up
+    // launch (FACES = 3, marked workgroups only) overwrites.  Clean maps (COMPACT = 2 / FACES = 2) never carry the pointer.
+    __shared__ double s_asym[(COMPACT == 2 || FACES == 2) ? 1 : kAsymSums];
+    __shared__ unsigned s_hitw[kBlock / 64];
+    constexpr bool kAsymHere = COMPACT != 2 && FACES != 2 && FACES != 4;
+    if (kAsymHere) asym_mark(P.A, rp, s_hitw);
     block_reduce_pair_sum<kRedPass, STATS ? kSums : kSums - 3>(P, s_buf, s_red);
+    if (FACES == 4) {
+        if (rp.asym && threadIdx.x < (unsigned)kAsymSums) rp.asym[(size_t)L * kAsymSums + threadIdx.x] = 0.0;
+    } else if (kAsymHere) {
+        asym_side_store(P.A, P.ax, P.ay, P.az, L, rp, s_buf, s_asym, s_hitw);
+    }
     if (FACES == 3) { // added to the record the fused walk of this workgroup wrote earlier on the stream (the solve's reduction comes after both)
         if (threadIdx.x < (unsigned)kSums - 3u) partials[(size_t)L * kSums + threadIdx.x] += s_red[threadIdx.x];
         return;
@@ -2985,7 +3044,11 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : 1) void k_solve(const ScanDesc*
     const bool done = S.done != 0;
     const bool fused = rp.tickets != nullptr; // the accumulate kernels' last workgroups have left the scan's sums in `sums`
     const bool radar = rp.radar != 0;         // k_accumulate_radar's records: 64 doubles, all 36 entries of J^T M J (single GPU, unfused)
-    __shared__ double full[36];               // radar: J^T M J row-major
+    __shared__ double full[36];               // radar / asymmetric side sums: J^T M J row-major, all 36 entries
+    // a map with an asymmetric flagged covariance: the accumulate kernels also wrote 16-double side records (asym_side_store)
+    const bool asym = rp.asym != nullptr && !radar && rp.method != ELM_P2P;
+    __shared__ double dsum[kAsymSums];        // the scan's side sums: the strict lower triangle of H_w - H_w^T
+    __shared__ double apart[kSolveThreads / kAsymSums][kAsymSums];
     if (radar) {
         // multi-rank: mode 1 leaves the 64 sums of the scan in sums[s][64] for the all-reduce, mode 2 (one wavefront) reads them back
         double a = 0.0;
@@ -3051,6 +3114,26 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : 1) void k_solve(const ScanDesc*
 #pragma unroll 1
             for (int g = t >> 5; g < (int)G; g += NT / 32) part[g][k] = group_sum(g);
         }
+        if (asym) {
+            // the side records, 64 groups of 16 lanes, one running sum per group (trailing all-zero records of a slot sized for a larger
+            // scan change nothing), the groups added in a fixed order below
+            constexpr int GA = kSolveThreads / kAsymSums;
+            const int k2 = t & (kAsymSums - 1);
+            auto side_sum = [&](int g) -> double {
+                double v = 0.0;
+                if (!done) {
+                    const ScanDesc sd = scans[s];
+                    for (unsigned b = sd.blk_begin + (unsigned)g; b < sd.blk_end; b += (unsigned)GA) v += rp.asym[(size_t)b * kAsymSums + k2];
+                }
+                return v;
+            };
+            if (NT == kSolveThreads) {
+                apart[t / kAsymSums][k2] = side_sum(t / kAsymSums);
+            } else {
+#pragma unroll 1
+                for (int g = t / kAsymSums; g < GA; g += NT / kAsymSums) apart[g][k2] = side_sum(g);
+            }
+        }
         __syncthreads();
         if (t < 32) {
             double a = part[0][t];
@@ -3058,11 +3141,20 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : 1) void k_solve(const ScanDesc*
             for (int q = 1; q < kSolveThreads / 32; ++q) a += part[q][t];
             if (mode == 1) sums[(size_t)s * kSums + t] = a; // zeros for finished scans keep the all-reduce buffer defined
             else tot[t] = a;
+        } else if (asym && t < 32 + kAsymSums) {
+            const int k2 = t - 32;
+            double a = apart[0][k2];
+#pragma unroll 1
+            for (int q = 1; q < kSolveThreads / kAsymSums; ++q) a += apart[q][k2];
+            if (mode == 1) rp.asym_sums[(size_t)s * kAsymSums + k2] = a;
+            else dsum[k2] = a;
         }
         if (mode == 1) return;
     } else {
         // (a scan without a single workgroup -- no points on this rank -- has no record and no sums: zeros)
         if (t < 32) tot[t] = (scans[s].blk_end > scans[s].blk_begin) ? sums[(size_t)s * kSums + t] : 0.0;
+        else if (asym && t < 32 + kAsymSums) // (the fused reduction does not produce side sums: the host never combines the two)
+            dsum[t - 32] = (rp.asym_sums && scans[s].blk_end > scans[s].blk_begin) ? rp.asym_sums[(size_t)s * kAsymSums + (t - 32)] : 0.0;
     }
     __syncthreads();
     if (t >= 64) return; // the first wave does the rest with uniform control flow; lane 0 owns the state
@@ -3073,13 +3165,25 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : 1) void k_solve(const ScanDesc*
     }
     const bool lead = (t == 0);
 
+    // Side sums that are not all zero: this iteration's J^T M J is not symmetric (some pair met an asymmetric stored inverse) -- all 36
+    // entries are carried from here on, the factorisation reads the lower triangle and GICP's covariance output inverts the full matrix,
+    // as for use_radar_cov.  All zero (every iteration of every ordinary registration on such a map): the symmetric path, bit for bit.
+    bool nonsym = false;
+    if (asym) {
+#pragma unroll 1
+        for (int k = 0; k < 15; ++k) nonsym = nonsym || (dsum[k] != 0.0);
+    }
+
     if (rp.method != ELM_P2P && !radar) {
         // the covariance-weighted kernels accumulate in the world frame (add_pair_world): H_l = P^T H_w P, b_l = P^T b_w with
         // P = diag(R, R), R the rotation the pairs were formed with (S.T is updated further down)
         __shared__ double hw[36], bw[6];
         if (t < 36) {
             const int i = t / 6, j = t % 6;
-            hw[t] = tot[tri(i < j ? i : j, i < j ? j : i)];
+            double hv = tot[tri(i < j ? i : j, i < j ? j : i)];
+            if (nonsym && i > j) // lower triangle = upper triangle + D (slot order of asym_side_store)
+                hv += dsum[(i < 3) ? (i - 1 + j) : (j < 3) ? (3 + (i - 3) * 3 + j) : (9 + i + j - 3 - 1)];
+            hw[t] = hv;
         }
         if (t < 6) bw[t] = tot[21 + t];
         __builtin_amdgcn_s_waitcnt(0);
@@ -3094,6 +3198,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : 1) void k_solve(const ScanDesc*
                 h += S.T[ii * 4 + k] * row;
             }
             if (i <= j) tot[tri(i, j)] = h;
+            if (nonsym) full[t] = h;
         }
         if (t < 6) {
             const int bi = (t / 3) * 3, ii = t % 3;
@@ -3143,12 +3248,13 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : 1) void k_solve(const ScanDesc*
     // JTJ + lambda * diag(JTJ), one element per lane (reg.cpp:55-56 / 136-138 / 213-214)
     const int li = (t < 36) ? t / 6 : 0, lj = (t < 36) ? t % 6 : 0;
     // (radar: JTJ is not symmetric and JTJ.ldlt() reads its lower triangle -- the factorisation of the symmetric matrix with that triangle)
-    const double hij = radar ? full[(li < lj ? lj : li) * 6 + (li < lj ? li : lj)] : tot[tri(li < lj ? li : lj, li < lj ? lj : li)];
+    const bool full36 = radar || nonsym;
+    const double hij = full36 ? full[(li < lj ? lj : li) * 6 + (li < lj ? li : lj)] : tot[tri(li < lj ? li : lj, li < lj ? lj : li)];
     const double a = (li == lj) ? hij + rp.lm_lambda * hij : hij;
     double x[6], inv_elem;
-    wave_ldlt6(a, &tot[21], x, rp.method == ELM_GICP && !radar, inv_elem);
-    if (rp.method == ELM_GICP && !radar && t < 36) S.local_cov[t] = inv_elem; // reg.cpp:141-142 (symmetric: layout-free)
-    if (rp.method == ELM_GICP && radar) {
+    wave_ldlt6(a, &tot[21], x, rp.method == ELM_GICP && !full36, inv_elem);
+    if (rp.method == ELM_GICP && !full36 && t < 36) S.local_cov[t] = inv_elem; // reg.cpp:141-142 (symmetric: layout-free)
+    if (rp.method == ELM_GICP && full36) {
         // JTJ_regularized.inverse() of the FULL matrix (reg.cpp:141-142): Eigen's PartialPivLU + solve against the identity; column-major out
         __shared__ double lu[36], invm[36], lu_work[12];
         if (t < 36) lu[t] = (li == lj) ? full[t] + rp.lm_lambda * full[t] : full[t];
@@ -3171,7 +3277,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : 1) void k_solve(const ScanDesc*
     }
     Tn[3] = 0.0; Tn[7] = 0.0; Tn[11] = 0.0; Tn[15] = 1.0;
     const double step = matrix_to_angle(dR) + sqrt((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2]); // reg.cpp:381-384
-    if (tr && t < 36) tr->JTJ[t] = radar ? full[lj * 6 + li] : hij; // column-major (symmetric unless radar)
+    if (tr && t < 36) tr->JTJ[t] = full36 ? full[lj * 6 + li] : hij; // column-major (symmetric unless radar / asymmetric side sums)
     bool fin = false;
     if (lead) {
         S.fitness = fitness;

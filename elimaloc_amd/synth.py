@@ -59,6 +59,20 @@ def make_world(n_points, seed=1001):
     return np.ascontiguousarray(pts.astype(np.float32))
 
 
+def collinear_triples(base, n_triples, seed, z=(1.2, 1.8), spacing=0.25):
+    """3 n points: n isolated triples (c - s d, c, c + s d) along random directions d, centres over the central half of `base`'s extent at
+    heights `z` (clear of the ground lattice and of each other's 0.4 m neighbourhoods with overwhelming probability).  A collinear
+    neighbourhood has a rank-1 sample covariance: the reference's JacobiSVD regularisation U diag(1, 1, 1e-3) V^T (vhm.hpp:141-146,
+    241-247) then returns U != V for most of them and the stored "covariance" is NOT symmetric -- what thin poles, wires and edges do to a
+    real map.  Used by the tests and by `bench.py --asym-triples` to put such records into an otherwise ordinary world."""
+    rng = np.random.default_rng(seed)
+    ext = 0.5 * np.abs(base[:, :2]).max(axis=0).astype(np.float64)
+    c = np.column_stack([rng.uniform(-ext[0], ext[0], n_triples), rng.uniform(-ext[1], ext[1], n_triples), rng.uniform(z[0], z[1], n_triples)])
+    d = rng.normal(size=(n_triples, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    return np.ascontiguousarray(np.concatenate([c - spacing * d, c, c + spacing * d]).astype(np.float32))
+
+
 def rot_zyx(roll, pitch, yaw):
     cr, sr, cp, sp, cy, sy = math.cos(roll), math.sin(roll), math.cos(pitch), math.sin(pitch), math.cos(yaw), math.sin(yaw)
     return np.array([[cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
@@ -92,9 +106,17 @@ def rows_times(d, R):
 _EXTENT_CACHE = {}
 
 
+def _array_key(a):
+    """Identity of a world array for the per-array caches: address + size + a content fingerprint (first / middle / last rows), so that a
+    world freed and another of the same length allocated at the same address does not inherit the old one's cache entry."""
+    n = a.shape[0]
+    fp = tuple(np.asarray(a[[0, n // 2, n - 1]], dtype=np.float64).ravel().tolist()) if n else ()
+    return (a.ctypes.data, n, fp)
+
+
 def _xy_extent(map_xyz):
     """max |x|, |y| over the map (cached per array: 10 M points cost 0.1-0.2 s, once per scan before)."""
-    key = (map_xyz.ctypes.data, map_xyz.shape[0])
+    key = _array_key(map_xyz)
     ext = _EXTENT_CACHE.get(key)
     if ext is None:
         ext = float(np.max(np.abs(map_xyz[:, :2])))
@@ -126,7 +148,7 @@ def _near_indices(map_xyz, centre, max_range, tile=32.0):
     if n < 2_000_000:
         d = map_xyz.astype(np.float64) - centre
         return np.flatnonzero(np.einsum("ij,ij->i", d, d) < max_range * max_range)
-    key = (map_xyz.ctypes.data, n)
+    key = _array_key(map_xyz)
     idx = _TILE_CACHE.get(key)
     if idx is None:
         tx = np.floor(map_xyz[:, 0] / tile).astype(np.int64)

@@ -1312,13 +1312,104 @@ def test_avgicp_fused_walk_with_flagged_voxels_fix_up_launch(oracle, monkeypatch
         assert ref["iterations"] == a["iterations"] and dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
 
 
-def test_strict_pairs_switch_is_exact_on_asymmetric_flagged_covariances():
+def _asym_case(n_base=1500, n_triples=150, seed=11):
+    """The jittered world + isolated collinear triples (synth.collinear_triples: rank-1 neighbourhoods whose regularised covariance is not
+    symmetric), and scans that contain every triple point beside a sample of the ordinary world."""
+    base = synth.make_world(100000, seed=1001)
+    tri = synth.collinear_triples(base, n_triples, seed=5)
+    world = np.ascontiguousarray(np.concatenate([base, tri]))
+    scans, T0s = [], []
+    for k in range(3):
+        rng = np.random.default_rng(seed + k)
+        T_true = np.eye(4)
+        T_true[:3, :3] = synth.rot_zyx(0.01, -0.02, 0.7 + k)
+        T_true[:3, 3] = [1.3 - k, -2.2 + 2 * k, 0.8]
+        pick = np.concatenate([base[rng.integers(0, len(base), n_base + 300 * k)], tri]).astype(np.float64)
+        sc = synth.rows_times(pick + rng.normal(0, 0.01, pick.shape) - T_true[:3, 3], T_true[:3, :3])
+        scans.append(np.ascontiguousarray(sc.astype(np.float32)))
+        T0s.append(synth.perturb(T_true, seed=5 + k, max_trans=0.1, max_rot_deg=0.5))
+    return world, scans, T0s
+
+
+@pytest.mark.parametrize("method", [1, 2, 3])
+def test_asymmetric_covariances_travel_in_side_records(oracle, method, monkeypatch):
     """a rank-deficient neighbourhood whose SVD returns U != V gives the reference an ASYMMETRIC regularised
-    covariance; the fast kernels pack the symmetric 21 sums and would deviate there (fuzz case 813687: GICP, exact lattice, one point per
-    voxel -- J^T J off by the reference matrix's own asymmetry, pose still inside the tolerance).  The covariance kernels count such
-    records (layout bits 7 / 8) and a map that holds one runs the reference's per-pair arithmetic (all 36 entries, LDLT on the lower
-    triangle): the DEFAULT agrees with the oracle to the 1e-9 bar on that case; ELM_STRICT_PAIRS=0 keeps the fast kernels and shows the
-    deviation the routing removes; ELM_STRICT_PAIRS=1 forces the per-pair arithmetic on every map."""
+    covariance; J^T M J is then not symmetric, LDLT reads its lower triangle and GICP's covariance output inverts the full matrix
+    (reg.cpp:107-113, 136-142).  The fast kernels pack the 21 upper entries of the world-frame sums; on a map that holds such a record
+    (layout bits 7 / 8) they also write the 15 entries of the antisymmetric part into side records, and the solve restores all 36
+    entries (asym_side_store).  DEFAULT == the oracle to the 1e-9 bar on every iteration's sums, == the per-pair checker
+    (ELM_STRICT_PAIRS=1), on single registrations and through the stream; ELM_STRICT_PAIRS=0 (fast kernels without the side records,
+    the behaviour before round 5) shows the deviation the records remove."""
+    from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, Scan
+    m = IcpMethod(method)
+    world, scans, T0s = _asym_case()
+    runs, streams, covs = {}, {}, {}
+    om = None
+    for mode in (None, "1", "0"):
+        if mode is None:
+            monkeypatch.delenv("ELM_STRICT_PAIRS", raising=False)
+        else:
+            monkeypatch.setenv("ELM_STRICT_PAIRS", mode)
+        c = Context(0)
+        try:
+            vm, om_ = _maps(c, oracle, world, m)
+            om = om or om_
+            bits = int(vm.info().layout_flags)
+            assert bits & (128 if method == 1 else 256), bits  # the map does hold asymmetric records of this method's kind
+            reg = Registration(RegistrationConfig(icp_method=m), c)
+            outs = [reg.RunRegister(sc, vm, T0, trace=True) for sc, T0 in zip(scans, T0s)]
+            runs[mode] = [o[-1] for o in outs]
+            covs[mode] = [o[3] for o in outs]
+            streams[mode] = reg.RunRegisterStream([Scan(c, sc) for sc in scans], vm, T0s, slots=2)
+        finally:
+            c.close()
+    worst_fast = 0.0
+    for k, (sc, T0) in enumerate(zip(scans, T0s)):
+        ref = oracle.register(om, sc, T0, oracle.default_config(method))
+        J0 = ref["iters"][0]["JTJ"]
+        assert np.abs(J0 - J0.T).max() > 1e-8 * np.abs(J0).max()  # the reference's matrix is not symmetric here
+        _compare_run(runs[None][k], ref)   # the default: side records
+        _compare_run(runs["1"][k], ref)    # the per-pair checker
+        if method == 1:  # GICP's covariance output: the inverse of the FULL damped matrix
+            np.testing.assert_allclose(covs[None][k], ref["local_cov"], rtol=1e-6, atol=1e-9 * np.abs(ref["local_cov"]).max())
+        for g, r in zip(runs["0"][k]["iters"], ref["iters"]):
+            worst_fast = max(worst_fast, float(np.abs(g["JTJ"] - r["JTJ"]).max() / np.abs(r["JTJ"]).max()))
+        st = streams[None][k]  # continuous batching (device-ordered scan: another summation tree)
+        assert st["iterations"] == ref["iterations"] and st["is_success"] == ref["is_success"]
+        np.testing.assert_allclose(st["T"], runs[None][k]["T"], rtol=0, atol=1e-9)
+        if method == 1:
+            np.testing.assert_allclose(st["local_cov"], ref["local_cov"], rtol=1e-6, atol=1e-9 * np.abs(ref["local_cov"]).max())
+    assert worst_fast > 10 * SUM_RTOL  # without the side records the sums are off by the antisymmetric part
+
+
+@pytest.mark.parametrize("method,stream", [(1, True), (2, False), (3, True)])
+def test_asymmetric_covariances_two_ranks(oracle, method, stream, monkeypatch):
+    """The side sums under an exchange: two real ranks on one GPU, every scan sharded in two, the all-reduce carrying 32 + 16 doubles per
+    scan on such a map.  Ranks bit-identical, the oracle's trajectory."""
+    from elimaloc_amd.registration import IcpMethod
+    monkeypatch.delenv("ELM_STRICT_PAIRS", raising=False)
+    m = IcpMethod(method)
+    world, scans, T0s = _asym_case()
+    res = _run_two_ranks(world, scans, T0s, m, stream=stream, slots=2)
+    om = oracle.Map(1.0, 30)
+    om.add_points(world)
+    if m in (IcpMethod.VGICP, IcpMethod.AVGICP):
+        om.cal_voxel_cov_all()
+    else:
+        om.cal_point_cov_all(0.4)
+    for k in range(len(scans)):
+        a, b = res[0][k], res[1][k]
+        assert np.array_equal(a["T"], b["T"]) and a["iterations"] == b["iterations"] and a["is_success"] == b["is_success"]
+        ref = oracle.register(om, scans[k], T0s[k], oracle.default_config(method))
+        assert (a["iterations"], a["is_success"]) == (ref["iterations"], ref["is_success"]), k
+        np.testing.assert_allclose(a["T"], ref["T"], rtol=0, atol=1e-9)
+        if method == 1:
+            np.testing.assert_allclose(a["local_cov"], ref["local_cov"], rtol=1e-6, atol=1e-9 * np.abs(ref["local_cov"]).max())
+
+
+def test_fuzz_case_with_asymmetric_covariances():
+    """Fuzz case 813687 (GICP, 0.4 m voxels, one point per voxel, exact lattice: the case that exposed the symmetric packing): the default
+    agrees with the oracle, ELM_STRICT_PAIRS=0 reproduces the old deviation (pose still inside the north_star tolerance), =1 agrees."""
     import os
     import subprocess
     import sys
@@ -1340,8 +1431,8 @@ def test_strict_pairs_switch_is_exact_on_asymmetric_flagged_covariances():
 
 
 def test_ordinary_maps_carry_no_asymmetric_covariance_and_stay_on_the_fast_kernels(ctx, world100k):
-    """Layout bits 7 / 8 (a flagged covariance with an asymmetric stored inverse -> per-pair arithmetic) are clear on the jittered world and
-    on the crafted rank-1 voxels of the fix-up test: the routing of section 5 (ii) costs ordinary maps nothing."""
+    """Layout bits 7 / 8 (a flagged covariance with an asymmetric stored inverse -> side records) are clear on the jittered world and
+    on the crafted rank-1 voxels of the fix-up test: ordinary maps do not even write the side records."""
     from elimaloc_amd.registration import VoxelHashMap
     rng = np.random.default_rng(5)
     xy = rng.uniform(-25, 25, (60, 2))
