@@ -129,7 +129,7 @@ EXPORTS = [
     "elm_ctx_synchronize", "elm_ctx_stream", "elm_ctx_set_profiling", "elm_ctx_set_work_counters", "elm_ctx_get_profile", "elm_map_build", "elm_map_destroy", "elm_map_cal_voxel_cov_all",
     "elm_map_cal_point_cov_all", "elm_map_build_neighbourhoods", "elm_map_get_info", "elm_map_empty", "elm_map_download_points",
     "elm_map_download_voxels", "elm_map_find_ground_height", "elm_scan_upload", "elm_scan_destroy",
-    "elm_scan_size", "elm_scan_download", "elm_register", "elm_register_batch", "elm_register_stream", "elm_register_stream_host", "elm_host_alloc", "elm_host_free", "elm_ctx_measure_h2d", "elm_register_batch_enqueue",
+    "elm_scan_size", "elm_scan_download", "elm_register", "elm_format_register_log", "elm_register_batch", "elm_register_stream", "elm_register_stream_host", "elm_host_alloc", "elm_host_free", "elm_ctx_measure_h2d", "elm_register_batch_enqueue",
     "elm_register_batch_finish", "elm_deskew", "elm_deskew_downsample", "elm_deskew_prepare", "elm_comm_get_unique_id", "elm_comm_init",
     "elm_comm_destroy", "elm_comm_info", "elm_comm_set_hook", "elm_filter_points_by_distance", "elm_voxel_downsample",
     "elm_get_interpolated_pose", "elm_shape_odom_covariance",
@@ -214,6 +214,9 @@ def lib():
     L.elm_ctx_synchronize.argtypes = [vp]
     L.elm_ctx_stream.argtypes = [vp]
     L.elm_ctx_stream.restype = vp
+    L.elm_format_register_log.argtypes = [C.POINTER(RegConfig), C.POINTER(RegResult), C.c_size_t, C.POINTER(IterTrace), C.POINTER(C.c_double),
+                                          C.c_double, C.c_char_p, C.c_size_t]
+    L.elm_format_register_log.restype = C.c_size_t
     L.elm_ctx_set_profiling.argtypes = [vp, C.c_int]
     L.elm_ctx_set_work_counters.argtypes = [vp, C.c_int]
     L.elm_ctx_get_profile.argtypes = [vp, C.POINTER(Profile), C.c_int]

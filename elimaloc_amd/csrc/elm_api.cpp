@@ -9,6 +9,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <new>
@@ -141,6 +142,8 @@ struct elm_ctx {
     int iter_hint = 0;       // iterations the longest of the last eight batches needed (0 = unknown): first early-stop check happens there
     int iter_ring[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned iter_ring_pos = 0;
+    const void* iter_key_map = nullptr; // the history belongs to ONE kind of call: (map, method, batch size); another kind starts afresh
+    int iter_key_method = -1, iter_key_batch = 0;
     void* h_state = nullptr; // pinned
     size_t h_state_cap = 0;
     void* h_trace = nullptr; // pinned
@@ -167,6 +170,8 @@ struct elm_ctx {
                          // 2 = the plain 27-probe walk of k_accumulate_direct (ELM_KERNEL=direct: in-kernel reference for tests)
     // optional hipEvent timing
     bool profiling = false;
+    bool keep_iter_ms = false;         // prof_collect also keeps every accumulate span of the call (b_debug_print: the reference's
+    std::vector<double> iter_acc_ms;   // per-iteration "Total Correspondence Time for" lines)
     std::vector<hipEvent_t> events;
     int events_used = 0;
     elm_profile prof{};
@@ -880,8 +885,12 @@ static int build_voxel_neighbourhoods(elm_map* m) {
             (void)hipGetLastError();
             // the fused AVGICP walk's record format; flagged voxels (NaN normals) are left to its fix-up launch (ELM_AVG_FIXUP=0: such maps
             // keep the nine-entry walk with its in-line fallback)
+            // The fix-up launch pays while few workgroups meet a flagged record (round 4: +14 % with 0.3 % of the voxels flagged); when
+            // flagged voxels are common -- sparse clutter: two or three points per voxel, rank-deficient -- nearly every workgroup is marked,
+            // the second launch repeats the whole walk, and the in-line fallback is the cheaper form: by default the map decides at 1 % of
+            // its voxels (ELM_AVG_FIXUP=1 / 0 force either form).
             const char* fx = std::getenv("ELM_AVG_FIXUP");
-            const bool fixup_ok = !(fx && strcmp(fx, "0") == 0);
+            const bool fixup_ok = fx ? strcmp(fx, "0") != 0 : (uint64_t)m->n_bad_vox * 100ull <= (uint64_t)m->dm.n_vox;
             const int plain = (m->dm.vox_compact && (m->n_bad_vox == 0 || fixup_ok) && !std::getenv("ELM_AVG_NINE") && !std::getenv("ELM_PAIR_NINE")) ? 1 : 0;
             launch_vface(ctx->stream, m->d_vnbr, d_off, d_nocc, n_q, d_fcnt, nullptr, nullptr, plain);
             VF_CHK(hipGetLastError());
@@ -1855,7 +1864,7 @@ static int prof_collect(elm_ctx* ctx) {
         for (int k = 0; k + 1 < ctx->events_used; ++k) {
             float ms = 0.f;
             HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->events[k], ctx->events[k + 1]));
-            if ((k & 1) == 0) { ctx->prof.accumulate_ms += ms; ctx->prof.accumulate_launches++; }
+            if ((k & 1) == 0) { ctx->prof.accumulate_ms += ms; ctx->prof.accumulate_launches++; if (ctx->keep_iter_ms) ctx->iter_acc_ms.push_back(ms); }
             else { ctx->prof.solve_ms += ms; ctx->prof.solve_steps++; }
         }
     }
@@ -1874,6 +1883,13 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int method = cfg->icp_method;
     const bool map_empty = map->dm.n_vox == 0;
+    if (ctx->iter_key_map != (const void*)map || ctx->iter_key_method != method || ctx->iter_key_batch != batch) {
+        // (a registration that ran to max_iteration on another map / method / batch shape must not push THIS call's first early-stop
+        // check -- and the graph's length -- to its count)
+        ctx->iter_key_map = map; ctx->iter_key_method = method; ctx->iter_key_batch = batch;
+        for (int k = 0; k < 8; ++k) ctx->iter_ring[k] = 0;
+        ctx->iter_hint = 0;
+    }
     // (use_radar_cov on several ranks: the all-reduce carries the radar kernel's 64 sums per scan instead of the 32 of the packed layout)
     if (!map_empty) {
         if ((method == ELM_VGICP || method == ELM_AVGICP) && !map->info.has_voxel_cov) {
@@ -1966,6 +1982,7 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
         rp.tickets = (int32_t*)ctx->d_tickets.p;
     }
     if (pc.asym && (rc = reserve_asym(ctx, rp, blocks, batch)) != ELM_OK) return rc;
+    rp.rank_check = ((ctx->comm || ctx->hook) && !radar && !rp.tickets && !rp.stats) ? 1 : 0;
     ctx->rp = rp;
 
     // the search index (choose_path built it on first use): dense / two-level cell grid, else the cell-indexed neighbourhood lists, else
@@ -1998,7 +2015,7 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
             HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
             hipError_t ce = hipMemcpyAsync(ctx->d_scans.p, hd, sizeof(ScanDesc), hipMemcpyHostToDevice, ctx->stream);
             if (ce == hipSuccess) ce = hipMemcpyAsync(ctx->d_T0.p, hT, 16 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-            if (ce == hipSuccess) ce = hipMemsetAsync(d_active, 0, sizeof(int), ctx->stream);
+            if (ce == hipSuccess) ce = hipMemsetAsync(d_active, 0, 2 * sizeof(int), ctx->stream);
             if (ce == hipSuccess) {
                 launch_init_state(ctx->stream, st, (const double*)ctx->d_T0.p, 1, 0, d_active, rp.tickets);
                 for (int it = 0; it < K; ++it) {
@@ -2044,7 +2061,7 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
         }
         launch_init_pack(ctx->stream, (ScanDesc*)ctx->d_scans.p, st, pack, batch, map_empty ? 1 : 0, d_active, n_dev, rp.tickets);
     } else {
-        HIPCHK(ctx, hipMemsetAsync(d_active, 0, sizeof(int), ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(d_active, 0, 2 * sizeof(int), ctx->stream));
         launch_init_state(ctx->stream, st, (const double*)ctx->d_T0.p, batch, map_empty ? 1 : 0, d_active, rp.tickets);
     }
     const bool distributed = (ctx->comm != nullptr) || (ctx->hook != nullptr);
@@ -2137,6 +2154,10 @@ extern "C" int elm_register_batch_finish(elm_ctx* ctx, elm_reg_result* results, 
         if (prc != ELM_OK) return prc;
     }
     const ScanState* hs = (const ScanState*)ctx->h_state;
+    if (ctx->rp.rank_check && ((const int*)((const char*)ctx->h_state + (size_t)ctx->batch * sizeof(ScanState)))[1] != 0) {
+        ctx->last_error = "the ranks iterated different registrations in one slot (rank-agreement check of the exchanged sums)";
+        return ELM_ERR_COMM;
+    }
     for (int b = 0; results && b < ctx->batch; ++b) state_to_result(hs[b], ctx->rp, results[b]);
     {
         int mx = 0;
@@ -2228,7 +2249,7 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
         hd[s].pts = nullptr; hd[s].n = 0; hd[s].n_total = 0;
         hd[s].blk_begin = cap_blocks * rel; hd[s].blk_end = cap_blocks * (rel + 1);
     }
-    hc->next = 0; hc->completed = 0; hc->total = count; hc->ready = count;
+    hc->next = 0; hc->completed = 0; hc->total = count; hc->ready = count; hc->done_iter = -1;
     if ((rc = dev_reserve(ctx, ctx->d_scans, d_bytes)) != ELM_OK) return rc;
     if ((rc = dev_reserve(ctx, ctx->d_state, (size_t)S * sizeof(ScanState))) != ELM_OK) return rc;
     if ((rc = dev_reserve(ctx, ctx->d_partials, (size_t)std::max<uint32_t>(blocks, 1) * kSums * sizeof(double))) != ELM_OK) return rc;
@@ -2253,7 +2274,7 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     HIPCHK(ctx, hipMemcpyAsync(d_q, hq, q_bytes + t_bytes, hipMemcpyHostToDevice, ctx->stream)); // items + guesses are contiguous
     HIPCHK(ctx, hipMemcpyAsync(d_ctrl, hc, sizeof(StreamCtrl), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_scans.p, hd, d_bytes, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_active.p, 0, sizeof(int), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_active.p, 0, 2 * sizeof(int), ctx->stream));
 
     RegParams rp;
     memset(&rp, 0, sizeof(rp)); // (padding too: the registration graph compares it bytewise)
@@ -2284,6 +2305,7 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
         rp.tickets = (int32_t*)ctx->d_tickets.p;
     }
     if (pc.asym && (rc = reserve_asym(ctx, rp, blocks, S)) != ELM_OK) return rc;
+    rp.rank_check = ((ctx->comm || ctx->hook) && !rp.tickets && !rp.stats) ? 1 : 0;
     ctx->rp = rp;
     const bool use_grid = pc.use_grid, use_cells = pc.use_cells, use_vnbr = pc.use_vnbr;
 
@@ -2352,16 +2374,16 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
                     // ... or a refill launch of its own (4 launches + 1 collective): ONE workgroup walks the slots in slot order and hands the
                     // finished ones the next pending registrations -- first come, first served like the single-rank stream, yet identical on
                     // every rank (the finished flags derive from the all-reduced sums), so no slot idles while the queue has work
-                    const StreamArgs sv = {dsc_h, d_q, d_qT0, d_out, d_ctrl, 0, /*save_only*/ 1, 0}; // the solve saves + counts, the refill assigns
+                    const StreamArgs sv = {dsc_h, d_q, d_qT0, d_out, d_ctrl, 0, /*save_only*/ 1, 0, it}; // the solve saves + counts, the refill assigns
                     launch_solve(ss, dsc_h, Sh, st_h, partials_h, sums_h, rph, d_trace, 2, d_active, &sv);
                     launch_stream_refill(ss, dsc, st, S, d_q, d_qT0, d_out, d_ctrl, 0, /*save*/ 0);
                 } else {
-                    const StreamArgs sr = {dsc_h, d_q, d_qT0, d_out, d_ctrl, 0, 0, S};
+                    const StreamArgs sr = {dsc_h, d_q, d_qT0, d_out, d_ctrl, 0, 0, S, it};
                     launch_solve(ss, dsc_h, Sh, st_h, partials_h, sums_h, rph, d_trace, 2, d_active, &sr);
                 }
             } else {
                 // single rank: the solve hands finished slots their next registration itself (no refill launch)
-                const StreamArgs sa = {dsc_h, d_q, d_qT0, d_out, d_ctrl, 0, 0, 0};
+                const StreamArgs sa = {dsc_h, d_q, d_qT0, d_out, d_ctrl, 0, 0, 0, it};
                 launch_solve(ss, dsc_h, Sh, st_h, partials_h, sums_h, rph, d_trace, 0, d_active, &sa);
             }
             if (H == 2) {
@@ -2388,11 +2410,22 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     if (trace)
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_trace, ctx->d_trace.p, (size_t)count * ELM_MAX_ITER_TRACE * sizeof(elm_iter_trace),
                                    hipMemcpyDeviceToHost, ctx->stream));
+    ctx->h_active[2] = 0;
+    if (rp.rank_check) HIPCHK(ctx, hipMemcpyAsync(ctx->h_active + 2, d_active + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->h_active[3] = -1;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_active + 3, &d_ctrl->done_iter, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if ((rc = prof_collect(ctx)) != ELM_OK) return rc;
+    if (ctx->h_active[2] != 0) {
+        ctx->last_error = "the ranks iterated different registrations in one slot (rank-agreement check of the exchanged sums)";
+        return ELM_ERR_COMM;
+    }
     ctx->stream_hint_count = count;
     ctx->stream_hint_slots = S;
-    ctx->stream_hint_iters = it;
+    // what the next call of this shape enqueues before it first looks: the iterations this one NEEDED (the device notes the iteration
+    // whose solve finished the last registration) -- not the count at which the host happened to look, which can only grow: a call
+    // with poor initial guesses would leave every later call of the shape enqueueing its iteration count in empty launches
+    ctx->stream_hint_iters = (ctx->h_active[3] >= 0) ? std::min(it, ctx->h_active[3] + 1) : it;
     const ScanState* hs = (const ScanState*)ctx->h_state;
     for (int b = 0; results && b < count; ++b) state_to_result(hs[b], rp, results[b]);
     if (trace) memcpy(trace, ctx->h_trace, (size_t)count * ELM_MAX_ITER_TRACE * sizeof(elm_iter_trace));
@@ -2542,7 +2575,7 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
     StreamCtrl* hc = (StreamCtrl*)((char*)ctx->h_desc + q_bytes + t_bytes);
     for (int b = 0; b < count; ++b) { hq[b].pts = hj[b].dst; hq[b].n = n_pts[b]; hq[b].n_total = n_pts[b]; }
     memcpy(hT, T0, t_bytes);
-    hc->next = 0; hc->completed = 0; hc->total = count; hc->ready = 0;
+    hc->next = 0; hc->completed = 0; hc->total = count; hc->ready = 0; hc->done_iter = -1;
     if ((rc = dev_reserve(ctx, ctx->d_scans, d_bytes)) != ELM_OK) return rc;
     if ((rc = dev_reserve(ctx, ctx->d_state, (size_t)S * sizeof(ScanState))) != ELM_OK) return rc;
     if ((rc = dev_reserve(ctx, ctx->d_partials, (size_t)std::max<uint32_t>(blocks, 1) * kSums * sizeof(double))) != ELM_OK) return rc;
@@ -2607,7 +2640,7 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
     HF_CHK(hipMemcpyAsync(d_q, hq, q_bytes + t_bytes, hipMemcpyHostToDevice, ctx->stream));
     HF_CHK(hipMemcpyAsync(d_ctrl, hc, sizeof(StreamCtrl), hipMemcpyHostToDevice, ctx->stream));
     HF_CHK(hipMemcpyAsync(ctx->d_order_jobs.p, hj, (size_t)count * sizeof(OrderJob), hipMemcpyHostToDevice, ctx->stream));
-    HF_CHK(hipMemsetAsync(ctx->d_active.p, 0, sizeof(int), ctx->stream));
+    HF_CHK(hipMemsetAsync(ctx->d_active.p, 0, 2 * sizeof(int), ctx->stream));
     ScanState* st = (ScanState*)ctx->d_state.p;
     ScanDesc* dsc = (ScanDesc*)ctx->d_scans.p;
     int* d_active = (int*)ctx->d_active.p;
@@ -2657,7 +2690,7 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
     };
     // Iterations are enqueued a few ahead of the device (an event per iteration throttles the host); the number of finished
     // registrations is read on a stream of its own, so that looking never waits for the iterations in flight.
-    const StreamArgs sa = {dsc, d_q, d_qT0, d_out, d_ctrl, 1, 0, 0};
+    const StreamArgs sa = {dsc, d_q, d_qT0, d_out, d_ctrl, 1, 0, 0, 0};
     int it = 0, done_seen = 0, idle_turns = 0, g_done = 0;
     const int idle_limit = 4000000; // ~ minutes of polling without a single registration finishing: a lost upload, give up
     const int groups_ahead = 2 * kStageSets; // uploads enqueued but not yet ordered: enough to keep the DMA engine fed; a long backlog
@@ -2708,10 +2741,40 @@ extern "C" int elm_register(elm_ctx* ctx, const elm_map* map, const float* scan_
     int rc = scan_upload_impl(ctx, scan_xyz, n, n, false, false, &s);
     if (rc != ELM_OK) return rc;
     elm_reg_result res;
-    rc = elm_register_batch(ctx, map, &s, 1, T0, cfg, &res, trace);
+    // b_debug_print (reg.cpp:343-347, 396-403): the reference's per-iteration and total timing lines need the iteration trace and one
+    // hipEvent pair per accumulate launch; the default (0) records neither -- and prints nothing unless a gate fails
+    const bool dbg = cfg->b_debug_print != 0;
+    std::vector<elm_iter_trace> own_trace;
+    elm_iter_trace* tr = trace;
+    const bool was_profiling = ctx->profiling;
+    const elm_profile saved_prof = ctx->prof;
+    std::chrono::steady_clock::time_point t_begin;
+    if (dbg) {
+        if (!tr) { own_trace.resize(ELM_MAX_ITER_TRACE); tr = own_trace.data(); }
+        ctx->profiling = true;
+        ctx->keep_iter_ms = true;
+        ctx->iter_acc_ms.clear();
+        t_begin = std::chrono::steady_clock::now();
+    }
+    rc = elm_register_batch(ctx, map, &s, 1, T0, cfg, &res, tr);
+    if (dbg) {
+        ctx->profiling = was_profiling;
+        ctx->keep_iter_ms = false;
+        if (!was_profiling) ctx->prof = saved_prof; // the caller did not ask for a profile: its totals are untouched
+    }
     if (rc != ELM_OK) (void)hipStreamSynchronize(ctx->stream); // the upload may still be reading the pinned staging buffer
     elm_scan_destroy(s);
     if (rc != ELM_OK) return rc;
+    if (dbg || res.gate != 0) {
+        // what RunRegister writes to stdout (elm_format_register_log): warnings always, the timing lines with b_debug_print
+        const double total_ms = dbg ? std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_begin).count() / 1000.0 : 0.0;
+        std::vector<double> corr(ctx->iter_acc_ms);
+        corr.resize((size_t)std::max(res.iterations, 0), 0.0);
+        char text[4096];
+        elm_format_register_log(cfg, &res, n, dbg ? tr : nullptr, dbg ? corr.data() : nullptr, total_ms, text, sizeof(text));
+        fputs(text, stdout);
+        fflush(stdout);
+    }
     if (T_out) memcpy(T_out, res.T, sizeof(res.T));
     if (is_success) *is_success = res.is_success;
     if (fitness_score && res.is_success) *fitness_score = res.fitness_score; // untouched on failure, like the reference

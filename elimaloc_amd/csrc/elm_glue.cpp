@@ -9,6 +9,8 @@
 #include <algorithm>
 #include <cmath>
 #include <chrono>
+#include <sstream>
+#include <string>
 #include <unordered_map>
 #include <vector>
 
@@ -439,4 +441,47 @@ extern "C" int elm_pcm_callback_point_cloud(elm_ctx* ctx, const elm_map* map, co
     if (rc != ELM_OK) return rc;
     *published = 1;
     return ELM_OK;
+}
+
+
+// ---- the reference's stdout lines of one RunRegister (reg.cpp:291-295, 343-356, 393-413) ------------------------------------------------
+extern "C" size_t elm_format_register_log(const elm_reg_config* cfg, const elm_reg_result* res, size_t n_points, const elm_iter_trace* trace,
+                                          const double* corr_ms, double total_ms, char* buf, size_t cap) {
+    static const char* RESET = "\033[0m"; // localization_functions.hpp:78-85
+    static const char* GREEN = "\033[32m";
+    static const char* YELLOW = "\033[33m";
+    std::ostringstream o; // std::cout's default formatting (%g, six significant digits)
+    if (cfg && res) {
+        const bool dbg = cfg->b_debug_print != 0;
+        const float ratio = n_points ? (float)res->n_corr_last / (float)n_points : 0.f; // reg.cpp:351: (float) corr / total
+        if (res->gate == 1) {
+            o << YELLOW << "VOXEL MAP EMPTY!" << RESET << "\n"; // reg.cpp:291-295
+        } else {
+            double corr_total = 0.0;
+            for (int i = 0; i < res->iterations; ++i) {
+                if (corr_ms) corr_total += corr_ms[i];
+                if (dbg && trace && corr_ms && i < ELM_MAX_ITER_TRACE) // reg.cpp:343-347
+                    o << "[Registration] Total Correspondence Time for: " << (i + 1) << " in " << corr_ms[i] << " ms, and cores num: "
+                      << (long long)trace[i].n_corr << RESET << "\n";
+            }
+            if (res->gate == 2) {
+                o << YELLOW << "[RunRegister] Small corresponding  ratio. " << ratio << RESET << "\n"; // reg.cpp:352-356 (returns here)
+            } else {
+                if (dbg) { // reg.cpp:396-403
+                    o << "[Registration] Total Correspondence Time: " << corr_total << " ms" << RESET << "\n";
+                    o << "[Registration] RunRegister: iteration " << res->iterations << " executed in " << total_ms << " ms" << RESET << "\n";
+                    o << GREEN << "[RunRegister] Corresponding ratio " << ratio << RESET << "\n";
+                }
+                if (res->gate == 3) o << YELLOW << "[RunRegister] ICP Fitness Score Low " << res->d_fitness << RESET << "\n"; // reg.cpp:405-409
+                else if (dbg) o << GREEN << "[RunRegister] ICP Fitness Score " << res->d_fitness << RESET << "\n";            // reg.cpp:411-413
+            }
+        }
+    }
+    const std::string t = o.str();
+    if (buf && cap) {
+        const size_t n = std::min(t.size(), cap - 1);
+        memcpy(buf, t.data(), n);
+        buf[n] = 0;
+    }
+    return t.size();
 }

@@ -171,6 +171,8 @@ struct StreamCtrl {
     int32_t completed; // registrations whose final state has been saved
     int32_t total;
     int32_t ready;     // host-fed streams: registrations whose scan has arrived in HBM (uploaded + ordered); a slot only takes r < ready
+    int32_t done_iter; // iteration (0-based) whose solve finished the LAST registration, -1 while the stream runs: what the next call of the
+                       // same shape enqueues before it first looks (the host's own count only says when it LOOKED)
 };
 
 // in-solve refill of finished slots (single-rank streams, see finish_slot in elm_kernels.hip)
@@ -185,6 +187,7 @@ struct StreamArgs {
                        // stays free for k_stream_refill to hand it the next registration in slot order
     int32_t stride;   // > 0 (multi-rank streams): slot s serves the registrations s, s + stride, s + 2 stride, ... -- an assignment that
                       // is a function of the slot alone, hence identical on every rank without any exchange; 0: first come, first served
+    int32_t iter;     // index of this iteration in the call (StreamCtrl::done_iter)
 };
 
 struct RegParams {
@@ -209,6 +212,12 @@ struct RegParams {
                          // map runs the nine-entry walk with its fallback instead)
     uint32_t* prev;      // [workgroups * kBlock] the winner (grid slot number, -1: none) of every scan point in the slot's previous iteration:
                          // bounds the exact search of the next one (k_accumulate_grid); nullptr: not kept
+    int32_t rank_check;  // 1 (several ranks, production kernels): slots 29..31 of every scan's exchanged sums -- the work counters, zero in
+                         // production -- carry (1, id, id^2), id = 16 (registration + 1) + (iteration & 15): after the all-reduce every rank
+                         // verifies sum(id) == n id and sum(id^2) == n id^2, i.e. that all ranks iterate the SAME registration in this slot
+                         // (the refill launch hands registrations out from flags every rank computes for itself); a mismatch sets active[1]
+                         // and the call returns ELM_ERR_COMM instead of adding up unrelated normal equations
+    int32_t _pad_rc;
     double* asym;        // [workgroups][16] side records of a map with an asymmetric flagged covariance (the strict lower triangle of
                          // H_w - H_w^T, see asym_side_store in elm_kernels.hip): written by every workgroup of such a launch, reduced by
                          // k_solve, which restores all 36 entries of J^T M J before the congruence; nullptr on every other map

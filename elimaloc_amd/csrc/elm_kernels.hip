@@ -642,9 +642,11 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_direct(const DevMap m, co
                 if (d2 < rp.th2) voxel_pair<ELM_AVGICP>(acc, m, S, rp, gx, gy, gz, pr.vid, cx, cy, cz);
             }
         }
-        acc[29] = n_cand;
-        acc[30] = n_occ;
-        acc[31] = n_cand; // every candidate is distance-tested on this path
+        if (rp.stats) { // the work counters read 0 unless elm_ctx_set_work_counters(ctx, 1), whatever the search index
+            acc[29] = n_cand;
+            acc[30] = n_occ;
+            acc[31] = n_cand; // every candidate is distance-tested on this path
+        }
     }
     __shared__ double red[kBlock / 64][32];
     __shared__ double s_scr[8 * kSums + 2];
@@ -740,9 +742,11 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_radar(const DevMap m, con
                 }
             }
         }
-        acc[44] = n_cand;
-        acc[45] = n_occ;
-        acc[46] = n_cand;
+        if (rp.stats) {
+            acc[44] = n_cand;
+            acc[45] = n_occ;
+            acc[46] = n_cand;
+        }
     }
     __shared__ double red[kBlock / 64][kRadarSums];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1445,9 +1449,11 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_CELL_WAVES : ELM_C
         } else {
             finish_point_pair<METHOD, true>(v, m, S, rp, px, py, pz, gx, gy, gz, bd2, bx, by, bz, bidx, m.pt_gicp);
         }
-        v[NV - 3] = (double)qp.cnt;  // candidates of the reference's walk
-        v[NV - 2] = (double)qp.nocc; // occupied neighbour voxels
-        v[NV - 1] = (double)n_tested + (hard ? kFallbackUnit : 0.0); // high part: points served by stage 2
+        if (rp.stats) { // (as in the grid / voxel-list kernels: 0 unless the work counters are switched on)
+            v[NV - 3] = (double)qp.cnt;  // candidates of the reference's walk
+            v[NV - 2] = (double)qp.nocc; // occupied neighbour voxels
+            v[NV - 1] = (double)n_tested + (hard ? kFallbackUnit : 0.0); // high part: points served by stage 2
+        }
     }
     block_reduce_to_lds<NV, kRedPass>(v, s_buf, s_red);
     publish_and_reduce((threadIdx.x < kSums) ? ((METHOD == ELM_P2P) ? p2p_expand(s_red, (int)threadIdx.x) : s_red[threadIdx.x]) : 0.0, L, s, sd.blk_begin,
@@ -2686,7 +2692,7 @@ __global__ __launch_bounds__(64) void k_init_state(ScanState* st, const double* 
 __global__ __launch_bounds__(64) void k_init_pack(ScanDesc* scans, ScanState* st, const InitPack pack, int batch, int map_empty, int* active,
                                                   const unsigned* __restrict__ n_dev, int* tickets) {
     const int s = threadIdx.x;
-    if (s == 0) *active = map_empty ? 0 : batch;
+    if (s == 0) { active[0] = map_empty ? 0 : batch; active[1] = 0; } // [1]: the rank-agreement fault word (RegParams::rank_check)
     if (s >= batch) return;
     if (tickets) tickets[s] = 0;
     ScanDesc d = pack.d[s];
@@ -2745,7 +2751,7 @@ __global__ __launch_bounds__(1024) void k_stream_refill(ScanDesc* scans, ScanSta
         __syncthreads(); // every thread has read ctrl->next
         if (threadIdx.x == 0) {
             ctrl->next = min(total, next0 + all);
-            if (first) ctrl->completed = 0;
+            if (first) { ctrl->completed = 0; ctrl->done_iter = -1; }
             else if (save) ctrl->completed += all; // (save = 0: the solve has saved and counted them)
         }
     }
@@ -3018,7 +3024,7 @@ __device__ __forceinline__ void finish_slot(const StreamArgs& sa, ScanState& S, 
     const double* src = reinterpret_cast<const double*>(&S);
     double* dst = reinterpret_cast<double*>(&sa.out_state[reg_old]);
     for (int k = lane; k < W; k += 64) dst[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (lane == 0) atomicAdd(&sa.ctrl->completed, 1);
+    if (lane == 0 && atomicAdd(&sa.ctrl->completed, 1) + 1 == sa.ctrl->total) sa.ctrl->done_iter = sa.iter; // the stream's last registration
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0); // the copy's loads are done before the state is overwritten
     __builtin_amdgcn_wave_barrier();
@@ -3139,8 +3145,13 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : 1) void k_solve(const ScanDesc*
             double a = part[0][t];
 #pragma unroll
             for (int q = 1; q < kSolveThreads / 32; ++q) a += part[q][t];
-            if (mode == 1) sums[(size_t)s * kSums + t] = a; // zeros for finished scans keep the all-reduce buffer defined
-            else tot[t] = a;
+            if (mode == 1) {
+                if (rp.rank_check && t >= 29) { // (1, id, id^2) in the slots of the work counters (zero in production): see RegParams::rank_check
+                    const double id = 16.0 * (double)(S.reg + 1) + (double)(S.iters & 15);
+                    a = (t == 29) ? 1.0 : (t == 30) ? id : id * id;
+                }
+                sums[(size_t)s * kSums + t] = a; // zeros for finished scans keep the all-reduce buffer defined
+            } else tot[t] = a;
         } else if (asym && t < 32 + kAsymSums) {
             const int k2 = t - 32;
             double a = apart[0][k2];
@@ -3158,6 +3169,15 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : 1) void k_solve(const ScanDesc*
     }
     __syncthreads();
     if (t >= 64) return; // the first wave does the rest with uniform control flow; lane 0 owns the state
+    if (mode == 2 && rp.rank_check && !radar) {
+        // every rank must be iterating the same registration (and iteration) in this slot: exact integer arithmetic in doubles
+        const double n = sums[(size_t)s * kSums + 29], a1 = sums[(size_t)s * kSums + 30], a2 = sums[(size_t)s * kSums + 31];
+        const double id = 16.0 * (double)(S.reg + 1) + (double)(S.iters & 15);
+        if (t == 0 && !(n >= 1.0 && a1 == n * id && a2 == n * id * id)) atomicOr(active + 1, 1);
+        if (t >= 29 && t < 32) tot[t] = 0.0; // (they are not work counters)
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+    }
     if (done) {
         // host-fed stream: an idle slot (nothing was pending when it last looked) takes a registration whose scan has arrived since
         if (sa.ctrl && sa.hostfed && __hip_atomic_load(&S.reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) start_slot(sa, S, s, -1);
@@ -3654,7 +3674,7 @@ void launch_nbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint3
 
 void launch_solve(hipStream_t s, const ScanDesc* scans, int batch, ScanState* st, const double* partials,
                   double* sums, const RegParams& rp, elm_iter_trace* trace, int mode, int* active, const StreamArgs* refill) {
-    StreamArgs sa = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+    StreamArgs sa = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
     if (refill) sa = *refill;
     // one wavefront per scan when the sums are already reduced (fused reduction, or the second half of a multi-rank iteration)
     const bool small = rp.solve_small != 0 && rp.radar == 0;

@@ -205,6 +205,17 @@ int elm_scan_download(const elm_scan* scan, float* xyz, size_t cap);
 int elm_register(elm_ctx* ctx, const elm_map* map, const float* scan_xyz, size_t n, const double T0[16],
                  const elm_reg_config* cfg, double T_out[16], int* is_success, double* fitness_score,
                  double local_cov[36], elm_reg_result* result, elm_iter_trace* trace);
+/* What Registration::RunRegister writes to stdout for one call (reg.cpp:291-295, 343-356, 393-413), rebuilt from the call's result:
+ * the warnings the reference prints whatever the configuration -- "VOXEL MAP EMPTY!", "[RunRegister] Small corresponding  ratio. r",
+ * "[RunRegister] ICP Fitness Score Low f" -- and, with cfg->b_debug_print, its per-iteration line "[Registration] Total Correspondence
+ * Time for: i in X ms, and cores num: N", the totals "[Registration] Total Correspondence Time: X ms" and "[Registration] RunRegister:
+ * iteration N executed in Y ms", the corresponding ratio and the fitness score, with the reference's colour codes
+ * (localization_functions.hpp:78-85) and stream formatting.  trace (per-iteration n_corr) and corr_ms (per-iteration correspondence
+ * time in ms: the accumulate launch, which IS the correspondence search + the sums here) may be NULL: the per-iteration lines are then
+ * left out.  Writes at most cap bytes including the terminating NUL; returns the length the whole text needs.  elm_register prints this
+ * text itself (debug lines only with b_debug_print: the default adds no event, no trace and no output on success). */
+size_t elm_format_register_log(const elm_reg_config* cfg, const elm_reg_result* res, size_t n_points, const elm_iter_trace* trace,
+                               const double* corr_ms, double total_ms, char* buf, size_t cap);
 
 /* The same on B device-resident scans against one map, all iterated together (one accumulate launch, one
  * optional all-reduce and one solve launch per ICP iteration for the whole batch).  T0: 16*B doubles.

@@ -201,3 +201,76 @@ def test_plain_c_closed_loop_runs(tmp_path):
     cal.write_text("[Rear To Main LiDAR]\ntransform_xyz_m = 1.0 0.0 1.6\nrotation_rpy_deg = 0.0 0.5 1.0\n[Rear To Imu]\nrotation_rpy_deg = 0 0 0\n")
     r = subprocess.run([exe, str(loc), str(cal)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_register_log_lines_are_the_references():
+    """debug_print (loc.ini `debug_print`, reg.cpp:343-347, 396-413): the text elm_register writes to stdout, built by
+    elm_format_register_log from a result, against the reference's own `std::cout <<` sequences (host-only: no GPU)."""
+    import ctypes as C
+    from elimaloc_amd import _lib
+    L = _lib.lib()
+    RESET, GREEN, YELLOW = "\033[0m", "\033[32m", "\033[33m"
+
+    def fmt(cfg, res, n, trace=None, corr=None, total=0.0):
+        buf = C.create_string_buffer(4096)
+        need = L.elm_format_register_log(C.byref(cfg), C.byref(res), n, trace, corr, total, buf, len(buf))
+        assert need == len(buf.value)
+        return buf.value.decode()
+
+    cfg = _lib.RegConfig()
+    L.elm_reg_config_default(C.byref(cfg))
+    res = _lib.RegResult()
+    res.iterations, res.gate, res.is_success, res.n_corr_last, res.d_fitness = 2, 0, 1, 7000.0, 0.0123456789
+    assert cfg.b_debug_print == 0 and fmt(cfg, res, 8000) == ""  # the default prints nothing on success
+    cfg.b_debug_print = 1
+    tr = (_lib.IterTrace * _lib.MAX_ITER_TRACE)()
+    tr[0].n_corr, tr[1].n_corr = 6990.0, 7000.0
+    corr = (C.c_double * 2)(0.125, 0.25)
+    want = (f"[Registration] Total Correspondence Time for: 1 in 0.125 ms, and cores num: 6990{RESET}\n"
+            f"[Registration] Total Correspondence Time for: 2 in 0.25 ms, and cores num: 7000{RESET}\n"
+            f"[Registration] Total Correspondence Time: 0.375 ms{RESET}\n"
+            f"[Registration] RunRegister: iteration 2 executed in 1.5 ms{RESET}\n"
+            f"{GREEN}[RunRegister] Corresponding ratio 0.875{RESET}\n"
+            f"{GREEN}[RunRegister] ICP Fitness Score 0.0123457{RESET}\n")
+    assert fmt(cfg, res, 8000, tr, corr, 1.5) == want
+    # the warnings do not depend on debug_print
+    cfg.b_debug_print = 0
+    res.gate, res.is_success, res.d_fitness = 3, 0, 0.75
+    assert fmt(cfg, res, 8000) == f"{YELLOW}[RunRegister] ICP Fitness Score Low 0.75{RESET}\n"
+    res.gate, res.n_corr_last, res.iterations = 2, 1000.0, 1
+    assert fmt(cfg, res, 8000) == f"{YELLOW}[RunRegister] Small corresponding  ratio. 0.125{RESET}\n"
+    res.gate, res.iterations = 1, 0
+    assert fmt(cfg, res, 8000) == f"{YELLOW}VOXEL MAP EMPTY!{RESET}\n"
+    # a short buffer is truncated, the needed length still reported
+    small = C.create_string_buffer(8)
+    assert L.elm_format_register_log(C.byref(cfg), C.byref(res), 8000, None, None, 0.0, small, 8) == len(f"{YELLOW}VOXEL MAP EMPTY!{RESET}\n")
+    assert len(small.value) == 7
+
+
+@pytest.mark.gpu
+def test_debug_print_costs_nothing_when_off(capfd):
+    """b_debug_print = 0 (the shipped default): elm_register records no event, keeps no trace and prints nothing on success;
+    = 1: the reference's lines appear on stdout, one per executed iteration + the totals, and the caller's profile is untouched."""
+    import numpy as np
+    from elimaloc_amd import synth
+    from elimaloc_amd.registration import Context, VoxelHashMap, Registration, RegistrationConfig, IcpMethod
+    ctx = Context(0)
+    world = synth.make_world(30000, seed=11)
+    scan, Tt = synth.make_scan(world, 4096, seed=12)
+    T0 = synth.perturb(Tt, seed=13)
+    vm = VoxelHashMap(1.0, 30, ctx)
+    vm.AddPoints(world)
+    reg = Registration(RegistrationConfig(icp_method=IcpMethod.P2P), ctx)
+    ctx.get_profile(reset=True)
+    pose0, ok0, _, _ = reg.RunRegister(scan, vm, T0)
+    out = capfd.readouterr().out
+    assert ok0 and "[Registration]" not in out and "[RunRegister]" not in out
+    assert ctx.get_profile()["accumulate_launches"] == 0  # no events were recorded
+    pose1, ok1, _, _, det = Registration(RegistrationConfig(icp_method=IcpMethod.P2P, b_debug_print=1), ctx).RunRegister(scan, vm, T0, trace=True)
+    out = capfd.readouterr().out
+    assert np.array_equal(pose0, pose1) and ok1
+    assert out.count("[Registration] Total Correspondence Time for: ") == det["iterations"]
+    assert f"[Registration] RunRegister: iteration {det['iterations']} executed in " in out
+    assert "[RunRegister] Corresponding ratio " in out and "[RunRegister] ICP Fitness Score " in out
+    assert ctx.get_profile()["accumulate_launches"] == 0  # ... and the caller's profile totals are as they were
+    ctx.close()

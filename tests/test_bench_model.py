@@ -1,0 +1,81 @@
+"""bench.py's roofline model as plain functions (no GPU): no utilisation above 1 is ever printed, a counter pass speaks only for its
+own operating point (per GPU, at every N), and the N > 1 default keeps the N = 1 operating point."""
+import glob
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_pmc_key_names_the_operating_point():
+    assert bench.pmc_key("k_accumulate_grid<P2P>", 131072, 10_000_000, "easy") == "k_accumulate_grid<P2P>"
+    assert bench.pmc_key("k_accumulate_grid<P2P>", 131072, 10_000_000, "hard") == "k_accumulate_grid<P2P>@hard"
+    assert bench.pmc_key("k_accumulate_vnbr<VGICP>", 32768, 50_000_000, "easy") == "k_accumulate_vnbr<VGICP>@32768/50000000"
+
+
+def test_index_is_charged_at_most_its_touched_part():
+    # the round-4 failure: 32 slots of 262144-point scans on the 50 M-point map were charged the whole 3.5 GB index per launch
+    idx = 3.5e9
+    b = bench.index_touch_bound(idx, 32 * 262144, 250.0, 32, 50_000_000)
+    assert b < 0.3 * idx
+    # the headline: 256 scans cover the 10 M-point map several times over -> the whole index, once
+    assert bench.index_touch_bound(0.25e9, 256 * 131072 * 0.9, 250.0, 230, 10_000_000) == 0.25e9
+    # never more than the points request
+    assert bench.index_touch_bound(1e9, 1000, 100.0, 1, 10_000_000) <= 1e5
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "profiles", "r04*_bench.json")) + glob.glob(os.path.join(ROOT, "profiles", "r05*_bench*.json"))))
+def test_no_recorded_operating_point_yields_a_fraction_above_one(path):
+    """every bench line committed under profiles/ re-priced with the current model: the compulsory stream stays below the HBM peak"""
+    r = json.load(open(path))
+    if "roofline" not in r or "config" not in r or r["config"].get("slots_per_gpu", 0) <= 0:
+        pytest.skip("not a stream bench line")
+    rf = r["roofline"]
+    hv = rf.get("hbm", rf)
+    method = {"P2P": 0, "GICP": 1, "VGICP": 2, "AVGICP": 3}[rf["kernel"].split("<")[1].rstrip(">")]
+    sp = int(r["config"].get("scan_points", 262144 if "262144" in r["config"]["workload"] else 131072))
+    mp = int(r["config"].get("map_points", 50_000_000 if "50000000" in r["config"]["workload"] else 10_000_000))
+    upl, sec = rf["units_per_launch"], rf["avg_launch_ms"] * 1e-3
+    h = bench.hbm_object(method, rf["index_bytes"], upl, sec, hv["requested_bytes_per_unit"], hv["algorithmic_ref_bytes_per_unit"], upl / sp, mp)
+    assert h["frac"] <= 1.05 and h["compulsory_frac"] <= 1.05, (path, h["frac"])
+    bench.assert_fractions({"roofline": bench.build_roofline(method, rf["kernel"], h, None, upl, rf["avg_launch_ms"])})
+
+
+def test_assert_fractions_refuses_a_utilisation_above_one():
+    bench.assert_fractions({"roofline": {"frac": 0.93, "hbm": {"frac": 0.26, "compulsory_frac": 0.11}}})
+    with pytest.raises(AssertionError):
+        bench.assert_fractions({"configs": {"C4_shard": {"roofline": {"frac": 4.997}}}})
+
+
+def test_counter_pass_speaks_for_its_own_operating_point_at_any_n(tmp_path, monkeypatch):
+    """per-GPU batch / slots and units per launch decide, not the number of ranks (round 4 refused every pass at N > 1)"""
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    entry = {"batch": 4096, "slots": 256, "guess": "easy", "scan_points": 131072, "map_points": 10_000_000, "units_per_launch_profiled": 30.0e6,
+             "hbm_bytes_per_unit": 58.7, "valu_insts_per_simd_cycle": 0.2448, "ta_busy": 0.81}
+    (prof / "pmc_latest.json").write_text(json.dumps({"k_accumulate_grid<P2P>": entry}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    k = "k_accumulate_grid<P2P>"
+    assert bench.load_counter_pass(k, 131072, 10_000_000, "easy", 4096, 256, 30.1e6) is not None
+    assert bench.load_counter_pass(k, 131072, 10_000_000, "easy", 4096, 256, 29.0e6) is not None  # a rank of an 8-GPU run: same per-GPU point
+    assert bench.load_counter_pass(k, 131072, 10_000_000, "easy", 1024, 256, 30.1e6) is None       # another batch: another launch mix
+    assert bench.load_counter_pass(k, 131072, 10_000_000, "easy", 4096, 256, 8.0e6) is None        # a quarter of the work per launch
+    assert bench.load_counter_pass(k, 131072, 10_000_000, "hard", 4096, 256, 30.1e6) is None
+    assert bench.load_counter_pass(k, 32768, 50_000_000, "easy", 4096, 256, 30.1e6) is None
+    pm = bench.load_counter_pass(k, 131072, 10_000_000, "easy", 4096, 256, 30.1e6)
+    h = bench.hbm_object(0, 0.25e9, 30.1e6, 0.84e-3, 303.0, 3348.0, 230, 10_000_000, pm["hbm_bytes_per_unit"] * 30.1e6, "test")
+    rf = bench.build_roofline(0, k, h, pm, 30.1e6, 0.84)
+    assert rf["bound"] == "valu_issue" and 0.9 < rf["frac"] < 0.95 and 0.2 < rf["hbm"]["frac"] < 0.3
+
+
+def test_default_operating_point_is_the_same_at_every_n():
+    """bench.py --batch 0: 4096 registrations per GPU at N = 1 and at N > 1 (round 4: 4096 vs 1024 -- the first step of the scaling curve
+    compared two different launch mixes)"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "args.batch = 4096  # the SAME per-GPU operating point at every N" in src
+    assert "4096 if world_size == 1 else 1024" not in src

@@ -973,7 +973,7 @@ def test_grid_budget_falls_back_to_lists(oracle, world100k, monkeypatch):
         c.close()
 
 
-def _run_two_ranks(world, full, T0s, m, stream, slots=3, cov_dist=0.4, cfg_kw=None):
+def _run_two_ranks(world, full, T0s, m, stream, slots=3, cov_dist=0.4, cfg_kw=None, corrupt_rank1=False, wait_s=120, errors_out=None):
     """Two REAL ranks on this GPU: two contexts (two host threads, two streams), every scan's points sharded in two, the map
     replicated, and an exchange hook that adds the two ranks' packed sums -- what the RCCL all-reduce does between the
     reduce-only and the solve-only launch of every iteration.  Returns the two ranks' result lists."""
@@ -1006,9 +1006,12 @@ def _run_two_ranks(world, full, T0s, m, stream, slots=3, cov_dist=0.4, cfg_kw=No
                 mine = np.empty(n, np.float64)
                 assert hip.hipMemcpy(mine.ctypes.data, ptr, n * 8, 2) == 0  # device -> host
                 bufs[r] = mine
-                barrier.wait(timeout=120)
+                barrier.wait(timeout=wait_s)
                 total = bufs[0] + bufs[1]  # the same operand order on both ranks
-                barrier.wait(timeout=120)
+                if corrupt_rank1 and r == 1:  # a broken collective: this rank receives other right-hand sides for its first slot
+                    total = total.copy()
+                    total[21:27] *= 0.25
+                barrier.wait(timeout=wait_s)
                 assert hip.hipMemcpy(ptr, total.ctypes.data, n * 8, 1) == 0  # host -> device
                 return 0
 
@@ -1025,6 +1028,9 @@ def _run_two_ranks(world, full, T0s, m, stream, slots=3, cov_dist=0.4, cfg_kw=No
     th = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
     [t.start() for t in th]
     [t.join(timeout=900) for t in th]
+    if errors_out is not None:
+        errors_out.extend(errors)
+        return results
     assert not errors, errors
     return results
 
@@ -1055,6 +1061,26 @@ def test_two_ranks_on_one_gpu(oracle, world100k, method, stream):
     ref = oracle.register(om, full[3], T0s[3], oracle.default_config(method))
     dt, dr = synth.pose_error(ref["T"], results[0][3]["T"])
     assert ref["iterations"] == results[0][3]["iterations"] and dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
+
+
+def test_ranks_that_disagree_are_reported_not_summed(world100k):
+    """Multi-rank streams hand registrations to free slots from flags every rank computes for itself -- identical as long as every rank
+    solves identical all-reduced sums.  The exchanged record carries (1, id, id^2) per slot -- id = the slot's registration and
+    iteration -- and the solve verifies after the all-reduce that all ranks agree (RegParams::rank_check).  Here the exchange is broken
+    on purpose (rank 1 receives other right-hand sides for its first slot), so the two ranks' slots drift apart: the call must end in
+    ELM_ERR_COMM (or in the exchange itself failing once a rank has stopped iterating), never in a silent sum of unrelated normal
+    equations."""
+    from elimaloc_amd.registration import IcpMethod
+    full, T0s = [], []
+    for i in range(6):
+        sc, Tt = synth.make_scan(world100k, 3000 + 500 * i, seed=1900 + i)
+        full.append(sc)
+        T0s.append(synth.perturb(Tt, seed=1950 + i, max_trans=0.3, max_rot_deg=1.0))
+    errors = []
+    res = _run_two_ranks(world100k, full, T0s, IcpMethod.P2P, stream=True, slots=2, corrupt_rank1=True, wait_s=20, errors_out=errors)
+    assert errors, "two ranks with different registrations in one slot went unnoticed"
+    assert any("rank-agreement" in e or "allreduce hook failed" in e or "Barrier" in e for e in errors), errors
+    assert res[0] is None or res[1] is None
 
 
 def test_full_size_c4_two_shards(oracle):

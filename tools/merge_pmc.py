@@ -17,8 +17,11 @@ for d in sys.argv[1:]:
     tag = os.path.basename(d.rstrip("/")).replace("prof_", "")
     pm = json.load(open(os.path.join(d, "pmc.json")))
     small = {k: v for k, v in pm.items() if k != "counters"}
-    if "kernel" in small:  # one entry per kernel and initial-guess set (bench.py looks its own up and checks batch / slots as well)
-        cur[small["kernel"] + ("@hard" if small.get("guess") == "hard" else "")] = small
+    if "kernel" in small:  # one entry per kernel, workload size and initial-guess set (bench.py: pmc_key; it checks batch / slots as well)
+        key = small["kernel"]
+        if int(small.get("scan_points", 131072)) != 131072 or int(small.get("map_points", 10_000_000)) != 10_000_000:
+            key += f"@{int(small['scan_points'])}/{int(small['map_points'])}"
+        cur[key + ("@hard" if small.get("guess") == "hard" else "")] = small
     for src, name in (("kernel_stats.csv", f"{tag}_kernel_stats.csv"), ("pmc.json", f"{tag}_pmc.json"), ("bench.json", f"{tag}_bench.json"),
                       ("bench_trace.json", f"{tag}_bench_under_rocprof.json")):
         if os.path.exists(os.path.join(d, src)):
