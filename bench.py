@@ -120,7 +120,7 @@ def launch_ranks(args, argv):
     os.execvpe(cmd[0], cmd, dict(os.environ))
 
 
-def generate_inputs(world, args, rank, world_size, dist, guess, n_keep, keep_own, consume):
+def generate_inputs(world, args, rank, world_size, dist, guess, n_keep, keep_own, consume, stats=None):
     """The step's registrations: n_batch = batch x world_size seeded scans + initial guesses; `consume(i, shard, n)` receives, in order
     of i, THIS rank's contiguous shard [n rank / W, n (rank + 1) / W) of scan i (packed float32 xyz, the caller's point order).
 
@@ -161,7 +161,9 @@ def generate_inputs(world, args, rank, world_size, dist, guess, n_keep, keep_own
             for m0 in range(0, args.batch, ROUND):
                 ms = list(range(m0, min(m0 + ROUND, args.batch)))
                 cnt = len(ms)
+                t_g = time.perf_counter()
                 own = list(pool.map(gen, [rank + world_size * m for m in ms]))
+                t_x = time.perf_counter()
                 if any(o[0].shape[0] != npts for o in own):
                     raise SystemExit("make_scan returned a scan of another size")
                 # send buffer: destination-major, then scan; receive buffer: source-major, then scan
@@ -170,6 +172,10 @@ def generate_inputs(world, args, rank, world_size, dist, guess, n_keep, keep_own
                 dist.all_to_all_single(out, inp, [cnt * mine * 3] * world_size, [cnt * (bounds[d + 1] - bounds[d]) * 3 for d in range(world_size)])
                 metas = [None] * world_size
                 dist.all_gather_object(metas, [(o[1], o[2], o[3], o[4]) for o in own])
+                if stats is not None:  # the launch budget (--dry-launch): where the host time of the N > 1 input path goes
+                    stats["generate_s"] = stats.get("generate_s", 0.0) + (t_x - t_g)
+                    stats["exchange_s"] = stats.get("exchange_s", 0.0) + (time.perf_counter() - t_x)
+                    stats["bytes_sent"] = stats.get("bytes_sent", 0) + int(inp.numel()) * 4 * (world_size - 1) // world_size
                 got = out.numpy().reshape(world_size, cnt, mine, 3)
                 for j, m in enumerate(ms):
                     for src in range(world_size):
@@ -201,9 +207,16 @@ def dry_launch(args, rank, world_size, local_rank, dist):
         shard_sha.update(shard.tobytes())
         shard_points[0] += shard.shape[0]
 
-    g = generate_inputs(world, args, rank, world_size, dist, guess, 0, False, consume)
+    stats = {}
+    t_all = time.perf_counter()
+    g = generate_inputs(world, args, rank, world_size, dist, guess, 0, False, consume, stats)
+    import resource
     who = [None] * world_size
-    mine = dict(rank=rank, local_rank=local_rank, pid=os.getpid(), shard_points=shard_points[0], shard_sha1=shard_sha.hexdigest())
+    mine = dict(rank=rank, local_rank=local_rank, pid=os.getpid(), shard_points=shard_points[0], shard_sha1=shard_sha.hexdigest(),
+                # launch budget of this rank: wall seconds generating its scans / in the all-to-all (+ metadata gather), bytes it sent, peak RSS
+                budget=dict(generate_s=stats.get("generate_s"), exchange_s=stats.get("exchange_s"), total_s=time.perf_counter() - t_all,
+                            bytes_sent=stats.get("bytes_sent"), peak_rss_mb=resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0,
+                            host_cpus=os.cpu_count()))
     if world_size > 1:
         dist.all_gather_object(who, mine)
     else:

@@ -955,7 +955,8 @@ static int refresh_grid_gicp(elm_map* m) {
     m->dm.grid_gicp = m->d_grid_gicp;
     m->dm.grid_gicp8 = m->d_grid_gicp8;
     // 2: no point outside the compact form -- the kernel has no full-record fallback and gathers the pair fused (ELM_PAIR_NINE=1: the
-    // nine-entry form with its fallback, as for maps with flagged points)
+    // nine-entry form with its fallback, as for maps with flagged points; fusing the compact lanes of THOSE kernels too and reading a
+    // flagged point's stored inverse row by row measured 15 % slower in round 5: profiles/r05_kernel_ab.txt)
     m->dm.gicp_compact = compact ? ((m->n_bad_pts == 0 && !std::getenv("ELM_PAIR_NINE")) ? 2 : 1) : 0;
     m->info.layout_flags = (m->info.layout_flags & ~(1 | 8)) | (compact ? 1 : 0) | (m->dm.gicp_compact == 2 ? 8 : 0);
     return ELM_OK;
@@ -1793,13 +1794,29 @@ static int build_voxel_neighbourhoods(elm_map* m);
 // map holds a flagged covariance of the method's kind whose stored inverse is not symmetric, and the fast kernels carry the antisymmetric
 // part of J^T M J in side records (RegParams::asym; grid and voxel-list kernels, unfused reduction).  Such a map on one of the fall-back
 // indices (lists / plain walk: maps the grid cannot hold, ELM_KERNEL=...) or under ELM_FUSED_REDUCE still takes the per-pair kernels.
+// pcm.cpp:92-100: the covariance methods need their covariances computed (the index builders read them)
+static int check_covariances(elm_ctx* ctx, const elm_map* map, int method) {
+    if (!map || map->dm.n_vox == 0) return ELM_OK;
+    if ((method == ELM_VGICP || method == ELM_AVGICP) && !map->info.has_voxel_cov) {
+        ctx->last_error = "VGICP/AVGICP need elm_map_cal_voxel_cov_all() (pcm.cpp:92-95)";
+        return ELM_ERR_INVALID;
+    }
+    if (method == ELM_GICP && !map->info.has_point_cov) {
+        ctx->last_error = "GICP needs elm_map_cal_point_cov_all() (pcm.cpp:97-100)";
+        return ELM_ERR_INVALID;
+    }
+    return ELM_OK;
+}
 struct PathChoice {
     bool radar = false, asym = false, use_grid = false, use_cells = false, use_vnbr = false;
 };
 static int choose_path(elm_ctx* ctx, const elm_map* map, const elm_reg_config* cfg, PathChoice* pc) {
     *pc = PathChoice();
     const int method = cfg->icp_method;
+    if (method < ELM_P2P || method > ELM_AVGICP) return ELM_ERR_INVALID;
     if (!map || map->dm.n_vox == 0) return ELM_OK;
+    int rc0;
+    if ((rc0 = check_covariances(ctx, map, method)) != ELM_OK) return rc0;
     const int mode = strict_pairs();
     if (method != ELM_P2P && (cfg->use_radar_cov != 0 || mode == 1)) { pc->radar = true; return ELM_OK; }
     int rc;

@@ -1480,13 +1480,21 @@ __device__ __forceinline__ Pt3 blk_point(const GridBlk* __restrict__ blk, int k)
 // per axis: the query's floor key f, the allowed cell range of the reference's walk, and 2 g / voxel_size (cell coordinate)
 struct GridAxis {
     int f, alo, ahi;
-    double t;
+    int cg;   // floor(t): the point's own half-voxel cell
+    float fr; // t - floor(t): its position inside that cell, [0, 1)
 };
 __device__ __forceinline__ GridAxis grid_axis(double g, const DevMap& m) {
     GridAxis a;
     const double q = (m.inv_vs_exact != 0.0) ? g * m.inv_vs_exact : g / m.voxel_size; // == g / voxel_size bit for bit
+    const double t = q + q; // exact: the cell coordinate, floor(t) in {2f, 2f+1}
+    const double fl = floor(t);
+    a.cg = (int)fl;
+    a.fr = (float)(t - fl);
+#if ELM_ONE_FLOOR
+    a.f = a.cg >> 1; // floor(q) == floor(floor(2 q) / 2): PointToVoxel (vhm.hpp:176-180) from the ONE floor the cell needs anyway
+#else
     a.f = (int)floor(q); // PointToVoxel (vhm.hpp:176-180)
-    a.t = q + q;         // exact: cell coordinate, floor(t) in {2f, 2f+1}
+#endif
     // stored keys f-1 .. f+1 -> cells: key k > 0 owns cells {2k, 2k+1}, key 0 owns {-2 .. 1}, key k < 0 owns {2k-2, 2k-1}
     const int kl = a.f - 1, kh = a.f + 1;
     a.alo = 2 * kl - ((kl <= 0) ? 2 : 0);
@@ -1496,9 +1504,8 @@ __device__ __forceinline__ GridAxis grid_axis(double g, const DevMap& m) {
 // the (clipped) two-cell span the query leans into and the distance to its open faces IN CELL UNITS (float: the fraction of g in
 // its own cell plus small integers; the 3e-8 m of rounding sit inside the 1e-6 m margin of the decision)
 __device__ __forceinline__ void grid_lean(const GridAxis& a, int& blo, int& bhi, float& rho_u, int& own, float& d_other) {
-    const double fl = floor(a.t);
-    const int cg = (int)fl;
-    const float fr = (float)(a.t - fl); // position inside the own cell, [0, 1)
+    const int cg = a.cg;
+    const float fr = a.fr; // position inside the own cell, [0, 1)
     const int c0 = (fr >= 0.5f) ? cg : cg - 1;
     blo = max(c0, a.alo);
     bhi = min(c0 + 1, a.ahi);
@@ -1579,6 +1586,21 @@ __device__ __forceinline__ const uint32_t* col_cells(const DevMap& m, int cx, in
 #ifndef ELM_S2_PIPE
 #define ELM_S2_PIPE 1
 #endif
+// Round-5 A/B switches of the per-point code (measured: profiles/r05_kernel_ab.txt)
+#ifndef ELM_REDUCE_WAVE
+#define ELM_REDUCE_WAVE 0 // 1: every wavefront reduces its P2P values by itself (DPP rows + two cross-row exchanges), one LDS pass adds the four
+                          // wavefronts -- instead of the transpose: 98.0 k -> 87.1 k registrations/s (324 instead of ~90 instructions per wave)
+#endif
+#ifndef ELM_ONE_FLOOR
+#define ELM_ONE_FLOOR 1   // the floor key from the cell's floor (f = cg >> 1) instead of a second v_floor_f64 + conversion per axis
+#endif
+#ifndef ELM_EG_BOUND
+#define ELM_EG_BOUND 1    // |g - float32(g)| bounded by half an ulp per axis instead of three float64 differences (nine conversions)
+#endif
+#ifndef ELM_STASH_OWN
+#define ELM_STASH_OWN 1   // the transformed point waits in the thread's OWN four slots of the reduction buffer (address = tid * 8) instead of
+                          // two 16-byte slots of its wavefront behind an eight-instruction swizzle at each of the four uses
+#endif
 #ifndef ELM_S2_SEED
 #define ELM_S2_SEED 1 // stage 2 seeds the ball of a point whose stage-1 block was empty (0: full walk of its 27 voxels, developer A/B)
 #endif
@@ -1645,16 +1667,35 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
     // redid the 18-operation float64 transform at both later uses -- in the epilogue and, for a wavefront with an undecided point, before
     // stage 2: 36 half-rate instructions per point.  The P2P pair also needs the point itself: x and y as floats in the stash's last 8
     // bytes, z in a 1 KB array of its own -- re-reading it from global memory at the epilogue cost 4.7 %.)
+#if ELM_STASH_OWN
+    // (round 5) the thread's OWN slots of values 4..7 of the reduction's first pass: doubles (4 + j) * kBlock + tid -- the address is
+    // tid * 8 plus immediate offsets (two ds_write2st64_b64 / ds_read2st64_b64), and the thread itself overwrites them first
+    auto stash_w = [&](double a, double b, double c, double d) {
+        double* p = s_buf + threadIdx.x;
+        p[4 * kBlock] = a; p[5 * kBlock] = b; p[6 * kBlock] = c; p[7 * kBlock] = d;
+    };
+    auto load_g = [&](double& gx, double& gy, double& gz, float& pxf, float& pyf) {
+        const double* p = s_buf + threadIdx.x;
+        gx = p[4 * kBlock]; gy = p[5 * kBlock]; gz = p[6 * kBlock];
+        const double w = p[7 * kBlock];
+        pxf = __int_as_float(__double2loint(w)); pyf = __int_as_float(__double2hiint(w));
+    };
+#else
     auto stash = [&](unsigned half) -> double2* { // recomputed at each use (an address held across the kernel costs a register)
         unsigned t = threadIdx.x;
         asm volatile("" : "+v"(t));
         return reinterpret_cast<double2*>(s_buf) + ((4u + 2u * half + ((t >> 5) & 1u)) * (kBlock / 2) + (t >> 6) * 32u + (t & 31u));
+    };
+    auto stash_w = [&](double a, double b, double c, double d) {
+        *stash(0) = make_double2(a, b);
+        *stash(1) = make_double2(c, d);
     };
     auto load_g = [&](double& gx, double& gy, double& gz, float& pxf, float& pyf) {
         const double2 a = *stash(0), b = *stash(1);
         gx = a.x; gy = a.y; gz = b.x;
         pxf = __int_as_float(__double2loint(b.y)); pyf = __int_as_float(__double2hiint(b.y));
     };
+#endif
     auto transform = [&](const float4 pf, double& px, double& py, double& pz, double& gx, double& gy, double& gz) {
         px = pf.x; py = pf.y; pz = pf.z;
         gx = ((S.T[0] * px + S.T[4] * py) + S.T[8] * pz) + S.T[12]; // g = T * [p, 1] (reg.hpp:141-146), the reference's association
@@ -1741,15 +1782,19 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
         // to gh and to g differ by at most eg = |g - gh|_1.  Everything the decision compares lies below rr (a winner at rr or
         // beyond is undecided anyway), so (sqrt(d) + eg)^2 <= d + egrr with egrr = 2 eg rr + eg^2: margins without a root.
         float ghx = (float)gx, ghy = (float)gy, ghz = (float)gz;
+#if ELM_EG_BOUND
+        // (|g - gh| <= half an ulp of gh per axis = 2^-24 |gh|: the bound instead of the three float64 differences)
+        const float eg = (fabsf(ghx) + fabsf(ghy) + fabsf(ghz)) * 5.9604652e-08f;
+#else
         const float eg = (fabsf((float)(gx - (double)ghx)) + fabsf((float)(gy - (double)ghy)) + fabsf((float)(gz - (double)ghz))) * 1.000001f;
+#endif
         float egrr = (2.0f * eg * fmaxf(rr, 0.f) + eg * eg) * 1.000001f;
         // for the ball of an undecided point: any block candidate is within 3.5 h of g
         float egblk = (7.0f * eg * (float)h + eg * eg) * 1.000001f;
         // a lane stops at the first column (in visiting order) that lies farther than its current winner
         float L1 = fminf(Bx, By), L2 = fmaxf(Bx, By), L3 = (Bx + By) * 0.999999f;
         asm volatile("" : "+v"(rr2), "+v"(ghx), "+v"(ghy), "+v"(ghz), "+v"(egrr), "+v"(egblk), "+v"(L1), "+v"(L2), "+v"(L3));
-        *stash(0) = make_double2(gx, gy);
-        *stash(1) = make_double2(gz, __hiloint2double(__float_as_int(pf.y), __float_as_int(pf.x)));
+        stash_w(gx, gy, gz, __hiloint2double(__float_as_int(pf.y), __float_as_int(pf.x)));
         if (METHOD == ELM_P2P) s_pz[threadIdx.x] = pf.z;
         if (STATS) s_st[threadIdx.x] = stat;
         {
@@ -2165,8 +2210,29 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
     __shared__ double s_asym[(METHOD != ELM_P2P && COMPACT != 2) ? kAsymSums : 1];
     __shared__ unsigned s_hitw[kBlock / 64];
     if (METHOD != ELM_P2P && COMPACT != 2) asym_mark(P.A, rp, s_hitw);
+#if ELM_REDUCE_WAVE
+    if (METHOD == ELM_P2P) {
+        const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            double a = v[k];
+            a += dpp_move<0xB1>(a);  // quad_perm [1,0,3,2]
+            a += dpp_move<0x4E>(a);  // quad_perm [2,3,0,1]
+            a += dpp_move<0x124>(a); // row_ror:4
+            a += dpp_move<0x128>(a); // row_ror:8
+            a += __shfl_xor(a, 16, 64);
+            a += __shfl_xor(a, 32, 64);
+            if (lane_ == 0) s_buf[wave_ * 32 + k] = a;
+        }
+        __syncthreads();
+        if (threadIdx.x < (unsigned)NV) s_red[threadIdx.x] = ((s_buf[threadIdx.x] + s_buf[32 + threadIdx.x]) + s_buf[64 + threadIdx.x]) + s_buf[96 + threadIdx.x];
+        __syncthreads();
+    } else
+#else
     if (METHOD == ELM_P2P) block_reduce_to_lds<NV, kRedPass>(v, s_buf, s_red);
-    else block_reduce_pair_sum<kRedPass, STATS ? kSums : kSums - 3>(P, s_buf, s_red);
+    else
+#endif
+        block_reduce_pair_sum<kRedPass, STATS ? kSums : kSums - 3>(P, s_buf, s_red);
     if (METHOD != ELM_P2P && COMPACT != 2) asym_side_store(P.A, P.ax, P.ay, P.az, L, rp, s_buf, s_asym, s_hitw);
     const int tk = (int)threadIdx.x;
     publish_and_reduce((tk < kSums && (STATS || tk < kSums - 3)) ? ((METHOD == ELM_P2P) ? p2p_expand(s_red, tk) : s_red[tk]) : 0.0, L, s, sd.blk_begin,
@@ -2891,62 +2957,62 @@ __device__ __forceinline__ void wave_ldlt6(double a, const double* b, double x[6
     }
 }
 
-// Matrix<double, 6, 6>::inverse() as Eigen computes it (PartialPivLU: row exchanges on the first largest |entry| of the column, then
-// the solve against the identity).  One lane, LDS operands throughout (row-major in `lu`, overwritten; row-major out; work = 12 doubles:
-// the permutation and one column) -- no private arrays, so the solve kernel stays free of scratch memory: only GICP with use_radar_cov
-// needs the inverse of a non-symmetric matrix.
-__device__ __forceinline__ void inverse6_partial_piv(double* lu, double* inv, double* work) {
-    double* perm = work;     // (exact small integers)
-    double* y = work + 6;
-#pragma unroll 1
-    for (int i = 0; i < 6; ++i) perm[i] = (double)i;
-#pragma unroll 1
+// Matrix<double, 6, 6>::inverse() as Eigen computes it (PartialPivLU: row exchanges on the first largest |entry| of the column, then the
+// solve against the identity), on the first wavefront: lane l < 36 holds A[l / 6][l % 6] and receives inverse[l / 6][l % 6].  Every
+// element sees the operations of the textbook one-thread loop in the same order (the eliminations of different elements are independent,
+// the substitutions run row by row) -- ~120 instructions instead of the ~1 500 of round 3's one-lane version with LDS operands (on a map
+// with asymmetric covariances nearly every GICP solve takes this path: 1.3 ms per bench step at 256 slots).  All 64 lanes execute it.
+__device__ __forceinline__ double wave_inverse6_partial_piv(double a) {
+    const int lane = threadIdx.x & 63;
+    const int li = (lane < 36) ? lane / 6 : 0, lj = (lane < 36) ? lane % 6 : 0;
+    int perm[6] = {0, 1, 2, 3, 4, 5};
+#pragma unroll
     for (int k = 0; k < 6; ++k) {
         int piv = k;
-        double best = fabs(lu[k * 6 + k]);
-#pragma unroll 1
+        double best = fabs(__shfl(a, k * 6 + k, 64));
+#pragma unroll
         for (int i = k + 1; i < 6; ++i) {
-            const double v = fabs(lu[i * 6 + k]);
-            if (v > best) { best = v; piv = i; }
+            const double v = fabs(__shfl(a, i * 6 + k, 64));
+            if (v > best) { best = v; piv = i; } // the first largest |entry| of the column
         }
-        if (piv != k) {
-#pragma unroll 1
-            for (int c = 0; c < 6; ++c) { const double tmp = lu[k * 6 + c]; lu[k * 6 + c] = lu[piv * 6 + c]; lu[piv * 6 + c] = tmp; }
-            const double tp = perm[k]; perm[k] = perm[piv]; perm[piv] = tp;
+        if (piv != k) { // (uniform) exchange rows k and piv
+            const int src = (li == k) ? piv : ((li == piv) ? k : li);
+            a = __shfl(a, src * 6 + lj, 64);
+#pragma unroll
+            for (int i = k + 1; i < 6; ++i)
+                if (i == piv) { const int t = perm[k]; perm[k] = perm[i]; perm[i] = t; }
         }
-        const double d = lu[k * 6 + k];
-        if (d != 0.0) {
-#pragma unroll 1
-            for (int i = k + 1; i < 6; ++i) lu[i * 6 + k] /= d;
-        }
-#pragma unroll 1
-        for (int c = k + 1; c < 6; ++c) {
-            const double ukc = lu[k * 6 + c];
-#pragma unroll 1
-            for (int i = k + 1; i < 6; ++i) lu[i * 6 + c] -= lu[i * 6 + k] * ukc;
-        }
+        const double d = __shfl(a, k * 6 + k, 64);
+        if (d != 0.0 && li > k && lj == k) a = a / d;
+        const double mult = __shfl(a, li * 6 + k, 64), ukc = __shfl(a, k * 6 + lj, 64);
+        if (li > k && lj > k) a -= mult * ukc;
     }
-#pragma unroll 1
-    for (int c = 0; c < 6; ++c) {
-#pragma unroll 1
-        for (int i = 0; i < 6; ++i) y[i] = (perm[i] == (double)c) ? 1.0 : 0.0;
-#pragma unroll 1
-        for (int i = 0; i < 6; ++i) {
-            double a = y[i];
-#pragma unroll 1
-            for (int j = 0; j < i; ++j) a -= lu[i * 6 + j] * y[j];
-            y[i] = a;
+    // the solve against the (row-permuted) identity: lane (i, c) holds y_i of column c
+    double Y = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Y = (li == i && perm[i] == lj) ? 1.0 : Y;
+#pragma unroll
+    for (int i = 1; i < 6; ++i) { // forward: unit lower triangle
+        double acc = Y;
+#pragma unroll
+        for (int j = 0; j < i; ++j) {
+            const double lij = __shfl(a, i * 6 + j, 64), yj = __shfl(Y, j * 6 + lj, 64);
+            acc -= lij * yj;
         }
-#pragma unroll 1
-        for (int i = 5; i >= 0; --i) {
-            double a = y[i];
-#pragma unroll 1
-            for (int j = i + 1; j < 6; ++j) a -= lu[i * 6 + j] * y[j];
-            y[i] = a / lu[i * 6 + i];
-        }
-#pragma unroll 1
-        for (int i = 0; i < 6; ++i) inv[i * 6 + c] = y[i];
+        if (li == i) Y = acc;
     }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) { // backward: upper triangle
+        double acc = Y;
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) {
+            const double uij = __shfl(a, i * 6 + j, 64), yj = __shfl(Y, j * 6 + lj, 64);
+            acc -= uij * yj;
+        }
+        const double uii = __shfl(a, i * 6 + i, 64);
+        if (li == i) Y = acc / uii;
+    }
+    return Y;
 }
 
 // queue position for a free slot, or -1 when nothing is pending.  Plain streams: every registration is there from the start, one
@@ -3276,14 +3342,10 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : 1) void k_solve(const ScanDesc*
     if (rp.method == ELM_GICP && !full36 && t < 36) S.local_cov[t] = inv_elem; // reg.cpp:141-142 (symmetric: layout-free)
     if (rp.method == ELM_GICP && full36) {
         // JTJ_regularized.inverse() of the FULL matrix (reg.cpp:141-142): Eigen's PartialPivLU + solve against the identity; column-major out
-        __shared__ double lu[36], invm[36], lu_work[12];
-        if (t < 36) lu[t] = (li == lj) ? full[t] + rp.lm_lambda * full[t] : full[t];
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
-        if (lead) inverse6_partial_piv(lu, invm, lu_work);
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
-        if (t < 36) S.local_cov[t] = invm[lj * 6 + li];
+        const double el = (t < 36) ? ((li == lj) ? full[t] + rp.lm_lambda * full[t] : full[t]) : 0.0;
+        const double inv_el = wave_inverse6_partial_piv(el);
+        const double inv_t = __shfl(inv_el, lj * 6 + li, 64);
+        if (t < 36) S.local_cov[t] = inv_t;
     }
 
     double dR[9];

@@ -65,6 +65,11 @@ struct PointStruct {
     }
 };
 
+// the reference's layout (vhm.hpp:55-87: 24 + 24 + 96 + 3 floats + pad + 8; Vector3d / Matrix3d of doubles are not "fixed-size
+// vectorizable" in Eigen, so neither struct carries an alignment requirement beyond 8 bytes or needs EIGEN_MAKE_ALIGNED_OPERATOR_NEW, and
+// std::vector<PointStruct> uses the default allocator there as here)
+static_assert(sizeof(CovStruct) == 96 && sizeof(PointStruct) == 168 && alignof(PointStruct) == 8, "PointStruct must keep the reference's layout");
+
 struct VoxelHashMap {
     using RadarPointVector = std::vector<PointStruct>;
     using RadarPointVectorTuple = std::tuple<RadarPointVector, RadarPointVector>;

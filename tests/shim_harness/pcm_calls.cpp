@@ -81,10 +81,8 @@ struct PcmMatching {
             return false;
         }
         cfg_.tf_ego_to_lidar = Eigen::Matrix4d::Identity();
-        for (int r = 0; r < 3; ++r) { // the reference writes these through .block<3,3>() / .block<3,1>() expressions (pcm.cpp:147-148)
-            for (int c = 0; c < 3; ++c) cfg_.tf_ego_to_lidar(r, c) = registration_config_.ego_to_lidar_rot(r, c);
-            cfg_.tf_ego_to_lidar(r, 3) = registration_config_.ego_to_lidar_trans(r);
-        }
+        cfg_.tf_ego_to_lidar.block<3, 3>(0, 0) = registration_config_.ego_to_lidar_rot;   // pcm.cpp:149-150: writable block expressions
+        cfg_.tf_ego_to_lidar.block<3, 1>(0, 3) = registration_config_.ego_to_lidar_trans;
         return true;
     }
 
@@ -119,7 +117,9 @@ struct PcmMatching {
         std::vector<PointStruct> vec_src_lidar_points =
                 local_map_.VoxelDownsample(vec_src_ori_lidar_points, cfg_.d_input_voxel_ds_m);
 
-        Eigen::Matrix4d sync_lidar_pose = sync_ego * cfg_.tf_ego_to_lidar;
+        Eigen::Affine3f sync_ego_affine = Eigen::Affine3f::Identity(); // (filled by GetInterpolatedPose in the node, pcm.cpp:248-251)
+        sync_ego_affine.matrix() = sync_ego.cast<float>();
+        Eigen::Matrix4d sync_lidar_pose = sync_ego_affine.matrix().cast<double>() * cfg_.tf_ego_to_lidar; // pcm.cpp:266
 
         bool b_icp_success = false;
         double d_fitness_score = 0.0;
@@ -131,7 +131,8 @@ struct PcmMatching {
             return false;
         }
         cfg_.d_icp_pose_std_m = d_fitness_score;
-        icp_ego_pose_out = icp_lidar_pose; // (* tf_ego_to_lidar.inverse() in the reference, pcm.cpp:298)
+        Eigen::Matrix4d icp_ego_pose = icp_lidar_pose * cfg_.tf_ego_to_lidar.inverse(); // pcm.cpp:298
+        icp_ego_pose_out = icp_ego_pose * cfg_.tf_ego_to_lidar; // (the harness checks the lidar pose)
 
         // transform vec_src_lidar_points to world frame
         registration_.TransformPoints(icp_lidar_pose, vec_src_lidar_points);
