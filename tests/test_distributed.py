@@ -187,3 +187,80 @@ def test_stream_static_slot_queue_world_size_2_gloo():
     assert res["same"]                       # identical refill decisions, collective counts and iteration counts on both ranks
     assert res["served"] == list(range(23))  # every registration was served exactly once
     assert len(set(res["iters"])) > 1        # and they finished at different iterations (the refills really interleave)
+
+
+def _refill_worker(rank, world_size, port, corrupt, out_q):
+    """The DEFAULT multi-rank stream protocol (k_solve mode 1 -> all-reduce -> mode 2 -> k_stream_refill): free slots take the pending
+    registrations in SLOT order (a prefix count over the finished flags, which derive from the all-reduced sums), and slots 29..31 of
+    every exchanged record carry the rank-agreement check (elimaloc_amd.dist.rank_check_*).  corrupt: rank 1 sees another termination
+    value for one slot once -- its slots drift apart from rank 0's, which the check must report on the very next exchange."""
+    import torch
+    import torch.distributed as dist
+    from elimaloc_amd.dist import rank_check_values, rank_check_ok
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    count, S, max_iter = 29, 6, 10
+    rng = np.random.default_rng(2000 + rank)
+    slot_reg = [s if s < count else -1 for s in range(S)]
+    slot_iter = [0] * S
+    nxt, completed, n_coll, fault_at, corrupted = min(S, count), 0, 0, None, None
+    order = []
+    for _ in range(((count + S - 1) // S + 1) * max_iter):  # the host's hard limit: every rank issues the same number of collectives
+        buf = np.zeros(S * 32)
+        for s in range(S):
+            if slot_reg[s] >= 0:
+                buf[s * 32] = rng.uniform(0.0, 1.0)
+            buf[s * 32 + 29:s * 32 + 32] = rank_check_values(slot_reg[s], slot_iter[s])
+        t = torch.from_numpy(buf)
+        dist.all_reduce(t)
+        n_coll += 1
+        free = []
+        for s in range(S):
+            if not rank_check_ok(buf[s * 32:(s + 1) * 32], slot_reg[s], slot_iter[s]) and fault_at is None:
+                fault_at = n_coll
+            if slot_reg[s] < 0:
+                continue
+            slot_iter[s] += 1
+            v = buf[s * 32]
+            if corrupt and rank == 1 and corrupted is None and n_coll >= 2 and v >= 0.45 * world_size and slot_iter[s] < max_iter:
+                v = 0.0  # this rank alone believes the slot has converged
+                corrupted = n_coll
+            if v < 0.45 * world_size or slot_iter[s] >= max_iter:
+                completed += 1
+                order.append(slot_reg[s])
+                free.append(s)
+        for s in free:  # slot order
+            slot_reg[s] = nxt if nxt < count else -1
+            slot_iter[s] = 0
+            nxt += 1 if slot_reg[s] >= 0 else 0
+        if fault_at is not None and corrupt:
+            break
+        if completed >= count and not corrupt:
+            break
+    gathered = [None] * world_size
+    dist.all_gather_object(gathered, (order, n_coll, fault_at, corrupted))
+    if rank == 0:
+        out_q.put(dict(orders=[g[0] for g in gathered], n_coll=[g[1] for g in gathered], fault_at=[g[2] for g in gathered], corrupted=gathered[1][3]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("corrupt", [False, True])
+def test_stream_slot_order_refill_and_rank_check_world_size_2_gloo(corrupt):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 200) + (50 if corrupt else 0)
+    procs = [ctx.Process(target=_refill_worker, args=(r, 2, port, corrupt, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if not corrupt:
+        assert res["orders"][0] == res["orders"][1] and sorted(res["orders"][0]) == list(range(29))  # same refill decisions, every registration once
+        assert res["n_coll"][0] == res["n_coll"][1] and res["fault_at"] == [None, None]
+    else:
+        # rank 1 freed a slot one exchange early and refilled it: at the NEXT exchange both ranks see sum(id) != n id for that slot
+        assert res["corrupted"] is not None and res["fault_at"] == [res["corrupted"] + 1] * 2, res

@@ -8,7 +8,7 @@
 #   dist1                      the default command under torch.distributed.run --nproc-per-node 1 (one-rank RCCL communicator)
 #   ab:<name>:<tags>[:args]    A/B of prebuilt library variants build_ab/lib_<tag>.so (comma list, each run twice, interleaved) on
 #                              `bench.py --no-cpu --no-extras <args, _ for spaces> $AB_ARGS`
-#   fuzz:<cases>:<seed0>       tools/fuzz_parity.py (env FUZZ_ENV="ELM_X=1 ..." is applied)
+#   fuzz:<cases>:<seed0>[:ENV=1,ENV2=x;--extra_args]   tools/fuzz_parity.py (environment assignments, then extra arguments with _ for spaces)
 #   profiles[:legs]            tools/r5_profiles.sh (legs comma list: p2p,gicp,vgicp,avgicp,hard,c4)
 #   timeline                   kernel timeline of one ICP iteration on the one-rank RCCL path (tools/trace_gaps_dist1.sh)
 #   probes                     tools/probes/run_valu_probe.sh + run_gather_probe.sh
@@ -84,7 +84,9 @@ except Exception as e:  # noqa: BLE001
 PY
       rm -rf $O/sq_$a $O/ta_$a ;;
     fuzz)
-      env ${FUZZ_ENV:-} timeout 1500 python tools/fuzz_parity.py --cases $a --seed0 $b > $O/fuzz_$b.txt 2>&1; echo "fuzz seed0 $b ${FUZZ_ENV:-}: $(tail -1 $O/fuzz_$b.txt)" ;;
+      fe=${c%%;*}; fa=""; [ "$c" != "${c#*;}" ] && fa=${c#*;}   # c = "ENV=1,ENV2=x;--extra_args" (both parts optional)
+      env ${FUZZ_ENV:-} ${fe//,/ } timeout 3000 python tools/fuzz_parity.py --cases $a --seed0 $b ${fa//_/ } > $O/fuzz_$b.txt 2>&1
+      echo "fuzz $a cases from seed $b [${fe}] [${fa//_/ }]: $(tail -1 $O/fuzz_$b.txt)"; grep -E "^MISMATCH|singular|raised" $O/fuzz_$b.txt | head -8 ;;
     profiles)
       tools/r5_profiles.sh ${a//,/ } ;;
     timeline)
