@@ -137,6 +137,13 @@ def generate_inputs(world, args, rank, world_size, dist, guess, n_keep, keep_own
     def gen(i):
         sc, Tt = synth.make_scan(world, npts, seed=2002 + i, max_range=SCAN_RANGE_M, noise=SCAN_NOISE_M)
         T0 = synth.perturb(Tt, seed=3003 + i, **guess)
+        pre = os.environ.get("ELM_BENCH_POINT_ORDER", "")  # developer A/B of the CALLER's point order (not the default workload)
+        if pre == "shuffle":  # no locality at all inside the ordering kernel's 2 m cells (a spinning LiDAR's firing order)
+            sc = np.ascontiguousarray(sc[np.random.default_rng(4004 + i).permutation(sc.shape[0])])
+        elif pre:  # rows sorted by the sensor-frame cell of that size (x-major) before the upload
+            c = float(pre)
+            key = np.floor(sc[:, 0] / c).astype(np.int64) * 65536 + np.floor(sc[:, 1] / c).astype(np.int64)
+            sc = np.ascontiguousarray(sc[np.argsort(key, kind="stable")])
         h = hashlib.sha1(sc.tobytes())
         h.update(np.ascontiguousarray(T0).tobytes())
         rmax = float(np.sqrt((sc.astype(np.float64) ** 2).sum(axis=1).max())) if sc.shape[0] else 0.0

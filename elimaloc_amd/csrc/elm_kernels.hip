@@ -1622,6 +1622,206 @@ __device__ __forceinline__ const uint32_t* col_cells(const DevMap& m, int cx, in
 #ifndef ELM_GICP_WAVES
 #define ELM_GICP_WAVES 7 // GICP: 5 (the old cap; the kernel used 72 VGPRs anyway) -> 71.2-71.6 k, 7 (one spill) -> 72.5-73.3 k, 8 (8 spills) -> 67.2 k
 #endif
+// The exact search of ONE undecided point by its group of LPI lanes (stage 2 of k_accumulate_grid): the ball of radius sqrt(R.r2) around g (seeded first when stage 1 found nothing) intersected with the reference's allowed cell
+// range and the grid, float32 keys first, the reference's float64 distances and visiting order on a near tie.  win: block * 4 + slot of the
+// nearest neighbour (-1: none), the same value in every lane of the group; walked: candidate slots this lane tested (instrumented builds).
+template <int TILED, unsigned LPI>
+__device__ __forceinline__ void grid_ball_walk(const DevMap& m, const GridBlk* __restrict__ lp, const GridHardRec& R, const bool live, const unsigned rl,
+                                               const unsigned lane, int& win_out, int& walked_out) {
+    const GridAxis ax = grid_axis(R.gx, m), ay = grid_axis(R.gy, m), az = grid_axis(R.gz, m);
+    int lox = ax.alo, hix = ax.ahi, loy = ay.alo, hiy = ay.ahi, loz = az.alo, hiz = az.ahi;
+    int seeded = 0;
+    float r2s = R.r2;
+#if ELM_S2_SEED
+    // A point whose stage-1 block came back EMPTY (a third of the undecided points under a poor initial guess: the surface is
+    // two cells below the point) has no ball: it would walk all 36 columns of its 27 voxels, ~240 candidates.  Seed it first:
+    // the group's lanes probe the 2 x 2 columns nearest to the point over the whole allowed z-range; the nearest candidate found
+    // there bounds the nearest neighbour, and the walk below is confined to that ball like any other undecided point's.
+    if (__any(live && !(r2s < __builtin_inff()))) { // wave-uniform
+        float best = __builtin_inff();
+        if (live && !(r2s < __builtin_inff())) {
+            const double inv_h = 2.0 / m.voxel_size;
+            const int cx0 = (int)floor(R.gx * inv_h - 0.5), cy0 = (int)floor(R.gy * inv_h - 0.5);
+            const float shx = (float)R.gx, shy = (float)R.gy, shz = (float)R.gz;
+            const f32x2 sxy = {shx, shy}, szl = {shz, (float)(R.gx - (double)shx)}, sl2 = {(float)(R.gy - (double)shy), (float)(R.gz - (double)shz)};
+            const int zlo = max(az.alo - m.gz0, 0), zhi = min(az.ahi - m.gz0, m.gnz - 1);
+            for (unsigned q = rl; q < 4u; q += LPI) {
+                const int cxa = cx0 + (int)(q & 1u), cya = cy0 + (int)(q >> 1);
+                const int cx = cxa - m.gx0, cy = cya - m.gy0;
+                if (cxa < ax.alo || cxa > ax.ahi || cya < ay.alo || cya > ay.ahi || cx < 0 || cx >= m.gnx || cy < 0 || cy >= m.gny || zlo > zhi) continue;
+                int zc0, nzc;
+                const uint32_t* e = col_cells<TILED>(m, cx, cy, zlo, zhi, zc0, nzc);
+                const int b0 = (int)e[0], b1 = (int)e[nzc];
+                seeded += 4 * (b1 - b0);
+                for (int b = b0; b < b1; ++b) {
+                    f32x2 da, db;
+                    blk_dist(lp[b], sxy, szl, sl2, da, db);
+                    best = fminf(best, fminf(fminf(da.x, da.y), fminf(db.x, db.y)));
+                }
+            }
+        }
+        best = __uint_as_float(group_min_u32<LPI>(__float_as_uint(best))); // non-negative floats order like their bit patterns
+        if (!(r2s < __builtin_inff()) && best < 1e30f) // (padding slots sit at 1e18: their squares are not candidates)
+            r2s = best + best * 4e-6f + 4e-11f * (fabsf((float)R.gx) + fabsf((float)R.gy) + fabsf((float)R.gz) + 1.0f);
+    }
+#endif
+    if (r2s < __builtin_inff()) {
+        // every candidate within sqrt(r2) of g -- the nearest one and whatever ties with it -- has its cell inside the
+        // per-axis cell range of [g - r, g + r] (1e-6 of margin: a stored coordinate exactly on a cell face counts to the
+        // cell further from zero, grid_cell_of)
+        const double r = (double)(__builtin_sqrtf(r2s) * 1.000001f) + 1e-6; // float32 root (1 ulp) inside the margin
+        const double inv_h = 2.0 / m.voxel_size;
+        lox = max(lox, (int)floor((R.gx - r) * inv_h)); hix = min(hix, (int)floor((R.gx + r) * inv_h));
+        loy = max(loy, (int)floor((R.gy - r) * inv_h)); hiy = min(hiy, (int)floor((R.gy + r) * inv_h));
+        loz = max(loz, (int)floor((R.gz - r) * inv_h)); hiz = min(hiz, (int)floor((R.gz + r) * inv_h));
+    }
+    lox = max(lox - m.gx0, 0); hix = min(hix - m.gx0, m.gnx - 1);
+    loy = max(loy - m.gy0, 0); hiy = min(hiy - m.gy0, m.gny - 1);
+    loz = max(loz - m.gz0, 0); hiz = min(hiz - m.gz0, m.gnz - 1);
+    const int nx = hix - lox + 1, ny = hiy - loy + 1, nz = hiz - loz + 1;
+    const int ncol = (live && nx > 0 && ny > 0 && nz > 0) ? nx * ny : 0;
+    // float32 pass over this lane's columns first (the arithmetic of stage 1): a winner that leads the runner-up of the
+    // whole ball by the margin is the float64 winner as well
+    const unsigned gsh = threadIdx.x & 63u & ~(LPI - 1u);
+    const unsigned long long gmask = ((1ull << LPI) - 1ull) << gsh;
+    int win = -1, walked = seeded;
+    bool need64 = false;
+    {
+        // distances to gh = float32(g) alone (six packed subtractions fewer per block, as in stage 1): an exact distance to g differs
+        // from the one to gh by at most eg = |g - gh|_1 in the ROOT, which the decision below pays for
+        const float ghx = (float)R.gx, ghy = (float)R.gy, ghz = (float)R.gz;
+        const float glx = (float)(R.gx - (double)ghx), gly = (float)(R.gy - (double)ghy), glz = (float)(R.gz - (double)ghz);
+        const float eg = ELM_S2_GH ? (fabsf(glx) + fabsf(gly) + fabsf(glz)) * 1.000001f : 0.f;
+        const f32x2 gxy = {ghx, ghy}, gzz = {ghz, 0.f}, gzl = {ghz, glx}, gl2 = {gly, glz};
+        (void)gzz; (void)gzl; (void)gl2;
+        unsigned m1 = 0x7F800000u, m2 = 0x7F800000u;
+        int jb = 0;
+        const float rny = __builtin_amdgcn_rcpf((float)ny); // c / ny for the few dozen columns of a ball: exact via float32
+#if ELM_S2_PIPE
+        // software-pipelined walk: the offsets of this lane's NEXT column are requested before the current column's blocks
+        // are walked, and block b + 1 before block b is evaluated -- the walk is a chain of dependent round trips (offsets ->
+        // blocks, column after column) that the other wavefronts only partly hide when many points are undecided
+        auto col_run = [&](int c, int& r0, int& r1) {
+            const int qx = (int)(((float)c + 0.5f) * rny);
+            const int cx = lox + qx, cy = loy + (c - qx * ny);
+            int zc0, nzc;
+            const uint32_t* e = col_cells<TILED>(m, cx, cy, loz, hiz, zc0, nzc);
+            r0 = (int)e[0]; r1 = (int)e[nzc];
+        };
+        int c = (int)rl, nb0 = 0, nb1 = 0;
+        if (c < ncol) col_run(c, nb0, nb1);
+        while (c < ncol) {
+            const int b0 = nb0, b1 = nb1;
+            c += (int)LPI;
+            if (c < ncol) col_run(c, nb0, nb1);
+            walked += 4 * (b1 - b0);
+            GridBlk Bn = lp[(b0 < b1) ? b0 : 0];
+            for (int b = b0; b < b1; ++b) {
+                const GridBlk B = Bn;
+                Bn = lp[(b + 1 < b1) ? b + 1 : 0]; // (block 0: the padding block, always resident)
+                f32x2 da, db;
+                if (ELM_S2_GH) blk_dist_h(B, gxy, gzz, da, db);
+                else blk_dist(B, gxy, gzl, gl2, da, db);
+                const unsigned was = m1;
+                two_smallest(da.x, 0u, m1, m2);
+                two_smallest(da.y, 1u, m1, m2);
+                two_smallest(db.x, 2u, m1, m2);
+                two_smallest(db.y, 3u, m1, m2);
+                jb = (m1 != was) ? b : jb;
+            }
+        }
+#else
+        for (int c = (int)rl; c < ncol; c += (int)LPI) {
+            const int qx = (int)(((float)c + 0.5f) * rny);
+            const int cx = lox + qx, cy = loy + (c - qx * ny);
+            int zc0, nzc;
+            const uint32_t* e = col_cells<TILED>(m, cx, cy, loz, hiz, zc0, nzc);
+            const int b0 = (int)e[0], b1 = (int)e[nzc];
+            walked += 4 * (b1 - b0);
+            for (int b = b0; b < b1; ++b) {
+                const GridBlk B = lp[b];
+                f32x2 da, db;
+                if (ELM_S2_GH) blk_dist_h(B, gxy, gzz, da, db);
+                else blk_dist(B, gxy, gzl, gl2, da, db);
+                const unsigned was = m1;
+                two_smallest(da.x, 0u, m1, m2);
+                two_smallest(da.y, 1u, m1, m2);
+                two_smallest(db.x, 2u, m1, m2);
+                two_smallest(db.y, 3u, m1, m2);
+                jb = (m1 != was) ? b : jb;
+            }
+        }
+#endif
+        const unsigned m1g = group_min_u32<LPI>(m1);
+        const unsigned long long holders = __ballot(m1 == m1g) & gmask;
+        const unsigned hl = (unsigned)__ffsll((long long)holders) - 1u; // first lane of the group that holds the minimum
+        const unsigned m2g = group_min_u32<LPI>((lane == hl) ? m2 : m1); // a second holder of the same key counts as a tie
+        const int jw = __shfl(jb * 4 + (int)(m1 & 3u), (int)hl, 64);
+        const float d1 = __uint_as_float(m1g & ~3u), d2 = __uint_as_float(m2g & ~3u);
+        // clear float32 winner: sqrt(d2) - sqrt(d1) > 2 eg holds for the distances to gh (2^-18: float32 arithmetic + key bits, see
+        // stage 1) <=> d2 > d1 + 4 eg sqrt(d1) + 4 eg^2, with sqrt(d2) >= sqrt(d1) in its place (one root per point, padding
+        // slots at 1e36 included: they never win)
+        const float s2 = __builtin_sqrtf(fminf(d2, 1e30f)) * 1.000001f;
+        const float slack = ELM_S2_GH ? (4.0f * eg * s2 + 4.0f * eg * eg) * 1.000001f : 4e-11f * (fabsf(ghx) + fabsf(ghy) + fabsf(ghz) + 1.0f);
+        if (jw >= 4 && d2 > d1 + d1 * 3.814697265625e-06f + slack) win = jw; // (2^-18 on one side covers both, as in stage 1)
+        else need64 = live && jw >= 4;                                         // near tie: the float64 walk below decides
+    }
+    if (__any(need64)) { // wave-uniform; practically never taken
+        // near tie in float32: the reference's float64 arithmetic decides.  First the float64 minimum over the ball, then,
+        // among the candidates that meet it (usually one), the one the reference meets first -- bucket visiting rank
+        // (vhm.cpp:234-240: x-major .. z-minor over the stored keys f-1..f+1), then insertion order (= bucket-order index).
+        // The bucket of a cell: c >= 2 -> c >> 1, -2 <= c <= 1 -> 0, c <= -3 -> (c + 2) >> 1.
+        const int ncol64 = need64 ? ncol : 0;
+        double bd = DBL_MAX;
+#pragma unroll 1
+        for (int c = (int)rl; c < ncol64; c += (int)LPI) {
+            const int cx = lox + c / ny, cy = loy + c % ny;
+            int zc0, nzc;
+            const uint32_t* e = col_cells<TILED>(m, cx, cy, loz, hiz, zc0, nzc);
+#pragma unroll 1
+            for (int k = 4 * (int)e[0]; k < 4 * (int)e[nzc]; ++k) {
+                const Pt3 q = blk_point(lp, k);
+                const double ex = (double)q.x - R.gx, ey = (double)q.y - R.gy, ez = (double)q.z - R.gz;
+                bd = fmin((ex * ex + ey * ey) + ez * ez, bd);
+            }
+        }
+        const double dmin = group_min<LPI>(bd);
+        unsigned brank = 0xFFFFFFFFu, bgi = 0xFFFFFFFFu;
+        int bk = -1;
+#pragma unroll 1
+        for (int c = (int)rl; c < ncol64; c += (int)LPI) {
+            const int cx = lox + c / ny, cy = loy + c % ny;
+            const int ccx = cx + m.gx0, ccy = cy + m.gy0;
+            const int kx = ccx >= 2 ? ccx >> 1 : (ccx >= -2 ? 0 : (ccx + 2) >> 1), ky = ccy >= 2 ? ccy >> 1 : (ccy >= -2 ? 0 : (ccy + 2) >> 1);
+            int zc0, nzc;
+            const uint32_t* e = col_cells<TILED>(m, cx, cy, loz, hiz, zc0, nzc);
+#pragma unroll 1
+            for (int z = 0; z < nzc; ++z) {
+                const int ccz = zc0 + z + m.gz0;
+                const int kz = ccz >= 2 ? ccz >> 1 : (ccz >= -2 ? 0 : (ccz + 2) >> 1);
+                const unsigned rank = (unsigned)(((kx - ax.f + 1) * 3 + (ky - ay.f + 1)) * 3 + (kz - az.f + 1));
+#pragma unroll 1
+                for (int k = 4 * (int)e[z]; k < 4 * (int)e[z + 1]; ++k) {
+                    const Pt3 q = blk_point(lp, k);
+                    const double ex = (double)q.x - R.gx, ey = (double)q.y - R.gy, ez = (double)q.z - R.gz;
+                    if ((ex * ex + ey * ey) + ez * ez != dmin) continue;
+                    const unsigned gi = m.grid_idx[k];
+                    if (rank < brank || (rank == brank && gi < bgi)) { brank = rank; bgi = gi; bk = k; }
+                }
+            }
+        }
+#pragma unroll
+        for (int off = (int)LPI / 2; off > 0; off >>= 1) {
+            const unsigned orank = (unsigned)__shfl_xor((int)brank, off, 64), og = (unsigned)__shfl_xor((int)bgi, off, 64);
+            const int ok = __shfl_xor(bk, off, 64);
+            if (orank < brank || (orank == brank && og < bgi)) { brank = orank; bgi = og; bk = ok; }
+        }
+        win = need64 ? bk : win;
+    }
+    win_out = win;
+    walked_out = walked;
+}
+
 // STATS = 1 (elm_ctx_set_work_counters): the launch also sums the three work counters (candidates / occupied buckets of the reference's
 // walk from the dense statistics box, candidates this kernel tested + points served by stage 2).  The production launches run with
 // STATS = 0: no statistics load, 18 (P2P) / 29 reduced values, no per-point bookkeeping in stage 2.
@@ -1919,196 +2119,8 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
             if (it0 + (threadIdx.x & ~63u) / LPI >= n_hard) break; // wave-uniform: this wavefront has no point in this pass
             const bool live = it < n_hard;
             const GridHardRec R = s_rec[live ? it : 0];
-            const GridAxis ax = grid_axis(R.gx, m), ay = grid_axis(R.gy, m), az = grid_axis(R.gz, m);
-            int lox = ax.alo, hix = ax.ahi, loy = ay.alo, hiy = ay.ahi, loz = az.alo, hiz = az.ahi;
-            int seeded = 0;
-            float r2s = R.r2;
-#if ELM_S2_SEED
-            // A point whose stage-1 block came back EMPTY (a third of the undecided points under a poor initial guess: the surface is
-            // two cells below the point) has no ball: it would walk all 36 columns of its 27 voxels, ~240 candidates.  Seed it first:
-            // the group's lanes probe the 2 x 2 columns nearest to the point over the whole allowed z-range; the nearest candidate found
-            // there bounds the nearest neighbour, and the walk below is confined to that ball like any other undecided point's.
-            if (__any(live && !(r2s < __builtin_inff()))) { // wave-uniform
-                float best = __builtin_inff();
-                if (live && !(r2s < __builtin_inff())) {
-                    const double inv_h = 2.0 / m.voxel_size;
-                    const int cx0 = (int)floor(R.gx * inv_h - 0.5), cy0 = (int)floor(R.gy * inv_h - 0.5);
-                    const float shx = (float)R.gx, shy = (float)R.gy, shz = (float)R.gz;
-                    const f32x2 sxy = {shx, shy}, szl = {shz, (float)(R.gx - (double)shx)}, sl2 = {(float)(R.gy - (double)shy), (float)(R.gz - (double)shz)};
-                    const int zlo = max(az.alo - m.gz0, 0), zhi = min(az.ahi - m.gz0, m.gnz - 1);
-                    for (unsigned q = rl; q < 4u; q += LPI) {
-                        const int cxa = cx0 + (int)(q & 1u), cya = cy0 + (int)(q >> 1);
-                        const int cx = cxa - m.gx0, cy = cya - m.gy0;
-                        if (cxa < ax.alo || cxa > ax.ahi || cya < ay.alo || cya > ay.ahi || cx < 0 || cx >= m.gnx || cy < 0 || cy >= m.gny || zlo > zhi) continue;
-                        int zc0, nzc;
-                        const uint32_t* e = col_cells<TILED>(m, cx, cy, zlo, zhi, zc0, nzc);
-                        const int b0 = (int)e[0], b1 = (int)e[nzc];
-                        seeded += 4 * (b1 - b0);
-                        for (int b = b0; b < b1; ++b) {
-                            f32x2 da, db;
-                            blk_dist(lp[b], sxy, szl, sl2, da, db);
-                            best = fminf(best, fminf(fminf(da.x, da.y), fminf(db.x, db.y)));
-                        }
-                    }
-                }
-                best = __uint_as_float(group_min_u32<LPI>(__float_as_uint(best))); // non-negative floats order like their bit patterns
-                if (!(r2s < __builtin_inff()) && best < 1e30f) // (padding slots sit at 1e18: their squares are not candidates)
-                    r2s = best + best * 4e-6f + 4e-11f * (fabsf((float)R.gx) + fabsf((float)R.gy) + fabsf((float)R.gz) + 1.0f);
-            }
-#endif
-            if (r2s < __builtin_inff()) {
-                // every candidate within sqrt(r2) of g -- the nearest one and whatever ties with it -- has its cell inside the
-                // per-axis cell range of [g - r, g + r] (1e-6 of margin: a stored coordinate exactly on a cell face counts to the
-                // cell further from zero, grid_cell_of)
-                const double r = (double)(__builtin_sqrtf(r2s) * 1.000001f) + 1e-6; // float32 root (1 ulp) inside the margin
-                const double inv_h = 2.0 / m.voxel_size;
-                lox = max(lox, (int)floor((R.gx - r) * inv_h)); hix = min(hix, (int)floor((R.gx + r) * inv_h));
-                loy = max(loy, (int)floor((R.gy - r) * inv_h)); hiy = min(hiy, (int)floor((R.gy + r) * inv_h));
-                loz = max(loz, (int)floor((R.gz - r) * inv_h)); hiz = min(hiz, (int)floor((R.gz + r) * inv_h));
-            }
-            lox = max(lox - m.gx0, 0); hix = min(hix - m.gx0, m.gnx - 1);
-            loy = max(loy - m.gy0, 0); hiy = min(hiy - m.gy0, m.gny - 1);
-            loz = max(loz - m.gz0, 0); hiz = min(hiz - m.gz0, m.gnz - 1);
-            const int nx = hix - lox + 1, ny = hiy - loy + 1, nz = hiz - loz + 1;
-            const int ncol = (live && nx > 0 && ny > 0 && nz > 0) ? nx * ny : 0;
-            // float32 pass over this lane's columns first (the arithmetic of stage 1): a winner that leads the runner-up of the
-            // whole ball by the margin is the float64 winner as well
-            const unsigned gsh = threadIdx.x & 63u & ~(LPI - 1u);
-            const unsigned long long gmask = ((1ull << LPI) - 1ull) << gsh;
-            int win = -1, walked = seeded;
-            bool need64 = false;
-            {
-                // distances to gh = float32(g) alone (six packed subtractions fewer per block, as in stage 1): an exact distance to g differs
-                // from the one to gh by at most eg = |g - gh|_1 in the ROOT, which the decision below pays for
-                const float ghx = (float)R.gx, ghy = (float)R.gy, ghz = (float)R.gz;
-                const float glx = (float)(R.gx - (double)ghx), gly = (float)(R.gy - (double)ghy), glz = (float)(R.gz - (double)ghz);
-                const float eg = ELM_S2_GH ? (fabsf(glx) + fabsf(gly) + fabsf(glz)) * 1.000001f : 0.f;
-                const f32x2 gxy = {ghx, ghy}, gzz = {ghz, 0.f}, gzl = {ghz, glx}, gl2 = {gly, glz};
-                (void)gzz; (void)gzl; (void)gl2;
-                unsigned m1 = 0x7F800000u, m2 = 0x7F800000u;
-                int jb = 0;
-                const float rny = __builtin_amdgcn_rcpf((float)ny); // c / ny for the few dozen columns of a ball: exact via float32
-#if ELM_S2_PIPE
-                // software-pipelined walk: the offsets of this lane's NEXT column are requested before the current column's blocks
-                // are walked, and block b + 1 before block b is evaluated -- the walk is a chain of dependent round trips (offsets ->
-                // blocks, column after column) that the other wavefronts only partly hide when many points are undecided
-                auto col_run = [&](int c, int& r0, int& r1) {
-                    const int qx = (int)(((float)c + 0.5f) * rny);
-                    const int cx = lox + qx, cy = loy + (c - qx * ny);
-                    int zc0, nzc;
-                    const uint32_t* e = col_cells<TILED>(m, cx, cy, loz, hiz, zc0, nzc);
-                    r0 = (int)e[0]; r1 = (int)e[nzc];
-                };
-                int c = (int)rl, nb0 = 0, nb1 = 0;
-                if (c < ncol) col_run(c, nb0, nb1);
-                while (c < ncol) {
-                    const int b0 = nb0, b1 = nb1;
-                    c += (int)LPI;
-                    if (c < ncol) col_run(c, nb0, nb1);
-                    walked += 4 * (b1 - b0);
-                    GridBlk Bn = lp[(b0 < b1) ? b0 : 0];
-                    for (int b = b0; b < b1; ++b) {
-                        const GridBlk B = Bn;
-                        Bn = lp[(b + 1 < b1) ? b + 1 : 0]; // (block 0: the padding block, always resident)
-                        f32x2 da, db;
-                        if (ELM_S2_GH) blk_dist_h(B, gxy, gzz, da, db);
-                        else blk_dist(B, gxy, gzl, gl2, da, db);
-                        const unsigned was = m1;
-                        two_smallest(da.x, 0u, m1, m2);
-                        two_smallest(da.y, 1u, m1, m2);
-                        two_smallest(db.x, 2u, m1, m2);
-                        two_smallest(db.y, 3u, m1, m2);
-                        jb = (m1 != was) ? b : jb;
-                    }
-                }
-#else
-                for (int c = (int)rl; c < ncol; c += (int)LPI) {
-                    const int qx = (int)(((float)c + 0.5f) * rny);
-                    const int cx = lox + qx, cy = loy + (c - qx * ny);
-                    int zc0, nzc;
-                    const uint32_t* e = col_cells<TILED>(m, cx, cy, loz, hiz, zc0, nzc);
-                    const int b0 = (int)e[0], b1 = (int)e[nzc];
-                    walked += 4 * (b1 - b0);
-                    for (int b = b0; b < b1; ++b) {
-                        const GridBlk B = lp[b];
-                        f32x2 da, db;
-                        if (ELM_S2_GH) blk_dist_h(B, gxy, gzz, da, db);
-                        else blk_dist(B, gxy, gzl, gl2, da, db);
-                        const unsigned was = m1;
-                        two_smallest(da.x, 0u, m1, m2);
-                        two_smallest(da.y, 1u, m1, m2);
-                        two_smallest(db.x, 2u, m1, m2);
-                        two_smallest(db.y, 3u, m1, m2);
-                        jb = (m1 != was) ? b : jb;
-                    }
-                }
-#endif
-                const unsigned m1g = group_min_u32<LPI>(m1);
-                const unsigned long long holders = __ballot(m1 == m1g) & gmask;
-                const unsigned hl = (unsigned)__ffsll((long long)holders) - 1u; // first lane of the group that holds the minimum
-                const unsigned m2g = group_min_u32<LPI>((lane == hl) ? m2 : m1); // a second holder of the same key counts as a tie
-                const int jw = __shfl(jb * 4 + (int)(m1 & 3u), (int)hl, 64);
-                const float d1 = __uint_as_float(m1g & ~3u), d2 = __uint_as_float(m2g & ~3u);
-                // clear float32 winner: sqrt(d2) - sqrt(d1) > 2 eg holds for the distances to gh (2^-18: float32 arithmetic + key bits, see
-                // stage 1) <=> d2 > d1 + 4 eg sqrt(d1) + 4 eg^2, with sqrt(d2) >= sqrt(d1) in its place (one root per point, padding
-                // slots at 1e36 included: they never win)
-                const float s2 = __builtin_sqrtf(fminf(d2, 1e30f)) * 1.000001f;
-                const float slack = ELM_S2_GH ? (4.0f * eg * s2 + 4.0f * eg * eg) * 1.000001f : 4e-11f * (fabsf(ghx) + fabsf(ghy) + fabsf(ghz) + 1.0f);
-                if (jw >= 4 && d2 > d1 + d1 * 3.814697265625e-06f + slack) win = jw; // (2^-18 on one side covers both, as in stage 1)
-                else need64 = live && jw >= 4;                                         // near tie: the float64 walk below decides
-            }
-            if (__any(need64)) { // wave-uniform; practically never taken
-                // near tie in float32: the reference's float64 arithmetic decides.  First the float64 minimum over the ball, then,
-                // among the candidates that meet it (usually one), the one the reference meets first -- bucket visiting rank
-                // (vhm.cpp:234-240: x-major .. z-minor over the stored keys f-1..f+1), then insertion order (= bucket-order index).
-                // The bucket of a cell: c >= 2 -> c >> 1, -2 <= c <= 1 -> 0, c <= -3 -> (c + 2) >> 1.
-                const int ncol64 = need64 ? ncol : 0;
-                double bd = DBL_MAX;
-#pragma unroll 1
-                for (int c = (int)rl; c < ncol64; c += (int)LPI) {
-                    const int cx = lox + c / ny, cy = loy + c % ny;
-                    int zc0, nzc;
-                    const uint32_t* e = col_cells<TILED>(m, cx, cy, loz, hiz, zc0, nzc);
-#pragma unroll 1
-                    for (int k = 4 * (int)e[0]; k < 4 * (int)e[nzc]; ++k) {
-                        const Pt3 q = blk_point(lp, k);
-                        const double ex = (double)q.x - R.gx, ey = (double)q.y - R.gy, ez = (double)q.z - R.gz;
-                        bd = fmin((ex * ex + ey * ey) + ez * ez, bd);
-                    }
-                }
-                const double dmin = group_min<LPI>(bd);
-                unsigned brank = 0xFFFFFFFFu, bgi = 0xFFFFFFFFu;
-                int bk = -1;
-#pragma unroll 1
-                for (int c = (int)rl; c < ncol64; c += (int)LPI) {
-                    const int cx = lox + c / ny, cy = loy + c % ny;
-                    const int ccx = cx + m.gx0, ccy = cy + m.gy0;
-                    const int kx = ccx >= 2 ? ccx >> 1 : (ccx >= -2 ? 0 : (ccx + 2) >> 1), ky = ccy >= 2 ? ccy >> 1 : (ccy >= -2 ? 0 : (ccy + 2) >> 1);
-                    int zc0, nzc;
-                    const uint32_t* e = col_cells<TILED>(m, cx, cy, loz, hiz, zc0, nzc);
-#pragma unroll 1
-                    for (int z = 0; z < nzc; ++z) {
-                        const int ccz = zc0 + z + m.gz0;
-                        const int kz = ccz >= 2 ? ccz >> 1 : (ccz >= -2 ? 0 : (ccz + 2) >> 1);
-                        const unsigned rank = (unsigned)(((kx - ax.f + 1) * 3 + (ky - ay.f + 1)) * 3 + (kz - az.f + 1));
-#pragma unroll 1
-                        for (int k = 4 * (int)e[z]; k < 4 * (int)e[z + 1]; ++k) {
-                            const Pt3 q = blk_point(lp, k);
-                            const double ex = (double)q.x - R.gx, ey = (double)q.y - R.gy, ez = (double)q.z - R.gz;
-                            if ((ex * ex + ey * ey) + ez * ez != dmin) continue;
-                            const unsigned gi = m.grid_idx[k];
-                            if (rank < brank || (rank == brank && gi < bgi)) { brank = rank; bgi = gi; bk = k; }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int off = (int)LPI / 2; off > 0; off >>= 1) {
-                    const unsigned orank = (unsigned)__shfl_xor((int)brank, off, 64), og = (unsigned)__shfl_xor((int)bgi, off, 64);
-                    const int ok = __shfl_xor(bk, off, 64);
-                    if (orank < brank || (orank == brank && og < bgi)) { brank = orank; bgi = og; bk = ok; }
-                }
-                win = need64 ? bk : win;
-            }
+            int win, walked;
+            grid_ball_walk<TILED, LPI>(m, lp, R, live, rl, lane, win, walked);
             if (STATS) walked = group_sum_int<LPI>(walked);
             if (rl == 0 && live) {
                 s_res[it] = win;
