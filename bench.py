@@ -252,14 +252,16 @@ def kernel_name_for(method, grid, forced=""):
     return f"k_accumulate_{'grid' if grid else 'cell'}<{m}>"
 
 
-def pmc_key(kernel_name, scan_points, map_points, guess):
+def pmc_key(kernel_name, scan_points, map_points, guess, world="lattice"):
     """key of a committed counter pass in profiles/pmc_latest.json: the kernel, the workload sizes when they are not the headline's,
-    the initial-guess set when it is the hard one (tools/merge_pmc.py writes the same key)"""
+    the initial-guess set when it is the hard one, the world when it is not the lattice (tools/merge_pmc.py writes the same key)"""
     k = kernel_name
     if int(scan_points) != 131072 or int(map_points) != 10_000_000:
         k += f"@{int(scan_points)}/{int(map_points)}"
     if guess == "hard":
         k += "@hard"
+    if world != "lattice":
+        k += f"@{world}"
     return k
 
 
@@ -315,7 +317,7 @@ def hbm_object(method, index_bytes, units_per_launch, sec, bytes_unit, bytes_ref
     }
 
 
-def load_counter_pass(kernel_name, scan_points, map_points, guess, batch, slots, units_per_launch):
+def load_counter_pass(kernel_name, scan_points, map_points, guess, batch, slots, units_per_launch, world="lattice"):
     """The committed counter pass that speaks for a run: same kernel, sizes, guess set, registrations per step and slots PER GPU (the launch
     mix -- live slots per launch, draining launches -- follows from those) and, within 10 %, the same units per launch on this GPU.  A rank of
     an N-GPU run qualifies with the N = 1 pass of the same per-GPU operating point (more, smaller shards: the same units per launch)."""
@@ -323,10 +325,10 @@ def load_counter_pass(kernel_name, scan_points, map_points, guess, batch, slots,
     if not os.path.exists(path):
         return None
     try:
-        pm = json.load(open(path)).get(pmc_key(kernel_name, scan_points, map_points, guess))
+        pm = json.load(open(path)).get(pmc_key(kernel_name, scan_points, map_points, guess, world))
     except Exception:  # noqa: BLE001
         return None
-    if not pm or pm.get("batch") != batch or pm.get("slots") != slots or pm.get("guess", "easy") != guess:
+    if not pm or pm.get("batch") != batch or pm.get("slots") != slots or pm.get("guess", "easy") != guess or pm.get("world", "lattice") != world:
         return None
     if int(pm.get("scan_points", 131072)) != int(scan_points) or int(pm.get("map_points", 10_000_000)) != int(map_points):
         return None
@@ -433,6 +435,8 @@ def main():
                     "height-field terrain + boxes + clutter + a voxel-centre lattice patch + collinear poles (synth.make_field_world)")
     ap.add_argument("--cpu-sample", type=int, default=20, help="registrations timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-full-sample", type=int, default=3, help="of those, registrations repeated on the un-cropped map (0 = skip)")
+    ap.add_argument("--pose-sample", type=int, default=64, help="registrations of the headline batch whose pose, iteration count and flags are compared with the "
+                    "CPU oracle (the first --cpu-sample of them are the timed baseline; the rest run with every core and are not timed)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip latency / reference-API / hard-guess / replica legs and the `configs` legs (profiling passes)")
     ap.add_argument("--no-latency", action="store_true", help="alias of --no-extras")
@@ -580,9 +584,9 @@ def main():
         upl = (pt_iters_ / world_size) * steps_ / launches_  # units one launch processes ON THIS GPU = its shard of the batch's live points
         sec_ = acc_ms_ * 1e-3
         live_scans_ = upl / max(op["scan_points"] / world_size, 1.0)
-        pm_ = load_counter_pass(kname, op["scan_points"], op["map_points"], op["guess"], op["batch"], op["slots"], upl) if op.get("world", "lattice") == "lattice" else None
+        pm_ = load_counter_pass(kname, op["scan_points"], op["map_points"], op["guess"], op["batch"], op["slots"], upl, op.get("world", "lattice"))
         traffic_ = pm_.get("hbm_bytes_per_unit") * upl if (pm_ and pm_.get("hbm_bytes_per_unit") is not None) else None
-        src_ = (f"profiles/pmc_latest.json[{pmc_key(kname, op['scan_points'], op['map_points'], op['guess'])}]: HBM bytes/unit of separate rocprofv3 --pmc passes of this "
+        src_ = (f"profiles/pmc_latest.json[{pmc_key(kname, op['scan_points'], op['map_points'], op['guess'], op.get('world', 'lattice'))}]: HBM bytes/unit of separate rocprofv3 --pmc passes of this "
                 f"leg's command ({pm_.get('source', 'see profiles/README.md')}) x this run's units per launch; counters cannot be read in the timed run") if traffic_ else None
         hbm_ = hbm_object(int(m), int(info_.index_bytes), upl, sec_, bytes_unit_, bytes_ref_, live_scans_, op["map_points"], traffic_, src_)
         roof = build_roofline(int(m), kname, hbm_, pm_, upl, acc_ms_)
@@ -655,7 +659,7 @@ def main():
     info = vm.info()
     t_map = time.time() - t0
     n_batch = args.batch * world_size  # weak scaling: per-GPU points per launch fixed
-    n_keep = max(args.cpu_sample, 8) if (rank == 0 and world_size == 1) else 0  # full host copies kept for the CPU / reference-API legs (N = 1)
+    n_keep = max(args.cpu_sample, 0 if args.no_cpu else min(args.pose_sample, args.batch), 8) if (rank == 0 and world_size == 1) else 0  # full host copies kept for the CPU / reference-API legs (N = 1)
     guess = dict(max_trans=0.15, max_rot_deg=0.5) if args.guess == "easy" else dict(max_trans=0.5, max_rot_deg=2.0)
     want_replica = extras and distributed and args.slots > 0 and (world_size > 1 or bool(os.environ.get("ELM_BENCH_FORCE_REPLICA")))
 
@@ -938,6 +942,11 @@ def main():
             tall.append(ra["elapsed_ms"] * 1e-3)
             call.append(ra["correspondence_ms"] * 1e-3)
             del om
+        # pose parity on more of the batch than the baseline times (every core; these runs are not part of `cpu_baseline`)
+        for i in range(n_s, min(args.pose_sample, len(scans_host)) if n_s else 0):
+            ref = O.register(crop_map(i), scans_host[i], T0s[i], ocfg_all)
+            errs.append(synth.pose_error(ref["T"], out[i]["T"]))
+            it_match.append(ref["iterations"] == out[i]["iterations"] and ref["is_success"] == out[i]["is_success"])
         full_info = None
         if args.cpu_full_sample > 0:
             tb = time.perf_counter()
@@ -1061,6 +1070,11 @@ def main():
                 lat_raw, lat_el, _, _ = time_stream(Registration(RegistrationConfig(icp_method=m), ctx), vm, reg.pack_inputs(scans[:n_f], T0s[:n_f]), args.slots, args.leg_steps, 1)
                 leg["lattice_world_same_shape"] = n_f * args.leg_steps / lat_el
                 leg["vs_lattice_world"] = leg["value"] / leg["lattice_world_same_shape"]
+                # registrations/s = iterations/s over iterations per registration: the second factor belongs to the method and the world (the
+                # oracle needs the same count), the first to the kernels
+                lat_iters = float(np.mean([r["iterations"] for r in results_from_raw(lat_raw)]))
+                leg["lattice_world_iterations_mean"] = lat_iters
+                leg["iteration_rate_vs_lattice_world"] = (leg["value"] * leg["iterations_mean"]) / (leg["lattice_world_same_shape"] * lat_iters)
                 fl[METHOD_NAMES[int(m)]] = leg
             fl["leg_wall_s"] = time.time() - tl
             configs["field_world"] = fl

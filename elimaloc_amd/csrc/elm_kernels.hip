@@ -532,10 +532,13 @@ __device__ __forceinline__ void block_reduce_store(double* acc, double (*red)[32
 // all-zero records of a slot sized for a larger scan leave every sum bit-identical), so the result does not depend on which
 // workgroup came last.  sums[scan][32] is what the solve kernel (and, on several GPUs, the all-reduce) reads: an ICP iteration
 // is accumulate (+ reduce) -> [all-reduce] -> solve, no reduce launch.  s_scratch: >= 2 KB + 16 bytes of LDS that is dead by now.
+#ifndef ELM_FUSED_REDUCE_CODE
+#define ELM_FUSED_REDUCE_CODE 1 // 0: the accumulate kernels are built without the fused reduction (ELM_FUSED_REDUCE=1 is then refused)
+#endif
 __device__ __forceinline__ void publish_and_reduce(double value, unsigned L, int s, unsigned blk_begin, unsigned blk_end, double* __restrict__ partials,
                                                    const RegParams& rp, double* s_scratch) {
     const unsigned t = threadIdx.x;
-    if (rp.tickets == nullptr) { // unfused: k_solve reduces
+    if (!ELM_FUSED_REDUCE_CODE || rp.tickets == nullptr) { // unfused: k_solve reduces
         if (t < (unsigned)kSums) partials[(size_t)L * kSums + t] = value;
         return;
     }

@@ -16,6 +16,7 @@ def test_pmc_key_names_the_operating_point():
     assert bench.pmc_key("k_accumulate_grid<P2P>", 131072, 10_000_000, "easy") == "k_accumulate_grid<P2P>"
     assert bench.pmc_key("k_accumulate_grid<P2P>", 131072, 10_000_000, "hard") == "k_accumulate_grid<P2P>@hard"
     assert bench.pmc_key("k_accumulate_vnbr<VGICP>", 32768, 50_000_000, "easy") == "k_accumulate_vnbr<VGICP>@32768/50000000"
+    assert bench.pmc_key("k_accumulate_grid<GICP>", 131072, 10_000_000, "easy", "field") == "k_accumulate_grid<GICP>@field"
 
 
 def test_index_is_charged_at_most_its_touched_part():
@@ -67,6 +68,7 @@ def test_counter_pass_speaks_for_its_own_operating_point_at_any_n(tmp_path, monk
     assert bench.load_counter_pass(k, 131072, 10_000_000, "easy", 4096, 256, 8.0e6) is None        # a quarter of the work per launch
     assert bench.load_counter_pass(k, 131072, 10_000_000, "hard", 4096, 256, 30.1e6) is None
     assert bench.load_counter_pass(k, 32768, 50_000_000, "easy", 4096, 256, 30.1e6) is None
+    assert bench.load_counter_pass(k, 131072, 10_000_000, "easy", 4096, 256, 30.1e6, "field") is None   # another world: another pass
     pm = bench.load_counter_pass(k, 131072, 10_000_000, "easy", 4096, 256, 30.1e6)
     h = bench.hbm_object(0, 0.25e9, 30.1e6, 0.84e-3, 303.0, 3348.0, 230, 10_000_000, pm["hbm_bytes_per_unit"] * 30.1e6, "test")
     rf = bench.build_roofline(0, k, h, pm, 30.1e6, 0.84)

@@ -31,7 +31,7 @@ try:
         if "value" in v: print("    %-14s %10.4g %s  %s %s" % (k, v["value"], v["unit"], v["roofline"].get("bound"), v["roofline"].get("frac")), v.get("pose_err_vs_cpu", {}).get("max_trans_m"), flush=True)
         else:
             for m in ("P2P", "GICP", "VGICP", "AVGICP"):
-                if m in v: print("    %-14s %-6s %9.0f (%.2f of the lattice world) iters %.2f undecided %.3f flags %d" % (k, m, v[m]["value"], v[m]["vs_lattice_world"], v[m]["iterations_mean"], v[m]["roofline"]["undecided_share_after_stage1"], v[m]["map_layout_flags"]), flush=True)
+                if m in v: print("    %-14s %-6s %9.0f (%.2f of the lattice world; per iteration %.2f) iters %.2f undecided %.3f flags %d %s %.3f" % (k, m, v[m]["value"], v[m]["vs_lattice_world"], v[m].get("iteration_rate_vs_lattice_world", 0.0), v[m]["iterations_mean"], v[m]["roofline"]["undecided_share_after_stage1"], v[m]["map_layout_flags"], v[m]["roofline"].get("bound"), v[m]["roofline"].get("frac", 0.0)), flush=True)
 except Exception as e:  # noqa: BLE001
     print(sys.argv[1], "FAILED", repr(e), flush=True)
 PY

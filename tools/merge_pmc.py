@@ -21,7 +21,7 @@ for d in sys.argv[1:]:
         key = small["kernel"]
         if int(small.get("scan_points", 131072)) != 131072 or int(small.get("map_points", 10_000_000)) != 10_000_000:
             key += f"@{int(small['scan_points'])}/{int(small['map_points'])}"
-        cur[key + ("@hard" if small.get("guess") == "hard" else "")] = small
+        cur[key + ("@hard" if small.get("guess") == "hard" else "") + ("" if small.get("world", "lattice") == "lattice" else "@" + small["world"])] = small
     for src, name in (("kernel_stats.csv", f"{tag}_kernel_stats.csv"), ("pmc.json", f"{tag}_pmc.json"), ("bench.json", f"{tag}_bench.json"),
                       ("bench_trace.json", f"{tag}_bench_under_rocprof.json")):
         if os.path.exists(os.path.join(d, src)):
