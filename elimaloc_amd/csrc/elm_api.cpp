@@ -427,6 +427,7 @@ struct elm_map {
     GridBlk* d_grid_blk = nullptr;    // dense cell grid (DevMap::grid_*), the default P2P / GICP search index
     uint32_t* d_grid_idx = nullptr;
     uint32_t* d_grid_start = nullptr;
+    uint4* d_grid_patch = nullptr; // dense grid only, optional (DevMap::grid_patch)
     uint2* d_grid_tiles = nullptr; // two-level grid only
     uint32_t* d_vox_stat = nullptr;
     double* d_grid_gicp = nullptr; // the GICP records in grid slot order (built with the grid / refreshed by CalPointCovAll)
@@ -590,7 +591,7 @@ static void build_host(const float* xyz, size_t n, double voxel_size, int max_po
 static void map_free(elm_map* m) {
     if (!m) return;
     if (ctx_alive(m->ctx, m->ctx_id)) (void)hipSetDevice(m->ctx->device); // a context destroyed first: just release the device memory
-    void* ptrs[] = {m->d_grid_tiles, m->d_vox_nk, m->d_bad, m->d_grid_gicp8, m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_vox_cinv, m->d_pt_gicp, m->d_pt_cov, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off, m->d_vqslots, m->d_vq_dense, m->d_vqf_dense, m->d_vface, m->d_vnbr, m->d_vnbr_blk,
+    void* ptrs[] = {m->d_grid_patch, m->d_grid_tiles, m->d_vox_nk, m->d_bad, m->d_grid_gicp8, m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_vox_cinv, m->d_pt_gicp, m->d_pt_cov, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off, m->d_vqslots, m->d_vq_dense, m->d_vqf_dense, m->d_vface, m->d_vnbr, m->d_vnbr_blk,
                     m->d_grid_blk, m->d_grid_idx, m->d_grid_start, m->d_vox_stat, m->d_grid_gicp};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -967,6 +968,46 @@ static int refresh_grid_gicp(elm_map* m) {
 // ELM_ERR_UNSUPPORTED (and grid_refused) when the grid is not affordable -- the box needs more than max_cells cells, its tables
 // do not fit the host / device memory that is free right now, or an allocation fails half-way -- the caller then builds the
 // neighbourhood lists instead; nothing is left allocated and the map is unchanged.
+// The patch table of the dense grid (DevMap::grid_patch): 16 bytes per cell, the runs of the four columns of a 2 x 2 x 2 block of cells in
+// one gather.  Optional -- any failure (budget, a cell of more than 15 blocks, 2^24 blocks or more, allocation) leaves the map on
+// grid_start alone.  ELM_GRID_PATCH=0 / 1 overrides the built-in default (on: still subject to the packing limits and the budget), ELM_GRID_PATCH_MAX_BYTES sets
+// the byte budget (default 2 GB: the 10 M-point bench map needs 0.37 GB).
+static bool grid_patch_wanted(uint64_t bytes) {
+    bool on = ELM_GRID_PATCH_DEFAULT != 0;
+    if (const char* e = getenv("ELM_GRID_PATCH")) on = atoi(e) != 0;
+    uint64_t budget = 2ull << 30;
+    if (const char* e = getenv("ELM_GRID_PATCH_MAX_BYTES")) budget = strtoull(e, nullptr, 10);
+    return on && bytes <= budget;
+}
+static void build_grid_patch(elm_map* m, uint64_t cells, uint64_t n_blk) {
+    elm_ctx* ctx = m->ctx;
+    const uint64_t bytes = cells * sizeof(uint4);
+    if (!grid_patch_wanted(bytes) || n_blk >= (1ull << 24)) return;
+    size_t dev_free = 0, dev_total = 0;
+    if (hipMemGetInfo(&dev_free, &dev_total) != hipSuccess || bytes + 64 > (uint64_t)dev_free / 10 * 8) { (void)hipGetLastError(); return; }
+    uint4* d_patch = nullptr;
+    unsigned* d_over = nullptr;
+    unsigned over = 1;
+    bool ok = hipMalloc((void**)&d_patch, bytes) == hipSuccess && hipMalloc((void**)&d_over, sizeof(unsigned)) == hipSuccess &&
+              hipMemsetAsync(d_over, 0, sizeof(unsigned), ctx->stream) == hipSuccess;
+    if (ok) {
+        launch_grid_patch(ctx->stream, m->dm, d_patch, d_over);
+        ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&over, d_over, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+             hipStreamSynchronize(ctx->stream) == hipSuccess;
+    }
+    if (d_over) (void)hipFree(d_over);
+    if (!ok || over) { // a cell of more than 15 blocks (or a device error): the grid works without the table
+        if (d_patch) (void)hipFree(d_patch);
+        (void)hipGetLastError();
+        if (getenv("ELM_DEBUG")) fprintf(stderr, "[elm] grid patch table: not built (ok %d, overflow %u)\n", (int)ok, over);
+        return;
+    }
+    m->d_grid_patch = d_patch;
+    m->dm.grid_patch = d_patch;
+    m->info.layout_flags |= 512;
+    m->info.device_bytes += bytes;
+    m->info.index_bytes += bytes;
+}
 static int build_cell_grid_impl(elm_map* m, uint64_t max_cells);
 static int build_cell_grid(elm_map* m, uint64_t max_cells) {
     if (m->has_grid) return ELM_OK;
@@ -1139,6 +1180,7 @@ static int build_cell_grid_impl(elm_map* m, uint64_t max_cells) {
     m->info.n_query_voxels = vcells;
     m->info.nbr_entries = n;
     m->info.index_bytes += gb.size() * sizeof(GridBlk) + (cells + 4) * sizeof(uint32_t) + vcells * sizeof(uint32_t);
+    build_grid_patch(m, cells, n_blk);
     return ELM_OK;
 }
 

@@ -120,10 +120,12 @@ typedef struct elm_map_info {
                            * bit 6: ... and some voxel is flagged: the fused walk skips its pairs and a fix-up launch over the marked
                            *        workgroups adds them (ELM_AVG_FIXUP=0 at map build: the nine-entry walk with its in-line fallback instead),
                            * bit 7: some flagged POINT covariance has an asymmetric stored inverse (rank-deficient neighbourhood, U != V in its
-                           *        SVD): GICP on this map runs the reference's per-pair arithmetic (all 36 entries of J^T M J, LDLT on the lower
-                           *        triangle; 12-27 times slower at 131 072-point scans) because the packed symmetric sums cannot carry it
-                           *        (ELM_STRICT_PAIRS=0: fast kernels anyway, =1: per-pair arithmetic on every map),
-                           * bit 8: the same for the voxel covariances (VGICP / AVGICP) */
+                           *        SVD): GICP's kernels on this map also write the 15 antisymmetric side sums per workgroup and the solve restores
+                           *        all 36 entries of J^T M J (LDLT on the lower triangle, as the reference); ELM_STRICT_PAIRS=1 runs the
+                           *        reference's per-pair arithmetic instead (the in-product checker, 12-27 times slower), =0 drops the side sums,
+                           * bit 8: the same for the voxel covariances (VGICP / AVGICP),
+                           * bit 9: the dense cell grid carries its patch table (16 bytes per cell: stage 1 reads the offsets of the four
+                           *        columns a point leans into with one gather; ELM_GRID_PATCH=0 / 1 at index build) */
     uint64_t device_bytes;
     uint64_t n_query_voxels; /* cell grid: voxels of the dense statistics box; neighbourhood lists: query voxels (0 until built) */
     uint64_t nbr_entries;    /* cell grid: == n_points (every map point once); neighbourhood lists: ~27 x n_points */

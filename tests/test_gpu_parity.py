@@ -555,15 +555,18 @@ def test_full_size_c4_vgicp_shape(ctx, oracle):
 
 
 def _set_kernel_env(monkeypatch, kernel_env):
-    """grid: dense cell grid (default); tiled: its two-level form forced; lists / direct: the older kernel generations"""
+    """grid: dense cell grid; patch: the same with its patch table; tiled: its two-level form forced; lists / direct: the older kernel generations"""
     if kernel_env == "tiled":
         monkeypatch.setenv("ELM_KERNEL", "grid")
         monkeypatch.setenv("ELM_GRID", "tiled")
+    elif kernel_env in ("grid", "patch"):  # the dense grid read through grid_start / through its patch table (layout bit 9)
+        monkeypatch.setenv("ELM_KERNEL", "grid")
+        monkeypatch.setenv("ELM_GRID_PATCH", "1" if kernel_env == "patch" else "0")
     else:
         monkeypatch.setenv("ELM_KERNEL", kernel_env)
 
 
-@pytest.mark.parametrize("kernel_env", ["grid", "tiled", "lists", "direct"])
+@pytest.mark.parametrize("kernel_env", ["grid", "patch", "tiled", "lists", "direct"])
 @pytest.mark.parametrize("voxel_size,max_pts,th,method", [
     (0.5, 30, 5.0, 0),    # finer voxels
     (1.5, 50, 5.0, 1),    # README-recommended 50 points per voxel (buckets > 32 points), GICP
@@ -609,7 +612,7 @@ def _tie_world():
     return lattice, scan
 
 
-@pytest.mark.parametrize("kernel_env", ["grid", "tiled", "lists", "direct"])
+@pytest.mark.parametrize("kernel_env", ["grid", "patch", "tiled", "lists", "direct"])
 @pytest.mark.parametrize("method", [0, 1, 2])
 def test_exact_ties_follow_the_reference_visiting_order(oracle, method, kernel_env, monkeypatch):
     """Equal float64 distances: the reference keeps the FIRST strict minimum of its walk (27 voxels x-major..z-minor,
@@ -629,7 +632,7 @@ def test_exact_ties_follow_the_reference_visiting_order(oracle, method, kernel_e
         ref = oracle.register(om, scan, T0, oracle.default_config(method, max_iteration=3, icp_termination_threshold_m=0.0,
                                                                   min_overlap_ratio=0.0, max_fitness_score=10.0))
         _compare_run(det, ref)
-        if kernel_env in ("grid", "tiled", "lists") and method in (0, 1):
+        if kernel_env in ("grid", "patch", "tiled", "lists") and method in (0, 1):
             assert det["fallback_blocks"] > 0  # the tied points really went through the exact float64 stage
     finally:
         c.close()
@@ -1649,3 +1652,69 @@ def test_radar_covariance_entry_points(ctx, oracle, world100k):
     p_off = Registration(RegistrationConfig(icp_method=IcpMethod.P2P), ctx).RunRegisterStream(scans, vm, T0s, slots=3)
     for a, b in zip(p_on, p_off):
         assert np.array_equal(a["T"], b["T"]) and a["iterations"] == b["iterations"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", [0, 1])
+def test_patch_table_is_the_same_search(oracle, method, monkeypatch):
+    """The patch table (DevMap::grid_patch, layout bit 9) only changes HOW stage 1 learns the runs of its four columns: every
+    iteration's sums, the pose and the counters are bit-identical with and without it -- on a world with negative coordinates,
+    scans that reach past the grid's edge, and a tight allowed-cell clip (voxel size 0.7).  A map with a cell of more than 15
+    blocks does not get the table (and still registers)."""
+    from elimaloc_amd.registration import Context, VoxelHashMap, Registration, RegistrationConfig, IcpMethod
+    m = IcpMethod(method)
+    rng = np.random.default_rng(99)
+    world = np.concatenate([synth.make_world(60000, seed=21), rng.uniform(-6, 6, size=(20000, 3)) * np.array([1.0, 1.0, 0.3])]).astype(np.float32)
+    runs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ELM_GRID_PATCH", mode)
+        c = Context(0)
+        try:
+            out = []
+            for vs in (1.0, 0.7):
+                vm = VoxelHashMap(vs, 30, c)
+                vm.AddPoints(world)
+                if m == IcpMethod.GICP:
+                    vm.CalPointCovAll(0.4)
+                vm.BuildNeighbourhoods()
+                assert bool(int(vm.info().layout_flags) & 512) == (mode == "1")
+                for seed in (1, 2, 3):
+                    scan, Tt = synth.make_scan(world, 5000, seed=500 + seed)
+                    if seed == 3:
+                        scan = (scan * np.float32(1.6)).astype(np.float32)  # a third of the points beyond the grid's box
+                    T0 = synth.perturb(Tt, seed=600 + seed, max_trans=0.4, max_rot_deg=1.5)
+                    out.append(Registration(RegistrationConfig(icp_method=m), c).RunRegister(scan, vm, T0, trace=True)[-1])
+            runs[mode] = out
+        finally:
+            c.close()
+    for a, b in zip(runs["0"], runs["1"]):
+        assert a["iterations"] == b["iterations"] and a["is_success"] == b["is_success"]
+        assert np.array_equal(a["T"], b["T"])
+        for ia, ib in zip(a["iters"], b["iters"]):
+            assert ia["n_corr"] == ib["n_corr"]
+            assert np.array_equal(ia["JTJ"], ib["JTJ"]) and np.array_equal(ia["JTr"], ib["JTr"])
+    # a dense blob (as many points in one cell as the spacing rule lets in: a cell of more than 15 blocks cannot be packed) and a table
+    # over its byte budget: no table in the second case, the oracle's answers in both
+    blob = (rng.uniform(0.0, 0.2, size=(400, 3)) + np.array([3.1, 3.1, 0.1])).astype(np.float32)
+    w2 = np.concatenate([world[:30000], blob])
+    for budget in (None, "1024"):
+        monkeypatch.setenv("ELM_GRID_PATCH", "1")
+        if budget:
+            monkeypatch.setenv("ELM_GRID_PATCH_MAX_BYTES", budget)
+        c = Context(0)
+        try:
+            vm = VoxelHashMap(1.0, 200, c)
+            vm.AddPoints(w2)
+            om = oracle.Map(1.0, 200)
+            om.add_points(w2)
+            if m == IcpMethod.GICP:
+                vm.CalPointCovAll(0.4); om.cal_point_cov_all(0.4)
+            vm.BuildNeighbourhoods()
+            if budget:
+                assert not int(vm.info().layout_flags) & 512
+            scan, Tt = synth.make_scan(w2, 4000, seed=77)
+            T0 = synth.perturb(Tt, seed=78, max_trans=0.2, max_rot_deg=1.0)
+            *_, det = Registration(RegistrationConfig(icp_method=m), c).RunRegister(scan, vm, T0, trace=True)
+            _compare_run(det, oracle.register(om, scan, T0, oracle.default_config(method)))
+        finally:
+            c.close()
