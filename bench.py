@@ -238,6 +238,7 @@ def dry_launch(args, rank, world_size, local_rank, dist):
 # ------------------------------------------------------------------ roofline model (plain functions: tests/test_bench_model.py) --------
 CLOCK_GHZ = 2.4  # MI355X_MICROARCH.md: max clock
 SIMD_GCYCLES = 1024 * CLOCK_GHZ  # G SIMD-cycles/s over the chip (256 CUs x 4 SIMDs)
+L1_HIT_LINES_PER_CYCLE, L1_MISS_LINES_PER_CYCLE = 1.6, 0.40  # distinct 128-byte lines a CU's vector-memory pipeline serves per cycle (tools/probes/l1_probe)
 ISSUE_CYCLES = {"k_accumulate_grid<P2P>": 3.78, "k_accumulate_grid<GICP>": 3.78, "k_accumulate_vnbr<VGICP>": 3.85,
                 "k_accumulate_vnbr<AVGICP>": 3.86}  # mean issue cost of the kernels' opcode mixes, profiles/r04_valu_mix.txt
 WORLD_PTS_PER_M2 = 27.5  # synth.make_world: ~25 ground points + the walls' share per square metre of map
@@ -371,6 +372,13 @@ def build_roofline(method, kernel_name, hbm, pm, units_per_launch, acc_ms_avg):
                         "traffic": hbm["traffic"]}
         roofline["hbm"] = hbm
         roofline["valu_issue_frac"] = vb
+        if extra.get("l1_line_accesses_per_cu_cycle") is not None and extra.get("l1_hit") is not None:
+            # tools/probes/l1_probe (profiles/r05_l1_probe.txt): the vector-memory pipeline serves 1.6 distinct lines per CU-cycle when they hit
+            # the L1 and 0.40 when they miss it, whatever the width of the load -- a model of the unit beside its busy counter
+            acc_, hit_ = float(extra["l1_line_accesses_per_cu_cycle"]), float(extra["l1_hit"])
+            roofline["vector_memory_model"] = {"utilisation": acc_ * (hit_ / L1_HIT_LINES_PER_CYCLE + (1.0 - hit_) / L1_MISS_LINES_PER_CYCLE),
+                                               "what": f"TCP_TOTAL_CACHE_ACCESSES per CU-cycle ({acc_:.3f}) x (L1 hit {hit_:.3f} / {L1_HIT_LINES_PER_CYCLE} + miss / "
+                                                       f"{L1_MISS_LINES_PER_CYCLE} lines per cycle, profiles/r05_l1_probe.txt); TA_BUSY reads {tb:.3f}"}
         if extra.get("ps_per_unit_traced") is not None and units_per_launch > 0:
             roofline["counter_pass_ps_per_unit"] = extra["ps_per_unit_traced"]
             roofline["this_run_ps_per_unit"] = 1e9 * acc_ms_avg / units_per_launch

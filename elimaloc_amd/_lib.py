@@ -128,7 +128,7 @@ EXPORTS = [
     "elm_reg_config_default", "elm_ctx_create", "elm_ctx_destroy", "elm_last_error", "elm_strerror",
     "elm_ctx_synchronize", "elm_ctx_stream", "elm_ctx_set_profiling", "elm_ctx_set_work_counters", "elm_ctx_get_profile", "elm_map_build", "elm_map_destroy", "elm_map_cal_voxel_cov_all",
     "elm_map_cal_point_cov_all", "elm_map_build_neighbourhoods", "elm_map_get_info", "elm_map_empty", "elm_map_download_points",
-    "elm_map_download_voxels", "elm_map_find_ground_height", "elm_scan_upload", "elm_scan_destroy",
+    "elm_map_download_voxels", "elm_map_find_ground_height", "elm_map_get_correspondences", "elm_align_clouds_local", "elm_scan_upload", "elm_scan_destroy",
     "elm_scan_size", "elm_scan_download", "elm_register", "elm_format_register_log", "elm_register_batch", "elm_register_stream", "elm_register_stream_host", "elm_host_alloc", "elm_host_free", "elm_ctx_measure_h2d", "elm_register_batch_enqueue",
     "elm_register_batch_finish", "elm_deskew", "elm_deskew_downsample", "elm_deskew_prepare", "elm_comm_get_unique_id", "elm_comm_init",
     "elm_comm_destroy", "elm_comm_info", "elm_comm_set_hook", "elm_filter_points_by_distance", "elm_voxel_downsample",
@@ -231,6 +231,8 @@ def lib():
     L.elm_map_download_points.argtypes = [vp, dp, dp, dp, C.c_size_t]
     L.elm_map_download_voxels.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp, dp, C.c_size_t]
     L.elm_map_find_ground_height.argtypes = [vp, C.c_double, C.c_double, dp, ip]
+    L.elm_align_clouds_local.argtypes = [vp, C.c_int, dp, dp, dp, dp, C.c_size_t, dp, C.c_double, C.POINTER(RegConfig), dp, dp, dp]
+    L.elm_map_get_correspondences.argtypes = [vp, vp, C.c_int, dp, C.c_size_t, C.c_double, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.c_size_t, C.POINTER(C.c_size_t)]
     L.elm_scan_upload.argtypes = [vp, fp, C.c_size_t, C.c_size_t, C.POINTER(vp)]
     L.elm_scan_destroy.argtypes = [vp]
     L.elm_scan_destroy.restype = None

@@ -1877,6 +1877,175 @@ static int choose_path(elm_ctx* ctx, const elm_map* map, const elm_reg_config* c
     }
     return ELM_OK;
 }
+// VoxelHashMap::GetCorrespondencePoints / GetCorrespondencesCov / GetCorrespondencesAllCov (vhm.cpp:31-206) as calls of their own: the pairs
+// themselves, in input order, as (source index, target index).  The search is the production one -- the QUERY instantiations of the grid /
+// voxel-list kernels (the code the fused accumulate kernels run, minus the sums) -- or, without such an index (ELM_KERNEL=direct / lists, a
+// refused grid) and with ELM_QUERY=direct, the plain walk.
+extern "C" int elm_map_get_correspondences(elm_ctx* ctx, const elm_map* map, int what, const double* xyz, size_t n, double max_dist,
+                                           uint32_t* src_index, int32_t* tgt_index, size_t cap, size_t* n_pairs) {
+    if (!ctx || !map || what < 0 || what > 2 || (n && !xyz) || !n_pairs || map->ctx != ctx) return ELM_ERR_INVALID;
+    *n_pairs = 0;
+    if (n == 0) return ELM_OK;
+    if (n > 0x7FFFFF00ull) return ELM_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    elm_reg_config cfg;
+    elm_reg_config_default(&cfg);
+    cfg.icp_method = what == 0 ? ELM_P2P : what == 1 ? ELM_VGICP : ELM_AVGICP;
+    cfg.use_radar_cov = 0;
+    bool production = false;
+    const char* qe = getenv("ELM_QUERY");
+    const bool force_direct = qe && strcmp(qe, "direct") == 0;
+    if (map->dm.n_vox != 0) {
+        int rc;
+        if (what != 0 && (rc = check_covariances(ctx, map, cfg.icp_method)) != ELM_OK) return rc;
+        if (!force_direct && ctx->kernel_mode != 2) {
+            if (what == 0) {
+                bool g = ctx->kernel_mode == 4 && map->has_grid;
+                if (!g && ctx->kernel_mode == 4 && !map->has_nbr)
+                    if ((rc = build_search_index(const_cast<elm_map*>(map), &g)) != ELM_OK) return rc;
+                production = g;
+            } else {
+                if (!map->has_vnbr && (rc = build_voxel_neighbourhoods(const_cast<elm_map*>(map))) != ELM_OK) return rc;
+                production = map->has_vnbr;
+            }
+        }
+    }
+    const size_t per = what == 2 ? 8 : 1;
+    double* d_q = nullptr;
+    int32_t* d_out = nullptr;
+    ScanDesc* d_desc = nullptr;
+    ScanState* d_state = nullptr;
+    std::vector<int32_t> out(n * per);
+    auto release = [&]() {
+        for (void* q : {(void*)d_q, (void*)d_out, (void*)d_desc, (void*)d_state})
+            if (q) (void)hipFree(q);
+    };
+    hipError_t e = hipMalloc((void**)&d_q, n * 3 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_out, n * per * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_q, xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_out, 0xFF, n * per * sizeof(int32_t), ctx->stream); // (AllCov: < 0 = no pair with that neighbour)
+    if (e == hipSuccess && production) {
+        ScanDesc hd{};
+        hd.pts = nullptr; hd.n = (uint32_t)n; hd.n_total = (uint32_t)n; hd.blk_begin = 0; hd.blk_end = (uint32_t)((n + kBlock - 1) / kBlock);
+        e = hipMalloc((void**)&d_desc, sizeof(ScanDesc));
+        if (e == hipSuccess) e = hipMalloc((void**)&d_state, sizeof(ScanState));
+        if (e == hipSuccess) e = hipMemcpyAsync(d_desc, &hd, sizeof(ScanDesc), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_state, 0, sizeof(ScanState), ctx->stream); // done = 0; the pose is not read by a query
+        if (e == hipSuccess) {
+            RegParams rp{};
+            rp.th = max_dist; rp.th2 = max_dist * max_dist;
+            rp.method = cfg.icp_method; rp.max_iter = 1;
+            rp.query = d_q; rp.q_out = d_out;
+            if (what == 0) launch_accumulate_grid(ctx->stream, map->dm, d_desc, 1, (int)hd.blk_end, d_state, nullptr, rp);
+            else launch_accumulate_vnbr(ctx->stream, map->dm, d_desc, 1, (int)hd.blk_end, d_state, nullptr, rp);
+            e = hipGetLastError();
+        }
+    } else if (e == hipSuccess) {
+        launch_query_direct(ctx->stream, map->dm, what, d_q, n, max_dist * max_dist, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out.data(), d_out, n * per * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    release();
+    if (e != hipSuccess) {
+        ctx->last_error = std::string("elm_map_get_correspondences: ") + hipGetErrorString(e);
+        (void)hipGetLastError();
+        return ELM_ERR_DEVICE;
+    }
+    // marshalling: the reference's result vectors hold the pairs in input order (tbb::parallel_reduce joins its ranges in order)
+    size_t k = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (what == 2) {
+            for (int r = 0; r < 7; ++r) {
+                const int32_t v = out[8 * i + r];
+                if (v < 0) continue;
+                if (k < cap) { if (src_index) src_index[k] = (uint32_t)i; if (tgt_index) tgt_index[k] = v; }
+                ++k;
+            }
+        } else {
+            const int32_t v = out[i];
+            if (v < -1) continue;
+            if (k < cap) { if (src_index) src_index[k] = (uint32_t)i; if (tgt_index) tgt_index[k] = v; }
+            ++k;
+        }
+    }
+    *n_pairs = k; // (the count even when cap was too small: call again with more room)
+    return ELM_OK;
+}
+
+// Registration::AlignCloudsLocal (method ELM_P2P; reg.cpp:15-66), ::AlignCloudsLocalPointCov (ELM_GICP; :68-152) and
+// ::AlignCloudsLocalVoxelCov (ELM_VGICP / ELM_AVGICP; :154-225) on pairs the caller holds: accumulate on the device with the reference's
+// per-pair arithmetic, solve, return the step.
+extern "C" int elm_align_clouds_local(elm_ctx* ctx, int method, const double* src_local, const double* tgt_xyz, const double* tgt_cov9,
+                                      const double* src_cov9, size_t n, const double last_icp_pose[16], double trans_th,
+                                      const elm_reg_config* cfg, double T_out[16], double local_cov[36], double* fitness_score) {
+    if (!ctx || !last_icp_pose || !T_out || method < ELM_P2P || method > ELM_AVGICP || (n && (!src_local || !tgt_xyz))) return ELM_ERR_INVALID;
+    if (n && method != ELM_P2P && !tgt_cov9) return ELM_ERR_INVALID;
+    elm_reg_config dflt;
+    if (!cfg) { elm_reg_config_default(&dflt); cfg = &dflt; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    AlignArgs a{};
+    {
+        double R[9];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) R[r * 3 + c] = last_icp_pose[c * 4 + r];
+        elm::inv3(R, a.Rinv); // (the 3x3 cofactor inverse of the rotation block, as the registration's own state keeps it)
+        for (int r = 0; r < 3; ++r)
+            a.tinv[r] = -((a.Rinv[r * 3] * last_icp_pose[12] + a.Rinv[r * 3 + 1] * last_icp_pose[13]) + a.Rinv[r * 3 + 2] * last_icp_pose[14]);
+    }
+    a.th = trans_th; a.th2 = trans_th * trans_th;
+    a.lm_lambda = cfg->lm_lambda;
+    a.method = method == ELM_AVGICP ? ELM_VGICP : method;
+    a.use_src_cov = (cfg->use_radar_cov != 0 && src_cov9 && method != ELM_P2P) ? 1 : 0;
+    // staging: positions as they are, covariances column-major -> row-major
+    const bool cov = method != ELM_P2P;
+    std::vector<double> stage;
+    auto transposed = [&](const double* c9) {
+        stage.resize(n * 9);
+        for (size_t i = 0; i < n; ++i)
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) stage[9 * i + r * 3 + c] = c9[9 * i + c * 3 + r];
+        return stage.data();
+    };
+    double *d_src = nullptr, *d_tgt = nullptr, *d_cov = nullptr, *d_scov = nullptr, *d_part = nullptr, *d_out = nullptr;
+    auto release = [&]() {
+        for (void* q : {(void*)d_src, (void*)d_tgt, (void*)d_cov, (void*)d_scov, (void*)d_part, (void*)d_out})
+            if (q) (void)hipFree(q);
+    };
+    const size_t nb = std::max<size_t>(n, 1);
+    hipError_t e = hipMalloc((void**)&d_src, nb * 3 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_tgt, nb * 3 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_part, (size_t)1024 * kRadarRecord * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_out, kAlignOut * sizeof(double));
+    if (e == hipSuccess && n) e = hipMemcpy(d_src, src_local, n * 3 * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess && n) e = hipMemcpy(d_tgt, tgt_xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess && cov && n) {
+        e = hipMalloc((void**)&d_cov, n * 9 * sizeof(double));
+        if (e == hipSuccess) e = hipMemcpy(d_cov, transposed(tgt_cov9), n * 9 * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess && a.use_src_cov) {
+            e = hipMalloc((void**)&d_scov, n * 9 * sizeof(double));
+            if (e == hipSuccess) e = hipMemcpy(d_scov, transposed(src_cov9), n * 9 * sizeof(double), hipMemcpyHostToDevice);
+        }
+    }
+    double out[kAlignOut];
+    if (e == hipSuccess) {
+        launch_align_pairs(ctx->stream, d_src, d_tgt, d_cov, d_scov, n, a, d_part, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    release();
+    if (e != hipSuccess) {
+        ctx->last_error = std::string("elm_align_clouds_local: ") + hipGetErrorString(e);
+        (void)hipGetLastError();
+        return ELM_ERR_DEVICE;
+    }
+    memcpy(T_out, out, 16 * sizeof(double));
+    if (local_cov && method == ELM_GICP) memcpy(local_cov, out + 16, 36 * sizeof(double)); // (the reference writes local_cov in AlignCloudsLocalPointCov only)
+    if (fitness_score) *fitness_score = out[52];
+    return ELM_OK;
+}
+
 // the side records of a launch of `blocks` workgroups over `n_scans` scans / slots; the scans' reduced side sums sit right behind the
 // packed sums in d_sums (one exchange carries both)
 static int reserve_asym(elm_ctx* ctx, RegParams& rp, uint32_t blocks, int n_scans) {

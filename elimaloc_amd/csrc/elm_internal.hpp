@@ -230,6 +230,14 @@ struct RegParams {
     double* asym_sums;   // [scans][16] the scans' reduced side sums when the iteration is split around an exchange (modes 1 / 2 of k_solve;
                          // laid out right behind the packed sums, so ONE all-reduce carries both)
     double radar_var[3]; // range_variance_m, azimuth_variance_deg, elevation_variance_deg (reg.hpp:77-79)
+    // correspondence queries (elm_map_get_correspondences: the reference's public VoxelHashMap::GetCorrespondence* calls, vhm.cpp:31-206):
+    // the QUERY instantiations of the grid / voxel-list kernels (template STATS = 2) take point i of their one "scan" from query[3 i ..]
+    // (GLOBAL frame, float64: what Registration hands the map after TransformPoints) instead of T * p, run the production search and
+    // write the pair(s) instead of sums: q_out[i] = the map point (bucket order) / voxel id of the pair, -1 = the reference's default
+    // target at the origin (no neighbour bucket at all, vhm.cpp:37 / :105), -2 = no pair (beyond max_dist); GetCorrespondencesAllCov:
+    // q_out[8 i + r] = voxel id of the pair with the r-th voxel of the reference's visiting order (vhm.cpp:224-230), -2 = none
+    const double* query;
+    int32_t* q_out;
 };
 constexpr int kAsymRecord = 16; // doubles per side record (15 used)
 constexpr int kRadarRecord = 64; // doubles per partial record of k_accumulate_radar
@@ -272,6 +280,18 @@ void launch_accumulate_grid(hipStream_t s, const DevMap& m, const ScanDesc* scan
 #ifndef ELM_GRID_PATCH_DEFAULT
 #define ELM_GRID_PATCH_DEFAULT 0 // 1: the dense grid gets its patch table whenever it fits (ELM_GRID_PATCH=0 / 1 overrides at run time)
 #endif
+// Registration::AlignCloudsLocal / AlignCloudsLocalPointCov / AlignCloudsLocalVoxelCov (reg.cpp:15-225) on explicit pairs (elm_align_clouds_local)
+struct AlignArgs {
+    double Rinv[9], tinv[3]; // inverse of last_icp_pose: rotation block (row-major) and -Rinv t
+    double th, th2;          // trans_th
+    double lm_lambda;
+    int32_t method;          // ELM_P2P / ELM_GICP / ELM_VGICP (= AVGICP)
+    int32_t use_src_cov;     // use_radar_cov: the source points' covariance terms are added (reg.cpp:109-111 / 188-190)
+};
+constexpr int kAlignOut = 16 + 36 + 1 + 6 + 36 + 6 + 1; // T (column-major), local_cov (row-major), fitness, x, J^T M J (row-major), J^T M r, pair count
+void launch_align_pairs(hipStream_t s, const double* src_local, const double* tgt_xyz, const double* tgt_cov, const double* src_cov, size_t n,
+                        const AlignArgs& a, double* partials, double* out);
+void launch_query_direct(hipStream_t s, const DevMap& m, int what, const double* query, size_t n, double th2, int32_t* q_out); // the plain walk (27 / 7 hash probes, float64): the query form of k_accumulate_direct
 void launch_grid_patch(hipStream_t s, const DevMap& m, uint4* out, unsigned* overflow); // DevMap::grid_patch from grid_start; *overflow != 0: a run does not fit the packed word
 void launch_vox_stat(hipStream_t s, const DevMap& m, uint32_t* out); // fills DevMap::vox_stat's box (m.vx0.., m.vnx..)
 void launch_gather_gicp(hipStream_t s, const DevMap& m, size_t n_slots, double* out, int compact); // pt_gicp[grid_idx[slot]] -> out[slot] (16 or 8 doubles)

@@ -16,6 +16,7 @@
 // gates) is taken on fp64 values computed in the same operation order as the reference's scalar code; fused
 // multiply-adds are used only where written explicitly (fma()).
 #include <float.h>
+#include <algorithm>
 #include <hip/hip_runtime.h>
 
 #include "elm_internal.hpp"
@@ -1835,13 +1836,15 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
        const DevMap m, const ScanDesc* __restrict__ scans, int batch,
                                                                             unsigned total_blocks, const ScanState* __restrict__ st,
                                                                             double* __restrict__ partials, const RegParams rp) {
-    constexpr int NV = (METHOD == ELM_P2P) ? (STATS ? kP2PVals : kP2PVals - 3) : kSums;
+    constexpr int KS = (STATS == 1) ? 1 : 0;   // the instrumented build (work counters)
+    constexpr bool QUERY = STATS == 2;         // elm_map_get_correspondences: the search alone, on float64 GLOBAL-frame points (RegParams::query)
+    constexpr int NV = (METHOD == ELM_P2P) ? (KS ? kP2PVals : kP2PVals - 3) : kSums;
     __shared__ double s_buf[kRedPass * kBlock]; // stage 2: the queue of undecided points; afterwards the reduction's transpose buffer
     __shared__ double s_red[kSums];
     __shared__ int s_res[kBlock];
-    __shared__ int s_tst[STATS ? kBlock : 1];
+    __shared__ int s_tst[KS ? kBlock : 1];
     __shared__ float s_pz[METHOD == ELM_P2P ? kBlock : 1];  // P2P: the point's z (x and y ride in the stash's spare 8 bytes)
-    __shared__ unsigned s_st[STATS ? kBlock : 1];           // instrumented builds: the walk statistics of the query voxel
+    __shared__ unsigned s_st[KS ? kBlock : 1];           // instrumented builds: the walk statistics of the query voxel
     __shared__ unsigned s_cnt[kBlock / 64];
     const unsigned L = xcd_remap(blockIdx.x, total_blocks);
     const int s = find_scan(scans, batch, L, rp);
@@ -1907,13 +1910,19 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
     };
     if (valid) {
         double px, py, pz, gx, gy, gz;
-        const Pt3 p3 = sd.pts[i]; // 12 bytes per point: one global_load_dwordx3
-        float4 pf = make_float4(p3.x, p3.y, p3.z, 0.f);
-        transform(pf, px, py, pz, gx, gy, gz);
+        float4 pf = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (QUERY) { // the point as the caller holds it: already in the map's frame
+            gx = rp.query[3 * (size_t)i]; gy = rp.query[3 * (size_t)i + 1]; gz = rp.query[3 * (size_t)i + 2];
+            px = py = pz = 0.0;
+        } else {
+            const Pt3 p3 = sd.pts[i]; // 12 bytes per point: one global_load_dwordx3
+            pf = make_float4(p3.x, p3.y, p3.z, 0.f);
+            transform(pf, px, py, pz, gx, gy, gz);
+        }
         const GridAxis ax = grid_axis(gx, m), ay = grid_axis(gy, m), az = grid_axis(gz, m);
         // statistics of the reference's walk for this query voxel: candidates and occupied buckets among the 27
         unsigned stat = 0;
-        if (STATS && TILED != 1) { // (the two-level grid keeps no dense statistics box: its work counters read 0)
+        if (KS && TILED != 1) { // (the two-level grid keeps no dense statistics box: its work counters read 0)
             const int ux = ax.f - m.vx0, uy = ay.f - m.vy0, uz = az.f - m.vz0;
             const bool in_box = (unsigned)ux < (unsigned)m.vnx && (unsigned)uy < (unsigned)m.vny && (unsigned)uz < (unsigned)m.vnz;
             const unsigned sidx = in_box ? ((unsigned)ux * (unsigned)m.vny + (unsigned)uy) * (unsigned)m.vnz + (unsigned)uz : 0u;
@@ -2009,7 +2018,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
         asm volatile("" : "+v"(rr2), "+v"(ghx), "+v"(ghy), "+v"(ghz), "+v"(egrr), "+v"(egblk), "+v"(L1), "+v"(L2), "+v"(L3));
         stash_w(gx, gy, gz, __hiloint2double(__float_as_int(pf.y), __float_as_int(pf.x)));
         if (METHOD == ELM_P2P) s_pz[threadIdx.x] = pf.z;
-        if (STATS) s_st[threadIdx.x] = stat;
+        if (KS) s_st[threadIdx.x] = stat;
         {
             int b0v[4], b1v[4]; // (already in visiting order)
 #pragma unroll
@@ -2141,26 +2150,43 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
             const GridHardRec R = s_rec[live ? it : 0];
             int win, walked;
             grid_ball_walk<(TILED == 1 ? 1 : 0), LPI>(m, lp, R, live, rl, lane, win, walked);
-            if (STATS) walked = group_sum_int<LPI>(walked);
+            if (KS) walked = group_sum_int<LPI>(walked);
             if (rl == 0 && live) {
                 s_res[it] = win;
-                if (STATS) s_tst[it] = walked;
+                if (KS) s_tst[it] = walked;
             }
         }
         __syncthreads();
         if (hard) {
             bj = s_res[my_slot];
-            if (STATS) n_tested += s_tst[my_slot];
+            if (KS) n_tested += s_tst[my_slot];
         }
         __syncthreads(); // the queue is dead: the reduction may overwrite it
     }
     if (keep_prev && valid) rp.prev[pidx] = (unsigned)bj; // (-1: no candidate at all)
+    if (QUERY) { // the pair of GetCorrespondencePoints (vhm.cpp:31-88): the nearest point of the 27 buckets when it lies within max_dist
+        if (valid) {
+            double gx, gy, gz;
+            float pxf, pyf;
+            load_g(gx, gy, gz, pxf, pyf);
+            int out = -2;
+            if (bj >= 0) {
+                const Pt3 q = blk_point(lp, bj);
+                const double ex = (double)q.x - gx, ey = (double)q.y - gy, ez = (double)q.z - gz;
+                if ((ex * ex + ey * ey) + ez * ez < rp.th2) out = (int)m.grid_idx[bj];
+            } else if ((gx * gx + gy * gy) + gz * gz < rp.th2) {
+                out = -1; // no bucket at all: the default PointStruct at the origin (QUIRK, vhm.cpp:37)
+            }
+            rp.q_out[i] = out;
+        }
+        return; // (uniform)
+    }
     if (valid) {
         double gx, gy, gz;
         float pxf, pyf;
         load_g(gx, gy, gz, pxf, pyf);
         const double px = pxf, py = pyf, pz = (METHOD == ELM_P2P) ? (double)s_pz[threadIdx.x] : 0.0; // (the pair of P2P: J = [I | -[p]x])
-        const unsigned stat = STATS ? s_st[threadIdx.x] : 0u;
+        const unsigned stat = KS ? s_st[threadIdx.x] : 0u;
         // the winner's float64 distance in the reference's arithmetic (range test, weight); no bucket at all (the search came
         // back empty): the reference's default PointStruct at the origin (vhm.cpp:37, QUIRK)
         float bx = 0.f, by = 0.f, bz = 0.f;
@@ -2184,7 +2210,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
         const double c_tested = (double)n_tested + (hard ? kFallbackUnit : 0.0); // high part: points served by stage 2
         if (METHOD == ELM_P2P) {
             if (bd2 < rp.th2) pair_p2p(v, S.Rinv, px, py, pz, ex, ey, ez, bd2, rp);
-            if (STATS) { v[NV - 3] = c_cand; v[NV - 2] = c_occ; v[NV - 1] = c_tested; }
+            if (KS) { v[NV - 3] = c_cand; v[NV - 2] = c_occ; v[NV - 1] = c_tested; }
         } else {
             // finish_point_pair: no bucket at all -> the reference's default PointStruct at the origin with covariance I (QUIRK);
             // GICP's target position is the neighbourhood MEAN of the matched point (reg.cpp:97)
@@ -2235,7 +2261,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
                 pair_sum_single<ELM_GICP>(P, mean[0] - gx, mean[1] - gy, mean[2] - gz, Ci, nf, rp);
                 P.ax = gx - S.T[12]; P.ay = gy - S.T[13]; P.az = gz - S.T[14];
             }
-            if (STATS) { P.c29 = c_cand; P.c30 = c_occ; P.c31 = c_tested; }
+            if (KS) { P.c29 = c_cand; P.c30 = c_occ; P.c31 = c_tested; }
         }
     }
     // maps with an asymmetric flagged covariance (only the instantiations that read stored inverses can meet one): the side record
@@ -2264,10 +2290,10 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
     if (METHOD == ELM_P2P) block_reduce_to_lds<NV, kRedPass>(v, s_buf, s_red);
     else
 #endif
-        block_reduce_pair_sum<kRedPass, STATS ? kSums : kSums - 3>(P, s_buf, s_red);
+        block_reduce_pair_sum<kRedPass, KS ? kSums : kSums - 3>(P, s_buf, s_red);
     if (METHOD != ELM_P2P && COMPACT != 2) asym_side_store(P.A, P.ax, P.ay, P.az, L, rp, s_buf, s_asym, s_hitw);
     const int tk = (int)threadIdx.x;
-    publish_and_reduce((tk < kSums && (STATS || tk < kSums - 3)) ? ((METHOD == ELM_P2P) ? p2p_expand(s_red, tk) : s_red[tk]) : 0.0, L, s, sd.blk_begin,
+    publish_and_reduce((tk < kSums && (KS || tk < kSums - 3)) ? ((METHOD == ELM_P2P) ? p2p_expand(s_red, tk) : s_red[tk]) : 0.0, L, s, sd.blk_begin,
                        sd.blk_end, partials, rp, s_buf);
 }
 
@@ -2428,6 +2454,8 @@ template <int METHOD, int COMPACT, int STATS, int FACES>
 __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
                                                             unsigned total_blocks, const ScanState* __restrict__ st,
                                                             double* __restrict__ partials, const RegParams rp) {
+    constexpr int KS = (STATS == 1) ? 1 : 0;
+    constexpr bool QUERY = STATS == 2; // elm_map_get_correspondences (GetCorrespondencesCov / GetCorrespondencesAllCov): RegParams::query in, q_out out
     __shared__ double s_buf[kRedPass * kBlock];
     __shared__ double s_red[kSums];
     const unsigned L = xcd_remap(blockIdx.x, total_blocks);
@@ -2446,11 +2474,16 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
     PairSum P;
     pair_sum_zero(P);
     if (valid) {
-        const Pt3 pf = sd.pts[i];
-        const double px = pf.x, py = pf.y, pz = pf.z;
-        const double gx = ((S.T[0] * px + S.T[4] * py) + S.T[8] * pz) + S.T[12];
-        const double gy = ((S.T[1] * px + S.T[5] * py) + S.T[9] * pz) + S.T[13];
-        const double gz = ((S.T[2] * px + S.T[6] * py) + S.T[10] * pz) + S.T[14];
+        double px = 0.0, py = 0.0, pz = 0.0, gx, gy, gz;
+        if (QUERY) {
+            gx = rp.query[3 * (size_t)i]; gy = rp.query[3 * (size_t)i + 1]; gz = rp.query[3 * (size_t)i + 2];
+        } else {
+            const Pt3 pf = sd.pts[i];
+            px = pf.x; py = pf.y; pz = pf.z;
+            gx = ((S.T[0] * px + S.T[4] * py) + S.T[8] * pz) + S.T[12];
+            gy = ((S.T[1] * px + S.T[5] * py) + S.T[9] * pz) + S.T[13];
+            gz = ((S.T[2] * px + S.T[6] * py) + S.T[10] * pz) + S.T[14];
+        }
         const int vx = floor_key(gx, m), vy = floor_key(gy, m), vz = floor_key(gz, m);
         unsigned start = 0, cnt = 0;
         if (m.vq_dense) { // the dense floor-key box: no probe
@@ -2546,6 +2579,9 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
             }
             // finish_voxel_pair: no voxel at all -> the reference's default VoxelStruct at the origin with covariance I (QUIRK)
             const double dfin = (bvid >= 0) ? bd2 : (gx * gx + gy * gy) + gz * gz;
+            if (QUERY) { // the pair of GetCorrespondencesCov (vhm.cpp:90-151); no occupied neighbour at all: the default CovStruct at the origin
+                rp.q_out[i] = (dfin < rp.th2) ? bvid : -2;
+            } else
             if (COMPACT == 2) { // every voxel of this map is compact (no voxel at all: the default at the origin, covariance I: k = 0)
                 if (dfin < rp.th2) {
                     if (bvid < 0) bmx = bmy = bmz = 0.0;
@@ -2567,7 +2603,7 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
                 P.ax = gx - S.T[12]; P.ay = gy - S.T[13]; P.az = gz - S.T[14];
             }
             (void)px; (void)py; (void)pz;
-            if (STATS) { P.c29 = (double)cnt; P.c30 = (double)cnt; P.c31 = (double)cnt; }
+            if (KS) { P.c29 = (double)cnt; P.c30 = (double)cnt; P.c31 = (double)cnt; }
         } else {
             // AVGICP, GetCorrespondencesAllCov (vhm.cpp:153-206): every existing FACE neighbour (and the voxel itself) whose
             // mean is within range is a pair of its own.  The records carry the neighbour's position code (dx+1)*9+(dy+1)*3+
@@ -2667,6 +2703,12 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
                     n_pairs += 1.0;
                     const double ex = r[u].mx - gx, ey = r[u].my - gy, ez = r[u].mz - gz;
                     const double d2 = (ex * ex + ey * ey) + ez * ez;
+                    if (QUERY) { // GetCorrespondencesAllCov (vhm.cpp:153-206): the pair's place in the reference's order (0, +x, -x, +y, -y, +z, -z)
+                        // position codes (dx+1)*9 + (dy+1)*3 + (dz+1): 13, 22, 4, 16, 10, 14, 12
+                        const unsigned code = (unsigned)r[u].pad & 31u;
+                        const int rank = code == 13u ? 0 : code == 22u ? 1 : code == 4u ? 2 : code == 16u ? 3 : code == 10u ? 4 : code == 14u ? 5 : 6;
+                        if (d2 < rp.th2) rp.q_out[8 * (size_t)i + rank] = r[u].vid;
+                    } else
                     if (d2 < rp.th2) avg_pair_add(Q, ex, ey, ez, Ci[u], rp);
                 }
             }
@@ -2677,9 +2719,10 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
             if (Q.n > 0.0) { // (a point without a pair -- a NaN / infinite return among them -- contributes zeros, not 0 x NaN)
                 P.ax = gx - S.T[12]; P.ay = gy - S.T[13]; P.az = gz - S.T[14];
             }
-            if (STATS && FACES != 3) { P.c29 = n_pairs; P.c30 = n_pairs; P.c31 = n_pairs; } // (the fused walk has counted every record)
+            if (KS && FACES != 3) { P.c29 = n_pairs; P.c30 = n_pairs; P.c31 = n_pairs; } // (the fused walk has counted every record)
         }
     }
+    if (QUERY) return; // (uniform) the pairs are written, there are no sums
     // The side record of maps with an asymmetric flagged covariance (asym_side_store): every instantiation that reads stored inverses
     // computes it; the fused walk on a map with flagged voxels (FACES = 4) has skipped those pairs and writes zeros, which its fix-up
     // launch (FACES = 3, marked workgroups only) overwrites.  Clean maps (COMPACT = 2 / FACES = 2) never carry the pointer.
@@ -2687,7 +2730,7 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
     __shared__ unsigned s_hitw[kBlock / 64];
     constexpr bool kAsymHere = COMPACT != 2 && FACES != 2 && FACES != 4;
     if (kAsymHere) asym_mark(P.A, rp, s_hitw);
-    block_reduce_pair_sum<kRedPass, STATS ? kSums : kSums - 3>(P, s_buf, s_red);
+    block_reduce_pair_sum<kRedPass, KS ? kSums : kSums - 3>(P, s_buf, s_red);
     if (FACES == 4) {
         if (rp.asym && threadIdx.x < (unsigned)kAsymSums) rp.asym[(size_t)L * kAsymSums + threadIdx.x] = 0.0;
     } else if (kAsymHere) {
@@ -2697,7 +2740,7 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
         if (threadIdx.x < (unsigned)kSums - 3u) partials[(size_t)L * kSums + threadIdx.x] += s_red[threadIdx.x];
         return;
     }
-    publish_and_reduce((threadIdx.x < (STATS ? kSums : kSums - 3)) ? s_red[threadIdx.x] : 0.0, L, s, sd.blk_begin, sd.blk_end, partials, rp, s_buf);
+    publish_and_reduce((threadIdx.x < (KS ? kSums : kSums - 3)) ? s_red[threadIdx.x] : 0.0, L, s, sd.blk_begin, sd.blk_end, partials, rp, s_buf);
 }
 
 __global__ __launch_bounds__(256) void k_vnbr_fill(const DevMap m, const int32_t* __restrict__ qkeys, unsigned n_q,
@@ -3656,6 +3699,168 @@ void launch_accumulate_radar(hipStream_t s, const DevMap& m, const ScanDesc* sca
     default: hipLaunchKernelGGL(k_accumulate_radar<ELM_AVGICP>, grid, block, 0, s, m, scans, batch, (unsigned)total_blocks, st, partials, rp); break;
     }
 }
+// ---- Registration::AlignCloudsLocal* on explicit pairs (elm_align_clouds_local) ---------------------------------------------------------
+// The reference's public step functions (reg.cpp:15-66 P2P, :68-152 GICP, :154-225 VGICP / AVGICP): given the pairs -- source points in the
+// SENSOR frame, targets and their covariances in the map frame -- and last_icp_pose, the LM-damped Gauss-Newton step as a 4x4 transform.
+// RunRegister never calls them here (its kernels pair and accumulate at once); a caller that holds pairs of its own does.  The pairs are
+// accumulated with the reference's per-pair arithmetic in the sensor frame (add_pair / add_pair_radar: all 36 entries for the covariance
+// methods, so a non-symmetric covariance behaves as in the reference: LDLT on the lower triangle, the full inverse for local_cov).
+// SelfAdjointEigenSolver(cov).eigenvectors().col(0) (reg.cpp:89-91): the eigenvector of the smallest eigenvalue; only used through
+// |r . n| (the fitness score).  Cyclic Jacobi on the lower triangle, the FIRST minimum of equal eigenvalues (identity covariance: e_x).
+__device__ __forceinline__ void smallest_eigenvector3(const double C[9], double n[3]) {
+    double A[9] = {C[0], C[3], C[6], C[3], C[4], C[7], C[6], C[7], C[8]}; // (row-major; the lower triangle mirrored)
+    double V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        const double off = fabs(A[3]) + fabs(A[6]) + fabs(A[7]);
+        if (off == 0.0) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (A[p * 3 + q] == 0.0) continue;
+                const double theta = (A[q * 3 + q] - A[p * 3 + p]) / (2.0 * A[p * 3 + q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; ++k) { const double akp = A[k * 3 + p], akq = A[k * 3 + q]; A[k * 3 + p] = c * akp - s * akq; A[k * 3 + q] = s * akp + c * akq; }
+                for (int k = 0; k < 3; ++k) { const double apk = A[p * 3 + k], aqk = A[q * 3 + k]; A[p * 3 + k] = c * apk - s * aqk; A[q * 3 + k] = s * apk + c * aqk; }
+                for (int k = 0; k < 3; ++k) { const double vkp = V[k * 3 + p], vkq = V[k * 3 + q]; V[k * 3 + p] = c * vkp - s * vkq; V[k * 3 + q] = s * vkp + c * vkq; }
+            }
+    }
+    int best = 0;
+    for (int i = 1; i < 3; ++i)
+        if (A[i * 4] < A[best * 4]) best = i;
+    n[0] = V[best]; n[1] = V[3 + best]; n[2] = V[6 + best];
+}
+template <int METHOD>
+__global__ __launch_bounds__(256) void k_align_pairs(const double* __restrict__ src_local, const double* __restrict__ tgt_xyz, const double* __restrict__ tgt_cov,
+                                                     const double* __restrict__ src_cov, size_t n, const AlignArgs a, double* __restrict__ partials) {
+    RegParams rp{};
+    rp.th = a.th; rp.th2 = a.th2;
+    double acc[kRadarAcc];
+#pragma unroll
+    for (int k = 0; k < kRadarAcc; ++k) acc[k] = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const double px = src_local[3 * i], py = src_local[3 * i + 1], pz = src_local[3 * i + 2];
+        const double mx = tgt_xyz[3 * i], my = tgt_xyz[3 * i + 1], mz = tgt_xyz[3 * i + 2];
+        if (METHOD == ELM_P2P) {
+            double a32[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) a32[k] = 0.0;
+            add_pair<ELM_P2P>(a32, a.Rinv, a.tinv, px, py, pz, mx, my, mz, nullptr, nullptr, rp);
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c < 6; ++c) acc[r * 6 + c] += a32[r <= c ? tri(r, c) : tri(c, r)];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc[36 + k] += a32[21 + k];
+            acc[42] += a32[27]; acc[43] += a32[28];
+        } else {
+            double C[9], Cs[9], nf[3] = {1.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { C[k] = tgt_cov[9 * i + k]; Cs[k] = (a.use_src_cov && src_cov) ? src_cov[9 * i + k] : 0.0; }
+            if (METHOD == ELM_GICP) smallest_eigenvector3(C, nf);
+            add_pair_radar<METHOD>(acc, a.Rinv, a.tinv, px, py, pz, mx, my, mz, C, Cs, nf, rp);
+        }
+    }
+    __shared__ double red[256 / 64][kRadarAcc];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kRadarAcc; ++k) {
+        const double v = wave_sum(acc[k]);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < (unsigned)kRadarSums)
+        partials[(size_t)blockIdx.x * kRadarSums + threadIdx.x] =
+            threadIdx.x < (unsigned)kRadarAcc ? ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x] : 0.0;
+}
+// the step from the sums (reg.cpp:52-65 / 134-151 / 211-224): fitness, J^T M J + lambda diag, LDLT, (GICP) the inverse as local_cov, exp
+__global__ __launch_bounds__(64) void k_align_solve(const double* __restrict__ partials, int n_blocks, size_t n, const AlignArgs a, double* __restrict__ out) {
+    __shared__ double sums[kRadarSums];
+    const int t = threadIdx.x;
+    double v = 0.0;
+    for (int b = 0; b < n_blocks; ++b) v += partials[(size_t)b * kRadarSums + t]; // fixed order
+    sums[t] = v;
+    __syncthreads();
+    if (t != 0) return;
+    double JTJ[36], JTr[6], A[36], x[6], cov[36], R[9];
+    for (int k = 0; k < 36; ++k) JTJ[k] = sums[k];
+    for (int k = 0; k < 6; ++k) JTr[k] = sums[36 + k];
+    for (int k = 0; k < 36; ++k) A[k] = JTJ[k];
+    for (int k = 0; k < 6; ++k) A[k * 7] = JTJ[k * 7] + a.lm_lambda * JTJ[k * 7];
+    ldlt_solve6(A, JTr, x);
+    for (int k = 0; k < 36; ++k) cov[k] = (k % 7 == 0) ? 1.0 : 0.0;
+    if (a.method == ELM_GICP) inv6(A, cov);
+    rotvec_to_matrix(x + 3, R);
+    double* T = out; // column-major
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) T[c * 4 + r] = R[r * 3 + c];
+        T[12 + r] = x[r];
+        T[r * 4 + 3] = 0.0;
+    }
+    T[15] = 1.0;
+    for (int k = 0; k < 36; ++k) out[16 + k] = cov[k];
+    out[52] = sums[42] / (double)n; // d_fitness_score_ = d_residual_sum / source_global.size()
+    for (int k = 0; k < 6; ++k) out[53 + k] = x[k];
+    for (int k = 0; k < 36; ++k) out[59 + k] = JTJ[k];
+    for (int k = 0; k < 6; ++k) out[95 + k] = JTr[k];
+    out[101] = sums[43];
+}
+void launch_align_pairs(hipStream_t s, const double* src_local, const double* tgt_xyz, const double* tgt_cov, const double* src_cov, size_t n,
+                        const AlignArgs& a, double* partials, double* out) {
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 1024);
+    if (blocks) {
+        if (a.method == ELM_P2P) hipLaunchKernelGGL(k_align_pairs<ELM_P2P>, dim3(blocks), dim3(256), 0, s, src_local, tgt_xyz, tgt_cov, src_cov, n, a, partials);
+        else if (a.method == ELM_GICP) hipLaunchKernelGGL(k_align_pairs<ELM_GICP>, dim3(blocks), dim3(256), 0, s, src_local, tgt_xyz, tgt_cov, src_cov, n, a, partials);
+        else hipLaunchKernelGGL(k_align_pairs<ELM_VGICP>, dim3(blocks), dim3(256), 0, s, src_local, tgt_xyz, tgt_cov, src_cov, n, a, partials);
+    }
+    hipLaunchKernelGGL(k_align_solve, dim3(1), dim3(64), 0, s, partials, blocks, n, a, out);
+}
+// The query form of the plain walk (elm_map_get_correspondences without a search index, or with ELM_QUERY=direct as the in-product
+// checker of the production search): GetCorrespondencePoints / GetCorrespondencesCov / GetCorrespondencesAllCov (vhm.cpp:31-206) on
+// float64 GLOBAL-frame points -- 27 (7) hash probes per point, every bucket point, the reference's arithmetic.  q_out as RegParams::q_out.
+template <int WHAT>
+__global__ __launch_bounds__(256) void k_query_direct(const DevMap m, const double* __restrict__ query, size_t n, double th2, int32_t* __restrict__ q_out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double gx = query[3 * i], gy = query[3 * i + 1], gz = query[3 * i + 2];
+    const int vx = floor_key(gx, m.voxel_size), vy = floor_key(gy, m.voxel_size), vz = floor_key(gz, m.voxel_size);
+    double n_cand = 0.0, n_occ = 0.0;
+    if (WHAT == 0) {
+        double bd2 = DBL_MAX;
+        float bx = 0.f, by = 0.f, bz = 0.f;
+        int bidx = -1;
+        if (m.n_vox) nearest_point_direct(m, vx, vy, vz, gx, gy, gz, bd2, bx, by, bz, bidx, n_cand, n_occ);
+        const double dfin = (bidx >= 0) ? bd2 : (gx * gx + gy * gy) + gz * gz;
+        q_out[i] = (dfin < th2) ? bidx : -2;
+    } else if (WHAT == 1) {
+        double bd2 = DBL_MAX, bmx = 0.0, bmy = 0.0, bmz = 0.0;
+        int bvid = -1;
+        if (m.n_vox) nearest_voxel_direct(m, vx, vy, vz, gx, gy, gz, bd2, bvid, bmx, bmy, bmz, n_cand, n_occ);
+        const double dfin = (bvid >= 0) ? bd2 : (gx * gx + gy * gy) + gz * gz;
+        q_out[i] = (dfin < th2) ? bvid : -2;
+    } else {
+        const int ox[7] = {0, 1, -1, 0, 0, 0, 0}, oy[7] = {0, 0, 0, 1, -1, 0, 0}, oz[7] = {0, 0, 0, 0, 0, 1, -1}; // vhm.cpp:224-230
+#pragma unroll
+        for (int k7 = 0; k7 < 7; ++k7) {
+            int out = -2;
+            if (m.n_vox) {
+                const Probe pr = probe_voxel(m, vx + ox[k7], vy + oy[k7], vz + oz[k7]);
+                if (pr.vid >= 0 && pr.cnt != 0) {
+                    const double cx = m.vox_mean[(size_t)pr.vid * 3], cy = m.vox_mean[(size_t)pr.vid * 3 + 1], cz = m.vox_mean[(size_t)pr.vid * 3 + 2];
+                    const double ex = cx - gx, ey = cy - gy, ez = cz - gz;
+                    if ((ex * ex + ey * ey) + ez * ez < th2) out = pr.vid;
+                }
+            }
+            q_out[8 * i + k7] = out;
+        }
+        q_out[8 * i + 7] = -2;
+    }
+}
+void launch_query_direct(hipStream_t s, const DevMap& m, int what, const double* query, size_t n, double th2, int32_t* q_out) {
+    const dim3 g((unsigned)((n + 255) / 256)), b(256);
+    if (what == 0) hipLaunchKernelGGL(k_query_direct<0>, g, b, 0, s, m, query, n, th2, q_out);
+    else if (what == 1) hipLaunchKernelGGL(k_query_direct<1>, g, b, 0, s, m, query, n, th2, q_out);
+    else hipLaunchKernelGGL(k_query_direct<2>, g, b, 0, s, m, query, n, th2, q_out);
+}
 void launch_accumulate_direct(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                               ScanState* st, double* partials, const RegParams& rp) {
     dim3 g(total_blocks), b(kBlock);
@@ -3698,7 +3903,14 @@ void launch_accumulate_grid(hipStream_t s, const DevMap& m, const ScanDesc* scan
         else if (m.grid_patch) ELM_LAUNCH_G(M, C, 2);                              \
         else ELM_LAUNCH_G(M, C, 0);                                                \
     } while (0)
-    if (rp.method == ELM_P2P) ELM_LAUNCH_GT(ELM_P2P, 0);
+    if (rp.query) { // elm_map_get_correspondences: the search of the P2P kernel alone (STATS = 2)
+        if (m.grid_wide) {
+            if (m.grid_tiled) ELM_LAUNCH_GW(ELM_P2P, 0, 1, 2, 1); else if (m.grid_patch) ELM_LAUNCH_GW(ELM_P2P, 0, 2, 2, 1); else ELM_LAUNCH_GW(ELM_P2P, 0, 0, 2, 1);
+        } else {
+            if (m.grid_tiled) ELM_LAUNCH_GW(ELM_P2P, 0, 1, 2, 0); else if (m.grid_patch) ELM_LAUNCH_GW(ELM_P2P, 0, 2, 2, 0); else ELM_LAUNCH_GW(ELM_P2P, 0, 0, 2, 0);
+        }
+    }
+    else if (rp.method == ELM_P2P) ELM_LAUNCH_GT(ELM_P2P, 0);
     else if (m.gicp_compact == 2) ELM_LAUNCH_GT(ELM_GICP, 2);
     else if (m.gicp_compact) ELM_LAUNCH_GT(ELM_GICP, 1);
     else ELM_LAUNCH_GT(ELM_GICP, 0);
@@ -3744,7 +3956,11 @@ void launch_accumulate_vnbr(hipStream_t s, const DevMap& m, const ScanDesc* scan
             else ELM_LAUNCH_VF(M, C, 0, 0);                                        \
         }                                                                          \
     } while (0)
-    if (rp.method == ELM_VGICP) {
+    if (rp.query) { // elm_map_get_correspondences: the walk alone (STATS = 2), full records (the voxel ids and position codes)
+        if (rp.method == ELM_VGICP) ELM_LAUNCH_VF(ELM_VGICP, 0, 2, 0);
+        else ELM_LAUNCH_VF(ELM_AVGICP, 0, 2, 0);
+    }
+    else if (rp.method == ELM_VGICP) {
         if (m.vox_compact == 2) ELM_LAUNCH_V(ELM_VGICP, 2);
         else if (m.vox_compact) ELM_LAUNCH_V(ELM_VGICP, 1);
         else ELM_LAUNCH_V(ELM_VGICP, 0);

@@ -248,6 +248,55 @@ class VoxelHashMap:
               "elm_map_find_ground_height")
         return bool(found.value), z.value
 
+    def _correspondences(self, what, points, max_dist):
+        q = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        n = q.shape[0]
+        cap = n * (7 if what == 2 else 1)
+        src = np.empty(max(cap, 1), np.uint32); tgt = np.empty(max(cap, 1), np.int32)
+        k = C.c_size_t(0)
+        check(_lib.lib().elm_map_get_correspondences(self.ctx._h, self._handle(), int(what), _dp(q), n, float(max_dist),
+                                                     src.ctypes.data_as(C.POINTER(C.c_uint32)), tgt.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                     cap, C.byref(k)), self.ctx._h, "elm_map_get_correspondences")
+        return q, src[:k.value].astype(np.int64), tgt[:k.value].astype(np.int64)
+
+    def GetCorrespondencePoints(self, points, max_correspondence_dist, indices=False):
+        """vhm.cpp:31-88 -> (source points [k, 3], target points [k, 3]) in input order; a point with no neighbour bucket at all pairs
+        with the reference's default PointStruct at the origin when that is within range (QUIRK, vhm.cpp:37).  indices=True also returns
+        (source index, target index in Pointcloud() order or -1)."""
+        q, src, tgt = self._correspondences(0, points, max_correspondence_dist)
+        mp = self.Pointcloud()
+        target = np.where((tgt >= 0)[:, None], mp[np.maximum(tgt, 0)], 0.0) if tgt.size else np.zeros((0, 3))
+        return (q[src], target, src, tgt) if indices else (q[src], target)
+
+    def GetCorrespondencesCov(self, points, max_correspondence_dist, indices=False):
+        """vhm.cpp:90-151 -> (source points, target means, target covariances [k, 3, 3]): the nearest voxel MEAN among the occupied
+        neighbours; none at all: the default CovStruct (mean 0, covariance I) when the origin is within range."""
+        return self._cov_pairs(1, points, max_correspondence_dist, indices)
+
+    def GetCorrespondencesAllCov(self, points, max_correspondence_dist, indices=False):
+        """vhm.cpp:153-206 -> one pair per occupied FACE neighbour (and the point's own voxel) whose mean is within range, in the
+        reference's neighbour order (vhm.cpp:224-230)."""
+        return self._cov_pairs(2, points, max_correspondence_dist, indices)
+
+    def _cov_pairs(self, what, points, max_dist, indices):
+        q, src, tgt = self._correspondences(what, points, max_dist)
+        _, _, cov, mean = self.Voxels()
+        ok = tgt >= 0
+        tm = np.where(ok[:, None], mean[np.maximum(tgt, 0)], 0.0) if tgt.size else np.zeros((0, 3))
+        tc = np.where(ok[:, None, None], cov[np.maximum(tgt, 0)], np.eye(3)) if tgt.size else np.zeros((0, 3, 3))
+        return (q[src], tm, tc, src, tgt) if indices else (q[src], tm, tc)
+
+    def GetAdjacentVoxels(self, point, search_range):  # vhm.cpp:208-243: keys only, whether or not such voxels exist
+        v = self.PointToVoxel(point, self.voxel_size_).astype(np.int64)
+        if search_range == 0:
+            return v[None, :].copy()
+        if search_range == 1:
+            off = np.array([[0, 0, 0], [1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]])
+        else:  # any other range: the 27 of the 3 x 3 x 3 block, x slowest (voxel_neighbor = 1 whatever `range` says)
+            r = np.arange(-1, 2)
+            off = np.stack(np.meshgrid(r, r, r, indexing="ij"), -1).reshape(-1, 3)
+        return v[None, :] + off
+
     @staticmethod
     def PointToVoxel(point, voxel_size):  # vhm.hpp:176-180
         return np.floor(np.asarray(point, dtype=np.float64) / voxel_size).astype(np.int32)
@@ -357,6 +406,33 @@ class Registration:
         if trace:
             return out + (_result_dict(res, tr),)
         return out
+
+    def _align(self, method, source_local, target_xyz, target_cov, last_icp_pose, trans_th, m_config, source_cov=None):
+        cfg = m_config if m_config is not None else self.config_
+        src = np.ascontiguousarray(source_local, dtype=np.float64).reshape(-1, 3)
+        tgt = np.ascontiguousarray(target_xyz, dtype=np.float64).reshape(-1, 3)
+        n = src.shape[0]
+        colmajor = lambda c: None if c is None else np.ascontiguousarray(np.asarray(c, dtype=np.float64).reshape(n, 3, 3).transpose(0, 2, 1)).reshape(n, 9)
+        tc, sc = colmajor(target_cov), colmajor(source_cov)
+        T = _colmajor16(last_icp_pose)
+        Tout = np.empty(16); cov = np.zeros(36); fit = C.c_double(float("nan"))
+        check(_lib.lib().elm_align_clouds_local(self.ctx._h, int(method), _dp(src), _dp(tgt), None if tc is None else _dp(tc),
+                                                None if sc is None else _dp(sc), n, _dp(T), float(trans_th), C.byref(cfg), _dp(Tout),
+                                                _dp(cov), C.byref(fit)), self.ctx._h, "elm_align_clouds_local")
+        self.d_fitness_score_ = fit.value
+        return Tout.reshape(4, 4).T.copy(), cov.reshape(6, 6)
+
+    def AlignCloudsLocal(self, source_local, target_pose, last_icp_pose, trans_th, m_config=None):
+        """reg.cpp:15-66 on explicit pairs (source PointStruct::local, target PointStruct::pose) -> the step as a 4x4."""
+        return self._align(IcpMethod.P2P, source_local, target_pose, None, last_icp_pose, trans_th, m_config)[0]
+
+    def AlignCloudsLocalPointCov(self, source_local, target_mean, target_cov, last_icp_pose, trans_th, m_config=None, source_cov=None):
+        """reg.cpp:68-152 (targets' covariance.mean / covariance.cov) -> (step 4x4, local_cov 6x6)."""
+        return self._align(IcpMethod.GICP, source_local, target_mean, target_cov, last_icp_pose, trans_th, m_config, source_cov)
+
+    def AlignCloudsLocalVoxelCov(self, source_local, target_mean, target_cov, last_icp_pose, trans_th, m_config=None, source_cov=None):
+        """reg.cpp:154-225 (CovStruct targets) -> the step as a 4x4."""
+        return self._align(IcpMethod.VGICP, source_local, target_mean, target_cov, last_icp_pose, trans_th, m_config, source_cov)[0]
 
     def RunRegisterBatch(self, scans, voxel_map, initial_guesses, m_config=None, trace=False):
         """Many resident scans against one map, iterated together. Returns a list of result dicts."""

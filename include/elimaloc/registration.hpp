@@ -101,6 +101,24 @@ struct Registration {
         return T;
     }
 
+    // reg.cpp:15-66 / 68-152 / 154-225: the step functions of the reference's public interface on pairs the CALLER holds (RunRegister
+    // pairs and accumulates in one kernel and never calls them): source PointStruct::local against the targets' pose (P2P) /
+    // covariance.mean + covariance.cov, around last_icp_pose; the pairs are accumulated on the device (elm_align_clouds_local) with
+    // the reference's per-pair arithmetic.  d_fitness_score_ is set as the reference sets it.
+    elimaloc::Matrix4d AlignCloudsLocal(std::vector<PointStruct>& source_global, const std::vector<PointStruct>& target_global,
+                                        elimaloc::Matrix4d& last_icp_pose, double trans_th, RegistrationConfig m_config) {
+        return Align(ELM_P2P, source_global, &target_global, nullptr, nullptr, last_icp_pose, trans_th, m_config);
+    }
+    elimaloc::Matrix4d AlignCloudsLocalPointCov(std::vector<PointStruct>& source_global, const std::vector<PointStruct>& target_global,
+                                                elimaloc::Matrix6d& local_cov, elimaloc::Matrix4d& last_icp_pose, double trans_th,
+                                                RegistrationConfig m_config) {
+        return Align(ELM_GICP, source_global, &target_global, nullptr, &local_cov, last_icp_pose, trans_th, m_config);
+    }
+    elimaloc::Matrix4d AlignCloudsLocalVoxelCov(std::vector<PointStruct>& source_global, const std::vector<CovStruct>& target_cov_global,
+                                                elimaloc::Matrix4d& last_icp_pose, double trans_th, RegistrationConfig m_config) {
+        return Align(ELM_VGICP, source_global, nullptr, &target_cov_global, nullptr, last_icp_pose, trans_th, m_config);
+    }
+
     // reg.hpp:126-134: in place (the node's debug clouds, pcm.cpp:308-313); every other field is kept
     inline void TransformPoints(const elimaloc::Matrix4d& T, std::vector<PointStruct>& points) {
         for (auto& point : points) Apply(T, point.pose);
@@ -122,6 +140,34 @@ private:
     static inline void Apply(const elimaloc::Matrix4d& T, elimaloc::Vector3d& p) {
         const double x = p(0), y = p(1), z = p(2);
         for (int r = 0; r < 3; ++r) p(r) = ((T(r, 0) * x + T(r, 1) * y) + T(r, 2) * z) + T(r, 3) * 1.0;
+    }
+    elimaloc::Matrix4d Align(int method, const std::vector<PointStruct>& source, const std::vector<PointStruct>* target_points,
+                             const std::vector<CovStruct>* target_covs, elimaloc::Matrix6d* local_cov, const elimaloc::Matrix4d& last_icp_pose,
+                             double trans_th, const RegistrationConfig& m_config) {
+        const size_t n = source.size();
+        std::vector<double> src(3 * n), tgt(3 * n), cov(method == ELM_P2P ? 0 : 9 * n), scov(m_config.use_radar_cov && method != ELM_P2P ? 9 * n : 0);
+        for (size_t i = 0; i < n; ++i) {
+            const CovStruct* tc = target_covs ? &(*target_covs)[i] : &(*target_points)[i].covariance;
+            for (int k = 0; k < 3; ++k) {
+                src[3 * i + k] = source[i].local(k);
+                tgt[3 * i + k] = (method == ELM_P2P) ? (*target_points)[i].pose(k) : tc->mean(k);
+            }
+            if (method != ELM_P2P)
+                for (int k = 0; k < 9; ++k) cov[9 * i + k] = tc->cov.data()[k]; // both column-major
+            if (!scov.empty())
+                for (int k = 0; k < 9; ++k) scov[9 * i + k] = source[i].covariance.cov.data()[k];
+        }
+        const elm_reg_config c = m_config.c_struct();
+        elimaloc::Matrix4d T = elimaloc::Matrix4d::Identity();
+        double lc[36], fitness = 0.0;
+        elimaloc::check(elm_align_clouds_local(VoxelHashMap::ctx(), method, src.data(), tgt.data(), cov.empty() ? nullptr : cov.data(),
+                                               scov.empty() ? nullptr : scov.data(), n, last_icp_pose.data(), trans_th, &c, T.data(), lc, &fitness),
+                        VoxelHashMap::ctx(), "AlignCloudsLocal");
+        if (local_cov && method == ELM_GICP)
+            for (int r = 0; r < 6; ++r)
+                for (int q = 0; q < 6; ++q) (*local_cov)(r, q) = lc[r * 6 + q];
+        d_fitness_score_ = fitness;
+        return T;
     }
     std::vector<float> scratch_xyz_;
 };

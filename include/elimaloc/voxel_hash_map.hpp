@@ -163,12 +163,92 @@ struct VoxelHashMap {
             }
         return out;
     }
+    // vhm.cpp:31-88 / 90-151 / 153-206: the correspondence calls of the reference's public interface.  RunRegister never needs them
+    // here (its iterations search and accumulate in one kernel); a caller that wants the pairs themselves gets them from the same
+    // search (elm_map_get_correspondences), in input order like the reference's vectors.  Source points are copied whole (every
+    // PointStruct member), targets carry pose / local / covariance of the matched map point (or voxel); a point without any
+    // neighbour bucket pairs with the default-constructed target when the origin is within range (vhm.cpp:37 / :105).
+    std::tuple<std::vector<PointStruct>, std::vector<PointStruct>> GetCorrespondencePoints(const RadarPointVector& vec_points,
+                                                                                           double d_max_correspondence_dist) const {
+        std::vector<uint32_t> src;
+        std::vector<int32_t> tgt;
+        Pairs(0, vec_points, d_max_correspondence_dist, src, tgt);
+        const std::vector<PointStruct> cloud = tgt.empty() ? std::vector<PointStruct>() : Pointcloud();
+        std::vector<PointStruct> vec_source, vec_target;
+        vec_source.reserve(src.size());
+        vec_target.reserve(src.size());
+        for (size_t k = 0; k < src.size(); ++k) {
+            vec_source.emplace_back(vec_points[src[k]]);
+            vec_target.emplace_back(tgt[k] >= 0 ? cloud[(size_t)tgt[k]] : PointStruct());
+        }
+        return std::make_tuple(std::move(vec_source), std::move(vec_target));
+    }
+    std::tuple<std::vector<PointStruct>, std::vector<CovStruct>> GetCorrespondencesCov(const RadarPointVector& vec_points,
+                                                                                      double d_max_correspondence_dist) const {
+        return CovPairs(1, vec_points, d_max_correspondence_dist);
+    }
+    std::tuple<std::vector<PointStruct>, std::vector<CovStruct>> GetCorrespondencesAllCov(const RadarPointVector& vec_points,
+                                                                                         double d_max_correspondence_dist) const {
+        return CovPairs(2, vec_points, d_max_correspondence_dist);
+    }
+    // vhm.cpp:208-243: key arithmetic only (whether or not such voxels exist): range 0 the voxel itself, 1 the seven
+    // (0, +x, -x, +y, -y, +z, -z), anything else the 27 of the 3 x 3 x 3 block, x slowest
+    std::vector<Voxel> GetAdjacentVoxels(const PointStruct& point, int range) const {
+        const Voxel voxel = PointToVoxel(point.pose, voxel_size_);
+        const int vx = voxel(0), vy = voxel(1), vz = voxel(2);
+        if (range == 0) return std::vector<Voxel>{voxel};
+        if (range == 1)
+            return std::vector<Voxel>{Voxel(vx, vy, vz), Voxel(vx + 1, vy, vz), Voxel(vx - 1, vy, vz), Voxel(vx, vy + 1, vz),
+                                      Voxel(vx, vy - 1, vz), Voxel(vx, vy, vz + 1), Voxel(vx, vy, vz - 1)};
+        std::vector<Voxel> voxels;
+        voxels.reserve(27);
+        for (int i = vx - 1; i < vx + 2; ++i)
+            for (int j = vy - 1; j < vy + 2; ++j)
+                for (int k = vz - 1; k < vz + 2; ++k) voxels.emplace_back(i, j, k);
+        return voxels;
+    }
     inline bool FindGroundHeight(const elimaloc::Vector2d& position, double& ground_z) const { // vhm.hpp:285-322
         int found = 0;
         elimaloc::check(elm_map_find_ground_height(handle(), position(0), position(1), &ground_z, &found), ctx(), "FindGroundHeight");
         return found != 0;
     }
 
+    void Pairs(int what, const RadarPointVector& vec_points, double max_dist, std::vector<uint32_t>& src, std::vector<int32_t>& tgt) const {
+        std::vector<double> xyz(3 * vec_points.size());
+        for (size_t i = 0; i < vec_points.size(); ++i)
+            for (int k = 0; k < 3; ++k) xyz[3 * i + k] = vec_points[i].pose(k);
+        const size_t cap = vec_points.size() * (what == 2 ? 7 : 1);
+        src.resize(cap);
+        tgt.resize(cap);
+        size_t n_pairs = 0;
+        elimaloc::check(elm_map_get_correspondences(ctx(), handle(), what, xyz.data(), vec_points.size(), max_dist, src.data(), tgt.data(), cap, &n_pairs),
+                        ctx(), "elm_map_get_correspondences");
+        src.resize(n_pairs);
+        tgt.resize(n_pairs);
+    }
+    std::tuple<std::vector<PointStruct>, std::vector<CovStruct>> CovPairs(int what, const RadarPointVector& vec_points, double max_dist) const {
+        std::vector<uint32_t> src;
+        std::vector<int32_t> tgt;
+        Pairs(what, vec_points, max_dist, src, tgt);
+        elm_map_info mi;
+        elimaloc::check(elm_map_get_info(handle(), &mi), ctx(), "elm_map_get_info");
+        std::vector<double> cov(9 * mi.n_voxels), mean(3 * mi.n_voxels);
+        if (!tgt.empty()) elimaloc::check(elm_map_download_voxels(handle(), nullptr, nullptr, cov.data(), mean.data(), mi.n_voxels), ctx(), "elm_map_download_voxels");
+        std::vector<PointStruct> vec_source;
+        std::vector<CovStruct> vec_target;
+        vec_source.reserve(src.size());
+        vec_target.reserve(src.size());
+        for (size_t k = 0; k < src.size(); ++k) {
+            vec_source.emplace_back(vec_points[src[k]]);
+            CovStruct c; // (the default: identity covariance at the origin)
+            if (tgt[k] >= 0) {
+                for (int q = 0; q < 9; ++q) c.cov.data()[q] = cov[9 * (size_t)tgt[k] + q]; // both column-major
+                for (int q = 0; q < 3; ++q) c.mean(q) = mean[3 * (size_t)tgt[k] + q];
+            }
+            vec_target.push_back(c);
+        }
+        return std::make_tuple(std::move(vec_source), std::move(vec_target));
+    }
     // the device-resident map (built lazily from the accumulated points on first use; const like the reference's read paths)
     elm_map* handle() const {
         if (!map_) {

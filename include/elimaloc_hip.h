@@ -184,6 +184,31 @@ int elm_map_download_points(const elm_map* map, double* xyz, double* cov9, doubl
  * subset with count > 2 */
 int elm_map_download_voxels(const elm_map* map, int32_t* key3, int32_t* npts, double* cov9, double* mean3,
                             size_t cap);
+/* VoxelHashMap::GetCorrespondencePoints (what = 0; voxel_hash_map.cpp:31-88), ::GetCorrespondencesCov (1; :90-151) and
+ * ::GetCorrespondencesAllCov (2; :153-206) as calls of their own -- Registration::RunRegister (registration.cpp:317-334) never needs them
+ * (its iterations search and accumulate in one kernel), a caller of the map's public interface may.  xyz: n points in the MAP frame
+ * (PointStruct::pose after TransformPoints), column order x, y, z.  Pairs come back in input order (the reference's vectors: ranges joined
+ * in order): src_index[k] = the query point of pair k, tgt_index[k] = its target -- what 0: position of the map point in
+ * elm_map_download_points order, what 1 / 2: position of the voxel in elm_map_download_voxels order; -1 = the reference's default target at
+ * the origin (no neighbour bucket at all around the point, voxel_hash_map.cpp:37 / :105; never for what 2).  what 2 yields up to seven
+ * pairs per point in the reference's neighbour order (0, +x, -x, +y, -y, +z, -z).  At most `cap` pairs are written; *n_pairs is the full
+ * count.  The search is the accumulate kernels' own (their QUERY instantiations); ELM_QUERY=direct runs the plain 27-probe walk instead. */
+int elm_map_get_correspondences(elm_ctx* ctx, const elm_map* map, int what, const double* xyz, size_t n, double max_dist,
+                                uint32_t* src_index, int32_t* tgt_index, size_t cap, size_t* n_pairs);
+
+/* Registration::AlignCloudsLocal (method ELM_P2P; registration.cpp:15-66), ::AlignCloudsLocalPointCov (ELM_GICP; :68-152) and
+ * ::AlignCloudsLocalVoxelCov (ELM_VGICP / ELM_AVGICP; :154-225) on pairs the CALLER holds (RunRegister pairs and accumulates in one kernel and
+ * never calls them): src_local = PointStruct::local of the n source points (sensor frame), tgt_xyz = the targets' positions in the map
+ * frame -- PointStruct::pose for P2P, covariance.mean for the covariance methods (registration.cpp:97, 172) --, tgt_cov9 = their 3x3
+ * covariances (column-major; NULL for P2P), src_cov9 = the source points' covariance terms, added when cfg->use_radar_cov (NULL: none).
+ * T_out = the step as a column-major 4x4 (the reference's return value), local_cov = the inverse of the damped normal matrix (written
+ * for ELM_GICP only, like the reference's out-parameter), *fitness_score = d_fitness_score_ (residual sum / n).  cfg: lm_lambda and
+ * use_radar_cov are read (NULL: the defaults).  The pairs are accumulated on the device with the reference's per-pair arithmetic
+ * (all 36 entries of J^T M J for the covariance methods: a non-symmetric covariance behaves as in the reference). */
+int elm_align_clouds_local(elm_ctx* ctx, int method, const double* src_local, const double* tgt_xyz, const double* tgt_cov9,
+                           const double* src_cov9, size_t n, const double last_icp_pose[16], double trans_th,
+                           const elm_reg_config* cfg, double T_out[16], double local_cov[36], double* fitness_score);
+
 /* VoxelHashMap::FindGroundHeight (vhm.hpp:285-322); *found = 0/1 */
 int elm_map_find_ground_height(const elm_map* map, double x, double y, double* ground_z, int* found);
 

@@ -1225,6 +1225,67 @@ void orc_nearest_voxel(const orc_map* m, const double* q, size_t n, double max_d
     });
 }
 
+// GetCorrespondencesAllCov (vhm.cpp:153-206) as a call of its own: the pairs in input order (one range, joined in order) as
+// (source index, target mean, target covariance); returns the number of pairs (at most cap are written)
+size_t orc_all_cov_pairs(const orc_map* m, const double* q, size_t n, double max_dist, uint32_t* src_index, double* mean_xyz,
+                         double* cov9, size_t cap) {
+    const double d_max_dist_squared = max_dist * max_dist;
+    size_t k = 0;
+    for (size_t i = 0; i < n; ++i) {
+        V3 pose{q[3 * i], q[3 * i + 1], q[3 * i + 2]};
+        std::vector<Voxel> vec_voxels = GetAdjacentVoxels(*m, pose, 1);
+        std::vector<CovStruct> vec_neighbors_cov;
+        vec_neighbors_cov.reserve(vec_voxels.size());
+        for (const auto& voxel : vec_voxels) {
+            auto search = m->map_.find(voxel);
+            if (search != m->map_.end() && !search->second.points.empty()) vec_neighbors_cov.emplace_back(search->second.covariance);
+        }
+        for (const auto& cov : vec_neighbors_cov) {
+            if (sqn(sub(cov.mean, pose)) < d_max_dist_squared) {
+                if (k < cap) {
+                    src_index[k] = static_cast<uint32_t>(i);
+                    mean_xyz[3 * k] = cov.mean.x; mean_xyz[3 * k + 1] = cov.mean.y; mean_xyz[3 * k + 2] = cov.mean.z;
+                    if (cov9) std::memcpy(cov9 + 9 * k, cov.cov.m, 9 * sizeof(double));
+                }
+                ++k;
+            }
+        }
+    }
+    return k;
+}
+
+// Registration::AlignCloudsLocal / AlignCloudsLocalPointCov / AlignCloudsLocalVoxelCov (reg.cpp:15-225) as calls of their own.
+// method 0 / 1 / 2,3; src_local = PointStruct::local, tgt_xyz = target pose (P2P) or covariance.mean, covariances column-major
+void orc_align_clouds_local(int method, const double* src_local, const double* tgt_xyz, const double* tgt_cov9, const double* src_cov9,
+                            size_t n, const double last_icp_pose[16], double trans_th, const orc_config* cfg, double T_out[16],
+                            double local_cov[36], double* fitness, double JTJ_out[36], double JTr_out[6]) {
+    std::vector<PointStruct> src(n), tgt(n);
+    std::vector<CovStruct> tcov(n);
+    for (size_t i = 0; i < n; ++i) {
+        src[i].local = {src_local[3 * i], src_local[3 * i + 1], src_local[3 * i + 2]};
+        src[i].pose = src[i].local;
+        if (src_cov9) std::memcpy(src[i].covariance.cov.m, src_cov9 + 9 * i, 9 * sizeof(double));
+        tgt[i].pose = {tgt_xyz[3 * i], tgt_xyz[3 * i + 1], tgt_xyz[3 * i + 2]};
+        if (tgt_cov9) {
+            std::memcpy(tcov[i].cov.m, tgt_cov9 + 9 * i, 9 * sizeof(double));
+            tcov[i].mean = tgt[i].pose;
+            tgt[i].covariance = tcov[i];
+        }
+    }
+    M4 T;
+    std::memcpy(T.m, last_icp_pose, 16 * sizeof(double));
+    AlignOut o{};
+    M6 cov;
+    for (int k = 0; k < 36; ++k) cov.m[k] = (k % 7 == 0) ? 1.0 : 0.0;
+    if (method == 0) o = AlignCloudsLocal(src, tgt, T, trans_th, *cfg, fitness);
+    else if (method == 1) o = AlignCloudsLocalPointCov(src, tgt, cov, T, trans_th, *cfg, fitness);
+    else o = AlignCloudsLocalVoxelCov(src, tcov, T, trans_th, *cfg, fitness);
+    std::memcpy(T_out, o.transformation.m, 16 * sizeof(double));
+    if (local_cov) std::memcpy(local_cov, cov.m, 36 * sizeof(double));
+    if (JTJ_out) std::memcpy(JTJ_out, o.JTJ.m, 36 * sizeof(double));
+    if (JTr_out) std::memcpy(JTr_out, o.JTr, 6 * sizeof(double));
+}
+
 // RunRegister (reg.cpp:274-418)
 void orc_register(const orc_map* mp, const float* scan_xyz, size_t n, const double T0[16], const orc_config* cfgp,
                   orc_result* out) {

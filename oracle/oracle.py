@@ -229,6 +229,20 @@ class Map:
         return acc.astype(bool), mean, cov.reshape(n, 3, 3).transpose(0, 2, 1).copy()
 
 
+    def all_cov_pairs(self, q, max_dist=5.0):
+        """GetCorrespondencesAllCov (vhm.cpp:153-206): (source index, target mean, target covariance) per pair, input order."""
+        q = np.ascontiguousarray(q, dtype=np.float64).reshape(-1, 3)
+        n = q.shape[0]
+        cap = 7 * n
+        src = np.empty(max(cap, 1), np.uint32); mean = np.empty((max(cap, 1), 3)); cov = np.empty((max(cap, 1), 9))
+        f = lib().orc_all_cov_pairs
+        f.restype = C.c_size_t
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.c_double, C.POINTER(C.c_uint32), C.POINTER(C.c_double),
+                      C.POINTER(C.c_double), C.c_size_t]
+        k = f(self._h, _dp(q), n, max_dist, src.ctypes.data_as(C.POINTER(C.c_uint32)), _dp(mean), _dp(cov), cap)
+        return src[:k].astype(np.int64), mean[:k].copy(), cov[:k].reshape(k, 3, 3).transpose(0, 2, 1).copy()
+
+
 def register(m, scan_xyz, T0, cfg):
     """RunRegister restatement. T0: 4x4 numpy (row/col indexed normally). Returns dict."""
     scan = np.ascontiguousarray(scan_xyz, dtype=np.float32).reshape(-1, 3)
@@ -251,6 +265,25 @@ def register(m, scan_xyz, T0, cfg):
                 iterations=res.iterations, gate=res.gate, fitness=res.fitness,
                 local_cov=np.array(res.local_cov).reshape(6, 6, order="F"),
                 elapsed_ms=res.elapsed_ms, correspondence_ms=res.correspondence_ms, iters=iters)
+
+
+def align_clouds_local(method, src_local, tgt_xyz, tgt_cov, last_icp_pose, trans_th, cfg, src_cov=None):
+    """Registration::AlignCloudsLocal (method 0) / AlignCloudsLocalPointCov (1) / AlignCloudsLocalVoxelCov (2, 3), reg.cpp:15-225, on
+    explicit pairs -> dict(T 4x4, local_cov 6x6, fitness, JTJ 6x6, JTr)."""
+    src = np.ascontiguousarray(src_local, dtype=np.float64).reshape(-1, 3)
+    tgt = np.ascontiguousarray(tgt_xyz, dtype=np.float64).reshape(-1, 3)
+    n = src.shape[0]
+    colmajor = lambda c: None if c is None else np.ascontiguousarray(np.asarray(c, dtype=np.float64).reshape(n, 3, 3).transpose(0, 2, 1)).reshape(n, 9)
+    tc, sc = colmajor(tgt_cov), colmajor(src_cov)
+    T = np.asfortranarray(np.asarray(last_icp_pose, dtype=np.float64)).ravel(order="F").copy()
+    Tout = np.empty(16); cov = np.empty(36); fit = C.c_double(0.0); JTJ = np.empty(36); JTr = np.empty(6)
+    f = lib().orc_align_clouds_local
+    f.restype = None
+    dp = C.POINTER(C.c_double)
+    f.argtypes = [C.c_int, dp, dp, dp, dp, C.c_size_t, dp, C.c_double, C.POINTER(Config), dp, dp, C.POINTER(C.c_double), dp, dp]
+    f(int(method), _dp(src), _dp(tgt), None if tc is None else _dp(tc), None if sc is None else _dp(sc), n, _dp(T), float(trans_th),
+      C.byref(cfg), _dp(Tout), _dp(cov), C.byref(fit), _dp(JTJ), _dp(JTr))
+    return dict(T=Tout.reshape(4, 4).T.copy(), local_cov=cov.reshape(6, 6).T.copy(), fitness=fit.value, JTJ=JTJ.reshape(6, 6).T.copy(), JTr=JTr)
 
 
 def voxel_downsample(xyz, voxel_size):

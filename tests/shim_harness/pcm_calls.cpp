@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <iostream>
 #include <memory>
+#include <tuple>
 #include <vector>
 
 #include "registration.hpp"     // resolves to include/elimaloc/registration.hpp (include path order)
@@ -211,6 +212,42 @@ int main() {
         worst = std::fmax(worst, std::fabs(world[k].pose.x() - q.x) + std::fabs(world[k].pose.y() - q.y) + std::fabs(world[k].pose.z() - q.z));
     }
     std::printf("worst |world - map| = %.4f\n", worst);
+    // the map's public correspondence calls (vhm.cpp:31-243; registration.cpp:317-334 is their only caller in the reference) on the
+    // registered scan: every point of a scan cut from the map finds a pair, the targets are map points / voxel means near it
+    {
+        std::vector<PointStruct> src_p, tgt_p, src_c, src_a;
+        std::vector<CovStruct> tgt_c, tgt_a;
+        std::tie(src_p, tgt_p) = node.local_map_.GetCorrespondencePoints(world, 5.0);
+        std::tie(src_c, tgt_c) = node.local_map_.GetCorrespondencesCov(world, 5.0);
+        std::tie(src_a, tgt_a) = node.local_map_.GetCorrespondencesAllCov(world, 5.0);
+        double far_p = 0.0, far_c = 0.0;
+        auto dist = [](const Eigen::Vector3d& a, const Eigen::Vector3d& b) {
+            return std::sqrt((a.x() - b.x()) * (a.x() - b.x()) + (a.y() - b.y()) * (a.y() - b.y()) + (a.z() - b.z()) * (a.z() - b.z()));
+        };
+        for (size_t k = 0; k < src_p.size(); ++k) far_p = std::fmax(far_p, dist(tgt_p[k].pose, src_p[k].pose));
+        for (size_t k = 0; k < src_c.size(); ++k) far_c = std::fmax(far_c, dist(tgt_c[k].mean, src_c[k].pose));
+        const std::vector<VoxelHashMap::Voxel> adj = node.local_map_.GetAdjacentVoxels(world[0], 1);
+        std::printf("pairs: points %zu (worst %.3f) cov %zu (worst %.3f) all-cov %zu; adjacent %zu\n", src_p.size(), far_p, src_c.size(), far_c,
+                    src_a.size(), adj.size());
+        if (src_p.size() != world.size() || src_c.size() != world.size() || src_a.size() < world.size() || far_p > 0.3 || far_c > 1.8 ||
+            adj.size() != 7 || node.local_map_.GetAdjacentVoxels(world[0], 2).size() != 27)
+            return 5;
+        // one iteration of the reference's own loop from its public pieces (reg.cpp:317-372): the pairs above, then the step around the
+        // converged pose -- a few centimetres at most
+        Registration reg2;
+        Eigen::Matrix4d last = icp;
+        const Eigen::Matrix4d step_p = reg2.AlignCloudsLocal(src_p, tgt_p, last, 5.0, node.registration_config_);
+        const double fit_p = reg2.d_fitness_score_;
+        const Eigen::Matrix4d step_c = reg2.AlignCloudsLocalVoxelCov(src_c, tgt_c, last, 5.0, node.registration_config_);
+        Eigen::Matrix6d lc6;
+        const Eigen::Matrix4d step_g = reg2.AlignCloudsLocalPointCov(src_p, tgt_p, lc6, last, 5.0, node.registration_config_); // (default covariances: runs, not judged)
+        (void)step_g;
+        std::printf("steps: p2p t = (%.4f %.4f %.4f) fitness %.4f, voxel-cov t = (%.4f %.4f %.4f)\n", step_p(0, 3), step_p(1, 3), step_p(2, 3), fit_p,
+                    step_c(0, 3), step_c(1, 3), step_c(2, 3));
+        if (std::fabs(step_p(0, 3)) + std::fabs(step_p(1, 3)) + std::fabs(step_p(2, 3)) > 0.15 || !(fit_p >= 0.0 && fit_p < 0.3) ||
+            std::fabs(step_c(0, 3)) + std::fabs(step_c(1, 3)) + std::fabs(step_c(2, 3)) > 0.15)
+            return 6;
+    }
     // the reference's ICP stops on step size (0.02) with lm_lambda = 0.5, i.e. a few cm short of the fixed point: this harness checks
     // the call sequence end to end, pose parity against the oracle is the job of tests/test_gpu_parity.py
     const bool ok = std::fabs(icp(0, 3) - lx) < 0.1 && std::fabs(icp(1, 3) - ly) < 0.1 && std::fabs(icp(2, 3) - lz) < 0.1 &&

@@ -1,0 +1,201 @@
+"""The reference's public correspondence calls -- VoxelHashMap::GetCorrespondencePoints / GetCorrespondencesCov /
+GetCorrespondencesAllCov / GetAdjacentVoxels (vhm.cpp:31-243) -- as calls of their own: the PAIRS of the production search (the QUERY
+instantiations of the grid / voxel-list kernels, i.e. the code the fused accumulate kernels run) against the oracle, pair for pair,
+index for index, on every index form; the plain 27-probe walk (ELM_QUERY=direct) as the in-product checker."""
+import numpy as np
+import pytest
+
+from elimaloc_amd import synth
+
+
+def _queries(world, seed, n=6000):
+    """float64 MAP-frame points: transformed scan points (not float32-representable), points beyond the map, points whose 27 voxels are
+    all empty but that lie within range of the ORIGIN (the reference's default target, QUIRK), negative coordinates, exact map points."""
+    rng = np.random.default_rng(seed)
+    scan, Tt = synth.make_scan(world, n, seed=seed)
+    T = synth.perturb(Tt, seed=seed + 1, max_trans=0.4, max_rot_deg=1.5)
+    g = scan.astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+    far = rng.uniform(-400, 400, size=(300, 3))
+    near0 = rng.uniform(-4.5, 4.5, size=(300, 3)) * np.array([1.0, 1.0, 1.0]) + np.array([0.0, 0.0, 30.0]) * (rng.random((300, 1)) < 0.5)
+    exact = world[rng.choice(len(world), 300, replace=False)].astype(np.float64)
+    tight0 = rng.uniform(-0.6, 0.6, size=(60, 3))
+    return np.concatenate([g, far, near0, tight0, exact, -np.abs(g[:200])])
+
+
+def _set_env(monkeypatch, kernel_env):
+    if kernel_env == "tiled":
+        monkeypatch.setenv("ELM_KERNEL", "grid"); monkeypatch.setenv("ELM_GRID", "tiled")
+    elif kernel_env in ("grid", "patch"):
+        monkeypatch.setenv("ELM_KERNEL", "grid"); monkeypatch.setenv("ELM_GRID_PATCH", "1" if kernel_env == "patch" else "0")
+    elif kernel_env == "query_direct":
+        monkeypatch.setenv("ELM_QUERY", "direct")
+    else:
+        monkeypatch.setenv("ELM_KERNEL", kernel_env)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel_env", ["grid", "patch", "tiled", "lists", "direct", "query_direct"])
+def test_correspondence_calls_match_the_oracle_pair_for_pair(oracle, kernel_env, monkeypatch):
+    from elimaloc_amd.registration import Context, VoxelHashMap
+    _set_env(monkeypatch, kernel_env)
+    rng = np.random.default_rng(3)
+    world = np.concatenate([synth.make_world(80000, seed=31), rng.uniform(-40, 40, size=(4000, 3)) * np.array([1.0, 1.0, 0.1])]).astype(np.float32)
+    world = world[(np.abs(world[:, :2]) > 6.0).any(axis=1)]  # nothing near the origin: the default target is reachable
+    c = Context(0)
+    try:
+        for vs, th in ((1.0, 5.0), (0.7, 1.2)):
+            vm = VoxelHashMap(vs, 30, c)
+            vm.AddPoints(world)
+            vm.CalVoxelCovAll()
+            om = oracle.Map(vs, 30)
+            om.add_points(world)
+            om.cal_voxel_cov_all()
+            q = _queries(world, seed=100 + int(vs * 10))
+            # GetCorrespondencePoints
+            acc, tgt, _ = om.nearest_points(q, th)
+            sp, tp, si, ti = vm.GetCorrespondencePoints(q, th, indices=True)
+            assert np.array_equal(si, np.flatnonzero(acc))
+            assert np.array_equal(sp, q[acc]) and np.array_equal(tp, tgt[acc])
+            assert (ti == -1).sum() == int((acc & (np.abs(tgt).sum(axis=1) == 0)).sum()) and (ti == -1).sum() > 0
+            # GetCorrespondencesCov
+            acc, mean, cov = om.nearest_voxel(q, th)
+            sp, tm, tc, si, ti = vm.GetCorrespondencesCov(q, th, indices=True)
+            assert np.array_equal(si, np.flatnonzero(acc))
+            assert np.array_equal(tm, mean[acc])
+            np.testing.assert_allclose(tc, cov[acc], rtol=1e-9, atol=1e-12)
+            assert (ti == -1).any()
+            # GetCorrespondencesAllCov
+            osrc, omean, ocov = om.all_cov_pairs(q, th)
+            sp, tm, tc, si, ti = vm.GetCorrespondencesAllCov(q, th, indices=True)
+            assert np.array_equal(si, osrc) and np.array_equal(tm, omean)
+            np.testing.assert_allclose(tc, ocov, rtol=1e-9, atol=1e-12)
+            assert len(si) > len(q)  # several pairs per point
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel_env", ["grid", "patch", "tiled", "query_direct"])
+def test_exact_ties_pick_the_reference_s_neighbour(oracle, kernel_env, monkeypatch):
+    """Query points exactly half-way between lattice points: 2, 4 or 8 candidates at bit-identical distance; the pair is the FIRST strict
+    minimum of the reference's walk (bucket visiting order, insertion order inside a bucket)."""
+    from elimaloc_amd.registration import Context, VoxelHashMap
+    from test_gpu_parity import _tie_world
+    _set_env(monkeypatch, kernel_env)
+    lattice, scan = _tie_world()
+    c = Context(0)
+    try:
+        vm = VoxelHashMap(1.0, 30, c)
+        vm.AddPoints(lattice)
+        om = oracle.Map(1.0, 30)
+        om.add_points(lattice)
+        q = scan.astype(np.float64)
+        acc, tgt, _ = om.nearest_points(q, 5.0)
+        sp, tp, si, ti = vm.GetCorrespondencePoints(q, 5.0, indices=True)
+        assert np.array_equal(si, np.flatnonzero(acc)) and np.array_equal(tp, tgt[acc])
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
+def test_empty_and_degenerate_queries(oracle):
+    from elimaloc_amd.registration import Context, VoxelHashMap
+    c = Context(0)
+    try:
+        vm = VoxelHashMap(1.0, 30, c)
+        vm.AddPoints(synth.make_world(5000, seed=2))
+        sp, tp = vm.GetCorrespondencePoints(np.zeros((0, 3)), 5.0)
+        assert sp.shape == (0, 3) and tp.shape == (0, 3)
+        one = np.array([[1000.0, 1000.0, 1000.0]])
+        assert vm.GetCorrespondencePoints(one, 5.0)[0].shape == (0, 3)
+        with pytest.raises(Exception):
+            vm.GetCorrespondencesCov(one, 5.0)  # no CalVoxelCovAll yet: the same refusal as a VGICP registration
+    finally:
+        c.close()
+
+
+def test_get_adjacent_voxels_is_key_arithmetic(oracle):
+    """vhm.cpp:208-243: range 0 the voxel itself, 1 the seven (0, +x, -x, +y, -y, +z, -z), anything else the 27 (x slowest)."""
+    from elimaloc_amd.registration import VoxelHashMap
+    vm = VoxelHashMap.__new__(VoxelHashMap)
+    vm.voxel_size_ = 0.7
+    p = np.array([-0.1, 3.6, 0.69])
+    v = np.floor(p / 0.7).astype(int)
+    assert np.array_equal(vm.GetAdjacentVoxels(p, 0), v[None])
+    a1 = vm.GetAdjacentVoxels(p, 1)
+    assert np.array_equal(a1 - v, [[0, 0, 0], [1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]])
+    for r in (2, 5):
+        a = vm.GetAdjacentVoxels(p, r)
+        assert a.shape == (27, 3) and np.array_equal(a[0] - v, [-1, -1, -1]) and np.array_equal(a[1] - v, [-1, -1, 0]) and np.array_equal(a[9] - v, [0, -1, -1])
+
+
+def test_oracle_all_cov_pairs_against_brute_force(oracle):
+    """The oracle's GetCorrespondencesAllCov call against plain numpy: floor key of the query, the seven neighbour keys in the
+    reference's order, voxels looked up by their STORED (truncated) keys, mean within range."""
+    world = synth.make_world(20000, seed=9)
+    om = oracle.Map(1.0, 30)
+    om.add_points(world)
+    om.cal_voxel_cov_all()
+    keys, npts, covs, means = om.voxels()
+    table = {tuple(int(x) for x in k): i for i, k in enumerate(keys)}
+    rng = np.random.default_rng(4)
+    q = np.concatenate([world[rng.choice(len(world), 500)].astype(np.float64) + rng.normal(0, 0.3, (500, 3)), rng.uniform(-3, 3, (100, 3))])
+    src, mean, cov = om.all_cov_pairs(q, 1.1)
+    exp_src, exp_mean = [], []
+    for i, p in enumerate(q):
+        f = np.floor(p / 1.0).astype(int)
+        for off in ([0, 0, 0], [1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]):
+            v = table.get(tuple(int(x) for x in f + np.array(off)))
+            if v is None or npts[v] == 0:
+                continue
+            d = means[v] - p
+            if (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2] < 1.1 * 1.1:
+                exp_src.append(i); exp_mean.append(means[v])
+    assert np.array_equal(src, np.array(exp_src)) and np.array_equal(mean, np.array(exp_mean))
+    assert len(src) > 600
+
+
+def _pairs_for_align(seed, n=4000):
+    rng = np.random.default_rng(seed)
+    src = rng.uniform(-40, 40, (n, 3)) * np.array([1.0, 1.0, 0.1])
+    T = synth.perturb(np.eye(4), seed=seed + 1, max_trans=2.0, max_rot_deg=20.0)
+    tgt = src @ T[:3, :3].T + T[:3, 3] + rng.normal(0, 0.08, (n, 3))
+    tgt[::50] += rng.normal(0, 6.0, (len(tgt[::50]), 3))  # some pairs far out: tiny weights, the VGICP skip (reg.cpp:201)
+    A = rng.normal(0, 0.3, (n, 3, 3))
+    cov = A @ A.transpose(0, 2, 1) + 1e-3 * np.eye(3)
+    cov[::7] = np.eye(3)                                   # identity covariances (a neighbourhood of the point alone)
+    cov[3::11] += rng.normal(0, 0.02, (len(cov[3::11]), 3, 3))  # NOT symmetric (the regularised covariance of a rank-deficient neighbourhood)
+    return src, tgt, cov, T
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_align_clouds_local_on_explicit_pairs(oracle, method):
+    """Registration::AlignCloudsLocal / PointCov / VoxelCov (reg.cpp:15-225) as calls of their own, against the oracle's restatement:
+    step, local_cov (GICP), d_fitness_score_; symmetric and non-symmetric covariances, identity covariances, use_radar_cov."""
+    from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod
+    c = Context(0)
+    try:
+        for seed in (1, 2):
+            src, tgt, cov, T = _pairs_for_align(10 * seed + method)
+            for radar in ((False, True) if method else (False,)):
+                rng = np.random.default_rng(seed)
+                scov = rng.normal(0, 0.05, (len(src), 3, 3)) if radar else None
+                cfg = RegistrationConfig(icp_method=IcpMethod(method), use_radar_cov=int(radar))
+                reg = Registration(cfg, c)
+                ref = oracle.align_clouds_local(method, src, tgt, None if method == 0 else cov, T, 5.0,
+                                                oracle.default_config(method, use_radar_cov=int(radar)), src_cov=scov)
+                if method == 0:
+                    step = reg.AlignCloudsLocal(src, tgt, T, 5.0)
+                elif method == 1:
+                    step, lc = reg.AlignCloudsLocalPointCov(src, tgt, cov, T, 5.0, source_cov=scov)
+                    np.testing.assert_allclose(lc, ref["local_cov"], rtol=1e-7, atol=1e-12)
+                else:
+                    step = reg.AlignCloudsLocalVoxelCov(src, tgt, cov, T, 5.0, source_cov=scov)
+                np.testing.assert_allclose(step, ref["T"], rtol=0, atol=1e-10)
+                assert abs(reg.d_fitness_score_ - ref["fitness"]) <= 1e-9 * max(abs(ref["fitness"]), 1e-12)
+        # no pairs at all: the zero system -> the identity step, fitness 0 / 0
+        step = Registration(RegistrationConfig(icp_method=IcpMethod.P2P), c).AlignCloudsLocal(np.zeros((0, 3)), np.zeros((0, 3)), np.eye(4), 5.0)
+        assert np.array_equal(step, np.eye(4))
+    finally:
+        c.close()
