@@ -199,3 +199,53 @@ def test_align_clouds_local_on_explicit_pairs(oracle, method):
         assert np.array_equal(step, np.eye(4))
     finally:
         c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", [0, 1, 2, 3])
+def test_run_register_equals_its_public_pieces(oracle, method):
+    """RunRegister (one fused kernel per iteration) against the reference's own loop built from the public calls (reg.cpp:317-378):
+    TransformPoints -> GetCorrespondence* -> AlignCloudsLocal* -> T <- T * step, iteration by iteration."""
+    from elimaloc_amd.registration import Context, VoxelHashMap, Registration, RegistrationConfig, IcpMethod
+    m = IcpMethod(method)
+    world = synth.make_world(60000, seed=77)
+    scan, Tt = synth.make_scan(world, 5000, seed=78)
+    T0 = synth.perturb(Tt, seed=79, max_trans=0.3, max_rot_deg=1.0)
+    c = Context(0)
+    try:
+        vm = VoxelHashMap(1.0, 30, c)
+        vm.AddPoints(world)
+        if m == IcpMethod.GICP:
+            vm.CalPointCovAll(0.4)
+        if m in (IcpMethod.VGICP, IcpMethod.AVGICP):
+            vm.CalVoxelCovAll()
+        reg = Registration(RegistrationConfig(icp_method=m), c)
+        *_, det = reg.RunRegister(scan, vm, T0, trace=True)
+        assert det["iterations"] >= 2
+        if m == IcpMethod.GICP:
+            _, pcov, pmean = vm.Pointcloud(with_cov=True)
+        th = reg.config_.max_search_dist
+        local = scan.astype(np.float64)
+        T = np.array(T0, dtype=np.float64)
+        for it in range(det["iterations"]):
+            x, y, z = local[:, 0], local[:, 1], local[:, 2]
+            g = np.stack([((T[r, 0] * x + T[r, 1] * y) + T[r, 2] * z) + T[r, 3] for r in range(3)], 1)  # reg.hpp:141-146
+            if method == 0:
+                _, tp, si, ti = vm.GetCorrespondencePoints(g, th, indices=True)
+                step = reg.AlignCloudsLocal(local[si], tp, T, th)
+            elif method == 1:
+                _, tp, si, ti = vm.GetCorrespondencePoints(g, th, indices=True)
+                ok = ti >= 0
+                tm = np.where(ok[:, None], pmean[np.maximum(ti, 0)], 0.0)
+                tc = np.where(ok[:, None, None], pcov[np.maximum(ti, 0)], np.eye(3))
+                step, _ = reg.AlignCloudsLocalPointCov(local[si], tm, tc, T, th)
+            else:
+                f = vm.GetCorrespondencesCov if method == 2 else vm.GetCorrespondencesAllCov
+                _, tm, tc, si, ti = f(g, th, indices=True)
+                step = reg.AlignCloudsLocalVoxelCov(local[si], tm, tc, T, th)
+            assert len(si) == int(det["iters"][it]["n_corr"])
+            T = T @ step
+            np.testing.assert_allclose(T, det["iters"][it]["T"], rtol=0, atol=2e-9)
+        assert abs(reg.d_fitness_score_ - det["d_fitness"]) <= 1e-8 * max(abs(det["d_fitness"]), 1e-9)
+    finally:
+        c.close()
