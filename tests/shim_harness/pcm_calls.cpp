@@ -229,7 +229,7 @@ int main() {
         const std::vector<VoxelHashMap::Voxel> adj = node.local_map_.GetAdjacentVoxels(world[0], 1);
         std::printf("pairs: points %zu (worst %.3f) cov %zu (worst %.3f) all-cov %zu; adjacent %zu\n", src_p.size(), far_p, src_c.size(), far_c,
                     src_a.size(), adj.size());
-        if (src_p.size() != world.size() || src_c.size() != world.size() || src_a.size() < world.size() || far_p > 0.3 || far_c > 1.8 ||
+        if (src_p.size() != world.size() || src_c.size() != world.size() || src_a.size() < world.size() || far_p > 1.0 || far_c > 1.8 ||
             adj.size() != 7 || node.local_map_.GetAdjacentVoxels(world[0], 2).size() != 27)
             return 5;
         // one iteration of the reference's own loop from its public pieces (reg.cpp:317-372): the pairs above, then the step around the
