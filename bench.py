@@ -643,18 +643,61 @@ def main():
         d = wpts[:, :2].astype(np.float64) - T_true_[:2, 3]
         return wpts[(d * d).sum(axis=1) < r * r]
 
-    def pose_check(wpts, m, scans_h, T_true_, T0_, out_, idx):
+    _cloud_cache = {}
+
+    def pairs_check(vmap_, m, om_, scan_h, T0_, acc_):
+        """The first iteration's PAIRS, point by point: the product's search (elm_map_get_correspondences -- the QUERY instantiation of the
+        kernel the registration runs, on the whole map) against the oracle's walk (reg.cpp:317-334 / vhm.cpp:31-206): the same source
+        points paired, every target bit-identical.  acc_: [points, pairs, mismatching points or pairs] summed over the checked registrations."""
+        th_ = 5.0  # RegistrationConfig::max_search_dist (localization.ini)
+        x, y, z = (scan_h[:, k].astype(np.float64) for k in range(3))
+        T_ = np.asarray(T0_, dtype=np.float64)
+        g = np.stack([((T_[r, 0] * x + T_[r, 1] * y) + T_[r, 2] * z) + T_[r, 3] for r in range(3)], 1)  # TransformPoints (reg.hpp:141-146)
+        key = (id(vmap_), int(m) in (0, 1))
+        if int(m) in (0, 1):
+            a_, t_, _ = om_.nearest_points(g, th_, min(threads, ncpu))
+            _, si, ti = vmap_._correspondences(0, g, th_)
+            if key not in _cloud_cache:
+                _cloud_cache.clear()
+                _cloud_cache[key] = vmap_.Pointcloud()
+            tp = np.where((ti >= 0)[:, None], _cloud_cache[key][np.maximum(ti, 0)], 0.0)
+            want_src, want_tgt = np.flatnonzero(a_), t_[a_]
+        else:
+            if int(m) == 2:
+                a_, t_, _c = om_.nearest_voxel(g, th_, min(threads, ncpu))
+                want_src, want_tgt = np.flatnonzero(a_), t_[a_]
+            else:
+                want_src, want_tgt, _c = om_.all_cov_pairs(g, th_)
+            _, si, ti = vmap_._correspondences(int(m) - 1, g, th_)
+            if key not in _cloud_cache:
+                _cloud_cache.clear()
+                _cloud_cache[key] = vmap_.Voxels()[3]
+            tp = np.where((ti >= 0)[:, None], _cloud_cache[key][np.maximum(ti, 0)], 0.0)
+        if np.array_equal(si, want_src):
+            bad = int((tp != want_tgt).any(axis=1).sum())
+        else:
+            bad = int(len(np.setxor1d(si, want_src))) + 1
+        acc_[0] += int(g.shape[0]); acc_[1] += int(len(want_src)); acc_[2] += bad
+
+    def pose_check(wpts, m, scans_h, T_true_, T0_, out_, idx, vmap_=None):
         """pose_err_vs_cpu of the registrations `idx`: the CPU oracle on the same scan / guess against the part of the map the scan reaches"""
         errs_, match_ = [], []
+        pairs_ = [0, 0, 0]
         ocfg_ = O.default_config(int(m), max_thread=min(threads, ncpu))
         for i in idx:
             om_ = oracle_map(crop_world(wpts, scans_h[i], T_true_[i]), m)
             ref_ = O.register(om_, scans_h[i], T0_[i], ocfg_)
             errs_.append(synth.pose_error(ref_["T"], out_[i]["T"]))
             match_.append(ref_["iterations"] == out_[i]["iterations"] and ref_["is_success"] == out_[i]["is_success"])
+            if vmap_ is not None:
+                pairs_check(vmap_, m, om_, scans_h[i], T0_[i], pairs_)
             del om_
-        return {"max_trans_m": float(max(e[0] for e in errs_)), "max_rot_rad": float(max(e[1] for e in errs_)), "n_checked": len(errs_),
+        res_ = {"max_trans_m": float(max(e[0] for e in errs_)), "max_rot_rad": float(max(e[1] for e in errs_)), "n_checked": len(errs_),
                 "iterations_and_flags_match": bool(all(match_)), "tolerance": "1e-4 m / 1e-5 rad"}
+        if vmap_ is not None:
+            res_["first_iteration_pairs"] = {"points": pairs_[0], "pairs": pairs_[1], "mismatches": pairs_[2],
+                                             "what": "elm_map_get_correspondences (the registration kernel's own search, pairs written out) against the oracle's walk: same source points, bit-identical targets"}
+        return res_
 
     # ---------------- synthetic inputs (seeded, BLAS-free arithmetic: bit-identical whoever generates them) ----------------
     t0 = time.time()
@@ -936,6 +979,7 @@ def main():
         for _ in range(3):  # warm-ups
             O.register(om, scans_host[0], T0s[0], ocfg10)
         t10, c10, tall, call, errs, it_match = [], [], [], [], [], []
+        head_pairs = [0, 0, 0]
         refs = []
         for i in range(n_s):
             if i:
@@ -949,12 +993,16 @@ def main():
             ra = O.register(om, scans_host[i], T0s[i], ocfg_all)  # every physical core for the correspondence search; accumulation stays serial
             tall.append(ra["elapsed_ms"] * 1e-3)
             call.append(ra["correspondence_ms"] * 1e-3)
+            if i < 8:  # (after the timed runs of this registration: the oracle reports its own elapsed time)
+                pairs_check(vm, method, om, scans_host[i], T0s[i], head_pairs)
             del om
         # pose parity on more of the batch than the baseline times (every core; these runs are not part of `cpu_baseline`)
         for i in range(n_s, min(args.pose_sample, len(scans_host)) if n_s else 0):
-            ref = O.register(crop_map(i), scans_host[i], T0s[i], ocfg_all)
+            om_i = crop_map(i)
+            ref = O.register(om_i, scans_host[i], T0s[i], ocfg_all)
             errs.append(synth.pose_error(ref["T"], out[i]["T"]))
             it_match.append(ref["iterations"] == out[i]["iterations"] and ref["is_success"] == out[i]["is_success"])
+            del om_i
         full_info = None
         if args.cpu_full_sample > 0:
             tb = time.perf_counter()
@@ -1000,11 +1048,13 @@ def main():
             "n_checked": len(errs),
             "iterations_and_flags_match": bool(all(it_match)),
             "tolerance": "1e-4 m / 1e-5 rad",
+            "first_iteration_pairs": {"points": head_pairs[0], "pairs": head_pairs[1], "mismatches": head_pairs[2],
+                                      "what": "elm_map_get_correspondences (the registration kernel's own search, pairs written out) against the oracle's walk on the first 8 checked registrations: same source points, bit-identical targets"},
         }
         result["gpu_over_cpu"] = value / (1.0 / med10)
         if outh is not None:
             # pose parity on the hard set as well (a few: up to 10 iterations each on the CPU)
-            result["hard_guess"]["pose_err_vs_cpu"] = pose_check(world, method, scans_host, T_true, T0h, outh, list(range(min(4, n_s))))
+            result["hard_guess"]["pose_err_vs_cpu"] = pose_check(world, method, scans_host, T_true, T0h, outh, list(range(min(4, n_s))), vm)
 
     # ---------------- the other single-GPU BASELINE configurations, timed in the same process (N = 1) ----------------
     legs = [] if (args.legs == "none" or not extras) else (["gicp", "vgicp", "avgicp", "c5", "c4", "field"] if args.legs == "all" else [x for x in args.legs.split(",") if x])
@@ -1034,7 +1084,7 @@ def main():
                 "roofline": leg_roofline(m, vmap, pr, args.leg_steps, o, cv, op, el),
             }
             if want_cpu and scans_h:
-                leg["pose_err_vs_cpu"] = pose_check(wpts, m, scans_h, Ttrue_, T0_, o, list(range(min(4, len(scans_h)))))
+                leg["pose_err_vs_cpu"] = pose_check(wpts, m, scans_h, Ttrue_, T0_, o, list(range(min(4, len(scans_h)))), vmap)
             leg["leg_wall_s"] = time.time() - tl
             return leg
 

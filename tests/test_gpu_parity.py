@@ -446,6 +446,19 @@ def test_full_size_properties(ctx, oracle):
     refp = oracle.register(om, scan_n, T0, oracle.default_config(0))
     dt, dr = synth.pose_error(refp["T"], out[0]["T"])
     assert refp["iterations"] == out[0]["iterations"] and dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
+    # the PAIRS of the first iteration at full size, point by point: the production search with the pairs written out
+    # (elm_map_get_correspondences, the 10 M-point map) against the oracle's walk (the sub-map): same source points, bit-identical targets
+    x, y, z = (scan_n[:, k].astype(np.float64) for k in range(3))
+    g = np.stack([((T0[r, 0] * x + T0[r, 1] * y) + T0[r, 2] * z) + T0[r, 3] for r in range(3)], 1)
+    acc, tgt, _ = om.nearest_points(g, 5.0)
+    _, tp, si, ti = vm.GetCorrespondencePoints(g, 5.0, indices=True)
+    assert len(si) > 130000 and np.array_equal(si, np.flatnonzero(acc)) and np.array_equal(tp, tgt[acc])
+    acc, mean, _ = om.nearest_voxel(g, 5.0)
+    _, tm, _, si, ti = vm.GetCorrespondencesCov(g, 5.0, indices=True)
+    assert np.array_equal(si, np.flatnonzero(acc)) and np.array_equal(tm, mean[acc])
+    osrc, omean, _ = om.all_cov_pairs(g, 5.0)
+    _, tm, _, si, ti = vm.GetCorrespondencesAllCov(g, 5.0, indices=True)
+    assert np.array_equal(si, osrc) and np.array_equal(tm, omean)
     # the host-fed stream (uploads + device-side ordering overlapped with the iterations): bit-identical to the resident one,
     # from page-locked and from pageable sources
     from elimaloc_amd.registration import PinnedBuffer
