@@ -126,6 +126,7 @@ struct elm_ctx {
     std::vector<hipEvent_t> ev_groups; // host-fed streams: per upload group its "copied" and "ordered" events
     uint16_t* d_hilbert = nullptr; // Hilbert index of every cell of the ordering grid (kOrderCells^2 entries)
     DevBuf d_order_jobs, d_order_tmp, d_arena, d_raw, d_tickets, d_prev, d_flagged, d_asym;
+    DevBuf d_q0, d_q1, d_q2, d_q3, d_q4, d_q5; // scratch of elm_map_get_correspondences / elm_align_clouds_local (kept between calls)
     bool prev_winner = false; // ELM_PREV_WINNER=1 (with a library built with -DELM_PREV_WINNER=1): the grid kernels keep every point's previous winner
     bool work_counters = false; // elm_ctx_set_work_counters / ELM_WORK_COUNTERS=1: the accumulate launches also sum the work counters of
                                 // elm_reg_result (n_cand_total, n_occ_total, n_tested_total, fallback_blocks); off: those fields read 0
@@ -345,7 +346,7 @@ extern "C" void elm_ctx_destroy(elm_ctx* ctx) {
     if (ctx->d_hilbert) (void)hipFree(ctx->d_hilbert);
     if (ctx->h_jobs) (void)hipHostFree(ctx->h_jobs);
     DevBuf* bufs[] = {&ctx->d_scans, &ctx->d_state, &ctx->d_partials, &ctx->d_sums, &ctx->d_T0, &ctx->d_trace, &ctx->d_stage_pts, &ctx->d_active, &ctx->d_queue, &ctx->d_ds,
-                      &ctx->d_order_jobs, &ctx->d_order_tmp, &ctx->d_arena, &ctx->d_raw, &ctx->d_tickets, &ctx->d_prev, &ctx->d_flagged, &ctx->d_asym};
+                      &ctx->d_order_jobs, &ctx->d_order_tmp, &ctx->d_arena, &ctx->d_raw, &ctx->d_tickets, &ctx->d_prev, &ctx->d_flagged, &ctx->d_asym, &ctx->d_q0, &ctx->d_q1, &ctx->d_q2, &ctx->d_q3, &ctx->d_q4, &ctx->d_q5};
     if (ctx->h_active) (void)hipHostFree(ctx->h_active);
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -1911,47 +1912,35 @@ extern "C" int elm_map_get_correspondences(elm_ctx* ctx, const elm_map* map, int
         }
     }
     const size_t per = what == 2 ? 8 : 1;
-    double* d_q = nullptr;
-    int32_t* d_out = nullptr;
-    ScanDesc* d_desc = nullptr;
-    ScanState* d_state = nullptr;
     std::vector<int32_t> out(n * per);
-    auto release = [&]() {
-        for (void* q : {(void*)d_q, (void*)d_out, (void*)d_desc, (void*)d_state})
-            if (q) (void)hipFree(q);
-    };
-    hipError_t e = hipMalloc((void**)&d_q, n * 3 * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_out, n * per * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMemcpyAsync(d_q, xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_out, 0xFF, n * per * sizeof(int32_t), ctx->stream); // (AllCov: < 0 = no pair with that neighbour)
-    if (e == hipSuccess && production) {
+    int rc;
+    if ((rc = dev_reserve(ctx, ctx->d_q0, n * 3 * sizeof(double))) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_q1, n * per * sizeof(int32_t))) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_q2, sizeof(ScanDesc))) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_q3, sizeof(ScanState))) != ELM_OK) return rc;
+    double* d_q = (double*)ctx->d_q0.p;
+    int32_t* d_out = (int32_t*)ctx->d_q1.p;
+    ScanDesc* d_desc = (ScanDesc*)ctx->d_q2.p;
+    ScanState* d_state = (ScanState*)ctx->d_q3.p;
+    HIPCHK(ctx, hipMemcpyAsync(d_q, xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(d_out, 0xFF, n * per * sizeof(int32_t), ctx->stream)); // (AllCov: < 0 = no pair with that neighbour)
+    if (production) {
         ScanDesc hd{};
         hd.pts = nullptr; hd.n = (uint32_t)n; hd.n_total = (uint32_t)n; hd.blk_begin = 0; hd.blk_end = (uint32_t)((n + kBlock - 1) / kBlock);
-        e = hipMalloc((void**)&d_desc, sizeof(ScanDesc));
-        if (e == hipSuccess) e = hipMalloc((void**)&d_state, sizeof(ScanState));
-        if (e == hipSuccess) e = hipMemcpyAsync(d_desc, &hd, sizeof(ScanDesc), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(d_state, 0, sizeof(ScanState), ctx->stream); // done = 0; the pose is not read by a query
-        if (e == hipSuccess) {
-            RegParams rp{};
-            rp.th = max_dist; rp.th2 = max_dist * max_dist;
-            rp.method = cfg.icp_method; rp.max_iter = 1;
-            rp.query = d_q; rp.q_out = d_out;
-            if (what == 0) launch_accumulate_grid(ctx->stream, map->dm, d_desc, 1, (int)hd.blk_end, d_state, nullptr, rp);
-            else launch_accumulate_vnbr(ctx->stream, map->dm, d_desc, 1, (int)hd.blk_end, d_state, nullptr, rp);
-            e = hipGetLastError();
-        }
-    } else if (e == hipSuccess) {
+        HIPCHK(ctx, hipMemcpyAsync(d_desc, &hd, sizeof(ScanDesc), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(d_state, 0, sizeof(ScanState), ctx->stream)); // done = 0; the pose is not read by a query
+        RegParams rp{};
+        rp.th = max_dist; rp.th2 = max_dist * max_dist;
+        rp.method = cfg.icp_method; rp.max_iter = 1;
+        rp.query = d_q; rp.q_out = d_out;
+        if (what == 0) launch_accumulate_grid(ctx->stream, map->dm, d_desc, 1, (int)hd.blk_end, d_state, nullptr, rp);
+        else launch_accumulate_vnbr(ctx->stream, map->dm, d_desc, 1, (int)hd.blk_end, d_state, nullptr, rp);
+    } else {
         launch_query_direct(ctx->stream, map->dm, what, d_q, n, max_dist * max_dist, d_out);
-        e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(out.data(), d_out, n * per * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    release();
-    if (e != hipSuccess) {
-        ctx->last_error = std::string("elm_map_get_correspondences: ") + hipGetErrorString(e);
-        (void)hipGetLastError();
-        return ELM_ERR_DEVICE;
-    }
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(out.data(), d_out, n * per * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // (also: the stack copy of the descriptor has been read)
     // marshalling: the reference's result vectors hold the pairs in input order (tbb::parallel_reduce joins its ranges in order)
     size_t k = 0;
     for (size_t i = 0; i < n; ++i) {
@@ -2007,39 +1996,31 @@ extern "C" int elm_align_clouds_local(elm_ctx* ctx, int method, const double* sr
                 for (int c = 0; c < 3; ++c) stage[9 * i + r * 3 + c] = c9[9 * i + c * 3 + r];
         return stage.data();
     };
-    double *d_src = nullptr, *d_tgt = nullptr, *d_cov = nullptr, *d_scov = nullptr, *d_part = nullptr, *d_out = nullptr;
-    auto release = [&]() {
-        for (void* q : {(void*)d_src, (void*)d_tgt, (void*)d_cov, (void*)d_scov, (void*)d_part, (void*)d_out})
-            if (q) (void)hipFree(q);
-    };
+    int rc;
     const size_t nb = std::max<size_t>(n, 1);
-    hipError_t e = hipMalloc((void**)&d_src, nb * 3 * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_tgt, nb * 3 * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_part, (size_t)1024 * kRadarRecord * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_out, kAlignOut * sizeof(double));
-    if (e == hipSuccess && n) e = hipMemcpy(d_src, src_local, n * 3 * sizeof(double), hipMemcpyHostToDevice);
-    if (e == hipSuccess && n) e = hipMemcpy(d_tgt, tgt_xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice);
-    if (e == hipSuccess && cov && n) {
-        e = hipMalloc((void**)&d_cov, n * 9 * sizeof(double));
-        if (e == hipSuccess) e = hipMemcpy(d_cov, transposed(tgt_cov9), n * 9 * sizeof(double), hipMemcpyHostToDevice);
-        if (e == hipSuccess && a.use_src_cov) {
-            e = hipMalloc((void**)&d_scov, n * 9 * sizeof(double));
-            if (e == hipSuccess) e = hipMemcpy(d_scov, transposed(src_cov9), n * 9 * sizeof(double), hipMemcpyHostToDevice);
+    if ((rc = dev_reserve(ctx, ctx->d_q0, nb * 3 * sizeof(double))) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_q1, nb * 3 * sizeof(double))) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_q2, (size_t)1024 * kRadarRecord * sizeof(double))) != ELM_OK) return rc;
+    if ((rc = dev_reserve(ctx, ctx->d_q3, kAlignOut * sizeof(double))) != ELM_OK) return rc;
+    double *d_src = (double*)ctx->d_q0.p, *d_tgt = (double*)ctx->d_q1.p, *d_part = (double*)ctx->d_q2.p, *d_out = (double*)ctx->d_q3.p;
+    double *d_cov = nullptr, *d_scov = nullptr;
+    if (n) HIPCHK(ctx, hipMemcpy(d_src, src_local, n * 3 * sizeof(double), hipMemcpyHostToDevice));
+    if (n) HIPCHK(ctx, hipMemcpy(d_tgt, tgt_xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice));
+    if (cov && n) {
+        if ((rc = dev_reserve(ctx, ctx->d_q4, n * 9 * sizeof(double))) != ELM_OK) return rc;
+        d_cov = (double*)ctx->d_q4.p;
+        HIPCHK(ctx, hipMemcpy(d_cov, transposed(tgt_cov9), n * 9 * sizeof(double), hipMemcpyHostToDevice));
+        if (a.use_src_cov) {
+            if ((rc = dev_reserve(ctx, ctx->d_q5, n * 9 * sizeof(double))) != ELM_OK) return rc;
+            d_scov = (double*)ctx->d_q5.p;
+            HIPCHK(ctx, hipMemcpy(d_scov, transposed(src_cov9), n * 9 * sizeof(double), hipMemcpyHostToDevice));
         }
     }
     double out[kAlignOut];
-    if (e == hipSuccess) {
-        launch_align_pairs(ctx->stream, d_src, d_tgt, d_cov, d_scov, n, a, d_part, d_out);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    release();
-    if (e != hipSuccess) {
-        ctx->last_error = std::string("elm_align_clouds_local: ") + hipGetErrorString(e);
-        (void)hipGetLastError();
-        return ELM_ERR_DEVICE;
-    }
+    launch_align_pairs(ctx->stream, d_src, d_tgt, d_cov, d_scov, n, a, d_part, d_out);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(T_out, out, 16 * sizeof(double));
     if (local_cov && method == ELM_GICP) memcpy(local_cov, out + 16, 36 * sizeof(double)); // (the reference writes local_cov in AlignCloudsLocalPointCov only)
     if (fitness_score) *fitness_score = out[52];

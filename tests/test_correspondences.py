@@ -19,7 +19,8 @@ def _queries(world, seed, n=6000):
     near0 = rng.uniform(-4.5, 4.5, size=(300, 3)) * np.array([1.0, 1.0, 1.0]) + np.array([0.0, 0.0, 30.0]) * (rng.random((300, 1)) < 0.5)
     exact = world[rng.choice(len(world), 300, replace=False)].astype(np.float64)
     tight0 = rng.uniform(-0.6, 0.6, size=(60, 3))
-    return np.concatenate([g, far, near0, tight0, exact, -np.abs(g[:200])])
+    odd = np.array([[np.nan, 0.0, 0.0], [np.inf, 1.0, 1.0], [1.0, -np.inf, 2.0], [1e300, 0.0, 0.0], [3e9, -3e9, 1.0]])  # pair with nothing
+    return np.concatenate([g, far, near0, tight0, exact, -np.abs(g[:200]), odd])
 
 
 def _set_env(monkeypatch, kernel_env):
