@@ -40,5 +40,12 @@ int main() {
     elimaloc::Matrix4d T = registration_.RunRegister(ds, local_map_, T0, cfg, ok, fitness, cov); // pcm.cpp:280-282
     registration_.TransformPoints(T, ds);                                                        // pcm.cpp:308
     std::printf("ok=%d fitness=%.4f t=(%.4f %.4f %.4f) n=%zu\n", ok, fitness, T(0, 3), T(1, 3), T(2, 3), ds.size());
-    return ok && std::fabs(T(0, 3)) < 0.02 && std::fabs(T(1, 3)) < 0.02 ? 0 : 1;
+    // one more iteration from the reference's public pieces (reg.cpp:317-372): the pairs of the registered scan, then the step around T
+    std::vector<PointStruct> src;
+    std::vector<CovStruct> tgt;
+    std::tie(src, tgt) = local_map_.GetCorrespondencesCov(ds, cfg.max_search_dist);             // reg.cpp:329
+    const elimaloc::Matrix4d step = registration_.AlignCloudsLocalVoxelCov(src, tgt, T, cfg.max_search_dist, cfg); // reg.cpp:368
+    std::printf("pairs=%zu step t=(%.4f %.4f %.4f) adjacent=%zu\n", src.size(), step(0, 3), step(1, 3), step(2, 3), local_map_.GetAdjacentVoxels(ds[0], 2).size());
+    const bool small = std::fabs(step(0, 3)) + std::fabs(step(1, 3)) + std::fabs(step(2, 3)) < 0.05;
+    return ok && std::fabs(T(0, 3)) < 0.02 && std::fabs(T(1, 3)) < 0.02 && src.size() == ds.size() && small ? 0 : 1;
 }

@@ -20,6 +20,8 @@ ap.add_argument("--seed0", type=int, default=0)
 ap.add_argument("--kernel", default="grid")
 ap.add_argument("--dump", action="store_true", help="per-iteration detail of every case (use with --cases 1)")
 ap.add_argument("--radar", type=float, default=0.0, help="share of the covariance-method cases run with use_radar_cov = 1")
+ap.add_argument("--pairs", action="store_true", help="also compare the PAIRS of the first iteration index for index (elm_map_get_correspondences: the kernel's own "
+                                                     "search with the pairs written out) with the oracle's walk -- exact, no tie-sensitive category")
 a = ap.parse_args()
 os.environ["ELM_KERNEL"] = a.kernel
 from elimaloc_amd import synth  # noqa: E402
@@ -31,6 +33,8 @@ bad = 0
 soft = 0
 singular = 0
 ill = 0
+pairs_bad = 0
+pairs_points = 0
 for case in range(a.seed0, a.seed0 + a.cases):
     rng = np.random.default_rng(50_000 + case)
     method = int(rng.integers(0, 4))
@@ -76,6 +80,27 @@ for case in range(a.seed0, a.seed0 + a.cases):
         vm.CalVoxelCovAll(); om.cal_voxel_cov_all()
     if method == 1:
         vm.CalPointCovAll(cov); om.cal_point_cov_all(cov)
+    if a.pairs:
+        try:
+            x, y, z = (scan[:, k].astype(np.float64) for k in range(3))
+            g = np.stack([((T0[r, 0] * x + T0[r, 1] * y) + T0[r, 2] * z) + T0[r, 3] for r in range(3)], 1)  # TransformPoints (reg.hpp:141-146)
+            acc, tgt, _ = om.nearest_points(g, th)
+            _, tp, si, ti = vm.GetCorrespondencePoints(g, th, indices=True)
+            pok = np.array_equal(si, np.flatnonzero(acc)) and np.array_equal(tp, tgt[acc])
+            if method in (2, 3):
+                acc, mean, _c = om.nearest_voxel(g, th)
+                _, tm, _tc, si, ti = vm.GetCorrespondencesCov(g, th, indices=True)
+                pok = pok and np.array_equal(si, np.flatnonzero(acc)) and np.array_equal(tm, mean[acc])
+                osrc, omean, _c = om.all_cov_pairs(g, th)
+                _, tm, _tc, si, ti = vm.GetCorrespondencesAllCov(g, th, indices=True)
+                pok = pok and np.array_equal(si, osrc) and np.array_equal(tm, omean)
+            pairs_points += len(g)
+        except Exception as e:  # noqa: BLE001
+            pok = False
+            print("case", case, "pairs raised", repr(e))
+        if not pok:
+            pairs_bad += 1
+            print(f"PAIR MISMATCH case {case}: method {method} voxel {voxel} max_pts {max_pts} th {th} kind {kind} n_scan {len(scan)}")
     kw = dict(max_search_dist=th, max_iteration=6, min_overlap_ratio=float(rng.choice([0.0, 0.4])), max_fitness_score=float(rng.choice([0.5, 100.0])))
     radar = method != 0 and np.random.default_rng(90_000 + case).random() < a.radar
     if radar:  # reg.hpp:186-217: non-symmetric first-iteration metric
@@ -182,5 +207,7 @@ for case in range(a.seed0, a.seed0 + a.cases):
         print(f"MISMATCH case {case}: method {method} voxel {voxel} max_pts {max_pts} th {th} kind {kind} n_scan {len(scan)} "
               f"iters {det.get('iterations')} vs {ref.get('iterations')} gate {det.get('gate')} vs {ref.get('gate')}")
 print(f"singular-metric radar cases: {singular}; singular-system cases: {ill}")
+if a.pairs:
+    print(f"pairs: {a.cases - pairs_bad}/{a.cases} cases identical pair for pair ({pairs_points} query points), {pairs_bad} mismatches")
 print(f"{a.cases - bad - soft}/{a.cases} cases agree, {soft} tie-sensitive, {bad} mismatches (kernel {a.kernel})")
-sys.exit(1 if bad else 0)
+sys.exit(1 if (bad or pairs_bad) else 0)

@@ -86,7 +86,7 @@ PY
     fuzz)
       fe=${c%%;*}; fa=""; [ "$c" != "${c#*;}" ] && fa=${c#*;}   # c = "ENV=1,ENV2=x;--extra_args" (both parts optional)
       env ${FUZZ_ENV:-} ${fe//,/ } timeout 3000 python tools/fuzz_parity.py --cases $a --seed0 $b ${fa//_/ } > $O/fuzz_$b.txt 2>&1
-      echo "fuzz $a cases from seed $b [${fe}] [${fa//_/ }]: $(tail -1 $O/fuzz_$b.txt)"; grep -E "^MISMATCH|singular|raised" $O/fuzz_$b.txt | head -8 ;;
+      echo "fuzz $a cases from seed $b [${fe}] [${fa//_/ }]: $(tail -1 $O/fuzz_$b.txt)"; grep -E "^MISMATCH|^PAIR MISMATCH|^pairs:|singular|raised" $O/fuzz_$b.txt | head -8 ;;
     profiles)
       tools/r5_profiles.sh ${a//,/ } ;;
     timeline)
