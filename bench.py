@@ -53,6 +53,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# multi-process GPU work on this pool: the host driver only supports dmabuf IPC (RCCL / hipIpc* fail with "invalid argument" otherwise).
+# Exported by the image already; set here as well so that a launcher with a scrubbed environment still forms its communicator.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 
