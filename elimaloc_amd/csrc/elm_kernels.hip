@@ -1836,15 +1836,15 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
        const DevMap m, const ScanDesc* __restrict__ scans, int batch,
                                                                             unsigned total_blocks, const ScanState* __restrict__ st,
                                                                             double* __restrict__ partials, const RegParams rp) {
-    constexpr int KS = (STATS == 1) ? 1 : 0;   // the instrumented build (work counters)
+    constexpr int kStats = (STATS == 1) ? 1 : 0;   // the instrumented build (work counters)
     constexpr bool QUERY = STATS == 2;         // elm_map_get_correspondences: the search alone, on float64 GLOBAL-frame points (RegParams::query)
-    constexpr int NV = (METHOD == ELM_P2P) ? (KS ? kP2PVals : kP2PVals - 3) : kSums;
+    constexpr int NV = (METHOD == ELM_P2P) ? (kStats ? kP2PVals : kP2PVals - 3) : kSums;
     __shared__ double s_buf[kRedPass * kBlock]; // stage 2: the queue of undecided points; afterwards the reduction's transpose buffer
     __shared__ double s_red[kSums];
     __shared__ int s_res[kBlock];
-    __shared__ int s_tst[KS ? kBlock : 1];
+    __shared__ int s_tst[kStats ? kBlock : 1];
     __shared__ float s_pz[METHOD == ELM_P2P ? kBlock : 1];  // P2P: the point's z (x and y ride in the stash's spare 8 bytes)
-    __shared__ unsigned s_st[KS ? kBlock : 1];           // instrumented builds: the walk statistics of the query voxel
+    __shared__ unsigned s_st[kStats ? kBlock : 1];           // instrumented builds: the walk statistics of the query voxel
     __shared__ unsigned s_cnt[kBlock / 64];
     const unsigned L = xcd_remap(blockIdx.x, total_blocks);
     const int s = find_scan(scans, batch, L, rp);
@@ -1922,7 +1922,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
         const GridAxis ax = grid_axis(gx, m), ay = grid_axis(gy, m), az = grid_axis(gz, m);
         // statistics of the reference's walk for this query voxel: candidates and occupied buckets among the 27
         unsigned stat = 0;
-        if (KS && TILED != 1) { // (the two-level grid keeps no dense statistics box: its work counters read 0)
+        if (kStats && TILED != 1) { // (the two-level grid keeps no dense statistics box: its work counters read 0)
             const int ux = ax.f - m.vx0, uy = ay.f - m.vy0, uz = az.f - m.vz0;
             const bool in_box = (unsigned)ux < (unsigned)m.vnx && (unsigned)uy < (unsigned)m.vny && (unsigned)uz < (unsigned)m.vnz;
             const unsigned sidx = in_box ? ((unsigned)ux * (unsigned)m.vny + (unsigned)uy) * (unsigned)m.vnz + (unsigned)uz : 0u;
@@ -2018,7 +2018,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
         asm volatile("" : "+v"(rr2), "+v"(ghx), "+v"(ghy), "+v"(ghz), "+v"(egrr), "+v"(egblk), "+v"(L1), "+v"(L2), "+v"(L3));
         stash_w(gx, gy, gz, __hiloint2double(__float_as_int(pf.y), __float_as_int(pf.x)));
         if (METHOD == ELM_P2P) s_pz[threadIdx.x] = pf.z;
-        if (KS) s_st[threadIdx.x] = stat;
+        if (kStats) s_st[threadIdx.x] = stat;
         {
             int b0v[4], b1v[4]; // (already in visiting order)
 #pragma unroll
@@ -2150,16 +2150,16 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
             const GridHardRec R = s_rec[live ? it : 0];
             int win, walked;
             grid_ball_walk<(TILED == 1 ? 1 : 0), LPI>(m, lp, R, live, rl, lane, win, walked);
-            if (KS) walked = group_sum_int<LPI>(walked);
+            if (kStats) walked = group_sum_int<LPI>(walked);
             if (rl == 0 && live) {
                 s_res[it] = win;
-                if (KS) s_tst[it] = walked;
+                if (kStats) s_tst[it] = walked;
             }
         }
         __syncthreads();
         if (hard) {
             bj = s_res[my_slot];
-            if (KS) n_tested += s_tst[my_slot];
+            if (kStats) n_tested += s_tst[my_slot];
         }
         __syncthreads(); // the queue is dead: the reduction may overwrite it
     }
@@ -2186,7 +2186,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
         float pxf, pyf;
         load_g(gx, gy, gz, pxf, pyf);
         const double px = pxf, py = pyf, pz = (METHOD == ELM_P2P) ? (double)s_pz[threadIdx.x] : 0.0; // (the pair of P2P: J = [I | -[p]x])
-        const unsigned stat = KS ? s_st[threadIdx.x] : 0u;
+        const unsigned stat = kStats ? s_st[threadIdx.x] : 0u;
         // the winner's float64 distance in the reference's arithmetic (range test, weight); no bucket at all (the search came
         // back empty): the reference's default PointStruct at the origin (vhm.cpp:37, QUIRK)
         float bx = 0.f, by = 0.f, bz = 0.f;
@@ -2210,7 +2210,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
         const double c_tested = (double)n_tested + (hard ? kFallbackUnit : 0.0); // high part: points served by stage 2
         if (METHOD == ELM_P2P) {
             if (bd2 < rp.th2) pair_p2p(v, S.Rinv, px, py, pz, ex, ey, ez, bd2, rp);
-            if (KS) { v[NV - 3] = c_cand; v[NV - 2] = c_occ; v[NV - 1] = c_tested; }
+            if (kStats) { v[NV - 3] = c_cand; v[NV - 2] = c_occ; v[NV - 1] = c_tested; }
         } else {
             // finish_point_pair: no bucket at all -> the reference's default PointStruct at the origin with covariance I (QUIRK);
             // GICP's target position is the neighbourhood MEAN of the matched point (reg.cpp:97)
@@ -2261,7 +2261,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
                 pair_sum_single<ELM_GICP>(P, mean[0] - gx, mean[1] - gy, mean[2] - gz, Ci, nf, rp);
                 P.ax = gx - S.T[12]; P.ay = gy - S.T[13]; P.az = gz - S.T[14];
             }
-            if (KS) { P.c29 = c_cand; P.c30 = c_occ; P.c31 = c_tested; }
+            if (kStats) { P.c29 = c_cand; P.c30 = c_occ; P.c31 = c_tested; }
         }
     }
     // maps with an asymmetric flagged covariance (only the instantiations that read stored inverses can meet one): the side record
@@ -2290,10 +2290,10 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
     if (METHOD == ELM_P2P) block_reduce_to_lds<NV, kRedPass>(v, s_buf, s_red);
     else
 #endif
-        block_reduce_pair_sum<kRedPass, KS ? kSums : kSums - 3>(P, s_buf, s_red);
+        block_reduce_pair_sum<kRedPass, kStats ? kSums : kSums - 3>(P, s_buf, s_red);
     if (METHOD != ELM_P2P && COMPACT != 2) asym_side_store(P.A, P.ax, P.ay, P.az, L, rp, s_buf, s_asym, s_hitw);
     const int tk = (int)threadIdx.x;
-    publish_and_reduce((tk < kSums && (KS || tk < kSums - 3)) ? ((METHOD == ELM_P2P) ? p2p_expand(s_red, tk) : s_red[tk]) : 0.0, L, s, sd.blk_begin,
+    publish_and_reduce((tk < kSums && (kStats || tk < kSums - 3)) ? ((METHOD == ELM_P2P) ? p2p_expand(s_red, tk) : s_red[tk]) : 0.0, L, s, sd.blk_begin,
                        sd.blk_end, partials, rp, s_buf);
 }
 
@@ -2454,7 +2454,7 @@ template <int METHOD, int COMPACT, int STATS, int FACES>
 __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
                                                             unsigned total_blocks, const ScanState* __restrict__ st,
                                                             double* __restrict__ partials, const RegParams rp) {
-    constexpr int KS = (STATS == 1) ? 1 : 0;
+    constexpr int kStats = (STATS == 1) ? 1 : 0;
     constexpr bool QUERY = STATS == 2; // elm_map_get_correspondences (GetCorrespondencesCov / GetCorrespondencesAllCov): RegParams::query in, q_out out
     __shared__ double s_buf[kRedPass * kBlock];
     __shared__ double s_red[kSums];
@@ -2603,7 +2603,7 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
                 P.ax = gx - S.T[12]; P.ay = gy - S.T[13]; P.az = gz - S.T[14];
             }
             (void)px; (void)py; (void)pz;
-            if (KS) { P.c29 = (double)cnt; P.c30 = (double)cnt; P.c31 = (double)cnt; }
+            if (kStats) { P.c29 = (double)cnt; P.c30 = (double)cnt; P.c31 = (double)cnt; }
         } else {
             // AVGICP, GetCorrespondencesAllCov (vhm.cpp:153-206): every existing FACE neighbour (and the voxel itself) whose
             // mean is within range is a pair of its own.  The records carry the neighbour's position code (dx+1)*9+(dy+1)*3+
@@ -2719,7 +2719,7 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
             if (Q.n > 0.0) { // (a point without a pair -- a NaN / infinite return among them -- contributes zeros, not 0 x NaN)
                 P.ax = gx - S.T[12]; P.ay = gy - S.T[13]; P.az = gz - S.T[14];
             }
-            if (KS && FACES != 3) { P.c29 = n_pairs; P.c30 = n_pairs; P.c31 = n_pairs; } // (the fused walk has counted every record)
+            if (kStats && FACES != 3) { P.c29 = n_pairs; P.c30 = n_pairs; P.c31 = n_pairs; } // (the fused walk has counted every record)
         }
     }
     if (QUERY) return; // (uniform) the pairs are written, there are no sums
@@ -2730,7 +2730,7 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
     __shared__ unsigned s_hitw[kBlock / 64];
     constexpr bool kAsymHere = COMPACT != 2 && FACES != 2 && FACES != 4;
     if (kAsymHere) asym_mark(P.A, rp, s_hitw);
-    block_reduce_pair_sum<kRedPass, KS ? kSums : kSums - 3>(P, s_buf, s_red);
+    block_reduce_pair_sum<kRedPass, kStats ? kSums : kSums - 3>(P, s_buf, s_red);
     if (FACES == 4) {
         if (rp.asym && threadIdx.x < (unsigned)kAsymSums) rp.asym[(size_t)L * kAsymSums + threadIdx.x] = 0.0;
     } else if (kAsymHere) {
@@ -2740,7 +2740,7 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
         if (threadIdx.x < (unsigned)kSums - 3u) partials[(size_t)L * kSums + threadIdx.x] += s_red[threadIdx.x];
         return;
     }
-    publish_and_reduce((threadIdx.x < (KS ? kSums : kSums - 3)) ? s_red[threadIdx.x] : 0.0, L, s, sd.blk_begin, sd.blk_end, partials, rp, s_buf);
+    publish_and_reduce((threadIdx.x < (kStats ? kSums : kSums - 3)) ? s_red[threadIdx.x] : 0.0, L, s, sd.blk_begin, sd.blk_end, partials, rp, s_buf);
 }
 
 __global__ __launch_bounds__(256) void k_vnbr_fill(const DevMap m, const int32_t* __restrict__ qkeys, unsigned n_q,
