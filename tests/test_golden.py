@@ -90,3 +90,59 @@ def test_gpu_map_deskew_c1_golden(ctx):
     imu = np.concatenate([G["dk_imu_t"][:, None], G["dk_imu_w"]], axis=1)
     ok, out = dk.DeskewPointCloud(G["dk_xyz"], G["dk_time"], float(G["dk_stamp"][0]), imu, G["dk_odom"])
     assert ok and np.abs(out - G["dk_out"]).max() <= 2e-6
+
+
+# ---- the pairs and steps of the reference's public calls (tests/golden/golden_r05_pairs.npz, made by make_golden_pairs.py) ----
+P = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_r05_pairs.npz"))
+
+
+def test_oracle_reproduces_pair_golden(oracle):
+    m = oracle.Map(1.0, 30)
+    m.add_points(G["world"])
+    m.cal_voxel_cov_all(3)
+    g = P["queries"]
+    acc, tgt, _ = m.nearest_points(g, 5.0, 3)
+    assert np.array_equal(np.flatnonzero(acc), P["points_src"]) and np.array_equal(tgt[acc], P["points_tgt"])
+    acc, mean, cov = m.nearest_voxel(g, 5.0, 3)
+    assert np.array_equal(np.flatnonzero(acc), P["cov_src"]) and np.array_equal(mean[acc], P["cov_mean"]) and np.array_equal(cov[acc], P["cov_cov"])
+    src, amean, acov = m.all_cov_pairs(g, 5.0)
+    assert np.array_equal(src, P["allcov_src"]) and np.array_equal(amean, P["allcov_mean"])
+    local = np.concatenate([G["scan"].astype(np.float64), np.zeros((3, 3))])
+    r = oracle.align_clouds_local(0, local[P["points_src"]], P["points_tgt"], None, G["T0"], 5.0, oracle.default_config(0))
+    assert np.array_equal(r["T"], P["step_p2p"]) and r["fitness"] == P["fit_p2p"][0]
+    r = oracle.align_clouds_local(1, local[P["points_src"]], P["gicp_mean"], P["gicp_cov"], G["T0"], 5.0, oracle.default_config(1))
+    assert np.array_equal(r["T"], P["step_gicp"]) and np.array_equal(r["local_cov"], P["cov_gicp"])
+    r = oracle.align_clouds_local(3, local[P["allcov_src"]], P["allcov_mean"], P["allcov_cov"], G["T0"], 5.0, oracle.default_config(3))
+    assert np.array_equal(r["T"], P["step_avgicp"])
+
+
+@pytest.mark.gpu
+def test_gpu_matches_pair_golden(ctx):
+    """The product's correspondence and step calls against the committed vectors, without the oracle: pairs index for index and bit for
+    bit, steps to 1e-10."""
+    from elimaloc_amd.registration import VoxelHashMap, Registration, RegistrationConfig, IcpMethod
+    vm = VoxelHashMap(1.0, 30, ctx)
+    vm.AddPoints(G["world"])
+    vm.CalVoxelCovAll()
+    g = P["queries"]
+    _, tp, si, _ = vm.GetCorrespondencePoints(g, 5.0, indices=True)
+    assert np.array_equal(si, P["points_src"]) and np.array_equal(tp, P["points_tgt"])
+    _, tm, tc, si, _ = vm.GetCorrespondencesCov(g, 5.0, indices=True)
+    assert np.array_equal(si, P["cov_src"]) and np.array_equal(tm, P["cov_mean"])
+    np.testing.assert_allclose(tc, P["cov_cov"], rtol=1e-9, atol=1e-12)
+    _, tm, tc, si, _ = vm.GetCorrespondencesAllCov(g, 5.0, indices=True)
+    assert np.array_equal(si, P["allcov_src"]) and np.array_equal(tm, P["allcov_mean"])
+    local = np.concatenate([G["scan"].astype(np.float64), np.zeros((3, 3))])
+    T0 = G["T0"]
+    for method, key, src, tgt, cov in ((0, "p2p", P["points_src"], P["points_tgt"], None), (1, "gicp", P["points_src"], P["gicp_mean"], P["gicp_cov"]),
+                                       (2, "vgicp", P["cov_src"], P["cov_mean"], P["cov_cov"]), (3, "avgicp", P["allcov_src"], P["allcov_mean"], P["allcov_cov"])):
+        reg = Registration(RegistrationConfig(icp_method=IcpMethod(method)), ctx)
+        if method == 0:
+            step = reg.AlignCloudsLocal(local[src], tgt, T0, 5.0)
+        elif method == 1:
+            step, lc = reg.AlignCloudsLocalPointCov(local[src], tgt, cov, T0, 5.0)
+            np.testing.assert_allclose(lc, P["cov_gicp"], rtol=1e-7, atol=1e-12)
+        else:
+            step = reg.AlignCloudsLocalVoxelCov(local[src], tgt, cov, T0, 5.0)
+        np.testing.assert_allclose(step, P[f"step_{key}"], rtol=0, atol=1e-10)
+        assert abs(reg.d_fitness_score_ - P[f"fit_{key}"][0]) <= 1e-9 * abs(P[f"fit_{key}"][0])
