@@ -132,7 +132,7 @@ EXPORTS = [
     "elm_scan_size", "elm_scan_download", "elm_register", "elm_format_register_log", "elm_register_batch", "elm_register_stream", "elm_register_stream_host", "elm_host_alloc", "elm_host_free", "elm_ctx_measure_h2d", "elm_register_batch_enqueue",
     "elm_register_batch_finish", "elm_deskew", "elm_deskew_downsample", "elm_deskew_prepare", "elm_comm_get_unique_id", "elm_comm_init",
     "elm_comm_destroy", "elm_comm_info", "elm_comm_set_hook", "elm_filter_points_by_distance", "elm_voxel_downsample",
-    "elm_get_interpolated_pose", "elm_shape_odom_covariance",
+    "elm_get_interpolated_pose", "elm_shape_odom_covariance", "elm_cal_frame_point_cov",
     "elm_ekf_config_default", "elm_ekf_create", "elm_ekf_destroy", "elm_ekf_predict_imu", "elm_ekf_predict", "elm_ekf_update_can", "elm_gps_project", "elm_ekf_update_navsatfix",
     "elm_ekf_update_pose", "elm_ekf_update_pcm_odom", "elm_ekf_get_state", "elm_ekf_publish",
     "elm_ini_load", "elm_ini_destroy", "elm_ini_get_string", "elm_ini_get_int", "elm_ini_get_bool", "elm_ini_get_double",
@@ -231,6 +231,7 @@ def lib():
     L.elm_map_download_points.argtypes = [vp, dp, dp, dp, C.c_size_t]
     L.elm_map_download_voxels.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp, dp, C.c_size_t]
     L.elm_map_find_ground_height.argtypes = [vp, C.c_double, C.c_double, dp, ip]
+    L.elm_cal_frame_point_cov.argtypes = [dp, C.c_size_t, C.c_double, C.c_double, C.c_double, dp]
     L.elm_align_clouds_local.argtypes = [vp, C.c_int, dp, dp, dp, dp, C.c_size_t, dp, C.c_double, C.POINTER(RegConfig), dp, dp, dp]
     L.elm_map_get_correspondences.argtypes = [vp, vp, C.c_int, dp, C.c_size_t, C.c_double, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.c_size_t, C.POINTER(C.c_size_t)]
     L.elm_scan_upload.argtypes = [vp, fp, C.c_size_t, C.c_size_t, C.POINTER(vp)]

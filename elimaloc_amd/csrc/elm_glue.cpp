@@ -14,6 +14,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include "elm_la.hpp"
+
 #include "../../include/elimaloc_hip.h"
 #include "elm_hostapi.hpp"
 
@@ -281,6 +283,19 @@ extern "C" int elm_get_interpolated_pose(const double* odom14, size_t n_odom, do
     T_out[3] = T_out[7] = T_out[11] = 0.f;
     T_out[15] = 1.f;
     *ok = 1;
+    return ELM_OK;
+}
+
+// Registration::CalFramePointCov (reg.hpp:211-217; called at reg.cpp:302-305 under use_radar_cov on the points in the MAP frame under the
+// initial guess): per point the R S term of CalPointCov.  Plain host arithmetic, the function the radar kernel itself evaluates.
+extern "C" int elm_cal_frame_point_cov(const double* xyz, size_t n, double range_var_m, double azim_var_deg, double ele_var_deg, double* cov9) {
+    if (n && (!xyz || !cov9)) return ELM_ERR_INVALID;
+    for (size_t i = 0; i < n; ++i) {
+        double C[9];
+        elm::radar_point_cov(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], range_var_m, azim_var_deg, ele_var_deg, C);
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) cov9[9 * i + c * 3 + r] = C[r * 3 + c]; // column-major out
+    }
     return ELM_OK;
 }
 

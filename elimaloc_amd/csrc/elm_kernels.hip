@@ -219,24 +219,7 @@ __device__ __forceinline__ void add_pair(double* acc, const double* Rinv, const 
 constexpr int kRadarAcc = 47;
 constexpr int kRadarSums = 64; // doubles per partial record of the radar kernel
 __device__ __forceinline__ void radar_source_cov(double gx, double gy, double gz, const RegParams& rp, double* Cs) {
-    const double kPi = 3.14159265358979323846;
-    const double dist = sqrt(gx * gx + gy * gy);
-    const double s_x = rp.radar_var[0];
-    const double s_y = fmax(0.1, dist * sin(rp.radar_var[1] / 180 * kPi));
-    const double s_z = fmax(0.1, dist * sin(rp.radar_var[2] / 180 * kPi));
-    const double ele = atan2(gz, dist), azi = atan2(gy, gx);
-    // AngleAxisd(azi, UnitZ) * AngleAxisd(ele, UnitY) -> Matrix3d: quaternion product, then Quaternion::toRotationMatrix
-    const double yw = cos(azi / 2.0), yz = sin(azi / 2.0), pw = cos(ele / 2.0), py = sin(ele / 2.0);
-    const double w = yw * pw, x = -(yz * py), y = yw * py, z = yz * pw;
-    const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
-    const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
-    const double R[9] = {1.0 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1.0 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1.0 - (txx + tyy)};
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        Cs[r * 3 + 0] = R[r * 3 + 0] * s_x;
-        Cs[r * 3 + 1] = R[r * 3 + 1] * s_y;
-        Cs[r * 3 + 2] = R[r * 3 + 2] * s_z;
-    }
+    radar_point_cov(gx, gy, gz, rp.radar_var[0], rp.radar_var[1], rp.radar_var[2], Cs); // (elm_la.hpp: the same code serves elm_cal_frame_point_cov)
 }
 // p = source point in the sensor frame, (mx, my, mz) = target position and C = target covariance (row-major) in the map frame,
 // Cs = the source point's covariance term, nfit = GICP's plane normal in the map frame

@@ -3,7 +3,7 @@
 #pragma once
 #include <math.h>
 
-#if defined(__HIPCC__)
+#if defined(__HIPCC__) && defined(__forceinline__) // (a host-only translation unit that never included the HIP runtime header takes the plain form)
 #define ELM_HD __host__ __device__ __forceinline__
 #else
 #define ELM_HD inline
@@ -264,6 +264,29 @@ ELM_HD void plane_regularize(const double cov[9], double cov_out[9], double norm
     normal[0] = ev[2];
     normal[1] = ev[5];
     normal[2] = ev[8];
+}
+
+// Registration::CalPointCov (reg.hpp:186-209): the "covariance" the reference attaches to a source point under use_radar_cov -- R S with
+// R = AngleAxisd(azimuth, UnitZ) * AngleAxisd(elevation, UnitY) of the point's position (quaternion product, then
+// Quaternion::toRotationMatrix) and S = diag(range spread, max(0.1, d sin(azimuth spread)), max(0.1, d sin(elevation spread))), d the
+// horizontal range: a product, not R S R^T -- the matrix is not symmetric.  Row-major.
+ELM_HD void radar_point_cov(double gx, double gy, double gz, double range_var_m, double azim_var_deg, double ele_var_deg, double* Cs) {
+    const double kPi = 3.14159265358979323846;
+    const double dist = sqrt(gx * gx + gy * gy);
+    const double s_x = range_var_m;
+    const double s_y = fmax(0.1, dist * sin(azim_var_deg / 180 * kPi));
+    const double s_z = fmax(0.1, dist * sin(ele_var_deg / 180 * kPi));
+    const double ele = atan2(gz, dist), azi = atan2(gy, gx);
+    const double yw = cos(azi / 2.0), yz = sin(azi / 2.0), pw = cos(ele / 2.0), py = sin(ele / 2.0);
+    const double w = yw * pw, x = -(yz * py), y = yw * py, z = yz * pw;
+    const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    const double R[9] = {1.0 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1.0 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1.0 - (txx + tyy)};
+    for (int r = 0; r < 3; ++r) {
+        Cs[r * 3 + 0] = R[r * 3 + 0] * s_x;
+        Cs[r * 3 + 1] = R[r * 3 + 1] * s_y;
+        Cs[r * 3 + 2] = R[r * 3 + 2] * s_z;
+    }
 }
 
 // ---- 6x6 ------------------------------------------------------------------------------------------

@@ -422,6 +422,18 @@ class Registration:
         self.d_fitness_score_ = fit.value
         return Tout.reshape(4, 4).T.copy(), cov.reshape(6, 6)
 
+    @staticmethod
+    def CalFramePointCov(points, range_var_m, azim_var_deg, ele_var_deg):
+        """reg.hpp:186-217: the covariance term R S of every point (from its position: the MAP frame under the initial guess at the
+        reference's call site, reg.cpp:302-305) -> [n, 3, 3], not symmetric.  Host arithmetic (elm_cal_frame_point_cov)."""
+        q = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        n = q.shape[0]
+        cov = np.empty((max(n, 1), 9))
+        rc = _lib.lib().elm_cal_frame_point_cov(_dp(q), n, float(range_var_m), float(azim_var_deg), float(ele_var_deg), _dp(cov))
+        if rc != 0:
+            raise ElmError("elm_cal_frame_point_cov failed")
+        return cov[:n].reshape(n, 3, 3).transpose(0, 2, 1).copy()
+
     def AlignCloudsLocal(self, source_local, target_pose, last_icp_pose, trans_th, m_config=None):
         """reg.cpp:15-66 on explicit pairs (source PointStruct::local, target PointStruct::pose) -> the step as a 4x4."""
         return self._align(IcpMethod.P2P, source_local, target_pose, None, last_icp_pose, trans_th, m_config)[0]

@@ -119,6 +119,34 @@ struct Registration {
         return Align(ELM_VGICP, source_global, nullptr, &target_cov_global, nullptr, last_icp_pose, trans_th, m_config);
     }
 
+    // reg.hpp:186-217: the covariance term R S the reference attaches to the source points under use_radar_cov (called on the points in
+    // the map frame under the initial guess, reg.cpp:302-305); RunRegister evaluates the same function inside its radar kernel
+    inline PointStruct CalPointCov(const PointStruct point, double range_var_m, double azim_var_deg, double ele_var_deg) {
+        PointStruct cov_point = point;
+        const double xyz[3] = {point.pose(0), point.pose(1), point.pose(2)};
+        double c9[9];
+        elimaloc::check(elm_cal_frame_point_cov(xyz, 1, range_var_m, azim_var_deg, ele_var_deg, c9), VoxelHashMap::ctx(), "CalPointCov");
+        for (int k = 0; k < 9; ++k) cov_point.covariance.cov.data()[k] = c9[k]; // both column-major
+        return cov_point;
+    }
+    inline void CalFramePointCov(std::vector<PointStruct>& points, double range_var_m, double azim_var_deg, double ele_var_deg) {
+        std::vector<double> xyz(3 * points.size()), c9(9 * points.size());
+        for (size_t i = 0; i < points.size(); ++i)
+            for (int k = 0; k < 3; ++k) xyz[3 * i + k] = points[i].pose(k);
+        elimaloc::check(elm_cal_frame_point_cov(xyz.data(), points.size(), range_var_m, azim_var_deg, ele_var_deg, c9.data()), VoxelHashMap::ctx(),
+                        "CalFramePointCov");
+        for (size_t i = 0; i < points.size(); ++i)
+            for (int k = 0; k < 9; ++k) points[i].covariance.cov.data()[k] = c9[9 * i + k];
+    }
+    inline double square(double x) { return x * x; } // reg.hpp:219
+    inline elimaloc::Matrix3d vectorToSkewSymmetricMatrix(const elimaloc::Vector3d& vec) { // reg.hpp:221-225
+        elimaloc::Matrix3d skew_symmetric = elimaloc::Matrix3d::Identity();
+        skew_symmetric(0, 0) = 0.0; skew_symmetric(0, 1) = -vec(2); skew_symmetric(0, 2) = vec(1);
+        skew_symmetric(1, 0) = vec(2); skew_symmetric(1, 1) = 0.0; skew_symmetric(1, 2) = -vec(0);
+        skew_symmetric(2, 0) = -vec(1); skew_symmetric(2, 1) = vec(0); skew_symmetric(2, 2) = 0.0;
+        return skew_symmetric;
+    }
+
     // reg.hpp:126-134: in place (the node's debug clouds, pcm.cpp:308-313); every other field is kept
     inline void TransformPoints(const elimaloc::Matrix4d& T, std::vector<PointStruct>& points) {
         for (auto& point : points) Apply(T, point.pose);

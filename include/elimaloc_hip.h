@@ -334,6 +334,12 @@ int elm_voxel_downsample(const float* xyz, size_t n, double voxel_size, int64_t*
 /* GetInterpolatedPose (pcm.cpp:933-1045): odom rows as in elm_deskew_prepare; T_out = Eigen::Affine3f matrix,
  * column-major; *ok = 0 when no odometry at or before the time exists. */
 int elm_get_interpolated_pose(const double* odom14, size_t n_odom, double d_cur_time, float T_out[16], int* ok);
+/* Registration::CalFramePointCov / CalPointCov (registration.hpp:186-217; called at registration.cpp:302-305 under use_radar_cov): the
+ * covariance term R S of every source point from its position (map frame under the initial guess at the call site) and the range /
+ * azimuth / elevation spreads.  cov9: n column-major 3x3 (not symmetric).  Host arithmetic; elm_register evaluates the same function
+ * inside its radar kernel. */
+int elm_cal_frame_point_cov(const double* xyz, size_t n, double range_var_m, double azim_var_deg, double ele_var_deg, double* cov9);
+
 /* Covariance of the published odometry (PublishPcmOdom pcm.cpp:1082-1098, NormalizeCovariance pcm.hpp:248-268):
  * cov_out is the row-major 6x6 of nav_msgs/Odometry.pose.covariance. */
 int elm_shape_odom_covariance(const double local_cov[36], const double icp_ego_pose[16], double d_icp_pose_std_m,

@@ -1286,6 +1286,14 @@ void orc_align_clouds_local(int method, const double* src_local, const double* t
     if (JTr_out) std::memcpy(JTr_out, o.JTr, 6 * sizeof(double));
 }
 
+// Registration::CalFramePointCov (reg.hpp:211-217) as a call of its own: cov9 = n column-major 3x3
+void orc_cal_frame_point_cov(const double* xyz, size_t n, double range_var_m, double azim_var_deg, double ele_var_deg, double* cov9) {
+    std::vector<PointStruct> pts(n);
+    for (size_t i = 0; i < n; ++i) pts[i].pose = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+    CalFramePointCov(pts, range_var_m, azim_var_deg, ele_var_deg);
+    for (size_t i = 0; i < n; ++i) std::memcpy(cov9 + 9 * i, pts[i].covariance.cov.m, 9 * sizeof(double));
+}
+
 // RunRegister (reg.cpp:274-418)
 void orc_register(const orc_map* mp, const float* scan_xyz, size_t n, const double T0[16], const orc_config* cfgp,
                   orc_result* out) {

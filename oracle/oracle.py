@@ -286,6 +286,18 @@ def align_clouds_local(method, src_local, tgt_xyz, tgt_cov, last_icp_pose, trans
     return dict(T=Tout.reshape(4, 4).T.copy(), local_cov=cov.reshape(6, 6).T.copy(), fitness=fit.value, JTJ=JTJ.reshape(6, 6).T.copy(), JTr=JTr)
 
 
+def cal_frame_point_cov(xyz, range_var_m, azim_var_deg, ele_var_deg):
+    """Registration::CalFramePointCov (reg.hpp:186-217): the R S term per point -> [n, 3, 3]."""
+    q = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+    n = q.shape[0]
+    cov = np.empty((max(n, 1), 9))
+    f = lib().orc_cal_frame_point_cov
+    f.restype = None
+    f.argtypes = [C.POINTER(C.c_double), C.c_size_t, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double)]
+    f(_dp(q), n, float(range_var_m), float(azim_var_deg), float(ele_var_deg), _dp(cov))
+    return cov[:n].reshape(n, 3, 3).transpose(0, 2, 1).copy()
+
+
 def voxel_downsample(xyz, voxel_size):
     xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
     keep = np.empty(xyz.shape[0], np.int64)

@@ -242,6 +242,11 @@ int main() {
         Eigen::Matrix6d lc6;
         const Eigen::Matrix4d step_g = reg2.AlignCloudsLocalPointCov(src_p, tgt_p, lc6, last, 5.0, node.registration_config_); // (default covariances: runs, not judged)
         (void)step_g;
+        std::vector<PointStruct> radar_pts(src_p.begin(), src_p.begin() + 4);
+        reg2.CalFramePointCov(radar_pts, 0.5, 2.0, 1.0); // reg.cpp:302-305
+        const PointStruct one = reg2.CalPointCov(src_p[0], 0.5, 2.0, 1.0);
+        const Eigen::Matrix3d sk = reg2.vectorToSkewSymmetricMatrix(src_p[0].pose);
+        if (one.covariance.cov(0, 0) != radar_pts[0].covariance.cov(0, 0) || sk(0, 1) != -src_p[0].pose.z() || reg2.square(3.0) != 9.0) return 7;
         std::printf("steps: p2p t = (%.4f %.4f %.4f) fitness %.4f, voxel-cov t = (%.4f %.4f %.4f)\n", step_p(0, 3), step_p(1, 3), step_p(2, 3), fit_p,
                     step_c(0, 3), step_c(1, 3), step_c(2, 3));
         if (std::fabs(step_p(0, 3)) + std::fabs(step_p(1, 3)) + std::fabs(step_p(2, 3)) > 0.15 || !(fit_p >= 0.0 && fit_p < 0.3) ||

@@ -203,6 +203,53 @@ def test_align_clouds_local_on_explicit_pairs(oracle, method):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("method", [1, 2])
+def test_run_register_with_radar_cov_equals_its_public_pieces(oracle, method):
+    """use_radar_cov = 1 (reg.cpp:302-305, 109-111, 188-190): CalFramePointCov on the points under the initial guess feeds the FIRST iteration's
+    metric; the re-transform at the end of every iteration leaves the default identity covariance for the later ones."""
+    from elimaloc_amd.registration import Context, VoxelHashMap, Registration, RegistrationConfig, IcpMethod
+    m = IcpMethod(method)
+    world = synth.make_world(60000, seed=87)
+    scan, Tt = synth.make_scan(world, 3000, seed=88)
+    T0 = synth.perturb(Tt, seed=89, max_trans=0.3, max_rot_deg=1.0)
+    rv, av, ev = 0.5, 2.0, 1.0
+    c = Context(0)
+    try:
+        vm = VoxelHashMap(1.0, 30, c)
+        vm.AddPoints(world)
+        if m == IcpMethod.GICP:
+            vm.CalPointCovAll(0.4)
+            _, pcov, pmean = vm.Pointcloud(with_cov=True)
+        else:
+            vm.CalVoxelCovAll()
+        cfg = RegistrationConfig(icp_method=m, use_radar_cov=1, range_variance_m=rv, azimuth_variance_deg=av, elevation_variance_deg=ev)
+        reg = Registration(cfg, c)
+        *_, det = reg.RunRegister(scan, vm, T0, trace=True)
+        assert det["iterations"] >= 2
+        th = cfg.max_search_dist
+        local = scan.astype(np.float64)
+        T = np.array(T0, dtype=np.float64)
+        for it in range(det["iterations"]):
+            x, y, z = local[:, 0], local[:, 1], local[:, 2]
+            g = np.stack([((T[r, 0] * x + T[r, 1] * y) + T[r, 2] * z) + T[r, 3] for r in range(3)], 1)
+            scov = Registration.CalFramePointCov(g, rv, av, ev) if it == 0 else np.broadcast_to(np.eye(3), (len(g), 3, 3))
+            if method == 1:
+                _, tp, si, ti = vm.GetCorrespondencePoints(g, th, indices=True)
+                ok = ti >= 0
+                tm = np.where(ok[:, None], pmean[np.maximum(ti, 0)], 0.0)
+                tc = np.where(ok[:, None, None], pcov[np.maximum(ti, 0)], np.eye(3))
+                step, _ = reg.AlignCloudsLocalPointCov(local[si], tm, tc, T, th, source_cov=scov[si])
+            else:
+                _, tm, tc, si, ti = vm.GetCorrespondencesCov(g, th, indices=True)
+                step = reg.AlignCloudsLocalVoxelCov(local[si], tm, tc, T, th, source_cov=scov[si])
+            assert len(si) == int(det["iters"][it]["n_corr"])
+            T = T @ step
+            np.testing.assert_allclose(T, det["iters"][it]["T"], rtol=0, atol=5e-9)
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("method", [0, 1, 2, 3])
 def test_run_register_equals_its_public_pieces(oracle, method):
     """RunRegister (one fused kernel per iteration) against the reference's own loop built from the public calls (reg.cpp:317-378):
@@ -250,3 +297,16 @@ def test_run_register_equals_its_public_pieces(oracle, method):
         assert abs(reg.d_fitness_score_ - det["d_fitness"]) <= 1e-8 * max(abs(det["d_fitness"]), 1e-9)
     finally:
         c.close()
+
+
+def test_cal_frame_point_cov_matches_the_oracle(oracle):
+    """Registration::CalFramePointCov (reg.hpp:186-217): R S per point, not symmetric; points on the z axis and at the origin included."""
+    from elimaloc_amd.registration import Registration
+    rng = np.random.default_rng(8)
+    p = rng.uniform(-60, 60, (3000, 3))
+    p[:4] = [[0, 0, 0], [0, 0, 5], [-3, 0, 0], [1e-9, -1e-9, 2]]
+    for rv, av, ev in ((0.5, 2.0, 1.0), (0.05, 0.4, 0.4), (1.0, 0.0, 30.0)):
+        a = oracle.cal_frame_point_cov(p, rv, av, ev)
+        b = Registration.CalFramePointCov(p, rv, av, ev)
+        np.testing.assert_allclose(b, a, rtol=0, atol=2e-15 * max(1.0, np.abs(a).max()))
+        assert np.abs(a - a.transpose(0, 2, 1)).max() > 0.1  # R S, not R S R^T
