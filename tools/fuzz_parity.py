@@ -113,7 +113,7 @@ for case in range(a.seed0, a.seed0 + a.cases):
         ok = det["iterations"] == ref["iterations"] and det["is_success"] == ref["is_success"] and det["gate"] == ref["gate"]
         for k, (g, r) in enumerate(zip(det["iters"], ref["iters"])):
             ok = ok and g["n_corr"] == r["n_corr"]
-            if not (ref["gate"] == 2 and g is det["iters"][ref["iterations"] - 1]):
+            if not (ref["gate"] == 2 and k == ref["iterations"] - 1):
                 scale = max(np.abs(r["JTJ"]).max(), 1e-300)
                 # iteration 0 sees identical inputs; later ones see poses that differ by the rounding of the earlier solves, which an
                 # ill-conditioned problem (few points per voxel) amplifies ~30x per iteration (case 7405: 1.6e-14 -> 1.7e-9 in six
