@@ -35,5 +35,5 @@ def _cdll(path, *a, **k):
 ctypes.CDLL = _cdll
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(root)
-sys.exit(pytest.main(["tests/test_oracle.py", "tests/test_golden.py", "tests/test_ekf.py", "tests/test_formats.py", "tests/test_glue.py",
+sys.exit(pytest.main(["tests/test_oracle.py", "tests/test_golden.py", "tests/test_ekf.py", "tests/test_formats.py", "tests/test_glue.py", "tests/test_correspondences.py",
                       "-q", "-x", "-rs", "-m", "not gpu", "-p", "no:cacheprovider"] + sys.argv[1:]))
