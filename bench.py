@@ -425,6 +425,48 @@ def host_cpu_info():
     return ncpu, phys, cpu_model
 
 
+def c_caller_numbers(timeout_s=120):
+    """What a plain-C caller of the C ABI sees (no Python): examples/register_latency.c (one RunRegister-equivalent call: pageable /
+    page-locked / resident) and examples/stream_harness.c at config-5 size (node callback + EKF update per scan).  Compiled with gcc into a
+    temporary directory and run as child processes AFTER every timed region; any failure is reported, never raised."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    out = {"what": "examples/register_latency.c and examples/stream_harness.c: child processes, plain C, 131 072-point scans against a 9 M-point map "
+                   "(ground lattice + wall; these registrations take 2 iterations)"}
+    if not shutil.which("gcc"):
+        out["error"] = "no gcc"
+        return out
+    libdir = os.path.join(ROOT, "elimaloc_amd")
+    d = tempfile.mkdtemp(prefix="elm_c_")
+    try:
+        for src, key, env in (("register_latency.c", "register", {"ELM_LAT_CALLS": "100"}),
+                              ("stream_harness.c", "config5", {"ELM_HARNESS_GRID": "3000", "ELM_HARNESS_SCAN": "131072", "ELM_HARNESS_SCANS": "60"})):
+            exe = os.path.join(d, src[:-2])
+            try:
+                subprocess.check_call(["gcc", "-O2", "-std=c11", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", src), "-L", libdir,
+                                       "-lelimaloc_hip", "-lm", "-Wl,-rpath," + libdir, "-o", exe], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=60)
+                r = subprocess.run([exe], capture_output=True, text=True, timeout=timeout_s, env=dict(os.environ, **env))
+                if key == "register":
+                    got = {}
+                    for line in r.stdout.splitlines():
+                        m = re.match(r"(elm_register\w*), (.*?)\s+median ([0-9.]+) ms\s+p10 ([0-9.]+)\s+p90 ([0-9.]+)\s+\((\d+) calls, ([0-9.]+) iterations", line)
+                        if m:
+                            got[(m.group(1) + " " + m.group(2)).strip()] = {"ms_median": float(m.group(3)), "ms_p10": float(m.group(4)), "ms_p90": float(m.group(5)),
+                                                                            "calls": int(m.group(6)), "iterations_mean": float(m.group(7))}
+                    out[key] = got if got else {"error": (r.stdout + r.stderr)[-300:], "returncode": r.returncode}
+                else:
+                    m = re.search(r"per scan \(.*?\): mean ([0-9.]+) ms\s+median ([0-9.]+) ms\s+max ([0-9.]+) ms\s+\(n = (\d+)\)", r.stdout)
+                    out[key] = ({"ms_per_scan_mean": float(m.group(1)), "ms_per_scan_median": float(m.group(2)), "ms_per_scan_max": float(m.group(3)), "scans": int(m.group(4)),
+                                 "returncode": r.returncode} if m else {"error": (r.stdout + r.stderr)[-300:], "returncode": r.returncode})
+            except Exception as e:  # noqa: BLE001
+                out[key] = {"error": repr(e)}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1176,6 +1218,11 @@ def main():
             configs["C4_shard"] = leg
             del scans4, vm4, world4, g4
         result["configs"] = configs
+        if legs and want_cpu and args.world == "lattice" and not os.environ.get("ELM_BENCH_NO_C_CALLER"):
+            # the drop-in numbers as a C caller sees them (child processes, after every timed region of this one)
+            tcc = time.time()
+            result["c_caller"] = c_caller_numbers()
+            result["c_caller"]["wall_s"] = time.time() - tcc
     result["process_wall_s"] = time.time() - t_process
 
     assert_fractions(result)
