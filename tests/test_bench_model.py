@@ -81,3 +81,15 @@ def test_default_operating_point_is_the_same_at_every_n():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "args.batch = 4096  # the SAME per-GPU operating point at every N" in src
     assert "4096 if world_size == 1 else 1024" not in src
+
+
+def test_c_caller_numbers_never_raise():
+    """bench.py's c_caller object: compiles the two plain-C examples and runs them as child processes; without a GPU (here) both exit with
+    an error -- reported inside the object, never raised (an auxiliary leg must not cost the line its timed numbers)."""
+    import bench
+    out = bench.c_caller_numbers(timeout_s=30)
+    assert isinstance(out, dict) and "what" in out
+    for key in ("register", "config5"):
+        assert key in out or "error" in out
+        if key in out:
+            assert isinstance(out[key], dict)
