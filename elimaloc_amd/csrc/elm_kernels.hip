@@ -1588,6 +1588,10 @@ __device__ __forceinline__ const uint32_t* col_cells(const DevMap& m, int cx, in
 #define ELM_STASH_OWN 1   // the transformed point waits in the thread's OWN four slots of the reduction buffer (address = tid * 8) instead of
                           // two 16-byte slots of its wavefront behind an eight-instruction swizzle at each of the four uses
 #endif
+#ifndef ELM_S2_PRIO
+#define ELM_S2_PRIO 0 // 1..3: s_setprio around stage 2's walk (its wavefronts' dependent gathers issue ahead of the other wavefronts' arithmetic).
+                      // Measured (profiles/r05_s2_prio.txt): hard guesses -0.5 %, P2P / GICP +-0.1 %
+#endif
 #ifndef ELM_S2_SEED
 #define ELM_S2_SEED 1 // stage 2 seeds the ball of a point whose stage-1 block was empty (0: full walk of its 27 voxels, developer A/B)
 #endif
@@ -2126,6 +2130,9 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
         __syncthreads();
         constexpr unsigned LPI = ELM_HARD_LANES; // lanes per undecided point (a power of two <= 16: one DPP row holds 16 / LPI points)
         const unsigned rl = threadIdx.x & (LPI - 1u), row = threadIdx.x / LPI;
+#if ELM_S2_PRIO
+        __builtin_amdgcn_s_setprio(ELM_S2_PRIO); // the walk is a chain of dependent gathers: its wavefronts issue ahead of the others' arithmetic
+#endif
         for (unsigned it0 = 0; it0 < n_hard; it0 += kBlock / LPI) {
             const unsigned it = it0 + row;
             if (it0 + (threadIdx.x & ~63u) / LPI >= n_hard) break; // wave-uniform: this wavefront has no point in this pass
@@ -2139,6 +2146,9 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
                 if (kStats) s_tst[it] = walked;
             }
         }
+#if ELM_S2_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         __syncthreads();
         if (hard) {
             bj = s_res[my_slot];
