@@ -93,3 +93,72 @@ def test_c_caller_numbers_never_raise():
         assert key in out or "error" in out
         if key in out:
             assert isinstance(out[key], dict)
+
+
+# ---- the driver line (round 5's 45 KB line was not parsed) ----
+REQUIRED_TOP = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline")
+REQUIRED_ROOFLINE = ("bound", "achieved", "peak", "unit", "frac", "traffic", "hbm_frac", "compulsory_bytes_per_unit", "kernel", "avg_launch_ms",
+                     "units_per_launch")
+
+
+def _strings(obj, path=""):
+    if isinstance(obj, dict):
+        for k, v in obj.items():
+            yield from _strings(v, f"{path}.{k}")
+    elif isinstance(obj, list):
+        for i, v in enumerate(obj):
+            yield from _strings(v, f"{path}[{i}]")
+    elif isinstance(obj, str):
+        yield path, obj
+
+
+@pytest.mark.parametrize("name", ["r05_final_default_bench.json", "r05_final_dist1_bench.json"])
+def test_driver_line_is_small_and_complete(name):
+    """the ONE stdout line, built from a committed full record: below the hard size limit, one line, every contract key present, numbers only
+    under `configs`, and the top-level roofline is the HBM one (north_star) with the busiest unit beside it"""
+    full = json.load(open(os.path.join(ROOT, "profiles", name)))
+    text = bench.driver_line(full)
+    assert len(text) < bench.LINE_LIMIT <= 6000 and "\n" not in text
+    line = json.loads(text)
+    for k in REQUIRED_TOP:
+        assert k in line, k
+    for k in REQUIRED_ROOFLINE:
+        assert line["roofline"].get(k) is not None, k
+    rf = line["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and rf["frac"] == rf["hbm_frac"]
+    assert abs(rf["achieved"] - rf["traffic"] / (rf["avg_launch_ms"] * 1e-3) / 1e9) < 0.01 * rf["achieved"]
+    assert rf["limiter"] in ("valu_issue", "vector_memory_issue", "hbm") and rf["limiter_frac"] <= 1.05
+    assert abs(line["value"] - full["value"]) < 1e-5 * full["value"] and line["steps"] == full["steps"] and line["warmup"] == full["warmup"]
+    assert "workload" in line["config"] and line["config"]["iterations_mean"] > 1
+    if "cpu_baseline" in full:
+        for k in ("value", "unit", "cores", "kind", "sample", "cpu_model", "value_all_cores"):
+            assert k in line["cpu_baseline"], k
+        assert line["pose_err_vs_cpu"]["max_trans_m"] < 1e-4 and line["pose_err_vs_cpu"]["max_rot_rad"] < 1e-5
+        assert line["pose_err_vs_cpu"]["pair_mismatches"] == 0
+    if "configs" in full:
+        assert set(line["configs"]) == set(full["configs"])
+        for path, s in _strings(line["configs"]):
+            assert len(s) <= 24, (path, s)          # unit names only: no prose
+        for leg in ("C3_gicp", "vgicp", "avgicp", "C4_shard"):
+            assert len(json.dumps(line["configs"][leg])) < 400
+    long_strings = [(p, s) for p, s in _strings(line) if len(s) > 130]
+    assert not long_strings, long_strings
+
+
+def test_driver_line_sheds_optional_blocks_rather_than_break_the_limit():
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_final_default_bench.json")))
+    full["configs"] = {f"leg{i}": dict(full["configs"]["C3_gicp"]) for i in range(40)}   # a future builder adds legs
+    text = bench.driver_line(full)
+    line = json.loads(text)
+    assert len(text) < bench.LINE_LIMIT and "configs" not in line and "roofline" in line and "cpu_baseline" in line
+
+
+def test_emit_writes_the_full_record_beside_the_line(tmp_path, capsys):
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_final_default_bench.json")))
+    path = tmp_path / "bench_full.json"
+    text = bench.emit(full, str(path))
+    out = capsys.readouterr()
+    assert out.out.strip() == text and out.out.count("\n") == 1
+    assert json.load(open(path)) == full and json.loads(out.err) == full
