@@ -422,8 +422,8 @@ struct elm_map {
     HashSlot* d_vqslots = nullptr;
     uint32_t* d_vq_dense = nullptr;
     uint32_t* d_vqf_dense = nullptr;
-    VoxRec* d_vnbr = nullptr;
-    GridBlk* d_vnbr_blk = nullptr;
+    VoxRec* d_vox_rec = nullptr;   // [n_vox] (DevMap::vox_rec)
+    VoxBlk* d_vnbr_blk = nullptr;
     VoxRec* d_vface = nullptr;
     GridBlk* d_grid_blk = nullptr;    // dense cell grid (DevMap::grid_*), the default P2P / GICP search index
     uint32_t* d_grid_idx = nullptr;
@@ -438,7 +438,8 @@ struct elm_map {
     unsigned n_bad_pts = 0, n_bad_vox = 0; // covariances outside the compact form (diagnostics)
     unsigned n_asym_pts = 0, n_asym_vox = 0; // ... of which the stored inverse is not symmetric: such a map carries side records (choose_path)
     bool grid_refused = false; // the bounding box needs more cells than the budget: neighbourhood lists instead
-    bool has_vnbr = false; // voxel-mean lists (VGICP)
+    bool has_vnbr = false; // voxel-mean lists (VGICP / AVGICP)
+    bool has_vface = false, vface_refused = false; // AVGICP's face sublists (built at the first AVGICP call; refused: no dense table / too many records)
     bool has_cells = false; // lists sorted by half-voxel cell + offset tables (every list <= 1024 entries)
     bool has_nbr = false;
     std::vector<int32_t> h_keys;
@@ -592,7 +593,7 @@ static void build_host(const float* xyz, size_t n, double voxel_size, int max_po
 static void map_free(elm_map* m) {
     if (!m) return;
     if (ctx_alive(m->ctx, m->ctx_id)) (void)hipSetDevice(m->ctx->device); // a context destroyed first: just release the device memory
-    void* ptrs[] = {m->d_grid_patch, m->d_grid_tiles, m->d_vox_nk, m->d_bad, m->d_grid_gicp8, m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_vox_cinv, m->d_pt_gicp, m->d_pt_cov, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off, m->d_vqslots, m->d_vq_dense, m->d_vqf_dense, m->d_vface, m->d_vnbr, m->d_vnbr_blk,
+    void* ptrs[] = {m->d_grid_patch, m->d_grid_tiles, m->d_vox_nk, m->d_bad, m->d_grid_gicp8, m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_vox_cinv, m->d_pt_gicp, m->d_pt_cov, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off, m->d_vqslots, m->d_vq_dense, m->d_vqf_dense, m->d_vface, m->d_vox_rec, m->d_vnbr_blk,
                     m->d_grid_blk, m->d_grid_idx, m->d_grid_start, m->d_vox_stat, m->d_grid_gicp};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -774,21 +775,26 @@ static void enumerate_query_keys(const elm_map* m, std::vector<int32_t>& qkeys) 
 }
 
 static uint64_t grid_max_cells();
-// Voxel-mean lists for VGICP (see DevMap::vnbr): built lazily at the first VGICP registration, after CalVoxelCovAll.
-static int build_voxel_neighbourhoods(elm_map* m) {
-    if (m->has_vnbr) return ELM_OK;
+// Voxel-mean lists for VGICP / AVGICP (DevMap::vnbr_blk, vox_rec): built lazily at the first VGICP / AVGICP registration, after
+// CalVoxelCovAll.  The lists hold 16 bytes per slot (float32 mean + voxel id | position code); a voxel's float64 record is stored ONCE in
+// vox_rec (round 6: rounds 2-5 copied the 64-byte record into every list, 27 x).  AVGICP's face sublists (whole records, <= 7 per query
+// voxel) are built only when an AVGICP call asks for them (want_faces): a VGICP map does not pay their bytes.
+static int build_voxel_neighbourhoods(elm_map* m, bool want_faces) {
+    const bool need_lists = !m->has_vnbr;
+    // faces exist only beside the dense floor-key table; a map whose lists were built without one never gets them
+    const bool need_faces = want_faces && !m->has_vface && !m->vface_refused && (need_lists || m->d_vq_dense != nullptr);
+    if (!need_lists && !need_faces) return ELM_OK;
     elm_ctx* ctx = m->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (m->dm.n_vox > kVidMask) { ctx->last_error = "voxel-mean lists: more than 2^26 voxels"; return ELM_ERR_UNSUPPORTED; }
     std::vector<int32_t> qkeys;
     enumerate_query_keys(m, qkeys);
     const uint32_t n_q = (uint32_t)(qkeys.size() / 3);
     int32_t* d_qkeys = nullptr;
-    uint32_t *d_counts = nullptr, *d_nocc = nullptr, *d_off = nullptr;
+    uint32_t *d_counts = nullptr, *d_nocc = nullptr, *d_off = nullptr, *d_fcnt = nullptr, *d_foff = nullptr;
     auto cleanup = [&]() {
-        if (d_qkeys) (void)hipFree(d_qkeys);
-        if (d_counts) (void)hipFree(d_counts);
-        if (d_nocc) (void)hipFree(d_nocc);
-        if (d_off) (void)hipFree(d_off);
+        for (void* p : {(void*)d_qkeys, (void*)d_counts, (void*)d_nocc, (void*)d_off, (void*)d_fcnt, (void*)d_foff})
+            if (p) (void)hipFree(p);
     };
 #define VN_CHK(call)                                                                          \
     do {                                                                                      \
@@ -806,136 +812,128 @@ static int build_voxel_neighbourhoods(elm_map* m) {
     VN_CHK(hipMalloc((void**)&d_off, nq_alloc * sizeof(uint32_t)));
     std::vector<uint32_t> nocc(n_q), offs(n_q);
     uint64_t total = 0;
-    if (n_q) {
+    if (n_q) { // (deterministic: a later face build finds the offsets the lists were written with)
         VN_CHK(hipMemcpy(d_qkeys, qkeys.data(), (size_t)n_q * 3 * sizeof(int32_t), hipMemcpyHostToDevice));
         (void)hipGetLastError();
         launch_nbr_count(ctx->stream, m->dm, d_qkeys, n_q, d_counts, d_nocc);
         VN_CHK(hipGetLastError());
         VN_CHK(hipStreamSynchronize(ctx->stream));
         VN_CHK(hipMemcpy(nocc.data(), d_nocc, (size_t)n_q * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        for (uint32_t q = 0; q < n_q; ++q) { offs[q] = (uint32_t)total; total += (nocc[q] + 3u) & ~3u; } // list starts: multiples of four records
+        for (uint32_t q = 0; q < n_q; ++q) { offs[q] = (uint32_t)total; total += (nocc[q] + 3u) & ~3u; } // list starts: multiples of four slots
         VN_CHK(hipMemcpy(d_off, offs.data(), (size_t)n_q * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
-    if (total >= (1ull << 32)) { ctx->last_error = "voxel-mean lists exceed 2^32 records"; cleanup(); return ELM_ERR_UNSUPPORTED; }
-    VN_CHK(hipMalloc((void**)&m->d_vnbr, std::max<size_t>((size_t)total * sizeof(VoxRec), 256)));
-    VN_CHK(hipMemsetAsync(m->d_vnbr, 0, std::max<size_t>((size_t)total * sizeof(VoxRec), 256), ctx->stream)); // the padding records are never read
-    {   // + one block of padding slots at the end: the target of the filter's loads past a list's last block
-        const size_t nb = (size_t)(total / 4) + 1;
-        VN_CHK(hipMalloc((void**)&m->d_vnbr_blk, nb * sizeof(GridBlk)));
-        std::vector<GridBlk> padblk(1);
-        for (int u = 0; u < 4; ++u) padblk[0].x[u] = padblk[0].y[u] = padblk[0].z[u] = 1e18f;
-        VN_CHK(hipMemcpy(m->d_vnbr_blk + (nb - 1), padblk.data(), sizeof(GridBlk), hipMemcpyHostToDevice));
-        m->dm.vnbr_pad_blk = (uint32_t)(nb - 1);
-    }
-    if (n_q) {
+    if (total >= (1ull << 32)) { ctx->last_error = "voxel-mean lists exceed 2^32 slots"; cleanup(); return ELM_ERR_UNSUPPORTED; }
+    // the dense box of floor keys (when it fits the cell budget and the packed word holds the offsets): no hash probe in the kernel --
+    // one 4-byte load at a computed, spatially coherent address
+    int32_t klo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, khi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    for (uint32_t q = 0; q < n_q; ++q)
+        for (int a = 0; a < 3; ++a) {
+            klo[a] = std::min(klo[a], qkeys[3 * q + a]);
+            khi[a] = std::max(khi[a], qkeys[3 * q + a]);
+        }
+    const int64_t vd[3] = {n_q ? (int64_t)khi[0] - klo[0] + 1 : 0, n_q ? (int64_t)khi[1] - klo[1] + 1 : 0, n_q ? (int64_t)khi[2] - klo[2] + 1 : 0};
+    const uint64_t vcells = (uint64_t)vd[0] * (uint64_t)vd[1] * (uint64_t)vd[2];
+    auto dense_index = [&](uint32_t q) {
+        return ((uint64_t)(qkeys[3 * q] - klo[0]) * (uint64_t)vd[1] + (uint64_t)(qkeys[3 * q + 1] - klo[1])) * (uint64_t)vd[2] + (uint64_t)(qkeys[3 * q + 2] - klo[2]);
+    };
+    const bool dense_ok = n_q && total / 4 < (1ull << 27) && vcells <= grid_max_cells() && m->ctx->kernel_mode == 4;
+    if (need_lists) {
+        const size_t nb = (size_t)(total / 4) + 1; // + one block of padding slots at the end: the target of the filter's loads past a list's last block
+        VN_CHK(hipMalloc((void**)&m->d_vnbr_blk, nb * sizeof(VoxBlk)));
+        {
+            VoxBlk padblk;
+            for (int u = 0; u < 4; ++u) { padblk.g.x[u] = padblk.g.y[u] = padblk.g.z[u] = 1e18f; padblk.vc[u] = -1; }
+            VN_CHK(hipMemcpy(m->d_vnbr_blk + (nb - 1), &padblk, sizeof(VoxBlk), hipMemcpyHostToDevice));
+            m->dm.vnbr_pad_blk = (uint32_t)(nb - 1);
+        }
+        VN_CHK(hipMalloc((void**)&m->d_vox_rec, std::max<size_t>((size_t)m->dm.n_vox * sizeof(VoxRec), 256)));
         (void)hipGetLastError();
-        launch_vnbr_fill(ctx->stream, m->dm, d_qkeys, n_q, d_off, m->d_vnbr, m->d_vnbr_blk);
+        launch_vox_rec_fill(ctx->stream, m->dm, m->d_vox_rec);
+        if (n_q) launch_vnbr_fill(ctx->stream, m->dm, d_qkeys, n_q, d_off, m->d_vnbr_blk);
         VN_CHK(hipGetLastError());
         VN_CHK(hipStreamSynchronize(ctx->stream));
-    }
-    const uint32_t qcap = next_pow2((uint64_t)n_q * 2);
-    {
-        std::vector<HashSlot> qs(qcap);
-        for (auto& e : qs) { e.kx = e.ky = e.kz = 0; e.vid = -1; e.start = e.cnt = e.pad0 = e.pad1 = 0; }
-        for (uint32_t q = 0; q < n_q; ++q) {
-            uint32_t h = hash3(qkeys[3 * q], qkeys[3 * q + 1], qkeys[3 * q + 2]) & (qcap - 1);
-            while (qs[h].vid >= 0) h = (h + 1) & (qcap - 1);
-            qs[h].kx = qkeys[3 * q]; qs[h].ky = qkeys[3 * q + 1]; qs[h].kz = qkeys[3 * q + 2];
-            qs[h].vid = (int32_t)q;
-            qs[h].start = offs[q]; qs[h].cnt = nocc[q];
-        }
-        VN_CHK(hipMalloc((void**)&m->d_vqslots, (size_t)qcap * sizeof(HashSlot)));
-        VN_CHK(hipMemcpy(m->d_vqslots, qs.data(), (size_t)qcap * sizeof(HashSlot), hipMemcpyHostToDevice));
-    }
-    // the same table addressed directly by the dense box of floor keys (when the box fits the cell budget and the packed word
-    // holds the offsets): the kernel then needs no hash probe -- one 4-byte load at a computed, spatially coherent address
-    if (n_q && total / 4 < (1ull << 27)) {
-        int32_t klo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, khi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
-        for (uint32_t q = 0; q < n_q; ++q)
-            for (int a = 0; a < 3; ++a) {
-                klo[a] = std::min(klo[a], qkeys[3 * q + a]);
-                khi[a] = std::max(khi[a], qkeys[3 * q + a]);
-            }
-        const int64_t vd[3] = {(int64_t)khi[0] - klo[0] + 1, (int64_t)khi[1] - klo[1] + 1, (int64_t)khi[2] - klo[2] + 1};
-        const uint64_t vcells = (uint64_t)vd[0] * (uint64_t)vd[1] * (uint64_t)vd[2];
-        if (vcells <= grid_max_cells() && m->ctx->kernel_mode == 4) {
-            std::vector<uint32_t> dense(vcells, 0u);
+        const uint32_t qcap = next_pow2((uint64_t)n_q * 2);
+        {
+            std::vector<HashSlot> qs(qcap);
+            for (auto& e : qs) { e.kx = e.ky = e.kz = 0; e.vid = -1; e.start = e.cnt = e.pad0 = e.pad1 = 0; }
             for (uint32_t q = 0; q < n_q; ++q) {
-                const uint64_t idx = ((uint64_t)(qkeys[3 * q] - klo[0]) * (uint64_t)vd[1] + (uint64_t)(qkeys[3 * q + 1] - klo[1])) * (uint64_t)vd[2] +
-                                     (uint64_t)(qkeys[3 * q + 2] - klo[2]);
-                dense[idx] = ((offs[q] >> 2) << 5) | nocc[q]; // first block of four records, nocc <= 27
+                uint32_t h = hash3(qkeys[3 * q], qkeys[3 * q + 1], qkeys[3 * q + 2]) & (qcap - 1);
+                while (qs[h].vid >= 0) h = (h + 1) & (qcap - 1);
+                qs[h].kx = qkeys[3 * q]; qs[h].ky = qkeys[3 * q + 1]; qs[h].kz = qkeys[3 * q + 2];
+                qs[h].vid = (int32_t)q;
+                qs[h].start = offs[q]; qs[h].cnt = nocc[q];
             }
+            VN_CHK(hipMalloc((void**)&m->d_vqslots, (size_t)qcap * sizeof(HashSlot)));
+            VN_CHK(hipMemcpy(m->d_vqslots, qs.data(), (size_t)qcap * sizeof(HashSlot), hipMemcpyHostToDevice));
+        }
+        size_t bytes = nb * sizeof(VoxBlk) + (size_t)m->dm.n_vox * sizeof(VoxRec);
+        if (dense_ok) {
+            std::vector<uint32_t> dense(vcells, 0u);
+            for (uint32_t q = 0; q < n_q; ++q) dense[dense_index(q)] = ((offs[q] >> 2) << 5) | nocc[q]; // first block of four slots, nocc <= 27
             VN_CHK(hipMalloc((void**)&m->d_vq_dense, vcells * sizeof(uint32_t)));
             VN_CHK(hipMemcpy(m->d_vq_dense, dense.data(), vcells * sizeof(uint32_t), hipMemcpyHostToDevice));
             m->dm.vq_dense = m->d_vq_dense;
             m->dm.vq_x0 = klo[0]; m->dm.vq_y0 = klo[1]; m->dm.vq_z0 = klo[2];
             m->dm.vq_nx = (int32_t)vd[0]; m->dm.vq_ny = (int32_t)vd[1]; m->dm.vq_nz = (int32_t)vd[2];
-            m->info.device_bytes += vcells * sizeof(uint32_t);
-            m->info.index_bytes += vcells * sizeof(uint32_t);
-            // AVGICP pairs with the face neighbours only (<= 7 of a list's <= 27 records): their sublists, addressed the same way
-            uint32_t* d_fcnt = nullptr;
-            uint32_t* d_foff = nullptr;
-            VN_CHK(hipMalloc((void**)&d_fcnt, nq_alloc * sizeof(uint32_t)));
-            hipError_t fe = hipMalloc((void**)&d_foff, nq_alloc * sizeof(uint32_t));
-            if (fe != hipSuccess) { (void)hipFree(d_fcnt); VN_CHK(fe); }
-            auto face_cleanup = [&]() { (void)hipFree(d_fcnt); (void)hipFree(d_foff); };
-#define VF_CHK(call)                                                                          \
-    do {                                                                                      \
-        hipError_t e2_ = (call);                                                              \
-        if (e2_ != hipSuccess) { face_cleanup(); VN_CHK(e2_); }                               \
-    } while (0)
-            (void)hipGetLastError();
-            // the fused AVGICP walk's record format; flagged voxels (NaN normals) are left to its fix-up launch (ELM_AVG_FIXUP=0: such maps
-            // keep the nine-entry walk with its in-line fallback)
-            // The fix-up launch pays while few workgroups meet a flagged record (round 4: +14 % with 0.3 % of the voxels flagged); when
-            // flagged voxels are common -- sparse clutter: two or three points per voxel, rank-deficient -- nearly every workgroup is marked,
-            // the second launch repeats the whole walk, and the in-line fallback is the cheaper form: by default the map decides at 1 % of
-            // its voxels (ELM_AVG_FIXUP=1 / 0 force either form).
-            const char* fx = std::getenv("ELM_AVG_FIXUP");
-            const bool fixup_ok = fx ? strcmp(fx, "0") != 0 : (uint64_t)m->n_bad_vox * 100ull <= (uint64_t)m->dm.n_vox;
-            const int plain = (m->dm.vox_compact && (m->n_bad_vox == 0 || fixup_ok) && !std::getenv("ELM_AVG_NINE") && !std::getenv("ELM_PAIR_NINE")) ? 1 : 0;
-            launch_vface(ctx->stream, m->d_vnbr, d_off, d_nocc, n_q, d_fcnt, nullptr, nullptr, plain);
-            VF_CHK(hipGetLastError());
-            VF_CHK(hipStreamSynchronize(ctx->stream));
-            std::vector<uint32_t> fcnt(n_q), foff(n_q);
-            VF_CHK(hipMemcpy(fcnt.data(), d_fcnt, (size_t)n_q * sizeof(uint32_t), hipMemcpyDeviceToHost));
-            uint64_t ftotal = 0;
-            for (uint32_t q = 0; q < n_q; ++q) { foff[q] = (uint32_t)ftotal; ftotal += fcnt[q]; }
-            if (ftotal < (1ull << 29)) {
-                VF_CHK(hipMemcpy(d_foff, foff.data(), (size_t)n_q * sizeof(uint32_t), hipMemcpyHostToDevice));
-                VF_CHK(hipMalloc((void**)&m->d_vface, std::max<size_t>((size_t)ftotal * sizeof(VoxRec), 256)));
-                launch_vface(ctx->stream, m->d_vnbr, d_off, d_nocc, n_q, d_fcnt, d_foff, m->d_vface, plain);
-                VF_CHK(hipGetLastError());
-                VF_CHK(hipStreamSynchronize(ctx->stream));
-                std::fill(dense.begin(), dense.end(), 0u);
-                for (uint32_t q = 0; q < n_q; ++q) {
-                    const uint64_t idx = ((uint64_t)(qkeys[3 * q] - klo[0]) * (uint64_t)vd[1] + (uint64_t)(qkeys[3 * q + 1] - klo[1])) * (uint64_t)vd[2] +
-                                         (uint64_t)(qkeys[3 * q + 2] - klo[2]);
-                    dense[idx] = (foff[q] << 3) | fcnt[q]; // fcnt <= 7
-                }
-                VF_CHK(hipMalloc((void**)&m->d_vqf_dense, vcells * sizeof(uint32_t)));
-                VF_CHK(hipMemcpy(m->d_vqf_dense, dense.data(), vcells * sizeof(uint32_t), hipMemcpyHostToDevice));
-                m->dm.vface = m->d_vface;
-                m->dm.vqf_dense = m->d_vqf_dense;
-                m->dm.vface_plain = plain;
-                m->dm.vface_flagged = (plain && m->n_bad_vox != 0) ? ((fx && strcmp(fx, "skip") == 0) ? 2 : 1) : 0; // (2: tests only -- no fix-up launch, the flagged pairs are dropped)
-                m->info.layout_flags = (m->info.layout_flags & ~(32 | 64)) | (plain ? 32 : 0) | (m->dm.vface_flagged ? 64 : 0);
-                m->info.device_bytes += vcells * sizeof(uint32_t) + (size_t)ftotal * sizeof(VoxRec);
-                m->info.index_bytes += vcells * sizeof(uint32_t) + (size_t)ftotal * sizeof(VoxRec);
-            }
-            face_cleanup();
-#undef VF_CHK
+            bytes += vcells * sizeof(uint32_t);
+        } else {
+            bytes += (size_t)qcap * sizeof(HashSlot); // (the probe table is read only without the dense one)
         }
+        m->dm.vqslots = m->d_vqslots;
+        m->dm.vqmask = qcap - 1;
+        m->dm.vox_rec = m->d_vox_rec;
+        m->dm.vnbr_blk = m->d_vnbr_blk;
+        m->has_vnbr = true;
+        m->info.device_bytes += bytes + (dense_ok ? (size_t)qcap * sizeof(HashSlot) : 0);
+        m->info.index_bytes += bytes + (size_t)m->n_bad_vox * 9 * sizeof(double); // + the stored inverses flagged voxels read
+    }
+    if (need_faces && m->d_vq_dense && n_q) {
+        // AVGICP pairs with the face neighbours only (<= 7 of a list's <= 27 slots): their sublists as whole records, addressed like vq_dense
+        VN_CHK(hipMalloc((void**)&d_fcnt, nq_alloc * sizeof(uint32_t)));
+        VN_CHK(hipMalloc((void**)&d_foff, nq_alloc * sizeof(uint32_t)));
+        (void)hipGetLastError();
+        // the fused AVGICP walk's record format; flagged voxels (NaN normals) are left to its fix-up launch (ELM_AVG_FIXUP=0: such maps
+        // keep the nine-entry walk with its in-line fallback)
+        // The fix-up launch pays while few workgroups meet a flagged record (round 4: +14 % with 0.3 % of the voxels flagged); when
+        // flagged voxels are common -- sparse clutter: two or three points per voxel, rank-deficient -- nearly every workgroup is marked,
+        // the second launch repeats the whole walk, and the in-line fallback is the cheaper form: by default the map decides at 1 % of
+        // its voxels (ELM_AVG_FIXUP=1 / 0 force either form).
+        const char* fx = std::getenv("ELM_AVG_FIXUP");
+        const bool fixup_ok = fx ? strcmp(fx, "0") != 0 : (uint64_t)m->n_bad_vox * 100ull <= (uint64_t)m->dm.n_vox;
+        const int plain = (m->dm.vox_compact && (m->n_bad_vox == 0 || fixup_ok) && !std::getenv("ELM_AVG_NINE") && !std::getenv("ELM_PAIR_NINE")) ? 1 : 0;
+        launch_vface(ctx->stream, m->dm, d_off, d_nocc, n_q, d_fcnt, nullptr, nullptr, plain);
+        VN_CHK(hipGetLastError());
+        VN_CHK(hipStreamSynchronize(ctx->stream));
+        std::vector<uint32_t> fcnt(n_q), foff(n_q);
+        VN_CHK(hipMemcpy(fcnt.data(), d_fcnt, (size_t)n_q * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        uint64_t ftotal = 0;
+        for (uint32_t q = 0; q < n_q; ++q) { foff[q] = (uint32_t)ftotal; ftotal += fcnt[q]; }
+        if (ftotal < (1ull << 29)) {
+            VN_CHK(hipMemcpy(d_foff, foff.data(), (size_t)n_q * sizeof(uint32_t), hipMemcpyHostToDevice));
+            VN_CHK(hipMalloc((void**)&m->d_vface, std::max<size_t>((size_t)ftotal * sizeof(VoxRec), 256)));
+            launch_vface(ctx->stream, m->dm, d_off, d_nocc, n_q, d_fcnt, d_foff, m->d_vface, plain);
+            VN_CHK(hipGetLastError());
+            VN_CHK(hipStreamSynchronize(ctx->stream));
+            std::vector<uint32_t> dense(vcells, 0u);
+            for (uint32_t q = 0; q < n_q; ++q) dense[dense_index(q)] = (foff[q] << 3) | fcnt[q]; // fcnt <= 7
+            VN_CHK(hipMalloc((void**)&m->d_vqf_dense, vcells * sizeof(uint32_t)));
+            VN_CHK(hipMemcpy(m->d_vqf_dense, dense.data(), vcells * sizeof(uint32_t), hipMemcpyHostToDevice));
+            m->dm.vface = m->d_vface;
+            m->dm.vqf_dense = m->d_vqf_dense;
+            m->dm.vface_plain = plain;
+            m->dm.vface_flagged = (plain && m->n_bad_vox != 0) ? ((fx && strcmp(fx, "skip") == 0) ? 2 : 1) : 0; // (2: tests only -- no fix-up launch, the flagged pairs are dropped)
+            m->info.layout_flags = (m->info.layout_flags & ~(32 | 64)) | (plain ? 32 : 0) | (m->dm.vface_flagged ? 64 : 0);
+            m->info.device_bytes += vcells * sizeof(uint32_t) + (size_t)ftotal * sizeof(VoxRec);
+            m->info.index_bytes += vcells * sizeof(uint32_t) + (size_t)ftotal * sizeof(VoxRec);
+            m->has_vface = true;
+        } else {
+            m->vface_refused = true;
+        }
+    } else if (need_faces) {
+        m->vface_refused = true;
     }
 #undef VN_CHK
     cleanup();
-    m->dm.vqslots = m->d_vqslots;
-    m->dm.vqmask = qcap - 1;
-    m->dm.vnbr = m->d_vnbr;
-    m->dm.vnbr_blk = m->d_vnbr_blk;
-    m->has_vnbr = true;
-    m->info.device_bytes += (size_t)total * sizeof(VoxRec) + ((size_t)(total / 4) + 1) * sizeof(GridBlk) + (size_t)qcap * sizeof(HashSlot);
-    m->info.index_bytes += (size_t)total * sizeof(VoxRec) + (size_t)qcap * sizeof(HashSlot) + (size_t)m->dm.n_vox * 9 * sizeof(double);
     return ELM_OK;
 }
 
@@ -1831,7 +1829,7 @@ static int strict_pairs() { // 1: per-pair kernels always, 0: fast kernels witho
     return !e ? -1 : (strcmp(e, "0") != 0 ? 1 : 0);
 }
 static int build_search_index(elm_map* m, bool* use_grid);
-static int build_voxel_neighbourhoods(elm_map* m);
+static int build_voxel_neighbourhoods(elm_map* m, bool want_faces);
 // Which kernels one registration call runs.  `radar`: the per-pair kernels (use_radar_cov, or ELM_STRICT_PAIRS=1).  Otherwise the search
 // index (built on first use) -- dense / two-level cell grid, neighbourhood lists, voxel-mean lists, or the plain walk -- and `asym`: the
 // map holds a flagged covariance of the method's kind whose stored inverse is not symmetric, and the fast kernels carry the antisymmetric
@@ -1869,8 +1867,8 @@ static int choose_path(elm_ctx* ctx, const elm_map* map, const elm_reg_config* c
         if ((rc = build_search_index(const_cast<elm_map*>(map), &pc->use_grid)) != ELM_OK) return rc;
     pc->use_cells = use_nbr && !pc->use_grid && map->has_cells;
     pc->use_vnbr = ctx->kernel_mode != 2 && (method == ELM_VGICP || method == ELM_AVGICP);
-    if (pc->use_vnbr && !map->has_vnbr)
-        if ((rc = build_voxel_neighbourhoods(const_cast<elm_map*>(map))) != ELM_OK) return rc;
+    if (pc->use_vnbr)
+        if ((rc = build_voxel_neighbourhoods(const_cast<elm_map*>(map), method == ELM_AVGICP)) != ELM_OK) return rc;
     const bool asym_map = mode < 0 && method != ELM_P2P && (method == ELM_GICP ? map->n_asym_pts != 0 : map->n_asym_vox != 0);
     if (asym_map) {
         if ((pc->use_grid || pc->use_vnbr) && !ctx->fused_reduce) pc->asym = true;
@@ -1906,7 +1904,7 @@ extern "C" int elm_map_get_correspondences(elm_ctx* ctx, const elm_map* map, int
                     if ((rc = build_search_index(const_cast<elm_map*>(map), &g)) != ELM_OK) return rc;
                 production = g;
             } else {
-                if (!map->has_vnbr && (rc = build_voxel_neighbourhoods(const_cast<elm_map*>(map))) != ELM_OK) return rc;
+                if ((rc = build_voxel_neighbourhoods(const_cast<elm_map*>(map), what == 2)) != ELM_OK) return rc;
                 production = map->has_vnbr;
             }
         }

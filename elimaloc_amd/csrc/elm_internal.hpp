@@ -39,6 +39,16 @@ struct __attribute__((aligned(64))) VoxRec {
     int32_t pad; // position code of the neighbour (dx + 1) * 9 + (dy + 1) * 3 + (dz + 1)
 };
 
+// Four slots of a voxel-mean list (VGICP / AVGICP): the float32 means (the filter of the VGICP search) and, per slot, the voxel's id
+// with the neighbour's position code (dx + 1) * 9 + (dy + 1) * 3 + (dz + 1) above it -- 64 bytes, one memory sector, never straddling a
+// 128-byte line.  Padding slots: mean 1e18, word -1.  The float64 record of a voxel lives ONCE in DevMap::vox_rec.
+constexpr uint32_t kVidBits = 26;                    // voxel ids of the lists: < 2^26 voxels (a 1.6 G-point map at 25 points per voxel)
+constexpr uint32_t kVidMask = (1u << kVidBits) - 1u;
+struct __attribute__((aligned(64))) VoxBlk {
+    GridBlk g;
+    int32_t vc[4];
+};
+
 struct DevMap {
     const HashSlot* slots;
     uint32_t mask; // capacity - 1 (capacity is a power of two >= 4 * n_voxels)
@@ -70,10 +80,11 @@ struct DevMap {
     const HashSlot* vqslots;
     uint32_t vqmask;
     uint32_t _pad2;
-    const VoxRec* vnbr;
+    const VoxRec* vox_rec;    // [n_vox] the float64 record {mean, normal, k, vid} of every voxel, ONCE (round 6; rounds 2-5 replicated it into
+                              // every query list: 27 copies, 4.3 GB on the 50 M-point map)
     const uint32_t* vq_dense; // optional: the same (start << 5 | cnt) addressed by the dense floor-key box (vq_x0.., no hash probe)
-    const GridBlk* vnbr_blk;    // the lists' means once more as float32 blocks of four (the filter of the VGICP walk): list q starts at block
-                                // start(q) / 4 (list starts are multiples of four records), padding slots 1e18
+    const VoxBlk* vnbr_blk;     // the lists: blocks of four slots {float32 mean, vid | code}: list q starts at block
+                                // start(q) / 4 (list starts are multiples of four slots), padding slots 1e18 / -1
     uint32_t vnbr_pad_blk;      // index of the all-padding block at the end of vnbr_blk
     const VoxRec* vface;        // optional (with vq_dense): the FACE neighbours (+ the voxel itself) of every query voxel, in list order --
                                 // what AVGICP pairs with (vhm.cpp:153-206) -- and
@@ -268,9 +279,10 @@ void launch_solve(hipStream_t s, const ScanDesc* scans, int batch, ScanState* st
 void launch_nbr_count(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, uint32_t* counts, uint32_t* nocc);
 void launch_accumulate_vnbr(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                             ScanState* st, double* partials, const RegParams& rp);
-void launch_vnbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets, VoxRec* out, GridBlk* out_blk);
+void launch_vnbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets, VoxBlk* out_blk);
+void launch_vox_rec_fill(hipStream_t s, const DevMap& m, VoxRec* out);
 // face-neighbour sublists of the voxel-mean lists: counts (out == nullptr) or the records at face_off
-void launch_vface(hipStream_t s, const VoxRec* vnbr, const uint32_t* offsets, const uint32_t* counts, uint32_t n_q, uint32_t* face_cnt,
+void launch_vface(hipStream_t s, const DevMap& m, const uint32_t* offsets, const uint32_t* counts, uint32_t n_q, uint32_t* face_cnt,
                   const uint32_t* face_off, VoxRec* out, int plain);
 void launch_accumulate_cell(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                             ScanState* st, double* partials, const RegParams& rp);

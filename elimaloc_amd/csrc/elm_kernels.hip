@@ -2419,11 +2419,17 @@ __global__ __launch_bounds__(64) void k_nbr_cellsort(const DevMap m, const int32
     }
 }
 
+// slot `slot` of the voxel-mean lists: its word (voxel id | position code << kVidBits; -1: padding) / its voxel id
+__device__ __forceinline__ int vnbr_vc(const DevMap& m, unsigned slot) { return m.vnbr_blk[slot >> 2].vc[slot & 3u]; }
+__device__ __forceinline__ unsigned vnbr_vid(const DevMap& m, unsigned slot) { return (unsigned)vnbr_vc(m, slot) & kVidMask; }
+
 // ---- K1e: voxel-mean lists (VGICP) ------------------------------------------------------------------------
 // GetCorrespondencesCov (vhm.cpp:90-151) visits the 27 neighbour voxels of the point's floor-keyed voxel and keeps the
 // nearest voxel MEAN (strict <, first met wins).  Here the occupied ones (~10 of 27) are precomputed per query voxel in
-// that visiting order as 32-byte (mean, id) records: one probe, then <= 27 contiguous records, float64 distances in the
-// reference's order -- no staging, no barriers before the block reduction.
+// that visiting order as 64-byte blocks of four {float32 means, voxel id | position code}: one probe, then <= 7 contiguous blocks for
+// the float32 filter, then ONE float64 record of the winner from the per-voxel table DevMap::vox_rec (round 6: a voxel's record is
+// stored once, 64 B x n_vox -- cache resident -- instead of once per query list it appears in, 27 x) -- no staging, no barriers before
+// the block reduction.  A float32 near-tie walks the list's records in the reference's order, float64.
 #ifndef ELM_VNBR_RECS
 #define ELM_VNBR_RECS 3 // VGICP: list records per round trip (measured 2 / 3 / 4 / 6 / 8: 105.9 / 110.5 / 102.3 / 99.3 / 92.3 k registrations/s)
 #endif
@@ -2506,7 +2512,8 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
                 h = (h + 2) & m.vqmask;
             }
         }
-        const VoxRec* __restrict__ lp = ((METHOD == ELM_AVGICP && m.vq_dense && m.vqf_dense) ? m.vface : m.vnbr) + start;
+        // AVGICP with the face table: lp = the face sublist (whole records); everything else addresses the list's slots through vnbr_vc
+        const VoxRec* __restrict__ lp = m.vface + ((METHOD == ELM_AVGICP && m.vq_dense && m.vqf_dense) ? start : 0u);
         if (METHOD == ELM_VGICP) {
             double bd2 = DBL_MAX, bmx = 0.0, bmy = 0.0, bmz = 0.0;
             double bn[4] = {1.0, 0.0, 0.0, 0.0}; // the winner's plane normal and k (compact records)
@@ -2516,43 +2523,46 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
             // a winner that is clear of the runner-up by the rounding of the stored means and of the arithmetic is the strict
             // float64 minimum as well; its float64 record is read afterwards.  Near ties (practically never) take the float64 walk.
             bool exact = cnt != 0u;
-            if (cnt != 0u && m.vnbr_blk) {
+            int wv0 = -1, wv1 = -1, wv2 = -1, wv3 = -1, wvc = -1; // slot words of the block that holds the current winner; the winner's
+            if (cnt != 0u) {
                 const unsigned nblk = (cnt + 3u) >> 2, blk0 = start >> 2;
                 // distances to gh = float32(g): |g - gh| joins the stored means' rounding in the margin of the decision
                 const float ghx = (float)gx, ghy = (float)gy, ghz = (float)gz;
                 const float eg = (fabsf((float)(gx - (double)ghx)) + fabsf((float)(gy - (double)ghy)) + fabsf((float)(gz - (double)ghz))) * 1.000001f;
                 const f32x2 gxy = {ghx, ghy}, gzz = {ghz, 0.f};
-                unsigned m1 = 0x7F800000u, m2 = 0x7F800000u, jb = 0u;
+                unsigned m1 = 0x7F800000u, m2 = 0x7F800000u;
                 for (unsigned b0 = 0; b0 < nblk; b0 += ELM_VNBR_BLKS) {
-                    GridBlk B[ELM_VNBR_BLKS];
+                    VoxBlk B[ELM_VNBR_BLKS];
 #pragma unroll
                     for (int u = 0; u < ELM_VNBR_BLKS; ++u) B[u] = m.vnbr_blk[(b0 + u < nblk) ? blk0 + b0 + u : m.vnbr_pad_blk];
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int u = 0; u < ELM_VNBR_BLKS; ++u) {
                         f32x2 da, db;
-                        blk_dist_h(B[u], gxy, gzz, da, db);
+                        blk_dist_h(B[u].g, gxy, gzz, da, db);
                         const unsigned was = m1;
                         two_smallest(da.x, 0u, m1, m2);
                         two_smallest(da.y, 1u, m1, m2);
                         two_smallest(db.x, 2u, m1, m2);
                         two_smallest(db.y, 3u, m1, m2);
-                        jb = (m1 != was) ? b0 + (unsigned)u : jb;
+                        const bool ch = m1 != was;
+                        wv0 = ch ? B[u].vc[0] : wv0; wv1 = ch ? B[u].vc[1] : wv1; wv2 = ch ? B[u].vc[2] : wv2; wv3 = ch ? B[u].vc[3] : wv3;
                     }
                 }
                 // |float32(mean) - mean| <= 2^-24 |mean|_1 <= 6.5e-8 (|g|_1 + 6 voxel sizes); float32 arithmetic + key bits: 2^-18
                 const float em = 6.5e-8f * (fabsf(ghx) + fabsf(ghy) + fabsf(ghz) + 6.0f * (float)m.voxel_size) + eg;
                 const float s1 = __builtin_sqrtf(__uint_as_float(m1 & ~3u)), s2 = __builtin_sqrtf(__uint_as_float(m2 & ~3u));
                 if (s2 - s2 * 3.814697265625e-06f - em > s1 + s1 * 3.814697265625e-06f + em) {
-                    bj = jb * 4u + (m1 & 3u);
+                    const unsigned sl = m1 & 3u; // the winner's slot word rode along with its block
+                    wvc = sl == 0u ? wv0 : sl == 1u ? wv1 : sl == 2u ? wv2 : wv3;
                     exact = false;
                 }
             }
             if (exact) {
-                for (unsigned j = 0; j < cnt; j += ELM_VNBR_RECS) { // ELM_VNBR_RECS records (two 16-byte loads each) per round trip
+                for (unsigned j = 0; j < cnt; j += ELM_VNBR_RECS) { // ELM_VNBR_RECS records per round trip (slot word, then the voxel's record)
                     VoxRec r[ELM_VNBR_RECS];
 #pragma unroll
-                    for (int u = 0; u < ELM_VNBR_RECS; ++u) r[u] = lp[min(j + u, cnt - 1)]; // past the end: the last record again (never < itself)
+                    for (int u = 0; u < ELM_VNBR_RECS; ++u) r[u] = m.vox_rec[vnbr_vid(m, start + min(j + u, cnt - 1))]; // past the end: the last record again (never < itself)
 #pragma unroll
                     for (int u = 0; u < ELM_VNBR_RECS; ++u) {
                         const double ex = r[u].mx - gx, ey = r[u].my - gy, ez = r[u].mz - gz;
@@ -2563,8 +2573,8 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
                     }
                 }
             }
-            if (cnt) { // the winner's float64 record (after the float64 walk: an L1 hit instead of five registers carried through it)
-                const VoxRec w = lp[min(bj, cnt - 1)];
+            if (cnt) { // the winner's float64 record, from the per-voxel table (after the float64 walk: its slot word is an L1 hit)
+                const VoxRec w = m.vox_rec[exact ? vnbr_vid(m, start + min(bj, cnt - 1)) : ((unsigned)wvc & kVidMask)];
                 bvid = w.vid; bmx = w.mx; bmy = w.my; bmz = w.mz;
                 if (COMPACT) { bn[0] = w.nx; bn[1] = w.ny; bn[2] = w.nz; bn[3] = w.k; }
                 const double ex = w.mx - gx, ey = w.my - gy, ez = w.mz - gz;
@@ -2606,6 +2616,7 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
             AvgPairSum Q;
             avg_pair_init(Q);
             const bool faces_only = FACES != 0; // lp is a face sublist (the launcher checks m.vq_dense && m.vqf_dense)
+            const bool via_faces = FACES != 0 || (m.vq_dense && m.vqf_dense); // (the QUERY instantiation reads the face sublists too when the map has them)
             if (COMPACT && (FACES == 2 || FACES == 4)) { // (4: on a map with flagged voxels -- their pairs are left to the fix-up launch)
                 // Face sublists of a map whose every voxel is of the compact form (DevMap::vface_plain): 48 bytes per record as below, and
                 // A_v = w (I + k n n^T) is never formed -- the point gathers sum w, sum (w k) n n^T (six entries) and
@@ -2670,8 +2681,17 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
             } else
             for (unsigned j = 0; j < cnt; j += ELM_AVG_RECS) { // ELM_AVG_RECS records (two 16-byte loads each) per round trip
                 VoxRec r[ELM_AVG_RECS];
+                if (via_faces) {
 #pragma unroll
-                for (int u = 0; u < ELM_AVG_RECS; ++u) r[u] = lp[min(j + u, cnt - 1)];
+                    for (int u = 0; u < ELM_AVG_RECS; ++u) r[u] = lp[min(j + u, cnt - 1)];
+                } else { // the whole list: the slot word carries the position code, the record comes from the per-voxel table
+#pragma unroll
+                    for (int u = 0; u < ELM_AVG_RECS; ++u) {
+                        const unsigned vc = (unsigned)vnbr_vc(m, start + min(j + u, cnt - 1));
+                        r[u] = m.vox_rec[vc & kVidMask];
+                        r[u].pad = (int32_t)(vc >> kVidBits);
+                    }
+                }
                 // the face neighbours among them: their inverse covariances are requested together, before the first is used
                 bool use[ELM_AVG_RECS];
                 double Ci[ELM_AVG_RECS][9];
@@ -2737,8 +2757,7 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
 }
 
 __global__ __launch_bounds__(256) void k_vnbr_fill(const DevMap m, const int32_t* __restrict__ qkeys, unsigned n_q,
-                                                   const unsigned* __restrict__ offsets, VoxRec* __restrict__ out,
-                                                   GridBlk* __restrict__ out_blk) {
+                                                   const unsigned* __restrict__ offsets, VoxBlk* __restrict__ out_blk) {
     const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n_q) return;
     const int vx = qkeys[3 * q], vy = qkeys[3 * q + 1], vz = qkeys[3 * q + 2];
@@ -2749,26 +2768,32 @@ __global__ __launch_bounds__(256) void k_vnbr_fill(const DevMap m, const int32_t
             for (int dz = -1; dz <= 1; ++dz) {
                 const Probe pr = probe_voxel(m, vx + dx, vy + dy, vz + dz);
                 if (pr.vid < 0 || pr.cnt == 0) continue;
-                VoxRec r;
-                r.mx = m.vox_mean[(size_t)pr.vid * 3]; r.my = m.vox_mean[(size_t)pr.vid * 3 + 1]; r.mz = m.vox_mean[(size_t)pr.vid * 3 + 2];
-                r.nx = m.vox_nk[(size_t)pr.vid * 4]; r.ny = m.vox_nk[(size_t)pr.vid * 4 + 1]; r.nz = m.vox_nk[(size_t)pr.vid * 4 + 2];
-                r.k = m.vox_nk[(size_t)pr.vid * 4 + 3];
-                r.vid = pr.vid;
-                r.pad = ((dx + 1) * 3 + (dy + 1)) * 3 + (dz + 1); // position code of this neighbour (AVGICP picks the face ones)
-                if (out_blk) { // the float32 filter copy: slot o % 4 of block o / 4
-                    GridBlk& B = out_blk[o >> 2];
-                    B.x[o & 3u] = (float)r.mx; B.y[o & 3u] = (float)r.my; B.z[o & 3u] = (float)r.mz;
-                }
-                out[o++] = r;
+                VoxBlk& B = out_blk[o >> 2]; // slot o % 4 of block o / 4: the float32 mean (the filter) + voxel id | position code << 26
+                B.g.x[o & 3u] = (float)m.vox_mean[(size_t)pr.vid * 3];
+                B.g.y[o & 3u] = (float)m.vox_mean[(size_t)pr.vid * 3 + 1];
+                B.g.z[o & 3u] = (float)m.vox_mean[(size_t)pr.vid * 3 + 2];
+                B.vc[o & 3u] = (int32_t)((unsigned)pr.vid | ((unsigned)(((dx + 1) * 3 + (dy + 1)) * 3 + (dz + 1)) << kVidBits)); // (AVGICP picks the face codes)
+                ++o;
             }
-    if (out_blk)
-        for (; ((o - o0) & 3u) != 0u; ++o) { // padding slots of the last block: never the nearest
-            GridBlk& B = out_blk[o >> 2];
-            B.x[o & 3u] = 1e18f; B.y[o & 3u] = 1e18f; B.z[o & 3u] = 1e18f;
-        }
+    for (; ((o - o0) & 3u) != 0u; ++o) { // padding slots of the last block: never the nearest
+        VoxBlk& B = out_blk[o >> 2];
+        B.g.x[o & 3u] = 1e18f; B.g.y[o & 3u] = 1e18f; B.g.z[o & 3u] = 1e18f;
+        B.vc[o & 3u] = -1;
+    }
+}
+// the per-voxel float64 record of the voxel-mean search (DevMap::vox_rec): mean, plane normal, k -- ONE copy per voxel
+__global__ __launch_bounds__(256) void k_vox_rec_fill(const DevMap m, VoxRec* __restrict__ out) {
+    const unsigned v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= m.n_vox) return;
+    VoxRec r;
+    r.mx = m.vox_mean[(size_t)v * 3]; r.my = m.vox_mean[(size_t)v * 3 + 1]; r.mz = m.vox_mean[(size_t)v * 3 + 2];
+    r.nx = m.vox_nk[(size_t)v * 4]; r.ny = m.vox_nk[(size_t)v * 4 + 1]; r.nz = m.vox_nk[(size_t)v * 4 + 2];
+    r.k = m.vox_nk[(size_t)v * 4 + 3];
+    r.vid = (int32_t)v;
+    r.pad = 0;
+    out[v] = r;
 }
 
-// map build: size and content of the neighbourhood list of every query voxel (init time)
 __global__ __launch_bounds__(256) void k_nbr_count(const DevMap m, const int32_t* __restrict__ qkeys, unsigned n_q,
                                                    unsigned* __restrict__ counts, unsigned* __restrict__ nocc) {
     const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3966,17 +3991,18 @@ void launch_accumulate_vnbr(hipStream_t s, const DevMap& m, const ScanDesc* scan
 __device__ __forceinline__ bool is_face_code(int code) {
     return code == 13 || code == 22 || code == 4 || code == 16 || code == 10 || code == 14 || code == 12;
 }
-__global__ __launch_bounds__(256) void k_vface(const VoxRec* __restrict__ vnbr, const uint32_t* __restrict__ offsets,
+__global__ __launch_bounds__(256) void k_vface(const DevMap m, const uint32_t* __restrict__ offsets,
                                                const uint32_t* __restrict__ counts, unsigned n_q, uint32_t* __restrict__ face_cnt,
                                                const uint32_t* __restrict__ face_off, VoxRec* __restrict__ out, int plain) {
     const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n_q) return;
-    const VoxRec* lp = vnbr + offsets[q];
     unsigned n = 0;
     const unsigned o = out ? face_off[q] : 0u;
     for (unsigned j = 0; j < counts[q]; ++j) {
-        VoxRec r = lp[j];
-        if (!is_face_code(r.pad)) continue;
+        const unsigned vc = (unsigned)vnbr_vc(m, offsets[q] + j);
+        if (!is_face_code((int)(vc >> kVidBits))) continue;
+        VoxRec r = m.vox_rec[vc & kVidMask];
+        r.pad = (int32_t)(vc >> kVidBits);
         // the first 48 bytes tell the three kinds of record apart (k_accumulate_vnbr<AVGICP> loads only those in the common case):
         //   k = kCompactK (regularised covariance): the unit normal as it is;  k = 0 (identity): n.x = 2 (not a unit vector);
         //   anything else (k = NaN: outside the compact form, or another k): n.x = NaN -> the stored inverse is read
@@ -3989,12 +4015,15 @@ __global__ __launch_bounds__(256) void k_vface(const VoxRec* __restrict__ vnbr, 
     }
     if (!out) face_cnt[q] = n;
 }
-void launch_vface(hipStream_t s, const VoxRec* vnbr, const uint32_t* offsets, const uint32_t* counts, uint32_t n_q, uint32_t* face_cnt,
+void launch_vface(hipStream_t s, const DevMap& m, const uint32_t* offsets, const uint32_t* counts, uint32_t n_q, uint32_t* face_cnt,
                   const uint32_t* face_off, VoxRec* out, int plain) {
-    if (n_q) hipLaunchKernelGGL(k_vface, dim3((n_q + 255) / 256), dim3(256), 0, s, vnbr, offsets, counts, n_q, face_cnt, face_off, out, plain);
+    if (n_q) hipLaunchKernelGGL(k_vface, dim3((n_q + 255) / 256), dim3(256), 0, s, m, offsets, counts, n_q, face_cnt, face_off, out, plain);
 }
-void launch_vnbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets, VoxRec* out, GridBlk* out_blk) {
-    hipLaunchKernelGGL(k_vnbr_fill, dim3((n_q + 255) / 256), dim3(256), 0, s, m, qkeys, n_q, offsets, out, out_blk);
+void launch_vnbr_fill(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets, VoxBlk* out_blk) {
+    hipLaunchKernelGGL(k_vnbr_fill, dim3((n_q + 255) / 256), dim3(256), 0, s, m, qkeys, n_q, offsets, out_blk);
+}
+void launch_vox_rec_fill(hipStream_t s, const DevMap& m, VoxRec* out) {
+    if (m.n_vox) hipLaunchKernelGGL(k_vox_rec_fill, dim3((m.n_vox + 255) / 256), dim3(256), 0, s, m, out);
 }
 void launch_nbr_cellsort(hipStream_t s, const DevMap& m, const int32_t* qkeys, uint32_t n_q, const uint32_t* offsets,
                          const uint32_t* counts, Pt3* pts, uint32_t* idx, uint16_t* cell_off) {
