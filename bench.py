@@ -125,7 +125,9 @@ def launch_ranks(args, argv):
 
 def generate_inputs(world, args, rank, world_size, dist, guess, n_keep, keep_own, consume, stats=None):
     """The step's registrations: n_batch = batch x world_size seeded scans + initial guesses; `consume(i, shard, n)` receives, in order
-    of i, THIS rank's contiguous shard [n rank / W, n (rank + 1) / W) of scan i (packed float32 xyz, the caller's point order).
+    of i, THIS rank's shard of scan i (packed float32 xyz).  One rank: the whole scan in the generator's order.  W ranks: the contiguous
+    part [n rank / W, n (rank + 1) / W) of the scan sorted along the ordering kernel's Hilbert curve (elimaloc_amd.dist.spatial_order:
+    locality-aware sharding -- a rank holds a compact sector of the scan at full density, not a thinned copy of all of it).
 
     One rank: every scan is generated here.  W ranks: rank r generates only the scans i = r (mod W) -- the host work per rank does not
     grow with W -- and one all-to-all per round of 32 scans (host tensors over gloo, outside every timed region) hands every rank its
@@ -134,11 +136,17 @@ def generate_inputs(world, args, rank, world_size, dist, guess, n_keep, keep_own
     Returns dict(T_true, T0s, digests, rmaxs, kept = {i: full scan} for i < n_keep on rank 0 (+ this rank's own scans if keep_own))."""
     from concurrent.futures import ThreadPoolExecutor
     from elimaloc_amd import synth
+    from elimaloc_amd import dist as elm_dist
     n_batch = args.batch * world_size
     npts = args.scan_points
 
     def gen(i):
-        sc, Tt = synth.make_scan(world, npts, seed=2002 + i, max_range=SCAN_RANGE_M, noise=SCAN_NOISE_M)
+        K = max(1, int(getattr(args, "shard_of", 1)))
+        if K > 1:  # --shard-of K: registration i is shard i mod K of a K x npts-point scan (the C4_shard leg's shape, for its counter passes)
+            full, Tt = synth.make_scan(world, npts * K, seed=2002 + i, max_range=SCAN_RANGE_M, noise=SCAN_NOISE_M)
+            sc = elm_dist.spatial_shards(full, K)[i % K]
+        else:
+            sc, Tt = synth.make_scan(world, npts, seed=2002 + i, max_range=SCAN_RANGE_M, noise=SCAN_NOISE_M)
         T0 = synth.perturb(Tt, seed=3003 + i, **guess)
         pre = os.environ.get("ELM_BENCH_POINT_ORDER", "")  # developer A/B of the CALLER's point order (not the default workload)
         if pre == "shuffle":  # no locality at all inside the ordering kernel's 2 m cells (a spinning LiDAR's firing order)
@@ -150,7 +158,9 @@ def generate_inputs(world, args, rank, world_size, dist, guess, n_keep, keep_own
         h = hashlib.sha1(sc.tobytes())
         h.update(np.ascontiguousarray(T0).tobytes())
         rmax = float(np.sqrt((sc.astype(np.float64) ** 2).sum(axis=1).max())) if sc.shape[0] else 0.0
-        return sc, Tt, T0, h.digest(), rmax
+        # what the ranks receive their shards of (W > 1): the spatially ordered scan; `kept` and the SHA-1 stay the generator's
+        so = sc[elm_dist.spatial_order(sc)] if (world_size > 1 and not os.environ.get("ELM_BENCH_PLAIN_SHARDS")) else sc
+        return sc, Tt, T0, h.digest(), rmax, so
 
     synth.make_scan(world, 16, seed=1)  # builds the (cached) tile index of the world before the threads start
     meta = [None] * n_batch  # (T_true, T0, digest, rmax)
@@ -158,7 +168,7 @@ def generate_inputs(world, args, rank, world_size, dist, guess, n_keep, keep_own
     workers = max(2, min(16, (os.cpu_count() or 16) // max(world_size, 1)))
     with ThreadPoolExecutor(max_workers=workers) as pool:  # numpy releases the GIL in the heavy parts; make_scan calls no BLAS
         if world_size == 1:
-            for i, (sc, Tt, T0, dg, rmax) in enumerate(pool.map(gen, range(n_batch))):
+            for i, (sc, Tt, T0, dg, rmax, _) in enumerate(pool.map(gen, range(n_batch))):
                 meta[i] = (Tt, T0, dg, rmax)
                 if i < n_keep or keep_own:
                     kept[i] = sc
@@ -177,7 +187,7 @@ def generate_inputs(world, args, rank, world_size, dist, guess, n_keep, keep_own
                 if any(o[0].shape[0] != npts for o in own):
                     raise SystemExit("make_scan returned a scan of another size")
                 # send buffer: destination-major, then scan; receive buffer: source-major, then scan
-                inp = torch.from_numpy(np.concatenate([o[0][bounds[d]:bounds[d + 1]].reshape(-1) for d in range(world_size) for o in own]))
+                inp = torch.from_numpy(np.concatenate([o[5][bounds[d]:bounds[d + 1]].reshape(-1) for d in range(world_size) for o in own]))
                 out = torch.empty(world_size * cnt * mine * 3, dtype=torch.float32)
                 dist.all_to_all_single(out, inp, [cnt * mine * 3] * world_size, [cnt * (bounds[d + 1] - bounds[d]) * 3 for d in range(world_size)])
                 metas = [None] * world_size
@@ -653,6 +663,8 @@ def main():
     ap.add_argument("--asym-triples", type=int, default=0, help="append this many isolated collinear point triples to the world (synth.collinear_triples): "
                     "rank-1 neighbourhoods whose regularised covariance is not symmetric (layout bits 7 / 8) -- the covariance methods then "
                     "carry the antisymmetric side records")
+    ap.add_argument("--shard-of", type=int, default=1, help="K > 1: every registration is shard i mod K (dist.spatial_shards) of a K x --scan-points scan: one rank's "
+                    "launches of a K-GPU run as registrations of their own (the C4_shard leg's shape; N = 1 only)")
     ap.add_argument("--dry-launch", action="store_true", help="launcher + rendezvous + sharded input generation only, gloo, no GPU (CPU test of the N > 1 path)")
     args = ap.parse_args()
     extras = not (args.no_extras or args.no_latency)
@@ -1354,8 +1366,15 @@ def main():
             vm4.AddPoints(world4)
             pool_n = max(2, min(16, ncpu))
 
+            from elimaloc_amd import dist as elm_dist
+            plain4 = bool(os.environ.get("ELM_BENCH_PLAIN_SHARDS"))  # developer A/B: rounds 2-5's shape (a 32768-point scan of the whole footprint)
+
             def gen4(i):
-                sc, Tt = synth.make_scan(world4, pts4, seed=2002 + i, max_range=SCAN_RANGE_M, noise=SCAN_NOISE_M)
+                if plain4:
+                    sc, Tt = synth.make_scan(world4, pts4, seed=2002 + i, max_range=SCAN_RANGE_M, noise=SCAN_NOISE_M)
+                else:  # shard i mod 8 of a 262144-point scan, cut the way `bench.py --gpus 8` cuts it (dist.spatial_shards)
+                    full, Tt = synth.make_scan(world4, 8 * pts4, seed=2002 + i, max_range=SCAN_RANGE_M, noise=SCAN_NOISE_M)
+                    sc = elm_dist.spatial_shards(full, 8)[i % 8]
                 return sc, Tt, synth.perturb(Tt, seed=3003 + i, **guess)
             synth.make_scan(world4, 16, seed=1)
             with ThreadPoolExecutor(max_workers=pool_n) as pool:
@@ -1365,10 +1384,11 @@ def main():
             host4 = [g[0] for g in g4[:4]]
             op4 = dict(scan_points=pts4, map_points=map4, guess=args.guess, batch=n4, slots=slots4, world="lattice")
             leg = method_leg(IcpMethod.VGICP, vm4, reg.pack_inputs(scans4, T04), n4, world4, host4, T4, T04, op4,
-                             f"VGICP, {pts4}-point scans (the per-rank shard of BASELINE configs[3]'s 262144-point scans at N = 8) vs the {map4}-point map, "
-                             f"{n4} registrations through {slots4} slots: the launches ONE rank of the 8-GPU run issues per ICP iteration, without the exchange "
-                             "(there all 8 ranks hold a shard of the same registration; here every shard-sized scan is a registration of its own, so the "
-                             "value is also the whole-job rate 8 such ranks would reach if the collective were free)")
+                             f"VGICP, {pts4}-point shards (one of the 8 Hilbert-contiguous shards of BASELINE configs[3]'s 262144-point scans, shard i mod 8 of "
+                             f"scan i) vs the {map4}-point map, {n4} registrations through {slots4} slots: the launches ONE rank of the 8-GPU run issues per ICP "
+                             "iteration, without the exchange (there all 8 ranks hold a shard of the same registration; here every shard is a registration of "
+                             "its own, so the value is also the whole-job rate 8 such ranks would reach if the collective were free)")
+            leg["shards"] = "plain" if plain4 else "spatial"
             leg["setup_s"] = time.time() - tl - leg["leg_wall_s"]
             configs["C4_shard"] = leg
             del scans4, vm4, world4, g4

@@ -28,6 +28,7 @@ def expected(n_batch, npts, map_points, world_size):
     """inputs.sha1 and, per rank, (points, sha1) of its shards in registration order -- generated here, in one process."""
     sys.path.insert(0, ROOT)
     from elimaloc_amd import synth
+    from elimaloc_amd import dist as elm_dist
     world = synth.make_world(map_points, seed=1001)
     digests = []
     shard = [hashlib.sha1() for _ in range(world_size)]
@@ -38,9 +39,13 @@ def expected(n_batch, npts, map_points, world_size):
         h = hashlib.sha1(sc.tobytes())
         h.update(np.ascontiguousarray(T0).tobytes())
         digests.append(h.digest())
+        # W > 1: the ranks hold contiguous parts of the spatially ORDERED scan (locality-aware sharding, round 6)
+        parts = elm_dist.spatial_shards(sc, world_size) if world_size > 1 else [sc]
+        assert sum(len(q) for q in parts) == npts and sorted(map(tuple, np.concatenate(parts))) == sorted(map(tuple, sc))  # a partition of the scan
         for r in range(world_size):
             lo, hi = npts * r // world_size, npts * (r + 1) // world_size
-            shard[r].update(np.ascontiguousarray(sc[lo:hi]).tobytes())
+            assert len(parts[r]) == hi - lo
+            shard[r].update(parts[r].tobytes())
             pts[r] += hi - lo
     return hashlib.sha1(b"".join(digests)).hexdigest(), [(pts[r], shard[r].hexdigest()) for r in range(world_size)]
 

@@ -264,3 +264,25 @@ def test_stream_slot_order_refill_and_rank_check_world_size_2_gloo(corrupt):
     else:
         # rank 1 freed a slot one exchange early and refilled it: at the NEXT exchange both ranks see sum(id) != n id for that slot
         assert res["corrupted"] is not None and res["fault_at"] == [res["corrupted"] + 1] * 2, res
+
+
+def test_spatial_shards_partition_the_scan_compactly():
+    """locality-aware sharding (dist.spatial_shards): a partition of the scan into world_size contiguous parts of its Hilbert order --
+    every point in exactly one shard, shard sizes as shard_bounds, and a shard's footprint (occupied 2 m cells) is about 1 / W of the
+    scan's, where a strided shard occupies nearly all of them"""
+    from elimaloc_amd import dist as D
+    world = synth.make_world(200000, seed=1001)
+    sc, _ = synth.make_scan(world, 20001, seed=77)
+    for W in (1, 2, 3, 8):
+        parts = D.spatial_shards(sc, W)
+        assert [len(p) for p in parts] == [D.shard_bounds(len(sc), r, W)[1] - D.shard_bounds(len(sc), r, W)[0] for r in range(W)]
+        allp = np.concatenate(parts)
+        assert sorted(map(tuple, allp)) == sorted(map(tuple, sc))
+    cells = lambda p: len({(int(np.floor(x / 2)), int(np.floor(y / 2))) for x, y, _ in p})  # noqa: E731
+    total = cells(sc)
+    parts = D.spatial_shards(sc, 8)
+    assert max(cells(p) for p in parts) < 0.3 * total          # compact: ~1/8 of the footprint (+ boundary cells)
+    assert cells(sc[0::8]) > 0.6 * total                        # a thinned copy touches most of it
+    # the order is the device's: stable sort by the Hilbert index of the 2 m cell
+    o = D.spatial_order(sc)
+    assert sorted(o) == list(range(len(sc)))

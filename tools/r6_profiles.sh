@@ -12,7 +12,7 @@ for leg in $LEGS; do
     vgicp)  BENCH_ARGS="--method 2" PROF_BATCH=4096 tools/collect_profiles.sh r06_vgicp ;;
     avgicp) BENCH_ARGS="--method 3" PROF_BATCH=4096 tools/collect_profiles.sh r06_avgicp ;;
     hard)   BENCH_ARGS="--guess hard" PROF_BATCH=4096 tools/collect_profiles.sh r06_hard ;;
-    c4)     BENCH_ARGS="--method 2 --scan-points 32768 --map-points 50000000 --slots 256" PROF_BATCH=2048 tools/collect_profiles.sh r06_c4shard ;;
+    c4)     BENCH_ARGS="--method 2 --scan-points 32768 --shard-of 8 --map-points 50000000 --slots 256" PROF_BATCH=2048 tools/collect_profiles.sh r06_c4shard ;;
     field0|field1|field2|field3)  # the field world's legs: 1024 registrations per method (bench.py's `field_world`)
             BENCH_ARGS="--world field --method ${leg#field}" PROF_BATCH=1024 tools/collect_profiles.sh r06_field_m${leg#field} ;;
   esac | tail -1 | cut -c1-400

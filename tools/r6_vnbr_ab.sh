@@ -6,7 +6,7 @@ O=gpurun_out/$TAG
 mkdir -p $O
 python -m pytest tests -m gpu -x -q > $O/gputest.log 2>&1; tail -3 $O/gputest.log
 python bench.py --method 2 --no-cpu --no-extras --steps 5 --warmup 1 > $O/vgicp.json 2> $O/vgicp.err
-python bench.py --method 2 --scan-points 32768 --map-points 50000000 --slots 256 --batch 2048 --no-cpu --no-extras --steps 5 --warmup 1 > $O/c4.json 2> $O/c4.err
+python bench.py --method 2 --scan-points 32768 --shard-of 8 --map-points 50000000 --slots 256 --batch 2048 --no-cpu --no-extras --steps 5 --warmup 1 > $O/c4.json 2> $O/c4.err
 python bench.py --method 3 --no-cpu --no-extras --steps 5 --warmup 1 > $O/avgicp.json 2> $O/avgicp.err
 for f in vgicp c4 avgicp; do python - $O/$f.json <<'PY'
 import json,sys
