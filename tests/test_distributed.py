@@ -271,6 +271,7 @@ def test_spatial_shards_partition_the_scan_compactly():
     every point in exactly one shard, shard sizes as shard_bounds, and a shard's footprint (occupied 2 m cells) is about 1 / W of the
     scan's, where a strided shard occupies nearly all of them"""
     from elimaloc_amd import dist as D
+    from elimaloc_amd import synth
     world = synth.make_world(200000, seed=1001)
     sc, _ = synth.make_scan(world, 20001, seed=77)
     for W in (1, 2, 3, 8):
