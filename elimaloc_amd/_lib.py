@@ -125,7 +125,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void
 
 # every symbol include/elimaloc_hip.h declares (checked by the CPU test-suite)
 EXPORTS = [
-    "elm_reg_config_default", "elm_ctx_create", "elm_ctx_destroy", "elm_last_error", "elm_strerror",
+    "elm_reg_config_default", "elm_ctx_create", "elm_ctx_create_multi", "elm_ctx_group_info", "elm_register_shard", "elm_ctx_destroy", "elm_last_error", "elm_strerror",
     "elm_ctx_synchronize", "elm_ctx_stream", "elm_ctx_set_profiling", "elm_ctx_set_work_counters", "elm_ctx_get_profile", "elm_map_build", "elm_map_destroy", "elm_map_cal_voxel_cov_all",
     "elm_map_cal_point_cov_all", "elm_map_build_neighbourhoods", "elm_map_get_info", "elm_map_empty", "elm_map_download_points",
     "elm_map_download_voxels", "elm_map_find_ground_height", "elm_map_get_correspondences", "elm_align_clouds_local", "elm_scan_upload", "elm_scan_destroy",
@@ -206,6 +206,9 @@ def lib():
     L.elm_reg_config_default.restype = None
     L.elm_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.elm_ctx_destroy.argtypes = [vp]
+    L.elm_ctx_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    L.elm_ctx_group_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
+    L.elm_register_shard.argtypes = [vp, vp, fp, C.c_size_t, C.c_size_t, dp, C.POINTER(RegConfig), C.POINTER(RegResult), C.POINTER(IterTrace), C.c_int]
     L.elm_ctx_destroy.restype = None
     L.elm_last_error.argtypes = [vp]
     L.elm_last_error.restype = C.c_char_p

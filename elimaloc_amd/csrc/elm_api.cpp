@@ -38,6 +38,8 @@ struct elm_scan {
     Pt3* d_pts = nullptr;
     size_t cap_bytes = 0;
     uint32_t n = 0, n_total = 0;
+    std::vector<elm_scan*> shards; // a scan uploaded through a device GROUP (elm_ctx_create_multi): this handle is rank 0's shard, these
+                                   // are the shards of ranks 1 .. N-1 (elm_multi.cpp)
 };
 
 typedef int (*nccl_get_unique_id_t)(void*);
@@ -181,6 +183,8 @@ struct elm_ctx {
     int rank = 0, nranks = 1;
     elm_allreduce_fn hook = nullptr;
     void* hook_user = nullptr;
+    elm_group* group = nullptr; // elm_ctx_create_multi: this context LEADS a group of per-device contexts inside this process (elm_multi.cpp);
+                                // maps built and scans uploaded through it are replicated / sharded over the group, registrations run on all
 };
 
 // Contexts that are alive.  Maps and scans hold a pointer to their context; destroying the context first is legal (e.g. Python
@@ -195,6 +199,10 @@ static bool ctx_alive(const elm_ctx* ctx, uint64_t id) {
     auto it = g_live_ctx.find(ctx);
     return it != g_live_ctx.end() && it->second == id;
 }
+
+// A group's lead context seen from the caller's thread: the public entry points hand the call to elm_multi (which runs it on every
+// rank's own context from that rank's worker thread -- where the same entry points take their plain single-device path).
+static inline bool group_call(const elm_ctx* ctx) { return ctx && ctx->group && !elm_multi::in_worker(); }
 
 #define HIPCHK(ctx, call)                                                                              \
     do {                                                                                               \
@@ -328,6 +336,10 @@ extern "C" int elm_ctx_create(int device_id, elm_ctx** out) {
 
 extern "C" void elm_ctx_destroy(elm_ctx* ctx) {
     if (!ctx) return;
+    if (ctx->group && !elm_multi::in_worker()) { // the group first: its workers, communicators and the other ranks' contexts
+        elm_group* g = ctx->group;
+        elm_multi::destroy(g); // (clears ctx->group)
+    }
     {
         std::lock_guard<std::mutex> lk(g_live_mu);
         if (!g_live_ctx.erase(ctx)) return; // not a live context (double destroy)
@@ -404,6 +416,7 @@ extern "C" int elm_ctx_synchronize(elm_ctx* ctx) {
 struct elm_map {
     elm_ctx* ctx = nullptr;
     uint64_t ctx_id = 0;
+    std::vector<elm_map*> replicas; // built through a device group: the same map on the devices of ranks 1 .. N-1 (this one is rank 0's)
     elm_map_info info{};
     DevMap dm{};
     HashSlot* d_slots = nullptr;
@@ -592,6 +605,8 @@ static void build_host(const float* xyz, size_t n, double voxel_size, int max_po
 
 static void map_free(elm_map* m) {
     if (!m) return;
+    for (elm_map* r : m->replicas) map_free(r);
+    m->replicas.clear();
     if (ctx_alive(m->ctx, m->ctx_id)) (void)hipSetDevice(m->ctx->device); // a context destroyed first: just release the device memory
     void* ptrs[] = {m->d_grid_patch, m->d_grid_tiles, m->d_vox_nk, m->d_bad, m->d_grid_gicp8, m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_vox_cinv, m->d_pt_gicp, m->d_pt_cov, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off, m->d_vqslots, m->d_vq_dense, m->d_vqf_dense, m->d_vface, m->d_vox_rec, m->d_vnbr_blk,
                     m->d_grid_blk, m->d_grid_idx, m->d_grid_start, m->d_vox_stat, m->d_grid_gicp};
@@ -604,6 +619,7 @@ extern "C" int elm_map_build(elm_ctx* ctx, const float* xyz, size_t n, double vo
                              elm_map** out) {
     if (!ctx || !out || (!xyz && n) || !(voxel_size > 0.0) || max_points_per_voxel <= 0 || n > 0xFFFFFFF0ull) return ELM_ERR_INVALID;
     *out = nullptr;
+    if (group_call(ctx)) return elm_multi::map_build(ctx, xyz, n, voxel_size, max_points_per_voxel, out);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HostBuild hb;
     if (n) build_host(xyz, n, voxel_size, max_points_per_voxel, hb);
@@ -685,6 +701,7 @@ static bool full_records_forced() {
 extern "C" int elm_map_cal_voxel_cov_all(elm_map* m) {
     if (!m) return ELM_ERR_INVALID;
     elm_ctx* ctx = m->ctx;
+    if (!m->replicas.empty() && group_call(ctx)) return elm_multi::map_call(m, 0, 0.0);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (!m->d_vox_mean) {
         HIPCHK(ctx, hipMalloc((void**)&m->d_vox_mean, std::max<size_t>((size_t)m->dm.n_vox * 3 * sizeof(double), 256)));
@@ -724,6 +741,7 @@ static int refresh_grid_gicp(elm_map* m);
 extern "C" int elm_map_cal_point_cov_all(elm_map* m, double d_search_dist) {
     if (!m) return ELM_ERR_INVALID;
     elm_ctx* ctx = m->ctx;
+    if (!m->replicas.empty() && group_call(ctx)) return elm_multi::map_call(m, 1, d_search_dist);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (!m->d_pt_gicp) {
         HIPCHK(ctx, hipMalloc((void**)&m->d_pt_gicp, std::max<size_t>((size_t)m->dm.n_pts * 16 * sizeof(double), 256)));
@@ -1490,6 +1508,7 @@ static int build_search_index(elm_map* m, bool* use_grid) {
 }
 extern "C" int elm_map_build_neighbourhoods(elm_map* m) {
     if (!m) return ELM_ERR_INVALID;
+    if (!m->replicas.empty() && group_call(m->ctx)) return elm_multi::map_call(m, 2, 0.0);
     bool g;
     return build_search_index(m, &g);
 }
@@ -1754,11 +1773,20 @@ static int scan_upload_impl(elm_ctx* ctx, const float* xyz, size_t n, size_t n_t
 }
 
 extern "C" int elm_scan_upload(elm_ctx* ctx, const float* xyz, size_t n, size_t n_total, elm_scan** out) {
+    if (group_call(ctx)) { // sharded over the group (the whole scan is handed over: a shard of a shard is not a thing)
+        if (n_total != n) return ELM_ERR_INVALID;
+        return elm_multi::scan_upload(ctx, xyz, n, out);
+    }
     return scan_upload_impl(ctx, xyz, n, n_total, true, true, out);
 }
 
 extern "C" void elm_scan_destroy(elm_scan* s) {
     if (!s || !s->ctx) return; // a handle that is already back in the pool (double destroy)
+    if (!s->shards.empty()) { // a group scan: the other ranks' shards first (each returns to its own context's pool)
+        std::vector<elm_scan*> sh;
+        sh.swap(s->shards);
+        for (elm_scan* q : sh) elm_scan_destroy(q);
+    }
     if (!ctx_alive(s->ctx, s->ctx_id)) { // the context went first (or its address was reused): release the device buffer, nothing to pool
         if (s->d_pts) (void)hipFree(s->d_pts);
         delete s;
@@ -1779,9 +1807,22 @@ extern "C" void elm_scan_destroy(elm_scan* s) {
     if (ctx->scan_free.size() < 64) ctx->scan_free.push_back(s);
     else delete s;
 }
-extern "C" size_t elm_scan_size(const elm_scan* s) { return s ? s->n : 0; }
+extern "C" size_t elm_scan_size(const elm_scan* s) { return !s ? 0 : (s->shards.empty() ? s->n : s->n_total); }
 extern "C" int elm_scan_download(const elm_scan* s, float* xyz, size_t cap) {
     if (!s || !s->ctx || (!xyz && cap)) return ELM_ERR_INVALID;
+    if (!s->shards.empty() && group_call(s->ctx)) { // a group scan: rank 0's shard, then the others', each in its device order
+        size_t done = std::min<size_t>(cap, s->n);
+        elm_scan first = *s; // (a view without the shard list: the plain path below)
+        first.shards.clear();
+        int rc = elm_scan_download(&first, xyz, done);
+        for (const elm_scan* q : s->shards) {
+            if (rc != ELM_OK || done >= cap) break;
+            const size_t k = std::min<size_t>(cap - done, q->n);
+            rc = elm_scan_download(q, xyz + 3 * done, k);
+            done += k;
+        }
+        return rc;
+    }
     elm_ctx* ctx = s->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t n = std::min<size_t>(cap, s->n);
@@ -1880,12 +1921,25 @@ static int choose_path(elm_ctx* ctx, const elm_map* map, const elm_reg_config* c
 // themselves, in input order, as (source index, target index).  The search is the production one -- the QUERY instantiations of the grid /
 // voxel-list kernels (the code the fused accumulate kernels run, minus the sums) -- or, without such an index (ELM_KERNEL=direct / lists, a
 // refused grid) and with ELM_QUERY=direct, the plain walk.
+static int get_correspondences_impl(elm_ctx* ctx, const elm_map* map, int what, const double* xyz, size_t n, double max_dist,
+                                    uint32_t* src_index, int32_t* tgt_index, size_t cap, size_t* n_pairs);
+// (the host staging of these two calls is sized by the caller's n: an allocation failure is a status, never an exception through the C ABI)
 extern "C" int elm_map_get_correspondences(elm_ctx* ctx, const elm_map* map, int what, const double* xyz, size_t n, double max_dist,
                                            uint32_t* src_index, int32_t* tgt_index, size_t cap, size_t* n_pairs) {
+    try {
+        return get_correspondences_impl(ctx, map, what, xyz, n, max_dist, src_index, tgt_index, cap, n_pairs);
+    } catch (const std::bad_alloc&) {
+        if (ctx) ctx->last_error = "elm_map_get_correspondences: host allocation failed";
+        return ELM_ERR_ALLOC;
+    }
+}
+static int get_correspondences_impl(elm_ctx* ctx, const elm_map* map, int what, const double* xyz, size_t n, double max_dist,
+                                    uint32_t* src_index, int32_t* tgt_index, size_t cap, size_t* n_pairs) {
     if (!ctx || !map || what < 0 || what > 2 || (n && !xyz) || !n_pairs || map->ctx != ctx) return ELM_ERR_INVALID;
     *n_pairs = 0;
     if (n == 0) return ELM_OK;
     if (n > 0x7FFFFF00ull) return ELM_ERR_INVALID;
+    if (ctx->in_flight) return ELM_ERR_INVALID; // the context's stream and query scratch belong to the batch in flight
     HIPCHK(ctx, hipSetDevice(ctx->device));
     elm_reg_config cfg;
     elm_reg_config_default(&cfg);
@@ -1963,11 +2017,26 @@ extern "C" int elm_map_get_correspondences(elm_ctx* ctx, const elm_map* map, int
 // Registration::AlignCloudsLocal (method ELM_P2P; reg.cpp:15-66), ::AlignCloudsLocalPointCov (ELM_GICP; :68-152) and
 // ::AlignCloudsLocalVoxelCov (ELM_VGICP / ELM_AVGICP; :154-225) on pairs the caller holds: accumulate on the device with the reference's
 // per-pair arithmetic, solve, return the step.
+static int align_clouds_local_impl(elm_ctx* ctx, int method, const double* src_local, const double* tgt_xyz, const double* tgt_cov9,
+                                   const double* src_cov9, size_t n, const double last_icp_pose[16], double trans_th,
+                                   const elm_reg_config* cfg, double T_out[16], double local_cov[36], double* fitness_score);
 extern "C" int elm_align_clouds_local(elm_ctx* ctx, int method, const double* src_local, const double* tgt_xyz, const double* tgt_cov9,
                                       const double* src_cov9, size_t n, const double last_icp_pose[16], double trans_th,
                                       const elm_reg_config* cfg, double T_out[16], double local_cov[36], double* fitness_score) {
+    try {
+        return align_clouds_local_impl(ctx, method, src_local, tgt_xyz, tgt_cov9, src_cov9, n, last_icp_pose, trans_th, cfg, T_out, local_cov, fitness_score);
+    } catch (const std::bad_alloc&) {
+        if (ctx) ctx->last_error = "elm_align_clouds_local: host allocation failed";
+        return ELM_ERR_ALLOC;
+    }
+}
+static int align_clouds_local_impl(elm_ctx* ctx, int method, const double* src_local, const double* tgt_xyz, const double* tgt_cov9,
+                                   const double* src_cov9, size_t n, const double last_icp_pose[16], double trans_th,
+                                   const elm_reg_config* cfg, double T_out[16], double local_cov[36], double* fitness_score) {
     if (!ctx || !last_icp_pose || !T_out || method < ELM_P2P || method > ELM_AVGICP || (n && (!src_local || !tgt_xyz))) return ELM_ERR_INVALID;
     if (n && method != ELM_P2P && !tgt_cov9) return ELM_ERR_INVALID;
+    if (n > 0x7FFFFF00ull) return ELM_ERR_INVALID; // (the same bound as elm_map_get_correspondences: the pairs of one scan)
+    if (ctx->in_flight) return ELM_ERR_INVALID;    // the context's stream and scratch belong to the batch in flight
     elm_reg_config dflt;
     if (!cfg) { elm_reg_config_default(&dflt); cfg = &dflt; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1986,8 +2055,8 @@ extern "C" int elm_align_clouds_local(elm_ctx* ctx, int method, const double* sr
     a.use_src_cov = (cfg->use_radar_cov != 0 && src_cov9 && method != ELM_P2P) ? 1 : 0;
     // staging: positions as they are, covariances column-major -> row-major
     const bool cov = method != ELM_P2P;
-    std::vector<double> stage;
-    auto transposed = [&](const double* c9) {
+    std::vector<double> stage_t, stage_s; // one per upload: both are read by asynchronous copies until the synchronisation below
+    auto transposed = [&](const double* c9, std::vector<double>& stage) {
         stage.resize(n * 9);
         for (size_t i = 0; i < n; ++i)
             for (int r = 0; r < 3; ++r)
@@ -2002,16 +2071,17 @@ extern "C" int elm_align_clouds_local(elm_ctx* ctx, int method, const double* sr
     if ((rc = dev_reserve(ctx, ctx->d_q3, kAlignOut * sizeof(double))) != ELM_OK) return rc;
     double *d_src = (double*)ctx->d_q0.p, *d_tgt = (double*)ctx->d_q1.p, *d_part = (double*)ctx->d_q2.p, *d_out = (double*)ctx->d_q3.p;
     double *d_cov = nullptr, *d_scov = nullptr;
-    if (n) HIPCHK(ctx, hipMemcpy(d_src, src_local, n * 3 * sizeof(double), hipMemcpyHostToDevice));
-    if (n) HIPCHK(ctx, hipMemcpy(d_tgt, tgt_xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice));
+    // uploads on the context's stream, like the launch behind them (the stream is non-blocking: nothing orders it after the null stream)
+    if (n) HIPCHK(ctx, hipMemcpyAsync(d_src, src_local, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (n) HIPCHK(ctx, hipMemcpyAsync(d_tgt, tgt_xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     if (cov && n) {
         if ((rc = dev_reserve(ctx, ctx->d_q4, n * 9 * sizeof(double))) != ELM_OK) return rc;
         d_cov = (double*)ctx->d_q4.p;
-        HIPCHK(ctx, hipMemcpy(d_cov, transposed(tgt_cov9), n * 9 * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpyAsync(d_cov, transposed(tgt_cov9, stage_t), n * 9 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         if (a.use_src_cov) {
             if ((rc = dev_reserve(ctx, ctx->d_q5, n * 9 * sizeof(double))) != ELM_OK) return rc;
             d_scov = (double*)ctx->d_q5.p;
-            HIPCHK(ctx, hipMemcpy(d_scov, transposed(src_cov9), n * 9 * sizeof(double), hipMemcpyHostToDevice));
+            HIPCHK(ctx, hipMemcpyAsync(d_scov, transposed(src_cov9, stage_s), n * 9 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         }
     }
     double out[kAlignOut];
@@ -2312,6 +2382,7 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
 }
 extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_scan* const* scans, int batch,
                                           const double* T0, const elm_reg_config* cfg, int want_trace) {
+    if (group_call(ctx)) { ctx->last_error = "elm_register_batch_enqueue: not available on a device group (use elm_register_batch / _stream)"; return ELM_ERR_UNSUPPORTED; }
     return batch_enqueue_impl(ctx, map, scans, batch, T0, cfg, want_trace, nullptr);
 }
 
@@ -2385,6 +2456,7 @@ extern "C" int elm_register_batch_finish(elm_ctx* ctx, elm_reg_result* results, 
 
 extern "C" int elm_register_batch(elm_ctx* ctx, const elm_map* map, elm_scan* const* scans, int batch, const double* T0,
                                   const elm_reg_config* cfg, elm_reg_result* results, elm_iter_trace* trace) {
+    if (group_call(ctx)) return elm_multi::reg_batch(ctx, map, scans, batch, T0, cfg, 0, results, trace);
     int rc = elm_register_batch_enqueue(ctx, map, scans, batch, T0, cfg, trace != nullptr);
     if (rc != ELM_OK) return rc;
     return elm_register_batch_finish(ctx, results, trace);
@@ -2397,6 +2469,7 @@ extern "C" int elm_register_batch(elm_ctx* ctx, const elm_map* map, elm_scan* co
 extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* const* scans, int count, const double* T0,
                                    const elm_reg_config* cfg, int slots, elm_reg_result* results, elm_iter_trace* trace) {
     if (!ctx || !map || !scans || count <= 0 || !T0 || !cfg || slots <= 0) return ELM_ERR_INVALID;
+    if (group_call(ctx)) return elm_multi::reg_batch(ctx, map, scans, count, T0, cfg, slots, results, trace);
     if (map->dm.n_vox == 0 || cfg->max_iteration <= 0) // nothing iterates: the lockstep path handles the degenerate cases
         return elm_register_batch(ctx, map, scans, count, T0, cfg, results, trace);
     if (map->ctx != ctx) return ELM_ERR_INVALID;
@@ -2938,14 +3011,17 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
     return ELM_OK;
 }
 
-extern "C" int elm_register(elm_ctx* ctx, const elm_map* map, const float* scan_xyz, size_t n, const double T0[16],
-                            const elm_reg_config* cfg, double T_out[16], int* is_success, double* fitness_score,
-                            double local_cov[36], elm_reg_result* result, elm_iter_trace* trace) {
-    if (!ctx || !map || !T0 || !cfg) return ELM_ERR_INVALID;
+// RunRegister on host buffers; n_total > n: this context holds a SHARD of an n_total-point scan (a rank of a process-per-GPU job, or a
+// rank of a device group: elm_multi.cpp) -- the sums are exchanged, the overlap gate is taken against n_total.  quiet: no log text (only one
+// rank of a job prints what RunRegister prints).
+static int register_impl(elm_ctx* ctx, const elm_map* map, const float* scan_xyz, size_t n, size_t n_total, const double T0[16],
+                         const elm_reg_config* cfg, double T_out[16], int* is_success, double* fitness_score,
+                         double local_cov[36], elm_reg_result* result, elm_iter_trace* trace, bool quiet) {
+    if (!ctx || !map || !T0 || !cfg || n_total < n) return ELM_ERR_INVALID;
     elm_scan* s = nullptr;
     // the caller's point order (see scan_upload_impl); no wait between the upload and the iterations: the pinned staging buffer is
     // not touched again before elm_register_batch has synchronised the stream
-    int rc = scan_upload_impl(ctx, scan_xyz, n, n, false, false, &s);
+    int rc = scan_upload_impl(ctx, scan_xyz, n, n_total, false, false, &s);
     if (rc != ELM_OK) return rc;
     elm_reg_result res;
     // b_debug_print (reg.cpp:343-347, 396-403): the reference's per-iteration and total timing lines need the iteration trace and one
@@ -2972,14 +3048,16 @@ extern "C" int elm_register(elm_ctx* ctx, const elm_map* map, const float* scan_
     if (rc != ELM_OK) (void)hipStreamSynchronize(ctx->stream); // the upload may still be reading the pinned staging buffer
     elm_scan_destroy(s);
     if (rc != ELM_OK) return rc;
-    if (dbg || res.gate != 0) {
+    if ((dbg || res.gate != 0) && !quiet) {
         // what RunRegister writes to stdout (elm_format_register_log): warnings always, the timing lines with b_debug_print
         const double total_ms = dbg ? std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_begin).count() / 1000.0 : 0.0;
         std::vector<double> corr(ctx->iter_acc_ms);
         corr.resize((size_t)std::max(res.iterations, 0), 0.0);
-        char text[4096];
-        elm_format_register_log(cfg, &res, n, dbg ? tr : nullptr, dbg ? corr.data() : nullptr, total_ms, text, sizeof(text));
-        fputs(text, stdout);
+        // sized from the text itself (up to ELM_MAX_ITER_TRACE per-iteration lines of ~95 bytes: a fixed 4 KB buffer cut the totals off)
+        const size_t need = elm_format_register_log(cfg, &res, n_total, dbg ? tr : nullptr, dbg ? corr.data() : nullptr, total_ms, nullptr, 0);
+        std::vector<char> text(need + 1);
+        elm_format_register_log(cfg, &res, n_total, dbg ? tr : nullptr, dbg ? corr.data() : nullptr, total_ms, text.data(), text.size());
+        fputs(text.data(), stdout);
         fflush(stdout);
     }
     if (T_out) memcpy(T_out, res.T, sizeof(res.T));
@@ -2989,6 +3067,30 @@ extern "C" int elm_register(elm_ctx* ctx, const elm_map* map, const float* scan_
     if (result) *result = res;
     return ELM_OK;
 }
+extern "C" int elm_register(elm_ctx* ctx, const elm_map* map, const float* scan_xyz, size_t n, const double T0[16],
+                            const elm_reg_config* cfg, double T_out[16], int* is_success, double* fitness_score,
+                            double local_cov[36], elm_reg_result* result, elm_iter_trace* trace) {
+    if (group_call(ctx)) return elm_multi::reg(ctx, map, scan_xyz, n, T0, cfg, T_out, is_success, fitness_score, local_cov, result, trace);
+    return register_impl(ctx, map, scan_xyz, n, n, T0, cfg, T_out, is_success, fitness_score, local_cov, result, trace, false);
+}
+extern "C" int elm_register_shard(elm_ctx* ctx, const elm_map* map, const float* shard_xyz, size_t n, size_t n_total, const double T0[16],
+                                  const elm_reg_config* cfg, elm_reg_result* result, elm_iter_trace* trace, int quiet) {
+    if (!result) return ELM_ERR_INVALID;
+    if (group_call(ctx)) return ELM_ERR_INVALID; // a group shards for itself
+    return register_impl(ctx, map, shard_xyz, n, n_total, T0, cfg, nullptr, nullptr, nullptr, nullptr, result, trace, quiet != 0);
+}
+
+// accessors for elm_multi.cpp (the structs live in this file)
+namespace elm_host {
+elm_group*& ctx_group(elm_ctx* ctx) { return ctx->group; }
+int ctx_device(const elm_ctx* ctx) { return ctx->device; }
+void ctx_set_error(elm_ctx* ctx, const std::string& text) { if (ctx) ctx->last_error = text; }
+std::vector<elm_map*>& map_replicas(elm_map* m) { return m->replicas; }
+elm_ctx* map_ctx(const elm_map* m) { return m->ctx; }
+std::vector<elm_scan*>& scan_shards(elm_scan* s) { return s->shards; }
+elm_ctx* scan_ctx(const elm_scan* s) { return s->ctx; }
+void scan_set_total(elm_scan* s, size_t n_total) { s->n_total = (uint32_t)n_total; }
+} // namespace elm_host
 
 // ------------------------------------------------------------------------------------------------------
 // deskew
@@ -3149,6 +3251,10 @@ int callback_register(elm_ctx* ctx, const elm_map* map, const void* stage, const
     if (!ctx || !map || !stage || stage != ctx->h_stage || !rel_time || !tab || !T0 || !cfg || !result || !n_source || !unpackable || n == 0 ||
         n > 0x7FFFFFFFull)
         return ELM_ERR_INVALID;
+    if (group_call(ctx)) { // the node callback registers ~10 k downsampled points: one device's work (create a plain context for it)
+        ctx->last_error = "elm_pcm_callback_point_cloud: not available on a device group";
+        return ELM_ERR_UNSUPPORTED;
+    }
     *unpackable = 0;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc;
@@ -3359,6 +3465,7 @@ extern "C" int elm_comm_get_unique_id(void* id_bytes) {
 
 extern "C" int elm_comm_init(elm_ctx* ctx, int rank, int nranks, const void* id_bytes) {
     if (!ctx || !id_bytes || nranks < 1 || rank < 0 || rank >= nranks) return ELM_ERR_INVALID;
+    if (group_call(ctx)) { ctx->last_error = "elm_comm_init: a device group exchanges among its own ranks"; return ELM_ERR_INVALID; }
     if (!load_rccl(&ctx->last_error)) return ELM_ERR_COMM;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     elm_nccl_id id;

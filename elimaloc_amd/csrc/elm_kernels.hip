@@ -3218,6 +3218,14 @@ constexpr int kSolveThreads = 1024;
 // NT = 1024 threads (default) or 256 (half-set streams: a workgroup of 4 waves and <= 80 VGPRs fits the slot a retiring accumulate
 // workgroup frees, so the solve can run beside the other half's accumulate launch).  The reduction always adds the partial records in
 // the order of 32 groups of 32 lanes -- 256 threads walk four of those groups each -- so the sums do not depend on NT.
+// id of a slot's (registration, iteration) in the exchanged record (RegParams::rank_check).  The registration index enters modulo 2^19 so
+// that n id^2 stays an exact integer in a double for any number of registrations per call (id < 2^23 + 16, id^2 < 2^47, n <= 64 ranks:
+// below 2^53); an idle slot (registration -1) has id = iteration & 15.  Two ranks that swap registrations r and r + 2^19 k in one slot, or
+// that swap two registrations between two slots while each slot agrees with itself across the ranks, are not told apart: the check sees
+// ranks that DISAGREE about a slot, which is what a broken collective or a non-deterministic solve produces.
+__device__ __forceinline__ double rank_check_id(int reg, int iters) {
+    return 16.0 * (double)((reg < 0 ? -1 : (reg & 0x7FFFF)) + 1) + (double)(iters & 15);
+}
 template <int NT>
 __global__ __launch_bounds__(NT, NT == 256 ? 6 : 1) void k_solve(const ScanDesc* scans, ScanState* st,
                                                          const double* __restrict__ partials, double* sums,
@@ -3329,7 +3337,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : 1) void k_solve(const ScanDesc*
             for (int q = 1; q < kSolveThreads / 32; ++q) a += part[q][t];
             if (mode == 1) {
                 if (rp.rank_check && t >= 29) { // (1, id, id^2) in the slots of the work counters (zero in production): see RegParams::rank_check
-                    const double id = 16.0 * (double)(S.reg + 1) + (double)(S.iters & 15);
+                    const double id = rank_check_id(S.reg, S.iters);
                     a = (t == 29) ? 1.0 : (t == 30) ? id : id * id;
                 }
                 sums[(size_t)s * kSums + t] = a; // zeros for finished scans keep the all-reduce buffer defined
@@ -3354,7 +3362,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : 1) void k_solve(const ScanDesc*
     if (mode == 2 && rp.rank_check && !radar) {
         // every rank must be iterating the same registration (and iteration) in this slot: exact integer arithmetic in doubles
         const double n = sums[(size_t)s * kSums + 29], a1 = sums[(size_t)s * kSums + 30], a2 = sums[(size_t)s * kSums + 31];
-        const double id = 16.0 * (double)(S.reg + 1) + (double)(S.iters & 15);
+        const double id = rank_check_id(S.reg, S.iters);
         if (t == 0 && !(n >= 1.0 && a1 == n * id && a2 == n * id * id)) atomicOr(active + 1, 1);
         if (t >= 29 && t < 32) tot[t] = 0.0; // (they are not work counters)
         __builtin_amdgcn_s_waitcnt(0);

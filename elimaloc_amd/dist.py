@@ -33,8 +33,9 @@ def pack_sums(JTJ, JTr, residual_sum, n_corr, counters=(0.0, 0.0, 0.0)):
 
 
 def rank_check_id(registration, iteration):
-    """id of a slot's (registration, iteration) as the solve packs it; an idle slot (registration -1) has id = iteration & 15"""
-    return 16.0 * (registration + 1) + (iteration & 15)
+    """id of a slot's (registration, iteration) as the solve packs it; an idle slot (registration -1) has id = iteration & 15.  The
+    registration enters modulo 2^19: n id^2 stays an exact integer in a double for any number of registrations per call (n <= 64 ranks)"""
+    return 16.0 * ((registration & 0x7FFFF if registration >= 0 else -1) + 1) + (iteration & 15)
 
 
 def rank_check_values(registration, iteration):

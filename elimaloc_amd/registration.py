@@ -46,13 +46,32 @@ def _colmajor16(T):
 
 
 class Context:
-    """One GPU, one HIP stream (one process per GPU).  elm_ctx_create fails without a gfx950 device."""
+    """One GPU, one HIP stream -- or, Context.multi([0, 1, ...]), the LEAD context of a device group: N GPUs inside this process, maps
+    replicated, scans sharded, one all-reduce of the packed sums per ICP iteration (elm_ctx_create_multi).  elm_ctx_create fails without a
+    gfx950 device."""
 
-    def __init__(self, device_id=0):
+    def __init__(self, device_id=0, _devices=None):
         self._h = C.c_void_p()
-        check(_lib.lib().elm_ctx_create(device_id, C.byref(self._h)), None, "elm_ctx_create")
+        if _devices is None:
+            check(_lib.lib().elm_ctx_create(device_id, C.byref(self._h)), None, "elm_ctx_create")
+        else:
+            ids = (C.c_int * len(_devices))(*[int(d) for d in _devices])
+            check(_lib.lib().elm_ctx_create_multi(ids, len(_devices), C.byref(self._h)), None, "elm_ctx_create_multi")
+            device_id = int(_devices[0])
         self.device_id = device_id
         self._hook_ref = None
+
+    @classmethod
+    def multi(cls, device_ids):
+        """the lead context of a device group over device_ids (an id may repeat: ranks sharing a GPU exchange through host memory)"""
+        return cls(_devices=list(device_ids))
+
+    def group_info(self):
+        """(ranks, exchange, device ids): exchange 0 = a plain context, 1 = RCCL, 2 = host memory"""
+        n, ex = C.c_int(0), C.c_int(0)
+        ids = (C.c_int * 64)()
+        check(_lib.lib().elm_ctx_group_info(self._h, C.byref(n), C.byref(ex), ids, 64), self._h, "elm_ctx_group_info")
+        return n.value, ex.value, [ids[i] for i in range(n.value)]
 
     def close(self):
         if getattr(self, "_h", None):
@@ -116,7 +135,17 @@ class Context:
         if fn is None:
             self._hook_ref = _lib.ALLREDUCE_FN(0)
         else:
-            self._hook_ref = _lib.ALLREDUCE_FN(lambda p, n, s, u: int(fn(p, n, s)))
+            self.hook_error = None
+
+            def call(p, n, s, u):
+                # an exception must not escape a ctypes callback (it would be printed and swallowed, the exchange reported as done): the
+                # call that is exchanging ends with ELM_ERR_COMM "allreduce hook failed" and the exception is kept in hook_error
+                try:
+                    return int(fn(p, n, s))
+                except BaseException as e:  # noqa: BLE001
+                    self.hook_error = e
+                    return 1
+            self._hook_ref = _lib.ALLREDUCE_FN(call)
         check(_lib.lib().elm_comm_set_hook(self._h, self._hook_ref, None), self._h, "elm_comm_set_hook")
 
 
@@ -448,8 +477,13 @@ class Registration:
 
     def RunRegisterBatch(self, scans, voxel_map, initial_guesses, m_config=None, trace=False):
         """Many resident scans against one map, iterated together. Returns a list of result dicts."""
-        self.EnqueueBatch(scans, voxel_map, initial_guesses, m_config, trace)
-        return self.FinishBatch()
+        cfg = m_config if m_config is not None else self.config_
+        B = len(scans)
+        arr, T0 = self.pack_inputs(scans, initial_guesses)
+        res = (RegResult * B)()
+        tr = (IterTrace * (_lib.MAX_ITER_TRACE * B))() if trace else None
+        check(_lib.lib().elm_register_batch(self.ctx._h, voxel_map._handle(), arr, B, _dp(T0), C.byref(cfg), res, tr), self.ctx._h, "elm_register_batch")
+        return [_result_dict(res[b], tr[b * _lib.MAX_ITER_TRACE:(b + 1) * _lib.MAX_ITER_TRACE] if trace else None) for b in range(B)]
 
     @staticmethod
     def pack_inputs(scans, initial_guesses):

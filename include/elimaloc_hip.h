@@ -336,8 +336,10 @@ int elm_voxel_downsample(const float* xyz, size_t n, double voxel_size, int64_t*
 int elm_get_interpolated_pose(const double* odom14, size_t n_odom, double d_cur_time, float T_out[16], int* ok);
 /* Registration::CalFramePointCov / CalPointCov (registration.hpp:186-217; called at registration.cpp:302-305 under use_radar_cov): the
  * covariance term R S of every source point from its position (map frame under the initial guess at the call site) and the range /
- * azimuth / elevation spreads.  cov9: n column-major 3x3 (not symmetric).  Host arithmetic; elm_register evaluates the same function
- * inside its radar kernel. */
+ * azimuth / elevation spreads.  cov9: n column-major 3x3 (not symmetric).  Host arithmetic (glibc sin / cos / atan2); elm_register
+ * evaluates the same formula inside its radar kernel with the device's math library: the two agree to a few ulp, not bit for bit, so a
+ * RunRegister re-assembled from this call + GetCorrespondences* + AlignCloudsLocal* under use_radar_cov follows elm_register to the
+ * tolerance of the sums (1e-9; an ill-conditioned first-iteration metric amplifies the difference), not to the last bit. */
 int elm_cal_frame_point_cov(const double* xyz, size_t n, double range_var_m, double azim_var_deg, double ele_var_deg, double* cov9);
 
 /* Covariance of the published odometry (PublishPcmOdom pcm.cpp:1082-1098, NormalizeCovariance pcm.hpp:248-268):
@@ -466,7 +468,34 @@ int elm_pcm_callback_point_cloud(elm_ctx* ctx, const elm_map* map, const elm_pcm
                                  size_t n_imu, const double* odom14, size_t n_odom, elm_pcm_scan_output* out, int* published);
 
 /* ---------------------------------------------------------------- multi-GPU ----------------------- */
-/* One process per GPU.  Rank 0 obtains an id, the host distributes its bytes (e.g. torch.distributed
+/* (a) ONE process, N GPUs -- a device group (elm_ctx_create(device_ids[], n, &ctx); the reference's pcm_matching node is
+ * one process that calls Registration::RunRegister, pcm.cpp:280-282).  elm_ctx_create_multi creates one context per entry of device_ids
+ * and returns the first as the group's LEAD context; everything else keeps its signature.  On the lead:
+ *   elm_map_build / elm_map_cal_voxel_cov_all / elm_map_cal_point_cov_all / elm_map_build_neighbourhoods   the map is REPLICATED on every
+ *       device (the handle is rank 0's replica: read-backs, elm_map_get_correspondences, elm_map_find_ground_height work on it);
+ *   elm_scan_upload          the scan is ordered along the ordering kernel's Hilbert curve and cut into N contiguous SHARDS, one per
+ *       device (locality-aware sharding: a rank holds a compact sector of the scan at full density); elm_scan_size = the whole scan;
+ *   elm_register             RunRegister on host buffers: the caller's point order cut into N contiguous shards;
+ *   elm_register_batch / elm_register_stream   on scans uploaded through the lead;
+ *   every ICP iteration all-reduces the ranks' packed normal equations (ONE ncclAllReduce(double, sum) of ELM_PACKED_SUMS doubles per
+ *       scan over the communicators the ranks form among themselves -- RCCL over xGMI -- each rank driven by its own host thread) and
+ *       every rank solves the same sums; the ranks' results are compared bit for bit (ELM_ERR_COMM if they differ);
+ *   elm_ctx_destroy          destroys the group.
+ * Not available on a group (ELM_ERR_UNSUPPORTED): elm_register_stream_host, elm_register_batch_enqueue / _finish,
+ * elm_pcm_callback_point_cloud (the node callback registers ~10 k downsampled points: one device's work -- use a plain context).
+ * A device id may repeat ({0, 0}: two ranks on one GPU).  RCCL refuses two ranks on one device; such a group exchanges through
+ * page-locked host memory (sum in rank order) -- the form a one-GPU box can test.  ELM_GROUP_EXCHANGE=host | rccl forces either.
+ * n = 1 returns a plain context. */
+int elm_ctx_create_multi(const int* device_ids, int n, elm_ctx** out);
+/* ranks of the group a context leads (1: a plain context), its exchange (0 none, 1 RCCL, 2 host memory), its devices */
+int elm_ctx_group_info(elm_ctx* ctx, int* n_ranks, int* exchange, int* device_ids, int cap);
+/* RunRegister on ONE RANK's shard of an n_total-point scan (host buffers, the caller's point order): what a rank of a process-per-GPU
+ * job (b) calls where the one-GPU caller calls elm_register -- the sums are exchanged over the context's communicator / hook, the overlap
+ * gate (reg.cpp:351) is taken against n_total.  quiet != 0: RunRegister's log text is not printed (one rank of a job prints it). */
+int elm_register_shard(elm_ctx* ctx, const elm_map* map, const float* shard_xyz, size_t n, size_t n_total, const double T0[16],
+                       const elm_reg_config* cfg, elm_reg_result* result, elm_iter_trace* trace, int quiet);
+
+/* (b) One process per GPU.  Rank 0 obtains an id, the host distributes its bytes (e.g. torch.distributed
  * broadcast), every rank calls elm_comm_init.  Afterwards elm_register_batch* sums the packed normal
  * equations of every scan over all ranks with ONE ncclAllReduce(double, sum) per ICP iteration (RCCL/xGMI).
  * RCCL is dlopen'ed ("librccl.so.1") on first use, a single-GPU process never needs it. */

@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950); run with -m gpu on the GPU box")
+    # an exception that escapes a ctypes callback / a finaliser is a failure, not a warning
+    config.addinivalue_line("filterwarnings", "error::pytest.PytestUnraisableExceptionWarning")
     # a fresh checkout has no in-tree libelimaloc_hip.so (it is git-ignored): build it once (hipcc cross-compiles without a GPU)
     lib = os.path.join(ROOT, "elimaloc_amd", "libelimaloc_hip.so")
     if not os.path.exists(lib) and os.path.exists("/opt/rocm/bin/hipcc"):

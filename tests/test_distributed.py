@@ -287,3 +287,20 @@ def test_spatial_shards_partition_the_scan_compactly():
     # the order is the device's: stable sort by the Hilbert index of the 2 m cell
     o = D.spatial_order(sc)
     assert sorted(o) == list(range(len(sc)))
+
+
+def test_rank_check_id_stays_exact_for_any_registration_count():
+    """n id^2 must be an exact integer in a double whatever the registration index (the index enters modulo 2^19)"""
+    from elimaloc_amd.dist import rank_check_id, rank_check_values, rank_check_ok
+    for reg in (-1, 0, 1, 2**19 - 1, 2**19, 3 * 2**19 + 5, 2**31 - 1):
+        for it in (0, 9, 31):
+            i = rank_check_id(reg, it)
+            assert i < 2**23 + 16 and float(int(i)) == i
+            for n in (1, 2, 8, 64):
+                rec = np.zeros(32)
+                for _ in range(n):  # the all-reduce: n ranks add the same triple (any summation tree: every partial sum is exact)
+                    rec[29:32] += rank_check_values(reg, it)
+                assert rec[31] == n * i * i < 2**53 and rank_check_ok(rec, reg, it)
+                rec[30] += 16.0  # one rank iterated the next registration in this slot
+                assert not rank_check_ok(rec, reg, it)
+    assert rank_check_id(-1, 3) == 3.0 and rank_check_id(0, 0) == 16.0
