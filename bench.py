@@ -137,7 +137,7 @@ def generate_inputs(world, args, rank, world_size, dist, guess, n_keep, keep_own
     from concurrent.futures import ThreadPoolExecutor
     from elimaloc_amd import synth
     from elimaloc_amd import dist as elm_dist
-    n_batch = args.batch * world_size
+    n_batch = args.batch * world_size * max(1, int(getattr(args, "group_ranks", 1)))  # (a device group: one process generates every scan whole)
     npts = args.scan_points
 
     def gen(i):
@@ -516,9 +516,11 @@ def driver_line(full):
                     ("host_fed", ("value", "pcie_achieved_gbs", "pcie_h2d_probe_gbs", "frac_of_pcie_probe", "bit_identical_to_resident")),
                     ("reference_api", ("registrations_per_s", "ms_per_call_median")),
                     ("replica", ("value", "max_abs_pose_diff_vs_sharded")),
-                    ("single_process", ("value", "devices", "max_abs_pose_diff_vs_ranks"))):
+                    ("single_process", ("value", "devices", "batch_per_gpu", "rccl_ranks", "max_abs_pose_diff_vs_ranks", "iterations_match", "wall_s"))):
         if isinstance(full.get(k), dict):
             line[k] = _pick(full[k], keys)
+    if isinstance(full.get("single_process"), dict) and full["single_process"].get("error"):
+        line["single_process"]["error"] = str(full["single_process"]["error"])[-120:]
     if isinstance(full.get("hard_guess"), dict) and isinstance(full["hard_guess"].get("pose_err_vs_cpu"), dict):
         hp = _compact_pose(full["hard_guess"]["pose_err_vs_cpu"])
         line["hard_guess"].update({"pose_max_m": hp.get("max_trans_m"), "flags_match": hp.get("iterations_and_flags_match"), "pair_mismatches": hp.get("pair_mismatches")})
@@ -564,6 +566,45 @@ def emit(full, path=None):
     print(blob, file=sys.stderr, flush=True)
     print(text, flush=True)
     return text
+
+
+def single_process_leg(args, n, out, timeout_s=300):
+    """The same N GPUs driven by ONE process (a device group, `bench.py --single-process`) -- the reference node's process model -- as a
+    CHILD process of rank 0 after this job's own timed region, bounded by a timeout: a smaller batch at the same slots, its poses compared
+    with this job's for the same registrations.  Any failure is reported in the record, never raised (the job's own line must not depend
+    on it)."""
+    import subprocess
+    import tempfile
+    d = tempfile.mkdtemp(prefix="elm_sp_")
+    poses = os.path.join(d, "poses.npz")
+    per_gpu = min(512, args.batch)
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n), "--single-process", "--batch", str(per_gpu), "--steps", "5", "--warmup", "1",
+           "--method", str(args.method), "--scan-points", str(args.scan_points), "--map-points", str(args.map_points), "--slots", str(args.slots),
+           "--guess", args.guess, "--world", args.world, "--dump-poses", poses]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+                                                            "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "GROUP_WORLD_SIZE", "ROLE_NAME")}
+    t0 = time.time()
+    rec = {"batch_per_gpu": per_gpu, "devices": n}
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            rec["error"] = (r.stderr or r.stdout)[-300:]
+            rec["returncode"] = r.returncode
+        else:
+            line = json.loads(lines[-1])
+            rec.update({"value": line.get("value"), "ms_per_step": line.get("ms_per_step"), "rccl_ranks": line.get("rccl_ranks"),
+                        "process_model": (line.get("config") or {}).get("process_model"),
+                        "avg_launch_ms": (line.get("roofline") or {}).get("avg_launch_ms")})
+            z = np.load(poses)
+            k = min(len(z["T"]), len(out))
+            rec["registrations_compared"] = int(k)
+            rec["max_abs_pose_diff_vs_ranks"] = float(max(np.abs(z["T"][i] - out[i]["T"]).max() for i in range(k))) if k else None
+            rec["iterations_match"] = bool(all(int(z["iterations"][i]) == out[i]["iterations"] for i in range(k)))
+    except Exception as e:  # noqa: BLE001
+        rec["error"] = repr(e)[-300:]
+    rec["wall_s"] = time.time() - t0
+    return rec
 
 
 def host_cpu_info():
@@ -665,12 +706,20 @@ def main():
                     "carry the antisymmetric side records")
     ap.add_argument("--shard-of", type=int, default=1, help="K > 1: every registration is shard i mod K (dist.spatial_shards) of a K x --scan-points scan: one rank's "
                     "launches of a K-GPU run as registrations of their own (the C4_shard leg's shape; N = 1 only)")
+    ap.add_argument("--single-process", action="store_true", help="the N GPUs as ONE process: a device group (elm_ctx_create_multi) instead of one rank per GPU -- "
+                    "the process model of the reference's node (one process calling RunRegister); same per-GPU operating point; no CPU / extras legs")
+    ap.add_argument("--devices", default="", help="--single-process: comma list of device ids (default 0..N-1; an id may repeat: ranks sharing a GPU exchange "
+                    "through host memory -- the one-GPU test form)")
+    ap.add_argument("--dump-poses", default="", help="write the final poses / iteration counts of the last step to this .npz (rank 0)")
     ap.add_argument("--dry-launch", action="store_true", help="launcher + rendezvous + sharded input generation only, gloo, no GPU (CPU test of the N > 1 path)")
     args = ap.parse_args()
     extras = not (args.no_extras or args.no_latency)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
-    if args.gpus > 1 and "RANK" not in os.environ:
+    if args.single_process:
+        extras = False
+        args.no_cpu = True
+    if args.gpus > 1 and "RANK" not in os.environ and not args.single_process:
         launch_ranks(args, sys.argv[1:])  # does not return
 
     # stdout carries exactly ONE JSON line: everything libraries print (RCCL banners, gloo notices) goes to stderr
@@ -683,9 +732,13 @@ def main():
     import torch.distributed as dist
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    devices = [int(x) for x in args.devices.split(",") if x.strip()] if args.devices else list(range(args.gpus))
+    if args.single_process:
+        if world_size != 1 or len(devices) != args.gpus:
+            raise SystemExit(f"--single-process: one process drives the {args.gpus} GPUs (WORLD_SIZE {world_size}, --devices {devices})")
     # --gpus IS the number of ranks, whoever launched them (the driver's torch.distributed.run for N > 1, launch_ranks above, plain
     # python for N = 1): a mismatch is an error, never a silently smaller run
-    if args.gpus != world_size:
+    elif args.gpus != world_size:
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world_size}: launch one rank per GPU (python bench.py --gpus N does it itself)")
     if args.batch <= 0:
         args.batch = 4096  # the SAME per-GPU operating point at every N (registrations per slot do not change along the scaling curve)
@@ -693,7 +746,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # launched by torch.distributed.run (RANK set): take the collective path even for one rank, so that a 1-GPU box
     # exercises exactly the code the 8-GPU node runs
-    distributed = world_size > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    distributed = (world_size > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)) and not args.single_process
+    ranks = len(devices) if args.single_process else world_size  # GPUs that share every registration
     if args.dry_launch:
         if distributed:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -708,6 +762,8 @@ def main():
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback")
+    if args.single_process and max(devices) >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py --single-process --devices {devices}: {torch.cuda.device_count()} GPU(s) visible")
     if torch.cuda.device_count() < world_size or local_rank >= torch.cuda.device_count():
         raise SystemExit(f"bench.py --gpus {args.gpus}: {torch.cuda.device_count()} GPU(s) visible to rank {rank} (local rank {local_rank}); one rank per GPU is the only mode")
     torch.cuda.set_device(local_rank)
@@ -721,8 +777,15 @@ def main():
                                            results_from_raw)
 
     method = IcpMethod(args.method)
-    ctx = Context(local_rank)
+    ctx = Context.multi(devices) if args.single_process else Context(local_rank)
     rccl_ranks, rank_table = None, None
+    group_exchange = None
+    if args.single_process:
+        g_ranks, g_ex, g_dev = ctx.group_info()
+        if g_ranks != len(devices):
+            raise SystemExit(f"device group reports {g_ranks} ranks, expected {len(devices)}")
+        group_exchange = {0: "none", 1: "rccl", 2: "host"}[g_ex]
+        rccl_ranks = g_ranks if g_ex == 1 else None  # (elm_ctx_create_multi verified ncclCommCount / ncclCommUserRank of every rank's communicator)
     if distributed:
         ids = [Context.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
@@ -801,18 +864,18 @@ def main():
         kname = kernel_name_for(m, grid_, os.environ.get("ELM_KERNEL", ""))
         launches_ = max(prof_["accumulate_launches"], 1)
         acc_ms_ = prof_["accumulate_ms"] / launches_
-        upl = (pt_iters_ / world_size) * steps_ / launches_  # units one launch processes ON THIS GPU = its shard of the batch's live points
+        upl = (pt_iters_ / ranks) * steps_ / launches_  # units one launch processes ON THIS GPU = its shard of the batch's live points
         sec_ = acc_ms_ * 1e-3
-        live_scans_ = upl / max(op["scan_points"] / world_size, 1.0)
+        live_scans_ = upl / max(op["scan_points"] / ranks, 1.0)
         pm_ = load_counter_pass(kname, op["scan_points"], op["map_points"], op["guess"], op["batch"], op["slots"], upl, op.get("world", "lattice"))
         traffic_ = pm_.get("hbm_bytes_per_unit") * upl if (pm_ and pm_.get("hbm_bytes_per_unit") is not None) else None
         src_ = (f"profiles/pmc_latest.json[{pmc_key(kname, op['scan_points'], op['map_points'], op['guess'], op.get('world', 'lattice'))}]: HBM bytes/unit of separate rocprofv3 --pmc passes of this "
                 f"leg's command ({pm_.get('source', 'see profiles/README.md')}) x this run's units per launch; counters cannot be read in the timed run") if traffic_ else None
         hbm_ = hbm_object(int(m), int(info_.index_bytes), upl, sec_, bytes_unit_, bytes_ref_, live_scans_, op["map_points"], traffic_, src_)
         roof = build_roofline(int(m), kname, hbm_, pm_, upl, acc_ms_)
-        if pm_ and world_size > 1:
-            roof["counter_pass_shape"] = (f"taken at N = 1 ({op['slots']} slots x {op['scan_points']}-point scans); this rank runs {op['slots'] * world_size} slots x "
-                                          f"{op['scan_points'] // world_size}-point shards: the same per-GPU registrations, slots and units per launch")
+        if pm_ and ranks > 1:
+            roof["counter_pass_shape"] = (f"taken at N = 1 ({op['slots']} slots x {op['scan_points']}-point scans); this rank runs {op['slots'] * ranks} slots x "
+                                          f"{op['scan_points'] // ranks}-point shards: the same per-GPU registrations, slots and units per launch")
         roof.update({
             "kernel": kname,
             "search_index": "voxel-mean lists" if int(m) in (2, 3) else ("dense cell grid" if grid_ else "neighbourhood lists"),
@@ -928,7 +991,7 @@ def main():
     ensure_covariances(vm, method)
     info = vm.info()
     t_map = time.time() - t0
-    n_batch = args.batch * world_size  # weak scaling: per-GPU points per launch fixed
+    n_batch = args.batch * ranks  # weak scaling: per-GPU points per launch fixed
     n_keep = max(args.cpu_sample, 0 if args.no_cpu else min(args.pose_sample, args.batch), 8) if (rank == 0 and world_size == 1) else 0  # full host copies kept for the CPU / reference-API legs (N = 1)
     guess = dict(max_trans=0.15, max_rot_deg=0.5) if args.guess == "easy" else dict(max_trans=0.5, max_rot_deg=2.0)
     want_replica = extras and distributed and args.slots > 0 and (world_size > 1 or bool(os.environ.get("ELM_BENCH_FORCE_REPLICA")))
@@ -946,6 +1009,7 @@ def main():
             fed_sizes.append(shard.shape[0])
         scans.append(Scan(ctx, shard, n_total=n))  # H2D upload + device-side ordering of THIS rank's shard
 
+    args.group_ranks = ranks if args.single_process else 1
     gin = generate_inputs(world, args, rank, world_size, dist, guess, n_keep, want_replica, consume)
     T_true, T0s, digests, rmaxs = gin["T_true"], gin["T0s"], gin["digests"], gin["rmaxs"]
     scans_host = [gin["kept"][i] for i in range(n_keep)] if n_keep else []
@@ -957,7 +1021,7 @@ def main():
     cfg = RegistrationConfig(icp_method=method)
     reg = Registration(cfg, ctx)
 
-    n_slots = args.slots * world_size  # per-GPU points per launch stay fixed as ranks are added
+    n_slots = args.slots * ranks  # per-GPU points per launch stay fixed as ranks are added
     packed = reg.pack_inputs(scans, T0s)  # handle array + column-major guesses, marshalled once
     op_point = dict(scan_points=args.scan_points, map_points=args.map_points, guess=args.guess, batch=args.batch, slots=args.slots, world=args.world)
 
@@ -1001,7 +1065,7 @@ def main():
         "metric": "ICP registrations/sec, 128k-pt scan vs 10M-pt map; pose err vs CPU ref",
         "value": value,
         "unit": "registrations/s",
-        "n_gpus": world_size,
+        "n_gpus": ranks,
         "rccl_ranks": rccl_ranks,  # ncclCommCount of the communicator the timed region all-reduced over (null: one process, no communicator)
         "ranks": rank_table,
         "steps": args.steps,
@@ -1024,8 +1088,10 @@ def main():
             "registrations_per_slot": (args.batch / args.slots) if args.slots > 0 else None,  # the same at every N: the scaling curve compares one operating point
             "scheduling": ("continuous batching: every ICP iteration is one launch over the slots, finished slots are refilled on "
                            "the device from the step's queue" if args.slots > 0 else "lockstep batch"),
-            "parallelism": "1 GPU" if world_size == 1 else f"scan points sharded over {world_size} GPUs, map replicated, "
+            "parallelism": "1 GPU" if ranks == 1 else f"scan points sharded over {ranks} GPUs, map replicated, "
                            "one RCCL all-reduce (32 doubles/scan) per ICP iteration",
+            "process_model": (f"one process, device group of {ranks} ({group_exchange} exchange), devices {devices}" if args.single_process else
+                              ("one process per GPU" if ranks > 1 else "one process, one GPU")),
             "iterations_mean": float(iters.mean()),
             "iterations_min": int(iters.min()),
             "iterations_max": int(iters.max()),
@@ -1398,8 +1464,16 @@ def main():
             tcc = time.time()
             result["c_caller"] = c_caller_numbers()
             result["c_caller"]["wall_s"] = time.time() - tcc
+    if distributed and (world_size > 1 or os.environ.get("ELM_BENCH_FORCE_SINGLE_PROCESS")) and extras and not os.environ.get("ELM_BENCH_NO_SINGLE_PROCESS"):
+        # both process models on the same GPUs in one driver run: the N ranks wait while rank 0's child drives all N devices by itself
+        if rank == 0:
+            result["single_process"] = single_process_leg(args, world_size, out)
+        dist.barrier()
     result["process_wall_s"] = time.time() - t_process
 
+    if args.dump_poses and rank == 0:
+        np.savez(args.dump_poses, T=np.stack([r["T"] for r in out]), iterations=np.array([r["iterations"] for r in out]),
+                 success=np.array([r["is_success"] for r in out]))
     assert_fractions(result)
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)

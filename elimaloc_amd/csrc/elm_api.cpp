@@ -378,6 +378,7 @@ extern "C" void* elm_ctx_stream(elm_ctx* ctx) { return ctx ? (void*)ctx->stream 
 extern "C" int elm_ctx_set_work_counters(elm_ctx* ctx, int enable) {
     if (!ctx) return ELM_ERR_INVALID;
     if (ctx->in_flight) return ELM_ERR_INVALID;
+    if (group_call(ctx)) return elm_multi::set_work_counters(ctx, enable); // every rank: the counters ride in the exchanged record
     ctx->work_counters = enable != 0;
     return ELM_OK;
 }

@@ -35,6 +35,7 @@ void scan_set_total(elm_scan* s, size_t n_total);
 namespace elm_multi {
 bool in_worker(); // this thread is a group's worker: the entry points take their single-device path
 void destroy(elm_group* g);
+int set_work_counters(elm_ctx* lead, int enable);
 int map_build(elm_ctx* lead, const float* xyz, size_t n, double voxel_size, int max_points_per_voxel, elm_map** out);
 int map_call(elm_map* lead_map, int which, double arg); // 0 CalVoxelCovAll, 1 CalPointCovAll(arg), 2 the search index
 int scan_upload(elm_ctx* lead, const float* xyz, size_t n, elm_scan** out);

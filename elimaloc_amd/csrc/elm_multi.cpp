@@ -240,6 +240,12 @@ void destroy(elm_group* g) {
     delete g;
 }
 
+int set_work_counters(elm_ctx* lead, int enable) {
+    elm_group* g = group_of(lead);
+    std::lock_guard<std::mutex> call(g->call_mu);
+    return run_all(g, [&](int r) { return elm_ctx_set_work_counters(g->ctx[r], enable); });
+}
+
 int map_build(elm_ctx* lead, const float* xyz, size_t n, double voxel_size, int max_points_per_voxel, elm_map** out) {
     elm_group* g = group_of(lead);
     std::lock_guard<std::mutex> call(g->call_mu);

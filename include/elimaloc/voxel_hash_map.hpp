@@ -7,6 +7,7 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -16,11 +17,26 @@
 #include "linalg_types.hpp"
 
 namespace elimaloc {
+// The process-wide context of the shims.  ELM_DEVICES="0,1,2,3" (e.g. exported by the launch file): a device GROUP -- the map is replicated
+// on those GPUs, every RunRegister shards its scan over them and all-reduces the 6x6 normal equations per ICP iteration (RCCL over xGMI);
+// pcm_matching.cpp's call sites (pcm.cpp:82-105, 280-282, 412-414) do not change.  Unset: device 0.
 inline elm_ctx* default_context() {
     static elm_ctx* ctx = [] {
+        std::vector<int> ids;
+        if (const char* e = std::getenv("ELM_DEVICES")) {
+            for (const char* p = e; *p;) {
+                char* end = nullptr;
+                const long v = std::strtol(p, &end, 10);
+                if (end == p) break;
+                ids.push_back((int)v);
+                p = end;
+                while (*p == ',' || *p == ' ') ++p;
+            }
+        }
+        if (ids.empty()) ids.push_back(0);
         elm_ctx* c = nullptr;
-        int rc = elm_ctx_create(0, &c);
-        if (rc != ELM_OK) throw std::runtime_error(std::string("elm_ctx_create: ") + elm_strerror(rc));
+        int rc = elm_ctx_create_multi(ids.data(), (int)ids.size(), &c);
+        if (rc != ELM_OK) throw std::runtime_error(std::string("elm_ctx_create_multi: ") + elm_strerror(rc));
         return c;
     }();
     return ctx;

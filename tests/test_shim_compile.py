@@ -58,3 +58,12 @@ def test_reference_call_sequence_runs(tmp_path):
 def test_plain_shim_harness_runs(tmp_path):
     r = subprocess.run([_build_plain(tmp_path)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_reference_call_sequence_runs_on_a_device_group(tmp_path):
+    """the same harness with ELM_DEVICES=0,0: the shims' process-wide context is a device GROUP (two ranks on this GPU, host-memory
+    exchange) -- map replicated, every RunRegister sharded -- and pcm_matching.cpp's call lines do not change"""
+    exe = _build(tmp_path, run=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, ELM_DEVICES="0,0"))
+    assert r.returncode == 0, r.stdout + r.stderr
