@@ -96,45 +96,13 @@ struct elm_ctx {
     hipStream_t stream = nullptr;
     // host-fed streams / ordered uploads: uploads (DMA) and the scan-ordering kernel run beside the iterations on the compute stream
     hipStream_t copy_stream = nullptr, order_stream = nullptr, poll_stream = nullptr;
-    hipStream_t solve_stream = nullptr; // half-set streams: the solve side (reduce -> all-reduce -> solve + refill) of one half of the slots runs
-                                        // here, under the other half's accumulate launch on the compute stream
-    std::vector<hipEvent_t> ev_halves;  // its cross-stream events (never re-recorded while a wait on them may be pending: one pair per half-iteration)
-    // hipGraph of ONE registration (batch = 1: RunRegister's own shape): descriptor + guess upload, init, K x (accumulate, solve), result
-    // download captured once and replayed -- no launch gaps between the 2 K + 1 kernels.  Rebuilt when anything baked into it changes
-    // (graph_key: the map's device view, the registration parameters, the grid size, K, the buffers).  ELM_GRAPH=0: plain launches.
-    bool use_graph = false; // ELM_GRAPH=1 (opt-in: measured on this runtime the replay is SLOWER than the plain launches -- 0.135 ms against 0.127 ms per
-                            // resident 131 072-point registration -- a graph launch costs more than the five launch gaps it removes)
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    std::vector<unsigned char> graph_key;
-    int graph_K = 0;          // iterations inside the cached graph
-    int graph_K_want = 0;     // grows with the iteration counts seen
-    int graph_short_run = 0;  // consecutive registrations that needed fewer
-    struct {
-        bool active = false;  // the in-flight batch went through the graph: finish may have to continue it
-        const elm_map* map = nullptr;
-        bool use_grid = false, use_cells = false, use_vnbr = false;
-        uint32_t blocks = 0;
-        int iters = 0, max_iter = 0;
-    } grun;
-    bool dist_refill_kernel = true; // multi-rank streams refill their slots with a launch of their own (dynamic, in slot order: 4 launches + 1 collective
-                                    // per iteration); ELM_DIST_REFILL=solve: the static per-slot queue inside the solve (3 + 1).  One-rank RCCL path,
-                                    // two runs each: 94.3 k against 89.7 k registrations/s (48 instead of 56 accumulate launches per step)
-    int half_sets = 0;                  // ELM_HALF_SETS=1: the two-half pipeline (off by default: measured on one MI355X it LOSES 4 % without a
-                                        // communicator and 40 % on the one-rank RCCL path -- the solve's 1024-thread, 84-VGPR workgroups are not
-                                        // placed while the other half's accumulate grid still has workgroups to issue, so nothing overlaps and the
-                                        // half-size launches pay their tails twice; profiles/r04_halfsets.txt)
     hipEvent_t ev_iter[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ev_groups; // host-fed streams: per upload group its "copied" and "ordered" events
     uint16_t* d_hilbert = nullptr; // Hilbert index of every cell of the ordering grid (kOrderCells^2 entries)
-    DevBuf d_order_jobs, d_order_tmp, d_arena, d_raw, d_tickets, d_prev, d_flagged, d_asym;
+    DevBuf d_order_jobs, d_order_tmp, d_arena, d_raw, d_flagged, d_asym;
     DevBuf d_q0, d_q1, d_q2, d_q3, d_q4, d_q5; // scratch of elm_map_get_correspondences / elm_align_clouds_local (kept between calls)
-    bool prev_winner = false; // ELM_PREV_WINNER=1 (with a library built with -DELM_PREV_WINNER=1): the grid kernels keep every point's previous winner
     bool work_counters = false; // elm_ctx_set_work_counters / ELM_WORK_COUNTERS=1: the accumulate launches also sum the work counters of
                                 // elm_reg_result (n_cand_total, n_occ_total, n_tested_total, fallback_blocks); off: those fields read 0
-    bool fused_reduce = false; // ELM_FUSED_REDUCE=1: the accumulate kernels' last workgroups reduce the partial records (no reduce launch:
-                               // accumulate -> [all-reduce] -> solve).  Off by default: measured on one GPU the write-through publish + ticket
-                               // cost every workgroup more (accumulate +4 %) than the lighter solve saves: 83.7 k vs 86.5 k registrations/s
     void* h_jobs = nullptr; // pinned: ordering job descriptors
     size_t h_jobs_cap = 0;
     std::string last_error;
@@ -247,15 +215,6 @@ static uint64_t host_available_bytes() {
     fclose(f);
     return found ? kb * 1024ull : ~0ull;
 }
-// the previous-winner buffer of the grid kernels: all -1 when it is (re)allocated (entries are only ever slot numbers or -1)
-static int prev_reserve(elm_ctx* ctx, size_t entries) {
-    const size_t bytes = entries * sizeof(uint32_t);
-    if (bytes <= ctx->d_prev.cap) return ELM_OK;
-    int rc = dev_reserve(ctx, ctx->d_prev, bytes);
-    if (rc != ELM_OK) return rc;
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_prev.p, 0xFF, ctx->d_prev.cap, ctx->stream));
-    return ELM_OK;
-}
 static int pinned_reserve(elm_ctx* ctx, void** p, size_t* cap, size_t bytes) {
     if (bytes <= *cap) return ELM_OK;
     if (*p) HIPCHK(ctx, hipHostFree(*p));
@@ -319,12 +278,7 @@ extern "C" int elm_ctx_create(int device_id, elm_ctx** out) {
     }
     if (const char* k = getenv("ELM_KERNEL")) ctx->kernel_mode = (strcmp(k, "direct") == 0) ? 2 : (strcmp(k, "lists") == 0) ? 3 : 4;
     if (const char* o = getenv("ELM_SCAN_ORDER")) ctx->scan_order = (strcmp(o, "none") == 0) ? 0 : 1;
-    if (const char* f = getenv("ELM_FUSED_REDUCE")) ctx->fused_reduce = strcmp(f, "0") != 0;
     if (const char* f = getenv("ELM_WORK_COUNTERS")) ctx->work_counters = strcmp(f, "0") != 0;
-    if (const char* f = getenv("ELM_HALF_SETS")) ctx->half_sets = strcmp(f, "0") != 0 ? 1 : 0;
-    if (const char* f = getenv("ELM_DIST_REFILL")) ctx->dist_refill_kernel = strcmp(f, "solve") != 0;
-    if (const char* f = getenv("ELM_PREV_WINNER")) ctx->prev_winner = strcmp(f, "0") != 0;
-    if (const char* f = getenv("ELM_GRAPH")) ctx->use_graph = strcmp(f, "0") != 0;
     {
         std::lock_guard<std::mutex> lk(g_live_mu);
         ctx->id = g_next_ctx_id++;
@@ -347,10 +301,7 @@ extern "C" void elm_ctx_destroy(elm_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm && g_rccl.comm_destroy) g_rccl.comm_destroy(ctx->comm);
-    if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
-    if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
-    for (hipEvent_t e : ctx->ev_halves) (void)hipEventDestroy(e);
-    for (hipStream_t st : {ctx->copy_stream, ctx->order_stream, ctx->poll_stream, ctx->solve_stream})
+    for (hipStream_t st : {ctx->copy_stream, ctx->order_stream, ctx->poll_stream})
         if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (hipEvent_t e : {ctx->ev_iter[0], ctx->ev_iter[1], ctx->ev_iter[2], ctx->ev_iter[3]})
         if (e) (void)hipEventDestroy(e);
@@ -358,7 +309,7 @@ extern "C" void elm_ctx_destroy(elm_ctx* ctx) {
     if (ctx->d_hilbert) (void)hipFree(ctx->d_hilbert);
     if (ctx->h_jobs) (void)hipHostFree(ctx->h_jobs);
     DevBuf* bufs[] = {&ctx->d_scans, &ctx->d_state, &ctx->d_partials, &ctx->d_sums, &ctx->d_T0, &ctx->d_trace, &ctx->d_stage_pts, &ctx->d_active, &ctx->d_queue, &ctx->d_ds,
-                      &ctx->d_order_jobs, &ctx->d_order_tmp, &ctx->d_arena, &ctx->d_raw, &ctx->d_tickets, &ctx->d_prev, &ctx->d_flagged, &ctx->d_asym, &ctx->d_q0, &ctx->d_q1, &ctx->d_q2, &ctx->d_q3, &ctx->d_q4, &ctx->d_q5};
+                      &ctx->d_order_jobs, &ctx->d_order_tmp, &ctx->d_arena, &ctx->d_raw, &ctx->d_flagged, &ctx->d_asym, &ctx->d_q0, &ctx->d_q1, &ctx->d_q2, &ctx->d_q3, &ctx->d_q4, &ctx->d_q5};
     if (ctx->h_active) (void)hipHostFree(ctx->h_active);
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -1698,7 +1649,7 @@ __attribute__((target("avx2"))) static void stage_copy_avx2(void* dst, const voi
     if (i < len) memcpy(d + i, s + i, len - i);
 }
 static void stage_copy(void* dst, const void* src, size_t len) {
-    static const bool avx2 = __builtin_cpu_supports("avx2") && !getenv("ELM_STAGE_MEMCPY");
+    static const bool avx2 = __builtin_cpu_supports("avx2");
     if (avx2 && (((uintptr_t)dst) & 31u) == 0) stage_copy_avx2(dst, src, len);
     else memcpy(dst, src, len);
 }
@@ -1742,7 +1693,7 @@ static int scan_upload_impl(elm_ctx* ctx, const float* xyz, size_t n, size_t n_t
     } else {
         rc = ensure_hilbert(ctx);
         if (rc == ELM_OK) rc = dev_reserve(ctx, ctx->d_raw, bytes);
-        const bool wide = n >= 16384 && !getenv("ELM_ORDER_NARROW"); // one scan on its own: many workgroups (same bytes, ~10x sooner)
+        const bool wide = n >= 16384; // one scan on its own: many workgroups (same bytes, ~10x sooner)
         const size_t tmp_bytes = ((n * sizeof(uint32_t) + 255) / 256) * 256;
         if (rc == ELM_OK) rc = dev_reserve(ctx, ctx->d_order_tmp, tmp_bytes + (wide ? order_wide_scratch_bytes((unsigned)n) : 0));
         if (rc == ELM_OK) rc = dev_reserve(ctx, ctx->d_order_jobs, sizeof(OrderJob));
@@ -1864,11 +1815,10 @@ static int exchange(elm_ctx* ctx, double* d_sums, size_t count, hipStream_t stre
 // scans, profiles/r04k_strict_rate.txt).
 // Unset (the default): every map runs the fast kernels; a map with a flagged covariance of the method's own kind whose stored inverse is
 // not symmetric (layout_flags bits 7 / 8, counted by k_point_cov / k_voxel_cov) additionally carries the antisymmetric part of J^T M J in
-// side records (choose_path, asym_side_store) -- exact like the per-pair arithmetic.  ELM_STRICT_PAIRS=0: fast kernels WITHOUT the side
-// records (the behaviour before round 5: off by the antisymmetric part on such maps; kept for the test that shows the side records matter).
-static int strict_pairs() { // 1: per-pair kernels always, 0: fast kernels without side records, -1: fast kernels, side records by map
+// side records (choose_path, asym_side_store) -- exact like the per-pair arithmetic.
+static int strict_pairs() { // 1: per-pair kernels always, -1: fast kernels, side records by map
     const char* e = getenv("ELM_STRICT_PAIRS"); // (read per call: a registration call, not a launch)
-    return !e ? -1 : (strcmp(e, "0") != 0 ? 1 : 0);
+    return (e && strcmp(e, "1") == 0) ? 1 : -1;
 }
 static int build_search_index(elm_map* m, bool* use_grid);
 static int build_voxel_neighbourhoods(elm_map* m, bool want_faces);
@@ -1913,7 +1863,7 @@ static int choose_path(elm_ctx* ctx, const elm_map* map, const elm_reg_config* c
         if ((rc = build_voxel_neighbourhoods(const_cast<elm_map*>(map), method == ELM_AVGICP)) != ELM_OK) return rc;
     const bool asym_map = mode < 0 && method != ELM_P2P && (method == ELM_GICP ? map->n_asym_pts != 0 : map->n_asym_vox != 0);
     if (asym_map) {
-        if ((pc->use_grid || pc->use_vnbr) && !ctx->fused_reduce) pc->asym = true;
+        if (pc->use_grid || pc->use_vnbr) pc->asym = true;
         else { pc->radar = true; pc->use_grid = pc->use_cells = pc->use_vnbr = false; }
     }
     return ELM_OK;
@@ -2117,14 +2067,12 @@ static int enqueue_accumulate(elm_ctx* ctx, const elm_map* map, const ScanDesc* 
         if (rp.radar) launch_accumulate_radar(ctx->stream, map->dm, dsc, n_scans, (int)blocks, st, partials, rp);
         else if (use_grid) launch_accumulate_grid(ctx->stream, map->dm, dsc, n_scans, (int)blocks, st, partials, rp);
         else if (use_cells) launch_accumulate_cell(ctx->stream, map->dm, dsc, n_scans, (int)blocks, st, partials, rp);
-        else if (use_vnbr && rp.method == ELM_AVGICP && map->dm.vface_flagged && !rp.tickets) {
+        else if (use_vnbr && rp.method == ELM_AVGICP && map->dm.vface_flagged) {
             // the fused walk on a map with flagged voxels: one flag per workgroup (all zero between launches: the fix-up launch clears what
-            // the walk sets).  Not while a graph is being captured (no allocation there): the launcher then takes the nine-entry walk.
+            // the walk sets)
             RegParams rq = rp;
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            (void)hipStreamIsCapturing(ctx->stream, &cs);
             const size_t need = (size_t)blocks * sizeof(uint32_t);
-            if (cs == hipStreamCaptureStatusNone && need > ctx->d_flagged.cap) {
+            if (need > ctx->d_flagged.cap) {
                 if ((rc = dev_reserve(ctx, ctx->d_flagged, need + need / 2)) != ELM_OK) return rc;
                 HIPCHK(ctx, hipMemsetAsync(ctx->d_flagged.p, 0, ctx->d_flagged.cap, ctx->stream));
             }
@@ -2163,7 +2111,7 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
     const bool map_empty = map->dm.n_vox == 0;
     if (ctx->iter_key_map != (const void*)map || ctx->iter_key_method != method || ctx->iter_key_batch != batch) {
         // (a registration that ran to max_iteration on another map / method / batch shape must not push THIS call's first early-stop
-        // check -- and the graph's length -- to its count)
+        // check to its count)
         ctx->iter_key_map = map; ctx->iter_key_method = method; ctx->iter_key_batch = batch;
         for (int k = 0; k < 8; ++k) ctx->iter_ring[k] = 0;
         ctx->iter_hint = 0;
@@ -2220,18 +2168,14 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
         HIPCHK(ctx, hipMemsetAsync(ctx->d_trace.p, 0, tb, ctx->stream));
         d_trace = (elm_iter_trace*)ctx->d_trace.p;
     }
-    // one resident registration without trace / profiling / exchange: the replayed graph (descriptor and guess travel through the pinned
-    // staging buffer, so nothing call-specific is baked into it)
-    const bool graph_mode = ctx->use_graph && batch == 1 && !want_trace && !ctx->profiling && !n_dev && !map_empty && !radar && !pc.asym && !ctx->comm && !ctx->hook &&
-                            cfg->max_iteration > 0 && blocks > 0 && ctx->iter_hint > 0; // (iter_hint: a first call has no history to size the graph with)
-    const bool packed_init = batch <= kInitPack && !graph_mode;
-    if (!packed_init && !graph_mode) {
+    const bool packed_init = batch <= kInitPack;
+    if (!packed_init) {
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_scans.p, hd, (size_t)batch * sizeof(ScanDesc), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_T0.p, hT, (size_t)batch * 16 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     }
 
     RegParams rp;
-    memset(&rp, 0, sizeof(rp)); // (padding too: the registration graph compares it bytewise)
+    memset(&rp, 0, sizeof(rp));
     rp.th = cfg->max_search_dist;
     rp.th2 = cfg->max_search_dist * cfg->max_search_dist;
     rp.lm_lambda = cfg->lm_lambda;
@@ -2243,24 +2187,11 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
     rp.uniform_blocks = uniform_blocks;
     rp.radar = radar ? (cfg->use_radar_cov != 0 ? 1 : 2) : 0; // 2: the radar kernels without a source covariance (ELM_STRICT_PAIRS)
     rp.stats = ctx->work_counters ? 1 : 0;
-    rp.solve_small = ctx->half_sets ? 1 : 0;
     rp.radar_var[0] = cfg->range_variance_m;
     rp.radar_var[1] = cfg->azimuth_variance_deg;
     rp.radar_var[2] = cfg->elevation_variance_deg;
-    rp.sums = nullptr;
-    rp.tickets = nullptr;
-    rp.prev = nullptr;
-    if (ctx->prev_winner && !radar && blocks) { // one slot number per scan point: the next iteration's exact search starts from it
-        if ((rc = prev_reserve(ctx, (size_t)blocks * kBlock)) != ELM_OK) return rc;
-        rp.prev = (uint32_t*)ctx->d_prev.p;
-    }
-    if (ctx->fused_reduce && !radar) {
-        if ((rc = dev_reserve(ctx, ctx->d_tickets, (size_t)batch * sizeof(int32_t))) != ELM_OK) return rc;
-        rp.sums = (double*)ctx->d_sums.p;
-        rp.tickets = (int32_t*)ctx->d_tickets.p;
-    }
     if (pc.asym && (rc = reserve_asym(ctx, rp, blocks, batch)) != ELM_OK) return rc;
-    rp.rank_check = ((ctx->comm || ctx->hook) && !radar && !rp.tickets && !rp.stats) ? 1 : 0;
+    rp.rank_check = ((ctx->comm || ctx->hook) && !radar && !rp.stats) ? 1 : 0;
     ctx->rp = rp;
 
     // the search index (choose_path built it on first use): dense / two-level cell grid, else the cell-indexed neighbourhood lists, else
@@ -2270,66 +2201,6 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
     const ScanDesc* dsc = (const ScanDesc*)ctx->d_scans.p;
     int* d_active = (int*)((char*)ctx->d_state.p + st_bytes);
     (void)hipGetLastError();
-    ctx->grun.active = false;
-    if (graph_mode) {
-        // K iterations inside the graph: one more than the longest registration seen on this context (a finished scan's launches return
-        // at once); a registration that needs more is continued with plain launches by elm_register_batch_finish
-        // (never shrinks while longer registrations keep coming: one graph per shape; 32 short ones in a row let it shrink again)
-        ctx->graph_short_run = (ctx->iter_hint + 1 < ctx->graph_K_want) ? ctx->graph_short_run + 1 : 0;
-        if (ctx->graph_short_run >= 32) { ctx->graph_K_want = ctx->iter_hint + 1; ctx->graph_short_run = 0; }
-        const int K = std::min(cfg->max_iteration, std::max(ctx->graph_K_want, ctx->iter_hint + 1));
-        ctx->graph_K_want = K;
-        std::vector<unsigned char> key;
-        auto put = [&](const void* p, size_t n) { key.insert(key.end(), (const unsigned char*)p, (const unsigned char*)p + n); };
-        put(&map->dm, sizeof(DevMap));
-        put(&rp, sizeof(RegParams));
-        const void* ptrs[] = {ctx->d_scans.p, ctx->d_T0.p, ctx->d_state.p, ctx->d_partials.p, ctx->d_sums.p, ctx->h_desc, ctx->h_state};
-        put(ptrs, sizeof(ptrs));
-        const uint32_t shape[] = {blocks, (uint32_t)K, (uint32_t)use_grid, (uint32_t)use_cells, (uint32_t)use_vnbr, (uint32_t)st_bytes};
-        put(shape, sizeof(shape));
-        if (!ctx->graph_exec || key != ctx->graph_key) {
-            if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
-            if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
-            HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-            hipError_t ce = hipMemcpyAsync(ctx->d_scans.p, hd, sizeof(ScanDesc), hipMemcpyHostToDevice, ctx->stream);
-            if (ce == hipSuccess) ce = hipMemcpyAsync(ctx->d_T0.p, hT, 16 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-            if (ce == hipSuccess) ce = hipMemsetAsync(d_active, 0, 2 * sizeof(int), ctx->stream);
-            if (ce == hipSuccess) {
-                launch_init_state(ctx->stream, st, (const double*)ctx->d_T0.p, 1, 0, d_active, rp.tickets);
-                for (int it = 0; it < K; ++it) {
-                    if (enqueue_accumulate(ctx, map, dsc, 1, blocks, st, rp, use_grid, use_cells, use_vnbr) != ELM_OK) { ce = hipErrorUnknown; break; }
-                    launch_solve(ctx->stream, dsc, 1, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, nullptr, 0, d_active);
-                }
-            }
-            if (ce == hipSuccess) ce = hipMemcpyAsync(ctx->h_state, st, st_bytes + 64, hipMemcpyDeviceToHost, ctx->stream);
-            hipGraph_t g = nullptr;
-            const hipError_t ee = hipStreamEndCapture(ctx->stream, &g);
-            if (ce == hipSuccess) ce = ee;
-            if (ce == hipSuccess) ce = hipGraphInstantiate(&ctx->graph_exec, g, nullptr, nullptr, 0);
-            if (ce != hipSuccess) {
-                if (g) (void)hipGraphDestroy(g);
-                ctx->graph_exec = nullptr;
-                ctx->last_error = std::string("registration graph: ") + hipGetErrorString(ce);
-                (void)hipGetLastError();
-                return ELM_ERR_DEVICE;
-            }
-            ctx->graph = g;
-            ctx->graph_key = key;
-            ctx->graph_K = K;
-        }
-        HIPCHK(ctx, hipGraphLaunch(ctx->graph_exec, ctx->stream));
-        ctx->grun.active = true;
-        ctx->grun.map = map;
-        ctx->grun.use_grid = use_grid; ctx->grun.use_cells = use_cells; ctx->grun.use_vnbr = use_vnbr;
-        ctx->grun.blocks = blocks;
-        ctx->grun.iters = ctx->graph_K;
-        ctx->grun.max_iter = cfg->max_iteration;
-        ctx->events_used = 0;
-        ctx->batch = batch;
-        ctx->want_trace = false;
-        ctx->in_flight = true;
-        return ELM_OK;
-    }
     if (packed_init) { // descriptors and guesses as kernel arguments: no H2D copies, no memset
         InitPack pack;
         memset(&pack, 0, sizeof(pack));
@@ -2337,10 +2208,10 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
             pack.d[b] = hd[b];
             memcpy(pack.T0[b], T0 + (size_t)b * 16, 16 * sizeof(double));
         }
-        launch_init_pack(ctx->stream, (ScanDesc*)ctx->d_scans.p, st, pack, batch, map_empty ? 1 : 0, d_active, n_dev, rp.tickets);
+        launch_init_pack(ctx->stream, (ScanDesc*)ctx->d_scans.p, st, pack, batch, map_empty ? 1 : 0, d_active, n_dev);
     } else {
         HIPCHK(ctx, hipMemsetAsync(d_active, 0, 2 * sizeof(int), ctx->stream));
-        launch_init_state(ctx->stream, st, (const double*)ctx->d_T0.p, batch, map_empty ? 1 : 0, d_active, rp.tickets);
+        launch_init_state(ctx->stream, st, (const double*)ctx->d_T0.p, batch, map_empty ? 1 : 0, d_active);
     }
     const bool distributed = (ctx->comm != nullptr) || (ctx->hook != nullptr);
     ctx->events_used = 0;
@@ -2348,8 +2219,7 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
         for (int it = 0; it < cfg->max_iteration; ++it) {
             if ((rc = enqueue_accumulate(ctx, map, dsc, batch, blocks, st, rp, use_grid, use_cells, use_vnbr)) != ELM_OK) return rc;
             if (distributed) {
-                // fused reduction: the sums are already in d_sums -- accumulate -> all-reduce -> solve (two launches + one collective)
-                if (!rp.tickets) launch_solve(ctx->stream, dsc, batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 1, d_active);
+                launch_solve(ctx->stream, dsc, batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 1, d_active); // reduce only
                 if ((rc = exchange(ctx, (double*)ctx->d_sums.p, (size_t)batch * (radar ? kRadarRecord : (rp.asym ? kSums + kAsymRecord : kSums)))) != ELM_OK) return rc;
                 launch_solve(ctx->stream, dsc, batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, rp, d_trace, 2, d_active);
             } else {
@@ -2410,24 +2280,6 @@ extern "C" int elm_register_batch_finish(elm_ctx* ctx, elm_reg_result* results, 
     ctx->in_flight = false;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (!ctx->results_ready || ctx->want_trace || ctx->profiling) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->grun.active) {
-        // the graph ran its K iterations; a registration that is still iterating goes on with plain launches, two iterations per look
-        ctx->grun.active = false;
-        const size_t st_bytes = (size_t)ctx->batch * sizeof(ScanState);
-        ScanState* st = (ScanState*)ctx->d_state.p;
-        const ScanDesc* dsc = (const ScanDesc*)ctx->d_scans.p;
-        int* d_active = (int*)((char*)ctx->d_state.p + st_bytes);
-        int it = ctx->grun.iters;
-        while (*(const int*)((const char*)ctx->h_state + st_bytes) != 0 && it < ctx->grun.max_iter) {
-            for (int k = 0; k < 2 && it < ctx->grun.max_iter; ++k, ++it) {
-                int rc = enqueue_accumulate(ctx, ctx->grun.map, dsc, ctx->batch, ctx->grun.blocks, st, ctx->rp, ctx->grun.use_grid, ctx->grun.use_cells, ctx->grun.use_vnbr);
-                if (rc != ELM_OK) return rc;
-                launch_solve(ctx->stream, dsc, ctx->batch, st, (const double*)ctx->d_partials.p, (double*)ctx->d_sums.p, ctx->rp, nullptr, 0, d_active);
-            }
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_state, st, st_bytes + 64, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        }
-    }
     {
         int prc = prof_collect(ctx);
         if (prc != ELM_OK) return prc;
@@ -2518,17 +2370,9 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     StreamCtrl* hc = (StreamCtrl*)((char*)ctx->h_desc + q_bytes + t_bytes + d_bytes);
     for (int b = 0; b < count; ++b) { hq[b].pts = scans[b]->d_pts; hq[b].n = scans[b]->n; hq[b].n_total = scans[b]->n_total; }
     memcpy(hT, T0, t_bytes);
-    // Half-sets: the slots are split into two halves that alternate on the compute stream; the solve side of a half (reduce ->
-    // all-reduce -> solve + refill: three small launches and the collective) runs on a second, high-priority stream UNDER the other
-    // half's accumulate launch, so neither the collective's latency nor the solve is exposed.  The accumulate launches stay on ONE
-    // stream, back to back (their hipEvent brackets time one kernel at a time).  Each half is a stream of its own in everything but the
-    // queue: its descriptors' workgroup ranges and its partial records start at zero.
-    const int H = (ctx->half_sets && S >= 16) ? 2 : 1;
-    const int S0 = (H == 2) ? (S + 1) / 2 : S; // slots of half 0; half 1: S - S0
     for (int s = 0; s < S; ++s) {
-        const uint32_t rel = (uint32_t)(s < S0 ? s : s - S0);
         hd[s].pts = nullptr; hd[s].n = 0; hd[s].n_total = 0;
-        hd[s].blk_begin = cap_blocks * rel; hd[s].blk_end = cap_blocks * (rel + 1);
+        hd[s].blk_begin = cap_blocks * (uint32_t)s; hd[s].blk_end = cap_blocks * (uint32_t)(s + 1);
     }
     hc->next = 0; hc->completed = 0; hc->total = count; hc->ready = count; hc->done_iter = -1;
     if ((rc = dev_reserve(ctx, ctx->d_scans, d_bytes)) != ELM_OK) return rc;
@@ -2558,7 +2402,7 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     HIPCHK(ctx, hipMemsetAsync(ctx->d_active.p, 0, 2 * sizeof(int), ctx->stream));
 
     RegParams rp;
-    memset(&rp, 0, sizeof(rp)); // (padding too: the registration graph compares it bytewise)
+    memset(&rp, 0, sizeof(rp));
     rp.th = cfg->max_search_dist;
     rp.th2 = cfg->max_search_dist * cfg->max_search_dist;
     rp.lm_lambda = cfg->lm_lambda;
@@ -2570,23 +2414,9 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     rp.uniform_blocks = cap_blocks; // every slot owns cap_blocks workgroups
     rp.radar = 0;
     rp.stats = ctx->work_counters ? 1 : 0;
-    rp.solve_small = ctx->half_sets ? 1 : 0;
     rp.radar_var[0] = rp.radar_var[1] = rp.radar_var[2] = 0.0;
-    rp.sums = nullptr;
-    rp.tickets = nullptr;
-    rp.prev = nullptr;
-    if (ctx->prev_winner && blocks) {
-        if ((rc = prev_reserve(ctx, (size_t)blocks * kBlock)) != ELM_OK) return rc;
-        rp.prev = (uint32_t*)ctx->d_prev.p;
-    }
-    if (ctx->fused_reduce) {
-        if ((rc = dev_reserve(ctx, ctx->d_tickets, (size_t)S * sizeof(int32_t))) != ELM_OK) return rc;
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_tickets.p, 0, (size_t)S * sizeof(int32_t), ctx->stream));
-        rp.sums = (double*)ctx->d_sums.p;
-        rp.tickets = (int32_t*)ctx->d_tickets.p;
-    }
     if (pc.asym && (rc = reserve_asym(ctx, rp, blocks, S)) != ELM_OK) return rc;
-    rp.rank_check = ((ctx->comm || ctx->hook) && !rp.tickets && !rp.stats) ? 1 : 0;
+    rp.rank_check = ((ctx->comm || ctx->hook) && !rp.stats) ? 1 : 0;
     ctx->rp = rp;
     const bool use_grid = pc.use_grid, use_cells = pc.use_cells, use_vnbr = pc.use_vnbr;
 
@@ -2603,87 +2433,33 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     const int hard_limit = ((count + S - 1) / S + 1) * cfg->max_iteration;
     const bool same_shape = ctx->stream_hint_count == count && ctx->stream_hint_slots == S;
     const int predicted = same_shape ? ctx->stream_hint_iters : 0;
-    if (H == 2 && !ctx->solve_stream) {
-        int lo = 0, hi = 0;
-        HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->solve_stream, hipStreamNonBlocking, hi)); // its few workgroups go ahead of the accumulate's
-    }
-    size_t ev_used = 0;
-    auto half_event = [&](hipEvent_t* out) -> int { // a fresh event per use: re-recording one that still has a pending wait loses stream order here
-        if (ev_used == ctx->ev_halves.size()) {
-            hipEvent_t e;
-            HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            ctx->ev_halves.push_back(e);
-        }
-        *out = ctx->ev_halves[ev_used++];
-        return ELM_OK;
-    };
-    hipEvent_t solved[2] = {nullptr, nullptr}; // the half's previous solve (its next accumulate waits for it)
+    double* const partials = (double*)ctx->d_partials.p;
+    double* const sums = (double*)ctx->d_sums.p;
     int it = 0;
     for (; it < hard_limit; ++it) {
-        for (int h = 0; h < H; ++h) {
-            const int base = h ? S0 : 0, Sh = h ? S - S0 : S0;
-            const uint32_t blocks_h = cap_blocks * (uint32_t)Sh;
-            ScanDesc* dsc_h = dsc + base;
-            ScanState* st_h = st + base;
-            double* partials_h = (double*)ctx->d_partials.p + (size_t)cap_blocks * (size_t)base * kSums;
-            double* sums_h = (double*)ctx->d_sums.p + (size_t)base * kSums;
-            RegParams rph = rp;
-            if (rp.tickets) { rph.sums = sums_h; rph.tickets = rp.tickets + base; }
-            if (rp.prev) rph.prev = rp.prev + (size_t)cap_blocks * (size_t)base * kBlock;
-            if (rp.asym) { rph.asym = rp.asym + (size_t)cap_blocks * (size_t)base * kAsymRecord; rph.asym_sums = rp.asym_sums + (size_t)base * kAsymRecord; }
-            hipStream_t ss = ctx->stream;
-            if (H == 2) {
-                ss = ctx->solve_stream;
-                if (solved[h]) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, solved[h], 0));
-            }
-            if ((rc = enqueue_accumulate(ctx, map, dsc_h, Sh, blocks_h, st_h, rph, use_grid, use_cells, use_vnbr, partials_h)) != ELM_OK) return rc;
-            if (H == 2) {
-                hipEvent_t acc_done;
-                if ((rc = half_event(&acc_done)) != ELM_OK) return rc;
-                HIPCHK(ctx, hipEventRecord(acc_done, ctx->stream));
-                HIPCHK(ctx, hipStreamWaitEvent(ss, acc_done, 0));
-            }
-            if (distributed) {
-                if (!rp.tickets) launch_solve(ss, dsc_h, Sh, st_h, partials_h, sums_h, rph, d_trace, 1, d_active);
-                // (side sums of a map with an asymmetric covariance: right behind the packed sums -- one exchange; half-sets: one more)
-                if ((rc = exchange(ctx, sums_h, (size_t)Sh * ((rp.asym && H == 1) ? kSums + kAsymRecord : kSums), ss)) != ELM_OK) return rc;
-                if (rp.asym && H == 2 && (rc = exchange(ctx, rph.asym_sums, (size_t)Sh * kAsymRecord, ss)) != ELM_OK) return rc;
-                // the solve also refills: slot s serves the registrations s, s + S, s + 2 S, ... -- a function of the slot alone, so every
-                // rank hands out the same registrations without a refill launch (3 launches + 1 collective per iteration)
-                if (ctx->dist_refill_kernel && H == 1) {
-                    // ... or a refill launch of its own (4 launches + 1 collective): ONE workgroup walks the slots in slot order and hands the
-                    // finished ones the next pending registrations -- first come, first served like the single-rank stream, yet identical on
-                    // every rank (the finished flags derive from the all-reduced sums), so no slot idles while the queue has work
-                    const StreamArgs sv = {dsc_h, d_q, d_qT0, d_out, d_ctrl, 0, /*save_only*/ 1, 0, it}; // the solve saves + counts, the refill assigns
-                    launch_solve(ss, dsc_h, Sh, st_h, partials_h, sums_h, rph, d_trace, 2, d_active, &sv);
-                    launch_stream_refill(ss, dsc, st, S, d_q, d_qT0, d_out, d_ctrl, 0, /*save*/ 0);
-                } else {
-                    const StreamArgs sr = {dsc_h, d_q, d_qT0, d_out, d_ctrl, 0, 0, S, it};
-                    launch_solve(ss, dsc_h, Sh, st_h, partials_h, sums_h, rph, d_trace, 2, d_active, &sr);
-                }
-            } else {
-                // single rank: the solve hands finished slots their next registration itself (no refill launch)
-                const StreamArgs sa = {dsc_h, d_q, d_qT0, d_out, d_ctrl, 0, 0, 0, it};
-                launch_solve(ss, dsc_h, Sh, st_h, partials_h, sums_h, rph, d_trace, 0, d_active, &sa);
-            }
-            if (H == 2) {
-                if ((rc = half_event(&solved[h])) != ELM_OK) return rc;
-                HIPCHK(ctx, hipEventRecord(solved[h], ss));
-            }
+        if ((rc = enqueue_accumulate(ctx, map, dsc, S, blocks, st, rp, use_grid, use_cells, use_vnbr, partials)) != ELM_OK) return rc;
+        if (distributed) {
+            // reduce -> all-reduce -> solve -> refill: four launches + one collective per iteration.  (Side sums of a map with an asymmetric
+            // covariance sit right behind the packed sums: one exchange carries both.)  The refill launch walks the slots in slot order and
+            // hands the finished ones the next pending registrations -- first come, first served like the single-rank stream, yet identical
+            // on every rank (the finished flags derive from the all-reduced sums), so no slot idles while the queue has work.
+            launch_solve(ctx->stream, dsc, S, st, partials, sums, rp, d_trace, 1, d_active);
+            if ((rc = exchange(ctx, sums, (size_t)S * (rp.asym ? kSums + kAsymRecord : kSums))) != ELM_OK) return rc;
+            const StreamArgs sv = {dsc, d_q, d_qT0, d_out, d_ctrl, 0, /*save_only*/ 1, 0, it}; // the solve saves + counts, the refill assigns
+            launch_solve(ctx->stream, dsc, S, st, partials, sums, rp, d_trace, 2, d_active, &sv);
+            launch_stream_refill(ctx->stream, dsc, st, S, d_q, d_qT0, d_out, d_ctrl, 0, /*save*/ 0);
+        } else {
+            // single rank: the solve hands finished slots their next registration itself (no refill launch)
+            const StreamArgs sa = {dsc, d_q, d_qT0, d_out, d_ctrl, 0, 0, 0, it};
+            launch_solve(ctx->stream, dsc, S, st, partials, sums, rp, d_trace, 0, d_active, &sa);
         }
         const int done_iters = it + 1;
         const bool look = predicted > 0 ? done_iters >= predicted : (done_iters >= (count + S - 1) / S && (done_iters % 2) == 0);
         if (look) {
-            hipStream_t ls = (H == 2) ? ctx->solve_stream : ctx->stream; // both halves' solves of this iteration are queued there
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_active, &d_ctrl->completed, sizeof(int), hipMemcpyDeviceToHost, ls));
-            HIPCHK(ctx, hipStreamSynchronize(ls));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_active, &d_ctrl->completed, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
             if (*ctx->h_active == count) { ++it; break; }
         }
-    }
-    if (H == 2) { // the result download below is queued behind the last solves
-        for (int h = 0; h < 2; ++h)
-            if (solved[h]) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, solved[h], 0));
     }
     if ((rc = prof_mark(ctx)) != ELM_OK) return rc;
     HIPCHK(ctx, hipGetLastError());
@@ -2879,7 +2655,7 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
         d_trace = (elm_iter_trace*)ctx->d_trace.p;
     }
     RegParams rp;
-    memset(&rp, 0, sizeof(rp)); // (padding too: the registration graph compares it bytewise)
+    memset(&rp, 0, sizeof(rp));
     rp.th = cfg->max_search_dist;
     rp.th2 = cfg->max_search_dist * cfg->max_search_dist;
     rp.lm_lambda = cfg->lm_lambda;
@@ -2891,20 +2667,7 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
     rp.uniform_blocks = cap_blocks;
     rp.radar = 0;
     rp.stats = ctx->work_counters ? 1 : 0;
-    rp.solve_small = ctx->half_sets ? 1 : 0;
     rp.radar_var[0] = rp.radar_var[1] = rp.radar_var[2] = 0.0;
-    rp.sums = nullptr;
-    rp.tickets = nullptr;
-    rp.prev = nullptr;
-    if (ctx->prev_winner) {
-        if ((rc = prev_reserve(ctx, (size_t)cap_blocks * (size_t)S * kBlock)) != ELM_OK) return rc;
-        rp.prev = (uint32_t*)ctx->d_prev.p;
-    }
-    if (ctx->fused_reduce) {
-        if ((rc = dev_reserve(ctx, ctx->d_tickets, (size_t)S * sizeof(int32_t))) != ELM_OK) return rc;
-        rp.sums = (double*)ctx->d_sums.p;
-        rp.tickets = (int32_t*)ctx->d_tickets.p;
-    }
     if (pc.asym && (rc = reserve_asym(ctx, rp, blocks, S)) != ELM_OK) return rc;
     ctx->rp = rp;
     const bool use_grid = pc.use_grid, use_cells = pc.use_cells, use_vnbr = pc.use_vnbr;
@@ -2926,7 +2689,7 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
     ScanDesc* dsc = (ScanDesc*)ctx->d_scans.p;
     int* d_active = (int*)ctx->d_active.p;
     (void)hipGetLastError();
-    launch_slots_idle(ctx->stream, dsc, st, S, cap_blocks, rp.tickets);
+    launch_slots_idle(ctx->stream, dsc, st, S, cap_blocks);
     // the side streams start behind the control block's initialisation (and behind whatever the compute stream still reads from
     // the arena / staging of an earlier call)
     HF_CHK(hipEventRecord(ctx->ev_iter[0], ctx->stream));
@@ -2941,8 +2704,7 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
         HF_CHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->ev_groups.push_back(e);
     }
-    const bool serial = getenv("ELM_HOSTFED_SERIAL") != nullptr; // developer switch: uploads and ordering on the compute stream itself
-    hipStream_t copy_stream = serial ? ctx->stream : ctx->copy_stream, order_stream = serial ? ctx->stream : ctx->order_stream;
+    hipStream_t copy_stream = ctx->copy_stream, order_stream = ctx->order_stream;
     auto enqueue_group = [&](int g) -> hipError_t {
         const int set = g % kStageSets, r0 = g * G, r1 = std::min(count, r0 + G);
         hipEvent_t ev_copied = ctx->ev_groups[2 * g], ev_ordered = ctx->ev_groups[2 * g + 1];
@@ -3252,10 +3014,8 @@ int callback_register(elm_ctx* ctx, const elm_map* map, const void* stage, const
     if (!ctx || !map || !stage || stage != ctx->h_stage || !rel_time || !tab || !T0 || !cfg || !result || !n_source || !unpackable || n == 0 ||
         n > 0x7FFFFFFFull)
         return ELM_ERR_INVALID;
-    if (group_call(ctx)) { // the node callback registers ~10 k downsampled points: one device's work (create a plain context for it)
-        ctx->last_error = "elm_pcm_callback_point_cloud: not available on a device group";
-        return ELM_ERR_UNSUPPORTED;
-    }
+    if (group_call(ctx)) return ELM_ERR_UNSUPPORTED; // (a device group: the callback takes its stage-by-stage path -- deskew and downsample on the
+                                                     // lead device, the registration sharded over the ranks; elm_glue.cpp)
     *unpackable = 0;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc;

@@ -375,9 +375,6 @@ extern "C" int elm_pcm_callback_point_cloud(elm_ctx* ctx, const elm_map* map, co
     // The filtered cloud and the deskew tables are written straight into the context's page-locked staging buffer, laid out as
     // the device wants them ([tables | xyz] then the per-point times): two DMAs per scan, no pageable copies.  Scratch only grows:
     // no allocation on the per-scan path after warm-up.
-    static const bool dbg_time = getenv("ELM_DEBUG_TIMING") != nullptr; // developer: host-side phase times of the callback on stderr
-    const auto t_begin = std::chrono::steady_clock::now();
-    auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
     char* stage = (char*)elm_host::callback_staging(ctx, elm_host::kCbTableBytes + n * 4 * sizeof(float) + 64);
     if (!stage) return ELM_ERR_ALLOC;
     double* tab = (double*)stage;
@@ -398,9 +395,8 @@ extern "C" int elm_pcm_callback_point_cloud(elm_ctx* ctx, const elm_map* map, co
                             tab + TR, tab + 2 * TR, tab + 3 * TR, TR, &tabs);
     if (rc != ELM_OK) return rc;
     // Deskew + VoxelDownsample + RunRegister in one device pass (the undistorted cloud stays in HBM and becomes the registration
-    // source, the host waits once); ELM_CALLBACK=host, or voxel keys that do not pack, take the stage-by-stage host path with
-    // identical results.
-    static const bool host_path = [] { const char* e = getenv("ELM_CALLBACK"); return e && strcmp(e, "host") == 0; }();
+    // source, the host waits once); voxel keys that do not pack, or a device group (the registration is sharded over its ranks), take the
+    // stage-by-stage host path with identical results.
     int ok = 0, success = 0;
     double fit = 0.0, cov6[36], syncd[16], T0[16];
     float sync[16];
@@ -411,13 +407,8 @@ extern "C" int elm_pcm_callback_point_cloud(elm_ctx* ctx, const elm_map* map, co
     for (int i = 0; i < 16; ++i) syncd[i] = (double)sync[i];
     mul4_cm(syncd, node->tf_ego_to_lidar, T0); // sync_lidar_pose (pcm.cpp:266)
     int unpackable = 0;
-    const double us_host = since(t_begin);
-    const auto t_dev = std::chrono::steady_clock::now();
-    rc = host_path ? ELM_ERR_UNSUPPORTED
-                   : elm_host::callback_register(ctx, map, stage, ft, nf, &tabs, node->input_voxel_ds_m, T0, reg, &out->result, &out->n_source, &unpackable);
+    rc = elm_host::callback_register(ctx, map, stage, ft, nf, &tabs, node->input_voxel_ds_m, T0, reg, &out->result, &out->n_source, &unpackable);
     if (rc == ELM_OK && unpackable) rc = ELM_ERR_UNSUPPORTED;
-    if (dbg_time) fprintf(stderr, "[elm] callback: host filter + tables + pose %.1f us, device pass %.1f us (%d iterations, %zu -> %llu points)\n", us_host,
-                          since(t_dev), (int)out->result.iterations, nf, (unsigned long long)out->n_source);
     if (rc == ELM_OK) {
         memcpy(out->pose_lidar, out->result.T, sizeof(out->pose_lidar));
         memcpy(cov6, out->result.local_cov, sizeof(cov6));

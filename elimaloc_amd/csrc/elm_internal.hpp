@@ -118,8 +118,7 @@ struct DevMap {
     int32_t grid_tiled;         // 1: grid_start is addressed through grid_tiles
     int32_t gtny;               // tiles along y
     int32_t grid_wide;          // 1: the block array is 4 GB or more -- stage 1 addresses it in 16-byte units (template flag WIDE)
-    uint32_t grid_nslots;       // 4 * n_blk: candidate slots of the block array (a slot number from elsewhere -- RegParams::prev may hold
-                                // entries written against another map -- is only dereferenced below this)
+    uint32_t grid_nslots;       // 4 * n_blk: candidate slots of the block array
     const double* grid_gicp;    // [4 * n_blk][16]: pt_gicp gathered into slot order -- a GICP match reads its record without the index hop
                                 // (only for maps with a covariance outside the compact form)
     const double* grid_gicp8;   // [4 * n_blk][8]: the compact record {mean[3], unit normal[3], k, -}: 64 bytes = one memory sector per match;
@@ -220,15 +219,9 @@ struct RegParams {
     int32_t radar;           // use_radar_cov with a covariance method: k_accumulate_radar's 64-double partial records, full JTJ
     int32_t solve_small;     // 1 (half-set streams): k_solve<256> -- workgroups that fit beside a running accumulate launch
     int32_t stats;           // elm_ctx_set_work_counters: the grid / voxel-list kernels also sum the three work counters (STATS = 1)
-    // fused reduction: the LAST workgroup of a scan to arrive (ticket counter per scan) adds up the scan's partial records into
-    // sums[scan][32] -- no reduce launch; nullptr: the accumulate kernels only write partials, k_solve reduces (developer A/B)
-    double* sums;
-    int32_t* tickets;
     uint32_t* flagged;   // [workgroups] AVGICP on a map with flagged voxels: set by a workgroup of the fused walk that met (and skipped) a flagged
                          // record, read and cleared by the fix-up launch that adds those pairs to the workgroup's partial record (nullptr: the
                          // map runs the nine-entry walk with its fallback instead)
-    uint32_t* prev;      // [workgroups * kBlock] the winner (grid slot number, -1: none) of every scan point in the slot's previous iteration:
-                         // bounds the exact search of the next one (k_accumulate_grid); nullptr: not kept
     int32_t rank_check;  // 1 (several ranks, production kernels): slots 29..31 of every scan's exchanged sums -- the work counters, zero in
                          // production -- carry (1, id, id^2), id = 16 (registration + 1) + (iteration & 15): after the all-reduce every rank
                          // verifies sum(id) == n id and sum(id^2) == n id^2, i.e. that all ranks iterate the SAME registration in this slot
@@ -263,9 +256,8 @@ struct InitPack {
 constexpr int kSums = ELM_PACKED_SUMS; // 21 + 6 + 1 + 1 (+ n_cand, n_occ, pad)
 
 // ---- launchers (elm_kernels.hip) ----------------------------------------------------------------------
-void launch_init_state(hipStream_t s, ScanState* st, const double* T0, int batch, int map_empty, int* active, int* tickets);
-void launch_init_pack(hipStream_t s, ScanDesc* scans, ScanState* st, const InitPack& pack, int batch, int map_empty, int* active, const unsigned* n_dev,
-                      int* tickets);
+void launch_init_state(hipStream_t s, ScanState* st, const double* T0, int batch, int map_empty, int* active);
+void launch_init_pack(hipStream_t s, ScanDesc* scans, ScanState* st, const InitPack& pack, int batch, int map_empty, int* active, const unsigned* n_dev);
 void launch_stream_refill(hipStream_t s, ScanDesc* scans, ScanState* st, int slots, const QueueItem* queue, const double* qT0,
                           /* first: initial fill; save: copy finished states out + count them (0: the solve has done that) */
                           ScanState* out_state, StreamCtrl* ctrl, int first, int save = 1);
@@ -355,7 +347,7 @@ unsigned order_wide_groups(unsigned n);
 size_t order_wide_scratch_bytes(unsigned n);
 void launch_scan_order_wide(hipStream_t s, const OrderJob* job, unsigned n, const uint16_t* hilbert_lut, void* scratch);
 void launch_publish_ready(hipStream_t s, StreamCtrl* ctrl, int ready);
-void launch_slots_idle(hipStream_t s, ScanDesc* scans, ScanState* st, int slots, unsigned cap_blocks, int* tickets);
+void launch_slots_idle(hipStream_t s, ScanDesc* scans, ScanState* st, int slots, unsigned cap_blocks);
 constexpr int kOrderCells = 64; // cells per axis of the ordering grid (2 m cells: +-64 m around the sensor, clamped beyond)
 void launch_deskew(hipStream_t s, const float* xyz, const float* rel_time, uint32_t n, const DeskewDev& d,
                    float* xyz_out);

@@ -72,9 +72,6 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-#ifndef ELM_P2P_FUSED
-#define ELM_P2P_FUSED 1 // pair_p2p with fused multiply-adds (0: the reference's products and sums, one rounding each)
-#endif
 constexpr double kCompactK = 999.0; // 1 / 1e-3 - 1: the k of U diag(1, 1, 1e-3) U^T (vhm.hpp:143, 243)
 // inverse covariance I + k n n^T from the compact records (DevMap::grid_gicp8, VoxRec)
 __device__ __forceinline__ void compact_cinv(double nx, double ny, double nz, double k, double* Ci) {
@@ -508,65 +505,11 @@ __device__ __forceinline__ void block_reduce_store(double* acc, double (*red)[32
 }
 
 
-// ---- fused reduction of the partial records ----------------------------------------------------------------------------------
-// Every workgroup publishes its 32 block sums with 8-byte agent-scope stores (write-through: they leave the XCD's L2), drains
-// them (s_waitcnt vmcnt(0)) and takes a ticket on the scan's counter; the workgroup that draws the last ticket reads all records of
-// the scan back with agent-scope loads -- the "8-byte agent atomics on both sides" hand-off of MI355X_MICROARCH.md, no L2 write-back,
-// no acquire fence -- and adds them up in a FIXED order (eight interleaved groups, four rotating accumulators per group: trailing
-// all-zero records of a slot sized for a larger scan leave every sum bit-identical), so the result does not depend on which
-// workgroup came last.  sums[scan][32] is what the solve kernel (and, on several GPUs, the all-reduce) reads: an ICP iteration
-// is accumulate (+ reduce) -> [all-reduce] -> solve, no reduce launch.  s_scratch: >= 2 KB + 16 bytes of LDS that is dead by now.
-#ifndef ELM_FUSED_REDUCE_CODE
-#define ELM_FUSED_REDUCE_CODE 1 // 0: the accumulate kernels are built without the fused reduction (ELM_FUSED_REDUCE=1 is then refused)
-#endif
-__device__ __forceinline__ void publish_and_reduce(double value, unsigned L, int s, unsigned blk_begin, unsigned blk_end, double* __restrict__ partials,
-                                                   const RegParams& rp, double* s_scratch) {
-    const unsigned t = threadIdx.x;
-    if (!ELM_FUSED_REDUCE_CODE || rp.tickets == nullptr) { // unfused: k_solve reduces
-        if (t < (unsigned)kSums) partials[(size_t)L * kSums + t] = value;
-        return;
-    }
-    int* s_flag = reinterpret_cast<int*>(s_scratch + 8 * kSums);
-    if (t < (unsigned)kSums) __hip_atomic_store(&partials[(size_t)L * kSums + t], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t < 64u) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the record has left this CU before the ticket is drawn
-        if (t == 0u) {
-            const int nblk = (int)(blk_end - blk_begin);
-            const int tk = __hip_atomic_fetch_add(&rp.tickets[s], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = (tk == nblk - 1) ? 1 : 0;
-            if (last) __hip_atomic_store(&rp.tickets[s], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next iteration
-            *s_flag = last;
-        }
-    }
-    __syncthreads();
-    if (*s_flag == 0) return;
-    constexpr unsigned G = kBlock / 32; // 8 groups of 32 lanes, one lane per sum
-    const unsigned k = t & 31u, g = t >> 5;
-    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
-    unsigned b = blk_begin + g;
-    auto rec = [&](unsigned bb) { return __hip_atomic_load(&partials[(size_t)bb * kSums + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    for (; b + 7 * G < blk_end; b += 8 * G) { // eight loads in flight, summed in the order of the loop below
-        double a[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) a[q] = rec(b + q * G);
-#pragma unroll
-        for (int q = 0; q < 8; q += 4) { v0 += a[q]; v1 += a[q + 1]; v2 += a[q + 2]; v3 += a[q + 3]; }
-    }
-    for (; b + 3 * G < blk_end; b += 4 * G) {
-        const double a0 = rec(b), a1 = rec(b + G), a2 = rec(b + 2 * G), a3 = rec(b + 3 * G);
-        v0 += a0; v1 += a1; v2 += a2; v3 += a3;
-    }
-    if (b < blk_end) { v0 += rec(b); b += G; }
-    if (b < blk_end) { v1 += rec(b); b += G; }
-    if (b < blk_end) { v2 += rec(b); b += G; }
-    s_scratch[g * kSums + k] = (v0 + v1) + (v2 + v3);
-    __syncthreads();
-    if (t < (unsigned)kSums) {
-        double a = s_scratch[t];
-#pragma unroll
-        for (unsigned q = 1; q < G; ++q) a += s_scratch[q * kSums + t];
-        rp.sums[(size_t)s * kSums + t] = a;
-    }
+// A workgroup's 32 block sums -> its partial record; k_solve reduces the scan's records in a fixed order.  (Rounds 2-5 also carried a fused
+// form -- ticket counter per scan, the last workgroup reduces: -3 % on one rank, measured twice -- removed in round 6:
+// profiles/r06_removed_fused_reduce.patch.)
+__device__ __forceinline__ void publish_and_reduce(double value, unsigned L, int, unsigned, unsigned, double* __restrict__ partials, const RegParams&, double*) {
+    if (threadIdx.x < (unsigned)kSums) partials[(size_t)L * kSums + threadIdx.x] = value;
 }
 
 // DPP row operations (quad permutes, row rotations / mirrors) instead of ds_bpermute (__shfl), which goes through the LDS pipeline
@@ -1027,7 +970,6 @@ __device__ __forceinline__ void pair_sum_compact(PairSum& P, double ex, double e
 constexpr int kP2PVals = 21; // 18 sums + the three work counters
 __device__ __forceinline__ void pair_p2p(double* v, const double* Rinv, double px, double py, double pz, double ex, double ey, double ez,
                                          double d2, const RegParams& rp) {
-#if ELM_P2P_FUSED
     // (the rotation of e and the cross product with fused multiply-adds, the weight without the division's last correction: eleven
     // float64 instructions less per pair, the sums the same to the last bit or two)
     const double rx = __builtin_fma(Rinv[2], ez, __builtin_fma(Rinv[1], ey, Rinv[0] * ex));
@@ -1035,24 +977,13 @@ __device__ __forceinline__ void pair_p2p(double* v, const double* Rinv, double p
     const double rz = __builtin_fma(Rinv[8], ez, __builtin_fma(Rinv[7], ey, Rinv[6] * ex));
     const double den = rp.th + d2;
     const double w = div_close(rp.th2, den * den); // square(th) / square(th + |r|^2)  (reg.cpp:38-39)
-#else
-    const double rx = (Rinv[0] * ex + Rinv[1] * ey) + Rinv[2] * ez;
-    const double ry = (Rinv[3] * ex + Rinv[4] * ey) + Rinv[5] * ez;
-    const double rz = (Rinv[6] * ex + Rinv[7] * ey) + Rinv[8] * ez;
-    const double den = rp.th + d2;
-    const double w = div_normal(rp.th2, den * den); // square(th) / square(th + |r|^2)  (reg.cpp:38-39)
-#endif
     const double wx = w * px, wy = w * py, wz = w * pz;
     const double ax = w * rx, ay = w * ry, az = w * rz;
     v[0] = w;
     v[1] = wx; v[2] = wy; v[3] = wz;
     v[4] = wx * px; v[5] = wx * py; v[6] = wx * pz; v[7] = wy * py; v[8] = wy * pz; v[9] = wz * pz;
     v[10] = ax; v[11] = ay; v[12] = az;
-#if ELM_P2P_FUSED
     v[13] = __builtin_fma(py, az, -(pz * ay)); v[14] = __builtin_fma(pz, ax, -(px * az)); v[15] = __builtin_fma(px, ay, -(py * ax));
-#else
-    v[13] = py * az - pz * ay; v[14] = pz * ax - px * az; v[15] = px * ay - py * ax;
-#endif
     v[16] = sqrt_dist2(d2);
     v[17] = 1.0;
 }
@@ -1160,15 +1091,9 @@ __device__ __forceinline__ int row_sum_int(int v) {
 
 constexpr int kRedPass = 8;    // values per pass of the block reduction (16 KB of LDS per workgroup)
 
-#ifndef ELM_BLOCKS_PER_TRIP
-#define ELM_BLOCKS_PER_TRIP 2
-#endif
-#ifndef ELM_HARD_LANES
-#define ELM_HARD_LANES 4 // measured: 16 -> 56.9k, 8 -> 55.6k, 4 -> 63.0k, 2 -> 60.3k, 1 -> 55.2k registrations/s
-#endif
-#ifndef ELM_CELL_WAVES
-#define ELM_CELL_WAVES 5 // minimum waves per SIMD: caps the kernel at 96 VGPRs (measured: 5 -> 42.0k, unconstrained 4 -> 39.4k, 6 spills -> 36.5k registrations/s)
-#endif
+constexpr int kBlocksPerTrip = 2;
+constexpr int kHardLanes = 4; // measured: 16 -> 56.9k, 8 -> 55.6k, 4 -> 63.0k, 2 -> 60.3k, 1 -> 55.2k registrations/s
+constexpr int kCellWaves = 5; // minimum waves per SIMD: caps the kernel at 96 VGPRs (measured: 5 -> 42.0k, unconstrained 4 -> 39.4k, 6 spills -> 36.5k registrations/s)
 
 // an undecided point handed to the workgroup-cooperative exact stage of k_accumulate_cell
 struct HardRec {
@@ -1190,7 +1115,7 @@ struct HardRec {
 //     insertion order) lexicographically -- exactly the reference's first strict minimum in its visiting order (vhm.cpp:208-243).
 //   then every lane adds its pair and the workgroup reduces the packed sums.
 template <int METHOD>
-__global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? ELM_CELL_WAVES : ELM_CELL_WAVES - 1)) void k_accumulate_cell(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
+__global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? kCellWaves : kCellWaves - 1)) void k_accumulate_cell(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
                                                                             unsigned total_blocks, const ScanState* __restrict__ st,
                                                                             double* __restrict__ partials, const RegParams rp) {
     constexpr int NV = (METHOD == ELM_P2P) ? kP2PVals : kSums;
@@ -1477,11 +1402,7 @@ __device__ __forceinline__ GridAxis grid_axis(double g, const DevMap& m) {
     const double fl = floor(t);
     a.cg = (int)fl;
     a.fr = (float)(t - fl);
-#if ELM_ONE_FLOOR
     a.f = a.cg >> 1; // floor(q) == floor(floor(2 q) / 2): PointToVoxel (vhm.hpp:176-180) from the ONE floor the cell needs anyway
-#else
-    a.f = (int)floor(q); // PointToVoxel (vhm.hpp:176-180)
-#endif
     // stored keys f-1 .. f+1 -> cells: key k > 0 owns cells {2k, 2k+1}, key 0 owns {-2 .. 1}, key k < 0 owns {2k-2, 2k-1}
     const int kl = a.f - 1, kh = a.f + 1;
     a.alo = 2 * kl - ((kl <= 0) ? 2 : 0);
@@ -1570,49 +1491,10 @@ __device__ __forceinline__ const uint32_t* col_cells(const DevMap& m, int cx, in
     return m.grid_start + te.x + (unsigned)(((cx & (kTile - 1)) << kTileShift) | (cy & (kTile - 1))) * (unsigned)(nz + 1) + (unsigned)lo;
 }
 
-#ifndef ELM_S2_PIPE
-#define ELM_S2_PIPE 1
-#endif
-// Round-5 A/B switches of the per-point code (measured: profiles/r05_kernel_ab.txt)
-#ifndef ELM_REDUCE_WAVE
-#define ELM_REDUCE_WAVE 0 // 1: every wavefront reduces its P2P values by itself (DPP rows + two cross-row exchanges), one LDS pass adds the four
-                          // wavefronts -- instead of the transpose: 98.0 k -> 87.1 k registrations/s (324 instead of ~90 instructions per wave)
-#endif
-#ifndef ELM_ONE_FLOOR
-#define ELM_ONE_FLOOR 1   // the floor key from the cell's floor (f = cg >> 1) instead of a second v_floor_f64 + conversion per axis
-#endif
-#ifndef ELM_EG_BOUND
-#define ELM_EG_BOUND 1    // |g - float32(g)| bounded by half an ulp per axis instead of three float64 differences (nine conversions)
-#endif
-#ifndef ELM_STASH_OWN
-#define ELM_STASH_OWN 1   // the transformed point waits in the thread's OWN four slots of the reduction buffer (address = tid * 8) instead of
-                          // two 16-byte slots of its wavefront behind an eight-instruction swizzle at each of the four uses
-#endif
-#ifndef ELM_S2_PRIO
-#define ELM_S2_PRIO 0 // 1..3: s_setprio around stage 2's walk (its wavefronts' dependent gathers issue ahead of the other wavefronts' arithmetic).
-                      // Measured (profiles/r05_s2_prio.txt): hard guesses -0.5 %, P2P / GICP +-0.1 %
-#endif
-#ifndef ELM_S2_SEED
-#define ELM_S2_SEED 1 // stage 2 seeds the ball of a point whose stage-1 block was empty (0: full walk of its 27 voxels, developer A/B)
-#endif
-#ifndef ELM_S2_GH
-#define ELM_S2_GH 0 // 1: stage 2's float32 pass on float32(g) alone (six packed subtractions fewer per block).  Measured (tools/r4_call5.sh, prebuilt
-                    // variants, two runs each): easy 94.46 k -> 93.78 k, hard 20.46 k -> 20.20 k registrations/s -- the root and the wider margin of the
-                    // decision cost more than the subtractions save.  Off.
-#endif
-#ifndef ELM_PREV_WINNER
-#define ELM_PREV_WINNER 0 // 1: an undecided point's ball is also bounded by its previous iteration's winner (RegParams::prev).  Measured (same A/B):
-                          // hard 20.20 k -> 20.71 k (+2.5 %), easy 93.78 k -> 93.08 k (-0.75 %, although only workgroups with >= 1/8 undecided points keep
-                          // the winners).  The headline workload pays for it: off; built with -DELM_PREV_WINNER=1 and run with ELM_PREV_WINNER=1
-#endif
-#ifndef ELM_GRID_WAVES
-#define ELM_GRID_WAVES 8 // minimum waves per SIMD of the P2P kernel = a 64-VGPR cap.  Round 4, after the work counters left the production kernels (2 spilled
+constexpr int kGridWaves = 8; // minimum waves per SIMD of the P2P kernel = a 64-VGPR cap.  Round 4, after the work counters left the production kernels (2 spilled
                          // VGPRs, 26 spilled SGPRs at the cap): 6 -> 89.0 k, 7 -> 94.0-94.3 k, 8 -> 95.8-96.4 k registrations/s (hard guesses 20.5 -> 20.8 k);
                          // round 2, with the counters: 5 -> 59.8k, 6 -> 63.9k, 7 -> 65.6k, 8 (35 spills) -> 54.2k.  profiles/r04_sweep.txt
-#endif
-#ifndef ELM_GICP_WAVES
-#define ELM_GICP_WAVES 7 // GICP: 5 (the old cap; the kernel used 72 VGPRs anyway) -> 71.2-71.6 k, 7 (one spill) -> 72.5-73.3 k, 8 (8 spills) -> 67.2 k
-#endif
+constexpr int kGicpWaves = 7; // GICP: 5 (the old cap; the kernel used 72 VGPRs anyway) -> 71.2-71.6 k, 7 (one spill) -> 72.5-73.3 k, 8 (8 spills) -> 67.2 k
 // The exact search of ONE undecided point by its group of LPI lanes (stage 2 of k_accumulate_grid): the ball of radius sqrt(R.r2) around g (seeded first when stage 1 found nothing) intersected with the reference's allowed cell
 // range and the grid, float32 keys first, the reference's float64 distances and visiting order on a near tie.  win: block * 4 + slot of the
 // nearest neighbour (-1: none), the same value in every lane of the group; walked: candidate slots this lane tested (instrumented builds).
@@ -1623,7 +1505,6 @@ __device__ __forceinline__ void grid_ball_walk(const DevMap& m, const GridBlk* _
     int lox = ax.alo, hix = ax.ahi, loy = ay.alo, hiy = ay.ahi, loz = az.alo, hiz = az.ahi;
     int seeded = 0;
     float r2s = R.r2;
-#if ELM_S2_SEED
     // A point whose stage-1 block came back EMPTY (a third of the undecided points under a poor initial guess: the surface is
     // two cells below the point) has no ball: it would walk all 36 columns of its 27 voxels, ~240 candidates.  Seed it first:
     // the group's lanes probe the 2 x 2 columns nearest to the point over the whole allowed z-range; the nearest candidate found
@@ -1655,7 +1536,6 @@ __device__ __forceinline__ void grid_ball_walk(const DevMap& m, const GridBlk* _
         if (!(r2s < __builtin_inff()) && best < 1e30f) // (padding slots sit at 1e18: their squares are not candidates)
             r2s = best + best * 4e-6f + 4e-11f * (fabsf((float)R.gx) + fabsf((float)R.gy) + fabsf((float)R.gz) + 1.0f);
     }
-#endif
     if (r2s < __builtin_inff()) {
         // every candidate within sqrt(r2) of g -- the nearest one and whatever ties with it -- has its cell inside the
         // per-axis cell range of [g - r, g + r] (1e-6 of margin: a stored coordinate exactly on a cell face counts to the
@@ -1682,13 +1562,10 @@ __device__ __forceinline__ void grid_ball_walk(const DevMap& m, const GridBlk* _
         // from the one to gh by at most eg = |g - gh|_1 in the ROOT, which the decision below pays for
         const float ghx = (float)R.gx, ghy = (float)R.gy, ghz = (float)R.gz;
         const float glx = (float)(R.gx - (double)ghx), gly = (float)(R.gy - (double)ghy), glz = (float)(R.gz - (double)ghz);
-        const float eg = ELM_S2_GH ? (fabsf(glx) + fabsf(gly) + fabsf(glz)) * 1.000001f : 0.f;
-        const f32x2 gxy = {ghx, ghy}, gzz = {ghz, 0.f}, gzl = {ghz, glx}, gl2 = {gly, glz};
-        (void)gzz; (void)gzl; (void)gl2;
+        const f32x2 gxy = {ghx, ghy}, gzl = {ghz, glx}, gl2 = {gly, glz};
         unsigned m1 = 0x7F800000u, m2 = 0x7F800000u;
         int jb = 0;
         const float rny = __builtin_amdgcn_rcpf((float)ny); // c / ny for the few dozen columns of a ball: exact via float32
-#if ELM_S2_PIPE
         // software-pipelined walk: the offsets of this lane's NEXT column are requested before the current column's blocks
         // are walked, and block b + 1 before block b is evaluated -- the walk is a chain of dependent round trips (offsets ->
         // blocks, column after column) that the other wavefronts only partly hide when many points are undecided
@@ -1711,8 +1588,7 @@ __device__ __forceinline__ void grid_ball_walk(const DevMap& m, const GridBlk* _
                 const GridBlk B = Bn;
                 Bn = lp[(b + 1 < b1) ? b + 1 : 0]; // (block 0: the padding block, always resident)
                 f32x2 da, db;
-                if (ELM_S2_GH) blk_dist_h(B, gxy, gzz, da, db);
-                else blk_dist(B, gxy, gzl, gl2, da, db);
+                blk_dist(B, gxy, gzl, gl2, da, db);
                 const unsigned was = m1;
                 two_smallest(da.x, 0u, m1, m2);
                 two_smallest(da.y, 1u, m1, m2);
@@ -1721,39 +1597,15 @@ __device__ __forceinline__ void grid_ball_walk(const DevMap& m, const GridBlk* _
                 jb = (m1 != was) ? b : jb;
             }
         }
-#else
-        for (int c = (int)rl; c < ncol; c += (int)LPI) {
-            const int qx = (int)(((float)c + 0.5f) * rny);
-            const int cx = lox + qx, cy = loy + (c - qx * ny);
-            int zc0, nzc;
-            const uint32_t* e = col_cells<TILED>(m, cx, cy, loz, hiz, zc0, nzc);
-            const int b0 = (int)e[0], b1 = (int)e[nzc];
-            walked += 4 * (b1 - b0);
-            for (int b = b0; b < b1; ++b) {
-                const GridBlk B = lp[b];
-                f32x2 da, db;
-                if (ELM_S2_GH) blk_dist_h(B, gxy, gzz, da, db);
-                else blk_dist(B, gxy, gzl, gl2, da, db);
-                const unsigned was = m1;
-                two_smallest(da.x, 0u, m1, m2);
-                two_smallest(da.y, 1u, m1, m2);
-                two_smallest(db.x, 2u, m1, m2);
-                two_smallest(db.y, 3u, m1, m2);
-                jb = (m1 != was) ? b : jb;
-            }
-        }
-#endif
         const unsigned m1g = group_min_u32<LPI>(m1);
         const unsigned long long holders = __ballot(m1 == m1g) & gmask;
         const unsigned hl = (unsigned)__ffsll((long long)holders) - 1u; // first lane of the group that holds the minimum
         const unsigned m2g = group_min_u32<LPI>((lane == hl) ? m2 : m1); // a second holder of the same key counts as a tie
         const int jw = __shfl(jb * 4 + (int)(m1 & 3u), (int)hl, 64);
         const float d1 = __uint_as_float(m1g & ~3u), d2 = __uint_as_float(m2g & ~3u);
-        // clear float32 winner: sqrt(d2) - sqrt(d1) > 2 eg holds for the distances to gh (2^-18: float32 arithmetic + key bits, see
-        // stage 1) <=> d2 > d1 + 4 eg sqrt(d1) + 4 eg^2, with sqrt(d2) >= sqrt(d1) in its place (one root per point, padding
-        // slots at 1e36 included: they never win)
-        const float s2 = __builtin_sqrtf(fminf(d2, 1e30f)) * 1.000001f;
-        const float slack = ELM_S2_GH ? (4.0f * eg * s2 + 4.0f * eg * eg) * 1.000001f : 4e-11f * (fabsf(ghx) + fabsf(ghy) + fabsf(ghz) + 1.0f);
+        // clear float32 winner (2^-18: float32 arithmetic + key bits, see stage 1; the distances are to g itself -- gh + the low parts --
+        // so only the rounding of the low parts is left for the slack; padding slots at 1e36 never win)
+        const float slack = 4e-11f * (fabsf(ghx) + fabsf(ghy) + fabsf(ghz) + 1.0f);
         if (jw >= 4 && d2 > d1 + d1 * 3.814697265625e-06f + slack) win = jw; // (2^-18 on one side covers both, as in stage 1)
         else need64 = live && jw >= 4;                                         // near tie: the float64 walk below decides
     }
@@ -1819,7 +1671,7 @@ __device__ __forceinline__ void grid_ball_walk(const DevMap& m, const GridBlk* _
 // WIDE = 1: the block array does not fit 32-bit byte offsets (4 GB = ~275 M map points): stage 1 carries offsets in 16-byte units
 // (three per block) and forms the 64-bit address per block with one shift-add; everything else addresses blocks by index already.
 template <int METHOD, int COMPACT, int TILED, int STATS, int WIDE>
-__global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_WAVES) : ELM_GICP_WAVES)) void k_accumulate_grid( // (the instrumented P2P build holds 20.7 KB of LDS: 7 workgroups per CU)
+__global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : kGridWaves) : kGicpWaves)) void k_accumulate_grid( // (the instrumented P2P build holds 20.7 KB of LDS: 7 workgroups per CU)
        const DevMap m, const ScanDesc* __restrict__ scans, int batch,
                                                                             unsigned total_blocks, const ScanState* __restrict__ st,
                                                                             double* __restrict__ partials, const RegParams rp) {
@@ -1860,7 +1712,6 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
     // redid the 18-operation float64 transform at both later uses -- in the epilogue and, for a wavefront with an undecided point, before
     // stage 2: 36 half-rate instructions per point.  The P2P pair also needs the point itself: x and y as floats in the stash's last 8
     // bytes, z in a 1 KB array of its own -- re-reading it from global memory at the epilogue cost 4.7 %.)
-#if ELM_STASH_OWN
     // (round 5) the thread's OWN slots of values 4..7 of the reduction's first pass: doubles (4 + j) * kBlock + tid -- the address is
     // tid * 8 plus immediate offsets (two ds_write2st64_b64 / ds_read2st64_b64), and the thread itself overwrites them first
     auto stash_w = [&](double a, double b, double c, double d) {
@@ -1873,22 +1724,6 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
         const double w = p[7 * kBlock];
         pxf = __int_as_float(__double2loint(w)); pyf = __int_as_float(__double2hiint(w));
     };
-#else
-    auto stash = [&](unsigned half) -> double2* { // recomputed at each use (an address held across the kernel costs a register)
-        unsigned t = threadIdx.x;
-        asm volatile("" : "+v"(t));
-        return reinterpret_cast<double2*>(s_buf) + ((4u + 2u * half + ((t >> 5) & 1u)) * (kBlock / 2) + (t >> 6) * 32u + (t & 31u));
-    };
-    auto stash_w = [&](double a, double b, double c, double d) {
-        *stash(0) = make_double2(a, b);
-        *stash(1) = make_double2(c, d);
-    };
-    auto load_g = [&](double& gx, double& gy, double& gz, float& pxf, float& pyf) {
-        const double2 a = *stash(0), b = *stash(1);
-        gx = a.x; gy = a.y; gz = b.x;
-        pxf = __int_as_float(__double2loint(b.y)); pyf = __int_as_float(__double2hiint(b.y));
-    };
-#endif
     auto transform = [&](const float4 pf, double& px, double& py, double& pz, double& gx, double& gy, double& gz) {
         px = pf.x; py = pf.y; pz = pf.z;
         gx = ((S.T[0] * px + S.T[4] * py) + S.T[8] * pz) + S.T[12]; // g = T * [p, 1] (reg.hpp:141-146), the reference's association
@@ -1991,12 +1826,8 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
         // to gh and to g differ by at most eg = |g - gh|_1.  Everything the decision compares lies below rr (a winner at rr or
         // beyond is undecided anyway), so (sqrt(d) + eg)^2 <= d + egrr with egrr = 2 eg rr + eg^2: margins without a root.
         float ghx = (float)gx, ghy = (float)gy, ghz = (float)gz;
-#if ELM_EG_BOUND
         // (|g - gh| <= half an ulp of gh per axis = 2^-24 |gh|: the bound instead of the three float64 differences)
         const float eg = (fabsf(ghx) + fabsf(ghy) + fabsf(ghz)) * 5.9604652e-08f;
-#else
-        const float eg = (fabsf((float)(gx - (double)ghx)) + fabsf((float)(gy - (double)ghy)) + fabsf((float)(gz - (double)ghz))) * 1.000001f;
-#endif
         float egrr = (2.0f * eg * fmaxf(rr, 0.f) + eg * eg) * 1.000001f;
         // for the ball of an undecided point: any block candidate is within 3.5 h of g
         float egblk = (7.0f * eg * (float)h + eg * eg) * 1.000001f;
@@ -2031,24 +1862,24 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
             const f32x2 gxy = {ghx, ghy}, gzz = {ghz, 0.f};
             unsigned m1 = 0x7F800000u, m2 = 0x7F800000u; // +inf
             unsigned jb = 0;                             // byte offset of m1's block (block 0 = padding = none yet)
-            for (int t0 = 0; t0 < nblk; t0 += ELM_BLOCKS_PER_TRIP) { // ELM_BLOCKS_PER_TRIP blocks (three 16-byte loads each) per round trip
-                unsigned pb[ELM_BLOCKS_PER_TRIP]; // byte offsets (32-bit: the loads take the scalar base + this lane's offset)
+            for (int t0 = 0; t0 < nblk; t0 += kBlocksPerTrip) { // kBlocksPerTrip blocks (three 16-byte loads each) per round trip
+                unsigned pb[kBlocksPerTrip]; // byte offsets (32-bit: the loads take the scalar base + this lane's offset)
 #pragma unroll
-                for (int w = 0; w < ELM_BLOCKS_PER_TRIP; ++w) {
+                for (int w = 0; w < kBlocksPerTrip; ++w) {
                     const int t = t0 + w;
                     unsigned b_ = sb[3];
 #pragma unroll
                     for (int k = 2; k >= 0; --k) b_ = (t < cb[k + 1]) ? sb[k] : b_;
                     pb[w] = (t < nblk) ? b_ + (unsigned)t * kBlkStep : 0u; // past the end: block 0, four padding slots
                 }
-                GridBlk B[ELM_BLOCKS_PER_TRIP];
+                GridBlk B[kBlocksPerTrip];
 #pragma unroll
-                for (int w = 0; w < ELM_BLOCKS_PER_TRIP; ++w)
+                for (int w = 0; w < kBlocksPerTrip; ++w)
                     B[w] = *reinterpret_cast<const GridBlk*>(reinterpret_cast<const char*>(lp) + (WIDE ? ((size_t)pb[w] << 4) : (size_t)pb[w]));
                 __builtin_amdgcn_sched_barrier(0); // all six loads are in flight before the first is waited for (the scheduler otherwise
                                                    // sometimes starts on the first block between the two blocks' loads)
 #pragma unroll
-                for (int w = 0; w < ELM_BLOCKS_PER_TRIP; ++w) {
+                for (int w = 0; w < kBlocksPerTrip; ++w) {
                     f32x2 da, db;
                     blk_dist_h(B[w], gxy, gzz, da, db);
                     const unsigned was = m1;
@@ -2079,7 +1910,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
             }
         }
     }
-    // ---- stage 2: queue the undecided points in thread order, ELM_HARD_LANES lanes per point
+    // ---- stage 2: queue the undecided points in thread order, kHardLanes lanes per point
     const unsigned long long hm = __ballot(hard);
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (lane == 0) s_cnt[wave] = (unsigned)__popcll(hm);
@@ -2091,35 +1922,8 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
         n_hard += s_cnt[w];
     }
     my_slot += (unsigned)__popcll(hm & ((1ull << lane) - 1ull));
-    // A slot number per scan point (rp.prev) is kept -- read here, written at the end -- only by workgroups in which an eighth of the points
-    // or more are undecided (poor initial guesses; with a good one 2-3 % are, and the bookkeeping would cost more than it saves: -1.9 %
-    // on the easy set when unconditional).  An entry that is stale (an older iteration, an earlier registration of the slot) is still
-    // the slot of a real map point and is checked like any other before its distance is used; the buffer starts out as all -1.
-    const bool keep_prev = ELM_PREV_WINNER && rp.prev && n_hard >= (unsigned)kBlock / 8u; // uniform
-    const size_t pidx = (size_t)L * kBlock + threadIdx.x;
     if (n_hard) { // uniform
         GridHardRec* __restrict__ s_rec = reinterpret_cast<GridHardRec*>(s_buf);
-        if (keep_prev && hard) {
-            // its distance to the NEW g bounds the nearest neighbour before anything is walked: the point takes the smaller of this bound
-            // and stage 1's -- a tighter ball and, when the stage-1 block came back empty, no seeding pass.  Exactness is untouched: the
-            // ball is still cleared completely, the bound only has to be an upper bound (float64 distance, rounded up).
-            const unsigned pj = rp.prev[pidx];
-            if (pj < m.grid_nslots) { // (-1 = none; an entry written against another map may lie beyond this one's slots)
-                double gx, gy, gz;
-                float pxf_, pyf_;
-                load_g(gx, gy, gz, pxf_, pyf_);
-                const Pt3 q = blk_point(lp, (int)pj);
-                // only a point of one of the 27 buckets the reference visits for the NEW g is a candidate: stored (truncated) key within one
-                // of the query's floor key on every axis (vhm.cpp:275 / vhm.hpp:176-180, the arithmetic of grid_axis / visit_rank)
-                auto vk = [&](double v) { return (m.inv_vs_exact != 0.0) ? v * m.inv_vs_exact : v / m.voxel_size; };
-                const int dx = (int)vk((double)q.x) - (int)floor(vk(gx)), dy = (int)vk((double)q.y) - (int)floor(vk(gy)), dz = (int)vk((double)q.z) - (int)floor(vk(gz));
-                if (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1) {
-                    const double ex = (double)q.x - gx, ey = (double)q.y - gy, ez = (double)q.z - gz;
-                    const float d = (float)((ex * ex + ey * ey) + ez * ez);
-                    hr2 = fminf(hr2, d + d * 2.4e-7f + 1e-30f); // (float) rounds to nearest: 2^-22 relative covers it upwards
-                }
-            }
-        }
         if (hard) {
             GridHardRec r;
             float pxf_, pyf_;
@@ -2128,11 +1932,8 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
             s_rec[my_slot] = r;
         }
         __syncthreads();
-        constexpr unsigned LPI = ELM_HARD_LANES; // lanes per undecided point (a power of two <= 16: one DPP row holds 16 / LPI points)
+        constexpr unsigned LPI = kHardLanes; // lanes per undecided point (a power of two <= 16: one DPP row holds 16 / LPI points)
         const unsigned rl = threadIdx.x & (LPI - 1u), row = threadIdx.x / LPI;
-#if ELM_S2_PRIO
-        __builtin_amdgcn_s_setprio(ELM_S2_PRIO); // the walk is a chain of dependent gathers: its wavefronts issue ahead of the others' arithmetic
-#endif
         for (unsigned it0 = 0; it0 < n_hard; it0 += kBlock / LPI) {
             const unsigned it = it0 + row;
             if (it0 + (threadIdx.x & ~63u) / LPI >= n_hard) break; // wave-uniform: this wavefront has no point in this pass
@@ -2146,9 +1947,6 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
                 if (kStats) s_tst[it] = walked;
             }
         }
-#if ELM_S2_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         __syncthreads();
         if (hard) {
             bj = s_res[my_slot];
@@ -2156,7 +1954,6 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
         }
         __syncthreads(); // the queue is dead: the reduction may overwrite it
     }
-    if (keep_prev && valid) rp.prev[pidx] = (unsigned)bj; // (-1: no candidate at all)
     if (QUERY) { // the pair of GetCorrespondencePoints (vhm.cpp:31-88): the nearest point of the 27 buckets when it lies within max_dist
         if (valid) {
             double gx, gy, gz;
@@ -2261,28 +2058,8 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : ELM_GRID_
     __shared__ double s_asym[(METHOD != ELM_P2P && COMPACT != 2) ? kAsymSums : 1];
     __shared__ unsigned s_hitw[kBlock / 64];
     if (METHOD != ELM_P2P && COMPACT != 2) asym_mark(P.A, rp, s_hitw);
-#if ELM_REDUCE_WAVE
-    if (METHOD == ELM_P2P) {
-        const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            double a = v[k];
-            a += dpp_move<0xB1>(a);  // quad_perm [1,0,3,2]
-            a += dpp_move<0x4E>(a);  // quad_perm [2,3,0,1]
-            a += dpp_move<0x124>(a); // row_ror:4
-            a += dpp_move<0x128>(a); // row_ror:8
-            a += __shfl_xor(a, 16, 64);
-            a += __shfl_xor(a, 32, 64);
-            if (lane_ == 0) s_buf[wave_ * 32 + k] = a;
-        }
-        __syncthreads();
-        if (threadIdx.x < (unsigned)NV) s_red[threadIdx.x] = ((s_buf[threadIdx.x] + s_buf[32 + threadIdx.x]) + s_buf[64 + threadIdx.x]) + s_buf[96 + threadIdx.x];
-        __syncthreads();
-    } else
-#else
     if (METHOD == ELM_P2P) block_reduce_to_lds<NV, kRedPass>(v, s_buf, s_red);
     else
-#endif
         block_reduce_pair_sum<kRedPass, kStats ? kSums : kSums - 3>(P, s_buf, s_red);
     if (METHOD != ELM_P2P && COMPACT != 2) asym_side_store(P.A, P.ax, P.ay, P.az, L, rp, s_buf, s_asym, s_hitw);
     const int tk = (int)threadIdx.x;
@@ -2430,27 +2207,19 @@ __device__ __forceinline__ unsigned vnbr_vid(const DevMap& m, unsigned slot) { r
 // the float32 filter, then ONE float64 record of the winner from the per-voxel table DevMap::vox_rec (round 6: a voxel's record is
 // stored once, 64 B x n_vox -- cache resident -- instead of once per query list it appears in, 27 x) -- no staging, no barriers before
 // the block reduction.  A float32 near-tie walks the list's records in the reference's order, float64.
-#ifndef ELM_VNBR_RECS
-#define ELM_VNBR_RECS 3 // VGICP: list records per round trip (measured 2 / 3 / 4 / 6 / 8: 105.9 / 110.5 / 102.3 / 99.3 / 92.3 k registrations/s)
-#endif
-#ifndef ELM_AVG_RECS
-#define ELM_AVG_RECS 1 // AVGICP: records per round trip: 1 -> 68 VGPRs, 7 waves, 89-91k registrations/s; 2 -> 99 VGPRs, 4 waves, 77.9k; 3 -> 76.9k;
+constexpr int kVnbrRecs = 3; // VGICP: list records per round trip (measured 2 / 3 / 4 / 6 / 8: 105.9 / 110.5 / 102.3 / 99.3 / 92.3 k registrations/s)
+constexpr int kAvgRecs = 1; // AVGICP: records per round trip: 1 -> 68 VGPRs, 7 waves, 89-91k registrations/s; 2 -> 99 VGPRs, 4 waves, 77.9k; 3 -> 76.9k;
                        // 4 -> 56.1k (round 3, 64-byte self-contained records; accumulating the pairs' w (I + k n n^T) in symmetric form
                        // without forming the 3x3 per pair: the same 88-89k -- the walk is a chain of dependent record loads, not arithmetic)
-#endif
-#ifndef ELM_VNBR_BLKS
-#define ELM_VNBR_BLKS 1 // VGICP filter: float32 blocks of four means per round trip (1 / 2 / 3: 123.4 / 121.0 / 120.5 k registrations/s)
-#endif
-#ifndef ELM_VNBR_WAVES
-#define ELM_VNBR_WAVES 1
-#endif
+constexpr int kVnbrBlks = 1; // VGICP filter: float32 blocks of four means per round trip (1 / 2 / 3: 123.4 / 121.0 / 120.5 k registrations/s)
+constexpr int kVnbrWaves = 1;
 // FACES (AVGICP on maps with the dense face-sublist table; the walk reads the face sublists, 48 bytes per record):
 //   1  nine entries of w C^-1 per pair, flagged voxels read their stored inverse in line
 //   2  the fused walk (sum w, sum (w k) n n^T, b) on a map without a flagged voxel
 //   4  the fused walk on a map WITH flagged voxels: their pairs are skipped, the workgroup is marked (RegParams::flagged)
 //   3  the fix-up launch after 4: marked workgroups only, flagged records only (form 1's arithmetic), ADDED to the partial record
 template <int METHOD, int COMPACT, int STATS, int FACES>
-__global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
+__global__ __launch_bounds__(kBlock, kVnbrWaves) void k_accumulate_vnbr(const DevMap m, const ScanDesc* __restrict__ scans, int batch,
                                                             unsigned total_blocks, const ScanState* __restrict__ st,
                                                             double* __restrict__ partials, const RegParams rp) {
     constexpr int kStats = (STATS == 1) ? 1 : 0;
@@ -2531,13 +2300,13 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
                 const float eg = (fabsf((float)(gx - (double)ghx)) + fabsf((float)(gy - (double)ghy)) + fabsf((float)(gz - (double)ghz))) * 1.000001f;
                 const f32x2 gxy = {ghx, ghy}, gzz = {ghz, 0.f};
                 unsigned m1 = 0x7F800000u, m2 = 0x7F800000u;
-                for (unsigned b0 = 0; b0 < nblk; b0 += ELM_VNBR_BLKS) {
-                    VoxBlk B[ELM_VNBR_BLKS];
+                for (unsigned b0 = 0; b0 < nblk; b0 += kVnbrBlks) {
+                    VoxBlk B[kVnbrBlks];
 #pragma unroll
-                    for (int u = 0; u < ELM_VNBR_BLKS; ++u) B[u] = m.vnbr_blk[(b0 + u < nblk) ? blk0 + b0 + u : m.vnbr_pad_blk];
+                    for (int u = 0; u < kVnbrBlks; ++u) B[u] = m.vnbr_blk[(b0 + u < nblk) ? blk0 + b0 + u : m.vnbr_pad_blk];
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int u = 0; u < ELM_VNBR_BLKS; ++u) {
+                    for (int u = 0; u < kVnbrBlks; ++u) {
                         f32x2 da, db;
                         blk_dist_h(B[u].g, gxy, gzz, da, db);
                         const unsigned was = m1;
@@ -2559,12 +2328,12 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
                 }
             }
             if (exact) {
-                for (unsigned j = 0; j < cnt; j += ELM_VNBR_RECS) { // ELM_VNBR_RECS records per round trip (slot word, then the voxel's record)
-                    VoxRec r[ELM_VNBR_RECS];
+                for (unsigned j = 0; j < cnt; j += kVnbrRecs) { // kVnbrRecs records per round trip (slot word, then the voxel's record)
+                    VoxRec r[kVnbrRecs];
 #pragma unroll
-                    for (int u = 0; u < ELM_VNBR_RECS; ++u) r[u] = m.vox_rec[vnbr_vid(m, start + min(j + u, cnt - 1))]; // past the end: the last record again (never < itself)
+                    for (int u = 0; u < kVnbrRecs; ++u) r[u] = m.vox_rec[vnbr_vid(m, start + min(j + u, cnt - 1))]; // past the end: the last record again (never < itself)
 #pragma unroll
-                    for (int u = 0; u < ELM_VNBR_RECS; ++u) {
+                    for (int u = 0; u < kVnbrRecs; ++u) {
                         const double ex = r[u].mx - gx, ey = r[u].my - gy, ez = r[u].mz - gz;
                         const double d2 = (ex * ex + ey * ey) + ez * ez;
                         const bool c = d2 < bd2; // strict: the first met keeps a tie (vhm.cpp:128)
@@ -2679,24 +2448,24 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
                     if (d2 < rp.th2) avg_pair_add(Q, ex, ey, ez, Ci, rp);
                 }
             } else
-            for (unsigned j = 0; j < cnt; j += ELM_AVG_RECS) { // ELM_AVG_RECS records (two 16-byte loads each) per round trip
-                VoxRec r[ELM_AVG_RECS];
+            for (unsigned j = 0; j < cnt; j += kAvgRecs) { // kAvgRecs records (two 16-byte loads each) per round trip
+                VoxRec r[kAvgRecs];
                 if (via_faces) {
 #pragma unroll
-                    for (int u = 0; u < ELM_AVG_RECS; ++u) r[u] = lp[min(j + u, cnt - 1)];
+                    for (int u = 0; u < kAvgRecs; ++u) r[u] = lp[min(j + u, cnt - 1)];
                 } else { // the whole list: the slot word carries the position code, the record comes from the per-voxel table
 #pragma unroll
-                    for (int u = 0; u < ELM_AVG_RECS; ++u) {
+                    for (int u = 0; u < kAvgRecs; ++u) {
                         const unsigned vc = (unsigned)vnbr_vc(m, start + min(j + u, cnt - 1));
                         r[u] = m.vox_rec[vc & kVidMask];
                         r[u].pad = (int32_t)(vc >> kVidBits);
                     }
                 }
                 // the face neighbours among them: their inverse covariances are requested together, before the first is used
-                bool use[ELM_AVG_RECS];
-                double Ci[ELM_AVG_RECS][9];
+                bool use[kAvgRecs];
+                double Ci[kAvgRecs][9];
 #pragma unroll
-                for (int u = 0; u < ELM_AVG_RECS; ++u) {
+                for (int u = 0; u < kAvgRecs; ++u) {
                     // the face neighbours (and the voxel itself): position codes 4, 10, 12, 13, 14, 16, 22 -- one shift of a 27-bit mask; the
                     // face sublists hold nothing else (uniform branch: no test at all)
                     constexpr unsigned kFaceMask = (1u << 4) | (1u << 10) | (1u << 12) | (1u << 13) | (1u << 14) | (1u << 16) | (1u << 22);
@@ -2711,7 +2480,7 @@ __global__ __launch_bounds__(kBlock, ELM_VNBR_WAVES) void k_accumulate_vnbr(cons
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < ELM_AVG_RECS; ++u) {
+                for (int u = 0; u < kAvgRecs; ++u) {
                     if (!use[u]) continue;
                     n_pairs += 1.0;
                     const double ex = r[u].mx - gx, ey = r[u].my - gy, ez = r[u].mz - gz;
@@ -2860,10 +2629,9 @@ __device__ void init_scan_state(ScanState& S, const double* __restrict__ T0, int
 }
 
 __global__ __launch_bounds__(64) void k_init_state(ScanState* st, const double* __restrict__ T0, int batch, int map_empty,
-                                                   int* active, int* tickets) {
+                                                   int* active) {
     const int s = blockIdx.x * 64 + threadIdx.x;
     if (s >= batch) return;
-    if (tickets) tickets[s] = 0;
     if (!map_empty) atomicAdd(active, 1); // scans still iterating (the host zeroed the counter)
     init_scan_state(st[s], T0 + (size_t)s * 16, s, map_empty);
 }
@@ -2872,11 +2640,10 @@ __global__ __launch_bounds__(64) void k_init_state(ScanState* st, const double* 
 // memset of the counter.  n_dev != nullptr: the scan's size is only known on the device (the deskew + downsample kernels have just
 // produced it): the descriptor takes n from there, so the host never waits for it.
 __global__ __launch_bounds__(64) void k_init_pack(ScanDesc* scans, ScanState* st, const InitPack pack, int batch, int map_empty, int* active,
-                                                  const unsigned* __restrict__ n_dev, int* tickets) {
+                                                  const unsigned* __restrict__ n_dev) {
     const int s = threadIdx.x;
     if (s == 0) { active[0] = map_empty ? 0 : batch; active[1] = 0; } // [1]: the rank-agreement fault word (RegParams::rank_check)
     if (s >= batch) return;
-    if (tickets) tickets[s] = 0;
     ScanDesc d = pack.d[s];
     if (n_dev) {
         d.n = *n_dev;
@@ -2886,9 +2653,8 @@ __global__ __launch_bounds__(64) void k_init_pack(ScanDesc* scans, ScanState* st
     scans[s] = d;
     init_scan_state(st[s], pack.T0[s], s, map_empty);
 }
-void launch_init_pack(hipStream_t s, ScanDesc* scans, ScanState* st, const InitPack& pack, int batch, int map_empty, int* active, const unsigned* n_dev,
-                      int* tickets) {
-    hipLaunchKernelGGL(k_init_pack, dim3(1), dim3(64), 0, s, scans, st, pack, batch, map_empty, active, n_dev, tickets);
+void launch_init_pack(hipStream_t s, ScanDesc* scans, ScanState* st, const InitPack& pack, int batch, int map_empty, int* active, const unsigned* n_dev) {
+    hipLaunchKernelGGL(k_init_pack, dim3(1), dim3(64), 0, s, scans, st, pack, batch, map_empty, active, n_dev);
 }
 
 // Continuous batching: after the solve of an iteration, every slot whose registration has finished saves its final state
@@ -3238,7 +3004,6 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : 1) void k_solve(const ScanDesc*
     __shared__ double part[kSolveThreads / 32][kSums];
     static_assert(NT == kSolveThreads || NT == 256, "solve workgroup size");
     const bool done = S.done != 0;
-    const bool fused = rp.tickets != nullptr; // the accumulate kernels' last workgroups have left the scan's sums in `sums`
     const bool radar = rp.radar != 0;         // k_accumulate_radar's records: 64 doubles, all 36 entries of J^T M J (single GPU, unfused)
     __shared__ double full[36];               // radar / asymmetric side sums: J^T M J row-major, all 36 entries
     // a map with an asymmetric flagged covariance: the accumulate kernels also wrote 16-double side records (asym_side_store)
@@ -3272,7 +3037,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : 1) void k_solve(const ScanDesc*
             if (t < 36) full[t] = a;
             else if (t < kRadarAcc) tot[21 + (t - 36)] = a; // J^T M r, residual sum, pair count, statistics: the slots of the 32-sum layout
         }
-    } else if (mode != 2 && !fused) {
+    } else if (mode != 2) {
         // deterministic reduction of this scan's per-workgroup partial sums: 32 strided groups of 32 lanes read whole
         // 256-byte records (four independent loads in flight per lane), then the group sums are added in a fixed order
         const int k = t & 31;
@@ -3354,7 +3119,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : 1) void k_solve(const ScanDesc*
     } else {
         // (a scan without a single workgroup -- no points on this rank -- has no record and no sums: zeros)
         if (t < 32) tot[t] = (scans[s].blk_end > scans[s].blk_begin) ? sums[(size_t)s * kSums + t] : 0.0;
-        else if (asym && t < 32 + kAsymSums) // (the fused reduction does not produce side sums: the host never combines the two)
+        else if (asym && t < 32 + kAsymSums)
             dsum[t - 32] = (rp.asym_sums && scans[s].blk_end > scans[s].blk_begin) ? rp.asym_sums[(size_t)s * kAsymSums + (t - 32)] : 0.0;
     }
     __syncthreads();
@@ -3711,8 +3476,8 @@ void launch_stream_refill(hipStream_t s, ScanDesc* scans, ScanState* st, int slo
                           ScanState* out_state, StreamCtrl* ctrl, int first, int save) {
     hipLaunchKernelGGL(k_stream_refill, dim3(1), dim3(1024), 0, s, scans, st, slots, queue, qT0, out_state, ctrl, first, save);
 }
-void launch_init_state(hipStream_t s, ScanState* st, const double* T0, int batch, int map_empty, int* active, int* tickets) {
-    hipLaunchKernelGGL(k_init_state, dim3((batch + 63) / 64), dim3(64), 0, s, st, T0, batch, map_empty, active, tickets);
+void launch_init_state(hipStream_t s, ScanState* st, const double* T0, int batch, int map_empty, int* active) {
+    hipLaunchKernelGGL(k_init_state, dim3((batch + 63) / 64), dim3(64), 0, s, st, T0, batch, map_empty, active);
 }
 
 void launch_accumulate_radar(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks, ScanState* st, double* partials,
@@ -3964,8 +3729,8 @@ void launch_accumulate_vnbr(hipStream_t s, const DevMap& m, const ScanDesc* scan
 #define ELM_LAUNCH_V(M, C)                                                         \
     do {                                                                           \
         const bool faces_ = (M) == ELM_AVGICP && m.vq_dense && m.vqf_dense;        \
-        /* the fused walk; on a map with flagged voxels it needs the workgroup flags and partial records it can add to (no fused reduction) */ \
-        if (faces_ && (C) && m.vface_plain && (!m.vface_flagged || (rp.flagged && !rp.tickets))) { \
+        /* the fused walk; on a map with flagged voxels it needs the workgroup flags and partial records it can add to */ \
+        if (faces_ && (C) && m.vface_plain && (!m.vface_flagged || rp.flagged)) { \
             if (!m.vface_flagged) {                                                \
                 if (rp.stats) ELM_LAUNCH_VF(M, C, 1, ((M) == ELM_AVGICP && (C) ? 2 : 0)); \
                 else ELM_LAUNCH_VF(M, C, 0, ((M) == ELM_AVGICP && (C) ? 2 : 0));   \
@@ -4051,9 +3816,9 @@ void launch_solve(hipStream_t s, const ScanDesc* scans, int batch, ScanState* st
                   double* sums, const RegParams& rp, elm_iter_trace* trace, int mode, int* active, const StreamArgs* refill) {
     StreamArgs sa = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
     if (refill) sa = *refill;
-    // one wavefront per scan when the sums are already reduced (fused reduction, or the second half of a multi-rank iteration)
+    // one wavefront per scan when the sums are already reduced (the second half of a multi-rank iteration)
     const bool small = rp.solve_small != 0 && rp.radar == 0;
-    const int threads = (mode == 2 || rp.tickets != nullptr) ? 64 : (small ? 256 : kSolveThreads);
+    const int threads = mode == 2 ? 64 : (small ? 256 : kSolveThreads);
     if (small) hipLaunchKernelGGL(k_solve<256>, dim3(batch), dim3(threads), 0, s, scans, st, partials, sums, rp, trace, mode, active, sa);
     else hipLaunchKernelGGL(k_solve<kSolveThreads>, dim3(batch), dim3(threads), 0, s, scans, st, partials, sums, rp, trace, mode, active, sa);
 }
@@ -4185,11 +3950,8 @@ void launch_voxel_downsample(hipStream_t s, const float* xyz, uint32_t n, double
 //   B  every point moves to start[key] + offset[wave][key] + rank.
 // Within a key the order is (wave, step, lane) = the caller's order: the sort is stable.  A (degenerate) scan with more than 65535
 // points in one cell or per wave keeps the caller's order.
-#ifndef ELM_ORDER_WAVES
-#define ELM_ORDER_WAVES 8 // 512 threads, 80 KB of LDS (64 KB of counters + run starts): co-resides with the accumulate workgroups of the compute stream;
+constexpr int kOrderWaves = 8; // 512 threads, 80 KB of LDS (64 KB of counters + run starts): co-resides with the accumulate workgroups of the compute stream;
                            // host-fed stream: 8 -> 32.4k, 16 (144 KB: waits for an empty CU) -> 31.0k registrations/s
-#endif
-constexpr int kOrderWaves = ELM_ORDER_WAVES;
 constexpr int kOrderThreads = kOrderWaves * 64;
 constexpr int kOrderBins = kOrderCells * kOrderCells; // 4096 keys: kOrderWaves x 8 KB of 16-bit counters + 16 KB of run starts
 __device__ __forceinline__ unsigned order_key(const Pt3 p, const unsigned short* lut) {
@@ -4442,17 +4204,16 @@ __global__ void k_publish_ready(StreamCtrl* ctrl, int ready) {
 }
 void launch_publish_ready(hipStream_t s, StreamCtrl* ctrl, int ready) { hipLaunchKernelGGL(k_publish_ready, dim3(1), dim3(1), 0, s, ctrl, ready); }
 // host-fed streams start with every slot idle: the solve hands out registrations as their scans arrive
-__global__ void k_slots_idle(ScanDesc* scans, ScanState* st, int slots, unsigned cap_blocks, int* tickets) {
+__global__ void k_slots_idle(ScanDesc* scans, ScanState* st, int slots, unsigned cap_blocks) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= slots) return;
-    if (tickets) tickets[s] = 0;
     scans[s].pts = nullptr; scans[s].n = 0; scans[s].n_total = 0;
     scans[s].blk_begin = cap_blocks * (unsigned)s; scans[s].blk_end = cap_blocks * (unsigned)(s + 1); // every slot owns cap_blocks workgroups
     st[s].done = 1;
     st[s].reg = -1;
 }
-void launch_slots_idle(hipStream_t s, ScanDesc* scans, ScanState* st, int slots, unsigned cap_blocks, int* tickets) {
-    hipLaunchKernelGGL(k_slots_idle, dim3((slots + 255) / 256), dim3(256), 0, s, scans, st, slots, cap_blocks, tickets);
+void launch_slots_idle(hipStream_t s, ScanDesc* scans, ScanState* st, int slots, unsigned cap_blocks) {
+    hipLaunchKernelGGL(k_slots_idle, dim3((slots + 255) / 256), dim3(256), 0, s, scans, st, slots, cap_blocks);
 }
 
 void launch_deskew(hipStream_t s, const float* xyz, const float* rel_time, uint32_t n, const DeskewDev& d, float* xyz_out) {

@@ -481,8 +481,9 @@ int elm_pcm_callback_point_cloud(elm_ctx* ctx, const elm_map* map, const elm_pcm
  *       scan over the communicators the ranks form among themselves -- RCCL over xGMI -- each rank driven by its own host thread) and
  *       every rank solves the same sums; the ranks' results are compared bit for bit (ELM_ERR_COMM if they differ);
  *   elm_ctx_destroy          destroys the group.
- * Not available on a group (ELM_ERR_UNSUPPORTED): elm_register_stream_host, elm_register_batch_enqueue / _finish,
- * elm_pcm_callback_point_cloud (the node callback registers ~10 k downsampled points: one device's work -- use a plain context).
+ * Not available on a group (ELM_ERR_UNSUPPORTED): elm_register_stream_host, elm_register_batch_enqueue / _finish.
+ * elm_pcm_callback_point_cloud on a group takes its stage-by-stage path (deskew + downsample on the lead device, the registration
+ * sharded): same results; the fused one-pass form is a plain context's (the callback registers ~10 k downsampled points).
  * A device id may repeat ({0, 0}: two ranks on one GPU).  RCCL refuses two ranks on one device; such a group exchanges through
  * page-locked host memory (sum in rank order) -- the form a one-GPU box can test.  ELM_GROUP_EXCHANGE=host | rccl forces either.
  * n = 1 returns a plain context. */

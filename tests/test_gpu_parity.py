@@ -704,57 +704,11 @@ def test_stream_many_registrations_refilled_in_the_solve(ctx, oracle, world100k)
             assert np.array_equal(a["T"], b["T"]) and a["n_corr_last"] == b["n_corr_last"], k
 
 
-def test_single_registration_graph_replay(oracle, world100k, monkeypatch):
-    """One registration at a time (RunRegister's own shape) is replayed from a captured hipGraph after the first call: descriptor and
-    guess travel through pinned memory, K = (longest registration seen) + 1 iterations inside the graph, a registration that needs more
-    continues with plain launches.  Bit-identical to the plain-launch path (ELM_GRAPH=0) call by call -- short ones, a long one behind
-    short ones (continuation), another scan size (new graph), another method -- and to the oracle."""
+def test_multi_rank_stream_refill(oracle, world100k):
+    """A multi-rank stream hands finished slots their next registration identically on every rank: a refill launch walks the slots in slot
+    order (the finished flags derive from the all-reduced sums).  Driven through an identity exchange hook (the multi-rank control flow
+    on one rank): bit-identical to the lockstep batch, gated registrations included."""
     from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, Scan
-    seq = []
-    # (seed id, points, initial error, method); on the GPU box ids 1, 2 take 6 iterations, 3, 4 take 9, 0 and 5 all 10: the short ones first
-    for i, n, tr, rot, meth in [(1, 6000, 0.03, 0.1, 0), (2, 6000, 0.03, 0.1, 0), (3, 6000, 0.5, 2.0, 0), (4, 6000, 0.04, 0.1, 0), (0, 6000, 0.03, 0.1, 0),
-                                (5, 3500, 0.1, 0.5, 0), (6, 6000, 0.1, 0.5, 2), (7, 6000, 0.03, 0.1, 0)]:
-        sc, Tt = synth.make_scan(world100k, n, seed=4100 + i)
-        seq.append((sc, synth.perturb(Tt, seed=4200 + i, max_trans=tr, max_rot_deg=rot), meth))
-    TERM = {0: 1e-4, 2: 0.02}  # a tight P2P termination threshold: iteration counts follow the initial error (a handful .. max_iteration)
-    runs = {}
-    for graph in ("1", "0"):  # (opt-in: plain launches are the default)
-        monkeypatch.setenv("ELM_GRAPH", graph)
-        c = Context(0)
-        try:
-            maps = {m: _maps(c, oracle, world100k, IcpMethod(m)) for m in (0, 2)}
-            out = []
-            for sc, T0, meth in seq:
-                reg = Registration(RegistrationConfig(icp_method=IcpMethod(meth), icp_termination_threshold_m=TERM[meth]), c)
-                det = reg.RunRegisterBatch([Scan(c, sc)], maps[meth][0], [T0])[0]  # a batch of one: the shape elm_register itself enqueues
-                out.append((det["T"], det["is_success"], det["iterations"], det["gate"], det["n_corr_last"]))
-                pose, ok, fit, cov = reg.RunRegister(sc, maps[meth][0], T0)  # the reference API on host points (caller's order: other sums)
-                assert ok == det["is_success"] and float(np.abs(pose - det["T"]).max()) < 1e-9
-            runs[graph] = out
-            if graph == "1":
-                its = [o[2] for o in out]
-                # a registration really outlasts the graph sized by the ones before it (K = longest of the last eight + 1)
-                assert any(its[k] > max(its[max(0, k - 8):k]) + 1 for k in range(1, 5)), its
-                for (sc, T0, meth), o in zip(seq, out):
-                    ref = oracle.register(maps[meth][1], sc, T0, oracle.default_config(meth, icp_termination_threshold_m=TERM[meth]))
-                    assert ref["iterations"] == o[2] and ref["is_success"] == o[1]
-                    dt, dr = synth.pose_error(ref["T"], o[0])
-                    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
-            del maps
-        finally:
-            c.close()
-    for a, b in zip(runs["1"], runs["0"]):
-        assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
-
-
-@pytest.mark.parametrize("refill", ["kernel", "solve"])
-def test_multi_rank_stream_refill_forms(oracle, world100k, monkeypatch, refill):
-    """The two ways a multi-rank stream hands finished slots their next registration identically on every rank: the static per-slot queue
-    inside the solve launch (slot s serves s, s + S, ...) and (ELM_DIST_REFILL=kernel) a refill launch that walks the slots in slot order.
-    Driven through an identity exchange hook (the multi-rank control flow on one rank): bit-identical to the lockstep batch, gated
-    registrations included, and the dynamic form needs no more iterations than the static one."""
-    from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, Scan
-    monkeypatch.setenv("ELM_DIST_REFILL", refill)
     c = Context(0)
     try:
         vm, om = _maps(c, oracle, world100k, IcpMethod.P2P)
@@ -779,42 +733,6 @@ def test_multi_rank_stream_refill_forms(oracle, world100k, monkeypatch, refill):
                 assert set(calls) == {slots * 32}
         finally:
             c.set_allreduce_hook(None)
-        del scans, vm
-    finally:
-        c.close()
-
-
-def test_half_set_streams(oracle, world100k, monkeypatch):
-    """ELM_HALF_SETS=1 (opt-in): the slots split into two halves (16 + 16, 9 + 8) whose solve side -- reduce, exchange, solve + refill --
-    is queued on a second stream behind the half's accumulate launch while the compute stream goes on with the other half.  Results
-    bit-identical to the lockstep batch, also through an identity exchange hook = the multi-rank control flow (reduce-only launch ->
-    exchange -> solve-only launch with the static per-slot queue), one exchange of slots x 32 doubles per half per iteration."""
-    from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, Scan
-    monkeypatch.setenv("ELM_HALF_SETS", "1")
-    c = Context(0)
-    try:
-        vm, om = _maps(c, oracle, world100k, IcpMethod.P2P)
-        reg = Registration(RegistrationConfig(icp_method=IcpMethod.P2P, min_overlap_ratio=0.5), c)
-        scans, T0s = [], []
-        for i in range(150):
-            sc, Tt = synth.make_scan(world100k, 300 + 37 * (i % 11), seed=2000 + i)
-            if i % 13 == 5:
-                sc = sc + np.float32(500.0)  # fails the overlap gate in its first iteration
-            scans.append(Scan(c, sc))
-            T0s.append(synth.perturb(Tt, seed=3000 + i, max_trans=0.02 + 0.01 * (i % 17), max_rot_deg=0.1 * (i % 9)))
-        batch = reg.RunRegisterBatch(scans, vm, T0s)
-        calls = []
-        for slots, hooked in ((7, False), (32, False), (17, False), (17, True), (32, True)):
-            if hooked:
-                c.set_allreduce_hook(lambda p, n, s: (calls.append(n), 0)[1])
-            try:
-                out = reg.RunRegisterStream(scans, vm, T0s, slots=slots)
-            finally:
-                c.set_allreduce_hook(None)
-            for k, (a, b) in enumerate(zip(out, batch)):
-                assert (a["iterations"], a["is_success"], a["gate"]) == (b["iterations"], b["is_success"], b["gate"]), (slots, hooked, k)
-                assert np.array_equal(a["T"], b["T"]) and a["n_corr_last"] == b["n_corr_last"], (slots, hooked, k)
-        assert set(calls) == {9 * 32, 8 * 32, 16 * 32}
         del scans, vm
     finally:
         c.close()
@@ -1316,7 +1234,6 @@ def test_avgicp_fused_walk_with_flagged_voxels_fix_up_launch(oracle, monkeypatch
         sc, Tt = synth.make_scan(world, 6000 + 1000 * k, seed=6100 + k)
         scans.append(sc)
         T0s.append(synth.perturb(Tt, seed=6200 + k, max_trans=0.2, max_rot_deg=0.8))
-    monkeypatch.setenv("ELM_STRICT_PAIRS", "0")  # this test is about the fast kernels, whatever the symmetry of the crafted covariances
     runs = {}
     for mode in ("fixup", "inline", "skip"):  # skip: the fused walk WITHOUT its fix-up launch (a test switch): the flagged pairs go missing
         if mode != "fixup":
@@ -1383,14 +1300,14 @@ def test_asymmetric_covariances_travel_in_side_records(oracle, method, monkeypat
     (reg.cpp:107-113, 136-142).  The fast kernels pack the 21 upper entries of the world-frame sums; on a map that holds such a record
     (layout bits 7 / 8) they also write the 15 entries of the antisymmetric part into side records, and the solve restores all 36
     entries (asym_side_store).  DEFAULT == the oracle to the 1e-9 bar on every iteration's sums, == the per-pair checker
-    (ELM_STRICT_PAIRS=1), on single registrations and through the stream; ELM_STRICT_PAIRS=0 (fast kernels without the side records,
-    the behaviour before round 5) shows the deviation the records remove."""
+    (ELM_STRICT_PAIRS=1), on single registrations and through the stream.  (What the sums lose without the side records -- the behaviour
+    before round 5 -- is shown in plain numpy by tests/test_asym_algebra.py.)"""
     from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, Scan
     m = IcpMethod(method)
     world, scans, T0s = _asym_case()
     runs, streams, covs = {}, {}, {}
     om = None
-    for mode in (None, "1", "0"):
+    for mode in (None, "1"):
         if mode is None:
             monkeypatch.delenv("ELM_STRICT_PAIRS", raising=False)
         else:
@@ -1408,7 +1325,6 @@ def test_asymmetric_covariances_travel_in_side_records(oracle, method, monkeypat
             streams[mode] = reg.RunRegisterStream([Scan(c, sc) for sc in scans], vm, T0s, slots=2)
         finally:
             c.close()
-    worst_fast = 0.0
     for k, (sc, T0) in enumerate(zip(scans, T0s)):
         ref = oracle.register(om, sc, T0, oracle.default_config(method))
         J0 = ref["iters"][0]["JTJ"]
@@ -1417,14 +1333,11 @@ def test_asymmetric_covariances_travel_in_side_records(oracle, method, monkeypat
         _compare_run(runs["1"][k], ref)    # the per-pair checker
         if method == 1:  # GICP's covariance output: the inverse of the FULL damped matrix
             np.testing.assert_allclose(covs[None][k], ref["local_cov"], rtol=1e-6, atol=1e-9 * np.abs(ref["local_cov"]).max())
-        for g, r in zip(runs["0"][k]["iters"], ref["iters"]):
-            worst_fast = max(worst_fast, float(np.abs(g["JTJ"] - r["JTJ"]).max() / np.abs(r["JTJ"]).max()))
         st = streams[None][k]  # continuous batching (device-ordered scan: another summation tree)
         assert st["iterations"] == ref["iterations"] and st["is_success"] == ref["is_success"]
         np.testing.assert_allclose(st["T"], runs[None][k]["T"], rtol=0, atol=1e-9)
         if method == 1:
             np.testing.assert_allclose(st["local_cov"], ref["local_cov"], rtol=1e-6, atol=1e-9 * np.abs(ref["local_cov"]).max())
-    assert worst_fast > 10 * SUM_RTOL  # without the side records the sums are off by the antisymmetric part
 
 
 @pytest.mark.parametrize("method,stream", [(1, True), (2, False), (3, True)])
@@ -1454,7 +1367,7 @@ def test_asymmetric_covariances_two_ranks(oracle, method, stream, monkeypatch):
 
 def test_fuzz_case_with_asymmetric_covariances():
     """Fuzz case 813687 (GICP, 0.4 m voxels, one point per voxel, exact lattice: the case that exposed the symmetric packing): the default
-    agrees with the oracle, ELM_STRICT_PAIRS=0 reproduces the old deviation (pose still inside the north_star tolerance), =1 agrees."""
+    agrees with the oracle, and so does the per-pair checker (ELM_STRICT_PAIRS=1)."""
     import os
     import subprocess
     import sys
@@ -1464,12 +1377,6 @@ def test_fuzz_case_with_asymmetric_covariances():
     env.pop("ELM_STRICT_PAIRS", None)
     auto = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert auto.returncode == 0 and "1/1 cases agree" in auto.stdout, auto.stdout[-2000:] + auto.stderr[-2000:]
-    env["ELM_STRICT_PAIRS"] = "0"
-    fast = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert "MISMATCH case 813687" in fast.stdout and "pose error" in fast.stdout, fast.stdout[-2000:] + fast.stderr[-2000:]  # the known deviation
-    pe = [ln for ln in fast.stdout.splitlines() if "pose error" in ln][-1]
-    dt, dr = [float(v) for v in pe.split("(")[1].split(")")[0].split(",")]
-    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD  # ... stays inside the north_star tolerance
     env["ELM_STRICT_PAIRS"] = "1"
     strict = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert strict.returncode == 0 and "1/1 cases agree" in strict.stdout, strict.stdout[-2000:] + strict.stderr[-2000:]
@@ -1513,45 +1420,6 @@ def test_exactly_singular_normal_equations_zero_pivot(ctx, oracle, world100k):
         assert g["x"][3] == 0.0 and r["x"][3] == 0.0
         np.testing.assert_allclose(g["x"], r["x"], rtol=0, atol=1e-9 * max(1.0, np.abs(r["x"]).max()))
         np.testing.assert_allclose(g["T"], r["T"], rtol=0, atol=1e-9)
-
-
-@pytest.mark.parametrize("method", [0, 2])
-def test_fused_reduction_path(oracle, world100k, method, monkeypatch):
-    """ELM_FUSED_REDUCE=1: the last workgroup of every scan (ticket counter, 8-byte agent-scope stores / loads) adds up the scan's
-    partial records inside the accumulate launch and the solve reads the sums -- accumulate -> [exchange] -> solve.  Same
-    trajectory as the default path to the sum tolerance, bit-identical between a stream and one-at-a-time calls, oracle parity."""
-    from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, Scan
-    m = IcpMethod(method)
-    monkeypatch.setenv("ELM_FUSED_REDUCE", "1")
-    c = Context(0)
-    try:
-        vm, om = _maps(c, oracle, world100k, m)
-        reg = Registration(RegistrationConfig(icp_method=m), c)
-        scans, T0s, singles, hosts = [], [], [], []
-        for i, n in enumerate([6000, 1000, 0, 257, 5000, 70000, 256, 4097, 1]):
-            sc, Tt = synth.make_scan(world100k, max(n, 1), seed=500 + i)
-            sc = sc[:n]
-            hosts.append(sc)
-            T0s.append(synth.perturb(Tt, seed=600 + i, max_trans=0.05 + 0.04 * i, max_rot_deg=0.2 * (i + 1)))
-            scans.append(Scan(c, sc))
-            singles.append(reg.RunRegisterBatch([scans[-1]], vm, [T0s[-1]], trace=True)[0])
-        for slots in (3, 64):
-            out = reg.RunRegisterStream(scans, vm, T0s, slots=slots, trace=True)
-            for k, (b, s_) in enumerate(zip(out, singles)):
-                assert (b["iterations"], b["is_success"], b["gate"]) == (s_["iterations"], s_["is_success"], s_["gate"]), k
-                assert np.array_equal(b["T"], s_["T"]) and np.array_equal(b["local_cov"], s_["local_cov"]), k
-        calls = []
-        c.set_allreduce_hook(lambda p, n, s: (calls.append(n), 0)[1])  # the multi-rank control flow: no reduce launch before the exchange
-        try:
-            hooked = reg.RunRegisterStream(scans, vm, T0s, slots=3)
-        finally:
-            c.set_allreduce_hook(None)
-        assert calls and all(np.array_equal(a["T"], b["T"]) for a, b in zip(hooked, singles))
-        for k in (0, 5):
-            ref = oracle.register(om, hosts[k], T0s[k], oracle.default_config(method))
-            _compare_run(singles[k], ref)
-    finally:
-        c.close()
 
 
 RADAR = dict(use_radar_cov=1, range_variance_m=0.7, azimuth_variance_deg=1.5, elevation_variance_deg=0.9)
