@@ -292,7 +292,7 @@ def index_touch_bound(index_bytes, units_per_launch, requested_index_bytes_per_u
 def hbm_object(method, index_bytes, units_per_launch, sec, bytes_unit, bytes_ref, live_scans, map_points, traffic=None, traffic_src=None):
     """The HBM stream of one accumulate launch: measured (a committed counter pass) or compulsory (scan point + partial record + GICP
     payload + the touched part of the index once), plus the requested bytes and the SURVEY 8(d) figure of the reference's walk."""
-    payload = 64.0 if int(method) == 1 else 0.0  # the GICP match's compact record: one 64-byte sector per pair (128 with ELM_COV_RECORDS=full)
+    payload = 64.0 if int(method) == 1 else 0.0  # the GICP match's compact record: one 64-byte sector per pair (128 with ELM_CHECK=full_records)
     stream_unit = 12.0 + 1.0 + payload           # scan point (packed xyz) + its share of the 256-byte partial record + payload
     requested_index_unit = max(bytes_unit - 17.0 - (132.0 if int(method) == 1 else 0.0), 0.0)
     index_once = index_touch_bound(index_bytes, units_per_launch, requested_index_unit, live_scans, map_points)

@@ -65,7 +65,7 @@ class RegResult(C.Structure):
         ("is_success", C.c_int32),
         ("iterations", C.c_int32),
         ("gate", C.c_int32),
-        ("_pad", C.c_int32),
+        ("path", C.c_int32),
         ("n_corr_last", C.c_double),
         ("point_iterations", C.c_double),
         ("n_cand_total", C.c_double),

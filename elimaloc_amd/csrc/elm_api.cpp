@@ -101,7 +101,7 @@ struct elm_ctx {
     uint16_t* d_hilbert = nullptr; // Hilbert index of every cell of the ordering grid (kOrderCells^2 entries)
     DevBuf d_order_jobs, d_order_tmp, d_arena, d_raw, d_flagged, d_asym;
     DevBuf d_q0, d_q1, d_q2, d_q3, d_q4, d_q5; // scratch of elm_map_get_correspondences / elm_align_clouds_local (kept between calls)
-    bool work_counters = false; // elm_ctx_set_work_counters / ELM_WORK_COUNTERS=1: the accumulate launches also sum the work counters of
+    bool work_counters = false; // elm_ctx_set_work_counters: the accumulate launches also sum the work counters of
                                 // elm_reg_result (n_cand_total, n_occ_total, n_tested_total, fallback_blocks); off: those fields read 0
     void* h_jobs = nullptr; // pinned: ordering job descriptors
     size_t h_jobs_cap = 0;
@@ -151,6 +151,7 @@ struct elm_ctx {
     int rank = 0, nranks = 1;
     elm_allreduce_fn hook = nullptr;
     void* hook_user = nullptr;
+    int path = 0; // ELM_PATH_* of the registration call in progress (elm_reg_result.path)
     elm_group* group = nullptr; // elm_ctx_create_multi: this context LEADS a group of per-device contexts inside this process (elm_multi.cpp);
                                 // maps built and scans uploaded through it are replicated / sharded over the group, registrations run on all
 };
@@ -194,12 +195,33 @@ static int dev_reserve(elm_ctx* ctx, DevBuf& b, size_t bytes) {
 // Host memory a large temporary may take: MemAvailable of /proc/meminfo (free + reclaimable page cache -- after a big PCD has been read
 // most of the RAM is page cache, and MemFree alone would refuse the grid depending on the cache state); unknown: no limit (the
 // allocations themselves fail with bad_alloc, which the builders handle).
+// The library's run-time switches are FIVE environment variables (include/elimaloc_hip.h lists them): ELM_KERNEL, ELM_GRID, ELM_CHECK,
+// ELM_SCAN_ORDER, ELM_GROUP_EXCHANGE.  ELM_GRID and ELM_CHECK hold comma-separated tokens, `name` or `name=value`.
+static bool env_token(const char* var, const char* name, const char** value = nullptr) {
+    const char* e = getenv(var);
+    if (!e) return false;
+    const size_t ln = strlen(name);
+    for (const char* p = e; *p;) {
+        const char* q = strchr(p, ',');
+        const size_t len = q ? (size_t)(q - p) : strlen(p);
+        if (len >= ln && strncmp(p, name, ln) == 0 && (len == ln || p[ln] == '=')) {
+            if (value) *value = (len > ln) ? p + ln + 1 : "";
+            return true;
+        }
+        if (!q) break;
+        p = q + 1;
+    }
+    return false;
+}
+static bool check_mode(const char* name) { return env_token("ELM_CHECK", name); } // the in-product checkers of the fast forms (tests)
+
 // The block array of the cell grid: 4 slots per block must number below 2^31 (the kernels carry slot numbers as ints); below
-// grid_narrow_limit() bytes stage 1 uses 32-bit byte offsets, beyond it 16-byte units (ELM_GRID_MAX_BLOCK_BYTES lowers the limit: tests
+// grid_narrow_limit() bytes stage 1 uses 32-bit byte offsets, beyond it 16-byte units (ELM_GRID=max_block_bytes=N lowers the limit: tests
 // force the wide form onto small maps).
 constexpr uint64_t kGridMaxBlocks = 0x1FFFFFF0ull;
 static uint64_t grid_narrow_limit() {
-    if (const char* e = getenv("ELM_GRID_MAX_BLOCK_BYTES")) return std::min<uint64_t>(strtoull(e, nullptr, 10), 0xFFFFFF00ull);
+    const char* v = nullptr;
+    if (env_token("ELM_GRID", "max_block_bytes", &v)) return std::min<uint64_t>(strtoull(v, nullptr, 10), 0xFFFFFF00ull);
     return 0xFFFFFF00ull;
 }
 static uint64_t host_available_bytes() {
@@ -278,7 +300,6 @@ extern "C" int elm_ctx_create(int device_id, elm_ctx** out) {
     }
     if (const char* k = getenv("ELM_KERNEL")) ctx->kernel_mode = (strcmp(k, "direct") == 0) ? 2 : (strcmp(k, "lists") == 0) ? 3 : 4;
     if (const char* o = getenv("ELM_SCAN_ORDER")) ctx->scan_order = (strcmp(o, "none") == 0) ? 0 : 1;
-    if (const char* f = getenv("ELM_WORK_COUNTERS")) ctx->work_counters = strcmp(f, "0") != 0;
     {
         std::lock_guard<std::mutex> lk(g_live_mu);
         ctx->id = g_next_ctx_id++;
@@ -393,7 +414,6 @@ struct elm_map {
     GridBlk* d_grid_blk = nullptr;    // dense cell grid (DevMap::grid_*), the default P2P / GICP search index
     uint32_t* d_grid_idx = nullptr;
     uint32_t* d_grid_start = nullptr;
-    uint4* d_grid_patch = nullptr; // dense grid only, optional (DevMap::grid_patch)
     uint2* d_grid_tiles = nullptr; // two-level grid only
     uint32_t* d_vox_stat = nullptr;
     double* d_grid_gicp = nullptr; // the GICP records in grid slot order (built with the grid / refreshed by CalPointCovAll)
@@ -403,6 +423,7 @@ struct elm_map {
     unsigned n_bad_pts = 0, n_bad_vox = 0; // covariances outside the compact form (diagnostics)
     unsigned n_asym_pts = 0, n_asym_vox = 0; // ... of which the stored inverse is not symmetric: such a map carries side records (choose_path)
     bool grid_refused = false; // the bounding box needs more cells than the budget: neighbourhood lists instead
+    bool warned_slow_path = false; // choose_path has said that this map's covariance methods run the per-pair kernels
     bool has_vnbr = false; // voxel-mean lists (VGICP / AVGICP)
     bool has_vface = false, vface_refused = false; // AVGICP's face sublists (built at the first AVGICP call; refused: no dense table / too many records)
     bool has_cells = false; // lists sorted by half-voxel cell + offset tables (every list <= 1024 entries)
@@ -560,7 +581,7 @@ static void map_free(elm_map* m) {
     for (elm_map* r : m->replicas) map_free(r);
     m->replicas.clear();
     if (ctx_alive(m->ctx, m->ctx_id)) (void)hipSetDevice(m->ctx->device); // a context destroyed first: just release the device memory
-    void* ptrs[] = {m->d_grid_patch, m->d_grid_tiles, m->d_vox_nk, m->d_bad, m->d_grid_gicp8, m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_vox_cinv, m->d_pt_gicp, m->d_pt_cov, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off, m->d_vqslots, m->d_vq_dense, m->d_vqf_dense, m->d_vface, m->d_vox_rec, m->d_vnbr_blk,
+    void* ptrs[] = {m->d_grid_tiles, m->d_vox_nk, m->d_bad, m->d_grid_gicp8, m->d_slots, m->d_pts, m->d_ranges, m->d_keys, m->d_vox_mean, m->d_vox_cov, m->d_vox_cinv, m->d_pt_gicp, m->d_pt_cov, m->d_qslots, m->d_nbr_pts, m->d_nbr_idx, m->d_nbr_cell_off, m->d_vqslots, m->d_vq_dense, m->d_vqf_dense, m->d_vface, m->d_vox_rec, m->d_vnbr_blk,
                     m->d_grid_blk, m->d_grid_idx, m->d_grid_start, m->d_vox_stat, m->d_grid_gicp};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -647,8 +668,7 @@ extern "C" int elm_map_build(elm_ctx* ctx, const float* xyz, size_t n, double vo
 extern "C" void elm_map_destroy(elm_map* m) { map_free(m); }
 
 static bool full_records_forced() {
-    const char* e = getenv("ELM_COV_RECORDS");
-    return e && strcmp(e, "full") == 0;
+    return check_mode("full_records");
 }
 extern "C" int elm_map_cal_voxel_cov_all(elm_map* m) {
     if (!m) return ELM_ERR_INVALID;
@@ -679,11 +699,11 @@ extern "C" int elm_map_cal_voxel_cov_all(elm_map* m) {
     m->dm.vox_nk = m->d_vox_nk;
     // an inverse covariance of the form I + k n n^T (to 1e-10) is rebuilt by the pairs from the 64-byte list record; the `bad` voxels
     // outside that form (rank-deficient neighbourhood, U != V in its SVD) carry k = NaN and their pairs read the stored 3x3 inverse.
-    // ELM_COV_RECORDS=full: every pair reads the stored inverses.
+    // ELM_CHECK=full_records: every pair reads the stored inverses.
     m->n_bad_vox = bad;
     m->n_asym_vox = bad2[1];
     m->info.layout_flags = (m->info.layout_flags & ~256) | (bad2[1] ? 256 : 0);
-    m->dm.vox_compact = full_records_forced() ? 0 : ((bad == 0 && !std::getenv("ELM_PAIR_NINE")) ? 2 : 1); // 2: no flagged voxel at all
+    m->dm.vox_compact = full_records_forced() ? 0 : ((bad == 0 && !check_mode("pair_nine")) ? 2 : 1); // 2: no flagged voxel at all
     m->info.has_voxel_cov = 1;
     m->info.layout_flags = (m->info.layout_flags & ~(2 | 16)) | (m->dm.vox_compact ? 2 : 0) | (m->dm.vox_compact == 2 ? 16 : 0);
     return ELM_OK;
@@ -862,15 +882,15 @@ static int build_voxel_neighbourhoods(elm_map* m, bool want_faces) {
         VN_CHK(hipMalloc((void**)&d_fcnt, nq_alloc * sizeof(uint32_t)));
         VN_CHK(hipMalloc((void**)&d_foff, nq_alloc * sizeof(uint32_t)));
         (void)hipGetLastError();
-        // the fused AVGICP walk's record format; flagged voxels (NaN normals) are left to its fix-up launch (ELM_AVG_FIXUP=0: such maps
+        // the fused AVGICP walk's record format; flagged voxels (NaN normals) are left to its fix-up launch (ELM_CHECK=avg_inline: such maps
         // keep the nine-entry walk with its in-line fallback)
         // The fix-up launch pays while few workgroups meet a flagged record (round 4: +14 % with 0.3 % of the voxels flagged); when
         // flagged voxels are common -- sparse clutter: two or three points per voxel, rank-deficient -- nearly every workgroup is marked,
         // the second launch repeats the whole walk, and the in-line fallback is the cheaper form: by default the map decides at 1 % of
-        // its voxels (ELM_AVG_FIXUP=1 / 0 force either form).
-        const char* fx = std::getenv("ELM_AVG_FIXUP");
-        const bool fixup_ok = fx ? strcmp(fx, "0") != 0 : (uint64_t)m->n_bad_vox * 100ull <= (uint64_t)m->dm.n_vox;
-        const int plain = (m->dm.vox_compact && (m->n_bad_vox == 0 || fixup_ok) && !std::getenv("ELM_AVG_NINE") && !std::getenv("ELM_PAIR_NINE")) ? 1 : 0;
+        // its voxels (ELM_CHECK=avg_fixup / avg_inline force either form).
+        const bool fx_inline = check_mode("avg_inline"), fx_fixup = check_mode("avg_fixup"), fx_skip = check_mode("avg_skip");
+        const bool fixup_ok = fx_inline ? false : ((fx_fixup || fx_skip) ? true : (uint64_t)m->n_bad_vox * 100ull <= (uint64_t)m->dm.n_vox);
+        const int plain = (m->dm.vox_compact && (m->n_bad_vox == 0 || fixup_ok) && !check_mode("avg_nine") && !check_mode("pair_nine")) ? 1 : 0;
         launch_vface(ctx->stream, m->dm, d_off, d_nocc, n_q, d_fcnt, nullptr, nullptr, plain);
         VN_CHK(hipGetLastError());
         VN_CHK(hipStreamSynchronize(ctx->stream));
@@ -891,7 +911,7 @@ static int build_voxel_neighbourhoods(elm_map* m, bool want_faces) {
             m->dm.vface = m->d_vface;
             m->dm.vqf_dense = m->d_vqf_dense;
             m->dm.vface_plain = plain;
-            m->dm.vface_flagged = (plain && m->n_bad_vox != 0) ? ((fx && strcmp(fx, "skip") == 0) ? 2 : 1) : 0; // (2: tests only -- no fix-up launch, the flagged pairs are dropped)
+            m->dm.vface_flagged = (plain && m->n_bad_vox != 0) ? (fx_skip ? 2 : 1) : 0; // (2: tests only -- no fix-up launch, the flagged pairs are dropped)
             m->info.layout_flags = (m->info.layout_flags & ~(32 | 64)) | (plain ? 32 : 0) | (m->dm.vface_flagged ? 64 : 0);
             m->info.device_bytes += vcells * sizeof(uint32_t) + (size_t)ftotal * sizeof(VoxRec);
             m->info.index_bytes += vcells * sizeof(uint32_t) + (size_t)ftotal * sizeof(VoxRec);
@@ -924,10 +944,10 @@ static int refresh_grid_gicp(elm_map* m) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     m->dm.grid_gicp = m->d_grid_gicp;
     m->dm.grid_gicp8 = m->d_grid_gicp8;
-    // 2: no point outside the compact form -- the kernel has no full-record fallback and gathers the pair fused (ELM_PAIR_NINE=1: the
+    // 2: no point outside the compact form -- the kernel has no full-record fallback and gathers the pair fused (ELM_CHECK=pair_nine: the
     // nine-entry form with its fallback, as for maps with flagged points; fusing the compact lanes of THOSE kernels too and reading a
     // flagged point's stored inverse row by row measured 15 % slower in round 5: profiles/r05_kernel_ab.txt)
-    m->dm.gicp_compact = compact ? ((m->n_bad_pts == 0 && !std::getenv("ELM_PAIR_NINE")) ? 2 : 1) : 0;
+    m->dm.gicp_compact = compact ? ((m->n_bad_pts == 0 && !check_mode("pair_nine")) ? 2 : 1) : 0;
     m->info.layout_flags = (m->info.layout_flags & ~(1 | 8)) | (compact ? 1 : 0) | (m->dm.gicp_compact == 2 ? 8 : 0);
     return ELM_OK;
 }
@@ -937,46 +957,6 @@ static int refresh_grid_gicp(elm_map* m) {
 // ELM_ERR_UNSUPPORTED (and grid_refused) when the grid is not affordable -- the box needs more than max_cells cells, its tables
 // do not fit the host / device memory that is free right now, or an allocation fails half-way -- the caller then builds the
 // neighbourhood lists instead; nothing is left allocated and the map is unchanged.
-// The patch table of the dense grid (DevMap::grid_patch): 16 bytes per cell, the runs of the four columns of a 2 x 2 x 2 block of cells in
-// one gather.  Optional -- any failure (budget, a cell of more than 15 blocks, 2^24 blocks or more, allocation) leaves the map on
-// grid_start alone.  ELM_GRID_PATCH=0 / 1 overrides the built-in default (on: still subject to the packing limits and the budget), ELM_GRID_PATCH_MAX_BYTES sets
-// the byte budget (default 2 GB: the 10 M-point bench map needs 0.37 GB).
-static bool grid_patch_wanted(uint64_t bytes) {
-    bool on = ELM_GRID_PATCH_DEFAULT != 0;
-    if (const char* e = getenv("ELM_GRID_PATCH")) on = atoi(e) != 0;
-    uint64_t budget = 2ull << 30;
-    if (const char* e = getenv("ELM_GRID_PATCH_MAX_BYTES")) budget = strtoull(e, nullptr, 10);
-    return on && bytes <= budget;
-}
-static void build_grid_patch(elm_map* m, uint64_t cells, uint64_t n_blk) {
-    elm_ctx* ctx = m->ctx;
-    const uint64_t bytes = cells * sizeof(uint4);
-    if (!grid_patch_wanted(bytes) || n_blk >= (1ull << 24)) return;
-    size_t dev_free = 0, dev_total = 0;
-    if (hipMemGetInfo(&dev_free, &dev_total) != hipSuccess || bytes + 64 > (uint64_t)dev_free / 10 * 8) { (void)hipGetLastError(); return; }
-    uint4* d_patch = nullptr;
-    unsigned* d_over = nullptr;
-    unsigned over = 1;
-    bool ok = hipMalloc((void**)&d_patch, bytes) == hipSuccess && hipMalloc((void**)&d_over, sizeof(unsigned)) == hipSuccess &&
-              hipMemsetAsync(d_over, 0, sizeof(unsigned), ctx->stream) == hipSuccess;
-    if (ok) {
-        launch_grid_patch(ctx->stream, m->dm, d_patch, d_over);
-        ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&over, d_over, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
-             hipStreamSynchronize(ctx->stream) == hipSuccess;
-    }
-    if (d_over) (void)hipFree(d_over);
-    if (!ok || over) { // a cell of more than 15 blocks (or a device error): the grid works without the table
-        if (d_patch) (void)hipFree(d_patch);
-        (void)hipGetLastError();
-        if (getenv("ELM_DEBUG")) fprintf(stderr, "[elm] grid patch table: not built (ok %d, overflow %u)\n", (int)ok, over);
-        return;
-    }
-    m->d_grid_patch = d_patch;
-    m->dm.grid_patch = d_patch;
-    m->info.layout_flags |= 512;
-    m->info.device_bytes += bytes;
-    m->info.index_bytes += bytes;
-}
 static int build_cell_grid_impl(elm_map* m, uint64_t max_cells);
 static int build_cell_grid(elm_map* m, uint64_t max_cells) {
     if (m->has_grid) return ELM_OK;
@@ -1149,7 +1129,6 @@ static int build_cell_grid_impl(elm_map* m, uint64_t max_cells) {
     m->info.n_query_voxels = vcells;
     m->info.nbr_entries = n;
     m->info.index_bytes += gb.size() * sizeof(GridBlk) + (cells + 4) * sizeof(uint32_t) + vcells * sizeof(uint32_t);
-    build_grid_patch(m, cells, n_blk);
     return ELM_OK;
 }
 
@@ -1427,10 +1406,11 @@ static int build_neighbourhood_lists(elm_map* m) {
     return ELM_OK;
 }
 
-// The P2P / GICP search index of a map: the dense cell grid when its bounding box fits the cell budget (ELM_GRID_MAX_CELLS,
+// The P2P / GICP search index of a map: the dense cell grid when its bounding box fits the cell budget (ELM_GRID=max_cells=N,
 // default 1.5e9 = 6 GB of offsets), the per-query-voxel neighbourhood lists otherwise (or with ELM_KERNEL=lists).
 static uint64_t grid_max_cells() {
-    if (const char* e = getenv("ELM_GRID_MAX_CELLS")) return strtoull(e, nullptr, 10);
+    const char* v = nullptr;
+    if (env_token("ELM_GRID", "max_cells", &v)) return strtoull(v, nullptr, 10);
     return 1500000000ull;
 }
 // The P2P / GICP search index of a map: the dense cell grid when its bounding box fits the cell and byte budgets, the two-level
@@ -1440,13 +1420,10 @@ static int build_search_index(elm_map* m, bool* use_grid) {
     *use_grid = false;
     elm_ctx* ctx = m->ctx;
     if (ctx->kernel_mode == 4 && !m->grid_refused && m->dm.n_pts) {
-        const char* g = getenv("ELM_GRID");
-        const bool force_tiled = g && strcmp(g, "tiled") == 0, no_tiled = g && strcmp(g, "dense") == 0;
+        const bool force_tiled = env_token("ELM_GRID", "tiled"), no_tiled = env_token("ELM_GRID", "dense");
         int rc = force_tiled ? ELM_ERR_UNSUPPORTED : build_cell_grid(m, grid_max_cells());
-        if (getenv("ELM_DEBUG")) fprintf(stderr, "[elm] dense grid: rc %d (%s)\n", rc, ctx->last_error.c_str());
         if (rc == ELM_ERR_UNSUPPORTED && !no_tiled) {
             rc = build_tiled_grid(m);
-            if (getenv("ELM_DEBUG")) fprintf(stderr, "[elm] tiled grid: rc %d (%s)\n", rc, ctx->last_error.c_str());
             if (rc == ELM_ERR_UNSUPPORTED) m->grid_refused = true; // neither form: do not retry at every registration
             else if (rc == ELM_OK) m->grid_refused = false;
         }
@@ -1809,7 +1786,7 @@ static int exchange(elm_ctx* ctx, double* d_sums, size_t count, hipStream_t stre
 }
 
 // use_radar_cov (reg.hpp:186-217) changes the arithmetic of the covariance methods only: AlignCloudsLocal (P2P) never reads a covariance.
-// ELM_STRICT_PAIRS=1: the covariance-weighted methods run the reference's own per-pair arithmetic -- (R^-1 C R^-T)^-1 by 3x3 products and an
+// ELM_CHECK=strict_pairs: the covariance-weighted methods run the reference's own per-pair arithmetic -- (R^-1 C R^-T)^-1 by 3x3 products and an
 // inverse per pair, all 36 entries of J^T M J, LDLT on the lower triangle: the radar kernels with a zero source term -- instead of the
 // world-frame / fused forms: the in-product checker of the fast forms (a plain walk, no streams: 12-27 times slower at 131 072-point
 // scans, profiles/r04k_strict_rate.txt).
@@ -1817,12 +1794,11 @@ static int exchange(elm_ctx* ctx, double* d_sums, size_t count, hipStream_t stre
 // not symmetric (layout_flags bits 7 / 8, counted by k_point_cov / k_voxel_cov) additionally carries the antisymmetric part of J^T M J in
 // side records (choose_path, asym_side_store) -- exact like the per-pair arithmetic.
 static int strict_pairs() { // 1: per-pair kernels always, -1: fast kernels, side records by map
-    const char* e = getenv("ELM_STRICT_PAIRS"); // (read per call: a registration call, not a launch)
-    return (e && strcmp(e, "1") == 0) ? 1 : -1;
+    return check_mode("strict_pairs") ? 1 : -1; // (read per call: a registration call, not a launch)
 }
 static int build_search_index(elm_map* m, bool* use_grid);
 static int build_voxel_neighbourhoods(elm_map* m, bool want_faces);
-// Which kernels one registration call runs.  `radar`: the per-pair kernels (use_radar_cov, or ELM_STRICT_PAIRS=1).  Otherwise the search
+// Which kernels one registration call runs.  `radar`: the per-pair kernels (use_radar_cov, or ELM_CHECK=strict_pairs).  Otherwise the search
 // index (built on first use) -- dense / two-level cell grid, neighbourhood lists, voxel-mean lists, or the plain walk -- and `asym`: the
 // map holds a flagged covariance of the method's kind whose stored inverse is not symmetric, and the fast kernels carry the antisymmetric
 // part of J^T M J in side records (RegParams::asym; grid and voxel-list kernels, unfused reduction).  Such a map on one of the fall-back
@@ -1864,14 +1840,29 @@ static int choose_path(elm_ctx* ctx, const elm_map* map, const elm_reg_config* c
     const bool asym_map = mode < 0 && method != ELM_P2P && (method == ELM_GICP ? map->n_asym_pts != 0 : map->n_asym_vox != 0);
     if (asym_map) {
         if (pc->use_grid || pc->use_vnbr) pc->asym = true;
-        else { pc->radar = true; pc->use_grid = pc->use_cells = pc->use_vnbr = false; }
+        else {
+            // The one slow corner left: asymmetric covariances on a map whose search index is a fall-back form (neighbourhood lists / the
+            // plain walk: no cell grid could be built, or ELM_KERNEL forced one) -- those kernels carry no side records, so the covariance
+            // methods run the per-pair kernels (exact, 12-27 times slower).  Said ONCE per map, and visible in elm_reg_result.path.
+            pc->radar = true; pc->use_grid = pc->use_cells = pc->use_vnbr = false;
+            elm_map* mm = const_cast<elm_map*>(map);
+            if (!mm->warned_slow_path) {
+                mm->warned_slow_path = true;
+                fprintf(stderr, "[elimaloc] map %p: %u point / %u voxel covariances are asymmetric (rank-deficient neighbourhoods) and its search index is a "
+                                "fall-back form (%s): method %d runs the per-pair kernels, 12-27 times slower than the grid kernels (elm_reg_result.path = %d)\n",
+                        (const void*)map, map->n_asym_pts, map->n_asym_vox, ctx->kernel_mode == 2 ? "ELM_KERNEL=direct" : "neighbourhood lists", method, ELM_PATH_PAIRS);
+            }
+        }
     }
     return ELM_OK;
+}
+static int path_code(const PathChoice& pc) {
+    return pc.radar ? ELM_PATH_PAIRS : ((pc.use_grid ? ELM_PATH_GRID : pc.use_cells ? ELM_PATH_LISTS : pc.use_vnbr ? ELM_PATH_VOXEL_LISTS : ELM_PATH_WALK) | (pc.asym ? ELM_PATH_SIDE_RECORDS : 0));
 }
 // VoxelHashMap::GetCorrespondencePoints / GetCorrespondencesCov / GetCorrespondencesAllCov (vhm.cpp:31-206) as calls of their own: the pairs
 // themselves, in input order, as (source index, target index).  The search is the production one -- the QUERY instantiations of the grid /
 // voxel-list kernels (the code the fused accumulate kernels run, minus the sums) -- or, without such an index (ELM_KERNEL=direct / lists, a
-// refused grid) and with ELM_QUERY=direct, the plain walk.
+// refused grid) and with ELM_CHECK=query_direct, the plain walk.
 static int get_correspondences_impl(elm_ctx* ctx, const elm_map* map, int what, const double* xyz, size_t n, double max_dist,
                                     uint32_t* src_index, int32_t* tgt_index, size_t cap, size_t* n_pairs);
 // (the host staging of these two calls is sized by the caller's n: an allocation failure is a status, never an exception through the C ABI)
@@ -1897,8 +1888,7 @@ static int get_correspondences_impl(elm_ctx* ctx, const elm_map* map, int what, 
     cfg.icp_method = what == 0 ? ELM_P2P : what == 1 ? ELM_VGICP : ELM_AVGICP;
     cfg.use_radar_cov = 0;
     bool production = false;
-    const char* qe = getenv("ELM_QUERY");
-    const bool force_direct = qe && strcmp(qe, "direct") == 0;
+    const bool force_direct = check_mode("query_direct");
     if (map->dm.n_vox != 0) {
         int rc;
         if (what != 0 && (rc = check_covariances(ctx, map, cfg.icp_method)) != ELM_OK) return rc;
@@ -2130,6 +2120,7 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
     int rc;
     PathChoice pc;
     if ((rc = choose_path(ctx, map, cfg, &pc)) != ELM_OK) return rc;
+    ctx->path = (map && map->dm.n_vox) ? path_code(pc) : 0;
     const bool radar = pc.radar;
     // batch descriptors
     const size_t stage_bytes = (size_t)batch * (sizeof(ScanDesc) + 16 * sizeof(double));
@@ -2185,7 +2176,7 @@ static int batch_enqueue_impl(elm_ctx* ctx, const elm_map* map, elm_scan* const*
     rp.method = method;
     rp.max_iter = cfg->max_iteration;
     rp.uniform_blocks = uniform_blocks;
-    rp.radar = radar ? (cfg->use_radar_cov != 0 ? 1 : 2) : 0; // 2: the radar kernels without a source covariance (ELM_STRICT_PAIRS)
+    rp.radar = radar ? (cfg->use_radar_cov != 0 ? 1 : 2) : 0; // 2: the radar kernels without a source covariance (ELM_CHECK=strict_pairs)
     rp.stats = ctx->work_counters ? 1 : 0;
     rp.radar_var[0] = cfg->range_variance_m;
     rp.radar_var[1] = cfg->azimuth_variance_deg;
@@ -2257,8 +2248,9 @@ extern "C" int elm_register_batch_enqueue(elm_ctx* ctx, const elm_map* map, elm_
     return batch_enqueue_impl(ctx, map, scans, batch, T0, cfg, want_trace, nullptr);
 }
 
-static void state_to_result(const ScanState& h, const RegParams& rp, elm_reg_result& r) {
+static void state_to_result(const ScanState& h, const RegParams& rp, elm_reg_result& r, int path = 0) {
     memset(&r, 0, sizeof(r));
+    r.path = path;
     memcpy(r.T, h.T, sizeof(r.T));
     memcpy(r.local_cov, h.local_cov, sizeof(r.local_cov));
     r.d_fitness = h.fitness;
@@ -2289,7 +2281,7 @@ extern "C" int elm_register_batch_finish(elm_ctx* ctx, elm_reg_result* results, 
         ctx->last_error = "the ranks iterated different registrations in one slot (rank-agreement check of the exchanged sums)";
         return ELM_ERR_COMM;
     }
-    for (int b = 0; results && b < ctx->batch; ++b) state_to_result(hs[b], ctx->rp, results[b]);
+    for (int b = 0; results && b < ctx->batch; ++b) state_to_result(hs[b], ctx->rp, results[b], ctx->path);
     {
         int mx = 0;
         for (int b = 0; b < ctx->batch; ++b) mx = std::max(mx, (int)hs[b].iters);
@@ -2331,6 +2323,7 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     int rc;
     PathChoice pc;
     if ((rc = choose_path(ctx, map, cfg, &pc)) != ELM_OK) return rc;
+    ctx->path = (map && map->dm.n_vox) ? path_code(pc) : 0;
     if (pc.radar) {
         // use_radar_cov: lockstep batches of `slots` registrations (k_accumulate_radar is not a slot kernel; a radar scan is a few hundred
         // returns).  Per-registration arithmetic is that of elm_register_batch.
@@ -2484,7 +2477,7 @@ extern "C" int elm_register_stream(elm_ctx* ctx, const elm_map* map, elm_scan* c
     // with poor initial guesses would leave every later call of the shape enqueueing its iteration count in empty launches
     ctx->stream_hint_iters = (ctx->h_active[3] >= 0) ? std::min(it, ctx->h_active[3] + 1) : it;
     const ScanState* hs = (const ScanState*)ctx->h_state;
-    for (int b = 0; results && b < count; ++b) state_to_result(hs[b], rp, results[b]);
+    for (int b = 0; results && b < count; ++b) state_to_result(hs[b], rp, results[b], ctx->path);
     if (trace) memcpy(trace, ctx->h_trace, (size_t)count * ELM_MAX_ITER_TRACE * sizeof(elm_iter_trace));
     return ELM_OK;
 }
@@ -2579,6 +2572,7 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
     int rc;
     PathChoice pc;
     if ((rc = choose_path(ctx, map, cfg, &pc)) != ELM_OK) return rc;
+    ctx->path = (map && map->dm.n_vox) ? path_code(pc) : 0;
     if (map->dm.n_vox == 0 || cfg->max_iteration <= 0 || max_n == 0 || pc.radar) {
         // nothing iterates (or use_radar_cov: see elm_register_stream): upload and let the lockstep path handle the degenerate cases
         std::vector<elm_scan*> sc((size_t)count, nullptr);
@@ -2769,7 +2763,7 @@ extern "C" int elm_register_stream_host(elm_ctx* ctx, const elm_map* map, const 
 #undef HF_CHK
     if ((rc = prof_collect(ctx)) != ELM_OK) return rc;
     const ScanState* hs = (const ScanState*)ctx->h_state;
-    for (int b = 0; results && b < count; ++b) state_to_result(hs[b], rp, results[b]);
+    for (int b = 0; results && b < count; ++b) state_to_result(hs[b], rp, results[b], ctx->path);
     if (trace) memcpy(trace, ctx->h_trace, (size_t)count * ELM_MAX_ITER_TRACE * sizeof(elm_iter_trace));
     return ELM_OK;
 }

@@ -104,12 +104,6 @@ struct DevMap {
     const uint32_t* grid_idx;   // [4 * n_blk] bucket-order index of every candidate slot (GICP payload, insertion order for exact
                                 // ties); 0xFFFFFFFF in padding slots
     const uint32_t* grid_start; // [gnx * gny * gnz + 4]
-    // (round 5) PATCH table of the dense grid, optional: entry [linear cell (x, y, z)] = the runs of the FOUR columns (x, y), (x + 1, y),
-    // (x, y + 1), (x + 1, y + 1) from cell z on, one word each = first block (24 bits) | blocks of cell z << 24 | blocks of cell z + 1 << 28
-    // (a column outside the grid: 0).  Stage 1 reads the 2 x 2 x 2 block of cells a point leans into with ONE 16-byte gather instead
-    // of four 12-byte gathers of grid_start (the vector-memory front end pays per gather instruction and distinct line, not per byte:
-    // profiles/r05_l1_probe.txt).  Built only when every cell has <= 15 blocks, the block array < 2^24 blocks and the table fits its byte budget.
-    const uint4* grid_patch;    // [gnx * gny * gnz] or nullptr
     // two-level form of the same grid (maps whose bounding box is too large or too sparse for one dense offset table): the box is cut
     // into tiles of kTile x kTile (x, y) cells; grid_tiles[tile] = {first offset entry, z0 | nz << 16}: the tile stores offsets only for
     // the cells z0 .. z0 + nz - 1 that hold points, (nz + 1) entries per column (its cell starts + the column end), columns (x, y)-major.
@@ -281,9 +275,6 @@ void launch_accumulate_cell(hipStream_t s, const DevMap& m, const ScanDesc* scan
 int stream_max_slots(); // slots one elm_register_stream call can iterate concurrently
 void launch_accumulate_grid(hipStream_t s, const DevMap& m, const ScanDesc* scans, int batch, int total_blocks,
                             ScanState* st, double* partials, const RegParams& rp);
-#ifndef ELM_GRID_PATCH_DEFAULT
-#define ELM_GRID_PATCH_DEFAULT 0 // 1: the dense grid gets its patch table whenever it fits (ELM_GRID_PATCH=0 / 1 overrides at run time)
-#endif
 // Registration::AlignCloudsLocal / AlignCloudsLocalPointCov / AlignCloudsLocalVoxelCov (reg.cpp:15-225) on explicit pairs (elm_align_clouds_local)
 struct AlignArgs {
     double Rinv[9], tinv[3]; // inverse of last_icp_pose: rotation block (row-major) and -Rinv t
@@ -296,7 +287,6 @@ constexpr int kAlignOut = 16 + 36 + 1 + 6 + 36 + 6 + 1; // T (column-major), loc
 void launch_align_pairs(hipStream_t s, const double* src_local, const double* tgt_xyz, const double* tgt_cov, const double* src_cov, size_t n,
                         const AlignArgs& a, double* partials, double* out);
 void launch_query_direct(hipStream_t s, const DevMap& m, int what, const double* query, size_t n, double th2, int32_t* q_out); // the plain walk (27 / 7 hash probes, float64): the query form of k_accumulate_direct
-void launch_grid_patch(hipStream_t s, const DevMap& m, uint4* out, unsigned* overflow); // DevMap::grid_patch from grid_start; *overflow != 0: a run does not fit the packed word
 void launch_vox_stat(hipStream_t s, const DevMap& m, uint32_t* out); // fills DevMap::vox_stat's box (m.vx0.., m.vnx..)
 void launch_gather_gicp(hipStream_t s, const DevMap& m, size_t n_slots, double* out, int compact); // pt_gicp[grid_idx[slot]] -> out[slot] (16 or 8 doubles)
 // half-voxel cell of a stored coordinate (host + device; the binning of DevMap::grid_pts)

@@ -617,7 +617,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_radar(const DevMap m, con
         const double gy = ((S.T[1] * px + S.T[5] * py) + S.T[9] * pz) + S.T[13];
         const double gz = ((S.T[2] * px + S.T[6] * py) + S.T[10] * pz) + S.T[14];
         double Cs[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-        if (rp.radar == 2) { // ELM_STRICT_PAIRS: the reference's arithmetic of use_radar_cov = 0 -- no source term at all
+        if (rp.radar == 2) { // ELM_CHECK=strict_pairs: the reference's arithmetic of use_radar_cov = 0 -- no source term at all
 #pragma unroll
             for (int k = 0; k < 9; ++k) Cs[k] = 0.0;
         } else if (S.iters == 0) radar_source_cov(gx, gy, gz, rp, Cs); // S.T is still the initial guess: g is the pose CalFramePointCov reads
@@ -1744,7 +1744,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : kGridWave
         const GridAxis ax = grid_axis(gx, m), ay = grid_axis(gy, m), az = grid_axis(gz, m);
         // statistics of the reference's walk for this query voxel: candidates and occupied buckets among the 27
         unsigned stat = 0;
-        if (kStats && TILED != 1) { // (the two-level grid keeps no dense statistics box: its work counters read 0)
+        if (kStats && !TILED) { // (the two-level grid keeps no dense statistics box: its work counters read 0)
             const int ux = ax.f - m.vx0, uy = ay.f - m.vy0, uz = az.f - m.vz0;
             const bool in_box = (unsigned)ux < (unsigned)m.vnx && (unsigned)uy < (unsigned)m.vny && (unsigned)uz < (unsigned)m.vnz;
             const unsigned sidx = in_box ? ((unsigned)ux * (unsigned)m.vny + (unsigned)uy) * (unsigned)m.vnz + (unsigned)uz : 0u;
@@ -1781,17 +1781,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : kGridWave
         ok[1] = inside && (xfirst ? has_x : has_y);
         ok[2] = inside && (xfirst ? has_y : has_x);
         ok[3] = inside && has_x && has_y;
-        if (TILED == 2) {
-            // ONE 16-byte gather: the patch entry at the low corner of the 2 x 2 x 2 block holds the runs of all four columns (a span clipped
-            // to one cell on an axis sits at the patch's low column there; the entry's other column is masked by ok[]).  Word k ^ c of the
-            // entry, c = (own column's position in the patch), is the k-th column in the order own / x neighbour / y neighbour / diagonal.
-            const unsigned pidx = inside ? ((unsigned)rx0 * (unsigned)m.gny + (unsigned)ry0) * (unsigned)m.gnz + (unsigned)rz0 : 0u;
-            const uint4 e = m.grid_patch[pidx];
-            const bool ixb = ox && has_x, iyb = oy && has_y;
-            unsigned w0 = ixb ? e.y : e.x, w1 = ixb ? e.x : e.y, w2 = ixb ? e.w : e.z, w3 = ixb ? e.z : e.w;
-            unsigned u0 = iyb ? w2 : w0, u1 = iyb ? w3 : w1, u2 = iyb ? w0 : w2, u3 = iyb ? w1 : w3;
-            s0[0] = u0; s0[1] = xfirst ? u1 : u2; s0[2] = xfirst ? u2 : u1; s0[3] = u3;
-        } else if (!TILED) {
+        if (!TILED) {
             // cell index of the own column, the neighbours one column step away (x: gny * gnz cells, y: gnz), towards the other cell of the span
             const int own_x = ox ? rx1 : rx0, own_y = oy ? ry1 : ry0;
             const unsigned base = ((unsigned)own_x * (unsigned)m.gny + (unsigned)own_y) * (unsigned)m.gnz + (unsigned)rz0;
@@ -1841,15 +1831,8 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : kGridWave
             int b0v[4], b1v[4]; // (already in visiting order)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if (TILED == 2) { // first block | blocks of cell rz0 << 24 | blocks of cell rz0 + 1 << 28
-                    const unsigned w = s0[k];
-                    const int first = (int)(w & 0xFFFFFFu), len = (int)((w >> 24) & 15u) + ((rz1 > rz0) ? (int)(w >> 28) : 0);
-                    b0v[k] = ok[k] ? first : 0;
-                    b1v[k] = ok[k] ? first + len : 0;
-                } else {
-                    b0v[k] = ok[k] ? (int)s0[k] : 0;
-                    b1v[k] = ok[k] ? (int)((rz1 > rz0 || TILED) ? s2[k] : s1[k]) : 0;
-                }
+                b0v[k] = ok[k] ? (int)s0[k] : 0;
+                b1v[k] = ok[k] ? (int)((rz1 > rz0 || TILED) ? s2[k] : s1[k]) : 0;
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -1940,7 +1923,7 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? (STATS ? 7 : kGridWave
             const bool live = it < n_hard;
             const GridHardRec R = s_rec[live ? it : 0];
             int win, walked;
-            grid_ball_walk<(TILED == 1 ? 1 : 0), LPI>(m, lp, R, live, rl, lane, win, walked);
+            grid_ball_walk<TILED, LPI>(m, lp, R, live, rl, lane, win, walked);
             if (kStats) walked = group_sum_int<LPI>(walked);
             if (rl == 0 && live) {
                 s_res[it] = win;
@@ -2092,29 +2075,6 @@ __global__ __launch_bounds__(256) void k_gather_gicp(const DevMap m, size_t n_sl
 }
 
 // map build: cnt27 | nocc27 << 16 for every voxel of the dense floor-key box (see DevMap::vox_stat)
-// map build: the patch table of the dense grid (DevMap::grid_patch) -- one thread per cell, the runs of its 2 x 2 columns from that cell on
-__global__ __launch_bounds__(256) void k_grid_patch(const DevMap m, uint4* __restrict__ out, unsigned* __restrict__ overflow) {
-    const size_t n = (size_t)m.gnx * (size_t)m.gny * (size_t)m.gnz;
-    const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= n) return;
-    const int cz = (int)(c % (size_t)m.gnz), cy = (int)((c / (size_t)m.gnz) % (size_t)m.gny), cx = (int)(c / ((size_t)m.gnz * (size_t)m.gny));
-    unsigned w[4];
-    bool over = false;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int x = cx + (k & 1), y = cy + (k >> 1);
-        w[k] = 0u;
-        if (x < m.gnx && y < m.gny) {
-            const uint32_t* e = m.grid_start + (((size_t)x * (size_t)m.gny + (size_t)y) * (size_t)m.gnz + (size_t)cz);
-            const unsigned s0 = e[0], s1 = e[1], s2 = (cz + 1 < m.gnz) ? e[2] : s1; // (z fastest: the entry after a column's last cell is that cell's end)
-            const unsigned c0 = s1 - s0, c1 = s2 - s1;
-            over = over || c0 > 15u || c1 > 15u || s0 >= (1u << 24);
-            w[k] = s0 | (c0 << 24) | (c1 << 28);
-        }
-    }
-    if (over) atomicOr(overflow, 1u);
-    out[c] = make_uint4(w[0], w[1], w[2], w[3]);
-}
 __global__ __launch_bounds__(256) void k_vox_stat(const DevMap m, uint32_t* __restrict__ out) {
     const size_t n = (size_t)m.vnx * m.vny * m.vnz;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -3605,7 +3565,7 @@ void launch_align_pairs(hipStream_t s, const double* src_local, const double* tg
     }
     hipLaunchKernelGGL(k_align_solve, dim3(1), dim3(64), 0, s, partials, blocks, n, a, out);
 }
-// The query form of the plain walk (elm_map_get_correspondences without a search index, or with ELM_QUERY=direct as the in-product
+// The query form of the plain walk (elm_map_get_correspondences without a search index, or with ELM_CHECK=query_direct as the in-product
 // checker of the production search): GetCorrespondencePoints / GetCorrespondencesCov / GetCorrespondencesAllCov (vhm.cpp:31-206) on
 // float64 GLOBAL-frame points -- 27 (7) hash probes per point, every bucket point, the reference's arithmetic.  q_out as RegParams::q_out.
 template <int WHAT>
@@ -3687,18 +3647,17 @@ void launch_accumulate_grid(hipStream_t s, const DevMap& m, const ScanDesc* scan
             else ELM_LAUNCH_GW(M, C, T, 0, 0);                  \
         }                                                       \
     } while (0)
-    // index form (template parameter TILED): 0 dense grid, 1 two-level grid, 2 dense grid read through its patch table
+    // index form (template parameter TILED): 0 dense grid, 1 two-level grid
 #define ELM_LAUNCH_GT(M, C)                                                        \
     do {                                                                           \
         if (m.grid_tiled) ELM_LAUNCH_G(M, C, 1);                                   \
-        else if (m.grid_patch) ELM_LAUNCH_G(M, C, 2);                              \
         else ELM_LAUNCH_G(M, C, 0);                                                \
     } while (0)
     if (rp.query) { // elm_map_get_correspondences: the search of the P2P kernel alone (STATS = 2)
         if (m.grid_wide) {
-            if (m.grid_tiled) ELM_LAUNCH_GW(ELM_P2P, 0, 1, 2, 1); else if (m.grid_patch) ELM_LAUNCH_GW(ELM_P2P, 0, 2, 2, 1); else ELM_LAUNCH_GW(ELM_P2P, 0, 0, 2, 1);
+            if (m.grid_tiled) ELM_LAUNCH_GW(ELM_P2P, 0, 1, 2, 1); else ELM_LAUNCH_GW(ELM_P2P, 0, 0, 2, 1);
         } else {
-            if (m.grid_tiled) ELM_LAUNCH_GW(ELM_P2P, 0, 1, 2, 0); else if (m.grid_patch) ELM_LAUNCH_GW(ELM_P2P, 0, 2, 2, 0); else ELM_LAUNCH_GW(ELM_P2P, 0, 0, 2, 0);
+            if (m.grid_tiled) ELM_LAUNCH_GW(ELM_P2P, 0, 1, 2, 0); else ELM_LAUNCH_GW(ELM_P2P, 0, 0, 2, 0);
         }
     }
     else if (rp.method == ELM_P2P) ELM_LAUNCH_GT(ELM_P2P, 0);
@@ -3713,10 +3672,6 @@ void launch_gather_gicp(hipStream_t s, const DevMap& m, size_t n_slots, double* 
     const size_t threads = n_slots * (compact ? 8 : 16);
     if (compact) hipLaunchKernelGGL(k_gather_gicp<1>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, m, n_slots, out);
     else hipLaunchKernelGGL(k_gather_gicp<0>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, m, n_slots, out);
-}
-void launch_grid_patch(hipStream_t s, const DevMap& m, uint4* out, unsigned* overflow) {
-    const size_t n = (size_t)m.gnx * (size_t)m.gny * (size_t)m.gnz;
-    hipLaunchKernelGGL(k_grid_patch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, m, out, overflow);
 }
 void launch_vox_stat(hipStream_t s, const DevMap& m, uint32_t* out) {
     const size_t n = (size_t)m.vnx * m.vny * m.vnz;

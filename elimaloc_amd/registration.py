@@ -386,7 +386,7 @@ class PinnedBuffer:
 
 def _result_dict(r, trace=None):
     d = dict(T=np.array(r.T).reshape(4, 4).T.copy(), is_success=bool(r.is_success), iterations=int(r.iterations),
-             gate=int(r.gate), fitness_score=float(r.fitness_score), d_fitness=float(r.d_fitness),
+             gate=int(r.gate), path=int(r.path), fitness_score=float(r.fitness_score), d_fitness=float(r.d_fitness),
              local_cov=np.array(r.local_cov).reshape(6, 6).T.copy(), n_corr_last=float(r.n_corr_last),
              point_iterations=float(r.point_iterations), n_cand_total=float(r.n_cand_total),
              n_occ_total=float(r.n_occ_total), fallback_blocks=float(r.fallback_blocks), n_tested_total=float(r.n_tested_total))

@@ -80,6 +80,17 @@ typedef struct elm_iter_trace {
     double T[16];
 } elm_iter_trace;
 
+/* elm_reg_result.path: the accumulate kernels of the call.  GRID (dense / two-level cell grid: P2P, GICP) and VOXEL_LISTS (VGICP, AVGICP)
+ * are the fast kernels; LISTS / WALK are the fall-back index forms of maps no grid can hold (or ELM_KERNEL); PAIRS = the per-pair kernels
+ * (use_radar_cov, ELM_CHECK=strict_pairs, or -- with one warning per map on stderr -- asymmetric covariances on a fall-back index:
+ * 12-27 times slower); | SIDE_RECORDS: the map holds asymmetric covariances and the fast kernels carried their antisymmetric sums. */
+#define ELM_PATH_GRID 1
+#define ELM_PATH_LISTS 2
+#define ELM_PATH_VOXEL_LISTS 3
+#define ELM_PATH_WALK 4
+#define ELM_PATH_PAIRS 5
+#define ELM_PATH_SIDE_RECORDS 16
+
 /* Outputs of one RunRegister (reg.cpp:274-418). */
 typedef struct elm_reg_result {
     double T[16];         /* returned pose (column-major) */
@@ -89,7 +100,7 @@ typedef struct elm_reg_result {
     int32_t is_success;
     int32_t iterations; /* executed iterations */
     int32_t gate;       /* 0 none, 1 empty map, 2 overlap ratio (reg.cpp:352), 3 fitness (reg.cpp:405) */
-    int32_t _pad;
+    int32_t path;       /* which kernels ran (ELM_PATH_*; 0: nothing iterated) */
     double n_corr_last; /* correspondences of the last executed iteration */
     double point_iterations; /* scan points processed x iterations */
     /* work counters summed over the executed iterations (for the algorithmic-bytes model): 0 unless
@@ -111,26 +122,45 @@ typedef struct elm_map_info {
     int32_t has_point_cov;
     int32_t layout_flags; /* bit 0: GICP payload as 64-byte {mean, normal, k} records (a point covariance of the form I - 0.999 n n^T
                            * has its inverse rebuilt as I + k n n^T; a point outside that form is flagged and reads its stored inverse),
-                           * bit 1: the same for the voxel covariances of VGICP / AVGICP (clear: ELM_COV_RECORDS=full, all stored inverses),
+                           * bit 1: the same for the voxel covariances of VGICP / AVGICP (clear: ELM_CHECK=full_records, all stored inverses),
                            * bit 2: the P2P / GICP cell grid is the two-level (tiled) form (box too large / sparse for one dense table),
                            * bit 3: no point covariance is flagged: GICP runs the kernels without the stored-inverse fallback and gathers its
-                           *        pair fused, A = w I + (w k) n n^T (clear with ELM_PAIR_NINE=1 at map build: nine entries of w C^-1),
+                           *        pair fused, A = w I + (w k) n n^T (clear with ELM_CHECK=pair_nine at map build: nine entries of w C^-1),
                            * bit 4: the same for the voxel covariances (VGICP's pair; AVGICP gathers sum w and sum (w k) n n^T per point),
                            * bit 5: the face sublists are written for AVGICP's fused walk,
                            * bit 6: ... and some voxel is flagged: the fused walk skips its pairs and a fix-up launch over the marked
-                           *        workgroups adds them (ELM_AVG_FIXUP=0 at map build: the nine-entry walk with its in-line fallback instead),
+                           *        workgroups adds them (ELM_CHECK=avg_inline at map build: the nine-entry walk with its in-line fallback instead),
                            * bit 7: some flagged POINT covariance has an asymmetric stored inverse (rank-deficient neighbourhood, U != V in its
                            *        SVD): GICP's kernels on this map also write the 15 antisymmetric side sums per workgroup and the solve restores
-                           *        all 36 entries of J^T M J (LDLT on the lower triangle, as the reference); ELM_STRICT_PAIRS=1 runs the
-                           *        reference's per-pair arithmetic instead (the in-product checker, 12-27 times slower), =0 drops the side sums,
-                           * bit 8: the same for the voxel covariances (VGICP / AVGICP),
-                           * bit 9: the dense cell grid carries its patch table (16 bytes per cell: stage 1 reads the offsets of the four
-                           *        columns a point leans into with one gather; ELM_GRID_PATCH=0 / 1 at index build) */
+                           *        all 36 entries of J^T M J (LDLT on the lower triangle, as the reference); ELM_CHECK=strict_pairs runs
+                           *        the reference's per-pair arithmetic instead (the in-product checker, 12-27 times slower),
+                           * bit 8: the same for the voxel covariances (VGICP / AVGICP). */
     uint64_t device_bytes;
     uint64_t n_query_voxels; /* cell grid: voxels of the dense statistics box; neighbourhood lists: query voxels (0 until built) */
     uint64_t nbr_entries;    /* cell grid: == n_points (every map point once); neighbourhood lists: ~27 x n_points */
     uint64_t index_bytes;    /* device bytes of the search structures the accumulate kernels read (built on first use) */
 } elm_map_info;
+
+/* ---------------------------------------------------------------- run-time switches --------------- */
+/* The library reads FIVE environment variables (+ ELM_DEVICES, read by the C++ shims in include/elimaloc/).  None is needed in
+ * production: the defaults are what every number in DESIGN.md is measured with; the others select shipping code paths that other maps
+ * reach by themselves (so that tests can force them onto small maps) or run the in-product checkers of the fast forms.
+ *   ELM_KERNEL          grid (default: dense / two-level cell grid for P2P / GICP, voxel-mean lists for VGICP / AVGICP) | lists (the
+ *                       fall-back index of maps no grid can hold: per-query-voxel neighbourhood lists) | direct (the plain walk -- 27 hash
+ *                       probes, every bucket point, float64: the in-kernel reference of the parity tests).  Read at elm_ctx_create.
+ *   ELM_GRID            comma-separated: dense | tiled (forbid / force the two-level form), max_cells=N (cell budget of the dense offset
+ *                       table, default 1.5e9), max_block_bytes=N (block arrays beyond N bytes are addressed in 16-byte units, default 4 GB).
+ *                       Read when a map's search index is built.
+ *   ELM_CHECK           comma-separated in-product checkers: strict_pairs (covariance methods run the reference's per-pair arithmetic: all
+ *                       36 entries of J^T M J, 3x3 products and an inverse per pair), full_records (pairs read the stored 3x3 inverses
+ *                       instead of the compact {mean, normal, k} records), pair_nine / avg_nine (nine entries of w C^-1 per pair instead of
+ *                       the fused gathers), avg_inline / avg_fixup (AVGICP on maps with flagged voxels: in-line fallback / fix-up launch,
+ *                       whatever the map's share of flagged voxels), query_direct (elm_map_get_correspondences by the plain walk).
+ *   ELM_SCAN_ORDER      none: elm_scan_upload keeps the caller's point order (default: Hilbert order over 2 m cells, on the device).
+ *   ELM_GROUP_EXCHANGE  host | rccl: the exchange of a device group (default: RCCL when every rank has a device of its own).
+ *   ELM_DEVICES         (shims) "0,1,2,3": the process-wide context of the C++ shims is a device group over these GPUs.
+ * Measured-negative experiments of rounds 2-5 (fused reduction, half-set streams, graph replay, wave-level reduction, previous-winner
+ * bound, patch table ...) are not in the library any more: profiles/r06_removed_*.patch re-adds each. */
 
 /* ---------------------------------------------------------------- context ------------------------- */
 int elm_ctx_create(int device_id, elm_ctx** out);
@@ -151,7 +181,7 @@ typedef struct elm_profile {
 } elm_profile;
 int elm_ctx_set_profiling(elm_ctx* ctx, int enable);
 /* Work counters of elm_reg_result (n_cand_total, n_occ_total, n_tested_total, fallback_blocks): OFF by default -- the registration
- * launches then carry no instrumentation and those fields read 0; on (or ELM_WORK_COUNTERS=1 in the environment): the same kernels with
+ * launches then carry no instrumentation and those fields read 0; on: the same kernels with
  * the counters compiled in (~1 % slower).  poses, flags, iteration counts and point_iterations do not depend on the switch. */
 int elm_ctx_set_work_counters(elm_ctx* ctx, int enable);
 int elm_ctx_get_profile(elm_ctx* ctx, elm_profile* out, int reset);
@@ -192,7 +222,7 @@ int elm_map_download_voxels(const elm_map* map, int32_t* key3, int32_t* npts, do
  * elm_map_download_points order, what 1 / 2: position of the voxel in elm_map_download_voxels order; -1 = the reference's default target at
  * the origin (no neighbour bucket at all around the point, voxel_hash_map.cpp:37 / :105; never for what 2).  what 2 yields up to seven
  * pairs per point in the reference's neighbour order (0, +x, -x, +y, -y, +z, -z).  At most `cap` pairs are written; *n_pairs is the full
- * count.  The search is the accumulate kernels' own (their QUERY instantiations); ELM_QUERY=direct runs the plain 27-probe walk instead. */
+ * count.  The search is the accumulate kernels' own (their QUERY instantiations); ELM_CHECK=query_direct runs the plain 27-probe walk instead. */
 int elm_map_get_correspondences(elm_ctx* ctx, const elm_map* map, int what, const double* xyz, size_t n, double max_dist,
                                 uint32_t* src_index, int32_t* tgt_index, size_t cap, size_t* n_pairs);
 

@@ -1,7 +1,7 @@
 """The reference's public correspondence calls -- VoxelHashMap::GetCorrespondencePoints / GetCorrespondencesCov /
 GetCorrespondencesAllCov / GetAdjacentVoxels (vhm.cpp:31-243) -- as calls of their own: the PAIRS of the production search (the QUERY
 instantiations of the grid / voxel-list kernels, i.e. the code the fused accumulate kernels run) against the oracle, pair for pair,
-index for index, on every index form; the plain 27-probe walk (ELM_QUERY=direct) as the in-product checker."""
+index for index, on every index form; the plain 27-probe walk (ELM_CHECK=query_direct) as the in-product checker."""
 import numpy as np
 import pytest
 
@@ -26,16 +26,16 @@ def _queries(world, seed, n=6000):
 def _set_env(monkeypatch, kernel_env):
     if kernel_env == "tiled":
         monkeypatch.setenv("ELM_KERNEL", "grid"); monkeypatch.setenv("ELM_GRID", "tiled")
-    elif kernel_env in ("grid", "patch"):
-        monkeypatch.setenv("ELM_KERNEL", "grid"); monkeypatch.setenv("ELM_GRID_PATCH", "1" if kernel_env == "patch" else "0")
+    elif kernel_env == "grid":
+        monkeypatch.setenv("ELM_KERNEL", "grid")
     elif kernel_env == "query_direct":
-        monkeypatch.setenv("ELM_QUERY", "direct")
+        monkeypatch.setenv("ELM_CHECK", "query_direct")
     else:
         monkeypatch.setenv("ELM_KERNEL", kernel_env)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kernel_env", ["grid", "patch", "tiled", "lists", "direct", "query_direct"])
+@pytest.mark.parametrize("kernel_env", ["grid", "tiled", "lists", "direct", "query_direct"])
 def test_correspondence_calls_match_the_oracle_pair_for_pair(oracle, kernel_env, monkeypatch):
     from elimaloc_amd.registration import Context, VoxelHashMap
     _set_env(monkeypatch, kernel_env)
@@ -76,7 +76,7 @@ def test_correspondence_calls_match_the_oracle_pair_for_pair(oracle, kernel_env,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kernel_env", ["grid", "patch", "tiled", "query_direct"])
+@pytest.mark.parametrize("kernel_env", ["grid", "tiled", "query_direct"])
 def test_exact_ties_pick_the_reference_s_neighbour(oracle, kernel_env, monkeypatch):
     """Query points exactly half-way between lattice points: 2, 4 or 8 candidates at bit-identical distance; the pair is the FIRST strict
     minimum of the reference's walk (bucket visiting order, insertion order inside a bucket)."""

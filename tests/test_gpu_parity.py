@@ -568,18 +568,17 @@ def test_full_size_c4_vgicp_shape(ctx, oracle):
 
 
 def _set_kernel_env(monkeypatch, kernel_env):
-    """grid: dense cell grid; patch: the same with its patch table; tiled: its two-level form forced; lists / direct: the older kernel generations"""
+    """grid: dense cell grid; tiled: its two-level form forced; lists / direct: the older kernel generations"""
     if kernel_env == "tiled":
         monkeypatch.setenv("ELM_KERNEL", "grid")
         monkeypatch.setenv("ELM_GRID", "tiled")
-    elif kernel_env in ("grid", "patch"):  # the dense grid read through grid_start / through its patch table (layout bit 9)
+    elif kernel_env == "grid":
         monkeypatch.setenv("ELM_KERNEL", "grid")
-        monkeypatch.setenv("ELM_GRID_PATCH", "1" if kernel_env == "patch" else "0")
     else:
         monkeypatch.setenv("ELM_KERNEL", kernel_env)
 
 
-@pytest.mark.parametrize("kernel_env", ["grid", "patch", "tiled", "lists", "direct"])
+@pytest.mark.parametrize("kernel_env", ["grid", "tiled", "lists", "direct"])
 @pytest.mark.parametrize("voxel_size,max_pts,th,method", [
     (0.5, 30, 5.0, 0),    # finer voxels
     (1.5, 50, 5.0, 1),    # README-recommended 50 points per voxel (buckets > 32 points), GICP
@@ -625,7 +624,7 @@ def _tie_world():
     return lattice, scan
 
 
-@pytest.mark.parametrize("kernel_env", ["grid", "patch", "tiled", "lists", "direct"])
+@pytest.mark.parametrize("kernel_env", ["grid", "tiled", "lists", "direct"])
 @pytest.mark.parametrize("method", [0, 1, 2])
 def test_exact_ties_follow_the_reference_visiting_order(oracle, method, kernel_env, monkeypatch):
     """Equal float64 distances: the reference keeps the FIRST strict minimum of its walk (27 voxels x-major..z-minor,
@@ -645,7 +644,7 @@ def test_exact_ties_follow_the_reference_visiting_order(oracle, method, kernel_e
         ref = oracle.register(om, scan, T0, oracle.default_config(method, max_iteration=3, icp_termination_threshold_m=0.0,
                                                                   min_overlap_ratio=0.0, max_fitness_score=10.0))
         _compare_run(det, ref)
-        if kernel_env in ("grid", "patch", "tiled", "lists") and method in (0, 1):
+        if kernel_env in ("grid", "tiled", "lists") and method in (0, 1):
             assert det["fallback_blocks"] > 0  # the tied points really went through the exact float64 stage
     finally:
         c.close()
@@ -825,13 +824,11 @@ def test_randomized_configs_two_level_grid(oracle, seed, monkeypatch):
 
 @pytest.mark.parametrize("seed,tiled", [(s, t) for s in range(8) for t in (False, True)])
 def test_randomized_configs_wide_block_addressing(oracle, seed, tiled, monkeypatch):
-    """The same sweep with the block array treated as 4 GB or more (ELM_GRID_MAX_BLOCK_BYTES forces the limit down): stage 1 of the
+    """The same sweep with the block array treated as 4 GB or more (ELM_GRID=max_block_bytes=N forces the limit down): stage 1 of the
     grid kernels then carries block offsets in 16-byte units and forms 64-bit addresses (template flag WIDE) -- the form maps beyond
     ~275 M points take -- on the dense and on the two-level grid."""
     from elimaloc_amd.registration import Context
-    monkeypatch.setenv("ELM_GRID_MAX_BLOCK_BYTES", "48")
-    if tiled:
-        monkeypatch.setenv("ELM_GRID", "tiled")
+    monkeypatch.setenv("ELM_GRID", "max_block_bytes=48,tiled" if tiled else "max_block_bytes=48")
     c = Context(0)
     try:
         _randomized_case(c, oracle, 200 + seed)
@@ -876,7 +873,7 @@ def test_grid_budget_voxel_lists_use_the_hash(oracle, world100k, monkeypatch):
     """VGICP / AVGICP on a map whose floor-key box exceeds the cell budget: the voxel-mean lists are found through the query hash
     instead of the dense table: same results."""
     from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod
-    monkeypatch.setenv("ELM_GRID_MAX_CELLS", "1000")
+    monkeypatch.setenv("ELM_GRID", "max_cells=1000")
     c = Context(0)
     try:
         for method in (IcpMethod.VGICP, IcpMethod.AVGICP):
@@ -893,8 +890,7 @@ def test_grid_budget_falls_back_to_lists(oracle, world100k, monkeypatch):
     """A map whose bounding box exceeds the cell budget, with the two-level grid forbidden (ELM_GRID=dense), gets the
     neighbourhood lists: same results."""
     from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod
-    monkeypatch.setenv("ELM_GRID_MAX_CELLS", "1000")
-    monkeypatch.setenv("ELM_GRID", "dense")
+    monkeypatch.setenv("ELM_GRID", "max_cells=1000,dense")
     c = Context(0)
     try:
         vm, om = _maps(c, oracle, world100k, IcpMethod.P2P)
@@ -1076,7 +1072,7 @@ def test_api_misuse_fails_loudly(ctx, oracle, world100k):
 @pytest.mark.parametrize("method", [1, 2, 3])
 def test_compact_covariance_records_equal_the_stored_inverses(oracle, world100k, method, monkeypatch):
     """GICP / VGICP / AVGICP read 64-byte {mean, normal, k} records and rebuild the inverse covariance I + k n n^T in registers when
-    every covariance of the map has that form (checked per point / voxel at map build); ELM_COV_RECORDS=full keeps the stored 3x3
+    every covariance of the map has that form (checked per point / voxel at map build); ELM_CHECK=full_records keeps the stored 3x3
     inverses.  Both agree with each other to the sum tolerance on every iteration, and with the oracle."""
     from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, VoxelHashMap
     m = IcpMethod(method)
@@ -1085,7 +1081,7 @@ def test_compact_covariance_records_equal_the_stored_inverses(oracle, world100k,
     runs = {}
     for mode in ("compact", "full"):
         if mode == "full":
-            monkeypatch.setenv("ELM_COV_RECORDS", "full")
+            monkeypatch.setenv("ELM_CHECK", "full_records")
         c = Context(0)
         try:
             vm = VoxelHashMap(1.0, 30, c)
@@ -1118,11 +1114,11 @@ def test_compact_covariance_records_equal_the_stored_inverses(oracle, world100k,
         assert ref["iterations"] == r["iterations"] and dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
 
 
-@pytest.mark.parametrize("method,env", [(1, "ELM_PAIR_NINE"), (2, "ELM_PAIR_NINE"), (3, "ELM_PAIR_NINE"), (3, "ELM_AVG_NINE")])
+@pytest.mark.parametrize("method,env", [(1, "pair_nine"), (2, "pair_nine"), (3, "pair_nine"), (3, "avg_nine")])
 def test_fused_compact_pairs_agree_with_the_nine_entry_form(oracle, method, env, monkeypatch):
     """On a map whose every covariance is of the compact form the kernels never form C^-1 = I + k n n^T: GICP / VGICP gather
     A = w I + (w k) n n^T and b = w e + (w k)(n . e) n fused, AVGICP gathers sum w and sum (w k) n n^T per point (six entries)
-    instead of nine entries of w C^-1 per pair.  ELM_PAIR_NINE=1 (read at map build; ELM_AVG_NINE=1: AVGICP's walk alone) keeps
+    instead of nine entries of w C^-1 per pair.  ELM_CHECK=pair_nine (read at map build; ELM_CHECK=avg_nine: AVGICP's walk alone) keeps
     the nine-entry forms.  Same pairs, the same sums to the sum tolerance on every iteration, and the oracle's pose.
     A single flagged covariance (a rank-deficient neighbourhood: a handful per million points, depending on where the world is cut)
     makes the map use the nine-entry kernels with their fallback, so the world is chosen among a few seeds as one without any
@@ -1157,12 +1153,12 @@ def test_fused_compact_pairs_agree_with_the_nine_entry_form(oracle, method, env,
     runs = {}
     for mode in ("fused", "nine"):
         if mode == "nine":
-            monkeypatch.setenv(env, "1")
+            monkeypatch.setenv("ELM_CHECK", env)
         c = Context(0)
         try:
             vm = build(c, world)
             runs[mode] = Registration(RegistrationConfig(icp_method=m), c).RunRegister(scan, vm, T0, trace=True)[-1]
-            if env == "ELM_PAIR_NINE":  # layout bits 3 / 4: the fused kernels are what ran in the first mode, the nine-entry ones in the second
+            if env == "pair_nine":  # layout bits 3 / 4: the fused kernels are what ran in the first mode, the nine-entry ones in the second
                 assert bool(int(vm.info().layout_flags) & bit) == (mode == "fused")
         finally:
             c.close()
@@ -1217,7 +1213,7 @@ def test_rank_deficient_covariances_keep_the_full_records(oracle):
 def test_avgicp_fused_walk_with_flagged_voxels_fix_up_launch(oracle, monkeypatch):
     """A map with voxels outside the compact form still runs the fused AVGICP walk: it skips the pairs of flagged voxels (NaN normals in
     the face sublists), marks its workgroup, and a fix-up launch over the marked workgroups adds those pairs -- with the stored 3x3
-    inverse -- to the workgroup's partial record before the solve reduces it (layout bit 6).  ELM_AVG_FIXUP=0 keeps such maps on the
+    inverse -- to the workgroup's partial record before the solve reduces it (layout bit 6).  ELM_CHECK=avg_inline keeps such maps on the
     nine-entry walk with its in-line fallback.  Same pairs, same sums to the sum tolerance on every iteration, bit-identical when
     repeated, and the oracle's trajectory; the stream path (continuous batching) agrees with the single registrations."""
     from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, VoxelHashMap, Scan
@@ -1237,7 +1233,7 @@ def test_avgicp_fused_walk_with_flagged_voxels_fix_up_launch(oracle, monkeypatch
     runs = {}
     for mode in ("fixup", "inline", "skip"):  # skip: the fused walk WITHOUT its fix-up launch (a test switch): the flagged pairs go missing
         if mode != "fixup":
-            monkeypatch.setenv("ELM_AVG_FIXUP", "0" if mode == "inline" else "skip")
+            monkeypatch.setenv("ELM_CHECK", "avg_inline" if mode == "inline" else "avg_skip")
         c = Context(0)
         try:
             vm = VoxelHashMap(1.0, 30, c)
@@ -1300,7 +1296,7 @@ def test_asymmetric_covariances_travel_in_side_records(oracle, method, monkeypat
     (reg.cpp:107-113, 136-142).  The fast kernels pack the 21 upper entries of the world-frame sums; on a map that holds such a record
     (layout bits 7 / 8) they also write the 15 entries of the antisymmetric part into side records, and the solve restores all 36
     entries (asym_side_store).  DEFAULT == the oracle to the 1e-9 bar on every iteration's sums, == the per-pair checker
-    (ELM_STRICT_PAIRS=1), on single registrations and through the stream.  (What the sums lose without the side records -- the behaviour
+    (ELM_CHECK=strict_pairs), on single registrations and through the stream.  (What the sums lose without the side records -- the behaviour
     before round 5 -- is shown in plain numpy by tests/test_asym_algebra.py.)"""
     from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, Scan
     m = IcpMethod(method)
@@ -1309,9 +1305,9 @@ def test_asymmetric_covariances_travel_in_side_records(oracle, method, monkeypat
     om = None
     for mode in (None, "1"):
         if mode is None:
-            monkeypatch.delenv("ELM_STRICT_PAIRS", raising=False)
+            monkeypatch.delenv("ELM_CHECK", raising=False)
         else:
-            monkeypatch.setenv("ELM_STRICT_PAIRS", mode)
+            monkeypatch.setenv("ELM_CHECK", "strict_pairs")
         c = Context(0)
         try:
             vm, om_ = _maps(c, oracle, world, m)
@@ -1345,7 +1341,7 @@ def test_asymmetric_covariances_two_ranks(oracle, method, stream, monkeypatch):
     """The side sums under an exchange: two real ranks on one GPU, every scan sharded in two, the all-reduce carrying 32 + 16 doubles per
     scan on such a map.  Ranks bit-identical, the oracle's trajectory."""
     from elimaloc_amd.registration import IcpMethod
-    monkeypatch.delenv("ELM_STRICT_PAIRS", raising=False)
+    monkeypatch.delenv("ELM_CHECK", raising=False)
     m = IcpMethod(method)
     world, scans, T0s = _asym_case()
     res = _run_two_ranks(world, scans, T0s, m, stream=stream, slots=2)
@@ -1367,17 +1363,17 @@ def test_asymmetric_covariances_two_ranks(oracle, method, stream, monkeypatch):
 
 def test_fuzz_case_with_asymmetric_covariances():
     """Fuzz case 813687 (GICP, 0.4 m voxels, one point per voxel, exact lattice: the case that exposed the symmetric packing): the default
-    agrees with the oracle, and so does the per-pair checker (ELM_STRICT_PAIRS=1)."""
+    agrees with the oracle, and so does the per-pair checker (ELM_CHECK=strict_pairs)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "--cases", "1", "--seed0", "813687"]
     env = dict(os.environ)
-    env.pop("ELM_STRICT_PAIRS", None)
+    env.pop("ELM_CHECK", None)
     auto = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert auto.returncode == 0 and "1/1 cases agree" in auto.stdout, auto.stdout[-2000:] + auto.stderr[-2000:]
-    env["ELM_STRICT_PAIRS"] = "1"
+    env["ELM_CHECK"] = "strict_pairs"
     strict = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert strict.returncode == 0 and "1/1 cases agree" in strict.stdout, strict.stdout[-2000:] + strict.stderr[-2000:]
 
@@ -1538,67 +1534,39 @@ def test_radar_covariance_entry_points(ctx, oracle, world100k):
         assert np.array_equal(a["T"], b["T"]) and a["iterations"] == b["iterations"]
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("method", [0, 1])
-def test_patch_table_is_the_same_search(oracle, method, monkeypatch):
-    """The patch table (DevMap::grid_patch, layout bit 9) only changes HOW stage 1 learns the runs of its four columns: every
-    iteration's sums, the pose and the counters are bit-identical with and without it -- on a world with negative coordinates,
-    scans that reach past the grid's edge, and a tight allowed-cell clip (voxel size 0.7).  A map with a cell of more than 15
-    blocks does not get the table (and still registers)."""
-    from elimaloc_amd.registration import Context, VoxelHashMap, Registration, RegistrationConfig, IcpMethod
-    m = IcpMethod(method)
-    rng = np.random.default_rng(99)
-    world = np.concatenate([synth.make_world(60000, seed=21), rng.uniform(-6, 6, size=(20000, 3)) * np.array([1.0, 1.0, 0.3])]).astype(np.float32)
-    runs = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("ELM_GRID_PATCH", mode)
-        c = Context(0)
-        try:
-            out = []
-            for vs in (1.0, 0.7):
-                vm = VoxelHashMap(vs, 30, c)
-                vm.AddPoints(world)
-                if m == IcpMethod.GICP:
-                    vm.CalPointCovAll(0.4)
-                vm.BuildNeighbourhoods()
-                assert bool(int(vm.info().layout_flags) & 512) == (mode == "1")
-                for seed in (1, 2, 3):
-                    scan, Tt = synth.make_scan(world, 5000, seed=500 + seed)
-                    if seed == 3:
-                        scan = (scan * np.float32(1.6)).astype(np.float32)  # a third of the points beyond the grid's box
-                    T0 = synth.perturb(Tt, seed=600 + seed, max_trans=0.4, max_rot_deg=1.5)
-                    out.append(Registration(RegistrationConfig(icp_method=m), c).RunRegister(scan, vm, T0, trace=True)[-1])
-            runs[mode] = out
-        finally:
-            c.close()
-    for a, b in zip(runs["0"], runs["1"]):
-        assert a["iterations"] == b["iterations"] and a["is_success"] == b["is_success"]
-        assert np.array_equal(a["T"], b["T"])
-        for ia, ib in zip(a["iters"], b["iters"]):
-            assert ia["n_corr"] == ib["n_corr"]
-            assert np.array_equal(ia["JTJ"], ib["JTJ"]) and np.array_equal(ia["JTr"], ib["JTr"])
-    # a dense blob (as many points in one cell as the spacing rule lets in: a cell of more than 15 blocks cannot be packed) and a table
-    # over its byte budget: no table in the second case, the oracle's answers in both
-    blob = (rng.uniform(0.0, 0.2, size=(400, 3)) + np.array([3.1, 3.1, 0.1])).astype(np.float32)
-    w2 = np.concatenate([world[:30000], blob])
-    for budget in (None, "1024"):
-        monkeypatch.setenv("ELM_GRID_PATCH", "1")
-        if budget:
-            monkeypatch.setenv("ELM_GRID_PATCH_MAX_BYTES", budget)
-        c = Context(0)
-        try:
-            vm = VoxelHashMap(1.0, 200, c)
-            vm.AddPoints(w2)
-            om = oracle.Map(1.0, 200)
-            om.add_points(w2)
-            if m == IcpMethod.GICP:
-                vm.CalPointCovAll(0.4); om.cal_point_cov_all(0.4)
-            vm.BuildNeighbourhoods()
-            if budget:
-                assert not int(vm.info().layout_flags) & 512
-            scan, Tt = synth.make_scan(w2, 4000, seed=77)
-            T0 = synth.perturb(Tt, seed=78, max_trans=0.2, max_rot_deg=1.0)
-            *_, det = Registration(RegistrationConfig(icp_method=m), c).RunRegister(scan, vm, T0, trace=True)
-            _compare_run(det, oracle.register(om, scan, T0, oracle.default_config(method)))
-        finally:
-            c.close()
+
+
+def test_the_slow_corner_is_announced_and_visible(oracle, monkeypatch, capfd):
+    """The one combination that still leaves the fast kernels: asymmetric covariances on a map whose search index is a
+    fall-back form (here ELM_KERNEL=lists).  GICP then runs the per-pair kernels -- exact, 12-27 times slower.  It says so ONCE per map on
+    stderr and every result carries path = ELM_PATH_PAIRS; the same map on the default index reports the grid kernels with side records,
+    an ordinary map the plain grid kernels, P2P on any map never leaves them."""
+    from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod
+    PATH_GRID, PATH_LISTS, PATH_VOXEL_LISTS, PATH_PAIRS, SIDE = 1, 2, 3, 5, 16
+    world, scans, T0s = _asym_case()
+    monkeypatch.setenv("ELM_KERNEL", "lists")
+    c = Context(0)
+    try:
+        vm, om = _maps(c, oracle, world, IcpMethod.GICP)
+        reg = Registration(RegistrationConfig(icp_method=IcpMethod.GICP), c)
+        capfd.readouterr()
+        dets = [reg.RunRegister(sc, vm, T0, trace=True)[-1] for sc, T0 in zip(scans, T0s)]
+        err = capfd.readouterr().err
+        assert err.count("[elimaloc] map") == 1 and "per-pair kernels" in err and "neighbourhood lists" in err, err  # once per map
+        assert all(d["path"] == PATH_PAIRS for d in dets)
+        _compare_run(dets[0], oracle.register(om, scans[0], T0s[0], oracle.default_config(1)))  # slow, not wrong
+        p2p = Registration(RegistrationConfig(icp_method=IcpMethod.P2P), c).RunRegister(scans[0], vm, T0s[0], trace=True)[-1]
+        assert p2p["path"] == PATH_LISTS and not capfd.readouterr().err
+    finally:
+        c.close()
+    monkeypatch.delenv("ELM_KERNEL")
+    c = Context(0)
+    try:
+        vm, _ = _maps(c, oracle, world, IcpMethod.GICP)
+        d = Registration(RegistrationConfig(icp_method=IcpMethod.GICP), c).RunRegister(scans[0], vm, T0s[0], trace=True)[-1]
+        assert d["path"] == PATH_GRID | SIDE and not capfd.readouterr().err
+        vm2, _ = _maps(c, oracle, synth.make_world(100000, seed=1001), IcpMethod.VGICP)
+        d2 = Registration(RegistrationConfig(icp_method=IcpMethod.VGICP), c).RunRegister(scans[0], vm2, T0s[0], trace=True)[-1]
+        assert d2["path"] == PATH_VOXEL_LISTS
+    finally:
+        c.close()
