@@ -1,4 +1,4 @@
-// elm_internal.hpp -- device-side data layout shared by the kernels (elm_kernels.hip) and the C ABI (elm_api.cpp).
+// elm_internal.hpp -- device-side data layout shared by the kernels (elm_k_*.hip) and the C ABI (elm_api.cpp).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -185,7 +185,7 @@ struct StreamCtrl {
                        // same shape enqueues before it first looks (the host's own count only says when it LOOKED)
 };
 
-// in-solve refill of finished slots (single-rank streams, see finish_slot in elm_kernels.hip)
+// in-solve refill of finished slots (single-rank streams, see finish_slot in elm_k_solve.hip)
 struct StreamArgs {
     ScanDesc* scans;
     const QueueItem* queue;
@@ -211,7 +211,7 @@ struct RegParams {
     int32_t max_iter;
     uint32_t uniform_blocks; // > 0: every scan / slot owns exactly that many consecutive workgroups (scan = block / uniform_blocks)
     int32_t radar;           // use_radar_cov with a covariance method: k_accumulate_radar's 64-double partial records, full JTJ
-    int32_t solve_small;     // 1 (half-set streams): k_solve<256> -- workgroups that fit beside a running accumulate launch
+    int32_t _reserved0;
     int32_t stats;           // elm_ctx_set_work_counters: the grid / voxel-list kernels also sum the three work counters (STATS = 1)
     uint32_t* flagged;   // [workgroups] AVGICP on a map with flagged voxels: set by a workgroup of the fused walk that met (and skipped) a flagged
                          // record, read and cleared by the fix-up launch that adds those pairs to the workgroup's partial record (nullptr: the
@@ -223,7 +223,7 @@ struct RegParams {
                          // and the call returns ELM_ERR_COMM instead of adding up unrelated normal equations
     int32_t _pad_rc;
     double* asym;        // [workgroups][16] side records of a map with an asymmetric flagged covariance (the strict lower triangle of
-                         // H_w - H_w^T, see asym_side_store in elm_kernels.hip): written by every workgroup of such a launch, reduced by
+                         // H_w - H_w^T, see asym_side_store in elm_dev_reduce.hpp): written by every workgroup of such a launch, reduced by
                          // k_solve, which restores all 36 entries of J^T M J before the congruence; nullptr on every other map
     double* asym_sums;   // [scans][16] the scans' reduced side sums when the iteration is split around an exchange (modes 1 / 2 of k_solve;
                          // laid out right behind the packed sums, so ONE all-reduce carries both)
@@ -249,7 +249,7 @@ struct InitPack {
 };
 constexpr int kSums = ELM_PACKED_SUMS; // 21 + 6 + 1 + 1 (+ n_cand, n_occ, pad)
 
-// ---- launchers (elm_kernels.hip) ----------------------------------------------------------------------
+// ---- launchers (elm_k_*.hip) ----------------------------------------------------------------------
 void launch_init_state(hipStream_t s, ScanState* st, const double* T0, int batch, int map_empty, int* active);
 void launch_init_pack(hipStream_t s, ScanDesc* scans, ScanState* st, const InitPack& pack, int batch, int map_empty, int* active, const unsigned* n_dev);
 void launch_stream_refill(hipStream_t s, ScanDesc* scans, ScanState* st, int slots, const QueueItem* queue, const double* qT0,

@@ -1,4 +1,4 @@
-"""The algebra behind the antisymmetric side sums (elm_kernels.hip: asym_side_store, k_solve), checked in plain numpy on the CPU.
+"""The algebra behind the antisymmetric side sums (elm_dev_reduce.hpp: asym_side_store; elm_k_solve.hip: k_solve), checked in plain numpy on the CPU.
 
 The reference forms, per pair, J^T M J with M = (R^-1 C R^-T)^-1 and J = [I | -[p]x] (reg.cpp:100-125, 178-200) -- for an asymmetric
 "covariance" C all 36 entries matter (LDLT reads the lower triangle, reg.cpp:136-138).  The device accumulates in the world frame:

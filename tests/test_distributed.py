@@ -129,7 +129,7 @@ def test_pack_unpack_round_trip():
 
 
 def _stream_worker(rank, world_size, port, out_q):
-    """The multi-rank STREAM protocol of elm_register_stream (elm_kernels.hip: claim_registration with StreamArgs::stride): S slots,
+    """The multi-rank STREAM protocol of elm_register_stream (elm_k_solve.hip: claim_registration with StreamArgs::stride): S slots,
     slot s serves the registrations s, s + S, s + 2S, ...; whether a registration finishes at an iteration is decided on sums that
     every rank holds after the all-reduce of the slots' records -- so every rank takes the same refill decisions without any
     exchange about them, issues the same number of collectives, and stops at the same iteration."""
