@@ -83,16 +83,17 @@ def kernel_bytes_model(method, tested, V, pairs, grid=True):
     offset triples + 12 per distance-tested candidate + 12 winner re-read (+ 4 bucket index + 128 covariance record for
     GICP) + 1 (256-byte partial record per 256-point workgroup).  On the neighbourhood lists (k_accumulate_cell): 32 hash
     slot + 4 x 16 column records instead of the statistics word and the offset triples.
-    VGICP (k_accumulate_vnbr): 16 + 32 slot + 32 per voxel-mean record (V = occupied neighbours) + 72 winner covariance + 1.
-    AVGICP: 16 + 32 + 32 V + 72 per emitted pair + 1."""
+    VGICP (k_accumulate_vnbr, round 6 layout): 12 scan point + 4 dense-table word + 64 per block of four list slots (V = occupied
+    neighbours: ceil(V / 4) blocks) + 64 winner record from the per-voxel table + 1.
+    AVGICP: 12 + 4 + 48 per face record read (pairs) + 1."""
     index = (4.0 + 48.0) if grid else (32.0 + 64.0)
     if method == 0:
         return 16.0 + index + 12.0 * tested + 12.0 + 1.0
     if method == 1:
         return 16.0 + index + 12.0 * tested + 12.0 + 4.0 + 128.0 + 1.0
     if method == 2:
-        return 16.0 + 32.0 + 32.0 * V + 72.0 + 1.0
-    return 16.0 + 32.0 + 32.0 * V + 72.0 * pairs + 1.0
+        return 12.0 + 4.0 + 64.0 * math.ceil(V / 4.0) + 64.0 + 1.0
+    return 12.0 + 4.0 + 48.0 * pairs + 1.0
 
 
 def percentile(v, q):
@@ -279,23 +280,24 @@ def pmc_key(kernel_name, scan_points, map_points, guess, world="lattice"):
     return k
 
 
-def index_touch_bound(index_bytes, units_per_launch, requested_index_bytes_per_unit, live_scans, map_points, scan_range_m=SCAN_RANGE_M, search_m=5.0):
-    """Upper bound on the UNIQUE bytes of the search index one launch can touch: the whole index, what its points request, and the share of
-    the (spatially organised) index that lies under the launch's scans -- a scan reaches scan_range_m + the search radius from its sensor,
-    the map covers map_points / WORLD_PTS_PER_M2 square metres.  (Round 4 charged the whole index to every launch: a 32-slot launch on the
-    50 M-point map came out at five times the HBM peak.)"""
+def index_touch_bound(index_bytes, units_per_launch, requested_index_bytes_per_unit, live_scans, map_points, scan_range_m=SCAN_RANGE_M, search_m=5.0, shard_of=1):
+    """The UNIQUE bytes of the search index one launch has to touch at least once: the smallest of the index itself, what its points
+    request, and the share of the (spatially organised) index that lies under the launch's scans -- a scan reaches scan_range_m + the search
+    radius from its sensor (a Hilbert-contiguous shard of it: 1 / shard_of of that footprint), the map covers map_points /
+    WORLD_PTS_PER_M2 square metres.  `index_bytes` is the caller's figure for the bytes the leg's kernel is CERTAIN to read under that
+    footprint (bench.py: leg_roofline), so that the result is a lower bound of the measured traffic."""
     area = max(float(map_points) / WORLD_PTS_PER_M2, 1.0)
-    share = min(1.0, float(live_scans) * math.pi * (scan_range_m + search_m) ** 2 / area)
+    share = min(1.0, float(live_scans) * math.pi * (scan_range_m + search_m) ** 2 / max(1, int(shard_of)) / area)
     return min(float(index_bytes), float(requested_index_bytes_per_unit) * float(units_per_launch), share * float(index_bytes))
 
 
-def hbm_object(method, index_bytes, units_per_launch, sec, bytes_unit, bytes_ref, live_scans, map_points, traffic=None, traffic_src=None):
+def hbm_object(method, index_bytes, units_per_launch, sec, bytes_unit, bytes_ref, live_scans, map_points, traffic=None, traffic_src=None, shard_of=1):
     """The HBM stream of one accumulate launch: measured (a committed counter pass) or compulsory (scan point + partial record + GICP
     payload + the touched part of the index once), plus the requested bytes and the SURVEY 8(d) figure of the reference's walk."""
     payload = 64.0 if int(method) == 1 else 0.0  # the GICP match's compact record: one 64-byte sector per pair (128 with ELM_CHECK=full_records)
     stream_unit = 12.0 + 1.0 + payload           # scan point (packed xyz) + its share of the 256-byte partial record + payload
     requested_index_unit = max(bytes_unit - 17.0 - (132.0 if int(method) == 1 else 0.0), 0.0)
-    index_once = index_touch_bound(index_bytes, units_per_launch, requested_index_unit, live_scans, map_points)
+    index_once = index_touch_bound(index_bytes, units_per_launch, requested_index_unit, live_scans, map_points, shard_of=shard_of)
     compulsory_unit = stream_unit + index_once / max(units_per_launch, 1.0)
     gbs = lambda b: (b * units_per_launch / sec / 1e9) if sec > 0 else 0.0  # noqa: E731
     compulsory_gbs, requested_gbs, ref_gbs = gbs(compulsory_unit), gbs(bytes_unit), gbs(bytes_ref)
@@ -331,7 +333,7 @@ def hbm_object(method, index_bytes, units_per_launch, sec, bytes_unit, bytes_ref
     }
 
 
-def load_counter_pass(kernel_name, scan_points, map_points, guess, batch, slots, units_per_launch, world="lattice"):
+def load_counter_pass(kernel_name, scan_points, map_points, guess, batch, slots, units_per_launch, world="lattice", shard_of=1):
     """The committed counter pass that speaks for a run: same kernel, sizes, guess set, registrations per step and slots PER GPU (the launch
     mix -- live slots per launch, draining launches -- follows from those) and, within 10 %, the same units per launch on this GPU.  A rank of
     an N-GPU run qualifies with the N = 1 pass of the same per-GPU operating point (more, smaller shards: the same units per launch)."""
@@ -344,7 +346,7 @@ def load_counter_pass(kernel_name, scan_points, map_points, guess, batch, slots,
         return None
     if not pm or pm.get("batch") != batch or pm.get("slots") != slots or pm.get("guess", "easy") != guess or pm.get("world", "lattice") != world:
         return None
-    if int(pm.get("scan_points", 131072)) != int(scan_points) or int(pm.get("map_points", 10_000_000)) != int(map_points):
+    if int(pm.get("scan_points", 131072)) != int(scan_points) or int(pm.get("map_points", 10_000_000)) != int(map_points) or int(pm.get("shard_of", 1)) != int(shard_of):
         return None
     up = float(pm.get("units_per_launch_profiled", 0.0))
     if up > 0 and abs(units_per_launch - up) > 0.10 * up:
@@ -400,8 +402,12 @@ def build_roofline(method, kernel_name, hbm, pm, units_per_launch, acc_ms_avg):
 
 
 def assert_fractions(obj, where="line"):
-    """`Never print a roofline above 1`: every `frac` / `compulsory_frac` of the line is checked before it is printed."""
+    """`Never print a roofline above 1`: every `frac` / `compulsory_frac` of the line is checked before it is printed -- and a compulsory
+    bound is a LOWER bound: measured traffic below 0.95 of it means the byte model charges something the kernel does not read."""
     if isinstance(obj, dict):
+        if isinstance(obj.get("traffic"), (int, float)) and isinstance(obj.get("compulsory_gbs"), (int, float)) and isinstance(obj.get("achieved"), (int, float)) \
+                and obj.get("unit") == "GB/s" and obj["traffic"] and obj["achieved"] < 0.95 * obj["compulsory_gbs"]:
+            raise AssertionError(f"{where}: measured traffic ({obj['achieved']:.1f} GB/s) below the compulsory bound ({obj['compulsory_gbs']:.1f} GB/s): the bound is not a bound")
         for k, v in obj.items():
             if k in ("frac", "compulsory_frac", "valu_issue_frac") and isinstance(v, (int, float)) and v > 1.05:
                 raise AssertionError(f"{where}.{k} = {v}: a utilisation above 1 means the byte / cycle model is wrong for this operating point")
@@ -492,7 +498,7 @@ def driver_line(full):
                                            "scaling", "vs_baseline", "dtype", "data")}
     cfg = full.get("config", {})
     line["config"] = {"workload": str(cfg.get("workload", "")).split(" (BASELINE")[0][:120]}
-    line["config"].update(_pick(cfg, ("scan_points", "map_points", "batch_per_gpu", "registrations_per_step", "slots_per_gpu", "iterations_mean", "iterations_max",
+    line["config"].update(_pick(cfg, ("scan_points", "map_points", "guess", "world", "shard_of", "batch_per_gpu", "registrations_per_step", "slots_per_gpu", "iterations_mean", "iterations_max",
                                       "success_rate", "map_points_retained", "map_voxels", "candidates_per_point_C", "occupied_voxels_per_point_V",
                                       "latency_ms_batch1")))
     line["config"]["parallelism"] = str(cfg.get("parallelism", ""))[:120]
@@ -867,11 +873,25 @@ def main():
         upl = (pt_iters_ / ranks) * steps_ / launches_  # units one launch processes ON THIS GPU = its shard of the batch's live points
         sec_ = acc_ms_ * 1e-3
         live_scans_ = upl / max(op["scan_points"] / ranks, 1.0)
-        pm_ = load_counter_pass(kname, op["scan_points"], op["map_points"], op["guess"], op["batch"], op["slots"], upl, op.get("world", "lattice"))
+        pm_ = load_counter_pass(kname, op["scan_points"], op["map_points"], op["guess"], op["batch"], op["slots"], upl, op.get("world", "lattice"), int(op.get("shard_of", 1)))
         traffic_ = pm_.get("hbm_bytes_per_unit") * upl if (pm_ and pm_.get("hbm_bytes_per_unit") is not None) else None
         src_ = (f"profiles/pmc_latest.json[{pmc_key(kname, op['scan_points'], op['map_points'], op['guess'], op.get('world', 'lattice'))}]: HBM bytes/unit of separate rocprofv3 --pmc passes of this "
                 f"leg's command ({pm_.get('source', 'see profiles/README.md')}) x this run's units per launch; counters cannot be read in the timed run") if traffic_ else None
-        hbm_ = hbm_object(int(m), int(info_.index_bytes), upl, sec_, bytes_unit_, bytes_ref_, live_scans_, op["map_points"], traffic_, src_)
+        # the index bytes this leg's kernel is CERTAIN to read under its scans' footprint (the compulsory bound must stay below the measured
+        # traffic): P2P / GICP -- the cell grid's blocks and offsets (every block holds map points, every map point is a candidate of the
+        # scan points around it); VGICP / AVGICP -- the lists of the voxels that HOLD map points (their own query list: word + ~3 blocks of
+        # four slots + their record; AVGICP: word + ~3.5 face records of 48 bytes read); query voxels that are merely adjacent to the map are
+        # reached only by misaligned points and are not counted
+        parts_ = [int(x) for x in info_.index_part_bytes]
+        if int(m) in (0, 1):
+            certain_ = parts_[0] if grid_ else parts_[3]
+        elif int(m) == 2:
+            certain_ = min(parts_[1], int(info_.n_voxels) * (4 + 64 * 3 + 64))
+        else:
+            certain_ = min(parts_[2] if parts_[2] else parts_[1], int(info_.n_voxels) * (4 + 48 * 3))
+        part_bytes_ = (parts_[0] if grid_ else parts_[3]) if int(m) in (0, 1) else (parts_[1] if int(m) == 2 or not parts_[2] else parts_[2])
+        shard_of_ = int(op.get("shard_of", 1))
+        hbm_ = hbm_object(int(m), certain_, upl, sec_, bytes_unit_, bytes_ref_, live_scans_, op["map_points"], traffic_, src_, shard_of=shard_of_)
         roof = build_roofline(int(m), kname, hbm_, pm_, upl, acc_ms_)
         if pm_ and ranks > 1:
             roof["counter_pass_shape"] = (f"taken at N = 1 ({op['slots']} slots x {op['scan_points']}-point scans); this rank runs {op['slots'] * ranks} slots x "
@@ -879,7 +899,8 @@ def main():
         roof.update({
             "kernel": kname,
             "search_index": "voxel-mean lists" if int(m) in (2, 3) else ("dense cell grid" if grid_ else "neighbourhood lists"),
-            "index_bytes": int(info_.index_bytes),
+            "index_bytes": int(part_bytes_),            # the structures THIS leg's kernel reads (elm_map_info.index_part_bytes)
+            "index_bytes_certain": int(certain_),
             "map_device_bytes": int(info_.device_bytes),
             "candidates_per_point_C": Cc,
             "occupied_voxels_per_point_V": Vv,
@@ -1023,7 +1044,8 @@ def main():
 
     n_slots = args.slots * ranks  # per-GPU points per launch stay fixed as ranks are added
     packed = reg.pack_inputs(scans, T0s)  # handle array + column-major guesses, marshalled once
-    op_point = dict(scan_points=args.scan_points, map_points=args.map_points, guess=args.guess, batch=args.batch, slots=args.slots, world=args.world)
+    op_point = dict(scan_points=args.scan_points, map_points=args.map_points, guess=args.guess, batch=args.batch, slots=args.slots, world=args.world,
+                    shard_of=max(1, args.shard_of))
 
     if args.slots > 0:
         out_raw, elapsed, prof, step = time_stream(reg, vm, packed, n_slots, args.steps, args.warmup)
@@ -1082,6 +1104,7 @@ def main():
                         f"initial guess {guess['max_trans']} m / {guess['max_rot_deg']} deg ({args.guess})" + ("" if args.world == "lattice" else f", world `{args.world}`"),
             "scan_points": args.scan_points,
             "map_points": args.map_points,
+            "guess": args.guess, "world": args.world, "shard_of": max(1, args.shard_of),
             "batch_per_gpu": args.batch,
             "registrations_per_step": n_batch,
             "slots_per_gpu": args.slots,
@@ -1448,7 +1471,7 @@ def main():
             scans4 = [Scan(ctx, g[0]) for g in g4]
             T4, T04 = [g[1] for g in g4], [g[2] for g in g4]
             host4 = [g[0] for g in g4[:4]]
-            op4 = dict(scan_points=pts4, map_points=map4, guess=args.guess, batch=n4, slots=slots4, world="lattice")
+            op4 = dict(scan_points=pts4, map_points=map4, guess=args.guess, batch=n4, slots=slots4, world="lattice", shard_of=1 if plain4 else 8)
             leg = method_leg(IcpMethod.VGICP, vm4, reg.pack_inputs(scans4, T04), n4, world4, host4, T4, T04, op4,
                              f"VGICP, {pts4}-point shards (one of the 8 Hilbert-contiguous shards of BASELINE configs[3]'s 262144-point scans, shard i mod 8 of "
                              f"scan i) vs the {map4}-point map, {n4} registrations through {slots4} slots: the launches ONE rank of the 8-GPU run issues per ICP "

@@ -99,6 +99,8 @@ class MapInfo(C.Structure):
         ("n_query_voxels", C.c_uint64),
         ("nbr_entries", C.c_uint64),
         ("index_bytes", C.c_uint64),
+        ("index_part_bytes", C.c_uint64 * 4),
+        ("n_list_voxels", C.c_uint64),
     ]
 
 

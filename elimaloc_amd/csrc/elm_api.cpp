@@ -876,6 +876,8 @@ static int build_voxel_neighbourhoods(elm_map* m, bool want_faces) {
         m->has_vnbr = true;
         m->info.device_bytes += bytes + (dense_ok ? (size_t)qcap * sizeof(HashSlot) : 0);
         m->info.index_bytes += bytes + (size_t)m->n_bad_vox * 9 * sizeof(double); // + the stored inverses flagged voxels read
+        m->info.index_part_bytes[1] += bytes + (size_t)m->n_bad_vox * 9 * sizeof(double);
+        m->info.n_list_voxels = n_q;
     }
     if (need_faces && m->d_vq_dense && n_q) {
         // AVGICP pairs with the face neighbours only (<= 7 of a list's <= 27 slots): their sublists as whole records, addressed like vq_dense
@@ -915,6 +917,7 @@ static int build_voxel_neighbourhoods(elm_map* m, bool want_faces) {
             m->info.layout_flags = (m->info.layout_flags & ~(32 | 64)) | (plain ? 32 : 0) | (m->dm.vface_flagged ? 64 : 0);
             m->info.device_bytes += vcells * sizeof(uint32_t) + (size_t)ftotal * sizeof(VoxRec);
             m->info.index_bytes += vcells * sizeof(uint32_t) + (size_t)ftotal * sizeof(VoxRec);
+            m->info.index_part_bytes[2] += vcells * sizeof(uint32_t) + (size_t)ftotal * sizeof(VoxRec);
             m->has_vface = true;
         } else {
             m->vface_refused = true;
@@ -1129,6 +1132,7 @@ static int build_cell_grid_impl(elm_map* m, uint64_t max_cells) {
     m->info.n_query_voxels = vcells;
     m->info.nbr_entries = n;
     m->info.index_bytes += gb.size() * sizeof(GridBlk) + (cells + 4) * sizeof(uint32_t) + vcells * sizeof(uint32_t);
+    m->info.index_part_bytes[0] += gb.size() * sizeof(GridBlk) + (cells + 4) * sizeof(uint32_t); // (the statistics box is read by the instrumented kernels only)
     return ELM_OK;
 }
 
@@ -1300,6 +1304,7 @@ static int build_tiled_grid_impl(elm_map* m) {
     m->info.layout_flags |= 4;
     m->info.nbr_entries = n;
     m->info.index_bytes += idx_bytes;
+    m->info.index_part_bytes[0] += idx_bytes;
     return ELM_OK;
 }
 
@@ -1403,6 +1408,7 @@ static int build_neighbourhood_lists(elm_map* m) {
     m->info.n_query_voxels = n_q;
     m->info.nbr_entries = total;
     m->info.index_bytes += (size_t)total * sizeof(Pt3) + (size_t)qcap * sizeof(HashSlot) + cell_bytes;
+    m->info.index_part_bytes[3] += (size_t)total * sizeof(Pt3) + (size_t)qcap * sizeof(HashSlot) + cell_bytes;
     return ELM_OK;
 }
 

@@ -139,6 +139,10 @@ typedef struct elm_map_info {
     uint64_t n_query_voxels; /* cell grid: voxels of the dense statistics box; neighbourhood lists: query voxels (0 until built) */
     uint64_t nbr_entries;    /* cell grid: == n_points (every map point once); neighbourhood lists: ~27 x n_points */
     uint64_t index_bytes;    /* device bytes of the search structures the accumulate kernels read (built on first use) */
+    uint64_t index_part_bytes[4]; /* ... by structure: [0] cell grid (blocks + offsets: P2P / GICP), [1] voxel-mean lists + per-voxel records
+                                   * (VGICP; AVGICP without a face table), [2] AVGICP's face sublists + their table, [3] neighbourhood lists (the
+                                   * fall-back index of P2P / GICP) */
+    uint64_t n_list_voxels;       /* query voxels of the voxel-mean lists (0 until built) */
 } elm_map_info;
 
 /* ---------------------------------------------------------------- run-time switches --------------- */

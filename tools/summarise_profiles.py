@@ -68,8 +68,9 @@ try:
             # uncalibrated (tiny here).  FETCH_SIZE counts Infinity-Cache hits: fabric-side traffic, an upper bound on DRAM bytes.
             summary.update({"kernel": b["roofline"]["kernel"], "method": {"P2P": 0, "GICP": 1, "VGICP": 2, "AVGICP": 3}[b["roofline"]["kernel"].split("<")[1].rstrip(">")],
                             "batch": b["config"]["batch_per_gpu"], "slots": b["config"]["slots_per_gpu"], "steps": b["steps"], "warmup": b["warmup"],
-                            "guess": "hard" if "(hard)" in b["config"]["workload"] else "easy",
-                            "world": "field" if "world `field`" in b["config"]["workload"] else "lattice",
+                            "guess": b["config"].get("guess") or ("hard" if "(hard)" in b["config"]["workload"] else "easy"),
+                            "world": b["config"].get("world") or ("field" if "world `field`" in b["config"]["workload"] else "lattice"),
+                            "shard_of": int(b["config"].get("shard_of") or 1),
                             "scan_points": int(b["config"].get("scan_points", 131072)), "map_points": int(b["config"].get("map_points", 10_000_000)),
                             "avg_launch_ms_traced": b["roofline"]["avg_launch_ms"], "ps_per_unit_traced": 1e9 * b["roofline"]["avg_launch_ms"] / units,
                             "fetch_size_kb_avg_raw": fetch_kb, "write_size_kb_avg": write_kb,
