@@ -162,3 +162,35 @@ def test_emit_writes_the_full_record_beside_the_line(tmp_path, capsys):
     out = capsys.readouterr()
     assert out.out.strip() == text and out.out.count("\n") == 1
     assert json.load(open(path)) == full and json.loads(out.err) == full
+
+
+def test_compulsory_is_a_lower_bound_or_the_line_is_refused():
+    """measured traffic below the compulsory bound means the model charges bytes the kernel does not read"""
+    ok = {"roofline": {"unit": "GB/s", "achieved": 2100.0, "traffic": 1.8e9, "compulsory_gbs": 750.0, "frac": 0.26}}
+    bench.assert_fractions(ok)
+    bad = {"configs": {"vgicp": {"roofline": {"hbm": {"unit": "GB/s", "achieved": 1100.0, "traffic": 1.2e9, "compulsory_gbs": 1700.0, "frac": 0.14}}}}}
+    with pytest.raises(AssertionError):
+        bench.assert_fractions(bad)
+    # no counter pass (traffic None): `achieved` IS the compulsory figure, nothing to compare
+    bench.assert_fractions({"roofline": {"unit": "GB/s", "achieved": 750.0, "traffic": None, "compulsory_gbs": 750.0, "frac": 0.09}})
+
+
+def test_a_shard_covers_its_share_of_the_footprint():
+    """locality-aware shards: 256 shards of 1 / 8 of a scan's footprint lie over an eighth of the index a whole scan's footprint would"""
+    whole = bench.index_touch_bound(1.0e9, 7.8e6, 300.0, 32, 50_000_000)
+    shard = bench.index_touch_bound(1.0e9, 7.8e6, 300.0, 32, 50_000_000, shard_of=8)
+    assert abs(shard - whole / 8) < 1e-6 * whole
+    h1 = bench.hbm_object(2, 5.2e8, 7.8e6, 0.15e-3, 273.0, 584.0, 238, 50_000_000, 60.0 * 7.8e6, "test", shard_of=8)
+    assert h1["compulsory_bytes_per_unit"] < 60.0 and h1["achieved"] >= 0.95 * h1["compulsory_gbs"]
+
+
+def test_counter_pass_of_another_shard_shape_is_refused(tmp_path, monkeypatch):
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    k = "k_accumulate_vnbr<VGICP>"
+    entry = {"batch": 2048, "slots": 256, "guess": "easy", "scan_points": 32768, "map_points": 50_000_000, "units_per_launch_profiled": 7.8e6, "shard_of": 8,
+             "hbm_bytes_per_unit": 60.0}
+    (prof / "pmc_latest.json").write_text(json.dumps({bench.pmc_key(k, 32768, 50_000_000, "easy"): entry}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.load_counter_pass(k, 32768, 50_000_000, "easy", 2048, 256, 7.8e6, "lattice", 8) is not None
+    assert bench.load_counter_pass(k, 32768, 50_000_000, "easy", 2048, 256, 7.8e6, "lattice", 1) is None  # thinned-out scans: another traffic pattern
