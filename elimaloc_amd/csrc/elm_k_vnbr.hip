@@ -103,38 +103,35 @@ __global__ __launch_bounds__(kBlock, kVnbrWaves) void k_accumulate_vnbr(const De
             // a winner that is clear of the runner-up by the rounding of the stored means and of the arithmetic is the strict
             // float64 minimum as well; its float64 record is read afterwards.  Near ties (practically never) take the float64 walk.
             bool exact = cnt != 0u;
-            int wv0 = -1, wv1 = -1, wv2 = -1, wv3 = -1, wvc = -1; // slot words of the block that holds the current winner; the winner's
             if (cnt != 0u) {
                 const unsigned nblk = (cnt + 3u) >> 2, blk0 = start >> 2;
                 // distances to gh = float32(g): |g - gh| joins the stored means' rounding in the margin of the decision
                 const float ghx = (float)gx, ghy = (float)gy, ghz = (float)gz;
                 const float eg = (fabsf((float)(gx - (double)ghx)) + fabsf((float)(gy - (double)ghy)) + fabsf((float)(gz - (double)ghz))) * 1.000001f;
                 const f32x2 gxy = {ghx, ghy}, gzz = {ghz, 0.f};
-                unsigned m1 = 0x7F800000u, m2 = 0x7F800000u;
+                unsigned m1 = 0x7F800000u, m2 = 0x7F800000u, jb = 0u;
                 for (unsigned b0 = 0; b0 < nblk; b0 += kVnbrBlks) {
-                    VoxBlk B[kVnbrBlks];
+                    GridBlk B[kVnbrBlks]; // the means of the block's four slots (48 of its 64 bytes: the slot words are read for the winner alone)
 #pragma unroll
-                    for (int u = 0; u < kVnbrBlks; ++u) B[u] = m.vnbr_blk[(b0 + u < nblk) ? blk0 + b0 + u : m.vnbr_pad_blk];
+                    for (int u = 0; u < kVnbrBlks; ++u) B[u] = m.vnbr_blk[(b0 + u < nblk) ? blk0 + b0 + u : m.vnbr_pad_blk].g;
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int u = 0; u < kVnbrBlks; ++u) {
                         f32x2 da, db;
-                        blk_dist_h(B[u].g, gxy, gzz, da, db);
+                        blk_dist_h(B[u], gxy, gzz, da, db);
                         const unsigned was = m1;
                         two_smallest(da.x, 0u, m1, m2);
                         two_smallest(da.y, 1u, m1, m2);
                         two_smallest(db.x, 2u, m1, m2);
                         two_smallest(db.y, 3u, m1, m2);
-                        const bool ch = m1 != was;
-                        wv0 = ch ? B[u].vc[0] : wv0; wv1 = ch ? B[u].vc[1] : wv1; wv2 = ch ? B[u].vc[2] : wv2; wv3 = ch ? B[u].vc[3] : wv3;
+                        jb = (m1 != was) ? b0 + (unsigned)u : jb;
                     }
                 }
                 // |float32(mean) - mean| <= 2^-24 |mean|_1 <= 6.5e-8 (|g|_1 + 6 voxel sizes); float32 arithmetic + key bits: 2^-18
                 const float em = 6.5e-8f * (fabsf(ghx) + fabsf(ghy) + fabsf(ghz) + 6.0f * (float)m.voxel_size) + eg;
                 const float s1 = __builtin_sqrtf(__uint_as_float(m1 & ~3u)), s2 = __builtin_sqrtf(__uint_as_float(m2 & ~3u));
                 if (s2 - s2 * 3.814697265625e-06f - em > s1 + s1 * 3.814697265625e-06f + em) {
-                    const unsigned sl = m1 & 3u; // the winner's slot word rode along with its block
-                    wvc = sl == 0u ? wv0 : sl == 1u ? wv1 : sl == 2u ? wv2 : wv3;
+                    bj = jb * 4u + (m1 & 3u); // the winner's slot of the list
                     exact = false;
                 }
             }
@@ -153,8 +150,8 @@ __global__ __launch_bounds__(kBlock, kVnbrWaves) void k_accumulate_vnbr(const De
                     }
                 }
             }
-            if (cnt) { // the winner's float64 record, from the per-voxel table (after the float64 walk: its slot word is an L1 hit)
-                const VoxRec w = m.vox_rec[exact ? vnbr_vid(m, start + min(bj, cnt - 1)) : ((unsigned)wvc & kVidMask)];
+            if (cnt) { // the winner's slot word (the line its block's means came from: an L1 hit), then its float64 record from the per-voxel table
+                const VoxRec w = m.vox_rec[vnbr_vid(m, start + min(bj, cnt - 1))];
                 bvid = w.vid; bmx = w.mx; bmy = w.my; bmz = w.mz;
                 if (COMPACT) { bn[0] = w.nx; bn[1] = w.ny; bn[2] = w.nz; bn[3] = w.k; }
                 const double ex = w.mx - gx, ey = w.my - gy, ez = w.mz - gz;

@@ -274,3 +274,24 @@ def test_debug_print_costs_nothing_when_off(capfd):
     assert "[RunRegister] Corresponding ratio " in out and "[RunRegister] ICP Fitness Score " in out
     assert ctx.get_profile()["accumulate_launches"] == 0  # ... and the caller's profile totals are as they were
     ctx.close()
+
+
+def test_runtime_switches_are_the_documented_ones():
+    """the library reads a handful of environment variables and include/elimaloc_hip.h lists every one of them; a new
+    getenv() in the sources without a line there fails here.  (ELM_GRID / ELM_CHECK hold tokens: every token the sources test is listed too.)"""
+    import glob
+    import re
+    src = "".join(open(p).read() for p in sorted(glob.glob(os.path.join(ROOT, "elimaloc_amd", "csrc", "*.[ch]*"))))
+    header = open(os.path.join(ROOT, "include", "elimaloc_hip.h")).read()
+    shims = "".join(open(p).read() for p in sorted(glob.glob(os.path.join(ROOT, "include", "elimaloc", "*.hpp"))))
+    read = set(re.findall(r'getenv\("([A-Z_0-9]+)"\)', src)) | set(re.findall(r'env_token\("([A-Z_0-9]+)"', src)) | {"ELM_CHECK"}
+    assert read == {"ELM_KERNEL", "ELM_GRID", "ELM_CHECK", "ELM_SCAN_ORDER", "ELM_GROUP_EXCHANGE"}, read
+    assert set(re.findall(r'getenv\("([A-Z_0-9]+)"\)', shims)) == {"ELM_DEVICES"}
+    table = header[header.index("run-time switches"):header.index("/* ---------------------------------------------------------------- context")]
+    for name in sorted(read | {"ELM_DEVICES"}):
+        assert name in table, name
+    tokens = set(re.findall(r'check_mode\("([a-z_]+)"\)', src)) | set(re.findall(r'env_token\("ELM_GRID", "([a-z_]+)"', src))
+    assert tokens and all(t in table for t in tokens - {"avg_skip"}), tokens  # (avg_skip: a test-only token, drops pairs on purpose)
+    # no compile-time A/B macro is left in the kernels
+    kern = "".join(open(p).read() for p in sorted(glob.glob(os.path.join(ROOT, "elimaloc_amd", "csrc", "elm_k_*.hip")) + glob.glob(os.path.join(ROOT, "elimaloc_amd", "csrc", "elm_dev_*.hpp"))))
+    assert not re.findall(r"^#\s*ifn?def\s+ELM_|^#\s*if\s+!?ELM_", kern, flags=re.M)
