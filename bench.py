@@ -287,7 +287,9 @@ def index_touch_bound(index_bytes, units_per_launch, requested_index_bytes_per_u
     WORLD_PTS_PER_M2 square metres.  `index_bytes` is the caller's figure for the bytes the leg's kernel is CERTAIN to read under that
     footprint (bench.py: leg_roofline), so that the result is a lower bound of the measured traffic."""
     area = max(float(map_points) / WORLD_PTS_PER_M2, 1.0)
-    share = min(1.0, float(live_scans) * math.pi * (scan_range_m + search_m) ** 2 / max(1, int(shard_of)) / area)
+    # k footprints of a fraction f of the map each, placed independently: they cover 1 - (1 - f)^k ~ 1 - exp(-k f) of it (NOT min(1, k f):
+    # footprints overlap long before they tile the map)
+    share = 1.0 - math.exp(-float(live_scans) * math.pi * (scan_range_m + search_m) ** 2 / max(1, int(shard_of)) / area)
     return min(float(index_bytes), float(requested_index_bytes_per_unit) * float(units_per_launch), share * float(index_bytes))
 
 
@@ -547,6 +549,8 @@ def driver_line(full):
         if isinstance(cc.get("config5"), dict) and "ms_per_scan_median" in cc["config5"]:
             out["config5_ms_per_scan"] = _num(cc["config5"]["ms_per_scan_median"])
         line["c_caller_ms"] = out
+    if full.get("model_errors"):
+        line["model_errors"] = len(full["model_errors"])
     line["process_wall_s"] = _num(full.get("process_wall_s"))
     line["full_record"] = "bench_full.json"
     text = json.dumps(line, separators=(",", ":"))
@@ -611,6 +615,35 @@ def single_process_leg(args, n, out, timeout_s=300):
         rec["error"] = repr(e)[-300:]
     rec["wall_s"] = time.time() - t0
     return rec
+
+
+def sanitize_fractions(result):
+    """What main() does with assert_fractions' verdict: a model error must never cost the driver its line.  Every roofline object that breaks
+    a rule (a utilisation above 1.05, measured traffic below the compulsory bound) loses the offending figures and says so; the errors are
+    listed at the top level (`model_errors`).  The CPU tests call assert_fractions itself."""
+    errors = []
+
+    def walk(obj, where):
+        if isinstance(obj, dict):
+            try:
+                assert_fractions({k: v for k, v in obj.items() if not isinstance(v, (dict, list))}, where)
+            except AssertionError as e:
+                errors.append(str(e)[:200])
+                for k in ("frac", "compulsory_frac", "valu_issue_frac", "compulsory_gbs", "compulsory_bytes_per_unit"):
+                    if k in obj and k != "frac":
+                        obj[k] = None
+                if isinstance(obj.get("frac"), (int, float)) and obj["frac"] > 1.05:
+                    obj["frac"] = None
+                obj["model_error"] = str(e)[:200]
+            for k, v in obj.items():
+                walk(v, where + "." + str(k))
+        elif isinstance(obj, list):
+            for i, v in enumerate(obj):
+                walk(v, f"{where}[{i}]")
+    walk(result, "line")
+    if errors:
+        result["model_errors"] = errors
+    return errors
 
 
 def host_cpu_info():
@@ -1497,7 +1530,8 @@ def main():
     if args.dump_poses and rank == 0:
         np.savez(args.dump_poses, T=np.stack([r["T"] for r in out]), iterations=np.array([r["iterations"] for r in out]),
                  success=np.array([r["is_success"] for r in out]))
-    assert_fractions(result)
+    for e_ in sanitize_fractions(result):
+        print("bench.py: roofline model error: " + e_, file=sys.stderr)
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
     if rank == 0:

@@ -25,7 +25,7 @@ def test_index_is_charged_at_most_its_touched_part():
     b = bench.index_touch_bound(idx, 32 * 262144, 250.0, 32, 50_000_000)
     assert b < 0.3 * idx
     # the headline: 256 scans cover the 10 M-point map several times over -> the whole index, once
-    assert bench.index_touch_bound(0.25e9, 256 * 131072 * 0.9, 250.0, 230, 10_000_000) == 0.25e9
+    assert 0.2499e9 < bench.index_touch_bound(0.25e9, 256 * 131072 * 0.9, 250.0, 230, 10_000_000) <= 0.25e9
     # never more than the points request
     assert bench.index_touch_bound(1e9, 1000, 100.0, 1, 10_000_000) <= 1e5
 
@@ -179,7 +179,7 @@ def test_a_shard_covers_its_share_of_the_footprint():
     """locality-aware shards: 256 shards of 1 / 8 of a scan's footprint lie over an eighth of the index a whole scan's footprint would"""
     whole = bench.index_touch_bound(1.0e9, 7.8e6, 300.0, 32, 50_000_000)
     shard = bench.index_touch_bound(1.0e9, 7.8e6, 300.0, 32, 50_000_000, shard_of=8)
-    assert abs(shard - whole / 8) < 1e-6 * whole
+    assert 0.12 * whole < shard < 0.16 * whole  # ~1 / 8 of it (the overlap of 32 footprints is larger for the whole scans)
     h1 = bench.hbm_object(2, 5.2e8, 7.8e6, 0.15e-3, 273.0, 584.0, 238, 50_000_000, 60.0 * 7.8e6, "test", shard_of=8)
     assert h1["compulsory_bytes_per_unit"] < 60.0 and h1["achieved"] >= 0.95 * h1["compulsory_gbs"]
 
@@ -194,3 +194,21 @@ def test_counter_pass_of_another_shard_shape_is_refused(tmp_path, monkeypatch):
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     assert bench.load_counter_pass(k, 32768, 50_000_000, "easy", 2048, 256, 7.8e6, "lattice", 8) is not None
     assert bench.load_counter_pass(k, 32768, 50_000_000, "easy", 2048, 256, 7.8e6, "lattice", 1) is None  # thinned-out scans: another traffic pattern
+
+
+def test_a_model_error_never_costs_the_line():
+    """main() sanitises instead of raising: the offending figures are dropped and the error is listed; the line still builds"""
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_final_default_bench.json")))
+    h = full["configs"]["C4_shard"]["roofline"]["hbm"]
+    h["compulsory_gbs"] = 2.0 * h["achieved"]
+    errs = bench.sanitize_fractions(full)  # (round 5's record also holds the vnbr legs whose bound exceeded the measurement: VERDICT r5 weak 8)
+    assert errs and any("C4_shard" in e for e in errs) and h["compulsory_gbs"] is None and "model_error" in h
+    line = json.loads(bench.driver_line(full))
+    assert line["model_errors"] == len(errs) and line["configs"]["C4_shard"]["value"] > 0
+    bench.assert_fractions(full)  # nothing left to complain about
+
+
+def test_footprints_overlap_before_they_tile_the_map():
+    a = bench.index_touch_bound(1.0e9, 1e12, 1e6, 235, 50_000_000, shard_of=8)
+    assert 0.18e9 < a < 0.20e9  # 1 - exp(-0.214), not 0.214
+    assert bench.index_touch_bound(0.25e9, 1e12, 1e6, 235, 10_000_000) > 0.249e9
