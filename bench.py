@@ -919,7 +919,11 @@ def main():
         if int(m) in (0, 1):
             certain_ = parts_[0] if grid_ else parts_[3]
         elif int(m) == 2:
-            certain_ = min(parts_[1], int(info_.n_voxels) * (4 + 64 * 3 + 64))
+            # blocks per list: the map's own average over ALL its query lists (the lists of voxels that hold points are longer than those of
+            # the fringe: the average is on the safe side of a lower bound), at most the 3 of a fully surrounded ground voxel
+            nq_ = max(int(info_.n_list_voxels), 1)
+            blocks_ = min(3.0, max(1.0, (parts_[1] - 64.0 * int(info_.n_voxels)) / (64.0 * nq_)))
+            certain_ = min(parts_[1], int(info_.n_voxels) * (4 + 64 * blocks_ + 64))
         else:
             certain_ = min(parts_[2] if parts_[2] else parts_[1], int(info_.n_voxels) * (4 + 48 * 3))
         part_bytes_ = (parts_[0] if grid_ else parts_[3]) if int(m) in (0, 1) else (parts_[1] if int(m) == 2 or not parts_[2] else parts_[2])
