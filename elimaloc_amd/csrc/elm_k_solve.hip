@@ -438,7 +438,7 @@ __global__ __launch_bounds__(NT, 1) void k_solve(const ScanDesc* scans, ScanStat
             }
             if (mode == 1) return;
         } else if (t < 64) {
-            a = (scans[s].blk_end > scans[s].blk_begin) ? sums[(size_t)s * kRadarSums + t] : 0.0;
+            a = sums[(size_t)s * kRadarSums + t]; // (mode 2: the all-reduced sums -- also of a scan that has no point on THIS rank)
         }
         if (t < 64) {
             if (t < 36) full[t] = a;
@@ -524,10 +524,12 @@ __global__ __launch_bounds__(NT, 1) void k_solve(const ScanDesc* scans, ScanStat
         }
         if (mode == 1) return;
     } else {
-        // (a scan without a single workgroup -- no points on this rank -- has no record and no sums: zeros)
-        if (t < 32) tot[t] = (scans[s].blk_end > scans[s].blk_begin) ? sums[(size_t)s * kSums + t] : 0.0;
-        else if (asym && t < 32 + kAsymSums)
-            dsum[t - 32] = (rp.asym_sums && scans[s].blk_end > scans[s].blk_begin) ? rp.asym_sums[(size_t)s * kAsymSums + (t - 32)] : 0.0;
+        // mode 2: the all-reduced sums mode 1 left in `sums` on every rank.  A scan without a single workgroup HERE (no point of it on this
+        // rank) reads them like any other: the other ranks' pairs are in there.  (Round 6: rounds 2-5 zeroed them for such a scan -- a
+        // leftover of the fused reduction -- so a rank without points saw n_corr = 0 and failed the overlap gate while the others went on;
+        // found by tests/test_group.py::test_group_with_tiny_and_empty_shards.)
+        if (t < 32) tot[t] = sums[(size_t)s * kSums + t];
+        else if (asym && t < 32 + kAsymSums) dsum[t - 32] = rp.asym_sums ? rp.asym_sums[(size_t)s * kAsymSums + (t - 32)] : 0.0;
     }
     __syncthreads();
     if (t >= 64) return; // the first wave does the rest with uniform control flow; lane 0 owns the state

@@ -11,6 +11,8 @@
 // A device id may repeat (device_ids = {0, 0}: two ranks on one GPU).  RCCL refuses two ranks on one device; such a group exchanges through
 // page-locked host memory instead (sum in rank order, identical on every rank) -- the form the one-GPU test box runs.
 #include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -300,6 +302,15 @@ static bool same_result(const elm_reg_result& a, const elm_reg_result& b) {
     return memcmp(a.T, b.T, sizeof(a.T)) == 0 && a.iterations == b.iterations && a.is_success == b.is_success && a.gate == b.gate;
 }
 
+static std::string describe_difference(const elm_reg_result& a, const elm_reg_result& b) {
+    double d = 0.0;
+    for (int k = 0; k < 16; ++k) d = std::max(d, fabs(a.T[k] - b.T[k]));
+    char t[256];
+    snprintf(t, sizeof(t), "iterations %d / %d, is_success %d / %d, gate %d / %d, n_corr_last %.0f / %.0f, max |dT| %.3g", a.iterations, b.iterations, a.is_success,
+             b.is_success, a.gate, b.gate, a.n_corr_last, b.n_corr_last, d);
+    return t;
+}
+
 int reg(elm_ctx* lead, const elm_map* map, const float* scan_xyz, size_t n, const double T0[16], const elm_reg_config* cfg, double T_out[16],
         int* is_success, double* fitness_score, double local_cov[36], elm_reg_result* result, elm_iter_trace* trace) {
     elm_group* g = group_of(lead);
@@ -316,7 +327,7 @@ int reg(elm_ctx* lead, const elm_map* map, const float* scan_xyz, size_t n, cons
     if (rc != ELM_OK) return rc;
     for (int r = 1; r < g->n; ++r) {
         if (!same_result(res[0], res[r])) {
-            elm_host::ctx_set_error(lead, "device group: rank " + std::to_string(r) + " returned another pose than rank 0 (broken exchange)");
+            elm_host::ctx_set_error(lead, "device group: rank " + std::to_string(r) + " returned another pose than rank 0 (broken exchange): " + describe_difference(res[0], res[r]));
             return ELM_ERR_COMM;
         }
     }
@@ -354,7 +365,7 @@ int reg_batch(elm_ctx* lead, const elm_map* map, elm_scan* const* scans, int cou
             const elm_reg_result& q = res[(size_t)r][(size_t)b];
             if (!same_result(results[b], q)) {
                 elm_host::ctx_set_error(lead, "device group: rank " + std::to_string(r) + " returned another pose than rank 0 for registration " + std::to_string(b) +
-                                                  " (broken exchange)");
+                                                  " (broken exchange): " + describe_difference(results[b], q));
                 return ELM_ERR_COMM;
             }
         }

@@ -180,3 +180,35 @@ def test_group_misuse_fails_loudly(world100k):
     del gvm, pvm
     g.close()
     one.close()
+
+
+def test_group_with_tiny_and_empty_shards(oracle, world100k):
+    """ragged inputs: scans of 0, 1, 2 and 5 points on a group of three ranks (ranks without a single point of a scan still take part in
+    every exchange), through RunRegister (host buffers) and through resident scans; the same iterations, gates and poses as one context"""
+    from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, Scan, VoxelHashMap
+    base, Tt = synth.make_scan(world100k, 400, seed=4321)
+    T0 = synth.perturb(Tt, seed=4322, max_trans=0.05, max_rot_deg=0.2)
+    sizes = [0, 1, 2, 5, 400]
+    c = Context(0)
+    vm = VoxelHashMap(1.0, 30, c)
+    vm.AddPoints(world100k)
+    reg = Registration(RegistrationConfig(icp_method=IcpMethod.P2P), c)
+    plain = [reg.RunRegister(base[:n], vm, T0, trace=True) for n in sizes]
+    plain_b = reg.RunRegisterBatch([Scan(c, base[:n]) for n in sizes], vm, [T0] * len(sizes))
+    del vm
+    c.close()
+    g = Context.multi([0, 0, 0])
+    gvm = VoxelHashMap(1.0, 30, g)
+    gvm.AddPoints(world100k)
+    greg = Registration(RegistrationConfig(icp_method=IcpMethod.P2P), g)
+    for n, p in zip(sizes, plain):
+        pose, ok, fit, cov, det = greg.RunRegister(base[:n], gvm, T0, trace=True)
+        assert (ok, det["iterations"], det["gate"]) == (p[1], p[4]["iterations"], p[4]["gate"]), n
+        np.testing.assert_allclose(pose, p[0], rtol=0, atol=1e-9)
+    gb = greg.RunRegisterBatch([Scan(g, base[:n]) for n in sizes], gvm, [T0] * len(sizes))
+    for n, a, b in zip(sizes, gb, plain_b):
+        assert (a["is_success"], a["iterations"], a["gate"]) == (b["is_success"], b["iterations"], b["gate"]), n
+        if n >= 5:  # (fewer points than unknowns: a singular system -- any step; DESIGN section 7 (ii))
+            np.testing.assert_allclose(a["T"], b["T"], rtol=0, atol=1e-9)
+    del gvm
+    g.close()
