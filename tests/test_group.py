@@ -212,3 +212,39 @@ def test_group_with_tiny_and_empty_shards(oracle, world100k):
             np.testing.assert_allclose(a["T"], b["T"], rtol=0, atol=1e-9)
     del gvm
     g.close()
+
+
+@pytest.mark.parametrize("method", [1, 2, 3])
+def test_group_covariance_methods_ragged_stream(oracle, world100k, method):
+    """the covariance methods through a stream on a three-rank group: more slots than registrations, scans of very different sizes (one of
+    them smaller than the group), one that fails the overlap gate, use_radar_cov on one pass -- results as on one context"""
+    from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, Scan, VoxelHashMap
+    m = IcpMethod(method)
+    scans, T0s = [], []
+    for i, n in enumerate([2, 700, 5000, 64, 1300]):
+        sc, Tt = synth.make_scan(world100k, max(n, 8), seed=7700 + i)
+        sc = sc[:n]
+        if i == 3:
+            sc = sc + np.float32(400.0)  # nowhere near the map: overlap gate in the first iteration
+        scans.append(sc)
+        T0s.append(synth.perturb(Tt, seed=7800 + i, max_trans=0.08, max_rot_deg=0.4))
+    runs = {}
+    for name, devs in (("plain", None), ("group", [0, 0, 0])):
+        c = Context(0) if devs is None else Context.multi(devs)
+        vm = VoxelHashMap(1.0, 30, c)
+        vm.AddPoints(world100k)
+        _prepare(vm, m)
+        res = [Scan(c, s) for s in scans]
+        out = {}
+        for radar in (0, 1):
+            reg = Registration(RegistrationConfig(icp_method=m, use_radar_cov=radar, range_variance_m=0.7, azimuth_variance_deg=1.5, elevation_variance_deg=0.9), c)
+            out[radar] = reg.RunRegisterStream(res, vm, T0s, slots=16)
+        runs[name] = out
+        del res, vm
+        c.close()
+    for radar in (0, 1):
+        for k, (a, b) in enumerate(zip(runs["group"][radar], runs["plain"][radar])):
+            assert (a["is_success"], a["iterations"], a["gate"]) == (b["is_success"], b["iterations"], b["gate"]), (radar, k)
+            if len(scans[k]) >= 64:
+                np.testing.assert_allclose(a["T"], b["T"], rtol=0, atol=1e-8 if radar else 1e-9)
+    assert runs["plain"][0][3]["gate"] == 2
