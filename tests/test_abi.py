@@ -105,6 +105,13 @@ def test_no_device_no_fallback(L):
     from elimaloc_amd._lib import ElmError
     with pytest.raises(ElmError):
         Context(0)
+    # the device group's constructor: bad arguments are ELM_ERR_INVALID, a box without a GPU has no group either
+    ids = (C.c_int * 2)(0, 0)
+    assert L.elm_ctx_create_multi(None, 2, C.byref(h)) == -1 and L.elm_ctx_create_multi(ids, 0, C.byref(h)) == -1
+    assert L.elm_ctx_create_multi(ids, 65, C.byref(h)) == -1 and L.elm_ctx_create_multi(ids, 2, None) == -1
+    assert L.elm_ctx_create_multi(ids, 2, C.byref(h)) != 0 and not h.value
+    with pytest.raises(ElmError):
+        Context.multi([0, 0])
 
 
 def test_missing_library_fails_loudly(monkeypatch):
