@@ -496,7 +496,7 @@ def _compact_leg(leg, brief=False):
 def driver_line(full):
     """The ONE stdout line: the contract's keys + numbers only.  Every prose string of the full record lives in
     DESIGN.md section 5; the full record goes to bench_full.json beside bench.py and to stderr."""
-    line = {k: _num(full.get(k)) for k in ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better",
+    line = {k: _num(full.get(k)) for k in ("metric", "value", "unit", "n_gpus", "rehearsal", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better",
                                            "scaling", "vs_baseline", "dtype", "data")}
     cfg = full.get("config", {})
     line["config"] = {"workload": str(cfg.get("workload", "")).split(" (BASELINE")[0][:120]}
@@ -578,7 +578,7 @@ def emit(full, path=None):
     return text
 
 
-def single_process_leg(args, n, out, timeout_s=300):
+def single_process_leg(args, n, out, timeout_s=300, devices=""):
     """The same N GPUs driven by ONE process (a device group, `bench.py --single-process`) -- the reference node's process model -- as a
     CHILD process of rank 0 after this job's own timed region, bounded by a timeout: a smaller batch at the same slots, its poses compared
     with this job's for the same registrations.  Any failure is reported in the record, never raised (the job's own line must not depend
@@ -590,7 +590,7 @@ def single_process_leg(args, n, out, timeout_s=300):
     per_gpu = min(512, args.batch)
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n), "--single-process", "--batch", str(per_gpu), "--steps", "5", "--warmup", "1",
            "--method", str(args.method), "--scan-points", str(args.scan_points), "--map-points", str(args.map_points), "--slots", str(args.slots),
-           "--guess", args.guess, "--world", args.world, "--dump-poses", poses]
+           "--guess", args.guess, "--world", args.world, "--dump-poses", poses] + (["--devices", devices] if devices else [])
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
                                                             "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "GROUP_WORLD_SIZE", "ROLE_NAME")}
     t0 = time.time()
@@ -803,12 +803,19 @@ def main():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback")
     if args.single_process and max(devices) >= torch.cuda.device_count():
         raise SystemExit(f"bench.py --single-process --devices {devices}: {torch.cuda.device_count()} GPU(s) visible")
-    if torch.cuda.device_count() < world_size or local_rank >= torch.cuda.device_count():
+    # ELM_BENCH_SHARED_GPU=1 (developer REHEARSAL of the N > 1 flow on a box with fewer GPUs than ranks: the ranks share devices and exchange
+    # their sums through torch.distributed / gloo on the host instead of RCCL, which refuses two ranks on one device).  It exercises the
+    # launcher, the sharded input path, the sharded registrations, the replica and single-process legs and the line at N -- it measures
+    # nothing: the line says so (`config.process_model`) and carries `rehearsal: true`.
+    shared_gpu = bool(os.environ.get("ELM_BENCH_SHARED_GPU")) and world_size > 1
+    if shared_gpu:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    elif torch.cuda.device_count() < world_size or local_rank >= torch.cuda.device_count():
         raise SystemExit(f"bench.py --gpus {args.gpus}: {torch.cuda.device_count()} GPU(s) visible to rank {rank} (local rank {local_rank}); one rank per GPU is the only mode")
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world_size)
+        dist.init_process_group(backend="gloo" if shared_gpu else "cpu:gloo,cuda:nccl", rank=rank, world_size=world_size)
 
     from concurrent.futures import ThreadPoolExecutor
     from elimaloc_amd import synth
@@ -825,7 +832,22 @@ def main():
             raise SystemExit(f"device group reports {g_ranks} ranks, expected {len(devices)}")
         group_exchange = {0: "none", 1: "rccl", 2: "host"}[g_ex]
         rccl_ranks = g_ranks if g_ex == 1 else None  # (elm_ctx_create_multi verified ncclCommCount / ncclCommUserRank of every rank's communicator)
-    if distributed:
+    if distributed and shared_gpu:
+        import ctypes as C_
+        hip_ = C_.CDLL("libamdhip64.so")
+        hip_.hipMemcpy.argtypes = [C_.c_void_p, C_.c_void_p, C_.c_size_t, C_.c_int]
+        hip_.hipStreamSynchronize.argtypes = [C_.c_void_p]
+
+        def gloo_exchange(ptr, n, hip_stream):
+            if hip_.hipStreamSynchronize(C_.c_void_p(hip_stream)) != 0:
+                return 1
+            buf = torch.empty(n, dtype=torch.float64)
+            if hip_.hipMemcpy(buf.data_ptr(), ptr, n * 8, 2) != 0:
+                return 1
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            return 0 if hip_.hipMemcpy(ptr, buf.data_ptr(), n * 8, 1) == 0 else 1
+        ctx.set_allreduce_hook(gloo_exchange)
+    elif distributed:
         ids = [Context.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         ctx.comm_init(rank, world_size, ids[0])
@@ -849,7 +871,7 @@ def main():
     def max_over_ranks(seconds):
         if not distributed:
             return seconds
-        t = torch.tensor([seconds], dtype=torch.float64, device="cuda")
+        t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if shared_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -1125,6 +1147,7 @@ def main():
         "value": value,
         "unit": "registrations/s",
         "n_gpus": ranks,
+        "rehearsal": bool(shared_gpu),
         "rccl_ranks": rccl_ranks,  # ncclCommCount of the communicator the timed region all-reduced over (null: one process, no communicator)
         "ranks": rank_table,
         "steps": args.steps,
@@ -1151,7 +1174,8 @@ def main():
             "parallelism": "1 GPU" if ranks == 1 else f"scan points sharded over {ranks} GPUs, map replicated, "
                            "one RCCL all-reduce (32 doubles/scan) per ICP iteration",
             "process_model": (f"one process, device group of {ranks} ({group_exchange} exchange), devices {devices}" if args.single_process else
-                              ("one process per GPU" if ranks > 1 else "one process, one GPU")),
+                              ("REHEARSAL: ranks share GPUs, sums exchanged over gloo on the host" if shared_gpu else
+                               ("one process per GPU" if ranks > 1 else "one process, one GPU"))),
             "iterations_mean": float(iters.mean()),
             "iterations_min": int(iters.min()),
             "iterations_max": int(iters.max()),
@@ -1527,7 +1551,7 @@ def main():
     if distributed and (world_size > 1 or os.environ.get("ELM_BENCH_FORCE_SINGLE_PROCESS")) and extras and not os.environ.get("ELM_BENCH_NO_SINGLE_PROCESS"):
         # both process models on the same GPUs in one driver run: the N ranks wait while rank 0's child drives all N devices by itself
         if rank == 0:
-            result["single_process"] = single_process_leg(args, world_size, out)
+            result["single_process"] = single_process_leg(args, world_size, out, devices=",".join(str(r % torch.cuda.device_count()) for r in range(world_size)) if shared_gpu else "")
         dist.barrier()
     result["process_wall_s"] = time.time() - t_process
 
