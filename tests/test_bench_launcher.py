@@ -103,3 +103,23 @@ def test_gpus_must_equal_world_size():
     p = run(["--gpus", "1", "--dry-launch", "--batch", "1", "--scan-points", "64", "--map-points", "30000"],
             env_extra={"WORLD_SIZE": "2"}, timeout=300)
     assert p.returncode != 0 and "!= WORLD_SIZE" in p.stderr
+
+
+@pytest.mark.gpu
+def test_n2_flow_rehearsed_on_one_gpu():
+    """The WHOLE `bench.py --gpus 2` flow on a one-GPU box (ELM_BENCH_SHARED_GPU: both ranks on device 0, sums exchanged over gloo instead
+    of RCCL, which refuses two ranks on one device): launcher, sharded input path (Hilbert-contiguous shards through the all-to-all),
+    sharded registrations with one exchange per iteration, hard-guess leg, replica leg, the single-process device-group child, the line.
+    It measures nothing (`rehearsal: true`); it shows that the pieces the driver's first multi-GPU run executes do execute, and that the
+    three process models agree on the poses."""
+    p = run(["--gpus", "2", "--batch", "24", "--slots", "8", "--steps", "1", "--warmup", "1", "--scan-points", "6001", "--map-points", "200000"],
+            env_extra={"ELM_BENCH_SHARED_GPU": "1"}, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rehearsal"] is True and line["value"] > 0 and line["config"]["registrations_per_step"] == 48
+    assert line["replica"]["max_abs_pose_diff_vs_sharded"] < 1e-9             # whole registrations per rank vs the sharded ones
+    sp = line["single_process"]
+    assert "error" not in sp and sp["devices"] == 2 and sp["iterations_match"] is True and sp["max_abs_pose_diff_vs_ranks"] < 1e-9
+    assert len(lines[0]) < 6000
