@@ -253,8 +253,8 @@ def dry_launch(args, rank, world_size, local_rank, dist):
 CLOCK_GHZ = 2.4  # MI355X_MICROARCH.md: max clock
 SIMD_GCYCLES = 1024 * CLOCK_GHZ  # G SIMD-cycles/s over the chip (256 CUs x 4 SIMDs)
 L1_HIT_LINES_PER_CYCLE, L1_MISS_LINES_PER_CYCLE = 1.6, 0.40  # distinct 128-byte lines a CU's vector-memory pipeline serves per cycle (tools/probes/l1_probe)
-ISSUE_CYCLES = {"k_accumulate_grid<P2P>": 3.78, "k_accumulate_grid<GICP>": 3.78, "k_accumulate_vnbr<VGICP>": 3.85,
-                "k_accumulate_vnbr<AVGICP>": 3.86}  # mean issue cost of the kernels' opcode mixes, profiles/r04_valu_mix.txt
+ISSUE_CYCLES = {"k_accumulate_grid<P2P>": 3.80, "k_accumulate_grid<GICP>": 3.81, "k_accumulate_vnbr<VGICP>": 3.88,
+                "k_accumulate_vnbr<AVGICP>": 3.91}  # mean issue cost of the kernels' opcode mixes (tools/valu_mix.py), profiles/r06_valu_mix.txt
 WORLD_PTS_PER_M2 = 27.5  # synth.make_world: ~25 ground points + the walls' share per square metre of map
 
 
@@ -377,7 +377,7 @@ def build_roofline(method, kernel_name, hbm, pm, units_per_launch, acc_ms_avg):
         if vb >= tb and vb > hbm["frac"]:
             roofline = {"bound": "valu_issue", "achieved": vb * SIMD_GCYCLES, "peak": SIMD_GCYCLES, "unit": "G SIMD-cycles/s (VALU issue)", "frac": vb,
                         "achieved_is": f"SQ_INSTS_VALU per SIMD-cycle ({extra.get('valu_insts_per_simd_cycle')}) x {ISSUE_CYCLES.get(kernel_name, 4.0)} cycles mean issue cost "
-                                       "of this kernel's opcode mix (profiles/r04_valu_mix.txt, per-class costs measured by tools/probes/valu_probe: "
+                                       "of this kernel's opcode mix (profiles/r06_valu_mix.txt, per-class costs measured by tools/probes/valu_probe: "
                                        "profiles/r04_valu_probe.txt); counters: committed rocprofv3 --pmc pass of this command at this batch / slots "
                                        "(profiles/); the launch time it belongs to is measured live below",
                         "frac_bounds": {"every_instruction_2.4_cycles": float(extra.get("valu_insts_per_simd_cycle", 0.0)) * 2.4,

@@ -8,9 +8,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pat = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else r"k_accumulate_gridILi0ELi0ELi0ELi0ELi0E"
 asm = sys.argv[sys.argv.index("--asm") + 1] if "--asm" in sys.argv else None
 if not asm:
-    asm = os.path.join(tempfile.gettempdir(), "elm_kernels_gfx950.s")
+    # the translation unit that holds the kernel (round 6: the library is seven of them)
+    unit = "elm_k_vnbr.hip" if "vnbr" in pat else "elm_k_cell.hip" if "cell" in pat else "elm_k_solve.hip" if "solve" in pat else "elm_k_grid.hip"
+    asm = os.path.join(tempfile.gettempdir(), unit.replace(".hip", "_gfx950.s"))
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only",
-                           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "elimaloc_amd", "csrc", "elm_kernels.hip"), "-o", asm],
+                           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "elimaloc_amd", "csrc", unit), "-o", asm],
                           stderr=subprocess.DEVNULL)
 txt = open(asm).read()
 m = re.search(r"^(_Z\w*" + pat + r"\w*):[^\n]*\n(.*?)^\.Lfunc_end", txt, re.S | re.M)
