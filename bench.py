@@ -255,6 +255,7 @@ SIMD_GCYCLES = 1024 * CLOCK_GHZ  # G SIMD-cycles/s over the chip (256 CUs x 4 SI
 L1_HIT_LINES_PER_CYCLE, L1_MISS_LINES_PER_CYCLE = 1.6, 0.40  # distinct 128-byte lines a CU's vector-memory pipeline serves per cycle (tools/probes/l1_probe)
 ISSUE_CYCLES = {"k_accumulate_grid<P2P>": 3.80, "k_accumulate_grid<GICP>": 3.81, "k_accumulate_vnbr<VGICP>": 3.88,
                 "k_accumulate_vnbr<AVGICP>": 3.91}  # mean issue cost of the kernels' opcode mixes (tools/valu_mix.py), profiles/r06_valu_mix.txt
+L2_TOTAL_BYTES = 8 * 4 * 1024 * 1024  # MI355X_MICROARCH.md: 4 MB of L2 per XCD
 WORLD_PTS_PER_M2 = 27.5  # synth.make_world: ~25 ground points + the walls' share per square metre of map
 
 
@@ -290,7 +291,10 @@ def index_touch_bound(index_bytes, units_per_launch, requested_index_bytes_per_u
     # k footprints of a fraction f of the map each, placed independently: they cover 1 - (1 - f)^k ~ 1 - exp(-k f) of it (NOT min(1, k f):
     # footprints overlap long before they tile the map)
     share = 1.0 - math.exp(-float(live_scans) * math.pi * (scan_range_m + search_m) ** 2 / max(1, int(shard_of)) / area)
-    return min(float(index_bytes), float(requested_index_bytes_per_unit) * float(units_per_launch), share * float(index_bytes))
+    once = min(float(index_bytes), float(requested_index_bytes_per_unit) * float(units_per_launch), share * float(index_bytes))
+    # consecutive launches iterate the SAME scans: what of their index footprint still sits in the 8 x 4 MB of L2 from the previous launch
+    # is not fetched again (FETCH_SIZE counts L2 misses) -- a lower bound must not charge it
+    return max(once - L2_TOTAL_BYTES, 0.0)
 
 
 def hbm_object(method, index_bytes, units_per_launch, sec, bytes_unit, bytes_ref, live_scans, map_points, traffic=None, traffic_src=None, shard_of=1):

@@ -25,7 +25,7 @@ def test_index_is_charged_at_most_its_touched_part():
     b = bench.index_touch_bound(idx, 32 * 262144, 250.0, 32, 50_000_000)
     assert b < 0.3 * idx
     # the headline: 256 scans cover the 10 M-point map several times over -> the whole index, once
-    assert 0.2499e9 < bench.index_touch_bound(0.25e9, 256 * 131072 * 0.9, 250.0, 230, 10_000_000) <= 0.25e9
+    assert 0.2499e9 - bench.L2_TOTAL_BYTES < bench.index_touch_bound(0.25e9, 256 * 131072 * 0.9, 250.0, 230, 10_000_000) <= 0.25e9 - bench.L2_TOTAL_BYTES
     # never more than the points request
     assert bench.index_touch_bound(1e9, 1000, 100.0, 1, 10_000_000) <= 1e5
 
@@ -177,9 +177,10 @@ def test_compulsory_is_a_lower_bound_or_the_line_is_refused():
 
 def test_a_shard_covers_its_share_of_the_footprint():
     """locality-aware shards: 256 shards of 1 / 8 of a scan's footprint lie over an eighth of the index a whole scan's footprint would"""
-    whole = bench.index_touch_bound(1.0e9, 7.8e6, 300.0, 32, 50_000_000)
-    shard = bench.index_touch_bound(1.0e9, 7.8e6, 300.0, 32, 50_000_000, shard_of=8)
-    assert 0.12 * whole < shard < 0.16 * whole  # ~1 / 8 of it (the overlap of 32 footprints is larger for the whole scans)
+    L2 = bench.L2_TOTAL_BYTES
+    whole = bench.index_touch_bound(1.0e9, 7.8e6, 300.0, 64, 50_000_000) + L2
+    shard = bench.index_touch_bound(1.0e9, 7.8e6, 300.0, 64, 50_000_000, shard_of=8) + L2
+    assert 0.12 * whole < shard < 0.16 * whole  # ~1 / 8 of it (the 64 whole footprints overlap a little more than the 64 shard footprints)
     h1 = bench.hbm_object(2, 5.2e8, 7.8e6, 0.15e-3, 273.0, 584.0, 238, 50_000_000, 60.0 * 7.8e6, "test", shard_of=8)
     assert h1["compulsory_bytes_per_unit"] < 60.0 and h1["achieved"] >= 0.95 * h1["compulsory_gbs"]
 
@@ -210,5 +211,5 @@ def test_a_model_error_never_costs_the_line():
 
 def test_footprints_overlap_before_they_tile_the_map():
     a = bench.index_touch_bound(1.0e9, 1e12, 1e6, 235, 50_000_000, shard_of=8)
-    assert 0.18e9 < a < 0.20e9  # 1 - exp(-0.214), not 0.214
-    assert bench.index_touch_bound(0.25e9, 1e12, 1e6, 235, 10_000_000) > 0.249e9
+    assert 0.18e9 < a + bench.L2_TOTAL_BYTES < 0.20e9  # 1 - exp(-0.214), not 0.214 (minus what the L2s keep between launches)
+    assert bench.index_touch_bound(0.25e9, 1e12, 1e6, 235, 10_000_000) > 0.249e9 - bench.L2_TOTAL_BYTES
