@@ -1845,18 +1845,19 @@ static int choose_path(elm_ctx* ctx, const elm_map* map, const elm_reg_config* c
         if ((rc = build_voxel_neighbourhoods(const_cast<elm_map*>(map), method == ELM_AVGICP)) != ELM_OK) return rc;
     const bool asym_map = mode < 0 && method != ELM_P2P && (method == ELM_GICP ? map->n_asym_pts != 0 : map->n_asym_vox != 0);
     if (asym_map) {
-        if (pc->use_grid || pc->use_vnbr) pc->asym = true;
+        if (pc->use_grid || pc->use_vnbr || pc->use_cells) pc->asym = true; // (use_cells: P2P / GICP on the neighbourhood lists -- GICP's kernel
+                                                                            // there writes the side records too)
         else {
-            // The one slow corner left: asymmetric covariances on a map whose search index is a fall-back form (neighbourhood lists / the
-            // plain walk: no cell grid could be built, or ELM_KERNEL forced one) -- those kernels carry no side records, so the covariance
-            // methods run the per-pair kernels (exact, 12-27 times slower).  Said ONCE per map, and visible in elm_reg_result.path.
+            // The one slow corner left: asymmetric covariances on a map whose search runs the PLAIN WALK (ELM_KERNEL=direct, or lists that
+            // could not be cell-sorted) -- that kernel carries no side records, so the covariance methods run the per-pair kernels (exact,
+            // 12-27 times slower).  Said ONCE per map, and visible in elm_reg_result.path.
             pc->radar = true; pc->use_grid = pc->use_cells = pc->use_vnbr = false;
             elm_map* mm = const_cast<elm_map*>(map);
             if (!mm->warned_slow_path) {
                 mm->warned_slow_path = true;
                 fprintf(stderr, "[elimaloc] map %p: %u point / %u voxel covariances are asymmetric (rank-deficient neighbourhoods) and its search index is a "
                                 "fall-back form (%s): method %d runs the per-pair kernels, 12-27 times slower than the grid kernels (elm_reg_result.path = %d)\n",
-                        (const void*)map, map->n_asym_pts, map->n_asym_vox, ctx->kernel_mode == 2 ? "ELM_KERNEL=direct" : "neighbourhood lists", method, ELM_PATH_PAIRS);
+                        (const void*)map, map->n_asym_pts, map->n_asym_vox, ctx->kernel_mode == 2 ? "ELM_KERNEL=direct" : "lists without cell order", method, ELM_PATH_PAIRS);
             }
         }
     }

@@ -31,6 +31,12 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? kCellWaves : kCellWave
     __shared__ int s_res[kBlock];               // stage 2 results: winning list index per queued point
     __shared__ int s_tst[kBlock];               //                  candidates walked for it
     __shared__ unsigned s_cnt[kBlock / 64];
+    // maps with an asymmetric stored inverse (GICP reads stored inverses here): the workgroup's antisymmetric side record (round 6: the
+    // fall-back index carries it like the grid kernel, so such a map no longer drops to the per-pair kernels)
+    __shared__ double s_asym[(METHOD == ELM_GICP) ? kAsymSums : 1];
+    __shared__ unsigned s_hitw[kBlock / 64];
+    PairSum PA; // this lane's pair once more in the factored form -- filled only on such maps (rp.asym, uniform): A = w C^-1 feeds the side sums
+    pair_sum_zero(PA);
     static_assert(sizeof(HardRec) * kBlock <= sizeof(double) * kRedPass * kBlock, "HardRec queue must fit the reduction buffer");
     const unsigned L = xcd_remap(blockIdx.x, total_blocks);
     const int s = find_scan(scans, batch, L, rp);
@@ -267,6 +273,14 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? kCellWaves : kCellWave
             if (bd2 < rp.th2) pair_p2p(v, S.Rinv, px, py, pz, ex, ey, ez, bd2, rp);
         } else {
             finish_point_pair<METHOD, true>(v, m, S, rp, px, py, pz, gx, gy, gz, bd2, bx, by, bz, bidx, m.pt_gicp);
+            if (METHOD == ELM_GICP && rp.asym && bidx >= 0 && bd2 < rp.th2) { // (no bucket at all: the identity covariance -- symmetric)
+                const double* __restrict__ rec = m.pt_gicp + (size_t)bidx * 16;
+                double Ci[9], nf[3];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) Ci[k] = rec[3 + k];
+                nf[0] = rec[12]; nf[1] = rec[13]; nf[2] = rec[14];
+                pair_sum_single<ELM_GICP>(PA, rec[0] - gx, rec[1] - gy, rec[2] - gz, Ci, nf, rp); // finish_point_pair's weight and target (reg.cpp:97)
+            }
         }
         if (rp.stats) { // (as in the grid / voxel-list kernels: 0 unless the work counters are switched on)
             v[NV - 3] = (double)qp.cnt;  // candidates of the reference's walk
@@ -274,7 +288,14 @@ __global__ __launch_bounds__(kBlock, (METHOD == ELM_P2P ? kCellWaves : kCellWave
             v[NV - 1] = (double)n_tested + (hard ? kFallbackUnit : 0.0); // high part: points served by stage 2
         }
     }
+    if (METHOD == ELM_GICP) asym_mark(PA.A, rp, s_hitw);
     block_reduce_to_lds<NV, kRedPass>(v, s_buf, s_red);
+    if (METHOD == ELM_GICP) {
+        const double red_keep = (threadIdx.x < kSums) ? s_red[threadIdx.x] : 0.0; // (the side record's reduction reuses the buffers)
+        asym_side_store(PA.A, gx - S.T[12], gy - S.T[13], gz - S.T[14], L, rp, s_buf, s_asym, s_hitw);
+        publish_and_reduce(red_keep, L, s, sd.blk_begin, sd.blk_end, partials, rp, s_buf);
+        return;
+    }
     publish_and_reduce((threadIdx.x < kSums) ? ((METHOD == ELM_P2P) ? p2p_expand(s_red, (int)threadIdx.x) : s_red[threadIdx.x]) : 0.0, L, s, sd.blk_begin,
                        sd.blk_end, partials, rp, s_buf);
 }

@@ -82,8 +82,8 @@ typedef struct elm_iter_trace {
 
 /* elm_reg_result.path: the accumulate kernels of the call.  GRID (dense / two-level cell grid: P2P, GICP) and VOXEL_LISTS (VGICP, AVGICP)
  * are the fast kernels; LISTS / WALK are the fall-back index forms of maps no grid can hold (or ELM_KERNEL); PAIRS = the per-pair kernels
- * (use_radar_cov, ELM_CHECK=strict_pairs, or -- with one warning per map on stderr -- asymmetric covariances on a fall-back index:
- * 12-27 times slower); | SIDE_RECORDS: the map holds asymmetric covariances and the fast kernels carried their antisymmetric sums. */
+ * (use_radar_cov, ELM_CHECK=strict_pairs, or -- with one warning per map on stderr -- asymmetric covariances where the search is the plain
+ * walk: 12-27 times slower); | SIDE_RECORDS: the map holds asymmetric covariances and the fast kernels carried their antisymmetric sums. */
 #define ELM_PATH_GRID 1
 #define ELM_PATH_LISTS 2
 #define ELM_PATH_VOXEL_LISTS 3

@@ -1537,14 +1537,33 @@ def test_radar_covariance_entry_points(ctx, oracle, world100k):
 
 
 def test_the_slow_corner_is_announced_and_visible(oracle, monkeypatch, capfd):
-    """The one combination that still leaves the fast kernels: asymmetric covariances on a map whose search index is a
-    fall-back form (here ELM_KERNEL=lists).  GICP then runs the per-pair kernels -- exact, 12-27 times slower.  It says so ONCE per map on
-    stderr and every result carries path = ELM_PATH_PAIRS; the same map on the default index reports the grid kernels with side records,
-    an ordinary map the plain grid kernels, P2P on any map never leaves them."""
+    """Asymmetric covariances off the default index.  On the neighbourhood LISTS (the fall-back index of maps no cell
+    grid can hold; here ELM_KERNEL=lists) GICP's kernel writes the antisymmetric side records like the grid kernel since round 6: fast
+    kernels, the oracle's sums.  What is left is the plain walk (ELM_KERNEL=direct): the per-pair kernels -- exact, 12-27 times slower --
+    announced ONCE per map on stderr, every result carrying path = ELM_PATH_PAIRS.  The same map on the default index reports the grid
+    kernels with side records, an ordinary map the plain voxel-list kernels, P2P never leaves its search kernel."""
     from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod
-    PATH_GRID, PATH_LISTS, PATH_VOXEL_LISTS, PATH_PAIRS, SIDE = 1, 2, 3, 5, 16
+    PATH_GRID, PATH_LISTS, PATH_VOXEL_LISTS, PATH_WALK, PATH_PAIRS, SIDE = 1, 2, 3, 4, 5, 16
     world, scans, T0s = _asym_case()
     monkeypatch.setenv("ELM_KERNEL", "lists")
+    c = Context(0)
+    try:
+        vm, om = _maps(c, oracle, world, IcpMethod.GICP)
+        assert int(vm.info().layout_flags) & 128
+        reg = Registration(RegistrationConfig(icp_method=IcpMethod.GICP), c)
+        capfd.readouterr()
+        for sc, T0 in zip(scans, T0s):
+            pose, ok, fit, cov, det = reg.RunRegister(sc, vm, T0, trace=True)
+            ref = oracle.register(om, sc, T0, oracle.default_config(1))
+            assert det["path"] == PATH_LISTS | SIDE
+            _compare_run(det, ref)
+            np.testing.assert_allclose(cov, ref["local_cov"], rtol=1e-6, atol=1e-9 * np.abs(ref["local_cov"]).max())
+        assert not capfd.readouterr().err
+        p2p = Registration(RegistrationConfig(icp_method=IcpMethod.P2P), c).RunRegister(scans[0], vm, T0s[0], trace=True)[-1]
+        assert p2p["path"] & 15 == PATH_LISTS
+    finally:
+        c.close()
+    monkeypatch.setenv("ELM_KERNEL", "direct")
     c = Context(0)
     try:
         vm, om = _maps(c, oracle, world, IcpMethod.GICP)
@@ -1552,11 +1571,11 @@ def test_the_slow_corner_is_announced_and_visible(oracle, monkeypatch, capfd):
         capfd.readouterr()
         dets = [reg.RunRegister(sc, vm, T0, trace=True)[-1] for sc, T0 in zip(scans, T0s)]
         err = capfd.readouterr().err
-        assert err.count("[elimaloc] map") == 1 and "per-pair kernels" in err and "neighbourhood lists" in err, err  # once per map
+        assert err.count("[elimaloc] map") == 1 and "per-pair kernels" in err and "ELM_KERNEL=direct" in err, err  # once per map
         assert all(d["path"] == PATH_PAIRS for d in dets)
         _compare_run(dets[0], oracle.register(om, scans[0], T0s[0], oracle.default_config(1)))  # slow, not wrong
         p2p = Registration(RegistrationConfig(icp_method=IcpMethod.P2P), c).RunRegister(scans[0], vm, T0s[0], trace=True)[-1]
-        assert p2p["path"] == PATH_LISTS and not capfd.readouterr().err
+        assert p2p["path"] == PATH_WALK and not capfd.readouterr().err
     finally:
         c.close()
     monkeypatch.delenv("ELM_KERNEL")
