@@ -1,10 +1,12 @@
 """Developer soak (GPU): every method, 25 continuous-batching runs with four slot counts + one lockstep batch over the same 48
-registrations (large initial errors, so many points take the wave-cooperative stage) must be bit-identical."""
+registrations (large initial errors, so many points take the wave-cooperative stage) must be bit-identical.
+    python tools/soak_determinism.py [--group 0,0,0]     --group: the same through a device group (elm_ctx_create_multi) over those devices"""
 import sys, numpy as np
 sys.path.insert(0, '.')
 from elimaloc_amd import synth
 from elimaloc_amd.registration import Context, VoxelHashMap, Registration, RegistrationConfig, IcpMethod, Scan
-ctx = Context(0)
+ctx = Context.multi([int(x) for x in sys.argv[sys.argv.index("--group") + 1].split(",")]) if "--group" in sys.argv else Context(0)
+print("context:", ctx.group_info())
 world = synth.make_world(2_000_000, seed=1001)
 for method in (0, 1, 2, 3):
     m = IcpMethod(method)
