@@ -392,13 +392,13 @@ extern "C" int elm_ctx_create_multi(const int* device_ids, int n, elm_ctx** out)
         g->ctx.push_back(c);
     }
     elm_ctx* lead = g->ctx[0];
-    if (n == 1) { // a group of one is a plain context
-        delete g;
-        *out = lead;
+    const char* force = getenv("ELM_GROUP_EXCHANGE"); // rccl | host (default: RCCL when every rank has a device of its own)
+    if (n == 1 && !(force && strcmp(force, "rccl") == 0)) { // a group of one is a plain context
+        delete g;                                           // (forced RCCL: a one-rank GROUP -- worker thread, communicator and all-reduce of the
+        *out = lead;                                        //  in-process path on a single GPU: what a one-GPU box can run of it)
         return ELM_OK;
     }
     const bool distinct = std::set<int>(g->devices.begin(), g->devices.end()).size() == (size_t)n;
-    const char* force = getenv("ELM_GROUP_EXCHANGE"); // rccl | host (default: RCCL when every rank has a device of its own)
     g->exchange = (force && strcmp(force, "host") == 0) ? 2 : (force && strcmp(force, "rccl") == 0) ? 1 : (distinct ? 1 : 2);
     g->hx.out.assign((size_t)n, nullptr);
     g->hx.sum.assign((size_t)n, nullptr);

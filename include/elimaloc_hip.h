@@ -520,7 +520,8 @@ int elm_pcm_callback_point_cloud(elm_ctx* ctx, const elm_map* map, const elm_pcm
  * sharded): same results; the fused one-pass form is a plain context's (the callback registers ~10 k downsampled points).
  * A device id may repeat ({0, 0}: two ranks on one GPU).  RCCL refuses two ranks on one device; such a group exchanges through
  * page-locked host memory (sum in rank order) -- the form a one-GPU box can test.  ELM_GROUP_EXCHANGE=host | rccl forces either.
- * n = 1 returns a plain context. */
+ * n = 1 returns a plain context (with ELM_GROUP_EXCHANGE=rccl: a group of ONE rank -- worker thread, one-rank communicator, one
+ * ncclAllReduce per iteration: what a one-GPU box can run of the group's RCCL path). */
 int elm_ctx_create_multi(const int* device_ids, int n, elm_ctx** out);
 /* ranks of the group a context leads (1: a plain context), its exchange (0 none, 1 RCCL, 2 host memory), its devices */
 int elm_ctx_group_info(elm_ctx* ctx, int* n_ranks, int* exchange, int* device_ids, int cap);

@@ -248,3 +248,33 @@ def test_group_covariance_methods_ragged_stream(oracle, world100k, method):
             if len(scans[k]) >= 64:
                 np.testing.assert_allclose(a["T"], b["T"], rtol=0, atol=1e-8 if radar else 1e-9)
     assert runs["plain"][0][3]["gate"] == 2
+
+
+def test_one_rank_group_over_rccl(oracle, world100k, monkeypatch):
+    """What a one-GPU box can run of the group's RCCL path: ELM_GROUP_EXCHANGE=rccl makes elm_ctx_create_multi({0}, 1) a real group of ONE
+    rank -- its worker thread loads RCCL, forms a one-rank communicator (ncclCommInitRank from that thread), enqueues one ncclAllReduce per
+    iteration from that thread and destroys the communicator there.  Bit-identical to the plain context (a sum over one rank)."""
+    from elimaloc_amd.registration import Context, Registration, RegistrationConfig, IcpMethod, Scan, VoxelHashMap
+    full, T0s = _inputs(world100k, 5)
+    c = Context(0)
+    vm = VoxelHashMap(1.0, 30, c)
+    vm.AddPoints(world100k)
+    vm.CalVoxelCovAll()
+    plain = {m: Registration(RegistrationConfig(icp_method=IcpMethod(m)), c).RunRegisterStream([Scan(c, s) for s in full], vm, T0s, slots=3) for m in (0, 2)}
+    plain_one = Registration(RegistrationConfig(icp_method=IcpMethod.P2P), c).RunRegister(full[0], vm, T0s[0])
+    del vm
+    c.close()
+    monkeypatch.setenv("ELM_GROUP_EXCHANGE", "rccl")
+    g = Context.multi([0])
+    assert g.group_info() == (1, 1, [0])  # one rank, RCCL exchange
+    gvm = VoxelHashMap(1.0, 30, g)
+    gvm.AddPoints(world100k)
+    gvm.CalVoxelCovAll()
+    for m in (0, 2):
+        out = Registration(RegistrationConfig(icp_method=IcpMethod(m)), g).RunRegisterStream([Scan(g, s) for s in full], gvm, T0s, slots=3)
+        for a, b in zip(out, plain[m]):
+            assert np.array_equal(a["T"], b["T"]) and a["iterations"] == b["iterations"] and a["is_success"] == b["is_success"]
+    pose, ok, fit, cov = Registration(RegistrationConfig(icp_method=IcpMethod.P2P), g).RunRegister(full[0], gvm, T0s[0])
+    assert ok == plain_one[1] and np.array_equal(pose, plain_one[0])
+    del gvm
+    g.close()
