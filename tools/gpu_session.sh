@@ -9,7 +9,7 @@
 #   ab:<name>:<tags>[:args]    A/B of prebuilt library variants build_ab/lib_<tag>.so (comma list, each run twice, interleaved) on
 #                              `bench.py --no-cpu --no-extras <args, _ for spaces> $AB_ARGS`
 #   fuzz:<cases>:<seed0>[:ENV=1,ENV2=x;--extra_args]   tools/fuzz_parity.py (environment assignments, then extra arguments with _ for spaces)
-#   profiles[:legs]            tools/r5_profiles.sh (legs comma list: p2p,gicp,vgicp,avgicp,hard,c4)
+#   profiles[:legs]            tools/r6_profiles.sh (legs comma list: p2p,gicp,vgicp,avgicp,hard,c4)
 #   timeline                   kernel timeline of one ICP iteration on the one-rank RCCL path (tools/trace_gaps_dist1.sh)
 #   probes                     tools/probes/run_valu_probe.sh + run_gather_probe.sh
 set -u
@@ -18,20 +18,17 @@ cd $R
 TAG=${1:?tag}; shift
 O=gpurun_out/$TAG
 mkdir -p $O
-summ() { # bench json -> one line
+summ() { # bench line (the compact driver line of round 6) -> a few lines
   python - "$1" "$2" <<'PY'
 import json, sys
 try:
     r = json.load(open(sys.argv[2])); f = r["roofline"]
-    line = "%-14s %9.0f reg/s  launch %.4f ms  acc/step %.2f  solve/step %.2f  iters %.3f  %s %.3f" % (sys.argv[1], r["value"], f["avg_launch_ms"], f["accumulate_ms_per_step"], f["solve_ms_per_step"], r["config"]["iterations_mean"], f["bound"], f["frac"])
+    line = "%-14s %9.0f reg/s  launch %.4f ms  acc/step %.2f  solve/step %.2f  iters %.3f  hbm %.3f  %s %.3f" % (sys.argv[1], r["value"], f["avg_launch_ms"], f["accumulate_ms_per_step"], f["solve_ms_per_step"], r["config"]["iterations_mean"], f.get("hbm_frac") or 0.0, f.get("limiter"), f.get("limiter_frac") or 0.0)
     if "hard_guess" in r: line += "  hard %.0f" % r["hard_guess"]["value"]
     if "process_wall_s" in r: line += "  wall %.0f s" % r["process_wall_s"]
     print(line, flush=True)
-    for k, v in r.get("configs", {}).items():
-        if "value" in v: print("    %-14s %10.4g %s  %s %s" % (k, v["value"], v["unit"], v["roofline"].get("bound"), v["roofline"].get("frac")), v.get("pose_err_vs_cpu", {}).get("max_trans_m"), flush=True)
-        else:
-            for m in ("P2P", "GICP", "VGICP", "AVGICP"):
-                if m in v: print("    %-14s %-6s %9.0f (%.2f of the lattice world; per iteration %.2f) iters %.2f undecided %.3f flags %d %s %.3f" % (k, m, v[m]["value"], v[m]["vs_lattice_world"], v[m].get("iteration_rate_vs_lattice_world", 0.0), v[m]["iterations_mean"], v[m]["roofline"]["undecided_share_after_stage1"], v[m]["map_layout_flags"], v[m]["roofline"].get("bound"), v[m]["roofline"].get("frac", 0.0)), flush=True)
+    for k, v in (r.get("configs") or {}).items():
+        print("    %-14s %s" % (k, json.dumps(v)[:220]), flush=True)
 except Exception as e:  # noqa: BLE001
     print(sys.argv[1], "FAILED", repr(e), flush=True)
 PY
@@ -88,7 +85,7 @@ PY
       env ${FUZZ_ENV:-} ${fe//,/ } timeout 3000 python tools/fuzz_parity.py --cases $a --seed0 $b ${fa//_/ } > $O/fuzz_$b.txt 2>&1
       echo "fuzz $a cases from seed $b [${fe}] [${fa//_/ }]: $(tail -1 $O/fuzz_$b.txt)"; grep -E "^MISMATCH|^PAIR MISMATCH|^pairs:|singular|raised" $O/fuzz_$b.txt | head -8 ;;
     profiles)
-      tools/r5_profiles.sh ${a//,/ } ;;
+      tools/r6_profiles.sh ${a//,/ } ;;
     timeline)
       tools/trace_gaps_dist1.sh $TAG > $O/timeline.txt 2>&1; tail -25 $O/timeline.txt ;;
     probes)

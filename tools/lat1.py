@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Resident single-registration latency (131 072-point scan vs the 10 M-point map): median / p10 / p90 wall time of RunRegisterBatch([scan])
-over `--calls` calls cycling through eight scans, per method.  Environment switches (ELM_FUSED_REDUCE, ELM_GRAPH ...) are read by the library
+over `--calls` calls cycling through eight scans, per method.  Environment switches (ELM_KERNEL, ELM_GRID, ELM_CHECK ...) are read by the library
 at context creation: run once per setting.      python tools/lat1.py [--method 0] [--calls 80]"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

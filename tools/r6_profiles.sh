@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 6: rocprofv3 kernel-trace + counter passes AT THE OPERATING POINT of every timed leg of the default bench line
-#   tools/r5_profiles.sh [legs...]     legs: p2p gicp vgicp avgicp hard c4 field0 field1 field2 field3   (default: all)
+#   tools/r6_profiles.sh [legs...]     legs: p2p gicp vgicp avgicp hard c4 field0 field1 field2 field3   (default: all)
 # -> gpurun_out/prof_r06_<leg>/{kernel_stats.csv,pmc.json,bench_trace.json}; copy with tools/merge_pmc.py afterwards
 set -u
 LEGS=${@:-p2p gicp vgicp avgicp hard c4 field0 field1 field2 field3}

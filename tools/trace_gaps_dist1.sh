@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON THE MI355X BOX: kernel timeline of the one-rank COLLECTIVE path (RCCL communicator formed, bench.py as torch.distributed.run
-# would start it) -> the launch sequence of an ICP iteration and the gaps between launches.  ELM_FUSED_REDUCE=1 shows the 2 + 1 form.
+# would start it) -> the launch sequence of an ICP iteration and the gaps between launches.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/gaps_dist1
 rm -rf $OUT; mkdir -p $OUT
